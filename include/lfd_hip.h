@@ -1,0 +1,157 @@
+/*
+ * include/lfd_hip.h -- C ABI of liblfd_hip.so: the MI355X (gfx950) implementation of the
+ * LFD dense-prediction hot path (post-processing, losses, conv stack).
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it, no hidden sync, no
+ *     allocation: outputs and workspace are caller-owned (`*_workspace_bytes()` query);
+ *   - return value: 0 (LFD_OK) or a negative lfd_status code; no C++ exception crosses the ABI;
+ *   - thread-safe and re-entrant per stream.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef LFD_HIP_H_
+#define LFD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFD_HIP_ABI_VERSION 1
+#define LFD_MAX_LEVELS 8
+
+typedef void* lfd_stream_t; /* hipStream_t */
+
+#if defined(LFD_BUILDING)
+#define LFD_API __attribute__((visibility("default")))
+#else
+#define LFD_API
+#endif
+
+enum lfd_status {
+  LFD_OK = 0,
+  LFD_ERR_INVALID_ARGUMENT = -1,
+  LFD_ERR_WORKSPACE_TOO_SMALL = -2,
+  LFD_ERR_LAUNCH_FAILED = -3,
+  LFD_ERR_UNSUPPORTED = -4,
+  LFD_ERR_NO_DEVICE = -5
+};
+
+enum lfd_dtype { LFD_F32 = 0, LFD_F16 = 1 };
+
+LFD_API int lfd_hip_abi_version(void);
+LFD_API const char* lfd_hip_status_string(int status);
+/* "gfx950;<compiler>;<build date>" */
+LFD_API const char* lfd_hip_build_info(void);
+
+/* ------------------------------------------------------------------------------------------
+ * NMS.  Replaces nms_ext.nms(dets[n,5] f32, thr) -> LongTensor[k]
+ *   (lfd/model/utils/build/nms/src/nms_ext.cpp:18-27,45-49; CUDA path
+ *    src/cuda/nms_kernel.cu:24-68 kernel + :71-138 host sort / D2H mask / serial scan;
+ *    CPU path src/cpu/nms_cpu.cpp:7-66).
+ * dets = {x1,y1,x2,y2,score}; IoU = inter/(Sa+Sb-inter) in fp32, no +1, strict `>`;
+ * keep[0..*num_keep) = ORIGINAL row indices of the kept boxes in score-descending order
+ * (ties: lower original index first -- the reference leaves tie order unspecified).
+ * Sort, 64x64-tile bitmask and the greedy scan all run on the device (no D2H of the mask).
+ */
+LFD_API size_t lfd_nms_workspace_bytes(int64_t n);
+LFD_API int lfd_nms_f32(const float* dets, int64_t n, float iou_thr, int64_t* keep /*[n]*/,
+                int32_t* num_keep /*[1]*/, void* workspace, size_t workspace_bytes,
+                lfd_stream_t stream);
+
+/* batched_nms(bboxes[k,4], scores[k], inds[k], nms_cfg, class_agnostic)
+ *   (lfd/model/utils/nms.py:119-158): per-class NMS through the coordinate-offset trick
+ *   off = label * (max(bboxes)+1) evaluated in fp32 exactly as the reference does (:148-150),
+ *   IoU decided on the shifted boxes, offset subtracted from the kept rows (:156).
+ * out_dets[r] = {x1,y1,x2,y2,score} of kept row r, keep[r] = its index into the inputs. */
+LFD_API size_t lfd_batched_nms_workspace_bytes(int64_t k);
+LFD_API int lfd_batched_nms_f32(const float* boxes /*[k,4]*/, const float* scores /*[k]*/,
+                        const int64_t* labels /*[k]*/, int64_t k, float iou_thr,
+                        int32_t class_agnostic, float* out_dets /*[k,5]*/,
+                        int64_t* keep /*[k]*/, int32_t* num_keep /*[1]*/, void* workspace,
+                        size_t workspace_bytes, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused per-location decode + score threshold + multi-class NMS for a whole batch.
+ * Replaces LFD.get_results / _get_results_for_single_image / predict_for_single_image's
+ * post-processing (lfd/model/lfd.py:397-509, :577-655), distance2bbox (:261-282) and
+ * multiclass_nms (lfd/model/utils/nms.py:161-220), for every image of the batch in one call.
+ */
+typedef struct lfd_detect_desc {
+  int32_t num_levels;
+  int32_t level_h[LFD_MAX_LEVELS];       /* head_indexes_to_feature_map_sizes (lfd.py:532) */
+  int32_t level_w[LFD_MAX_LEVELS];
+  int32_t level_stride[LFD_MAX_LEVELS];  /* point_strides: x=j*stride, y=i*stride (lfd.py:93-98) */
+  float level_range_lo[LFD_MAX_LEVELS];  /* regression_ranges[i] */
+  float level_range_hi[LFD_MAX_LEVELS];
+  int32_t num_classes;                   /* C (foreground classes) */
+  int32_t num_cls_channels;              /* C for sigmoid scores, C+1 for softmax (CE loss) */
+  int32_t score_mode;                    /* 0: sigmoid (lfd.py:454); 1: softmax, drop last (:450-452) */
+  int32_t decode_mode;                   /* 0: sigmoid(reg)*max(range) (:483-486); 1: exp(reg) (:480-482);
+                                            2: reg*range_hi ('independent', :468-478) */
+  int32_t class_agnostic;                /* nms_cfg['class_agnostic'] (nms.py:143) */
+  int32_t max_candidates;                /* capacity K_cap per image of candidate / output rows */
+  float score_thr;                       /* strict `>` (nms.py:204) */
+  float iou_thr;                         /* strict `>` (nms_cpu.cpp:62) */
+} lfd_detect_desc_t;
+
+LFD_API size_t lfd_detect_workspace_bytes(const lfd_detect_desc_t* desc, int32_t batch);
+/* cls [N,P,C'] and reg [N,P,4] in `in_dtype` (level-concatenated, row-major as LFD.forward
+ * returns them, lfd.py:526-542).  img_meta [N,3] f32 = {clamp_width, clamp_height,
+ * resize_scale} (meta['resized_width'|'resized_height'|'resize_scale'], lfd.py:443-444,499).
+ * Outputs (rows beyond the count are untouched):
+ *   out_dets   [N,K_cap,5] f32  x1,y1,x2,y2,score of kept boxes, score-descending
+ *   out_labels [N,K_cap]   i32  0-based class
+ *   out_cand   [N,K_cap]   i32  candidate ordinal (position in the reference's nonzero() order)
+ *   out_point  [N,K_cap]   i32  flat point index p of the kept box
+ *   out_counts [N,4]       i32  {num_candidates (clamped), num_kept, overflow_flag, true_candidates}
+ */
+LFD_API int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void* cls,
+                       const void* reg, int32_t in_dtype, const float* img_meta,
+                       float* out_dets, int32_t* out_labels, int32_t* out_cand,
+                       int32_t* out_point, int32_t* out_counts, void* workspace,
+                       size_t workspace_bytes, lfd_stream_t stream);
+
+/* Decode only (no threshold/NMS): boxes [N,P,4] f32 and scores [N,P,C] f32 for parity tests
+ * and for callers that want the reference's intermediate tensors (lfd.py:449-499). */
+LFD_API int lfd_decode_all(const lfd_detect_desc_t* desc, int32_t batch, const void* cls, const void* reg,
+                   int32_t in_dtype, const float* img_meta, float* out_boxes, float* out_scores,
+                   lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sigmoid focal loss.  Replaces sigmoid_focal_loss_ext.forward / .backward
+ *   (lfd/model/losses/build/sigmoid_focal_loss/src/sigmoid_focal_loss_ext.cpp:19-57,
+ *    src/cuda/sigmoid_focal_loss_cuda.cu:24-59 fwd, :62-97 bwd).
+ * logits [n,c], targets [n] int64 (c == background, <0 == ignore), losses / d_logits [n,c]. */
+LFD_API int lfd_sigmoid_focal_loss_fwd(const void* logits, const int64_t* targets, int64_t n, int32_t c,
+                               float gamma, float alpha, void* losses, int32_t dtype,
+                               lfd_stream_t stream);
+LFD_API int lfd_sigmoid_focal_loss_bwd(const void* logits, const int64_t* targets, const void* d_losses,
+                               int64_t n, int32_t c, float gamma, float alpha, void* d_logits,
+                               int32_t dtype, lfd_stream_t stream);
+/* Fused forward + sum reduction (weight_reduce_loss 'sum/avg_factor',
+ * lfd/model/losses/utils.py:28-54): *loss_sum += sum(losses) accumulated in fp64 partials,
+ * deterministic (fixed-order two-stage reduction).  workspace: lfd_reduce_workspace_bytes(). */
+LFD_API size_t lfd_reduce_workspace_bytes(void);
+LFD_API int lfd_sigmoid_focal_loss_sum_f32(const float* logits, const int64_t* targets, int64_t n, int32_t c,
+                                   float gamma, float alpha, float* loss_sum /*[1]*/, void* workspace,
+                                   size_t workspace_bytes, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * IoU loss on aligned xyxy boxes.  Replaces bbox_overlaps(is_aligned=True) + iou_loss
+ *   (lfd/model/losses/iou_loss.py:67-79,98-102,105-123): loss = -log(max(ov/max(a1+a2-ov,1e-6), eps)).
+ * bwd: d_pred[n,4] = d_loss[n] * dloss/dpred (autograd of the reference expression). */
+LFD_API int lfd_iou_loss_fwd_f32(const float* pred, const float* target, int64_t n, float eps, float* loss,
+                         lfd_stream_t stream);
+LFD_API int lfd_iou_loss_bwd_f32(const float* pred, const float* target, const float* d_loss, int64_t n,
+                         float eps, float* d_pred, lfd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFD_HIP_H_ */

@@ -1,0 +1,682 @@
+// csrc/postproc.hip -- per-location decode + score threshold + NMS on gfx950 (wave64).
+//
+// Replaces, behind include/lfd_hip.h:
+//   * nms_ext.nms                 (reference nms_ext.cpp:18-27, nms_kernel.cu:24-138, nms_cpu.cpp:7-66)
+//   * batched_nms/multiclass_nms  (reference lfd/model/utils/nms.py:119-220)
+//   * LFD._get_results_for_single_image decode (reference lfd/model/lfd.py:434-509, 261-282)
+//
+// Pipeline, all on the device, per image ("segment"), no host round trip:
+//   count  : per 256-point block, number of (point,class) pairs with score > thr
+//   scatter: ordered compaction (point-major, class-minor == torch.nonzero order) of the
+//            candidates {decoded box, score, label, point}, + max coordinate (for the
+//            reference's class-offset trick)
+//   sort   : rank sort on the unique 64-bit key (~ord(score), index) -> stable,
+//            score-descending order; writes the offset-shifted boxes in sorted order
+//   mask   : 64x64-tile suppression bitmask, one wave64 per tile, lane = row box,
+//            64-bit row masks built by one lane each (wave == the reference's 64-thread block)
+//   scan   : greedy scan on the device: one workgroup per image; wave 0 resolves each
+//            64-box diagonal block with ballot/readlane on SALU, all waves OR the kept
+//            rows' masks into the LDS-resident `remv` words
+//
+// This TU is compiled with -ffp-contract=off: IoU and the class-offset arithmetic must be
+// evaluated exactly as written (separate fp32 mul/add/sub, IEEE divide) to be bit-identical
+// with the reference.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct SegBuffers {
+  int cap;            // candidate capacity per segment
+  int words;          // ceil(cap/64): mask row stride in 64-bit words
+  const int* counts;  // [nseg,4] device counts (slot 0 = K) or nullptr
+  int k_host;         // used when counts == nullptr
+  int class_agnostic; // nms_cfg['class_agnostic']: no coordinate offsets (nms.py:145-146)
+  float iou_thr;
+  float4* cand_box;   // [nseg,cap]
+  float* cand_score;  // [nseg,cap]
+  int* cand_label;    // [nseg,cap]
+  int* cand_point;    // [nseg,cap] (may be nullptr)
+  uint32_t* maxord;   // [nseg] ordered-uint max coordinate of the candidates
+  float4* s_box;      // [nseg,cap] sorted, offset-shifted boxes
+  float* s_area;      // [nseg,cap]
+  float* s_score;     // [nseg,cap]
+  int* s_label;       // [nseg,cap]
+  int* s_idx;         // [nseg,cap] candidate ordinal of sorted position
+  unsigned long long* mask;  // [nseg,cap,words]
+};
+
+__device__ __forceinline__ int seg_k(const SegBuffers& b, int seg) {
+  int k = b.counts ? b.counts[seg * 4] : b.k_host;
+  return k < b.cap ? k : b.cap;
+}
+
+// ------------------------------------------------------------------ block scan helpers
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = lfd_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over a 256-thread block; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* smem /*>=5 ints*/) {
+  const int lane = lfd_lane(), w = threadIdx.x >> 6;
+  int inc = wave_incl_scan(v);
+  if (lane == 63) smem[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / 64; ++i) {
+    int s = smem[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ------------------------------------------------------------------ decode helpers
+struct LevelTable {
+  int n;
+  int start[LFD_MAX_LEVELS + 1];
+  int w[LFD_MAX_LEVELS];
+  int stride[LFD_MAX_LEVELS];
+  float rmax[LFD_MAX_LEVELS];  // max(range) -- 'sigmoid' mode (lfd.py:484)
+  float rhi[LFD_MAX_LEVELS];   // range[1]   -- 'independent' mode (lfd.py:469)
+};
+
+struct DecodeParams {
+  LevelTable lv;
+  int P, C, Cc;  // points, foreground classes, classification channels
+  int score_mode, decode_mode, in_dtype;
+  float score_thr;
+  const void* cls;
+  const void* reg;
+  const float* meta;  // [N,3] = clampW, clampH, resize_scale
+};
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
+
+// score of (point p, class c); for softmax mode `mx`/`inv` come from softmax_stats().
+__device__ __forceinline__ void softmax_stats(const DecodeParams& d, int64_t row, float* mx, float* sum) {
+  float m = -INFINITY;
+  for (int c = 0; c < d.Cc; ++c) m = fmaxf(m, lfd_load_f(d.cls, row * d.Cc + c, d.in_dtype));
+  float s = 0.f;
+  for (int c = 0; c < d.Cc; ++c) s += expf(lfd_load_f(d.cls, row * d.Cc + c, d.in_dtype) - m);
+  *mx = m;
+  *sum = s;
+}
+
+__device__ __forceinline__ float score_of(const DecodeParams& d, int64_t row, int c, float mx, float sum) {
+  float x = lfd_load_f(d.cls, row * d.Cc + c, d.in_dtype);
+  if (d.score_mode == 1) return expf(x - mx) / sum;
+  return sigmoidf_ref(x);
+}
+
+// decoded, clamped, rescaled box of point p of image n (lfd.py:468-499, 261-282)
+__device__ __forceinline__ float4 decode_box(const DecodeParams& d, int n, int p) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LFD_MAX_LEVELS; ++i)
+    if (i < d.lv.n && p >= d.lv.start[i]) l = i;
+  const int q = p - d.lv.start[l];
+  const int iy = q / d.lv.w[l], ix = q - iy * d.lv.w[l];
+  const float px = (float)(ix * d.lv.stride[l]);
+  const float py = (float)(iy * d.lv.stride[l]);
+  const int64_t row = (int64_t)n * d.P + p;
+  float r0 = lfd_load_f(d.reg, row * 4 + 0, d.in_dtype);
+  float r1 = lfd_load_f(d.reg, row * 4 + 1, d.in_dtype);
+  float r2 = lfd_load_f(d.reg, row * 4 + 2, d.in_dtype);
+  float r3 = lfd_load_f(d.reg, row * 4 + 3, d.in_dtype);
+  float d0, d1, d2, d3;
+  if (d.decode_mode == 0) {
+    const float m = d.lv.rmax[l];
+    d0 = sigmoidf_ref(r0) * m; d1 = sigmoidf_ref(r1) * m;
+    d2 = sigmoidf_ref(r2) * m; d3 = sigmoidf_ref(r3) * m;
+  } else if (d.decode_mode == 1) {
+    d0 = expf(r0); d1 = expf(r1); d2 = expf(r2); d3 = expf(r3);
+  } else {
+    const float m = d.lv.rhi[l];
+    d0 = r0 * m; d1 = r1 * m; d2 = r2 * m; d3 = r3 * m;
+  }
+  const float W = d.meta[n * 3 + 0], H = d.meta[n * 3 + 1], sc = d.meta[n * 3 + 2];
+  float x1 = fminf(fmaxf(px - d0, 0.f), W);
+  float y1 = fminf(fmaxf(py - d1, 0.f), H);
+  float x2 = fminf(fmaxf(px + d2, 0.f), W);
+  float y2 = fminf(fmaxf(py + d3, 0.f), H);
+  return make_float4(x1 / sc, y1 / sc, x2 / sc, y2 / sc);
+}
+
+// ------------------------------------------------------------------ count / scatter
+__global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcounts, int nblk,
+                                                  uint32_t* maxord, int* counts) {
+  __shared__ int smem[8];
+  const int n = blockIdx.y, blk = blockIdx.x;
+  const int p = blk * kBlock + threadIdx.x;
+  int cnt = 0;
+  if (p < d.P) {
+    const int64_t row = (int64_t)n * d.P + p;
+    float mx = 0.f, sum = 1.f;
+    if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+    for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
+  }
+  int total;
+  block_excl_scan(cnt, &total, smem);
+  if (threadIdx.x == 0) {
+    blockcounts[n * nblk + blk] = total;
+    if (blk == 0) {
+      maxord[n] = 0u;
+      counts[n * 4 + 1] = 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* blockcounts, int nblk,
+                                                    SegBuffers b, int* counts) {
+  __shared__ int smem[8];
+  __shared__ uint32_t smax[kBlock / 64];
+  const int n = blockIdx.y, blk = blockIdx.x;
+  // base = sum of the counts of the preceding blocks of this image (fixed order -> deterministic)
+  int part = 0, all = 0;
+  for (int i = threadIdx.x; i < nblk; i += kBlock) {
+    int v = blockcounts[n * nblk + i];
+    all += v;
+    if (i < blk) part += v;
+  }
+  // two block reductions via the scan helper's totals
+  block_excl_scan(part, &part, smem);
+  block_excl_scan(all, &all, smem);
+  const int base = part;
+  if (blk == 0 && threadIdx.x == 0) {
+    counts[n * 4 + 0] = all < b.cap ? all : b.cap;
+    counts[n * 4 + 2] = all > b.cap;
+    counts[n * 4 + 3] = all;
+  }
+  const int p = blk * kBlock + threadIdx.x;
+  int cnt = 0;
+  float mx = 0.f, sum = 1.f;
+  int64_t row = 0;
+  if (p < d.P) {
+    row = (int64_t)n * d.P + p;
+    if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+    for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
+  }
+  int total;
+  int off = base + block_excl_scan(cnt, &total, smem);
+  uint32_t mo = 0u;
+  if (cnt > 0) {
+    const float4 box = decode_box(d, n, p);
+    bool wrote = false;
+    for (int c = 0; c < d.C; ++c) {
+      const float s = score_of(d, row, c, mx, sum);
+      if (s > d.score_thr) {
+        if (off < b.cap) {
+          const int64_t o = (int64_t)n * b.cap + off;
+          b.cand_box[o] = box;
+          b.cand_score[o] = s;
+          b.cand_label[o] = c;
+          if (b.cand_point) b.cand_point[o] = p;
+          wrote = true;
+        }
+        ++off;
+      }
+    }
+    if (wrote) mo = lfd_float_ord(fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
+  }
+  // block max -> one atomic
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    uint32_t o = __shfl_xor(mo, s, 64);
+    mo = o > mo ? o : mo;
+  }
+  if (lfd_lane() == 0) smax[threadIdx.x >> 6] = mo;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = smax[0];
+    for (int i = 1; i < kBlock / 64; ++i) m = smax[i] > m ? smax[i] : m;
+    if (m) atomicMax(&b.maxord[n], m);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_decode_all(DecodeParams d, float* out_boxes, float* out_scores) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= d.P) return;
+  const int64_t row = (int64_t)n * d.P + p;
+  float4 box = decode_box(d, n, p);
+  reinterpret_cast<float4*>(out_boxes)[row] = box;
+  float mx = 0.f, sum = 1.f;
+  if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+  for (int c = 0; c < d.C; ++c) out_scores[row * d.C + c] = score_of(d, row, c, mx, sum);
+}
+
+// ------------------------------------------------------------------ API-path prepare kernels
+// nms_ext.nms input: dets [n,5] -> candidate arrays (label 0, class agnostic).
+__global__ void k_prepare_dets(const float* dets, int n, SegBuffers b) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  b.cand_box[i] = make_float4(dets[i * 5 + 0], dets[i * 5 + 1], dets[i * 5 + 2], dets[i * 5 + 3]);
+  b.cand_score[i] = dets[i * 5 + 4];
+  b.cand_label[i] = 0;
+}
+
+// batched_nms inputs -> candidate arrays + max coordinate (nms.py:148)
+__global__ void k_prepare_batched(const float* boxes, const float* scores, const int64_t* labels, int k,
+                                  SegBuffers b) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t mo = 0u;
+  if (i < k) {
+    float4 bx = reinterpret_cast<const float4*>(boxes)[i];
+    b.cand_box[i] = bx;
+    b.cand_score[i] = scores[i];
+    b.cand_label[i] = (int)labels[i];
+    mo = lfd_float_ord(fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    uint32_t o = __shfl_xor(mo, s, 64);
+    mo = o > mo ? o : mo;
+  }
+  if (lfd_lane() == 0 && mo) atomicMax(&b.maxord[0], mo);
+}
+
+// ------------------------------------------------------------------ sort (rank sort on unique keys)
+__device__ __forceinline__ unsigned long long sort_key(float score, int idx) {
+  if (score == 0.f) score = 0.f;  // -0 == +0 (ties broken by index, as a stable sort would)
+  return ((unsigned long long)(~lfd_float_ord(score)) << 32) | (unsigned)idx;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rank_sort(SegBuffers b) {
+  __shared__ unsigned long long keys[kBlock];
+  const int seg = blockIdx.y;
+  const int K = seg_k(b, seg);
+  if ((int)(blockIdx.x * kBlock) >= K) return;  // uniform per block
+  const int64_t so = (int64_t)seg * b.cap;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < K;
+  const float my_score = live ? b.cand_score[so + i] : 0.f;
+  const unsigned long long my = live ? sort_key(my_score, i) : ~0ull;
+  int rank = 0;
+  for (int j0 = 0; j0 < K; j0 += kBlock) {
+    const int j = j0 + threadIdx.x;
+    __syncthreads();
+    keys[threadIdx.x] = j < K ? sort_key(b.cand_score[so + j], j) : ~0ull;
+    __syncthreads();
+    const int lim = (K - j0) < kBlock ? (K - j0) : kBlock;
+#pragma unroll 8
+    for (int t = 0; t < lim; ++t) rank += keys[t] < my;
+  }
+  if (!live) return;
+  const float4 bx = b.cand_box[so + i];
+  const int label = b.cand_label[so + i];
+  float4 sb = bx;
+  if (!b.class_agnostic) {
+    // offsets = label.to(f32) * (max_coordinate + 1); boxes + offsets   (nms.py:148-150)
+    const float step = lfd_ord_float(b.maxord[seg]) + 1.0f;
+    const float off = (float)label * step;
+    sb.x = bx.x + off; sb.y = bx.y + off; sb.z = bx.z + off; sb.w = bx.w + off;
+  }
+  b.s_idx[so + rank] = i;
+  b.s_score[so + rank] = my_score;
+  b.s_label[so + rank] = label;
+  b.s_box[so + rank] = sb;
+  b.s_area[so + rank] = (sb.z - sb.x) * (sb.w - sb.y);   // nms_cpu.cpp:21 / nms_kernel.cu:19-20
+}
+
+// ------------------------------------------------------------------ suppression bitmask
+// One wave64 per 64x64 tile (row block r, col block c >= r).  Lane t owns row box r*64+t and
+// builds its 64-bit mask of column boxes with IoU > thr (only j > i inside the diagonal tile),
+// exactly nms_kernel.cu:24-68 with threadsPerBlock == wave size.  Column boxes are broadcast
+// with v_readlane (constant lane after unrolling) instead of LDS.
+__device__ __forceinline__ float bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask(SegBuffers b) {
+  const int seg = blockIdx.y;
+  const int K = seg_k(b, seg);
+  const int nb = (K + 63) >> 6;
+  const int64_t so = (int64_t)seg * b.cap;
+  const int lane = lfd_lane();
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kBlock + threadIdx.x) >> 6));
+  const int nwaves = gridDim.x * (kBlock / 64);
+  const int ntiles = nb * nb;
+  const float thr = b.iou_thr;
+  for (int t = wave; t < ntiles; t += nwaves) {
+    const int r = t / nb, c = t - r * nb;
+    if (c < r) continue;
+    const int ri = r * 64 + lane, ci = c * 64 + lane;
+    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f), cb = rb;
+    float ra = 0.f, ca = 0.f;
+    if (ri < K) { rb = b.s_box[so + ri]; ra = b.s_area[so + ri]; }
+    if (ci < K) { cb = b.s_box[so + ci]; ca = b.s_area[so + ci]; }
+    const int ncol = (K - c * 64) < 64 ? (K - c * 64) : 64;
+    const int start = (r == c) ? lane + 1 : 0;
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const float bx = bcast(cb.x, j), by = bcast(cb.y, j), bz = bcast(cb.z, j), bw = bcast(cb.w, j);
+      const float sb = bcast(ca, j);
+      const float left = fmaxf(rb.x, bx), right = fminf(rb.z, bz);
+      const float top = fmaxf(rb.y, by), bottom = fminf(rb.w, bw);
+      const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+      const float inter = w * h;
+      const float iou = inter / (ra + sb - inter);
+      if (j >= start && j < ncol && iou > thr) m |= 1ull << j;
+    }
+    if (ri < K) b.mask[(so + ri) * b.words + c] = m;
+  }
+}
+
+// ------------------------------------------------------------------ greedy scan + outputs
+struct ScanOut {
+  float* dets;     // [nseg,cap,5] or nullptr
+  int* labels;     // [nseg,cap] or nullptr
+  int* cand;       // [nseg,cap] or nullptr
+  int* point;      // [nseg,cap] or nullptr
+  int64_t* keep64; // [cap] (API path, single segment) or nullptr
+  int* counts;     // [nseg,4]: slot 1 <- number kept      (or nullptr)
+  int* num_keep;   // [1] (API path)                       (or nullptr)
+};
+
+constexpr int kScanThreads = 512;
+constexpr int kScanMaxWords = 4096;  // cap <= 262144 candidates per segment
+
+__global__ __launch_bounds__(kScanThreads) void k_scan(SegBuffers b, ScanOut o) {
+  __shared__ unsigned long long remv[kScanMaxWords];
+  __shared__ unsigned long long s_keep;
+  __shared__ int s_nkept;
+  const int seg = blockIdx.x;
+  const int K = seg_k(b, seg);
+  const int nb = (K + 63) >> 6;
+  const int64_t so = (int64_t)seg * b.cap;
+  const int lane = lfd_lane();
+  const bool wave0 = threadIdx.x < 64;
+  for (int w = threadIdx.x; w < nb; w += kScanThreads) remv[w] = 0ull;
+  if (threadIdx.x == 0) s_nkept = 0;
+  __syncthreads();
+  float step = 0.f;
+  if (!b.class_agnostic && K > 0) step = lfd_ord_float(b.maxord[seg]) + 1.0f;
+  for (int c = 0; c < nb; ++c) {
+    if (wave0) {
+      const int row = c * 64 + lane;
+      const unsigned long long diag = row < K ? b.mask[(so + row) * b.words + c] : 0ull;
+      const unsigned long long r = remv[c];
+      unsigned long long alive = __ballot(row < K && !((r >> lane) & 1ull));
+      unsigned long long kb = 0ull;
+      const int dlo = (int)(diag & 0xffffffffull), dhi = (int)(diag >> 32);
+      while (alive) {
+        const int bit = __builtin_ctzll(alive);
+        kb |= 1ull << bit;
+        const unsigned long long m =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, bit) << 32) |
+            (unsigned)__builtin_amdgcn_readlane(dlo, bit);
+        alive &= ~m;
+        alive &= ~(1ull << bit);
+      }
+      // append the kept rows of this block, in order
+      const int base = s_nkept;
+      if ((kb >> lane) & 1ull) {
+        const int pos = base + __popcll(kb & ((1ull << lane) - 1ull));
+        const int64_t oo = so + pos;
+        const int label = b.s_label[so + row];
+        const int ci = b.s_idx[so + row];
+        if (o.dets) {
+          float4 bx = b.s_box[so + row];
+          if (!b.class_agnostic) {   // nms_bboxes[:, :4] - offsets[kept]   (nms.py:156)
+            const float off = (float)label * step;
+            bx.x = bx.x - off; bx.y = bx.y - off; bx.z = bx.z - off; bx.w = bx.w - off;
+          }
+          float* d = o.dets + oo * 5;
+          d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = b.s_score[so + row];
+        }
+        if (o.labels) o.labels[oo] = label;
+        if (o.cand) o.cand[oo] = ci;
+        if (o.point && b.cand_point) o.point[oo] = b.cand_point[so + ci];
+        if (o.keep64) o.keep64[pos] = (int64_t)ci;
+      }
+      if (lane == 0) {
+        s_keep = kb;
+        s_nkept = base + __popcll(kb);
+      }
+    }
+    __syncthreads();
+    const unsigned long long kb = s_keep;
+    const int nw = nb - c - 1;  // words to the right of the diagonal
+    if (nw > 0 && kb) {
+      const int nk = __popcll(kb);
+      const int total = nk * nw;
+      for (int q = threadIdx.x; q < total; q += kScanThreads) {
+        const int ki = q / nw, w = c + 1 + (q - ki * nw);
+        // ki-th set bit of kb
+        unsigned long long t = kb;
+        for (int s = 0; s < ki; ++s) t &= t - 1;
+        const int bit = __builtin_ctzll(t);
+        const unsigned long long v = b.mask[(so + c * 64 + bit) * b.words + w];
+        if (v) atomicOr(&remv[w], v);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (o.counts) o.counts[seg * 4 + 1] = s_nkept;
+    if (o.num_keep) o.num_keep[0] = s_nkept;
+  }
+}
+
+// ------------------------------------------------------------------ host-side plumbing
+struct SegLayout {
+  size_t bytes;
+};
+
+SegBuffers carve_seg(LfdCarver& cv, int nseg, int cap, bool need_point) {
+  SegBuffers b{};
+  b.cap = cap;
+  b.words = (cap + 63) / 64;
+  const size_t tot = (size_t)nseg * cap;
+  b.cand_box = cv.take<float4>(tot);
+  b.cand_score = cv.take<float>(tot);
+  b.cand_label = cv.take<int>(tot);
+  b.cand_point = need_point ? cv.take<int>(tot) : nullptr;
+  b.maxord = cv.take<uint32_t>(nseg);
+  b.s_box = cv.take<float4>(tot);
+  b.s_area = cv.take<float>(tot);
+  b.s_score = cv.take<float>(tot);
+  b.s_label = cv.take<int>(tot);
+  b.s_idx = cv.take<int>(tot);
+  b.mask = cv.take<unsigned long long>(tot * b.words);
+  return b;
+}
+
+size_t seg_bytes(int nseg, int cap, bool need_point) {
+  LfdCarver cv(nullptr);
+  carve_seg(cv, nseg, cap, need_point);
+  return cv.used();
+}
+
+int run_sort_mask_scan(const SegBuffers& b, const ScanOut& o, int nseg, hipStream_t st) {
+  if (b.words > kScanMaxWords) return LFD_ERR_UNSUPPORTED;
+  dim3 gs((b.cap + kBlock - 1) / kBlock, nseg);
+  hipLaunchKernelGGL(k_rank_sort, gs, dim3(kBlock), 0, st, b);
+  LFD_CHECK_LAUNCH();
+  // enough waves to cover the tile list of the capacity, capped: waves loop over tiles
+  long long nb = b.words, tiles = nb * (nb + 1) / 2;
+  long long blocks = (tiles + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_mask, dim3((unsigned)blocks, nseg), dim3(kBlock), 0, st, b);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_scan, dim3(nseg), dim3(kScanThreads), 0, st, b, o);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int fill_decode_params(const lfd_detect_desc_t* desc, int32_t in_dtype, const void* cls, const void* reg,
+                       const float* meta, DecodeParams* d) {
+  if (!desc || desc->num_levels < 1 || desc->num_levels > LFD_MAX_LEVELS) return LFD_ERR_INVALID_ARGUMENT;
+  if (desc->num_classes < 1 || desc->num_cls_channels < desc->num_classes) return LFD_ERR_INVALID_ARGUMENT;
+  if (in_dtype != LFD_F32 && in_dtype != LFD_F16) return LFD_ERR_INVALID_ARGUMENT;
+  d->lv.n = desc->num_levels;
+  int p = 0;
+  for (int i = 0; i < desc->num_levels; ++i) {
+    if (desc->level_h[i] < 0 || desc->level_w[i] < 0) return LFD_ERR_INVALID_ARGUMENT;
+    d->lv.start[i] = p;
+    d->lv.w[i] = desc->level_w[i] > 0 ? desc->level_w[i] : 1;
+    d->lv.stride[i] = desc->level_stride[i];
+    d->lv.rmax[i] = desc->level_range_lo[i] > desc->level_range_hi[i] ? desc->level_range_lo[i]
+                                                                      : desc->level_range_hi[i];
+    d->lv.rhi[i] = desc->level_range_hi[i];
+    p += desc->level_h[i] * desc->level_w[i];
+  }
+  for (int i = desc->num_levels; i <= LFD_MAX_LEVELS; ++i) d->lv.start[i] = p;
+  d->P = p;
+  d->C = desc->num_classes;
+  d->Cc = desc->num_cls_channels;
+  d->score_mode = desc->score_mode;
+  d->decode_mode = desc->decode_mode;
+  d->in_dtype = in_dtype;
+  d->score_thr = desc->score_thr;
+  d->cls = cls;
+  d->reg = reg;
+  d->meta = meta;
+  return LFD_OK;
+}
+
+int desc_points(const lfd_detect_desc_t* desc) {
+  int p = 0;
+  for (int i = 0; i < desc->num_levels && i < LFD_MAX_LEVELS; ++i) p += desc->level_h[i] * desc->level_w[i];
+  return p;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+size_t lfd_nms_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return seg_bytes(1, (int)n, false) + 256;
+}
+
+int lfd_nms_f32(const float* dets, int64_t n, float iou_thr, int64_t* keep, int32_t* num_keep,
+                void* workspace, size_t workspace_bytes, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n < 0 || !num_keep) return LFD_ERR_INVALID_ARGUMENT;
+  if (n == 0) {
+    if (hipMemsetAsync(num_keep, 0, sizeof(int32_t), st) != hipSuccess) return LFD_ERR_LAUNCH_FAILED;
+    return LFD_OK;
+  }
+  if (!dets || !keep || !workspace || n > (1 << 18)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_nms_workspace_bytes(n)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  LfdCarver cv(workspace);
+  SegBuffers b = carve_seg(cv, 1, (int)n, false);
+  b.counts = nullptr;
+  b.k_host = (int)n;
+  b.class_agnostic = 1;
+  b.iou_thr = iou_thr;
+  hipLaunchKernelGGL(k_prepare_dets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dets, (int)n, b);
+  LFD_CHECK_LAUNCH();
+  ScanOut o{};
+  o.keep64 = keep;
+  o.num_keep = num_keep;
+  return run_sort_mask_scan(b, o, 1, st);
+}
+
+size_t lfd_batched_nms_workspace_bytes(int64_t k) { return lfd_nms_workspace_bytes(k); }
+
+int lfd_batched_nms_f32(const float* boxes, const float* scores, const int64_t* labels, int64_t k,
+                        float iou_thr, int32_t class_agnostic, float* out_dets, int64_t* keep,
+                        int32_t* num_keep, void* workspace, size_t workspace_bytes, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k < 0 || !num_keep) return LFD_ERR_INVALID_ARGUMENT;
+  if (k == 0) {
+    if (hipMemsetAsync(num_keep, 0, sizeof(int32_t), st) != hipSuccess) return LFD_ERR_LAUNCH_FAILED;
+    return LFD_OK;
+  }
+  if (!boxes || !scores || !labels || !workspace || k > (1 << 18)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_batched_nms_workspace_bytes(k)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  LfdCarver cv(workspace);
+  SegBuffers b = carve_seg(cv, 1, (int)k, false);
+  b.counts = nullptr;
+  b.k_host = (int)k;
+  b.class_agnostic = class_agnostic ? 1 : 0;
+  b.iou_thr = iou_thr;
+  if (hipMemsetAsync(b.maxord, 0, sizeof(uint32_t), st) != hipSuccess) return LFD_ERR_LAUNCH_FAILED;
+  hipLaunchKernelGGL(k_prepare_batched, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, boxes, scores,
+                     labels, (int)k, b);
+  LFD_CHECK_LAUNCH();
+  ScanOut o{};
+  o.dets = out_dets;
+  o.keep64 = keep;
+  o.num_keep = num_keep;
+  return run_sort_mask_scan(b, o, 1, st);
+}
+
+size_t lfd_detect_workspace_bytes(const lfd_detect_desc_t* desc, int32_t batch) {
+  if (!desc || batch < 1 || desc->max_candidates < 1) return 0;
+  const int P = desc_points(desc);
+  const int nblk = (P + kBlock - 1) / kBlock;
+  LfdCarver cv(nullptr);
+  cv.take<int>((size_t)batch * (nblk > 0 ? nblk : 1));
+  carve_seg(cv, batch, desc->max_candidates, true);
+  return cv.used() + 256;
+}
+
+int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void* cls, const void* reg,
+                       int32_t in_dtype, const float* img_meta, float* out_dets, int32_t* out_labels,
+                       int32_t* out_cand, int32_t* out_point, int32_t* out_counts, void* workspace,
+                       size_t workspace_bytes, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DecodeParams d{};
+  int rc = fill_decode_params(desc, in_dtype, cls, reg, img_meta, &d);
+  if (rc != LFD_OK) return rc;
+  if (batch < 1 || !cls || !reg || !img_meta || !out_counts || !workspace || desc->max_candidates < 1)
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_detect_workspace_bytes(desc, batch)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  if (d.P == 0) {
+    if (hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 4 * batch, st) != hipSuccess) return LFD_ERR_LAUNCH_FAILED;
+    return LFD_OK;
+  }
+  const int nblk = (d.P + kBlock - 1) / kBlock;
+  LfdCarver cv(workspace);
+  int* blockcounts = cv.take<int>((size_t)batch * nblk);
+  SegBuffers b = carve_seg(cv, batch, desc->max_candidates, true);
+  b.counts = out_counts;
+  b.k_host = 0;
+  b.class_agnostic = desc->class_agnostic ? 1 : 0;
+  b.iou_thr = desc->iou_thr;
+  hipLaunchKernelGGL(k_count, dim3(nblk, batch), dim3(kBlock), 0, st, d, blockcounts, nblk, b.maxord, out_counts);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_scatter, dim3(nblk, batch), dim3(kBlock), 0, st, d, blockcounts, nblk, b, out_counts);
+  LFD_CHECK_LAUNCH();
+  ScanOut o{};
+  o.dets = out_dets;
+  o.labels = out_labels;
+  o.cand = out_cand;
+  o.point = out_point;
+  o.counts = out_counts;
+  return run_sort_mask_scan(b, o, batch, st);
+}
+
+int lfd_decode_all(const lfd_detect_desc_t* desc, int32_t batch, const void* cls, const void* reg,
+                   int32_t in_dtype, const float* img_meta, float* out_boxes, float* out_scores,
+                   lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DecodeParams d{};
+  int rc = fill_decode_params(desc, in_dtype, cls, reg, img_meta, &d);
+  if (rc != LFD_OK) return rc;
+  if (batch < 1 || !cls || !reg || !img_meta || !out_boxes || !out_scores) return LFD_ERR_INVALID_ARGUMENT;
+  if (d.P == 0) return LFD_OK;
+  hipLaunchKernelGGL(k_decode_all, dim3((d.P + kBlock - 1) / kBlock, batch), dim3(kBlock), 0, st, d, out_boxes,
+                     out_scores);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+}  // extern "C"

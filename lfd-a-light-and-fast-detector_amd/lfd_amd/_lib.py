@@ -1,0 +1,92 @@
+"""ctypes binding of liblfd_hip.so (C ABI: include/lfd_hip.h).
+
+This is the ONLY compute backend of the package.  There is no PyTorch / CPU fallback: if the
+library is missing or a call fails, a RuntimeError is raised (the reference raises the same
+way through AT_ERROR / TORCH_CHECK -> RuntimeError, nms_ext.cpp:22-24).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblfd_hip.so')
+MAX_LEVELS = 8
+F32, F16 = 0, 1
+
+_lib = None
+
+
+class DetectDesc(C.Structure):
+    """lfd_detect_desc_t"""
+    _fields_ = [('num_levels', C.c_int32),
+                ('level_h', C.c_int32 * MAX_LEVELS), ('level_w', C.c_int32 * MAX_LEVELS),
+                ('level_stride', C.c_int32 * MAX_LEVELS),
+                ('level_range_lo', C.c_float * MAX_LEVELS), ('level_range_hi', C.c_float * MAX_LEVELS),
+                ('num_classes', C.c_int32), ('num_cls_channels', C.c_int32),
+                ('score_mode', C.c_int32), ('decode_mode', C.c_int32),
+                ('class_agnostic', C.c_int32), ('max_candidates', C.c_int32),
+                ('score_thr', C.c_float), ('iou_thr', C.c_float)]
+
+
+_P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+_SIGNATURES = {
+    'lfd_hip_abi_version': (C.c_int, []),
+    'lfd_hip_status_string': (C.c_char_p, [C.c_int]),
+    'lfd_hip_build_info': (C.c_char_p, []),
+    'lfd_nms_workspace_bytes': (_SZ, [_I64]),
+    'lfd_nms_f32': (C.c_int, [_P, _I64, _F, _P, _P, _P, _SZ, _P]),
+    'lfd_batched_nms_workspace_bytes': (_SZ, [_I64]),
+    'lfd_batched_nms_f32': (C.c_int, [_P, _P, _P, _I64, _F, _I32, _P, _P, _P, _P, _SZ, _P]),
+    'lfd_detect_workspace_bytes': (_SZ, [C.POINTER(DetectDesc), _I32]),
+    'lfd_detect_batched': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'lfd_decode_all': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _I32, _P, _P, _P, _P]),
+    'lfd_sigmoid_focal_loss_fwd': (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _I32, _P]),
+    'lfd_sigmoid_focal_loss_bwd': (C.c_int, [_P, _P, _P, _I64, _I32, _F, _F, _P, _I32, _P]),
+    'lfd_reduce_workspace_bytes': (_SZ, []),
+    'lfd_sigmoid_focal_loss_sum_f32': (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _SZ, _P]),
+    'lfd_iou_loss_fwd_f32': (C.c_int, [_P, _P, _I64, _F, _P, _P]),
+    'lfd_iou_loss_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Loads liblfd_hip.so (after torch, so that the HIP runtime already mapped by torch is
+    the one the kernels register with -- same soname libamdhip64.so.7)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'liblfd_hip.so not found at %s -- build it with `python __graft_entry__.py` '
+                '(hipcc --offload-arch=gfx950); lfd_amd has no CPU/PyTorch fallback.' % LIB_PATH)
+        import torch  # noqa: F401  (maps the HIP runtime first)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)   # AttributeError -> missing export: loud by design
+            fn.restype, fn.argtypes = res, args
+        if l.lfd_hip_abi_version() != 1:
+            raise RuntimeError('liblfd_hip.so ABI version mismatch')
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed: %s (status %d)' % (what, lib().lfd_hip_status_string(status).decode(), status))
+
+
+def require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('%s: lfd_amd kernels run on the MI355X only (got a %s tensor); '
+                           'there is no CPU implementation' % (what, t.device))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,195 @@
+"""Thin tensor plumbing over the C ABI (pointers + current HIP stream); no arithmetic here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DetectDesc, F16, F32, check, lib, ptr, require_cuda, stream_ptr
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (caller-owned workspace of the C ABI)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise RuntimeError('unsupported dtype %s (float32 / float16 only)' % t.dtype)
+
+
+# ------------------------------------------------------------------ NMS
+def nms_indices(dets, iou_thr):
+    """nms_ext.nms: dets [n,5] float32 cuda -> int64 kept indices (score-descending)."""
+    require_cuda(dets, 'nms')
+    if dets.dim() != 2 or dets.size(1) != 5:
+        raise RuntimeError('nms: dets must be [n,5]')
+    n = dets.size(0)
+    if n == 0:
+        return torch.empty(0, dtype=torch.long)   # reference returns an empty CPU long (nms_cuda.cpp:10-11)
+    d = dets.contiguous().float()
+    with torch.cuda.device(d.device):
+        keep = torch.empty(n, dtype=torch.long, device=d.device)
+        num = torch.zeros(1, dtype=torch.int32, device=d.device)
+        wsb = lib().lfd_nms_workspace_bytes(n)
+        ws = _workspace(wsb, d.device)
+        check(lib().lfd_nms_f32(ptr(d), n, float(iou_thr), ptr(keep), ptr(num), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_nms_f32')
+        k = int(num.item())   # data-dependent output length: the reference path synchronises too
+    return keep[:k]
+
+
+def batched_nms_dets(boxes, scores, labels, iou_thr, class_agnostic=False):
+    """batched_nms core: returns (dets[k,5], keep[k] int64)."""
+    require_cuda(boxes, 'batched_nms')
+    k_in = boxes.size(0)
+    if k_in == 0:
+        return boxes.new_zeros((0, 5)), torch.empty(0, dtype=torch.long, device=boxes.device)
+    b = boxes.contiguous().float()
+    s = scores.contiguous().float()
+    l = labels.to(device=b.device, dtype=torch.long).contiguous()
+    with torch.cuda.device(b.device):
+        dets = torch.empty((k_in, 5), dtype=torch.float32, device=b.device)
+        keep = torch.empty(k_in, dtype=torch.long, device=b.device)
+        num = torch.zeros(1, dtype=torch.int32, device=b.device)
+        wsb = lib().lfd_batched_nms_workspace_bytes(k_in)
+        ws = _workspace(wsb, b.device)
+        check(lib().lfd_batched_nms_f32(ptr(b), ptr(s), ptr(l), k_in, float(iou_thr), int(bool(class_agnostic)),
+                                        ptr(dets), ptr(keep), ptr(num), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_batched_nms_f32')
+        k = int(num.item())
+    return dets[:k], keep[:k]
+
+
+# ------------------------------------------------------------------ fused decode + threshold + NMS
+def make_detect_desc(sizes, strides, ranges, num_classes, num_cls_channels, score_mode, decode_mode,
+                     class_agnostic, max_candidates, score_thr, iou_thr):
+    if len(sizes) > _lib.MAX_LEVELS:
+        raise RuntimeError('at most %d levels' % _lib.MAX_LEVELS)
+    d = DetectDesc()
+    d.num_levels = len(sizes)
+    for i, ((h, w), s, r) in enumerate(zip(sizes, strides, ranges)):
+        d.level_h[i], d.level_w[i], d.level_stride[i] = int(h), int(w), int(s)
+        d.level_range_lo[i], d.level_range_hi[i] = float(r[0]), float(r[1])
+    d.num_classes, d.num_cls_channels = int(num_classes), int(num_cls_channels)
+    d.score_mode, d.decode_mode = int(score_mode), int(decode_mode)
+    d.class_agnostic, d.max_candidates = int(bool(class_agnostic)), int(max_candidates)
+    d.score_thr, d.iou_thr = float(score_thr), float(iou_thr)
+    return d
+
+
+class DetectOutputs(object):
+    __slots__ = ('dets', 'labels', 'cand', 'point', 'counts')
+
+
+def detect_batched(desc, cls, reg, meta, out=None):
+    """Enqueues the whole post-processing of a batch; returns device-resident outputs (no sync)."""
+    require_cuda(cls, 'detect')
+    n = cls.size(0)
+    cls = cls.contiguous()
+    reg = reg.contiguous()
+    if cls.dtype != reg.dtype:
+        raise RuntimeError('cls / reg dtype mismatch')
+    dev = cls.device
+    cap = desc.max_candidates
+    with torch.cuda.device(dev):
+        if out is None:
+            out = DetectOutputs()
+            out.dets = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
+            out.labels = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.cand = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.point = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        wsb = lib().lfd_detect_workspace_bytes(C.byref(desc), n)
+        ws = _workspace(wsb, dev)
+        check(lib().lfd_detect_batched(C.byref(desc), n, ptr(cls), ptr(reg), _dtype_code(cls), ptr(meta),
+                                       ptr(out.dets), ptr(out.labels), ptr(out.cand), ptr(out.point),
+                                       ptr(out.counts), ptr(ws), ws.numel(), stream_ptr()), 'lfd_detect_batched')
+    return out
+
+
+def decode_all(desc, cls, reg, meta):
+    require_cuda(cls, 'decode')
+    n, p = cls.size(0), cls.size(1)
+    cls = cls.contiguous()
+    reg = reg.contiguous()
+    with torch.cuda.device(cls.device):
+        boxes = torch.empty((n, p, 4), dtype=torch.float32, device=cls.device)
+        scores = torch.empty((n, p, desc.num_classes), dtype=torch.float32, device=cls.device)
+        check(lib().lfd_decode_all(C.byref(desc), n, ptr(cls), ptr(reg), _dtype_code(cls), ptr(meta), ptr(boxes),
+                                   ptr(scores), stream_ptr()), 'lfd_decode_all')
+    return boxes, scores
+
+
+# ------------------------------------------------------------------ losses
+def focal_forward(logits, targets, gamma, alpha):
+    require_cuda(logits, 'sigmoid_focal_loss forward')
+    if logits.dim() != 2:
+        raise RuntimeError('logits should be NxClass')
+    x = logits.contiguous()
+    t = targets.contiguous()
+    if t.dtype != torch.long:
+        raise RuntimeError('targets must be int64')
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_sigmoid_focal_loss_fwd(ptr(x), ptr(t), x.size(0), x.size(1), float(gamma), float(alpha),
+                                               ptr(out), _dtype_code(x), stream_ptr()), 'lfd_sigmoid_focal_loss_fwd')
+    return out
+
+
+def focal_backward(logits, targets, d_losses, gamma, alpha):
+    require_cuda(logits, 'sigmoid_focal_loss backward')
+    x = logits.contiguous()
+    t = targets.contiguous()
+    g = d_losses.contiguous().to(x.dtype)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_sigmoid_focal_loss_bwd(ptr(x), ptr(t), ptr(g), x.size(0), x.size(1), float(gamma),
+                                               float(alpha), ptr(out), _dtype_code(x), stream_ptr()),
+              'lfd_sigmoid_focal_loss_bwd')
+    return out
+
+
+def focal_sum(logits, targets, gamma, alpha):
+    require_cuda(logits, 'sigmoid_focal_loss sum')
+    x = logits.contiguous().float()
+    t = targets.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws = _workspace(lib().lfd_reduce_workspace_bytes(), x.device)
+        check(lib().lfd_sigmoid_focal_loss_sum_f32(ptr(x), ptr(t), x.size(0), x.size(1), float(gamma), float(alpha),
+                                                   ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_sigmoid_focal_loss_sum_f32')
+    return out
+
+
+def iou_loss_forward(pred, target, eps):
+    require_cuda(pred, 'iou_loss forward')
+    a = pred.contiguous().float()
+    b = target.contiguous().float()
+    out = torch.empty(a.size(0), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().lfd_iou_loss_fwd_f32(ptr(a), ptr(b), a.size(0), float(eps), ptr(out), stream_ptr()),
+              'lfd_iou_loss_fwd_f32')
+    return out
+
+
+def iou_loss_backward(pred, target, d_loss, eps):
+    require_cuda(pred, 'iou_loss backward')
+    a = pred.contiguous().float()
+    b = target.contiguous().float()
+    g = d_loss.contiguous().float()
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(lib().lfd_iou_loss_bwd_f32(ptr(a), ptr(b), ptr(g), a.size(0), float(eps), ptr(out), stream_ptr()),
+              'lfd_iou_loss_bwd_f32')
+    return out
