@@ -151,6 +151,31 @@ LFD_API int lfd_iou_loss_fwd_f32(const float* pred, const float* target, int64_t
 LFD_API int lfd_iou_loss_bwd_f32(const float* pred, const float* target, const float* d_loss, int64_t n,
                          float eps, float* d_pred, lfd_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Inference conv stack, NHWC fp16, fp32 accumulate on MFMA.  Replaces the nn.Conv2d +
+ * nn.BatchNorm2d (folded) + ReLU (+ residual add) units of LFDResNet
+ *   (lfd/model/backbone/lfd_resnet.py:96-154 FasterBlock, :21-93 FastBlock, :157-215 FastestBlock,
+ *    :354-439 stem, :458-468 downsample; executed by cuDNN in the reference).
+ * out = relu?( conv(in, w) + bias (+ residual) ), optionally followed in the same kernel by a
+ * chained 1x1 conv: out = relu?( conv1x1(relu?(conv(in,w)+bias), tail_w) + tail_bias ).
+ * Weights are pre-packed in MFMA fragment order (see lfd_pack_conv_weight_f16).
+ */
+typedef struct lfd_conv_desc {
+  int32_t n, h, w;      /* input dims (NHWC) */
+  int32_t cin, cout;    /* cin in {32,64,128}; cout multiple of 32 */
+  int32_t ks, stride;   /* 1|3 (pad = ks/2), 1|2 */
+  int32_t relu;
+  int32_t tail_cout;    /* 0: no chained 1x1; else must equal cout */
+  int32_t tail_relu;
+} lfd_conv_desc_t;
+
+LFD_API size_t lfd_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t ks);
+LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, void* out,
+                                const void* w_packed, const float* bias, const void* residual,
+                                const void* tail_w_packed, const float* tail_bias,
+                                const void* zeros /* >=256 zero bytes */, lfd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

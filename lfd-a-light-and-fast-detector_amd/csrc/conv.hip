@@ -1,0 +1,377 @@
+// csrc/conv.hip -- NHWC fp16 implicit-GEMM convolution (1x1 / 3x3, stride 1 / 2) on gfx950 MFMA.
+//
+// Replaces the cuDNN-backed nn.Conv2d + nn.BatchNorm2d + ReLU (+ residual add) stacks of the
+// reference backbone (lfd/model/backbone/lfd_resnet.py:96-154 FasterBlock, :354-439 stem,
+// :458-468 downsample) for inference: BN is folded into the weights/bias on the host, the
+// epilogue fuses bias + residual + ReLU, and an optional chained 1x1 conv ("tail") consumes
+// the tile through LDS without a trip to HBM (stem 3x3 -> 1x1 pairs).
+//
+// Design (MI355X-first, not a port of a warp-tiled CUDA kernel):
+//   * weights-stationary: each wave64 keeps the whole [32 cout x K] filter slab of its
+//     cout tile in VGPRs (K = 9*64 -> 36 fragments = 144 VGPRs) for the lifetime of a
+//     persistent workgroup; only the activation operand streams through LDS;
+//   * v_mfma_f32_32x32x16_f16 with the roles swapped (A = weights, B = pixels) so that the
+//     accumulator layout is lane = pixel, registers = 4-channel groups -> 8-byte NHWC stores;
+//   * the input halo tile is fetched by direct global->LDS DMA (global_load_lds_dwordx4,
+//     no VGPR staging), double-buffered so tile t+1 lands while tile t is on the MFMA pipe;
+//     LDS image is lane-linear, the XOR bank swizzle is applied on the SOURCE address and on
+//     the ds_read_b128 side (guide rule 21); out-of-image pixels read a zero line;
+//   * workgroups are persistent (grid = 2 x 256 CUs) and walk XCD-contiguous tile ranges so
+//     neighbouring halo re-reads hit the same XCD's L2.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvArgs {
+  const _Float16* in;     // [N,H,W,CIN]
+  _Float16* out;          // [N,OH,OW,COUT_OUT]
+  const half8* w;         // packed main weights [cout_tile][NK][64 lanes] x 8 halfs
+  const float* bias;      // [COUT] (BN folded)
+  const _Float16* res;    // optional residual [N,OH,OW,COUT_OUT] (added before ReLU)
+  const half8* w2;        // tail 1x1 packed weights [cout2_tile][CMID/16][64]
+  const float* bias2;     // [COUT2]
+  const _Float16* zeros;  // >= 256 B of zeros (source of out-of-image pixels)
+  int N, H, W, OH, OW;
+  int cout;    // main conv output channels
+  int cout2;   // tail output channels (TAIL only)
+  int relu, relu2;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
+struct Cfg {
+  // k-steps whose weight fragments live in LDS instead of VGPRs (register-pressure relief for
+  // the 64-ch 3x3 s1 workhorse: 28 of 36 fragments stay in registers, 2 taps are LDS-resident)
+  static constexpr int WL = (WREG && CIN == 64 && KS == 3 && S == 1) ? 8 : 0;
+  static constexpr int PT = (S == 1) ? 2 : 1;       // 32-pixel MFMA tiles per wave
+  static constexpr int TW = (S == 1) ? 32 : 16;     // output tile width
+  static constexpr int RPT = 32 / TW;               // output rows per MFMA pixel tile
+  static constexpr int PG = 4 / NCT;                // pixel groups (waves along pixels) per block
+  static constexpr int TH = PG * PT * RPT;          // output tile height
+  static constexpr int PAD = KS / 2;
+  static constexpr int IH = (TH - 1) * S + KS;
+  static constexpr int IW = (TW - 1) * S + KS;
+  static constexpr int IWh = (IW + 1) / 2;
+  static constexpr int IWs = (S == 2) ? 2 * IWh : ((IW + 1) & ~1);  // slots per row (even)
+  static constexpr int CPP = CIN / 8;               // 16-byte chunks per pixel
+  static constexpr int PIXB = CIN * 2;
+  static constexpr int PPR = (CPP >= 16) ? 1 : 16 / CPP;  // pixels per 256-B bank row
+  static constexpr int NSLOT = IH * IWs;
+  static constexpr int IN_BYTES = ((NSLOT * PIXB + 1023) / 1024) * 1024;
+  static constexpr int NBUF = (S == 1) ? 2 : 1;     // S=2 tiles are 4x larger: single buffer, 2 blocks/CU
+  static constexpr int NK = KS * KS * CIN / 16;     // MFMA k-steps of the main conv
+  static constexpr int NQ = CIN / 16;
+  // tail (1x1 on the main conv's output): CMID = NCT*32 channels
+  static constexpr int CMID = NCT * 32;
+  static constexpr int MCPP = CMID / 8;
+  static constexpr int MPIXB = CMID * 2;
+  static constexpr int MPPR = (MCPP >= 16) ? 1 : 16 / MCPP;
+  static constexpr int NK2 = CMID / 16;
+  static constexpr int MID_BYTES = TAIL ? (PG * PT * 32 * MPIXB) : 0;
+  static constexpr int WL_BYTES = WL * NCT * 1024;
+  static constexpr int LDS_BYTES = NBUF * IN_BYTES + MID_BYTES + WL_BYTES;
+};
+
+__device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
+__global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
+  using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ct = wave % NCT;         // cout tile of this wave inside the block's cout group
+  const int pg = wave / NCT;         // pixel group
+  const int h = lane >> 5;           // k half / channel half
+  const int pix = lane & 31;
+  const int oyl = pix / C::TW, oxl = pix % C::TW;
+  const int cog = blockIdx.y;        // cout group (NCT*32 channels each)
+  const int co_base = (cog * NCT + ct) * 32;
+
+  // ---- stationary weights
+  constexpr int NKR = WREG ? (C::NK - C::WL) : 1;   // fragments held in VGPRs
+  half8 wreg[NKR];
+  const half8* wsrc = a.w + ((size_t)(cog * NCT + ct) * C::NK) * 64 + lane;
+  half8* wlds = reinterpret_cast<half8*>(smem + C::NBUF * C::IN_BYTES + C::MID_BYTES) + (ct * C::WL) * 64 + lane;
+  if (WREG) {
+#pragma unroll
+    for (int k = 0; k < NKR; ++k) wreg[k] = wsrc[(size_t)k * 64];
+#pragma unroll
+    for (int k = 0; k < C::WL; ++k) wlds[k * 64] = wsrc[(size_t)(NKR + k) * 64];  // visible after the first barrier
+  }
+  half8 w2reg[TAIL ? C::NK2 : 1];
+  if (TAIL) {
+#pragma unroll
+    for (int k = 0; k < C::NK2; ++k) w2reg[k] = a.w2[((size_t)ct * C::NK2 + k) * 64 + lane];
+  }
+
+  // ---- per-lane LDS read offsets: one per (column tap s, 16-channel group q)
+  int xoff[KS][C::NQ];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int ix = oxl * S + s;
+    const int rem = (S == 2) ? ((ix & 1) * C::IWh + (ix >> 1)) : ix;
+    const int f = (rem / C::PPR) % C::CPP;
+    const int rowbase = ((pg * C::PT * C::RPT + oyl) * S) * C::IWs + rem;
+#pragma unroll
+    for (int q = 0; q < C::NQ; ++q) xoff[s][q] = rowbase * C::PIXB + (((2 * q + h) ^ f) * 16);
+  }
+
+  // ---- persistent tile walk, XCD-contiguous ranges (block b runs on XCD b % 8)
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int t_begin = xcd * per_xcd;
+  const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
+  const int t_step = (nblk + 7 - xcd) / 8;  // blocks living on this XCD
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+  auto issue_dma = [&](int t, int buf) {
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * C::TH * S - C::PAD, gx0 = tx0 * C::TW * S - C::PAD;
+    constexpr int SPW = 64 / C::CPP;  // pixel slots per wave instruction
+    char* lbase = smem + buf * C::IN_BYTES;
+    for (int slot0 = wave * SPW; slot0 < C::NSLOT; slot0 += 4 * SPW) {
+      const int pslot = slot0 + lane / C::CPP;
+      const int cs = lane % C::CPP;
+      if (pslot < C::NSLOT) {
+        const int iy = pslot / C::IWs;
+        const int rem = pslot - iy * C::IWs;
+        const int ix = (S == 2) ? ((rem < C::IWh) ? 2 * rem : 2 * (rem - C::IWh) + 1) : rem;
+        const int c = cs ^ ((rem / C::PPR) % C::CPP);
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        bool needed = ix < C::IW;
+        if (KS == 1 && S == 2) needed = needed && !(ix & 1) && !(iy & 1);
+        if (needed) {
+          const bool valid = (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
+          const _Float16* src = valid ? a.in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + c * 8
+                                      : a.zeros + c * 8;
+          dma16(src, lbase + slot0 * C::PIXB);
+        }
+      }
+    }
+  };
+
+  int t = t_begin + bix;
+  int buf = 0;
+  if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
+  for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1)) {
+    if (C::NBUF == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile t landed for every wave; everyone is done with buffer buf^1 and `mid`
+      if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
+    } else {
+      __syncthreads();  // everyone is done reading the single buffer / `mid`
+      issue_dma(t, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const char* xb = smem + buf * C::IN_BYTES;
+
+    f32x16 acc[C::PT];
+    {
+      // accumulators start at the (BN-folded) bias of this lane's 16 channels
+      const float* bp = a.bias + co_base + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < C::PT; ++pt) {
+          acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y;
+          acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
+        }
+      }
+    }
+    auto tap_row = [&](int r) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int q = 0; q < C::NQ; ++q) {
+          const int k = (r * KS + s) * C::NQ + q;
+          half8 wf;
+          if constexpr (!WREG) wf = wsrc[(size_t)k * 64];
+          else if (k < NKR) wf = wreg[k < NKR ? k : 0];
+          else wf = wlds[(k - NKR) * 64];
+#pragma unroll
+          for (int pt = 0; pt < C::PT; ++pt) {
+            const half8 xf = *reinterpret_cast<const half8*>(
+                xb + xoff[s][q] + (r + pt * C::RPT * S) * C::IWs * C::PIXB);
+            acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[pt], 0, 0, 0);
+          }
+        }
+      }
+    };
+    if constexpr (WREG) {
+#pragma unroll
+      for (int r = 0; r < KS; ++r) tap_row(r);
+    } else {
+      // weights streamed from L2: keep the row loop rolled so the compiler cannot hoist all
+      // KS*KS*NQ fragment loads (72 x 4 VGPRs) ahead of the MFMAs
+#pragma unroll 1
+      for (int r = 0; r < KS; ++r) tap_row(r);
+    }
+
+    if (TAIL) {
+      // main conv epilogue -> fp16 -> LDS `mid` tile [pixel][CMID] (swizzled), then 1x1 tail
+      char* mid = smem + C::NBUF * C::IN_BYTES;
+#pragma unroll
+      for (int pt = 0; pt < C::PT; ++pt) {
+        const int pb = (pg * C::PT + pt) * 32 + pix;
+        const int fm = (pb / C::MPPR) % C::MCPP;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = acc[pt][4 * g + j];
+            if (a.relu) x = fmaxf(x, 0.f);
+            v[j] = (_Float16)x;
+          }
+          const int cm = ct * 4 + g;
+          *reinterpret_cast<half4*>(mid + pb * C::MPIXB + ((cm ^ fm) * 16) + 8 * h) = v;
+        }
+      }
+      __syncthreads();
+      {
+        const float* bp = a.bias2 + ct * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+          for (int pt = 0; pt < C::PT; ++pt) {
+            acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y;
+            acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < C::NK2; ++q) {
+#pragma unroll
+        for (int pt = 0; pt < C::PT; ++pt) {
+          const int pb = (pg * C::PT + pt) * 32 + pix;
+          const int fm = (pb / C::MPPR) % C::MCPP;
+          const half8 xf = *reinterpret_cast<const half8*>(mid + pb * C::MPIXB + (((2 * q + h) ^ fm) * 16));
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2reg[q], xf, acc[pt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: (+ residual) -> ReLU -> fp16 -> 8-byte NHWC stores
+    const int cout_out = TAIL ? a.cout2 : a.cout;
+    const int co_out = TAIL ? (ct * 32) : co_base;
+    const int do_relu = TAIL ? a.relu2 : a.relu;
+#pragma unroll
+    for (int pt = 0; pt < C::PT; ++pt) {
+      const int oy = ty0 * C::TH + (pg * C::PT + pt) * C::RPT + oyl;
+      const int ox = tx0 * C::TW + oxl;
+      if (oy < a.OH && ox < a.OW) {
+        const size_t o = (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + co_out + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float x0 = acc[pt][4 * g + 0], x1 = acc[pt][4 * g + 1], x2 = acc[pt][4 * g + 2], x3 = acc[pt][4 * g + 3];
+          if (a.res) {
+            const half4 rv = *reinterpret_cast<const half4*>(a.res + o + 8 * g);
+            x0 += (float)rv[0]; x1 += (float)rv[1]; x2 += (float)rv[2]; x3 += (float)rv[3];
+          }
+          if (do_relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
+          half4 v;
+          v[0] = (_Float16)x0; v[1] = (_Float16)x1; v[2] = (_Float16)x2; v[3] = (_Float16)x3;
+          *reinterpret_cast<half4*>(a.out + o + 8 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
+int launch_conv(const ConvArgs& a0, hipStream_t st) {
+  using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
+  ConvArgs a = a0;
+  a.tiles_x = (a.OW + C::TW - 1) / C::TW;
+  a.tiles_y = (a.OH + C::TH - 1) / C::TH;
+  a.ntiles = a.N * a.tiles_x * a.tiles_y;
+  const int cgroups = TAIL ? 1 : a.cout / (NCT * 32);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    attr_done = true;
+  }
+  int blocks = 512 / cgroups;
+  if (blocks > a.ntiles) blocks = a.ntiles;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL>), dim3(blocks, cgroups), dim3(256), C::LDS_BYTES, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Packed-weight sizes: [cout/32][NK][64 lanes] half8  (NK = ks*ks*cin/16).
+size_t lfd_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t ks) {
+  return (size_t)(cout / 32) * (size_t)(ks * ks * cin / 16) * 64 * 8;
+}
+
+int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                        const float* bias, const void* residual, const void* tail_w_packed,
+                        const float* tail_bias, const void* zeros, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!d || !in || !out || !w_packed || !bias || !zeros) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->n < 1 || d->h < 1 || d->w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if ((d->ks != 1 && d->ks != 3) || (d->stride != 1 && d->stride != 2)) return LFD_ERR_UNSUPPORTED;
+  if (d->cout % 32 || d->cin % 16) return LFD_ERR_UNSUPPORTED;
+  ConvArgs a{};
+  a.in = (const _Float16*)in; a.out = (_Float16*)out; a.w = (const half8*)w_packed; a.bias = bias;
+  a.res = (const _Float16*)residual; a.w2 = (const half8*)tail_w_packed; a.bias2 = tail_bias;
+  a.zeros = (const _Float16*)zeros;
+  a.N = d->n; a.H = d->h; a.W = d->w;
+  const int pad = d->ks / 2;
+  a.OH = (d->h + 2 * pad - d->ks) / d->stride + 1;
+  a.OW = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  a.cout = d->cout; a.cout2 = d->tail_cout; a.relu = d->relu; a.relu2 = d->tail_relu;
+  const bool tail = d->tail_cout > 0;
+  if (tail && (!tail_w_packed || !tail_bias || d->tail_cout != d->cout || residual)) return LFD_ERR_UNSUPPORTED;
+  const int key = d->cin * 10000 + d->ks * 1000 + d->stride * 100 + (d->cout / 32) * 10 + (tail ? 1 : 0);
+  switch (key) {
+    // ---- 64-channel backbone body
+    case 64 * 10000 + 3100 + 20: return launch_conv<64, 3, 1, 2, true, false>(a, st);
+    case 64 * 10000 + 3200 + 20: return launch_conv<64, 3, 2, 2, true, false>(a, st);
+    case 64 * 10000 + 3200 + 21: return launch_conv<64, 3, 2, 2, true, true>(a, st);
+    case 64 * 10000 + 3200 + 40: return launch_conv<64, 3, 2, 4, true, false>(a, st);
+    case 64 * 10000 + 1100 + 20: return launch_conv<64, 1, 1, 2, true, false>(a, st);
+    case 64 * 10000 + 1100 + 40: return launch_conv<64, 1, 1, 4, true, false>(a, st);
+    case 64 * 10000 + 1200 + 20: return launch_conv<64, 1, 2, 2, true, false>(a, st);
+    case 64 * 10000 + 1200 + 40: return launch_conv<64, 1, 2, 4, true, false>(a, st);
+    // ---- 128-channel stages (tiny maps): weights streamed from L2 per k-step
+    case 128 * 10000 + 3100 + 40: return launch_conv<128, 3, 1, 4, false, false>(a, st);
+    case 128 * 10000 + 3200 + 40: return launch_conv<128, 3, 2, 4, false, false>(a, st);
+    case 128 * 10000 + 1100 + 40: return launch_conv<128, 1, 1, 4, true, false>(a, st);
+    case 128 * 10000 + 1200 + 40: return launch_conv<128, 1, 2, 4, true, false>(a, st);
+    // ---- 32-channel stem of the XS model
+    case 32 * 10000 + 3200 + 11: return launch_conv<32, 3, 2, 1, true, true>(a, st);
+    case 32 * 10000 + 3200 + 10: return launch_conv<32, 3, 2, 1, true, false>(a, st);
+    case 32 * 10000 + 3200 + 20: return launch_conv<32, 3, 2, 2, true, false>(a, st);
+    case 32 * 10000 + 3100 + 10: return launch_conv<32, 3, 1, 1, true, false>(a, st);
+    case 32 * 10000 + 1100 + 10: return launch_conv<32, 1, 1, 1, true, false>(a, st);
+    case 32 * 10000 + 1200 + 20: return launch_conv<32, 1, 2, 2, true, false>(a, st);
+    default: return LFD_ERR_UNSUPPORTED;
+  }
+}
+
+}  // extern "C"

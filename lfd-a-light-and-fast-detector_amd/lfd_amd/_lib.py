@@ -27,6 +27,13 @@ class DetectDesc(C.Structure):
                 ('score_thr', C.c_float), ('iou_thr', C.c_float)]
 
 
+class ConvDesc(C.Structure):
+    """lfd_conv_desc_t"""
+    _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
+                ('ks', C.c_int32), ('stride', C.c_int32), ('relu', C.c_int32), ('tail_cout', C.c_int32),
+                ('tail_relu', C.c_int32)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
@@ -45,6 +52,8 @@ _SIGNATURES = {
     'lfd_sigmoid_focal_loss_sum_f32': (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _SZ, _P]),
     'lfd_iou_loss_fwd_f32': (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     'lfd_iou_loss_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
+    'lfd_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
+    'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -193,3 +193,50 @@ def iou_loss_backward(pred, target, d_loss, eps):
         check(lib().lfd_iou_loss_bwd_f32(ptr(a), ptr(b), ptr(g), a.size(0), float(eps), ptr(out), stream_ptr()),
               'lfd_iou_loss_bwd_f32')
     return out
+
+
+# ------------------------------------------------------------------ conv stack (NHWC fp16)
+def pack_conv_weight(w):
+    """[Cout,Cin,k,k] float (BN already folded) -> MFMA fragment order [Cout/32][k*k*Cin/16][64][8] fp16.
+    lane = 32*half + cout_local; the 8 halfs of a lane are channels 16q + 8*half + 0..7 of tap (r,s),
+    k-step index = (r*k + s)*(Cin/16) + q  (csrc/conv.hip)."""
+    cout, cin, ks, _ = w.shape
+    assert cout % 32 == 0 and cin % 16 == 0
+    nq = cin // 16
+    w5 = w.detach().float().permute(0, 2, 3, 1).reshape(cout // 32, 32, ks, ks, nq, 2, 8)
+    wp = w5.permute(0, 2, 3, 4, 5, 1, 6).reshape(cout // 32, ks * ks * nq, 64, 8)
+    return wp.half().contiguous()
+
+
+_zeros = {}
+
+
+def zero_line(device):
+    key = (device.type, device.index)
+    z = _zeros.get(key)
+    if z is None:
+        z = torch.zeros(4096, dtype=torch.uint8, device=device)
+        _zeros[key] = z
+    return z
+
+
+def conv2d_nhwc(x, w_packed, bias, cin, cout, ks, stride, relu, residual=None, tail=None, out=None):
+    """x [N,H,W,cin] fp16 -> [N,OH,OW,cout] fp16.  tail = (w2_packed, bias2, relu2) chains a 1x1."""
+    require_cuda(x, 'conv2d')
+    if x.dtype != torch.float16 or not x.is_contiguous():
+        raise RuntimeError('conv2d_nhwc: x must be contiguous fp16 NHWC')
+    n, h, w_, c = x.shape
+    if c != cin:
+        raise RuntimeError('conv2d_nhwc: channel mismatch')
+    pad = ks // 2
+    oh = (h + 2 * pad - ks) // stride + 1
+    ow = (w_ + 2 * pad - ks) // stride + 1
+    d = _lib.ConvDesc(n, h, w_, cin, cout, ks, stride, int(bool(relu)), cout if tail else 0,
+                      int(bool(tail[2])) if tail else 0)
+    with torch.cuda.device(x.device):
+        if out is None:
+            out = torch.empty((n, oh, ow, cout), dtype=torch.float16, device=x.device)
+        check(lib().lfd_conv2d_nhwc_f16(C.byref(d), ptr(x), ptr(out), ptr(w_packed), ptr(bias), ptr(residual),
+                                        ptr(tail[0]) if tail else None, ptr(tail[1]) if tail else None,
+                                        ptr(zero_line(x.device)), stream_ptr()), 'lfd_conv2d_nhwc_f16')
+    return out
