@@ -176,6 +176,48 @@ LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, voi
                                 const void* tail_w_packed, const float* tail_bias,
                                 const void* zeros /* >=256 zero bytes */, lfd_stream_t stream);
 
+/* First stem unit: conv3x3 s2 (3 -> C) + BN + ReLU chained with conv1x1 (C -> C) + BN + ReLU
+ * (lfd_resnet.py:356-374 'fast' stem; first half of the 'faster' stem :376-395).
+ * in_format: 0 = NCHW fp32 (the tensor LFD.forward receives, lfd.py:511), 1 = NHWC fp16,
+ * 2 = NHWC uint8 with simple_normalize (x/255-0.5)/0.5 fused (augmentation_pipeline.py:31-36).
+ * w2_packed == NULL: no chained 1x1.  out: NHWC fp16 [n, (h+1)/2, (w+1)/2, channels]. */
+LFD_API int lfd_stem_conv_f16(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w,
+                              int32_t channels, const void* w1_packed, const float* b1,
+                              const void* w2_packed, const float* b2, void* out, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Neck + head of one pyramid level.  Replaces SimpleNeck.forward (simple_neck.py:67-74),
+ * LFDHead.forward (lfd_head.py:164-185, GroupNorm towers + cls/reg convs + Scale) and the
+ * NCHW -> [N,P,C] permute/concat of LFD.forward (lfd.py:526-542): writes fp32 cls / reg rows of
+ * this level directly at `point_offset` of the level-concatenated outputs.
+ * GroupNorm statistics are obtained by recomputing the chain (pass 1, 2) -- see csrc/head.hip.
+ *   pass 1: stats of tower conv1 -> `partial`;  lfd_groupnorm_finalize -> ab1
+ *   pass 2: stats of tower conv2 -> `partial`;  lfd_groupnorm_finalize -> ab2
+ *   pass 3: outputs.
+ * For a BatchNorm / no-norm head, skip passes 1-2 and pass the folded (scale, shift) as ab1/ab2. */
+typedef struct lfd_head_desc {
+  int32_t n, hw;            /* images, pixels of this level (h*w) */
+  int32_t cin;              /* backbone tap channels: 64 | 128 */
+  int32_t head_channels;    /* 128 */
+  int32_t num_groups;       /* GroupNorm groups (16) */
+  int32_t total_points;     /* P */
+  int32_t point_offset;     /* first point of this level */
+  int32_t cls_channels;     /* C' (row length of out_cls) */
+  int32_t final_cout;       /* valid rows of the final conv (<= 64) */
+  int32_t final_split;      /* rows [0,split) -> cls, [split, final_cout) -> reg */
+} lfd_head_desc_t;
+
+LFD_API size_t lfd_head_partial_floats(int32_t n, int32_t hw, int32_t num_groups);
+LFD_API int lfd_head_level_f16(const lfd_head_desc_t* desc, int32_t pass, const void* x,
+                               const void* wn_packed, const float* bn, const void* w1_packed,
+                               const void* w2_packed, const void* wf_packed, const float* bf,
+                               const float* ab1, const float* ab2, float* partial, float* out_cls,
+                               float* out_reg, const float* scale, const void* zeros,
+                               lfd_stream_t stream);
+LFD_API int lfd_groupnorm_finalize(const float* partial, int32_t n, int32_t hw, int32_t num_groups,
+                                   const float* gamma, const float* beta, float eps,
+                                   float* ab /*[n][128][2]*/, lfd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,217 @@
+// csrc/stem.hip -- first stem unit: conv3x3 stride 2 (Cin = 3) + BN + ReLU, chained in the same
+// kernel with the following conv1x1 + BN + ReLU (reference lfd/model/backbone/lfd_resnet.py
+// :356-374 'fast' stem, :376-395 first half of the 'faster' stem).
+//
+// The pair is the most HBM-heavy part of the network (its output is the largest activation:
+// 540x960x64 per 1080p image); unfused it moves 3.4x the bytes.  The 3x3 has K = 27, padded to
+// two MFMA k-steps; im2col is done from an LDS copy of the raw input tile (3 channels, 6 B per
+// pixel), the 64-channel intermediate goes straight through LDS into the 1x1's MFMAs.
+//
+// Input formats (template): NCHW fp32 (the reference's tensor API, LFD.forward(x), lfd.py:511),
+// NHWC fp16 (resident-in-HBM format of the bench), NHWC uint8 with the reference's
+// simple_normalize (x/255-0.5)/0.5 fused into the load (augmentation_pipeline.py:31-36).
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+enum { IN_NCHW_F32 = 0, IN_NHWC_F16 = 1, IN_NHWC_U8 = 2 };
+
+struct StemArgs {
+  const void* in;
+  _Float16* out;       // [N,OH,OW,C]
+  const half8* w1;     // [C/32][2][64] packed 3x3 (K=27 -> 32) fragments
+  const float* b1;     // [C]
+  const half8* w2;     // [C/32][C/16][64] packed 1x1 fragments (TAIL)
+  const float* b2;     // [C]
+  int N, H, W, OH, OW;
+  int tiles_x, tiles_y;
+};
+
+template <int FMT>
+__device__ __forceinline__ _Float16 load_px(const void* in, int n, int H, int W, int gy, int gx, int c) {
+  if (FMT == IN_NCHW_F32) {
+    return (_Float16) reinterpret_cast<const float*>(in)[(((size_t)n * 3 + c) * H + gy) * W + gx];
+  } else if (FMT == IN_NHWC_F16) {
+    return reinterpret_cast<const _Float16*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+  } else {
+    const float v = (float)reinterpret_cast<const uint8_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+    return (_Float16)((v / 255.f - 0.5f) / 0.5f);
+  }
+}
+
+// NCT = C/32 (1 or 2).  4 waves: ct = wave % NCT, pg = wave / NCT; each wave: 2 x 32 px x 32 ch.
+template <int NCT, int FMT, bool TAIL>
+__global__ __launch_bounds__(256) void k_stem(StemArgs a) {
+  constexpr int C = NCT * 32;
+  constexpr int PG = 4 / NCT, PT = 2, TW = 32, TH = PG * PT;
+  constexpr int IH = 2 * TH + 1, IW = 2 * TW + 1;
+  constexpr int RS = ((IW * 3 + 1) / 2) * 2;           // halfs per LDS input row (even)
+  constexpr int IN_HALFS = IH * RS + 8;
+  constexpr int MCPP = C / 8, MPIXB = C * 2, MPPR = 16 / MCPP;
+  __shared__ __attribute__((aligned(16))) _Float16 s_in[IN_HALFS];
+  __shared__ __attribute__((aligned(16))) char s_mid[TAIL ? (TH * TW * MPIXB) : 16];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ct = wave % NCT, pg = wave / NCT;
+  const int h = lane >> 5, pix = lane & 31;
+  const int t = blockIdx.x;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int n = t / tiles_per_img;
+  const int tr = t - n * tiles_per_img;
+  const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+  const int gy0 = ty0 * TH * 2 - 1, gx0 = tx0 * TW * 2 - 1;
+
+  // ---- stage the raw input tile (zero padded) into LDS
+  for (int i = threadIdx.x; i < IH * IW * 3; i += 256) {
+    const int iy = i / (IW * 3), e = i - iy * (IW * 3);
+    const int ix = e / 3, c = e - ix * 3;
+    const int gy = gy0 + iy, gx = gx0 + ix;
+    _Float16 v = (_Float16)0.f;
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_px<FMT>(a.in, n, a.H, a.W, gy, gx, c);
+    s_in[iy * RS + e] = v;
+  }
+  const half8 w1a = a.w1[(ct * 2 + 0) * 64 + lane], w1b = a.w1[(ct * 2 + 1) * 64 + lane];
+  half8 w2r[TAIL ? C / 16 : 1];
+  if (TAIL) {
+#pragma unroll
+    for (int q = 0; q < C / 16; ++q) w2r[q] = a.w2[(ct * (C / 16) + q) * 64 + lane];
+  }
+  __syncthreads();
+
+  f32x16 acc[PT];
+  {
+    const float* bp = a.b1 + ct * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y; acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
+      }
+    }
+  }
+  // ---- 3x3 s2: im2col fragments.  k-slots: step0 {h=0: row0 e0..7, h=1: row1 e0..7},
+  //      step1 {h=0: row2 e0..7, h=1: (row0 e8, row1 e8, row2 e8, 0 x5)},  e = 3*s + c.
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int oy = pg * PT + pt;
+    const _Float16* base = s_in + (2 * oy) * RS + 6 * pix;   // pixel (2*oy, 2*pix) channel 0
+    union { half8 v; uint32_t u[4]; } f0, f1;
+    {
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(base + h * RS);         // row h
+      f0.u[0] = p0[0]; f0.u[1] = p0[1]; f0.u[2] = p0[2]; f0.u[3] = p0[3];
+    }
+    if (h == 0) {
+      const uint32_t* p2 = reinterpret_cast<const uint32_t*>(base + 2 * RS);
+      f1.u[0] = p2[0]; f1.u[1] = p2[1]; f1.u[2] = p2[2]; f1.u[3] = p2[3];
+    } else {
+      const uint32_t e0 = reinterpret_cast<const uint32_t*>(base + 8)[0] & 0xffffu;
+      const uint32_t e1 = reinterpret_cast<const uint32_t*>(base + RS + 8)[0] & 0xffffu;
+      const uint32_t e2 = reinterpret_cast<const uint32_t*>(base + 2 * RS + 8)[0] & 0xffffu;
+      f1.u[0] = e0 | (e1 << 16); f1.u[1] = e2; f1.u[2] = 0u; f1.u[3] = 0u;
+    }
+    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1a, f0.v, acc[pt], 0, 0, 0);
+    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1b, f1.v, acc[pt], 0, 0, 0);
+  }
+
+  if (TAIL) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int pb = (pg * PT + pt) * 32 + pix;
+      const int fm = (pb / MPPR) % MCPP;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)fmaxf(acc[pt][4 * g + j], 0.f);
+        *reinterpret_cast<half4*>(s_mid + pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h) = v;
+      }
+    }
+    __syncthreads();
+    {
+      const float* bp = a.b2 + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y; acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < C / 16; ++q) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int pb = (pg * PT + pt) * 32 + pix;
+        const int fm = (pb / MPPR) % MCPP;
+        const half8 xf = *reinterpret_cast<const half8*>(s_mid + pb * MPIXB + (((2 * q + h) ^ fm) * 16));
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[q], xf, acc[pt], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int oy = ty0 * TH + pg * PT + pt, ox = tx0 * TW + pix;
+    if (oy < a.OH && ox < a.OW) {
+      _Float16* o = a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * C + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)fmaxf(acc[pt][4 * g + j], 0.f);
+        *reinterpret_cast<half4*>(o + 8 * g) = v;
+      }
+    }
+  }
+}
+
+template <int NCT, int FMT, bool TAIL>
+int launch_stem(StemArgs a, hipStream_t st) {
+  constexpr int PG = 4 / NCT, TH = PG * 2, TW = 32;
+  a.tiles_x = (a.OW + TW - 1) / TW;
+  a.tiles_y = (a.OH + TH - 1) / TH;
+  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+  if (ntiles > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((k_stem<NCT, FMT, TAIL>), dim3((unsigned)ntiles), dim3(256), 0, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+template <int NCT, bool TAIL>
+int dispatch_fmt(int fmt, const StemArgs& a, hipStream_t st) {
+  switch (fmt) {
+    case IN_NCHW_F32: return launch_stem<NCT, IN_NCHW_F32, TAIL>(a, st);
+    case IN_NHWC_F16: return launch_stem<NCT, IN_NHWC_F16, TAIL>(a, st);
+    case IN_NHWC_U8: return launch_stem<NCT, IN_NHWC_U8, TAIL>(a, st);
+    default: return LFD_ERR_INVALID_ARGUMENT;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfd_stem_conv_f16(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
+                      const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
+                      void* out, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!in || !w1_packed || !b1 || !out || n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (channels != 32 && channels != 64) return LFD_ERR_UNSUPPORTED;
+  StemArgs a{};
+  a.in = in; a.out = (_Float16*)out; a.w1 = (const half8*)w1_packed; a.b1 = b1;
+  a.w2 = (const half8*)w2_packed; a.b2 = b2;
+  a.N = n; a.H = h; a.W = w; a.OH = (h + 2 - 3) / 2 + 1; a.OW = (w + 2 - 3) / 2 + 1;
+  const bool tail = w2_packed != nullptr;
+  if (tail && !b2) return LFD_ERR_INVALID_ARGUMENT;
+  if (channels == 64) return tail ? dispatch_fmt<2, true>(in_format, a, st) : dispatch_fmt<2, false>(in_format, a, st);
+  return tail ? dispatch_fmt<1, true>(in_format, a, st) : dispatch_fmt<1, false>(in_format, a, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""Named model configurations = the model sections of the reference's config scripts
+(`prepare_model()` in WIDERFACE_train/WIDERFACE_LFD_{L,M,S,XS}.py:76-158 and
+TT100K_train/TT100K_LFD_{L,S}.py:76-157), expressed as plain kwargs so the same dict drives
+this package's modules, the oracle (oracle/net_oracle.py `arch`) and the reference modules
+(tests/golden/make_golden.py).
+"""
+import torch
+
+WIDERFACE_RANGES = ((4, 20), (20, 40), (40, 80), (80, 160), (160, 320))      # WIDERFACE_LFD_S.py:134
+TT100K_RANGES = ((4, 32), (32, 64), (64, 128), (128, 256))                   # TT100K_LFD_L.py:131
+
+
+def _wf(stem_mode, stem_channels, body_architecture, body_channels, out_indices):
+    return dict(block_mode='faster', stem_mode=stem_mode, stem_channels=stem_channels,
+                body_architecture=body_architecture, body_channels=body_channels, out_indices=out_indices,
+                num_neck_channels=128, num_classes=1, num_head_channels=128, num_conv_layers=2, conv_kernel_size=1,
+                gn_groups=16, share_head_flag=True, merge_path_flag=True, classification_loss_type='FocalLoss',
+                regression_loss_type='IoULoss', regression_ranges=WIDERFACE_RANGES, gray_range_factors=(0.9, 1.1),
+                range_assign_mode='dist', distance_to_bbox_mode='sigmoid')
+
+
+def _tt(body_architecture, body_channels, out_indices):
+    return dict(block_mode='faster', stem_mode='fast', stem_channels=64, body_architecture=body_architecture,
+                body_channels=body_channels, out_indices=out_indices, num_neck_channels=128, num_classes=45,
+                num_head_channels=128, num_conv_layers=2, conv_kernel_size=1, gn_groups=16, share_head_flag=True,
+                merge_path_flag=False, classification_loss_type='CrossEntropyLoss', regression_loss_type='IoULoss',
+                regression_ranges=TT100K_RANGES, gray_range_factors=(0.9, 1.1), range_assign_mode='longer',
+                distance_to_bbox_mode='sigmoid')
+
+
+ARCHS = {
+    'WIDERFACE_LFD_L': _wf('fast', 64, [4, 2, 2, 1, 1], [64, 64, 64, 128, 128], ((0, 3), (1, 1), (2, 1), (3, 0), (4, 0))),
+    'WIDERFACE_LFD_M': _wf('fast', 64, [3, 2, 1, 1, 1], [64, 64, 64, 128, 128], ((0, 2), (1, 1), (2, 0), (3, 0), (4, 0))),
+    'WIDERFACE_LFD_S': _wf('faster', 64, [4, 2, 2, 3], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 1), (3, 0), (3, 2))),
+    'WIDERFACE_LFD_XS': _wf('faster', 32, [4, 2, 2, 3], [64, 64, 64, 64], ((0, 3), (1, 1), (2, 1), (3, 0), (3, 2))),
+    'TT100K_LFD_L': _tt([5, 3, 2, 2], [64, 64, 128, 128], ((0, 4), (1, 2), (2, 1), (3, 1))),
+    'TT100K_LFD_S': _tt([4, 2, 1, 1], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 0), (3, 0))),
+}
+
+
+def build_modules(arch, backbone_cls, neck_cls, head_cls, lfd_cls, focal_cls, iou_cls, ce_cls, seed=666):
+    """Instantiates (backbone, neck, head, LFD) from `arch` with the given classes (this package's
+    or the reference's -- identical kwargs), under torch.manual_seed(seed) (= the config seed,
+    WIDERFACE_LFD_S.py:51)."""
+    torch.manual_seed(seed)
+    if arch['classification_loss_type'] == 'CrossEntropyLoss':
+        cls_loss = ce_cls(reduction='mean', loss_weight=1.0)
+    else:
+        cls_loss = focal_cls(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0)
+    reg_loss = iou_cls(eps=1e-6, reduction='mean', loss_weight=1.0)
+    bb = backbone_cls(block_mode=arch['block_mode'], stem_mode=arch['stem_mode'], body_mode=None, input_channels=3,
+                      stem_channels=arch['stem_channels'], body_architecture=list(arch['body_architecture']),
+                      body_channels=list(arch['body_channels']), out_indices=arch['out_indices'], frozen_stages=-1,
+                      activation_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='BatchNorm2d'),
+                      init_with_weight_file=None, norm_eval=False)
+    neck = neck_cls(num_neck_channels=arch['num_neck_channels'], num_input_channels_list=bb.num_output_channels_list,
+                    num_input_strides_list=bb.num_output_strides_list, norm_cfg=dict(type='BatchNorm2d'),
+                    activation_cfg=dict(type='ReLU', inplace=True))
+    head = head_cls(num_classes=arch['num_classes'], num_heads=len(neck.num_output_strides_list),
+                    num_input_channels=arch['num_neck_channels'], num_head_channels=arch['num_head_channels'],
+                    num_conv_layers=arch['num_conv_layers'], activation_cfg=dict(type='ReLU', inplace=True),
+                    norm_cfg=dict(type='GroupNorm', num_groups=arch['gn_groups']),
+                    share_head_flag=arch['share_head_flag'], merge_path_flag=arch['merge_path_flag'],
+                    classification_loss_type=type(cls_loss).__name__, regression_loss_type=type(reg_loss).__name__)
+    model = lfd_cls(backbone=bb, neck=neck, head=head, num_classes=arch['num_classes'],
+                    regression_ranges=arch['regression_ranges'], gray_range_factors=arch['gray_range_factors'],
+                    range_assign_mode=arch['range_assign_mode'], point_strides=neck.num_output_strides_list,
+                    classification_loss_func=cls_loss, regression_loss_func=reg_loss,
+                    distance_to_bbox_mode=arch['distance_to_bbox_mode'])
+    return model
+
+
+def build_model(name_or_arch, seed=666):
+    """This package's LFD for a named configuration."""
+    from .model.backbone import LFDResNet
+    from .model.head import LFDHead
+    from .model.lfd import LFD
+    from .model.losses import CrossEntropyLoss, FocalLoss, IoULoss
+    from .model.neck import SimpleNeck
+    arch = ARCHS[name_or_arch] if isinstance(name_or_arch, str) else name_or_arch
+    return build_modules(arch, LFDResNet, SimpleNeck, LFDHead, LFD, FocalLoss, IoULoss, CrossEntropyLoss, seed)
+
+
+def perturb_weights(model, seed=1):
+    """Synthetic, non-degenerate weights (there are no downloadable checkpoints offline): fresh
+    init has gamma=1, beta=0, mean=0, var=1 and head std 0.01, which would hide BN-fold /
+    GroupNorm / Scale bugs and give near-constant logits.  Deterministic given the state_dict key
+    order: BN running_mean~N(0,.1), running_var~U(.5,1.5); every norm weight~U(.5,1.5),
+    bias~N(0,.1); Scale~U(.8,1.2); head conv weights re-drawn with std 0.1."""
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    seen = set()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if v.data_ptr() in seen:     # shared head: duplicated keys alias one tensor
+                continue
+            seen.add(v.data_ptr())
+            is_norm = (k.endswith('running_mean') or k.endswith('running_var') or
+                       (v.dim() == 1 and ('_norm' in k or '_stem.' in k or '_downsample.1' in k or
+                                          k.split('.')[-2].isdigit() and not k.endswith('num_batches_tracked'))))
+            if k.endswith('num_batches_tracked'):
+                continue
+            if k.endswith('running_mean'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith('running_var'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith('_scale'):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.4 + 0.8)
+            elif v.dim() == 1 and k.endswith('.weight'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif v.dim() == 1 and k.endswith('.bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif v.dim() == 4 and k.startswith('_head.'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            del is_norm
+    return model

@@ -1,0 +1,480 @@
+"""Inference engine: turns an `LFD` (or a bare `LFDResNet`) module tree into a plan of gfx950
+kernel launches behind the C ABI and runs it on the current HIP stream.
+
+Host-side responsibilities only (tensor plumbing, no arithmetic on activations):
+  * fold eval-mode BatchNorm into conv weights / bias (fp32, once per parameter version);
+  * re-pack OIHW fp32 weights into MFMA fragment order, fp16 (ops.pack_conv_weight);
+  * allocate NHWC fp16 activation buffers per input shape and keep them resident;
+  * order the launches: stem pair -> [stem pair 2] -> residual blocks -> per-level neck+head
+    (3 GroupNorm-recompute passes), outputs written directly as [N, P, C'] / [N, P, 4] fp32;
+  * optionally capture the whole forward in a HIP graph (torch.cuda.CUDAGraph as the graph
+    plumbing) so a forward is one replay (~55 launches -> one submission).
+
+Unsupported module configurations raise RuntimeError: there is no PyTorch fallback for
+inference (the reference's own cuDNN path is what this replaces).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import check, lib, ptr, stream_ptr
+
+IN_NCHW_F32, IN_NHWC_F16, IN_NHWC_U8 = 0, 1, 2
+_UNION = ('IoULoss', 'GIoULoss', 'DIoULoss', 'CIoULoss')
+
+
+def _unsupported(msg):
+    raise RuntimeError('lfd_amd engine: unsupported configuration: %s (no PyTorch fallback for inference)' % msg)
+
+
+# ---------------------------------------------------------------------------- weight preparation
+def fold_conv_norm(conv, norm):
+    """(conv, eval-mode BatchNorm2d | None) -> (weight fp32 OIHW, bias fp32)."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if norm is None:
+        return w, b
+    if not isinstance(norm, nn.BatchNorm2d):
+        _unsupported('only BatchNorm2d can be folded into a backbone/neck conv (got %s)' % type(norm).__name__)
+    inv = (norm.running_var.detach().double() + norm.eps).rsqrt()
+    g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(inv)
+    beta = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(inv)
+    s = g * inv
+    w = (w.double() * s.view(-1, 1, 1, 1)).float()
+    b = ((b.double() - norm.running_mean.detach().double()) * s + beta).float()
+    return w, b
+
+
+def pack_stem_weight(w):
+    """[C,3,3,3] -> [C/32][2][64][8] fp16 in the k-slot order of csrc/stem.hip:
+    step0: half0 = row0 e0..7, half1 = row1 e0..7; step1: half0 = row2 e0..7,
+    half1 = (row0 e8, row1 e8, row2 e8, 0 x5);  e = 3*s + c."""
+    c = w.shape[0]
+    assert w.shape[1:] == (3, 3, 3) and c % 32 == 0
+    wr = w.detach().float().permute(0, 2, 3, 1).reshape(c, 3, 9)      # [co][r][e = 3*s + c]
+    out = torch.zeros(c // 32, 2, 2, 32, 8, dtype=torch.float32, device=w.device)  # [tile][step][half][co_l][j]
+    wt = wr.reshape(c // 32, 32, 3, 9)
+    out[:, 0, 0, :, :] = wt[:, :, 0, :8]
+    out[:, 0, 1, :, :] = wt[:, :, 1, :8]
+    out[:, 1, 0, :, :] = wt[:, :, 2, :8]
+    out[:, 1, 1, :, 0] = wt[:, :, 0, 8]
+    out[:, 1, 1, :, 1] = wt[:, :, 1, 8]
+    out[:, 1, 1, :, 2] = wt[:, :, 2, 8]
+    return out.reshape(c // 32, 2, 64, 8).half().contiguous()
+
+
+def _pad_rows(w, b, rows):
+    """pad a [cout, cin, 1, 1] conv (and bias) with zero rows up to `rows`."""
+    cout = w.shape[0]
+    if cout == rows:
+        return w, b
+    wp = torch.zeros((rows,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    bp = torch.zeros(rows, dtype=b.dtype, device=b.device)
+    wp[:cout] = w
+    bp[:cout] = b
+    return wp, bp
+
+
+def _tail_supported(cin, cout, ks, stride):
+    """chained-1x1 instantiations compiled in csrc/conv.hip"""
+    return ks == 3 and stride == 2 and cin == cout and cin in (32, 64)
+
+
+class _Conv(object):
+    """one lfd_conv2d_nhwc_f16 launch"""
+    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res')
+
+
+class _HeadLevel(object):
+    __slots__ = ('cin', 'src', 'wn', 'bn', 'towers', 'hw', 'p_off')
+
+
+class _Tower(object):
+    __slots__ = ('w1', 'w2', 'wf', 'bf', 'norm1', 'norm2', 'fcout', 'split', 'scale', 'ab1', 'ab2', 'static_ab')
+
+
+# ---------------------------------------------------------------------------- plan
+class EnginePlan(object):
+    """Compiled launch plan for one (module tree, parameter version)."""
+
+    def __init__(self, backbone, neck=None, head=None, device=None):
+        self.device = device
+        self.backbone = backbone
+        self.neck = neck
+        self.head = head
+        self.param_sig = _param_signature(backbone, neck, head)
+        self._shape_cache = {}
+        self._build_backbone()
+        if head is not None:
+            self._build_head()
+
+    # ---- backbone
+    def _build_backbone(self):
+        bb = self.backbone
+        dev = self.device
+        if bb._input_channels != 3:
+            _unsupported('input_channels != 3')
+        if bb._norm_cfg is not None and bb._norm_cfg['type'] != 'BatchNorm2d':
+            _unsupported('backbone norm must be BatchNorm2d (or None)')
+        if type(bb._stem[2 if bb._norm_cfg is not None else 1]).__name__ != 'ReLU':
+            _unsupported('activation must be ReLU')
+        has_norm = bb._norm_cfg is not None
+        step = 3 if has_norm else 2
+        stem_convs = []
+        for i, (k, s, cin, cout) in enumerate(bb.stem_spec()):
+            conv = bb._stem[i * step]
+            norm = bb._stem[i * step + 1] if has_norm else None
+            stem_convs.append((k, s, cin, cout) + fold_conv_norm(conv, norm))
+        self.stem_first = None   # (C, w1, b1, w2|None, b2|None)
+        self.convs = []          # list of _Conv over symbolic buffer ids
+        nbuf = [0]
+
+        def new_buf():
+            nbuf[0] += 1
+            return nbuf[0] - 1
+
+        k, s, cin, c0, w, b = stem_convs[0]
+        if c0 not in (32, 64):
+            _unsupported('first stem conv must have 32 or 64 output channels')
+        idx = 1
+        if len(stem_convs) > 1 and stem_convs[1][0] == 1:   # 'fast' / 'faster': chained 1x1
+            _, _, _, c1, w2, b2 = stem_convs[1]
+            if c1 != c0:
+                _unsupported('stem 1x1 must keep the channel count')
+            self.stem_first = (c0, pack_stem_weight(w).to(dev), b.to(dev), ops.pack_conv_weight(w2).to(dev), b2.to(dev))
+            idx = 2
+        else:
+            self.stem_first = (c0, pack_stem_weight(w).to(dev), b.to(dev), None, None)
+        cur = new_buf()
+        self.stem_out = cur
+        self.buf_channels = {cur: c0}
+        self.buf_scale = {cur: 2}      # spatial stride of each buffer w.r.t. the input
+        while idx < len(stem_convs):
+            k, s, cin, cout, w, b = stem_convs[idx]
+            tail = None
+            if (idx + 1 < len(stem_convs) and stem_convs[idx + 1][0] == 1 and stem_convs[idx + 1][3] == cout and
+                    _tail_supported(cin, cout, k, s)):
+                _, _, _, _, w2, b2 = stem_convs[idx + 1]
+                tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True)
+                idx += 1
+            cur = self._add_conv(cur, new_buf, cin, cout, k, s, True, w, b, tail=tail)
+            idx += 1
+        # ---- stages
+        self.taps = []
+        for i, nblk in enumerate(bb._body_architecture):
+            for j in range(nblk):
+                blk = getattr(bb, 'stage%d' % i)[j]
+                x_in = cur
+                ident = x_in
+                if blk._downsample is not None:
+                    dconv = blk._downsample[0]
+                    dnorm = blk._downsample[1] if len(blk._downsample) > 1 else None
+                    w, b = fold_conv_norm(dconv, dnorm)
+                    ident = self._add_conv(x_in, new_buf, dconv.in_channels, dconv.out_channels, 1, 2, False, w, b)
+                nconv = blk.num_convs
+                y = x_in
+                ci = 1
+                while ci <= nconv:
+                    conv = getattr(blk, '_conv%d' % ci)
+                    norm = getattr(blk, '_norm%d' % ci, None)
+                    w, b = fold_conv_norm(conv, norm)
+                    last = ci == nconv
+                    tail = None
+                    if (not last) and ci + 1 < nconv:
+                        nxt = getattr(blk, '_conv%d' % (ci + 1))
+                        if (nxt.kernel_size[0] == 1 and nxt.out_channels == conv.out_channels and
+                                _tail_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0])):
+                            w2, b2 = fold_conv_norm(nxt, getattr(blk, '_norm%d' % (ci + 1), None))
+                            tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True)   # FastBlock 3x3 -> 1x1
+                    y = self._add_conv(y, new_buf, conv.in_channels, conv.out_channels, conv.kernel_size[0],
+                                       conv.stride[0], True, w, b, tail=tail, res=ident if last else None)
+                    ci += 2 if tail is not None else 1
+                cur = y
+                if (i, j) in [tuple(t) for t in bb._out_indices]:
+                    self.taps.append(cur)
+        self.num_bufs = nbuf[0]
+
+    def _add_conv(self, src, new_buf, cin, cout, ks, stride, relu, w, b, tail=None, res=None):
+        c = _Conv()
+        c.cin, c.cout, c.ks, c.stride, c.relu = cin, cout, ks, stride, relu
+        c.w = ops.pack_conv_weight(w).to(self.device)
+        c.b = b.to(self.device).contiguous()
+        c.tail = tail
+        c.src = src
+        c.dst = new_buf()
+        c.res = res
+        self.buf_channels[c.dst] = cout
+        self.buf_scale[c.dst] = self.buf_scale[src] * stride
+        self.convs.append(c)
+        return c.dst
+
+    # ---- neck + head
+    def _build_head(self):
+        neck, head, dev = self.neck, self.head, self.device
+        if neck._num_neck_channels != 128 or head._num_head_channels != 128 or head._num_input_channels != 128:
+            _unsupported('neck / head channels must be 128')
+        if head._num_conv_layers != 2 or head._conv_kernel_size != 1:
+            _unsupported('head towers must be 2 x conv1x1')
+        if neck._norm_cfg is not None and neck._norm_cfg['type'] != 'BatchNorm2d':
+            _unsupported('neck norm must be BatchNorm2d')
+        ncfg = head._norm_cfg
+        self.head_groups = 16
+        if ncfg is not None and ncfg['type'] == 'GroupNorm':
+            self.head_groups = int(ncfg['num_groups'])
+            g = 128 // self.head_groups
+            if g * self.head_groups != 128 or (g & (g - 1)) or g > 32:
+                _unsupported('GroupNorm group size must be a power of two <= 32')
+        self.head_gn = ncfg is not None and ncfg['type'] == 'GroupNorm'
+        union = head._regression_loss_type in _UNION
+        cc = head.num_cls_channels
+        self.cls_channels = cc
+        has_norm = ncfg is not None
+        lstep = 3 if has_norm else 2
+        self.levels = []
+        for i in range(head._num_heads):
+            lv = _HeadLevel()
+            nseq = getattr(neck, 'neck%d' % i)
+            nconv = nseq[0]
+            wn, bn = fold_conv_norm(nconv, nseq[1] if neck._norm_cfg is not None else None)
+            lv.cin = nconv.in_channels
+            if lv.cin not in (64, 128):
+                _unsupported('backbone tap channels must be 64 or 128')
+            lv.wn = ops.pack_conv_weight(wn).to(dev)
+            lv.bn = bn.to(dev)
+            lv.src = self.taps[i]
+            cls_path = getattr(head, 'head%d_classification_path' % i)
+            reg_path = getattr(head, 'head%d_regression_path' % i)
+            merge_path = getattr(head, 'head%d_merge_path' % i)
+            scale = head._scales[i]._scale if union else None
+            towers = []
+
+            def make_tower(seq, final_w, final_b, fcout, split, scale_p):
+                t = _Tower()
+                c1, c2 = seq[0], seq[lstep]
+                t.w1 = ops.pack_conv_weight(c1.weight.detach().float()).to(dev)
+                t.w2 = ops.pack_conv_weight(c2.weight.detach().float()).to(dev)
+                t.norm1 = seq[1] if has_norm else None
+                t.norm2 = seq[lstep + 1] if has_norm else None
+                t.static_ab = None
+                if not self.head_gn:   # BatchNorm / no norm: per-channel affine known ahead of time
+                    t.static_ab = [self._static_affine(c1, t.norm1), self._static_affine(c2, t.norm2)]
+                rows = ((fcout + 31) // 32) * 32
+                fw, fb = _pad_rows(final_w, final_b, rows)
+                t.wf = ops.pack_conv_weight(fw).to(dev)
+                t.bf = fb.to(dev).contiguous()
+                t.fcout, t.split, t.scale = fcout, split, scale_p
+                return t
+
+            if head._merge_path_flag:
+                cconv, rconv = cls_path[0], reg_path[0]
+                fw = torch.cat([cconv.weight.detach().float(), rconv.weight.detach().float()], 0)
+                fb = torch.cat([cconv.bias.detach().float(), rconv.bias.detach().float()], 0)
+                if cc + 4 > 64:
+                    _unsupported('num classes + 4 > 64 with a merged head')
+                towers.append(make_tower(merge_path, fw, fb, cc + 4, cc, scale))
+            else:
+                cconv, rconv = cls_path[2 * lstep], reg_path[2 * lstep]
+                if cc > 64:
+                    _unsupported('more than 64 classification channels')
+                towers.append(make_tower(cls_path, cconv.weight.detach().float(), cconv.bias.detach().float(), cc, cc, None))
+                towers.append(make_tower(reg_path, rconv.weight.detach().float(), rconv.bias.detach().float(), 4, 0, scale))
+            lv.towers = towers
+            self.levels.append(lv)
+
+    @staticmethod
+    def _static_affine(conv, norm):
+        """(scale, shift)[128] applied after a tower conv when the norm is BatchNorm2d or absent."""
+        c = conv.out_channels
+        dev = conv.weight.device
+        bias = conv.bias.detach().double() if conv.bias is not None else torch.zeros(c, dtype=torch.double, device=dev)
+        if norm is None:
+            return torch.ones(c, dtype=torch.double, device=dev), bias
+        inv = (norm.running_var.detach().double() + norm.eps).rsqrt()
+        s = norm.weight.detach().double() * inv
+        return s, (bias - norm.running_mean.detach().double()) * s + norm.bias.detach().double()
+
+    # ---- shape-dependent state
+    def state_for(self, n, h, w):
+        key = (n, h, w)
+        st = self._shape_cache.get(key)
+        if st is None:
+            st = _ShapeState(self, n, h, w)
+            self._shape_cache[key] = st
+        return st
+
+    # ---- execution
+    def run_backbone(self, x, fmt, st):
+        c0, w1, b1, w2, b2 = self.stem_first
+        l = lib()
+        sp = stream_ptr()
+        check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                  ptr(st.bufs[self.stem_out]), sp), 'lfd_stem_conv_f16')
+        z = ops.zero_line(self.device)
+        for c in self.convs:
+            src = st.bufs[c.src]
+            d = _lib.ConvDesc(st.n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
+                              c.cout if c.tail else 0, 1 if c.tail else 0)
+            check(l.lfd_conv2d_nhwc_f16(C.byref(d), ptr(src), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b),
+                                        ptr(st.bufs[c.res]) if c.res is not None else None,
+                                        ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,
+                                        ptr(z), sp), 'lfd_conv2d_nhwc_f16')
+
+    def run_head(self, st):
+        l = lib()
+        sp = stream_ptr()
+        z = ops.zero_line(self.device)
+        for li, lv in enumerate(self.levels):
+            x = st.bufs[lv.src]
+            hw = x.shape[1] * x.shape[2]
+            for ti, t in enumerate(lv.towers):
+                d = _lib.HeadDesc(st.n, hw, lv.cin, 128, self.head_groups, st.P, st.p_off[li], self.cls_channels,
+                                  t.fcout, t.split)
+                ab1, ab2 = st.ab[li][ti]
+                if self.head_gn:
+                    for p, (norm, ab) in enumerate(((t.norm1, ab1), (t.norm2, ab2)), start=1):
+                        check(l.lfd_head_level_f16(C.byref(d), p, ptr(x), ptr(lv.wn), ptr(lv.bn), ptr(t.w1), ptr(t.w2),
+                                                   None, None, ptr(ab1), None, ptr(st.partial), None, None, None,
+                                                   ptr(z), sp), 'lfd_head_level_f16(pass %d)' % p)
+                        check(l.lfd_groupnorm_finalize(ptr(st.partial), st.n, hw, self.head_groups, ptr(norm.weight),
+                                                       ptr(norm.bias), float(norm.eps), ptr(ab), sp),
+                              'lfd_groupnorm_finalize')
+                check(l.lfd_head_level_f16(C.byref(d), 3, ptr(x), ptr(lv.wn), ptr(lv.bn), ptr(t.w1), ptr(t.w2),
+                                           ptr(t.wf), ptr(t.bf), ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg),
+                                           ptr(t.scale) if t.scale is not None else None, ptr(z), sp),
+                      'lfd_head_level_f16(pass 3)')
+
+
+class _ShapeState(object):
+    """Activation buffers and outputs for one input shape."""
+
+    def __init__(self, plan, n, h, w):
+        dev = plan.device
+        self.n, self.h, self.w = n, h, w
+        self.bufs = {}
+        with torch.cuda.device(dev):
+            dims = {}
+            for b, sc in plan.buf_scale.items():
+                hh, ww = h, w
+                s = sc
+                while s > 1:
+                    hh, ww = (hh + 1) // 2, (ww + 1) // 2   # conv k3 p1 s2 and k1 p0 s2 agree: ceil(x/2)
+                    s //= 2
+                dims[b] = (hh, ww)
+                self.bufs[b] = torch.empty((n, hh, ww, plan.buf_channels[b]), dtype=torch.float16, device=dev)
+            self.dims = dims
+            if plan.head is not None:
+                self.sizes = [dims[t] for t in plan.taps]
+                self.p_off = []
+                p = 0
+                for (hh, ww) in self.sizes:
+                    self.p_off.append(p)
+                    p += hh * ww
+                self.P = p
+                self.cls = torch.empty((n, p, plan.cls_channels), dtype=torch.float32, device=dev)
+                self.reg = torch.empty((n, p, 4), dtype=torch.float32, device=dev)
+                maxhw = max(hh * ww for hh, ww in self.sizes)
+                self.partial = torch.empty(int(lib().lfd_head_partial_floats(n, maxhw, plan.head_groups)),
+                                           dtype=torch.float32, device=dev)
+                self.ab = []
+                for lv in plan.levels:
+                    per = []
+                    for t in lv.towers:
+                        if t.static_ab is not None:
+                            abs_ = []
+                            for s, sh in t.static_ab:
+                                abs_.append(torch.stack([s, sh], -1).float()[None].expand(n, 128, 2).contiguous().to(dev))
+                            per.append(tuple(abs_))
+                        else:
+                            per.append((torch.empty((n, 128, 2), dtype=torch.float32, device=dev),
+                                        torch.empty((n, 128, 2), dtype=torch.float32, device=dev)))
+                    self.ab.append(per)
+        self.graph = None
+        self.graph_input = None
+
+
+def _param_signature(*mods):
+    sig = []
+    for m in mods:
+        if m is None:
+            continue
+        for t in list(m.parameters()) + list(m.buffers()):
+            sig.append((t.data_ptr(), t._version))
+    return tuple(sig)
+
+
+# ---------------------------------------------------------------------------- entry points
+def get_plan(owner, backbone, neck, head, device):
+    """Plan cache on `owner` keyed by device; rebuilt when any parameter/buffer changed
+    (in-place update bumps tensor._version; .to()/.cuda() changes data_ptr)."""
+    cache = owner.__dict__.setdefault('_lfd_engine_cache', {})
+    key = (device.type, device.index)
+    plan = cache.get(key)
+    sig = _param_signature(backbone, neck, head)
+    if plan is None or plan.param_sig != sig:
+        with torch.no_grad():
+            plan = EnginePlan(backbone, neck, head, device)
+        cache[key] = plan
+    return plan
+
+
+def _input_format(x):
+    if x.dim() != 4:
+        raise RuntimeError('expected a 4-D image batch')
+    if x.dtype == torch.float32 and x.shape[1] == 3:
+        return IN_NCHW_F32, x.shape[0], x.shape[2], x.shape[3]
+    if x.dtype == torch.float16 and x.shape[3] == 3:
+        return IN_NHWC_F16, x.shape[0], x.shape[1], x.shape[2]
+    if x.dtype == torch.uint8 and x.shape[3] == 3:
+        return IN_NHWC_U8, x.shape[0], x.shape[1], x.shape[2]
+    raise RuntimeError('unsupported input: NCHW float32 [N,3,H,W], NHWC float16 [N,H,W,3] or NHWC uint8 [N,H,W,3]')
+
+
+def lfd_forward(model, x, use_graph=False):
+    """Full LFD forward on the engine.  Returns (cls [N,P,C'] fp32, reg [N,P,4] fp32, sizes).
+    The returned tensors are engine-owned buffers, overwritten by the next forward of the same
+    input shape (clone() to keep them)."""
+    _lib.require_cuda(x, 'LFD.forward')
+    if not x.is_contiguous():
+        x = x.contiguous()
+    fmt, n, h, w = _input_format(x)
+    plan = get_plan(model, model._backbone, model._neck, model._head, x.device)
+    st = plan.state_for(n, h, w)
+    with torch.cuda.device(x.device):
+        if use_graph:
+            _run_graphed(plan, st, x, fmt)
+        else:
+            plan.run_backbone(x, fmt, st)
+            plan.run_head(st)
+    return st.cls, st.reg, st.sizes
+
+
+def _run_graphed(plan, st, x, fmt):
+    if st.graph is None or st.graph_input[1] != fmt:
+        static_in = torch.empty_like(x)
+        static_in.copy_(x)
+        # warm-up outside capture (sets kernel attributes, sizes workspaces)
+        plan.run_backbone(static_in, fmt, st)
+        plan.run_head(st)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            plan.run_backbone(static_in, fmt, st)
+            plan.run_head(st)
+        st.graph, st.graph_input = g, (static_in, fmt)
+    if st.graph_input[0].data_ptr() != x.data_ptr():
+        st.graph_input[0].copy_(x)
+    st.graph.replay()
+
+
+def backbone_only_forward(backbone, x):
+    """LFDResNet.forward stand-alone: tuple of tapped maps as NCHW fp32 (reference return type,
+    lfd_resnet.py:488-501).  The layout/precision conversion is plain tensor plumbing."""
+    _lib.require_cuda(x, 'LFDResNet.forward')
+    fmt, n, h, w = _input_format(x.contiguous())
+    plan = get_plan(backbone, backbone, None, None, x.device)
+    st = plan.state_for(n, h, w)
+    with torch.cuda.device(x.device):
+        plan.run_backbone(x.contiguous(), fmt, st)
+    return tuple(st.bufs[t].permute(0, 3, 1, 2).float() for t in plan.taps)

@@ -1,3 +1,6 @@
 from .backbone import *   # noqa: F401,F403
 from .neck import *       # noqa: F401,F403
 from .head import *       # noqa: F401,F403
+from .losses import *     # noqa: F401,F403
+from .utils import *      # noqa: F401,F403
+from .lfd import LFD      # noqa: F401
