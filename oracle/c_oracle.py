@@ -71,6 +71,8 @@ def multiclass_nms(boxes, scores, score_thr, iou_thr, class_agnostic=False, max_
                                         C.c_float(score_thr), C.c_float(iou_thr),
                                         C.c_int(int(class_agnostic)), C.c_int64(max_num),
                                         _p(dets), _p(labels), _p(cand), C.byref(nc))
+    if nc.value == 0:   # empty-candidate early return: (bboxes[0,4], labels[0]), not [0,5]  (nms.py:207-212)
+        return np.zeros((0, 4), np.float32), labels[:0].copy(), cand[:0].copy(), 0
     return dets[:k].copy(), labels[:k].copy(), cand[:k].copy(), int(nc.value)
 
 

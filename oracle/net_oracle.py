@@ -332,3 +332,85 @@ def lfd_loss(arch, cls, reg, sizes, strides, gt_bboxes_list, gt_labels_list):
     return dict(loss=float(cls_loss + reg_loss), classification_loss=float(cls_loss),
                 regression_loss=float(reg_loss), n_pos=int(pos.nelement()), n_green=int(green.nelement()),
                 cls_targets=cls_t, reg_targets=reg_t, labels=label, green=green, pos=pos)
+
+
+# ---------------------------------------------------------------- fp16-storage emulation
+def _h(t):
+    """round-trip through fp16 (the engine's inter-layer storage type)"""
+    return t.half().float()
+
+
+def _fold(sd, conv, norm):
+    w = sd[conv + '.weight'].double()
+    b = sd[conv + '.bias'].double() if (conv + '.bias') in sd else torch.zeros(w.shape[0], dtype=torch.double)
+    if norm is not None:
+        s = sd[norm + '.weight'].double() * (sd[norm + '.running_var'].double() + BN_EPS).rsqrt()
+        w = w * s.view(-1, 1, 1, 1)
+        b = (b - sd[norm + '.running_mean'].double()) * s + sd[norm + '.bias'].double()
+    return _h(w.float()), b.float()
+
+
+def lfd_forward_fp16(sd, arch, x):
+    """Same network as lfd_forward but with the ENGINE's numerics emulated on the CPU: BatchNorm
+    folded, weights rounded to fp16, fp32 accumulation, activations rounded to fp16 at every
+    fused-unit boundary (after each conv(+residual)+ReLU, the downsample branch, the neck and the
+    GroupNorm+ReLU outputs); GroupNorm statistics and the final cls/reg convs stay fp32.
+    Gate G2 of SURVEY 8d: the HIP path must match THIS within accumulation-order noise."""
+    pf = '_backbone.'
+    seq = {'fast': [(0, 1, 2, 1), (3, 4, 1, 0)], 'faster': [(0, 1, 2, 1), (3, 4, 1, 0), (6, 7, 2, 1), (9, 10, 1, 0)],
+           'fastest': [(0, 1, 2, 1), (3, 4, 2, 1)]}[arch['stem_mode']]
+    y = _h(x)
+    for ci, ni, s, p in seq:
+        w, b = _fold(sd, f'{pf}_stem.{ci}', f'{pf}_stem.{ni}')
+        y = _h(F.relu(F.conv2d(y, w, b, stride=s, padding=p)))
+    feats = []
+    oi = sorted(tuple(t) for t in arch['out_indices'])
+    for i in range(max(s for s, _ in oi) + 1):
+        for j in range(arch['body_architecture'][i]):
+            bl = f'{pf}stage{i}.{j}.'
+            stride = 2 if j == 0 else 1
+            ident = y
+            if j == 0:
+                w, b = _fold(sd, bl + '_downsample.0', bl + '_downsample.1')
+                ident = _h(F.conv2d(y, w, b, stride=2))
+            nconv = 3 if arch['block_mode'] == 'fast' else 2
+            o = y
+            for c in range(1, nconv + 1):
+                w, b = _fold(sd, bl + f'_conv{c}', bl + f'_norm{c}')
+                k = w.shape[-1]
+                o = F.conv2d(o, w, b, stride=stride if c == 1 else 1, padding=k // 2)
+                if c < nconv:
+                    o = _h(F.relu(o))
+            y = _h(F.relu(o + ident))
+            if (i, j) in oi:
+                feats.append(y)
+    G = arch['gn_groups']
+    cls_l, reg_l = [], []
+    for i, f in enumerate(feats):
+        w, b = _fold(sd, f'_neck.neck{i}.0', f'_neck.neck{i}.1')
+        t = _h(F.relu(F.conv2d(f, w, b)))
+        hp = f'_head.head{i}_'
+
+        def tower(name, t):
+            for l in range(2):
+                yv = F.conv2d(t, _h(sd[f'{name}.{3 * l}.weight']))
+                yv = F.group_norm(yv, G, sd[f'{name}.{3 * l + 1}.weight'], sd[f'{name}.{3 * l + 1}.bias'], GN_EPS)
+                t = _h(F.relu(yv))
+            return t
+
+        if arch['merge_path_flag']:
+            tt = tower(hp + 'merge_path', t)
+            c = F.conv2d(tt, _h(sd[hp + 'classification_path.0.weight']), sd[hp + 'classification_path.0.bias'])
+            r = F.conv2d(tt, _h(sd[hp + 'regression_path.0.weight']), sd[hp + 'regression_path.0.bias'])
+        else:
+            c = F.conv2d(tower(hp + 'classification_path', t), _h(sd[hp + 'classification_path.6.weight']),
+                         sd[hp + 'classification_path.6.bias'])
+            r = F.conv2d(tower(hp + 'regression_path', t), _h(sd[hp + 'regression_path.6.weight']),
+                         sd[hp + 'regression_path.6.bias'])
+        r = r * sd[f'_head._scales.{i}._scale']
+        cls_l.append(c)
+        reg_l.append(r)
+    sizes = [(c.shape[2], c.shape[3]) for c in cls_l]
+    cls = torch.cat([c.permute(0, 2, 3, 1).reshape(c.shape[0], -1, c.shape[1]) for c in cls_l], 1)
+    reg = torch.cat([r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, 4) for r in reg_l], 1)
+    return cls, reg, sizes

@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/lfd_hip.h declares (no compute
+calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from lfd_amd import _lib
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
+    return sorted(set(re.findall(r'LFD_API\s+[\w\s\*]+?\b(lfd_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(_lib.declared_symbols()) == _header_symbols()
+
+
+def test_abi_version_and_strings():
+    l = _lib.lib()
+    assert l.lfd_hip_abi_version() == 1
+    assert l.lfd_hip_status_string(0) == b'ok'
+    assert l.lfd_hip_status_string(-2) == b'workspace too small'
+    assert l.lfd_hip_build_info().startswith(b'gfx950;')
+
+
+def test_workspace_queries_are_pure_host_functions():
+    l = _lib.lib()
+    assert l.lfd_nms_workspace_bytes(0) > 0
+    assert l.lfd_nms_workspace_bytes(4096) >= 4096 * 64 * 8     # 64x64-tile bitmask rows
+    d = _lib.DetectDesc()
+    d.num_levels = 1
+    d.level_h[0], d.level_w[0], d.level_stride[0] = 4, 4, 8
+    d.num_classes = d.num_cls_channels = 1
+    d.max_candidates = 16
+    assert l.lfd_detect_workspace_bytes(ctypes.byref(d), 2) > 0
+    assert l.lfd_conv_packed_weight_halfs(64, 64, 3) == 64 * 64 * 9
+    assert l.lfd_head_partial_floats(2, 130, 16) == 2 * 3 * 16 * 2
+
+
+def test_invalid_arguments_are_status_codes_not_crashes():
+    l = _lib.lib()
+    assert l.lfd_nms_f32(None, -1, 0.5, None, None, None, 0, None) == -1
+    assert l.lfd_conv2d_nhwc_f16(None, None, None, None, None, None, None, None, None, None) == -1
+    assert l.lfd_sigmoid_focal_loss_fwd(None, None, 4, 0, 2.0, 0.25, None, 0, None) == -1

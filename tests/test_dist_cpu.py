@@ -1,0 +1,49 @@
+"""Image-parallel sharding: world_size-2 gloo run of the batch partition + result
+gather + global loss normaliser used by bench.py / lfd_amd.parallel, on CPU."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'lfd-a-light-and-fast-detector_amd'))
+import torch, torch.distributed as dist
+from lfd_amd import parallel
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+# 1. contiguous image shards cover the batch exactly once
+lo, hi = parallel.shard_range(11, rank, world)
+sizes = [None] * world
+dist.all_gather_object(sizes, (lo, hi))
+assert sizes == [(0, 6), (6, 11)], sizes
+# 2. per-image result lists gathered in image order on every rank
+local = [[[rank, 0.5, float(i), 0., 1., 1.]] for i in range(lo, hi)]
+allr = parallel.gather_results(local, 11)
+assert [r[0][2] for r in allr] == [float(i) for i in range(11)]
+# 3. global loss normaliser: n_pos is summed over ranks before the division (reference computes the loss
+#    once over the gathered outputs of all replicas: executor.py:198-200, lfd.py:340,383)
+n_pos = torch.tensor([3.0 if rank == 0 else 5.0])
+assert float(parallel.global_count(n_pos)) == 8.0
+# 4. gradient averaging helper == mean over ranks
+g = torch.full((4,), float(rank + 1))
+parallel.allreduce_mean_([g])
+assert torch.allclose(g, torch.full((4,), 1.5))
+# 5. throughput aggregation: max time over ranks
+t = parallel.max_over_ranks(1.0 + rank)
+assert t == 2.0
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29577', str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count('ok') == 2

@@ -1,0 +1,97 @@
+"""Conv / stem kernels (through the C ABI) against a float64 CPU convolution of the same
+fp16-rounded operands: differences are fp32 accumulation order + the final fp16 rounding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lfd_amd import engine, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cin, cout, ks, s, n, h, w, relu=True, res=False, tail=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, h, w, cin, generator=g) * 0.5).half()
+    wt = (torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks) ** 0.5)).half().float()
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).double(), wt.double(), b.double(), stride=s, padding=ks // 2)
+    r = None
+    if res:
+        r = (torch.randn(n, ref.shape[2], ref.shape[3], cout, generator=g) * 0.5).half()
+        ref = ref + r.double().permute(0, 3, 1, 2)
+    if relu:
+        ref = ref.relu()
+    t = None
+    if tail:
+        w2 = (torch.randn(cout, cout, 1, 1, generator=g) * (1.0 / cout ** 0.5)).half().float()
+        b2 = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(ref.float().half().double(), w2.double(), b2.double()).relu()
+        t = (ops.pack_conv_weight(w2).cuda(), b2.cuda(), True)
+    out = ops.conv2d_nhwc(x.cuda(), ops.pack_conv_weight(wt).cuda(), b.cuda(), cin, cout, ks, s, relu,
+                          residual=r.cuda() if res else None, tail=t)
+    got = out.float().cpu().permute(0, 3, 1, 2).double()
+    assert got.shape == ref.shape
+    # fp16 output rounding: half an ulp at the value's magnitude (2^-11 relative) + accumulation noise
+    tol = 1.2e-3 * ref.abs().clamp(min=1.0)
+    assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize('cin,cout,ks,s', [(64, 64, 3, 1), (64, 64, 3, 2), (64, 128, 3, 2), (64, 64, 1, 1), (64, 128, 1, 1),
+                                           (64, 64, 1, 2), (64, 128, 1, 2), (128, 128, 3, 1), (128, 128, 3, 2),
+                                           (128, 128, 1, 1), (128, 128, 1, 2), (32, 32, 3, 2), (32, 64, 3, 2),
+                                           (32, 32, 3, 1), (32, 32, 1, 1), (32, 64, 1, 2)])
+def test_conv_variants_odd_sizes(cin, cout, ks, s):
+    _run(cin, cout, ks, s, 2, 37, 45)          # odd H/W: tile overhang, zero padding, s2 on odd inputs
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (3, 5, 7), (1, 17, 30), (2, 135, 240), (1, 68, 120)])
+def test_conv3x3_shapes(shape):
+    _run(64, 64, 3, 1, *shape)
+
+
+def test_conv_residual_norelu_tail():
+    _run(64, 64, 3, 1, 2, 34, 60, res=True)
+    _run(64, 64, 3, 1, 1, 17, 30, relu=False)
+    _run(128, 128, 3, 1, 2, 17, 30, res=True)
+    _run(64, 64, 3, 2, 2, 41, 51, tail=True)
+    _run(32, 32, 3, 2, 2, 41, 51, tail=True)
+
+
+def test_conv_unsupported_is_loud():
+    x = torch.zeros(1, 8, 8, 48, dtype=torch.float16).cuda()
+    with pytest.raises(RuntimeError, match='unsupported'):
+        ops.conv2d_nhwc(x, torch.zeros(1, 27, 64, 8, dtype=torch.float16).cuda(), torch.zeros(32).cuda(), 48, 32, 3, 1, True)
+
+
+@pytest.mark.parametrize('c', [32, 64])
+@pytest.mark.parametrize('fmt', ['nchw_f32', 'nhwc_f16', 'nhwc_u8'])
+@pytest.mark.parametrize('tail', [True, False])
+def test_stem_kernel_formats(c, fmt, tail):
+    from lfd_amd._lib import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(1)
+    n, h, w = 2, 45, 71
+    if fmt == 'nhwc_u8':
+        img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+        xin, code = img, 2
+        xf = ((img.float() / 255 - 0.5) / 0.5).half().float().permute(0, 3, 1, 2)     # simple_normalize
+    else:
+        xf = (torch.rand(n, 3, h, w, generator=g) * 2 - 1).half().float()
+        xin, code = (xf.contiguous(), 0) if fmt == 'nchw_f32' else (xf.permute(0, 2, 3, 1).contiguous().half(), 1)
+    w1 = (torch.randn(c, 3, 3, 3, generator=g) * 0.2).half().float()
+    b1 = torch.randn(c, generator=g) * 0.1
+    ref = F.conv2d(xf.double(), w1.double(), b1.double(), stride=2, padding=1).relu()
+    w2p = b2 = None
+    if tail:
+        w2 = (torch.randn(c, c, 1, 1, generator=g) * (1 / c ** 0.5)).half().float()
+        b2 = (torch.randn(c, generator=g) * 0.1).cuda()
+        ref = F.conv2d(ref.float().half().double(), w2.double(), b2.cpu().double()).relu()
+        w2p = ops.pack_conv_weight(w2).cuda()
+    out = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float16).cuda()
+    xin = xin.cuda()
+    w1p, b1d = engine.pack_stem_weight(w1).cuda(), b1.cuda()     # keep the device tensors alive across the call
+    check(lib().lfd_stem_conv_f16(ptr(xin), code, n, h, w, c, ptr(w1p), ptr(b1d), ptr(w2p), ptr(b2), ptr(out),
+                                  stream_ptr()), 'stem')
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2).double()
+    tol = 1.2e-3 * ref.abs().clamp(min=1.0)
+    assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())

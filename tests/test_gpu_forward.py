@@ -1,0 +1,136 @@
+"""Whole-network forward parity on the MI355X (eval mode, HIP engine):
+  G2a  vs the fp16-storage-emulating oracle (same rounding points): raw logits within the
+       cascade of 1-ulp fp16 flips that accumulation-order noise seeds (mean < 1.5e-3);
+  G2b  vs the reference's fp32 outputs (golden): what decode consumes -- sigmoid(cls)/softmax and
+       sigmoid(reg) -- within 2.5e-3 (fp16 inter-layer storage alone measures 0.9-1.3e-3 on the
+       reference modules); raw-logit error reported;
+  determinism, HIP-graph replay equality, input formats, size properties at 1080p."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_oracle
+from conftest import load_golden
+from lfd_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden(name):
+    g = load_golden('ref_model_%s.npz' % name)
+    m = configs.build_model(name, seed=666)
+    configs.perturb_weights(m, seed=1)
+    m.eval()
+    N, H, W = [int(v) for v in g['shape']]
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(int(g['x_seed']))) * 2 - 1
+    return g, m, x
+
+
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L'])
+def test_forward_vs_reference_fp32_golden(name):
+    g, m, x = _golden(name)
+    m.cuda()
+    with torch.no_grad():
+        cls, reg = m(x.cuda())
+    assert cls.dtype == torch.float32 and cls.shape == g['cls'].shape and reg.shape == g['reg'].shape
+    assert [list(m.head_indexes_to_feature_map_sizes[i]) for i in range(len(g['sizes']))] == g['sizes'].tolist()
+    c, r = cls.cpu(), reg.cpu()
+    rc, rr = torch.from_numpy(g['cls']), torch.from_numpy(g['reg'])
+    raw = max(float((c - rc).abs().max()), float((r - rr).abs().max()))
+    print('raw logit max-abs error vs fp32 reference: %.2e' % raw)
+    assert raw < 2e-2
+    if configs.ARCHS[name]['classification_loss_type'] == 'CrossEntropyLoss':
+        assert float((c.softmax(-1) - rc.softmax(-1)).abs().max()) < 2.5e-3
+    else:
+        assert float((c.sigmoid() - rc.sigmoid()).abs().max()) < 2.5e-3
+    assert float((r.sigmoid() - rr.sigmoid()).abs().max()) < 2.5e-3
+
+
+@pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_XS', (2, 96, 128)), ('WIDERFACE_LFD_S', (2, 135, 241)),
+                                        ('WIDERFACE_LFD_L', (1, 100, 156)), ('TT100K_LFD_L', (1, 90, 161)),
+                                        ('TT100K_LFD_S', (1, 64, 64)), ('WIDERFACE_LFD_M', (1, 64, 96))])
+def test_forward_vs_fp16_emulating_oracle(name, shape):
+    m = configs.build_model(name)
+    configs.perturb_weights(m)
+    m.eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = (torch.rand(*shape[:1], 3, *shape[1:], generator=torch.Generator().manual_seed(3)) * 2 - 1).half().float()
+    with torch.no_grad():
+        rc, rr, sizes = net_oracle.lfd_forward_fp16(sd, configs.ARCHS[name], x)
+        m.cuda()
+        c, r = m(x.cuda())
+    c, r = c.cpu(), r.cpu()
+    ec, er = (c - rc).abs(), (r - rr).abs()
+    print('%s: max %.2e / %.2e  mean %.2e / %.2e' % (name, ec.max(), er.max(), ec.mean(), er.mean()))
+    # Not tighter than this even with identical rounding points: fp32 accumulation-order noise flips
+    # ~0.1-1 % of the fp16-rounded activations by one ulp (2^-11 relative) and the flips random-walk
+    # through ~20 layers.  Kernel-level exactness is gated per layer in test_gpu_conv.py (vs float64).
+    assert float(ec.max()) < 1e-2 and float(er.max()) < 1e-2
+    assert float(ec.mean()) < 1.5e-3 and float(er.mean()) < 1.5e-3
+
+
+def test_forward_is_deterministic_and_graph_replay_matches():
+    m = configs.build_model('WIDERFACE_LFD_S')
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    x = (torch.rand(2, 200, 312, 3, device='cuda') * 2 - 1).half()          # NHWC fp16 fast-path input
+    with torch.no_grad():
+        a = [t.clone() for t in m.forward_resident(x)]
+        b = [t.clone() for t in m.forward_resident(x)]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        m.use_graph = True
+        c = [t.clone() for t in m.forward_resident(x)]
+        d = [t.clone() for t in m.forward_resident(x.clone())]
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+
+
+def test_input_formats_agree():
+    m = configs.build_model('WIDERFACE_LFD_XS')
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    img = torch.randint(0, 256, (1, 120, 168, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0))
+    xf = ((img.float() / 255 - 0.5) / 0.5)
+    with torch.no_grad():
+        a = [t.clone() for t in m.forward_resident(img.cuda())]                        # uint8 NHWC, normalisation fused
+        b = [t.clone() for t in m.forward_resident(xf.half().cuda())]                  # fp16 NHWC
+        c = [t.clone() for t in m.forward_resident(xf.half().float().permute(0, 3, 1, 2).contiguous().cuda())]  # NCHW fp32
+    assert torch.equal(a[0], b[0]) and torch.equal(b[0], c[0]) and torch.equal(b[1], c[1])
+
+
+def test_parameter_update_invalidates_plan():
+    m = configs.build_model('WIDERFACE_LFD_XS')
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    x = torch.rand(1, 3, 64, 96).cuda()
+    with torch.no_grad():
+        a = m(x)[0]
+        m._head._scales[0]._scale.mul_(2.0)
+        m._backbone._stem[0].weight.mul_(0.5)
+        b = m(x)[0]
+    assert not torch.equal(a, b)
+
+
+def test_backbone_standalone_returns_nchw_taps():
+    m = configs.build_model('WIDERFACE_LFD_S')
+    configs.perturb_weights(m)
+    bb = m._backbone.eval().cuda()
+    with torch.no_grad():
+        outs = bb(torch.rand(1, 3, 96, 128).cuda())
+    assert [tuple(o.shape) for o in outs] == [(1, 64, 12, 16), (1, 64, 6, 8), (1, 64, 3, 4), (1, 128, 2, 2), (1, 128, 2, 2)]
+    assert outs[0].dtype == torch.float32
+
+
+def test_full_size_properties_1080p():
+    """BASELINE config 2 shape: P = 43,620 points per image, finite outputs, batch independence
+    (image i of a batch of 8 == the same image run alone)."""
+    m = configs.build_model('WIDERFACE_LFD_S')
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    x = (torch.rand(8, 1080, 1920, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(0)) * 2 - 1).half()
+    with torch.no_grad():
+        cls, reg = [t.clone() for t in m.forward_resident(x)]
+        assert cls.shape == (8, 43620, 1) and reg.shape == (8, 43620, 4)
+        assert torch.isfinite(cls).all() and torch.isfinite(reg).all()
+        c1, r1 = [t.clone() for t in m.forward_resident(x[5:6].contiguous())]
+    assert torch.equal(c1[0], cls[5]) and torch.equal(r1[0], reg[5])

@@ -1,0 +1,133 @@
+"""Focal / IoU loss kernels and get_loss parity."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden
+from lfd_amd import configs, ops
+from lfd_amd.model.losses import FocalLoss, IoULoss
+from lfd_amd.model.losses.libs import sigmoid_focal_loss_ext as ext
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n,c', [(1, 1), (1000, 1), (777, 3), (4096, 45), (0, 4)])
+def test_focal_forward_backward_vs_oracle(n, c):
+    rng = np.random.default_rng(n + c)
+    x = rng.normal(0, 3, (n, c)).astype(np.float32)
+    t = rng.integers(0, c + 1, n).astype(np.int64)          # c == background
+    g = rng.normal(0, 1, (n, c)).astype(np.float32)
+    f = ext.forward(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), c, 2.0, 0.25)
+    b = ext.backward(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(g).cuda(), c, 2.0, 0.25)
+    assert f.shape == (n, c) and b.shape == (n, c)
+    if n == 0:
+        return
+    # tolerance: device expf/logf/powf vs glibc, a few ulp of fp32
+    np.testing.assert_allclose(f.cpu().numpy(), oracle.sigmoid_focal_loss_fwd(x, t), rtol=3e-5, atol=1e-6)
+    np.testing.assert_allclose(b.cpu().numpy(), oracle.sigmoid_focal_loss_bwd(x, t, g), rtol=3e-5, atol=1e-6)
+
+
+def test_focal_ignore_targets_and_extremes():
+    x = torch.tensor([[-90., 90., 0.], [30., -30., 5.]]).cuda()
+    t = torch.tensor([-1, 1]).cuda()                             # -1: ignored row (cu:33-38)
+    f = ext.forward(x, t, 3, 2.0, 0.25).cpu().numpy()
+    assert np.all(f[0] == 0) and np.all(np.isfinite(f))
+    np.testing.assert_allclose(f, oracle.sigmoid_focal_loss_fwd(x.cpu().numpy(), t.cpu().numpy()), rtol=3e-5, atol=1e-6)
+
+
+def test_focal_half_and_sum():
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 2, (513, 2)).astype(np.float32)
+    t = rng.integers(0, 3, 513).astype(np.int64)
+    ref = oracle.sigmoid_focal_loss_fwd(x.astype(np.float16).astype(np.float32), t)
+    fh = ext.forward(torch.from_numpy(x).cuda().half(), torch.from_numpy(t).cuda(), 2, 2.0, 0.25)
+    assert fh.dtype == torch.float16
+    np.testing.assert_allclose(fh.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-4)
+    s = ops.focal_sum(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), 2.0, 0.25)
+    assert float(s) == pytest.approx(float(oracle.sigmoid_focal_loss_fwd(x, t).astype(np.float64).sum()), rel=1e-6)
+    s2 = ops.focal_sum(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), 2.0, 0.25)
+    assert float(s) == float(s2)                                  # deterministic two-stage reduction
+
+
+def test_focal_module_autograd():
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.normal(0, 2, (300, 1)).astype(np.float32)).cuda().requires_grad_(True)
+    t = torch.from_numpy(rng.integers(0, 2, 300).astype(np.int64)).cuda()
+    loss = FocalLoss()(x, t, avg_factor=17)
+    loss.backward()
+    ref = oracle.sigmoid_focal_loss_fwd(x.detach().cpu().numpy(), t.cpu().numpy()).sum() / 17
+    assert float(loss) == pytest.approx(float(ref), rel=1e-5)
+    gref = oracle.sigmoid_focal_loss_bwd(x.detach().cpu().numpy(), t.cpu().numpy(), np.full((300, 1), 1 / 17, np.float32))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=3e-5, atol=1e-7)
+
+
+def _ref_iou_loss(pred, target, eps=1e-6):
+    """the reference expression (iou_loss.py:67-79,98-102,121-123) in torch, for autograd"""
+    lt = torch.max(pred[:, :2], target[:, :2])
+    rb = torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    ov = wh[:, 0] * wh[:, 1]
+    a1 = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    a2 = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    union = torch.max(a1 + a2 - ov, ov.new_tensor([1e-6]))
+    return -(ov / union).clamp(min=eps).log()
+
+
+def test_iou_loss_forward_backward():
+    rng = np.random.default_rng(4)
+    n = 2000
+    c = rng.uniform(20, 200, (n, 2))
+    s1, s2 = rng.uniform(2, 60, (n, 2)), rng.uniform(2, 60, (n, 2))
+    sh = rng.normal(0, 15, (n, 2))
+    pred = np.concatenate([c - s1, c + s1], 1).astype(np.float32)
+    tgt = np.concatenate([c + sh - s2, c + sh + s2], 1).astype(np.float32)
+    pred[:5] = [[0, 0, 1, 1]] * 5
+    tgt[:5] = [[50, 50, 60, 60]] * 5                               # disjoint: IoU 0 -> clamp(eps) -> zero gradient
+    p = torch.from_numpy(pred).cuda().requires_grad_(True)
+    loss = IoULoss()(p, torch.from_numpy(tgt).cuda(), avg_factor=n)
+    loss.backward()
+    np.testing.assert_allclose(ops.iou_loss_forward(p.detach(), torch.from_numpy(tgt).cuda(), 1e-6).cpu().numpy(),
+                               oracle.iou_loss_fwd(pred, tgt), rtol=2e-5, atol=1e-6)
+    pc = torch.from_numpy(pred).double().requires_grad_(True)
+    ref = _ref_iou_loss(pc, torch.from_numpy(tgt).double()).sum() / n
+    ref.backward()
+    assert float(loss) == pytest.approx(float(ref), rel=1e-5)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), pc.grad.numpy(), rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L'])
+def test_get_loss_vs_reference_golden(name):
+    """LFD.get_loss on the reference's own predictions + annotations: loss values and gradients
+    w.r.t. the predictions match the reference (its focal path ran through the C restatement)."""
+    g = load_golden('ref_model_%s.npz' % name)
+    m = configs.build_model(name).cuda()
+    for i, s in enumerate(g['sizes'].tolist()):
+        m._head_indexes_to_feature_map_sizes[i] = tuple(s)
+    cnt, o, ann = g['ann_counts'].tolist(), 0, []
+    for c in cnt:
+        ann.append((g['ann_boxes'][o:o + c], g['ann_labels'][o:o + c]))
+        o += c
+    cls = torch.from_numpy(g['cls']).cuda().requires_grad_(True)
+    reg = torch.from_numpy(g['reg']).cuda().requires_grad_(True)
+    out = m.get_loss((cls, reg), ann)
+    assert set(out) == {'loss', 'loss_values'} and set(out['loss_values']) == {'loss', 'classification_loss', 'regression_loss'}
+    lv = out['loss_values']
+    np.testing.assert_allclose([lv['loss'], lv['classification_loss'], lv['regression_loss']], g['loss'], rtol=2e-5)
+    out['loss'].backward()
+    np.testing.assert_allclose(cls.grad.cpu().numpy(), g['grad_cls'], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(reg.grad.cpu().numpy(), g['grad_reg'], rtol=2e-3, atol=1e-7)
+
+
+def test_get_loss_no_positives():
+    m = configs.build_model('WIDERFACE_LFD_XS').cuda()
+    sizes = [(4, 4), (2, 2), (1, 1), (1, 1), (1, 1)]
+    for i, s in enumerate(sizes):
+        m._head_indexes_to_feature_map_sizes[i] = s
+    P = 16 + 4 + 3
+    cls = torch.zeros(1, P, 1).cuda().requires_grad_(True)
+    reg = torch.zeros(1, P, 4).cuda().requires_grad_(True)
+    out = m.get_loss((cls, reg), [(np.zeros((0, 4), np.float32), np.zeros((0,), np.int64))])
+    assert out['loss_values']['regression_loss'] == 0.0          # empty.sum() (lfd.py:386-387)
+    out['loss'].backward()
+    assert torch.isfinite(cls.grad).all()

@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference interface: constructors, parameter names, properties,
+weight folding / packing, plan construction (all on CPU tensors -- no kernel launches)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from lfd_amd import configs, engine, ops
+from lfd_amd.model import LFD, LFDHead, LFDResNet, SimpleNeck
+from lfd_amd.model.backbone import FastBlock, FasterBlock, FastestBlock
+
+
+def test_state_dict_key_names_match_reference_convention():
+    m = configs.build_model('WIDERFACE_LFD_S')
+    keys = list(m.state_dict().keys())
+    for k in ('_backbone._stem.0.weight', '_backbone._stem.1.running_mean', '_backbone.stage0.0._conv1.weight',
+              '_backbone.stage0.0._downsample.0.weight', '_backbone.stage3.2._norm2.bias', '_neck.neck0.0.weight',
+              '_neck.neck4.1.running_var', '_head.head0_merge_path.0.weight', '_head.head0_merge_path.1.weight',
+              '_head.head0_classification_path.0.bias', '_head.head4_regression_path.0.weight',
+              '_head._scales.0._scale'):
+        assert k in keys, k
+    # shared head: duplicated keys alias the same storage (55 keys / 15 unique params)
+    hk = [k for k in keys if k.startswith('_head.')]
+    assert len(hk) == 55
+    assert len({m.state_dict()[k].data_ptr() for k in hk}) == 15
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 1565386                       # WF-S parameter count
+
+
+def test_strides_and_channels_properties():
+    m = configs.build_model('WIDERFACE_LFD_S')
+    assert m._backbone.num_output_strides_list == [8, 16, 32, 64, 64]
+    assert m._backbone.num_output_channels_list == [64, 64, 64, 128, 128]
+    assert m._neck.num_output_strides_list == [8, 16, 32, 64, 64]
+    t = configs.build_model('TT100K_LFD_L')
+    assert t._backbone.num_output_strides_list == [4, 8, 16, 32]
+    assert t._head.num_cls_channels == 46
+    assert sum(p.numel() for p in t.parameters()) == 1862646
+    assert sum(p.numel() for p in configs.build_model('WIDERFACE_LFD_XS').parameters()) == 898794
+
+
+def test_state_dict_roundtrip_strict():
+    a = configs.build_model('WIDERFACE_LFD_XS', seed=1)
+    b = configs.build_model('WIDERFACE_LFD_XS', seed=2)
+    b.load_state_dict(a.state_dict(), strict=True)
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+
+
+def test_block_variants_register_like_the_reference():
+    for cls, n in ((FastBlock, 3), (FasterBlock, 2), (FastestBlock, 2)):
+        ds = nn.Sequential(nn.Conv2d(32, 64, 1, 2, bias=False), nn.BatchNorm2d(64))
+        blk = cls(32, 64, stride=2, downsample=ds, norm_cfg=dict(type='BatchNorm2d'))
+        names = [n_ for n_, _ in blk.named_children()]
+        assert names[0] == '_downsample' and names[1:4] == ['_conv1', '_norm1', '_activation']
+        assert blk.num_convs == n
+    with pytest.raises(AssertionError):
+        FasterBlock(32, 64, stride=1, downsample=nn.Sequential())
+
+
+def test_train_mode_freeze_semantics():
+    bb = LFDResNet(block_mode='faster', stem_mode='faster', body_mode=None, stem_channels=32,
+                   body_architecture=[1, 1], body_channels=[32, 32], out_indices=((0, 0), (1, 0)), frozen_stages=1,
+                   norm_eval=True)
+    bb.train()
+    assert not bb._stem.training and not bb.stage0[0].training and bb.stage1[0].training
+    assert all(not p.requires_grad for p in bb._stem.parameters())
+    assert all(not m.training for m in bb.modules() if isinstance(m, nn.BatchNorm2d))
+
+
+def test_bn_fold_matches_eval_batchnorm():
+    torch.manual_seed(0)
+    conv = nn.Conv2d(8, 16, 3, padding=1, bias=False)
+    bn = nn.BatchNorm2d(16)
+    bn.running_mean.normal_(0, .3)
+    bn.running_var.uniform_(.5, 1.5)
+    bn.weight.data.uniform_(.5, 1.5)
+    bn.bias.data.normal_(0, .2)
+    bn.eval()
+    w, b = engine.fold_conv_norm(conv, bn)
+    x = torch.randn(2, 8, 9, 11)
+    ref = bn(conv(x))
+    got = torch.nn.functional.conv2d(x, w, b, padding=1)
+    torch.testing.assert_close(got, ref, atol=2e-6, rtol=1e-5)
+
+
+def test_pack_conv_weight_fragment_order():
+    w = torch.arange(64 * 32 * 9, dtype=torch.float32).reshape(64, 32, 3, 3) % 1000   # fp16-exact integers
+    p = ops.pack_conv_weight(w)
+    assert p.shape == (2, 18, 64, 8) and p.dtype == torch.float16
+    for tile, k, lane, j in ((0, 0, 0, 0), (1, 7, 45, 3), (0, 17, 63, 7), (1, 9, 31, 5)):
+        tap, q = divmod(k, 2)
+        r, s = divmod(tap, 3)
+        co = tile * 32 + (lane & 31)
+        ci = 16 * q + 8 * (lane >> 5) + j
+        assert float(p[tile, k, lane, j]) == float(w[co, ci, r, s])
+
+
+def test_pack_stem_weight_slot_order():
+    w = torch.arange(32 * 27, dtype=torch.float32).reshape(32, 3, 3, 3)
+    p = engine.pack_stem_weight(w)
+    assert p.shape == (1, 2, 64, 8)
+    e = lambda co, r, s, c: float(w[co, c, r, s])       # noqa: E731
+    assert float(p[0, 0, 5, 4]) == e(5, 0, 1, 1)         # step0 half0: row0, e=4 -> s=1,c=1
+    assert float(p[0, 0, 32 + 5, 7]) == e(5, 1, 2, 1)    # step0 half1: row1, e=7 -> s=2,c=1
+    assert float(p[0, 1, 9, 0]) == e(9, 2, 0, 0)         # step1 half0: row2
+    assert float(p[0, 1, 32 + 9, 1]) == e(9, 1, 2, 2)    # step1 half1: (row1, e=8)
+    assert float(p[0, 1, 32 + 9, 3]) == 0.0
+
+
+def test_engine_plan_structure_on_cpu():
+    m = configs.build_model('WIDERFACE_LFD_S')
+    m.eval()
+    plan = engine.EnginePlan(m._backbone, m._neck, m._head, torch.device('cpu'))
+    # stem pair 1 fused in the stem kernel, stem pair 2 = conv with a chained 1x1 tail
+    assert plan.stem_first[0] == 64 and plan.stem_first[3] is not None
+    assert plan.convs[0].tail is not None and plan.convs[0].stride == 2 and plan.convs[0].ks == 3
+    n3 = sum(1 for c in plan.convs if c.ks == 3)
+    n1 = sum(1 for c in plan.convs if c.ks == 1)
+    assert (n3, n1) == (1 + 2 * 11, 4)          # 11 FasterBlocks, 4 downsample branches
+    assert len(plan.taps) == 5 and len(plan.levels) == 5
+    assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
+    assert all(len(lv.towers) == 1 and lv.towers[0].fcout == 5 and lv.towers[0].split == 1 for lv in plan.levels)
+    t = configs.build_model('TT100K_LFD_L')
+    t.eval()
+    plan = engine.EnginePlan(t._backbone, t._neck, t._head, torch.device('cpu'))
+    assert all(len(lv.towers) == 2 for lv in plan.levels)
+    assert plan.levels[0].towers[0].fcout == 46 and plan.levels[0].towers[1].split == 0
+
+
+def test_unsupported_configs_fail_loudly():
+    bb = LFDResNet(block_mode='faster', stem_mode='fast', body_mode=None, stem_channels=64, body_architecture=[1],
+                   body_channels=[64], out_indices=((0, 0),), norm_cfg=dict(type='GroupNorm', num_groups=8))
+    with pytest.raises(RuntimeError, match='unsupported configuration'):
+        engine.EnginePlan(bb, None, None, torch.device('cpu'))
+
+
+def test_no_cpu_fallback():
+    m = configs.build_model('WIDERFACE_LFD_XS').eval()
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        m(torch.zeros(1, 3, 64, 64))
+    from lfd_amd.model.utils import nms
+    with pytest.raises(RuntimeError):
+        nms(torch.zeros(3, 5), 0.5)
+    from lfd_amd.model.losses.libs import sigmoid_focal_loss_ext as ext
+    with pytest.raises(RuntimeError, match='not implemented on the CPU'):   # reference: sigmoid_focal_loss_ext.cpp:32
+        ext.forward(torch.zeros(2, 1), torch.zeros(2, dtype=torch.long), 1, 2.0, 0.25)
+
+
+def test_point_grid_and_gray_ranges():
+    m = configs.build_model('WIDERFACE_LFD_S')
+    pts = m.generate_point_coordinates({0: (2, 3), 1: (1, 2), 2: (1, 1), 3: (1, 1), 4: (1, 1)})
+    assert pts[0].tolist() == [[0, 0], [8, 0], [16, 0], [0, 8], [8, 8], [16, 8]]     # x fastest, no half-stride offset
+    assert pts[1].tolist() == [[0, 0], [16, 0]] and pts[0].dtype == torch.int64
+    assert m._gray_ranges == [(3, 22), (18, 44), (36, 88), (72, 176), (144, 352)]
+
+
+def test_target_assignment_and_loss_match_golden_on_cpu_tensors():
+    """annotation_to_target / get_loss glue (tensor algebra) against the reference's outputs; the
+    focal/IoU kernels need the GPU, so only targets are checked here."""
+    from conftest import load_golden
+    g = load_golden('ref_model_WIDERFACE_LFD_XS.npz')
+    m = configs.build_model('WIDERFACE_LFD_XS')
+    for i, s in enumerate(g['sizes'].tolist()):
+        m._head_indexes_to_feature_map_sizes[i] = tuple(s)
+    pts = m.generate_point_coordinates(m.head_indexes_to_feature_map_sizes)
+    cnt, o, bb, ll = g['ann_counts'].tolist(), 0, [], []
+    for c in cnt:
+        bb.append(torch.from_numpy(g['ann_boxes'][o:o + c]))
+        ll.append(torch.from_numpy(g['ann_labels'][o:o + c]))
+        o += c
+    ct, rt = m.annotation_to_target(pts, bb, ll)
+    np.testing.assert_array_equal(ct.numpy(), g['cls_targets'])
+    np.testing.assert_array_equal(rt.numpy(), g['reg_targets'])
