@@ -1,0 +1,257 @@
+"""bench.py -- BASELINE.json metric: images/sec, WIDERFACE_LFD_S end-to-end inference
+(forward + per-location decode + score threshold + NMS, results left resident on the device),
+synthetic 1920x1080 frames, batch 8 per GPU, fp16 NHWC input already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; images shard across ranks with NO data-path collective (weak scaling:
+8 frames per GPU per step); rank 0 prints ONE JSON line.  `roofline` = the dominant kernel class
+timed live with HIP events on the launch stream; `cpu_baseline` = the oracle's port of the
+reference CPU path (PyTorch fp32 eager NCHW forward + decode + greedy NMS) on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'lfd-a-light-and-fast-detector_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODEL = 'WIDERFACE_LFD_S'
+BATCH, H, W = 8, 1080, 1920
+TARGET_K = 256            # candidates per image (SURVEY 8d "sparse-realistic" load), IoU 0.4
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(n, oh, ow, cin, cout, ks):
+    return 2.0 * n * oh * ow * cin * cout * ks * ks
+
+
+def kernel_breakdown(model, plan, st, x, fmt, reps=20):
+    """Times every launch of the plan with HIP events on the launch stream (torch's current
+    stream is the stream the C ABI receives).  Returns {class: dict(time_us, launches, flops, bytes)}."""
+    import ctypes as C
+    from lfd_amd import _lib, ops
+    from lfd_amd._lib import check, lib, ptr, stream_ptr
+    l = lib()
+    z = ops.zero_line(plan.device)
+    classes = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps   # us
+
+    def add(name, us, flops, nbytes):
+        c = classes.setdefault(name, dict(time_us=0.0, launches=0, flops=0.0, bytes=0.0))
+        c['time_us'] += us
+        c['launches'] += 1
+        c['flops'] += flops
+        c['bytes'] += nbytes
+
+    n = st.n
+    c0, w1, b1, w2, b2 = plan.stem_first
+    so = st.bufs[plan.stem_out]
+    us = timed(lambda: check(l.lfd_stem_conv_f16(ptr(x), fmt, n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                                 ptr(so), stream_ptr()), 'stem'))
+    add('stem_3x3s2_3toC+1x1 (k_stem)', us, conv_flops(n, so.shape[1], so.shape[2], 3, c0, 3) +
+        (conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1) if w2 is not None else 0), x.numel() * x.element_size() + so.numel() * 2)
+    for c in plan.convs:
+        src, dst = st.bufs[c.src], st.bufs[c.dst]
+        d = _lib.ConvDesc(n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
+                          c.cout if c.tail else 0, 1 if c.tail else 0)
+        fn = lambda: check(l.lfd_conv2d_nhwc_f16(C.byref(d), ptr(src), ptr(dst), ptr(c.w), ptr(c.b),  # noqa: E731
+                                                 ptr(st.bufs[c.res]) if c.res is not None else None,
+                                                 ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,
+                                                 ptr(z), stream_ptr()), 'conv')
+        us = timed(fn)
+        fl = conv_flops(n, dst.shape[1], dst.shape[2], c.cin, c.cout, c.ks)
+        if c.tail:
+            fl += conv_flops(n, dst.shape[1], dst.shape[2], c.cout, c.cout, 1)
+        by = (src.numel() + dst.numel() + (dst.numel() if c.res is not None else 0)) * 2
+        if c.ks == 1 and c.stride == 2:
+            by = (src.numel() // 4 + dst.numel()) * 2
+        name = 'conv%dx%d_s%d_%dto%d%s (k_conv)' % (c.ks, c.ks, c.stride, c.cin, c.cout, '+1x1' if c.tail else '')
+        add(name, us, fl, by)
+    us = timed(lambda: plan.run_head(st))
+    hf = 0.0
+    hb = 0.0
+    for lv, (hh, ww) in zip(plan.levels, st.sizes):
+        px = n * hh * ww
+        per_tower = 3 * 2 * px * lv.cin * 128 + (3 + 2) * 2 * px * 128 * 128 + 2 * px * 128 * 32
+        hf += per_tower * len(lv.towers)
+        hb += (3 * px * lv.cin * 2) * len(lv.towers) + px * (plan.cls_channels + 4) * 4
+    add('neck+head 3-pass GN recompute (k_head x3 + finalize x2 per level)', us, hf, hb)
+    return classes
+
+
+def cpu_baseline():
+    """oracle port of the reference CPU path on ONE 1080p frame (bounded sample)."""
+    from oracle import net_oracle
+    from lfd_amd import configs
+    arch = configs.ARCHS[MODEL]
+    m = configs.build_model(MODEL)
+    configs.perturb_weights(m)
+    m.eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    # torch's CPU conv does not scale past a few tens of threads on this class of host (a 256-thread
+    # run of one 1080p frame takes > 40 s, 16 threads measured fastest on the MI355X box's host)
+    cores = min(os.cpu_count() or 1, int(os.environ.get('LFD_CPU_BASELINE_THREADS', '16')))
+    torch.set_num_threads(cores)
+    x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    strides = net_oracle.strides_of(arch)
+    times = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.time()
+            cls, reg, sizes = net_oracle.lfd_forward(sd, arch, x)
+            sc = cls[0].sigmoid().numpy()
+            thr = float(np.partition(sc.reshape(-1), -TARGET_K)[-TARGET_K])
+            net_oracle.get_results_single(cls[0].numpy(), reg[0].numpy(), sizes, strides, arch, thr, 0.4, False, (H, W), 1.0)
+            times.append(time.time() - t0)
+    t = float(np.median(times[1:]))
+    return dict(value=round(1.0 / t, 3), unit='images/s', cores=cores, kind='port',
+                sample='1 warm-up + 3 timed 1920x1080 frames (bs 1), median; torch %s fp32 eager NCHW forward '
+                       '(oracle/net_oracle.py) + decode + C greedy NMS at K=%d candidates' % (torch.__version__, TARGET_K))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')        # RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from lfd_amd import configs, engine
+    model = configs.build_model(MODEL)
+    configs.perturb_weights(model)
+    model.eval().to(dev)
+    model.use_graph = not args.no_graph
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    x = (torch.rand(BATCH, H, W, 3, device=dev, generator=gen) * 2 - 1).half()      # resident NHWC fp16 frames
+    meta = torch.tensor([[float(W), float(H), 1.0]] * BATCH, dtype=torch.float32, device=dev)
+
+    with torch.no_grad():
+        cls, reg = model.forward_resident(x)
+        # score threshold giving ~TARGET_K candidates per image on these synthetic weights
+        thr = float(torch.quantile(cls.float().sigmoid().reshape(BATCH, -1)[0], 1.0 - TARGET_K / cls.shape[1]))
+        model._classification_threshold = thr
+        model._nms_cfg = dict(type='nms', iou_thr=0.4)
+
+        def step():
+            out = model.forward_resident(x)
+            return model.detect(out, meta)
+
+        for _ in range(args.warmup):
+            det = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            det = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        counts = det.counts.cpu().numpy()
+
+        result = None
+        if rank == 0:
+            value = world * BATCH * args.steps / dt
+            result = {
+                'metric': 'images/sec WIDERFACE-S 1920x1080 bs=8 end-to-end inference (forward + decode + NMS)',
+                'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+                'config': {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16 NHWC resident in HBM: '
+                                       'backbone+neck+head (HIP MFMA convs) + decode + threshold + NMS, results on device',
+                           'global_batch': world * BATCH, 'points_per_image': int(cls.shape[1]),
+                           'candidates_per_image': float(counts[:, 0].mean()), 'kept_per_image': float(counts[:, 1].mean()),
+                           'score_thr': thr, 'iou_thr': 0.4, 'parallelism': 'image-parallel x%d, no collective' % world,
+                           'hip_graph': bool(model.use_graph),
+                           'weights': 'random init (seed 666) + synthetic BN/GN/Scale perturbation (no checkpoints offline)'},
+            }
+            # ---- roofline of the dominant kernel classes (live HIP-event timing on the launch stream)
+            fmt, n, h, w = engine._input_format(x)
+            plan = engine.get_plan(model, model._backbone, model._neck, model._head, dev)
+            st = plan.state_for(n, h, w)
+            br = kernel_breakdown(model, plan, st, x, fmt)
+            tot = sum(c['time_us'] for c in br.values())
+            rows = []
+            for name, c in sorted(br.items(), key=lambda kv: -kv[1]['time_us']):
+                tf = c['flops'] / c['time_us'] / 1e6
+                gb = c['bytes'] / c['time_us'] / 1e3
+                rows.append({'kernel': name, 'launches': c['launches'], 'time_us_per_forward': round(c['time_us'], 1),
+                             'share': round(c['time_us'] / tot, 3), 'tflops': round(tf, 1), 'gbs': round(gb, 0),
+                             'frac_mfma': round(tf / MFMA_PEAK_TFLOPS, 3), 'frac_hbm': round(gb / HBM_PEAK_GBS, 3)})
+            dom = rows[0]
+            k33 = [r for r in rows if r['kernel'].startswith('conv3x3_s1_64to64')]
+            pmc = {}
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            except Exception:
+                pass
+            if dom['frac_mfma'] >= dom['frac_hbm']:
+                result['roofline'] = {'kernel': dom['kernel'], 'bound': 'mfma',
+                                      'achieved': round(dom['tflops'], 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                      'frac': dom['frac_mfma'], 'traffic': pmc.get(dom['kernel'])}
+            else:
+                result['roofline'] = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,
+                                      'unit': 'GB/s', 'frac': dom['frac_hbm'], 'traffic': pmc.get(dom['kernel'])}
+            result['roofline']['avg_launch_us'] = round(dom['time_us_per_forward'] / dom['launches'], 2)
+            if k33:
+                result['roofline_conv3x3_s1_64'] = {'bound': 'mfma', 'achieved': k33[0]['tflops'], 'peak': MFMA_PEAK_TFLOPS,
+                                                    'unit': 'TFLOP/s', 'frac': k33[0]['frac_mfma'],
+                                                    'avg_launch_us': round(k33[0]['time_us_per_forward'] / k33[0]['launches'], 2),
+                                                    'traffic': pmc.get(k33[0]['kernel'])}
+            result['kernels'] = rows
+            result['forward_sum_us'] = round(tot, 1)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline()
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -186,37 +186,51 @@ LFD_API int lfd_stem_conv_f16(const void* in, int32_t in_format, int32_t n, int3
                               const void* w2_packed, const float* b2, void* out, lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Neck + head of one pyramid level.  Replaces SimpleNeck.forward (simple_neck.py:67-74),
- * LFDHead.forward (lfd_head.py:164-185, GroupNorm towers + cls/reg convs + Scale) and the
- * NCHW -> [N,P,C] permute/concat of LFD.forward (lfd.py:526-542): writes fp32 cls / reg rows of
- * this level directly at `point_offset` of the level-concatenated outputs.
+ * Neck + head of ALL pyramid levels.  Replaces SimpleNeck.forward (simple_neck.py:67-74),
+ * LFDHead.forward (lfd_head.py:164-185: GroupNorm towers + cls/reg convs + Scale) and the
+ * NCHW -> [N,P,C] permute/concat of LFD.forward (lfd.py:526-542): writes the fp32 cls / reg rows of
+ * every level directly at its point offset of the level-concatenated outputs.
  * GroupNorm statistics are obtained by recomputing the chain (pass 1, 2) -- see csrc/head.hip.
- *   pass 1: stats of tower conv1 -> `partial`;  lfd_groupnorm_finalize -> ab1
- *   pass 2: stats of tower conv2 -> `partial`;  lfd_groupnorm_finalize -> ab2
+ *   pass 1: per-tile stats of tower conv1 -> `partial`;  lfd_groupnorm_finalize -> ab1
+ *   pass 2: per-tile stats of tower conv2 -> `partial`;  lfd_groupnorm_finalize -> ab2
  *   pass 3: outputs.
- * For a BatchNorm / no-norm head, skip passes 1-2 and pass the folded (scale, shift) as ab1/ab2. */
+ * For a BatchNorm / no-norm head, skip passes 1-2 and pass the folded (scale, shift) as ab1/ab2.
+ * One call = one tower (merged cls+reg tower, or the cls / reg tower of an unmerged head). */
 typedef struct lfd_head_desc {
-  int32_t n, hw;            /* images, pixels of this level (h*w) */
-  int32_t cin;              /* backbone tap channels: 64 | 128 */
-  int32_t head_channels;    /* 128 */
-  int32_t num_groups;       /* GroupNorm groups (16) */
-  int32_t total_points;     /* P */
-  int32_t point_offset;     /* first point of this level */
-  int32_t cls_channels;     /* C' (row length of out_cls) */
-  int32_t final_cout;       /* valid rows of the final conv (<= 64) */
-  int32_t final_split;      /* rows [0,split) -> cls, [split, final_cout) -> reg */
+  int32_t n;                                  /* images */
+  int32_t num_levels;
+  int32_t level_hw[LFD_MAX_LEVELS];           /* pixels (h*w) per level */
+  int32_t level_cin[LFD_MAX_LEVELS];          /* backbone tap channels per level: 64 | 128 */
+  int32_t level_point_offset[LFD_MAX_LEVELS]; /* first point of each level in [0, P) */
+  int32_t head_channels;                      /* 128 */
+  int32_t num_groups;                         /* GroupNorm groups (16) */
+  int32_t total_points;                       /* P */
+  int32_t cls_channels;                       /* C' (row length of out_cls) */
+  int32_t final_reg_rows;                     /* final conv rows [0, reg_rows) -> reg: 0 or 4 */
+  int32_t final_cls_rows;                     /* ... followed by cls_rows rows -> cls (reg+cls <= 64) */
 } lfd_head_desc_t;
 
-LFD_API size_t lfd_head_partial_floats(int32_t n, int32_t hw, int32_t num_groups);
-LFD_API int lfd_head_level_f16(const lfd_head_desc_t* desc, int32_t pass, const void* x,
-                               const void* wn_packed, const float* bn, const void* w1_packed,
-                               const void* w2_packed, const void* wf_packed, const float* bf,
-                               const float* ab1, const float* ab2, float* partial, float* out_cls,
-                               float* out_reg, const float* scale, const void* zeros,
-                               lfd_stream_t stream);
-LFD_API int lfd_groupnorm_finalize(const float* partial, int32_t n, int32_t hw, int32_t num_groups,
-                                   const float* gamma, const float* beta, float eps,
-                                   float* ab /*[n][128][2]*/, lfd_stream_t stream);
+typedef struct lfd_head_level_ptrs {
+  const void* x;           /* [n, hw, cin] fp16 backbone tap (NHWC) */
+  const void* wn_packed;   /* neck conv1x1 (BN folded), packed */
+  const float* bn;         /* neck bias [128] */
+  const void* w1_packed;   /* tower conv 1, packed */
+  const void* w2_packed;   /* tower conv 2, packed */
+  const void* wf_packed;   /* final conv (rows padded to a multiple of 32), packed */
+  const float* bf;         /* final bias */
+  const float* scale;      /* per-level Scale (device scalar) or NULL */
+} lfd_head_level_ptrs_t;
+
+LFD_API size_t lfd_head_partial_floats(const lfd_head_desc_t* desc);
+LFD_API int lfd_head_forward_f16(const lfd_head_desc_t* desc, int32_t pass,
+                                 const lfd_head_level_ptrs_t* levels /*[num_levels], host array*/,
+                                 const float* ab1 /*[L][n][128][2]*/, const float* ab2,
+                                 float* partial, float* out_cls, float* out_reg, const void* zeros,
+                                 lfd_stream_t stream);
+/* gamma / beta: host arrays of num_levels device pointers ([128] each). ab: [L][n][128][2]. */
+LFD_API int lfd_groupnorm_finalize(const lfd_head_desc_t* desc, const float* partial,
+                                   const float* const* gamma, const float* const* beta, float eps,
+                                   float* ab, lfd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,9 @@ struct Cfg {
   static constexpr int PIXB = CIN * 2;
   static constexpr int PPR = (CPP >= 16) ? 1 : 16 / CPP;  // pixels per 256-B bank row
   static constexpr int NSLOT = IH * IWs;
-  static constexpr int IN_BYTES = ((NSLOT * PIXB + 1023) / 1024) * 1024;
+  static constexpr int OUT_STAGE_BYTES = (4 / NCT) * PT * 32 * NCT * 64;   // epilogue staging tile (fp16)
+  static constexpr int IN_RAW = NSLOT * PIXB > OUT_STAGE_BYTES ? NSLOT * PIXB : OUT_STAGE_BYTES;
+  static constexpr int IN_BYTES = ((IN_RAW + 1023) / 1024) * 1024;
   static constexpr int NBUF = (S == 1) ? 2 : 1;     // S=2 tiles are 4x larger: single buffer, 2 blocks/CU
   static constexpr int NK = KS * KS * CIN / 16;     // MFMA k-steps of the main conv
   static constexpr int NQ = CIN / 16;
@@ -112,16 +114,22 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     for (int k = 0; k < C::NK2; ++k) w2reg[k] = a.w2[((size_t)ct * C::NK2 + k) * 64 + lane];
   }
 
-  // ---- per-lane LDS read offsets: one per (column tap s, 16-channel group q)
-  int xoff[KS][C::NQ];
+  // ---- per-lane LDS read offsets: one per (column tap s, 16-channel group q).  For 128 input
+  // channels (NQ = 8) the 24-entry table would cost more registers than the weight ring: keep the
+  // per-tap pixel base + swizzle key and form the XOR term at the read (2 VALU per ds_read).
+  constexpr bool XTAB = C::NQ <= 4;
+  int xoff[KS][XTAB ? C::NQ : 1];
+  int xbase[KS], xkey[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int ix = oxl * S + s;
     const int rem = (S == 2) ? ((ix & 1) * C::IWh + (ix >> 1)) : ix;
     const int f = (rem / C::PPR) % C::CPP;
     const int rowbase = ((pg * C::PT * C::RPT + oyl) * S) * C::IWs + rem;
+    xbase[s] = rowbase * C::PIXB;
+    xkey[s] = f ^ h;            // (2q + h) ^ f == (2q) ^ (f ^ h) because bit 0 of 2q is clear
 #pragma unroll
-    for (int q = 0; q < C::NQ; ++q) xoff[s][q] = rowbase * C::PIXB + (((2 * q + h) ^ f) * 16);
+    for (int q = 0; q < (XTAB ? C::NQ : 1); ++q) xoff[s][q] = rowbase * C::PIXB + (((2 * q + h) ^ f) * 16);
   }
 
   // ---- persistent tile walk, XCD-contiguous ranges (block b runs on XCD b % 8)
@@ -181,6 +189,21 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
     const char* xb = smem + buf * C::IN_BYTES;
 
+    // residual (identity branch) of this lane's outputs: requested now, consumed in the epilogue,
+    // so its latency hides under the contraction
+    half4 resv[C::PT][4];
+    if (!TAIL && a.res) {
+#pragma unroll
+      for (int pt = 0; pt < C::PT; ++pt) {
+        const int oy = ty0 * C::TH + (pg * C::PT + pt) * C::RPT + oyl;
+        const int ox = tx0 * C::TW + oxl;
+        const bool ok = oy < a.OH && ox < a.OW;
+        const size_t o = (((size_t)n * a.OH + (ok ? oy : 0)) * a.OW + (ok ? ox : 0)) * a.cout + co_base + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) resv[pt][g] = *reinterpret_cast<const half4*>(a.res + o + 8 * g);
+      }
+    }
+
     f32x16 acc[C::PT];
     {
       // accumulators start at the (BN-folded) bias of this lane's 16 channels
@@ -195,33 +218,65 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
       }
     }
-    auto tap_row = [&](int r) {
+    // ---- main contraction.  Flat, fully unrolled k loop with an explicit register ring: the
+    // activation fragments (and the LDS-resident weight fragments) of k-step k+PD are requested
+    // before the MFMAs of k-step k issue; sched_barrier pins that order so the compiler's counted
+    // lgkmcnt waits leave PD k-steps of LDS latency in flight (its own schedule prefetches only one).
+    auto xfrag = [&](int k, int pt) {
+      const int r = k / (KS * C::NQ), s = (k / C::NQ) % KS, q = k % C::NQ;
+      const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
+      return *reinterpret_cast<const half8*>(xb + off + (r + pt * C::RPT * S) * C::IWs * C::PIXB);
+    };
+    if constexpr (WREG) {
+      constexpr int PD = 3;                       // prefetch distance in k-steps
+      half8 xq[PD + 1][C::PT];
+      half8 wq[PD + 1];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      for (int k = 0; k < PD && k < C::NK; ++k) {
 #pragma unroll
-        for (int q = 0; q < C::NQ; ++q) {
-          const int k = (r * KS + s) * C::NQ + q;
-          half8 wf;
-          if constexpr (!WREG) wf = wsrc[(size_t)k * 64];
-          else if (k < NKR) wf = wreg[k < NKR ? k : 0];
-          else wf = wlds[(k - NKR) * 64];
+        for (int pt = 0; pt < C::PT; ++pt) xq[k][pt] = xfrag(k, pt);
+        if (k >= NKR) wq[k] = wlds[(k - NKR) * 64];
+      }
+#pragma unroll
+      for (int k = 0; k < C::NK; ++k) {
+        if (k + PD < C::NK) {
+#pragma unroll
+          for (int pt = 0; pt < C::PT; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
+          if (k + PD >= NKR) wq[(k + PD) % (PD + 1)] = wlds[(k + PD - NKR) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 wf = (k < NKR) ? wreg[k < NKR ? k : 0] : wq[k % (PD + 1)];
+#pragma unroll
+        for (int pt = 0; pt < C::PT; ++pt)
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // weights streamed from L2 (128-channel layers on tiny maps): a ring of PW fragments stays
+      // in flight across the (rolled) tap-row loop so the ~1 us L2 latency is paid once, not per row
+      constexpr int PW = 8;
+      constexpr int RK = KS * C::NQ;              // k-steps per tap row
+      static_assert(RK % PW == 0, "weight ring must wrap on a tap-row boundary");
+      half8 wq[PW];
+#pragma unroll
+      for (int i = 0; i < PW; ++i) wq[i] = wsrc[(size_t)i * 64];
+#pragma unroll 1
+      for (int r = 0; r < KS; ++r) {
+        const char* xr = xb + r * C::IWs * C::PIXB;
+        const int knext = r * RK + PW;   // ring refill index; clamped (re-reads the last fragment, branch-free)
+#pragma unroll
+        for (int j = 0; j < RK; ++j) {
+          const int s = j / C::NQ, q = j % C::NQ;
+          const half8 wf = wq[j % PW];
+          wq[j % PW] = wsrc[(size_t)((knext + j) < C::NK ? (knext + j) : (C::NK - 1)) * 64];
+          const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
 #pragma unroll
           for (int pt = 0; pt < C::PT; ++pt) {
-            const half8 xf = *reinterpret_cast<const half8*>(
-                xb + xoff[s][q] + (r + pt * C::RPT * S) * C::IWs * C::PIXB);
+            const half8 xf = *reinterpret_cast<const half8*>(xr + off + (pt * C::RPT * S) * C::IWs * C::PIXB);
             acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[pt], 0, 0, 0);
           }
         }
       }
-    };
-    if constexpr (WREG) {
-#pragma unroll
-      for (int r = 0; r < KS; ++r) tap_row(r);
-    } else {
-      // weights streamed from L2: keep the row loop rolled so the compiler cannot hoist all
-      // KS*KS*NQ fragment loads (72 x 4 VGPRs) ahead of the MFMAs
-#pragma unroll 1
-      for (int r = 0; r < KS; ++r) tap_row(r);
     }
 
     if (TAIL) {
@@ -269,27 +324,48 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
       }
     }
 
-    // ---- epilogue: (+ residual) -> ReLU -> fp16 -> 8-byte NHWC stores
+    // ---- epilogue: (+ residual) -> ReLU -> fp16 -> LDS staging -> full-line 16-byte NHWC stores.
+    // Straight from the accumulator layout every store instruction would touch 32 pixel lines with
+    // 16 bytes each (store-issue bound); staged through LDS, consecutive lanes write consecutive
+    // 16-byte chunks of one pixel line.  The staging tile lives in storage that is dead by now: the
+    // consumed input buffer (or the `mid` tile of the chained 1x1).
     const int cout_out = TAIL ? a.cout2 : a.cout;
-    const int co_out = TAIL ? (ct * 32) : co_base;
     const int do_relu = TAIL ? a.relu2 : a.relu;
+    constexpr int OCPP = NCT * 4;                         // 16-byte chunks per pixel of this block's channel slice
+    constexpr int OPIXB = NCT * 64;
+    constexpr int OPPR = (OCPP >= 16) ? 1 : 16 / OCPP;
+    constexpr int OPX = C::PG * C::PT * 32;
+    static_assert(OPX * OPIXB <= C::IN_BYTES, "output staging must fit the input buffer");
+    char* sout = TAIL ? (smem + C::NBUF * C::IN_BYTES) : (smem + buf * C::IN_BYTES);
+    __syncthreads();   // every wave is done reading the input buffer / mid tile
 #pragma unroll
     for (int pt = 0; pt < C::PT; ++pt) {
-      const int oy = ty0 * C::TH + (pg * C::PT + pt) * C::RPT + oyl;
-      const int ox = tx0 * C::TW + oxl;
-      if (oy < a.OH && ox < a.OW) {
-        const size_t o = (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + co_out + 4 * h;
+      const int pb = (pg * C::PT + pt) * 32 + pix;
+      const int fo = (pb / OPPR) % OCPP;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float x0 = acc[pt][4 * g + 0], x1 = acc[pt][4 * g + 1], x2 = acc[pt][4 * g + 2], x3 = acc[pt][4 * g + 3];
-          if (a.res) {
-            const half4 rv = *reinterpret_cast<const half4*>(a.res + o + 8 * g);
-            x0 += (float)rv[0]; x1 += (float)rv[1]; x2 += (float)rv[2]; x3 += (float)rv[3];
-          }
-          if (do_relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
-          half4 v;
-          v[0] = (_Float16)x0; v[1] = (_Float16)x1; v[2] = (_Float16)x2; v[3] = (_Float16)x3;
-          *reinterpret_cast<half4*>(a.out + o + 8 * g) = v;
+      for (int g = 0; g < 4; ++g) {
+        float x0 = acc[pt][4 * g + 0], x1 = acc[pt][4 * g + 1], x2 = acc[pt][4 * g + 2], x3 = acc[pt][4 * g + 3];
+        if (!TAIL && a.res) {
+          x0 += (float)resv[pt][g][0]; x1 += (float)resv[pt][g][1]; x2 += (float)resv[pt][g][2]; x3 += (float)resv[pt][g][3];
+        }
+        if (do_relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
+        half4 v;
+        v[0] = (_Float16)x0; v[1] = (_Float16)x1; v[2] = (_Float16)x2; v[3] = (_Float16)x3;
+        *reinterpret_cast<half4*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
+      }
+    }
+    __syncthreads();
+    {
+      const int cslice = TAIL ? 0 : cog * NCT * 32;
+      for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
+        const int pb = i / OCPP, c = i - pb * OCPP;
+        const int t32 = pb >> 5, p32 = pb & 31;
+        const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
+        const int ox = tx0 * C::TW + p32 % C::TW;
+        if (oy < a.OH && ox < a.OW) {
+          const int fo = (pb / OPPR) % OCPP;
+          const uint4 v = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
+          *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + cslice + c * 8) = v;
         }
       }
     }

@@ -12,6 +12,8 @@
 //   pass 1: neck -> conv1                         -> per-tile (sum, sumsq) of conv1 per group
 //   pass 2: neck -> conv1 -> GN1+ReLU -> conv2    -> per-tile (sum, sumsq) of conv2 per group
 //   pass 3: neck -> conv1 -> GN1+ReLU -> conv2 -> GN2+ReLU -> cls/reg conv -> fp32 outputs
+// All pyramid levels run in ONE launch per pass (persistent workgroups walk a level-major tile
+// list and reload the per-level neck weights on a level switch): 5 launches per forward.
 // (+13 % MFMA work for the whole network, -65 % head HBM bytes; pre-norm values never leave fp32
 // registers).  Partial sums are combined in fp64 in a fixed order (deterministic).
 //
@@ -29,29 +31,37 @@ namespace {
 
 constexpr int HC = 128;        // head / neck channels
 constexpr int TPX = 64;        // pixels per tile (2 MFMA pixel tiles)
-constexpr int NGROUP_MAX = 32;
 
-struct HeadArgs {
-  const _Float16* x;     // [N, HW, CIN] backbone tap (NHWC, flattened pixels)
-  const half8* wn;       // neck   [4][CIN/16][64]
+struct HeadLevel {
+  const _Float16* x;     // [N, HW, cin] backbone tap (NHWC, flattened pixels)
+  const half8* wn;       // neck   [4][cin/16][64]
   const float* bn;       // neck bias (BN folded) [128]
   const half8* w1;       // tower conv 1 [4][8][64]
   const half8* w2;       // tower conv 2 [4][8][64]
   const half8* wf;       // final conv   [FT][8][64]  (cout padded to FT*32)
   const float* bf;       // final bias   [FT*32]
-  const float* ab1;      // [N][128][2]  GN1 (scale, shift) per image/channel   (pass >= 2)
-  const float* ab2;      // [N][128][2]  GN2                                    (pass == 3)
-  float* part;           // [N*tiles][16 groups... up to 128/gsize][2] partial stats (pass 1, 2)
+  const float* scale;    // per-level Scale parameter (device scalar) or nullptr
+  int cin, hw, p_off;    // tap channels, pixels per image, first point of the level
+  int tile_start;        // first global tile of this level
+  int tiles_per_img;
+};
+
+struct HeadArgs {
+  HeadLevel lv[LFD_MAX_LEVELS];
+  int nlev;
+  const float* ab1;      // [L][N][128][2]  GN1 (scale, shift) per level/image/channel  (pass >= 2)
+  const float* ab2;      // [L][N][128][2]  GN2                                         (pass == 3)
+  float* part;           // [ntiles][128 >> gshift][2] per-tile partial statistics       (pass 1, 2)
   float* out_cls;        // [N, P, CC]
   float* out_reg;        // [N, P, 4]
-  const float* scale;    // per-level Scale parameter (device scalar) or nullptr
-  int N, HW;             // images, pixels per image at this level
-  int P, p_off;          // total points per image, offset of this level
-  int CC;                // classification channels
-  int split;             // final couts [0,split) -> cls, [split, split+4) -> reg (split = fcout if no reg)
-  int fcout;             // valid final couts
+  int N, P, CC;
+  int reg_rows;          // final conv rows [0,reg_rows) -> reg (0 or 4), then cls_rows rows -> cls
+  int cls_rows;
+  int grp_levels[LFD_MAX_LEVELS];      // levels handled by this launch (same tap channel count)
+  int grp_tile_start[LFD_MAX_LEVELS];  // first launch-local tile of each of them
+  int grp_n, grp_ntiles;
   int gshift;            // log2(channels per group)  (GroupNorm(16,128) -> 3)
-  int tiles_per_img, ntiles;
+  int ntiles;
   const _Float16* zeros;
 };
 
@@ -75,65 +85,83 @@ __device__ __forceinline__ int lds_addr(int px, int c) {
 
 template <int CIN, int PASS, int FT>
 __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
-  constexpr int CPPX = CIN / 8;           // chunks per pixel of the input tile
-  constexpr int XBYTES = TPX * CIN * 2;
+  constexpr int CPPX = CIN / 8;              // 16-byte chunks per input pixel
+  constexpr int XBYTES = TPX * CIN * 2;      // one input tile
+  constexpr int NB = 32768 / XBYTES;         // input ring depth: 4 (64 ch) / 2 (128 ch) tiles in flight
+  constexpr int KD = (TPX * CPPX) / 256;     // DMA instructions per wave per tile
   constexpr int ABYTES = TPX * HC * 2;
   constexpr int NKN = CIN / 16, NKH = HC / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xbuf0 = smem;                        // 2 x XBYTES (double-buffered input tile)
-  char* bufA = smem + 2 * XBYTES;            // stage ping
+  char* xring = smem;                        // NB x XBYTES = 32 KB
+  char* bufA = smem + 32768;                 // stage ping
   char* bufB = bufA + ABYTES;                // stage pong
+  float* s_ab = reinterpret_cast<float*>(bufB + ABYTES);   // [2 stages][128][2] GN (scale, shift) of the current (level, image)
+  float* s_bf = s_ab + 512;                                // [64] final bias of the current level
+  float* s_bn = s_bf + 64;                                 // [128] neck bias of the current level
+  half8* s_wf = reinterpret_cast<half8*>(s_bn + 128);      // [FT][8][64] final-conv fragments (LDS, not VGPRs)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = lane >> 5, pix = lane & 31;
   const int ct = wave;                       // 32-channel tile of the 128 head channels
-
-  half8 wn[NKN], w1[NKH], w2[PASS >= 2 ? NKH : 1], wf[PASS == 3 ? NKH : 1];
-#pragma unroll
-  for (int k = 0; k < NKN; ++k) wn[k] = a.wn[(ct * NKN + k) * 64 + lane];
-#pragma unroll
-  for (int k = 0; k < NKH; ++k) w1[k] = a.w1[(ct * NKH + k) * 64 + lane];
-  if constexpr (PASS >= 2) {
-#pragma unroll
-    for (int k = 0; k < NKH; ++k) w2[k] = a.w2[(ct * NKH + k) * 64 + lane];
-  }
-  // final stage: wave -> (cout tile fct, pixel tile fpt); FT=1: waves 0,1 ; FT=2: all four
-  const int fct = wave % FT, fpt = wave / FT;
+  const int fct = wave % FT, fpt = wave / FT;   // final stage: (cout tile, pixel tile) of this wave
   const bool f_active = fpt < 2;
-  if constexpr (PASS == 3) if (f_active) {
-#pragma unroll
-    for (int k = 0; k < NKH; ++k) wf[k] = a.wf[(fct * NKH + k) * 64 + lane];
-  }
-  float bnv[16];
-  {
-    const float* bp = a.bn + ct * 32 + 4 * h;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
-      bnv[4 * g] = b4.x; bnv[4 * g + 1] = b4.y; bnv[4 * g + 2] = b4.z; bnv[4 * g + 3] = b4.w;
-    }
-  }
-  const float scale = (PASS == 3 && a.scale) ? a.scale[0] : 1.f;
 
-  auto issue_dma = [&](int t, int buf) {
-    const int n = t / a.tiles_per_img;
-    const int p0 = (t - n * a.tiles_per_img) * TPX;
-    constexpr int SPW = 64 / CPPX;
-    char* lbase = xbuf0 + buf * XBYTES;
-    for (int slot0 = wave * SPW; slot0 < TPX; slot0 += 4 * SPW) {
+  half8 wn[NKN], w1[NKH], w2[PASS >= 2 ? NKH : 1];
+  float scale = 1.f;
+  int cur_level = -1, cur_n = -1;
+
+  struct TileId { int l, n, p0, tg; };
+  auto tile_of = [&](int u) {
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < LFD_MAX_LEVELS; ++i)
+      if (i < a.grp_n && u >= a.grp_tile_start[i]) gi = i;
+    TileId t;
+    t.l = a.grp_levels[gi];
+    const int tl = u - a.grp_tile_start[gi];
+    t.n = tl / a.lv[t.l].tiles_per_img;
+    t.p0 = (tl - t.n * a.lv[t.l].tiles_per_img) * TPX;
+    t.tg = a.lv[t.l].tile_start + tl;      // global tile index (partial statistics row)
+    return t;
+  };
+
+  auto load_level = [&](int l) {
+    const HeadLevel& L = a.lv[l];
+#pragma unroll
+    for (int k = 0; k < NKN; ++k) wn[k] = L.wn[(ct * NKN + k) * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < NKH; ++k) w1[k] = L.w1[(ct * NKH + k) * 64 + lane];
+    if constexpr (PASS >= 2) {
+#pragma unroll
+      for (int k = 0; k < NKH; ++k) w2[k] = L.w2[(ct * NKH + k) * 64 + lane];
+    }
+    if constexpr (PASS == 3) {
+      for (int i = threadIdx.x; i < FT * NKH * 64; i += 256) s_wf[i] = L.wf[i];
+      scale = L.scale ? L.scale[0] : 1.f;
+      if (threadIdx.x < FT * 32) s_bf[threadIdx.x] = L.bf[threadIdx.x];
+    }
+    if (threadIdx.x < HC) s_bn[threadIdx.x] = L.bn[threadIdx.x];
+  };
+
+  auto issue_dma = [&](int u, int slot) {
+    const TileId t = tile_of(u);
+    const HeadLevel& L = a.lv[t.l];
+    constexpr int SPW = 64 / CPPX, PPR = (CPPX >= 16) ? 1 : 16 / CPPX;
+    char* lbase = xring + slot * XBYTES;
+#pragma unroll
+    for (int i = 0; i < KD; ++i) {
+      const int slot0 = (wave + 4 * i) * SPW;
       const int px = slot0 + lane / CPPX;
-      const int cs = lane % CPPX;
-      constexpr int PPR = (CPPX >= 16) ? 1 : 16 / CPPX;
-      const int c = cs ^ ((px / PPR) % CPPX);
-      const bool valid = (p0 + px) < a.HW;
-      const _Float16* src = valid ? a.x + ((size_t)n * a.HW + p0 + px) * CIN + c * 8 : a.zeros + c * 8;
+      const int c = (lane % CPPX) ^ ((px / PPR) % CPPX);
+      const bool valid = (t.p0 + px) < L.hw;
+      const _Float16* src = valid ? L.x + ((size_t)t.n * L.hw + t.p0 + px) * CIN + c * 8 : a.zeros + c * 8;
       dma16(src, lbase + slot0 * (CIN * 2));
     }
   };
 
-  // one MFMA stage: acc[pt] (+)= W(ct) x tile(src)   (K = NK*16 channels)
-  auto stage = [&](f32x16 (&acc)[2], const half8* w, const char* src, auto cpp_tag, int nk) {
+  // one MFMA stage over a [TPX][CPP*8] swizzled LDS tile
+  auto stage = [&](f32x16 (&acc)[2], const half8* w, const char* src, auto cpp_tag) {
     constexpr int CPP = decltype(cpp_tag)::value;
 #pragma unroll
     for (int q = 0; q < (CPP / 2); ++q) {
@@ -143,29 +171,36 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
         acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[q], xf, acc[pt], 0, 0, 0);
       }
     }
-    (void)nk;
   };
-  // write relu(acc*sc + sh) as fp16 into a [TPX][128] LDS tile (this wave's 32 channels)
-  auto store_tile = [&](const f32x16 (&acc)[2], char* dst, const float* sc, const float* sh) {
+  // write relu(acc*sc + sh) as fp16 into a [TPX][128] LDS tile (this wave's 32 channels);
+  // ab == nullptr: plain ReLU (neck).  ab: LDS [128][2] (scale, shift) of the current image.
+  auto store_tile = [&](const f32x16 (&acc)[2], char* dst, const float* ab) {
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      const int px = pt * 32 + pix;
+    for (int g = 0; g < 4; ++g) {
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ab) {
+        const float4* p = reinterpret_cast<const float4*>(ab + (ct * 32 + 8 * g + 4 * h) * 2);
+        const float4 a0 = p[0], a1 = p[1];
+        sc[0] = a0.x; sh[0] = a0.y; sc[1] = a0.z; sh[1] = a0.w; sc[2] = a1.x; sh[2] = a1.y; sc[3] = a1.z; sh[3] = a1.w;
+      }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int pt = 0; pt < 2; ++pt) {
         half4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float x = acc[pt][4 * g + j];
-          if (sc) x = x * sc[4 * g + j] + sh[4 * g + j];
+          if (ab) x = x * sc[j] + sh[j];
           v[j] = (_Float16)fmaxf(x, 0.f);
         }
-        *reinterpret_cast<half4*>(dst + lds_addr<HC / 8>(px, ct * 4 + g) + 8 * h) = v;
+        *reinterpret_cast<half4*>(dst + lds_addr<HC / 8>(pt * 32 + pix, ct * 4 + g) + 8 * h) = v;
       }
     }
   };
-  // per-tile GroupNorm partial statistics of this wave's 32 channels
-  auto write_stats = [&](const f32x16 (&acc)[2], int t, int p0) {
-    const float v0 = (p0 + pix) < a.HW ? 1.f : 0.f, v1 = (p0 + 32 + pix) < a.HW ? 1.f : 0.f;
+  // per-tile GroupNorm partial statistics of this wave's 32 channels.  Each (tile, group) slot has
+  // exactly one writer for group sizes >= 8 (one 8-byte store per group, no zero-init needed);
+  // smaller groups accumulate with atomics into a buffer the host zeroes.
+  auto write_stats = [&](const f32x16 (&acc)[2], int tg, int p0, int hw) {
+    const float v0 = (p0 + pix) < hw ? 1.f : 0.f, v1 = (p0 + 32 + pix) < hw ? 1.f : 0.f;
     float s[16], ss[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -173,22 +208,24 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
       s[i] = y0 + y1;
       ss[i] = y0 * y0 + y1 * y1;
     }
-    // channel of acc index i = 8*(i>>2) + 4*h + (i&3).  Reduce to groups of 2^gshift channels.
-    // gshift <= 2: (i&3)>>gshift-subgroups stay lane-local per h; gshift == 3: whole g, both h.
-    const int ngl = 32 >> a.gshift;  // groups in this wave's tile
-    float* dst = a.part + ((size_t)t * (HC >> a.gshift) + (size_t)ct * ngl) * 2;
+    const int ngl = 32 >> a.gshift;  // groups in this wave's 32-channel tile
+    float* dst = a.part + ((size_t)tg * (HC >> a.gshift) + (size_t)ct * ngl) * 2;
     if (a.gshift >= 3) {
       const int gg = 1 << (a.gshift - 3);  // 8-channel blocks per group
+      float b8[4], b8q[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float x = s[4 * g] + s[4 * g + 1] + s[4 * g + 2] + s[4 * g + 3];
-        float xx = ss[4 * g] + ss[4 * g + 1] + ss[4 * g + 2] + ss[4 * g + 3];
-        x = wave_sum_f(x);
-        xx = wave_sum_f(xx);
-        if (lane == 0) { atomicAdd(dst + (g / gg) * 2, x); atomicAdd(dst + (g / gg) * 2 + 1, xx); }
+        b8[g] = wave_sum_f(s[4 * g] + s[4 * g + 1] + s[4 * g + 2] + s[4 * g + 3]);
+        b8q[g] = wave_sum_f(ss[4 * g] + ss[4 * g + 1] + ss[4 * g + 2] + ss[4 * g + 3]);
+      }
+      if (lane < ngl) {            // lane k owns group k: sum its gg 8-channel blocks
+        float x = 0.f, xx = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (g / gg == lane) { x += b8[g]; xx += b8q[g]; }
+        *reinterpret_cast<float2*>(dst + lane * 2) = make_float2(x, xx);
       }
     } else {
-      // groups of 4 (gshift 2), 2 or 1 channels: reduce over the 32 pixel lanes of each half
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float x = s[i], xx = ss[i];
@@ -203,117 +240,171 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
     }
   };
 
-  // ---- persistent tile loop
-  const int nblk = gridDim.x;
-  int t = blockIdx.x, buf = 0;
-  if (t < a.ntiles) issue_dma(t, 0);
-  for (; t < a.ntiles; t += nblk, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- persistent loop over a CONTIGUOUS range of this launch's tiles (same level / image for
+  //      long stretches: weights and GN tables reload rarely), input tiles NB-1 ahead in flight
+  const int per = (a.grp_ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int u0 = blockIdx.x * per;
+  const int u1 = (u0 + per) < a.grp_ntiles ? (u0 + per) : a.grp_ntiles;
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i)
+    if (u0 + i < u1) issue_dma(u0 + i, i);
+  for (int u = u0; u < u1; ++u) {
+    const int slot = (u - u0) % NB;
+    const TileId t = tile_of(u);
+    const HeadLevel& L = a.lv[t.l];
+    if (t.l != cur_level || t.n != cur_n) {
+      // (level, image) switch: everything in flight is drained by the compiler's own waits here
+      __syncthreads();                      // previous tile's readers of s_ab / s_bf are done
+      if (t.l != cur_level) load_level(t.l);
+      if constexpr (PASS >= 2) {
+        for (int i = threadIdx.x; i < 256 * (PASS - 1); i += 256) {
+          const float* src = (i < 256 ? a.ab1 : a.ab2) + ((size_t)t.l * a.N + t.n) * HC * 2;
+          s_ab[i] = src[i & 255];
+        }
+      }
+      cur_level = t.l; cur_n = t.n;
+    }
+    if (u + NB - 1 < u1) {
+      issue_dma(u + NB - 1, (u - u0 + NB - 1) % NB);
+      // loads retire in order: at most (NB-1)*KD younger DMA instructions may still be in flight
+      if constexpr (NB == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    if (t + nblk < a.ntiles) issue_dma(t + nblk, buf ^ 1);
-    const int n = t / a.tiles_per_img;
-    const int p0 = (t - n * a.tiles_per_img) * TPX;
+    static_assert((NB == 4 && KD == 2) || (NB == 2 && KD == 4), "vmcnt immediates above assume these");
 
     f32x16 acc[2];
     // neck: relu(Wn x + bn)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = bnv[i]; acc[1][i] = bnv[i]; }
-    stage(acc, wn, xbuf0 + buf * XBYTES, std::integral_constant<int, CPPX>{}, NKN);
-    store_tile(acc, bufA, nullptr, nullptr);
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *reinterpret_cast<const float4*>(s_bn + ct * 32 + 8 * g + 4 * h);
+      acc[0][4 * g] = b4.x; acc[0][4 * g + 1] = b4.y; acc[0][4 * g + 2] = b4.z; acc[0][4 * g + 3] = b4.w;
+      acc[1][4 * g] = b4.x; acc[1][4 * g + 1] = b4.y; acc[1][4 * g + 2] = b4.z; acc[1][4 * g + 3] = b4.w;
+    }
+    stage(acc, wn, xring + slot * XBYTES, std::integral_constant<int, CPPX>{});
+    store_tile(acc, bufA, nullptr);
     __syncthreads();
     // conv1 (no bias: norm follows, lfd_head.py:97)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-    stage(acc, w1, bufA, std::integral_constant<int, HC / 8>{}, NKH);
+    stage(acc, w1, bufA, std::integral_constant<int, HC / 8>{});
     if constexpr (PASS == 1) {
-      write_stats(acc, t, p0);
+      write_stats(acc, t.tg, t.p0, L.hw);
     } else {
-    float sc[16], sh[16];
-    {
-      const float* ab = a.ab1 + ((size_t)n * HC + ct * 32 + 4 * h) * 2;
+      store_tile(acc, bufB, s_ab);
+      __syncthreads();
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+      stage(acc, w2, bufB, std::integral_constant<int, HC / 8>{});
+      if constexpr (PASS == 2) {
+        write_stats(acc, t.tg, t.p0, L.hw);
+      } else {
+        store_tile(acc, bufA, s_ab + 256);   // bufA's neck tile was fully consumed before the last barrier
+        __syncthreads();
+        if (f_active) {
+          f32x16 fa;
+          {
+            const float* bp = s_bf + fct * 32 + 4 * h;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sc[4 * g + j] = ab[(8 * g + j) * 2]; sh[4 * g + j] = ab[(8 * g + j) * 2 + 1]; }
-      }
-    }
-    store_tile(acc, bufB, sc, sh);
-    __syncthreads();
+            for (int g = 0; g < 4; ++g) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+              fa[4 * g] = b4.x; fa[4 * g + 1] = b4.y; fa[4 * g + 2] = b4.z; fa[4 * g + 3] = b4.w;
+            }
+          }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-    stage(acc, w2, bufB, std::integral_constant<int, HC / 8>{}, NKH);
-    if constexpr (PASS == 2) {
-      write_stats(acc, t, p0);
-    } else {
-    {
-      const float* ab = a.ab2 + ((size_t)n * HC + ct * 32 + 4 * h) * 2;
+          for (int q = 0; q < NKH; ++q) {
+            const half8 xf = *reinterpret_cast<const half8*>(bufA + lds_addr<HC / 8>(fpt * 32 + pix, 2 * q + h));
+            fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wf[(fct * NKH + q) * 64 + lane], xf, fa, 0, 0, 0);
+          }
+          const int p = t.p0 + fpt * 32 + pix;
+          if (p < L.hw) {
+            const size_t row = (size_t)t.n * a.P + L.p_off + p;
+            // final rows: [reg x reg_rows][cls x cls_rows]; lane (pixel, h) holds rows 8g + 4h + j
+            if (a.reg_rows == 4 && fct == 0 && h == 0)
+              *reinterpret_cast<float4*>(a.out_reg + row * 4) =
+                  make_float4(fa[0] * scale, fa[1] * scale, fa[2] * scale, fa[3] * scale);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sc[4 * g + j] = ab[(8 * g + j) * 2]; sh[4 * g + j] = ab[(8 * g + j) * 2 + 1]; }
-      }
-    }
-    store_tile(acc, bufA, sc, sh);   // bufA's neck tile was fully consumed before the last barrier
-    __syncthreads();
-    if (f_active) {
-      f32x16 fa;
-      {
-        const float* bp = a.bf + fct * 32 + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
-          fa[4 * g] = b4.x; fa[4 * g + 1] = b4.y; fa[4 * g + 2] = b4.z; fa[4 * g + 3] = b4.w;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < NKH; ++q) {
-        const half8 xf = *reinterpret_cast<const half8*>(bufA + lds_addr<HC / 8>(fpt * 32 + pix, 2 * q + h));
-        fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[q], xf, fa, 0, 0, 0);
-      }
-      const int p = p0 + fpt * 32 + pix;
-      if (p < a.HW) {
-        const size_t row = (size_t)n * a.P + a.p_off + p;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int ch = fct * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-          if (ch < a.split) a.out_cls[row * a.CC + ch] = fa[i];
-          else if (ch < a.fcout) a.out_reg[row * 4 + (ch - a.split)] = fa[i] * scale;
+            for (int i = 0; i < 16; ++i) {
+              const int ch = fct * 32 + 8 * (i >> 2) + 4 * h + (i & 3) - a.reg_rows;
+              if (ch >= 0 && ch < a.cls_rows) a.out_cls[row * a.CC + ch] = fa[i];
+            }
+          }
         }
       }
     }
-    }  // PASS == 3
-    }  // PASS >= 2
   }
 }
 
-// per (image, group): combine tile partials in fp64, emit per-channel (scale, shift)
-__global__ void k_gn_finalize(const float* part, int tiles_per_img, int ngroups, int gsize, int hw,
-                              const float* gamma, const float* beta, float eps, float* ab /*[N][128][2]*/) {
-  const int n = blockIdx.x;
-  const int g = threadIdx.x;
-  if (g >= ngroups) return;
-  double s = 0.0, ss = 0.0;
-  for (int t = 0; t < tiles_per_img; ++t) {
-    const float* p = part + ((size_t)(n * tiles_per_img + t) * ngroups + g) * 2;
-    s += (double)p[0];
-    ss += (double)p[1];
-  }
-  const double cnt = (double)hw * gsize;
-  const double mean = s / cnt;
-  double var = ss / cnt - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  for (int j = 0; j < gsize; ++j) {
-    const int c = g * gsize + j;
-    const double sc = (double)gamma[c] * rstd;
-    ab[((size_t)n * HC + c) * 2] = (float)sc;
-    ab[((size_t)n * HC + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
+// per (level, image, group): combine tile partials in fp64 (fixed order), emit per-channel (scale, shift)
+struct FinalizeArgs {
+  int tile_start[LFD_MAX_LEVELS], tiles_per_img[LFD_MAX_LEVELS], hw[LFD_MAX_LEVELS];
+  const float* gamma[LFD_MAX_LEVELS];
+  const float* beta[LFD_MAX_LEVELS];
+  const float* part;
+  float* ab;   // [L][N][128][2]
+  int N, ngroups, gsize;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
+  // block = (image n, level l); thread = (tile lane tl = tid / 32, value v = tid % 32) over the
+  // [tiles][ngroups*2] partial rows (ngroups*2 <= 256/8 ... handled by looping v): coalesced row
+  // reads, 8 tile lanes in flight, fp64 accumulation, fixed-order LDS combine -> deterministic.
+  __shared__ double sm[8][64];
+  const int n = blockIdx.x, l = blockIdx.y;
+  const int nv = f.ngroups * 2;                  // values per tile row
+  const int t0 = f.tile_start[l] + n * f.tiles_per_img[l];
+  const int tl = threadIdx.x >> 5, v0 = threadIdx.x & 31;
+  for (int vb = 0; vb < nv; vb += 32) {          // 32 values per sweep
+    const int v = vb + v0;
+    double acc = 0.0;
+    if (v < nv) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const int T = f.tiles_per_img[l];
+      int t = tl;
+      for (; t + 24 < T; t += 32) {     // 4 independent loads in flight per thread
+        a0 += (double)f.part[(size_t)(t0 + t) * nv + v];
+        a1 += (double)f.part[(size_t)(t0 + t + 8) * nv + v];
+        a2 += (double)f.part[(size_t)(t0 + t + 16) * nv + v];
+        a3 += (double)f.part[(size_t)(t0 + t + 24) * nv + v];
+      }
+      for (; t < T; t += 8) a0 += (double)f.part[(size_t)(t0 + t) * nv + v];
+      acc = (a0 + a1) + (a2 + a3);
+    }
+    sm[tl][v0] = acc;
+    __syncthreads();
+    if (tl == 0 && v < nv) {
+      double s = 0.0;
+      for (int i = 0; i < 8; ++i) s += sm[i][v0];
+      sm[0][32 + v0] = s;                          // totals of this sweep: (sum, sumsq) interleaved
+    }
+    __syncthreads();
+    // threads 0..15 of the sweep: one group each (pair v0 = 2*g', 2*g'+1)
+    if (threadIdx.x < 16 && (vb / 2 + threadIdx.x) < f.ngroups) {
+      const int g = vb / 2 + threadIdx.x;
+      const double s = sm[0][32 + 2 * threadIdx.x], ss = sm[0][32 + 2 * threadIdx.x + 1];
+      const double cnt = (double)f.hw[l] * f.gsize;
+      const double mean = s / cnt;
+      double var = ss / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double rstd = 1.0 / sqrt(var + (double)f.eps);
+      for (int j = 0; j < f.gsize; ++j) {
+        const int c = g * f.gsize + j;
+        const double sc = (double)f.gamma[l][c] * rstd;
+        float* o = f.ab + (((size_t)l * f.N + n) * HC + c) * 2;
+        o[0] = (float)sc;
+        o[1] = (float)((double)f.beta[l][c] - mean * sc);
+      }
+    }
+    __syncthreads();
   }
 }
 
 template <int CIN, int PASS, int FT>
-int launch_head(HeadArgs a, hipStream_t st) {
-  constexpr int LDS = 2 * TPX * CIN * 2 + 2 * TPX * HC * 2;
+int launch_head(const HeadArgs& a, hipStream_t st) {
+  constexpr int LDS = 32768 + 2 * TPX * HC * 2 + 512 * 4 + 64 * 4 + 128 * 4 + (PASS == 3 ? FT * 8 * 1024 : 0);
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<CIN, PASS, FT>),
@@ -321,7 +412,7 @@ int launch_head(HeadArgs a, hipStream_t st) {
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
-  int blocks = a.ntiles < 512 ? a.ntiles : 512;
+  int blocks = a.grp_ntiles < 512 ? a.grp_ntiles : 512;
   if (blocks < 1) return LFD_OK;
   hipLaunchKernelGGL((k_head<CIN, PASS, FT>), dim3(blocks), dim3(256), LDS, st, a);
   LFD_CHECK_LAUNCH();
@@ -336,56 +427,105 @@ int dispatch_head(int pass, int ft, const HeadArgs& a, hipStream_t st) {
   return LFD_ERR_INVALID_ARGUMENT;
 }
 
+int fill_levels(const lfd_head_desc_t* d, int* tile_start, int* tiles_per_img, int* ntiles) {
+  if (!d || d->num_levels < 1 || d->num_levels > LFD_MAX_LEVELS || d->n < 1) return LFD_ERR_INVALID_ARGUMENT;
+  int t = 0;
+  for (int i = 0; i < d->num_levels; ++i) {
+    if (d->level_hw[i] < 0) return LFD_ERR_INVALID_ARGUMENT;
+    tile_start[i] = t;
+    tiles_per_img[i] = (d->level_hw[i] + TPX - 1) / TPX;
+    t += tiles_per_img[i] * d->n;
+  }
+  *ntiles = t;
+  return LFD_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-size_t lfd_head_partial_floats(int32_t n, int32_t hw, int32_t num_groups) {
-  const int tiles = (hw + TPX - 1) / TPX;
-  return (size_t)n * tiles * num_groups * 2;
+size_t lfd_head_partial_floats(const lfd_head_desc_t* d) {
+  int ts[LFD_MAX_LEVELS], tp[LFD_MAX_LEVELS], nt = 0;
+  if (fill_levels(d, ts, tp, &nt) != LFD_OK || d->num_groups < 1) return 0;
+  return (size_t)nt * d->num_groups * 2;
 }
 
-int lfd_head_level_f16(const lfd_head_desc_t* d, int32_t pass, const void* x, const void* wn_packed,
-                       const float* bn, const void* w1_packed, const void* w2_packed, const void* wf_packed,
-                       const float* bf, const float* ab1, const float* ab2, float* partial, float* out_cls,
-                       float* out_reg, const float* scale, const void* zeros, lfd_stream_t stream) {
+int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_level_ptrs_t* lv,
+                         const float* ab1, const float* ab2, float* partial, float* out_cls, float* out_reg,
+                         const void* zeros, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!d || !x || !wn_packed || !bn || !w1_packed || !zeros) return LFD_ERR_INVALID_ARGUMENT;
+  if (!d || !lv || !zeros) return LFD_ERR_INVALID_ARGUMENT;
   if (d->head_channels != HC) return LFD_ERR_UNSUPPORTED;
-  if (d->cin != 64 && d->cin != 128) return LFD_ERR_UNSUPPORTED;
-  const int gsize = HC / d->num_groups;
+  const int gsize = d->num_groups > 0 ? HC / d->num_groups : 0;
   if (d->num_groups < 1 || d->num_groups > HC || gsize * d->num_groups != HC || (gsize & (gsize - 1)) || gsize > 32)
     return LFD_ERR_UNSUPPORTED;
   int gshift = 0;
   while ((1 << gshift) < gsize) ++gshift;
   HeadArgs a{};
-  a.x = (const _Float16*)x; a.wn = (const half8*)wn_packed; a.bn = bn; a.w1 = (const half8*)w1_packed;
-  a.w2 = (const half8*)w2_packed; a.wf = (const half8*)wf_packed; a.bf = bf; a.ab1 = ab1; a.ab2 = ab2;
-  a.part = partial; a.out_cls = out_cls; a.out_reg = out_reg; a.scale = scale;
-  a.N = d->n; a.HW = d->hw; a.P = d->total_points; a.p_off = d->point_offset; a.CC = d->cls_channels;
-  a.split = d->final_split; a.fcout = d->final_cout; a.gshift = gshift;
-  a.tiles_per_img = (d->hw + TPX - 1) / TPX;
-  a.ntiles = d->n * a.tiles_per_img;
-  a.zeros = (const _Float16*)zeros;
+  int ts[LFD_MAX_LEVELS], tp[LFD_MAX_LEVELS];
+  int rc = fill_levels(d, ts, tp, &a.ntiles);
+  if (rc != LFD_OK) return rc;
+  a.nlev = d->num_levels;
+  for (int i = 0; i < d->num_levels; ++i) {
+    if (d->level_cin[i] != 64 && d->level_cin[i] != 128) return LFD_ERR_UNSUPPORTED;
+    if (!lv[i].x || !lv[i].wn_packed || !lv[i].bn || !lv[i].w1_packed) return LFD_ERR_INVALID_ARGUMENT;
+    if (pass >= 2 && !lv[i].w2_packed) return LFD_ERR_INVALID_ARGUMENT;
+    if (pass == 3 && (!lv[i].wf_packed || !lv[i].bf)) return LFD_ERR_INVALID_ARGUMENT;
+    HeadLevel& L = a.lv[i];
+    L.x = (const _Float16*)lv[i].x; L.wn = (const half8*)lv[i].wn_packed; L.bn = lv[i].bn;
+    L.w1 = (const half8*)lv[i].w1_packed; L.w2 = (const half8*)lv[i].w2_packed;
+    L.wf = (const half8*)lv[i].wf_packed; L.bf = lv[i].bf; L.scale = lv[i].scale;
+    L.cin = d->level_cin[i]; L.hw = d->level_hw[i]; L.p_off = d->level_point_offset[i];
+    L.tile_start = ts[i]; L.tiles_per_img = tp[i];
+  }
+  a.ab1 = ab1; a.ab2 = ab2; a.part = partial; a.out_cls = out_cls; a.out_reg = out_reg;
+  a.N = d->n; a.P = d->total_points; a.CC = d->cls_channels; a.reg_rows = d->final_reg_rows; a.cls_rows = d->final_cls_rows;
+  a.gshift = gshift; a.zeros = (const _Float16*)zeros;
   if (pass < 3) {
     if (!partial) return LFD_ERR_INVALID_ARGUMENT;
-    if (hipMemsetAsync(partial, 0, sizeof(float) * lfd_head_partial_floats(d->n, d->hw, d->num_groups), st) != hipSuccess)
+    if (gshift < 3 &&
+        hipMemsetAsync(partial, 0, sizeof(float) * lfd_head_partial_floats(d), st) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
   }
-  if (pass >= 2 && (!ab1 || !w2_packed)) return LFD_ERR_INVALID_ARGUMENT;
-  if (pass == 3 && (!ab2 || !wf_packed || !bf || !out_cls || !out_reg)) return LFD_ERR_INVALID_ARGUMENT;
-  const int ft = (d->final_cout + 31) / 32;
+  if (pass >= 2 && !ab1) return LFD_ERR_INVALID_ARGUMENT;
+  if (pass == 3 && (!ab2 || !out_cls || !out_reg)) return LFD_ERR_INVALID_ARGUMENT;
+  if ((d->final_reg_rows != 0 && d->final_reg_rows != 4) || d->final_cls_rows < 0) return LFD_ERR_INVALID_ARGUMENT;
+  const int ft = (d->final_reg_rows + d->final_cls_rows + 31) / 32;
   if (pass == 3 && (ft < 1 || ft > 2)) return LFD_ERR_UNSUPPORTED;
-  return d->cin == 64 ? dispatch_head<64>(pass, ft, a, st) : dispatch_head<128>(pass, ft, a, st);
+  if (pass < 1 || pass > 3) return LFD_ERR_INVALID_ARGUMENT;
+  // one launch per tap-channel class (64 / 128): homogeneous tiles, compile-time ring geometry
+  for (int cin = 64; cin <= 128; cin += 64) {
+    a.grp_n = 0;
+    a.grp_ntiles = 0;
+    for (int i = 0; i < d->num_levels; ++i)
+      if (d->level_cin[i] == cin) {
+        a.grp_levels[a.grp_n] = i;
+        a.grp_tile_start[a.grp_n] = a.grp_ntiles;
+        a.grp_ntiles += tp[i] * d->n;
+        ++a.grp_n;
+      }
+    if (a.grp_ntiles == 0) continue;
+    rc = cin == 64 ? dispatch_head<64>(pass, ft, a, st) : dispatch_head<128>(pass, ft, a, st);
+    if (rc != LFD_OK) return rc;
+  }
+  return LFD_OK;
 }
 
-int lfd_groupnorm_finalize(const float* partial, int32_t n, int32_t hw, int32_t num_groups, const float* gamma,
-                           const float* beta, float eps, float* ab, lfd_stream_t stream) {
+int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const float* const* gamma,
+                           const float* const* beta, float eps, float* ab, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!partial || !gamma || !beta || !ab || n < 1 || num_groups < 1 || num_groups > HC) return LFD_ERR_INVALID_ARGUMENT;
-  const int tiles = (hw + TPX - 1) / TPX;
-  hipLaunchKernelGGL(k_gn_finalize, dim3(n), dim3(128), 0, st, partial, tiles, num_groups, HC / num_groups, hw, gamma,
-                     beta, eps, ab);
+  if (!d || !partial || !gamma || !beta || !ab) return LFD_ERR_INVALID_ARGUMENT;
+  FinalizeArgs f{};
+  int nt = 0;
+  int rc = fill_levels(d, f.tile_start, f.tiles_per_img, &nt);
+  if (rc != LFD_OK) return rc;
+  if (d->num_groups < 1 || d->num_groups > HC || HC % d->num_groups) return LFD_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < d->num_levels; ++i) {
+    if (!gamma[i] || !beta[i]) return LFD_ERR_INVALID_ARGUMENT;
+    f.hw[i] = d->level_hw[i]; f.gamma[i] = gamma[i]; f.beta[i] = beta[i];
+  }
+  f.part = partial; f.ab = ab; f.N = d->n; f.ngroups = d->num_groups; f.gsize = HC / d->num_groups; f.eps = eps;
+  hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels), dim3(256), 0, st, f);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
   constexpr int PG = 4 / NCT, PT = 2, TW = 32, TH = PG * PT;
   constexpr int IH = 2 * TH + 1, IW = 2 * TW + 1;
   constexpr int RS = ((IW * 3 + 1) / 2) * 2;           // halfs per LDS input row (even)
-  constexpr int IN_HALFS = IH * RS + 8;
+  constexpr int OUT_BYTES = TH * TW * C * 2;
+  constexpr int IN_HALFS = (!TAIL && OUT_BYTES / 2 > IH * RS + 8) ? OUT_BYTES / 2 : IH * RS + 8;
   constexpr int MCPP = C / 8, MPIXB = C * 2, MPPR = 16 / MCPP;
   __shared__ __attribute__((aligned(16))) _Float16 s_in[IN_HALFS];
   __shared__ __attribute__((aligned(16))) char s_mid[TAIL ? (TH * TW * MPIXB) : 16];
@@ -156,18 +157,33 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
     }
   }
 
+  // ---- epilogue: ReLU -> fp16 -> LDS (swizzled [pixel][C]) -> full-line 16-byte coalesced stores.
+  // (8-byte per-lane stores straight from the accumulator layout touch 32 lines per instruction and
+  // are store-issue bound; through LDS every 8 (C=64) / 4 (C=32) consecutive lanes write one whole
+  // pixel line.)
+  if (TAIL) __syncthreads();   // all waves finished reading s_mid for the 1x1
+  char* s_out = TAIL ? s_mid : reinterpret_cast<char*>(s_in);
+  if (!TAIL) __syncthreads();  // (no-tail variant reuses the input tile storage)
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    const int oy = ty0 * TH + pg * PT + pt, ox = tx0 * TW + pix;
+    const int pb = (pg * PT + pt) * 32 + pix;
+    const int fm = (pb / MPPR) % MCPP;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (_Float16)fmaxf(acc[pt][4 * g + j], 0.f);
+      *reinterpret_cast<half4*>(s_out + pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h) = v;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TH * TW * MCPP; i += 256) {
+    const int pb = i / MCPP, c = i - pb * MCPP;
+    const int oy = ty0 * TH + pb / TW, ox = tx0 * TW + (pb % TW);
     if (oy < a.OH && ox < a.OW) {
-      _Float16* o = a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * C + ct * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        half4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (_Float16)fmaxf(acc[pt][4 * g + j], 0.f);
-        *reinterpret_cast<half4*>(o + 8 * g) = v;
-      }
+      const int fm = (pb / MPPR) % MCPP;
+      const uint4 v = *reinterpret_cast<const uint4*>(s_out + pb * MPIXB + ((c ^ fm) * 16));
+      *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * C + c * 8) = v;
     }
   }
 }

@@ -36,9 +36,16 @@ class ConvDesc(C.Structure):
 
 class HeadDesc(C.Structure):
     """lfd_head_desc_t"""
-    _fields_ = [('n', C.c_int32), ('hw', C.c_int32), ('cin', C.c_int32), ('head_channels', C.c_int32),
-                ('num_groups', C.c_int32), ('total_points', C.c_int32), ('point_offset', C.c_int32),
-                ('cls_channels', C.c_int32), ('final_cout', C.c_int32), ('final_split', C.c_int32)]
+    _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32), ('level_hw', C.c_int32 * MAX_LEVELS),
+                ('level_cin', C.c_int32 * MAX_LEVELS), ('level_point_offset', C.c_int32 * MAX_LEVELS),
+                ('head_channels', C.c_int32), ('num_groups', C.c_int32), ('total_points', C.c_int32),
+                ('cls_channels', C.c_int32), ('final_reg_rows', C.c_int32), ('final_cls_rows', C.c_int32)]
+
+
+class HeadLevelPtrs(C.Structure):
+    """lfd_head_level_ptrs_t"""
+    _fields_ = [('x', C.c_void_p), ('wn_packed', C.c_void_p), ('bn', C.c_void_p), ('w1_packed', C.c_void_p),
+                ('w2_packed', C.c_void_p), ('wf_packed', C.c_void_p), ('bf', C.c_void_p), ('scale', C.c_void_p)]
 
 
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
@@ -60,9 +67,9 @@ _SIGNATURES = {
     'lfd_iou_loss_fwd_f32': (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     'lfd_iou_loss_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
-    'lfd_head_partial_floats': (_SZ, [_I32, _I32, _I32]),
-    'lfd_head_level_f16': (C.c_int, [C.POINTER(HeadDesc), _I32] + [_P] * 15),
-    'lfd_groupnorm_finalize': (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _F, _P, _P]),
+    'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),
+    'lfd_head_forward_f16': (C.c_int, [C.POINTER(HeadDesc), _I32, C.POINTER(HeadLevelPtrs), _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_groupnorm_finalize': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P, _P]),
     'lfd_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

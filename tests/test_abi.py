@@ -44,7 +44,10 @@ def test_workspace_queries_are_pure_host_functions():
     d.max_candidates = 16
     assert l.lfd_detect_workspace_bytes(ctypes.byref(d), 2) > 0
     assert l.lfd_conv_packed_weight_halfs(64, 64, 3) == 64 * 64 * 9
-    assert l.lfd_head_partial_floats(2, 130, 16) == 2 * 3 * 16 * 2
+    hd = _lib.HeadDesc()
+    hd.n, hd.num_levels, hd.num_groups = 2, 2, 16
+    hd.level_hw[0], hd.level_hw[1] = 130, 64
+    assert l.lfd_head_partial_floats(ctypes.byref(hd)) == 2 * (3 + 1) * 16 * 2
 
 
 def test_invalid_arguments_are_status_codes_not_crashes():

@@ -120,12 +120,12 @@ def test_engine_plan_structure_on_cpu():
     assert (n3, n1) == (1 + 2 * 11, 4)          # 11 FasterBlocks, 4 downsample branches
     assert len(plan.taps) == 5 and len(plan.levels) == 5
     assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
-    assert all(len(lv.towers) == 1 and lv.towers[0].fcout == 5 and lv.towers[0].split == 1 for lv in plan.levels)
+    assert all(len(lv.towers) == 1 and lv.towers[0].reg_rows == 4 and lv.towers[0].cls_rows == 1 for lv in plan.levels)
     t = configs.build_model('TT100K_LFD_L')
     t.eval()
     plan = engine.EnginePlan(t._backbone, t._neck, t._head, torch.device('cpu'))
     assert all(len(lv.towers) == 2 for lv in plan.levels)
-    assert plan.levels[0].towers[0].fcout == 46 and plan.levels[0].towers[1].split == 0
+    assert plan.levels[0].towers[0].cls_rows == 46 and plan.levels[0].towers[1].reg_rows == 4
 
 
 def test_unsupported_configs_fail_loudly():
