@@ -66,12 +66,23 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
         c['bytes'] += nbytes
 
     n = st.n
-    c0, w1, b1, w2, b2 = plan.stem_first
-    so = st.bufs[plan.stem_out]
-    us = timed(lambda: check(l.lfd_stem_conv_f16(ptr(x), fmt, n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
-                                                 ptr(so), stream_ptr()), 'stem'))
-    add('stem_3x3s2_3toC+1x1 (k_stem)', us, conv_flops(n, so.shape[1], so.shape[2], 3, c0, 3) +
-        (conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1) if w2 is not None else 0), x.numel() * x.element_size() + so.numel() * 2)
+    if plan.stem_fused is not None:
+        c0, w1, b1, w2, b2, w3, b3, w4, b4, dst = plan.stem_fused
+        so = st.bufs[dst]
+        h1, w1_ = (st.h + 1) // 2, (st.w + 1) // 2
+        us = timed(lambda: check(l.lfd_stem_faster_fused_f16(ptr(x), fmt, n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2),
+                                                             ptr(b2), ptr(w3), ptr(b3), ptr(w4), ptr(b4), ptr(so),
+                                                             stream_ptr()), 'stem'))
+        fl = (conv_flops(n, h1, w1_, 3, c0, 3) + conv_flops(n, h1, w1_, c0, c0, 1) +
+              conv_flops(n, so.shape[1], so.shape[2], c0, c0, 3) + conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1))
+        add('whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem_fused)', us, fl, x.numel() * x.element_size() + so.numel() * 2)
+    else:
+        c0, w1, b1, w2, b2 = plan.stem_first
+        so = st.bufs[plan.stem_out]
+        us = timed(lambda: check(l.lfd_stem_conv_f16(ptr(x), fmt, n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                                     ptr(so), stream_ptr()), 'stem'))
+        add('stem_3x3s2_3toC+1x1 (k_stem)', us, conv_flops(n, so.shape[1], so.shape[2], 3, c0, 3) +
+            (conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1) if w2 is not None else 0), x.numel() * x.element_size() + so.numel() * 2)
     for c in plan.convs:
         src, dst = st.bufs[c.src], st.bufs[c.dst]
         d = _lib.ConvDesc(n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),

@@ -185,6 +185,16 @@ LFD_API int lfd_stem_conv_f16(const void* in, int32_t in_format, int32_t n, int3
                               int32_t channels, const void* w1_packed, const float* b1,
                               const void* w2_packed, const float* b2, void* out, lfd_stream_t stream);
 
+/* The whole 'faster' stem (lfd_resnet.py:376-413) in one kernel: conv3x3 s2 (3->C), conv1x1, conv3x3 s2
+ * (C->C), conv1x1, each + BN + ReLU.  The stride-2 intermediate (the largest activation of the
+ * network) is produced tile-by-tile into LDS and never written to HBM (csrc/stem_fused.hip).
+ * out: NHWC fp16 [n, ceil(ceil(h/2)/2), ceil(ceil(w/2)/2), channels]; channels in {32, 64}. */
+LFD_API int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w,
+                                      int32_t channels, const void* w1_packed, const float* b1,
+                                      const void* w2_packed, const float* b2, const void* w3_packed,
+                                      const float* b3, const void* w4_packed, const float* b4, void* out,
+                                      lfd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Neck + head of ALL pyramid levels.  Replaces SimpleNeck.forward (simple_neck.py:67-74),
  * LFDHead.forward (lfd_head.py:164-185: GroupNorm towers + cls/reg convs + Scale) and the

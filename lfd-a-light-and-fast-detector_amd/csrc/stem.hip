@@ -60,29 +60,56 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int ct = wave % NCT, pg = wave / NCT;
   const int h = lane >> 5, pix = lane & 31;
-  const int t = blockIdx.x;
   const int tiles_per_img = a.tiles_x * a.tiles_y;
-  const int n = t / tiles_per_img;
-  const int tr = t - n * tiles_per_img;
-  const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
-  const int gy0 = ty0 * TH * 2 - 1, gx0 = tx0 * TW * 2 - 1;
+  const int ntiles = a.N * tiles_per_img;
+  constexpr int NE = IH * IW * 3;
+  constexpr int NIT = (NE + 255) / 256;
 
-  // ---- stage the raw input tile (zero padded) into LDS
-  for (int i = threadIdx.x; i < IH * IW * 3; i += 256) {
-    const int iy = i / (IW * 3), e = i - iy * (IW * 3);
-    const int ix = e / 3, c = e - ix * 3;
-    const int gy = gy0 + iy, gx = gx0 + ix;
-    _Float16 v = (_Float16)0.f;
-    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = load_px<FMT>(a.in, n, a.H, a.W, gy, gx, c);
-    s_in[iy * RS + e] = v;
-  }
+  // persistent weights
   const half8 w1a = a.w1[(ct * 2 + 0) * 64 + lane], w1b = a.w1[(ct * 2 + 1) * 64 + lane];
   half8 w2r[TAIL ? C / 16 : 1];
   if (TAIL) {
 #pragma unroll
     for (int q = 0; q < C / 16; ++q) w2r[q] = a.w2[(ct * (C / 16) + q) * 64 + lane];
   }
+
+  // raw-tile fetch into registers: unconditional loads from clamped addresses + select (a branch
+  // around a load makes the compiler wait for each element separately).  The NEXT tile's fetch is
+  // issued before the current tile's compute, so its HBM round trip hides under the MFMA/epilogue work.
+  _Float16 rv[NIT];
+  auto fetch = [&](int t) {
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * TH * 2 - 1, gx0 = tx0 * TW * 2 - 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = it * 256 + threadIdx.x;
+      const int iy = i / (IW * 3), e = i - iy * (IW * 3);
+      const int ix = e / 3, c = e - ix * 3;
+      const int gy = gy0 + iy, gx = gx0 + ix;
+      const bool ok = i < NE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      const _Float16 v = load_px<FMT>(a.in, n, a.H, a.W, cy, cx, c);
+      rv[it] = ok ? v : (_Float16)0.f;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+  const int n = t / tiles_per_img;
+  const int tr = t - n * tiles_per_img;
+  const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+  __syncthreads();   // previous tile's readers of s_in / s_mid are done
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + threadIdx.x;
+    const int iy = i / (IW * 3), e = i - iy * (IW * 3);
+    if (i < NE) s_in[iy * RS + e] = rv[it];
+  }
   __syncthreads();
+  if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
 
   f32x16 acc[PT];
   {
@@ -186,6 +213,7 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
       *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * C + c * 8) = v;
     }
   }
+  }  // persistent tile loop
 }
 
 template <int NCT, int FMT, bool TAIL>
@@ -195,7 +223,8 @@ int launch_stem(StemArgs a, hipStream_t st) {
   a.tiles_y = (a.OH + TH - 1) / TH;
   const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
   if (ntiles > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_stem<NCT, FMT, TAIL>), dim3((unsigned)ntiles), dim3(256), 0, st, a);
+  const unsigned blocks = ntiles < 2048 ? (unsigned)ntiles : 2048u;   // 8 resident workgroups per CU
+  hipLaunchKernelGGL((k_stem<NCT, FMT, TAIL>), dim3(blocks), dim3(256), 0, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

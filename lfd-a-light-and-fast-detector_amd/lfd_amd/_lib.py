@@ -67,6 +67,7 @@ _SIGNATURES = {
     'lfd_iou_loss_fwd_f32': (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     'lfd_iou_loss_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),
     'lfd_head_forward_f16': (C.c_int, [C.POINTER(HeadDesc), _I32, C.POINTER(HeadLevelPtrs), _P, _P, _P, _P, _P, _P, _P]),
     'lfd_groupnorm_finalize': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P, _P]),

@@ -161,6 +161,14 @@ class EnginePlan(object):
                 idx += 1
             cur = self._add_conv(cur, new_buf, cin, cout, k, s, True, w, b, tail=tail)
             idx += 1
+        # ---- whole 'faster' stem in one kernel when it has the fusable shape
+        self.stem_fused = None
+        import os
+        if (bb._stem_mode == 'faster' and c0 in (32, 64) and self.stem_first[3] is not None and len(self.convs) == 1
+                and self.convs[0].tail is not None and self.convs[0].cin == c0 and self.convs[0].cout == c0
+                and os.environ.get('LFD_FUSED_STEM') == '1'):   # opt-in: measured slower than the two-kernel stem
+            cv = self.convs.pop(0)
+            self.stem_fused = (c0,) + tuple(self.stem_first[1:]) + (cv.w, cv.b, cv.tail[0], cv.tail[1], cv.dst)
         # ---- stages
         self.taps = []
         for i, nblk in enumerate(bb._body_architecture):
@@ -307,11 +315,17 @@ class EnginePlan(object):
 
     # ---- execution
     def run_backbone(self, x, fmt, st):
-        c0, w1, b1, w2, b2 = self.stem_first
         l = lib()
         sp = stream_ptr()
-        check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
-                                  ptr(st.bufs[self.stem_out]), sp), 'lfd_stem_conv_f16')
+        if self.stem_fused is not None:
+            c0, w1, b1, w2, b2, w3, b3, w4, b4, dst = self.stem_fused
+            check(l.lfd_stem_faster_fused_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                              ptr(w3), ptr(b3), ptr(w4), ptr(b4), ptr(st.bufs[dst]), sp),
+                  'lfd_stem_faster_fused_f16')
+        else:
+            c0, w1, b1, w2, b2 = self.stem_first
+            check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                      ptr(st.bufs[self.stem_out]), sp), 'lfd_stem_conv_f16')
         z = ops.zero_line(self.device)
         for c in self.convs:
             src = st.bufs[c.src]
@@ -353,6 +367,8 @@ class _ShapeState(object):
         with torch.cuda.device(dev):
             dims = {}
             for b, sc in plan.buf_scale.items():
+                if plan.stem_fused is not None and b == plan.stem_out:
+                    continue      # the stride-2 stem intermediate never exists in HBM
                 hh, ww = h, w
                 s = sc
                 while s > 1:

@@ -113,7 +113,7 @@ def test_engine_plan_structure_on_cpu():
     m.eval()
     plan = engine.EnginePlan(m._backbone, m._neck, m._head, torch.device('cpu'))
     # stem pair 1 fused in the stem kernel, stem pair 2 = conv with a chained 1x1 tail
-    assert plan.stem_first[0] == 64 and plan.stem_first[3] is not None
+    assert plan.stem_first[0] == 64 and plan.stem_first[3] is not None and plan.stem_fused is None
     assert plan.convs[0].tail is not None and plan.convs[0].stride == 2 and plan.convs[0].ks == 3
     n3 = sum(1 for c in plan.convs if c.ks == 3)
     n1 = sum(1 for c in plan.convs if c.ks == 1)
