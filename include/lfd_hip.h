@@ -174,7 +174,7 @@ LFD_API size_t lfd_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t k
 LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, void* out,
                                 const void* w_packed, const float* bias, const void* residual,
                                 const void* tail_w_packed, const float* tail_bias,
-                                const void* zeros /* >=256 zero bytes */, lfd_stream_t stream);
+                                const void* zeros /* 4096-byte line: [0,2048) zero (read), [2048,4096) trash (written) */, lfd_stream_t stream);
 
 /* First stem unit: conv3x3 s2 (3 -> C) + BN + ReLU chained with conv1x1 (C -> C) + BN + ReLU
  * (lfd_resnet.py:356-374 'fast' stem; first half of the 'faster' stem :376-395).

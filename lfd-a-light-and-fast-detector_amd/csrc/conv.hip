@@ -34,7 +34,8 @@ struct ConvArgs {
   const _Float16* res;    // optional residual [N,OH,OW,COUT_OUT] (added before ReLU)
   const half8* w2;        // tail 1x1 packed weights [cout2_tile][CMID/16][64]
   const float* bias2;     // [COUT2]
-  const _Float16* zeros;  // >= 256 B of zeros (source of out-of-image pixels)
+  const _Float16* zeros;  // 4 KB line: bytes [0,2048) stay zero (source of out-of-image pixels),
+                          // bytes [2048,4096) are a write-only trash area for masked stores
   int N, H, W, OH, OW;
   int cout;    // main conv output channels
   int cout2;   // tail output channels (TAIL only)
@@ -83,7 +84,7 @@ __device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,7 +175,14 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
   for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1)) {
     if (C::NBUF == 2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // Tile t's DMA was issued one iteration ago; the only VMEM operations issued after it that can
+      // still be in flight are the previous tile's NST copy-out stores (every lane issues exactly NST
+      // of them, out-of-image lanes into a trash line).  vmcnt retires in order, so allowing NST
+      // outstanding operations waits for the DMA but not for the stores' write latency.
+      constexpr int NST = (C::PG * C::PT * 32 * NCT * 4) / 256;
+      static_assert(NST == 2 || NST == 4, "copy-out stores per thread");
+      if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __syncthreads();  // tile t landed for every wave; everyone is done with buffer buf^1 and `mid`
       if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
     } else {
@@ -191,8 +199,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 
     // residual (identity branch) of this lane's outputs: requested now, consumed in the epilogue,
     // so its latency hides under the contraction
-    half4 resv[C::PT][4];
-    if (!TAIL && a.res) {
+    // (compile-time RES: a run-time branch around these loads would make the compiler drain vmcnt --
+    //  and with it the just-issued DMA of the next tile -- before the contraction starts)
+    half4 resv[RES ? C::PT : 1][4];
+    if constexpr (RES) {
 #pragma unroll
       for (int pt = 0; pt < C::PT; ++pt) {
         const int oy = ty0 * C::TH + (pg * C::PT + pt) * C::RPT + oyl;
@@ -254,8 +264,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     } else {
       // weights streamed from L2 (128-channel layers on tiny maps): a ring of PW fragments stays
       // in flight across the (rolled) tap-row loop so the ~1 us L2 latency is paid once, not per row
-      constexpr int PW = 8;
       constexpr int RK = KS * C::NQ;              // k-steps per tap row
+      constexpr int PW = (RK % 12 == 0) ? 12 : 8; // fragments in flight: half a tap row (cold L2/MALL: ~2 us per round trip)
       static_assert(RK % PW == 0, "weight ring must wrap on a tap-row boundary");
       half8 wq[PW];
 #pragma unroll
@@ -268,7 +278,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         for (int j = 0; j < RK; ++j) {
           const int s = j / C::NQ, q = j % C::NQ;
           const half8 wf = wq[j % PW];
+          __builtin_amdgcn_sched_barrier(0);
           wq[j % PW] = wsrc[(size_t)((knext + j) < C::NK ? (knext + j) : (C::NK - 1)) * 64];
+          __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: left alone, the compiler sinks every
+                                               // load next to its use PW steps later (load -> vmcnt(0) -> MFMA)
           const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
 #pragma unroll
           for (int pt = 0; pt < C::PT; ++pt) {
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float x0 = acc[pt][4 * g + 0], x1 = acc[pt][4 * g + 1], x2 = acc[pt][4 * g + 2], x3 = acc[pt][4 * g + 3];
-        if (!TAIL && a.res) {
+        if constexpr (RES) {
           x0 += (float)resv[pt][g][0]; x1 += (float)resv[pt][g][1]; x2 += (float)resv[pt][g][2]; x3 += (float)resv[pt][g][3];
         }
         if (do_relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
@@ -362,18 +375,21 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         const int t32 = pb >> 5, p32 = pb & 31;
         const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
         const int ox = tx0 * C::TW + p32 % C::TW;
-        if (oy < a.OH && ox < a.OW) {
-          const int fo = (pb / OPPR) % OCPP;
-          const uint4 v = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
-          *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + cslice + c * 8) = v;
-        }
+        const int fo = (pb / OPPR) % OCPP;
+        const uint4 v = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
+        // exactly one store per lane and iteration (see the counted wait at the loop top): lanes of
+        // out-of-image pixels write into the trash half of the `zeros` line
+        _Float16* dst = (oy < a.OH && ox < a.OW)
+                            ? a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + cslice + c * 8
+                            : const_cast<_Float16*>(a.zeros) + 1024 + (threadIdx.x & 127) * 8;
+        *reinterpret_cast<uint4*>(dst) = v;
       }
     }
   }
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
-int launch_conv(const ConvArgs& a0, hipStream_t st) {
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES>
+int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   ConvArgs a = a0;
   a.tiles_x = (a.OW + C::TW - 1) / C::TW;
@@ -382,7 +398,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int cgroups = TAIL ? 1 : a.cout / (NCT * 32);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     attr_done = true;
@@ -390,9 +406,20 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   int blocks = 512 / cgroups;
   if (blocks > a.ntiles) blocks = a.ntiles;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL>), dim3(blocks, cgroups), dim3(256), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES>), dim3(blocks, cgroups), dim3(256), C::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
+}
+
+// residual variants are only instantiated for the stride-1 3x3 convs that close a residual block
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if constexpr (KS == 3 && S == 1 && !TAIL) {
+    if (a.res) return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, true>(a, st);
+  } else {
+    if (a.res) return LFD_ERR_UNSUPPORTED;
+  }
+  return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, false>(a, st);
 }
 
 }  // namespace

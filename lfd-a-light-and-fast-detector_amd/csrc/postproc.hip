@@ -44,6 +44,7 @@ struct SegBuffers {
   float* s_score;     // [nseg,cap]
   int* s_label;       // [nseg,cap]
   int* s_idx;         // [nseg,cap] candidate ordinal of sorted position
+  int* s_point;       // [nseg,cap] point index of sorted position (nullptr when cand_point is)
   unsigned long long* mask;  // [nseg,cap,words]
 };
 
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_sort(SegBuffers b) {
     sb.x = bx.x + off; sb.y = bx.y + off; sb.z = bx.z + off; sb.w = bx.w + off;
   }
   b.s_idx[so + rank] = i;
+  if (b.s_point) b.s_point[so + rank] = b.cand_point[so + i];
   b.s_score[so + rank] = my_score;
   b.s_label[so + rank] = label;
   b.s_box[so + rank] = sb;
@@ -339,38 +341,49 @@ __device__ __forceinline__ float bcast(float v, int lane) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_mask(SegBuffers b) {
+  // One 256-thread workgroup per 64x64 tile: lane = row box, each of the 4 waves tests 16 of the 64
+  // column boxes (4x shorter dependent chain than one wave per tile); the 16-bit partial masks are
+  // merged through LDS.
+  __shared__ unsigned short part[4][64];
   const int seg = blockIdx.y;
   const int K = seg_k(b, seg);
   const int nb = (K + 63) >> 6;
   const int64_t so = (int64_t)seg * b.cap;
   const int lane = lfd_lane();
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kBlock + threadIdx.x) >> 6));
-  const int nwaves = gridDim.x * (kBlock / 64);
+  const int cg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // column group 0..3
   const int ntiles = nb * nb;
   const float thr = b.iou_thr;
-  for (int t = wave; t < ntiles; t += nwaves) {
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int r = t / nb, c = t - r * nb;
     if (c < r) continue;
-    const int ri = r * 64 + lane, ci = c * 64 + lane;
+    const int ri = r * 64 + lane, ci = c * 64 + cg * 16 + (lane & 15);
     float4 rb = make_float4(0.f, 0.f, 0.f, 0.f), cb = rb;
     float ra = 0.f, ca = 0.f;
     if (ri < K) { rb = b.s_box[so + ri]; ra = b.s_area[so + ri]; }
     if (ci < K) { cb = b.s_box[so + ci]; ca = b.s_area[so + ci]; }
-    const int ncol = (K - c * 64) < 64 ? (K - c * 64) : 64;
+    const int ncol = K - c * 64;   // valid columns of this tile (>= 64 except in the last one)
     const int start = (r == c) ? lane + 1 : 0;
-    unsigned long long m = 0ull;
+    unsigned m = 0u;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const float bx = bcast(cb.x, j), by = bcast(cb.y, j), bz = bcast(cb.z, j), bw = bcast(cb.w, j);
-      const float sb = bcast(ca, j);
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = cg * 16 + jj;
+      const float bx = bcast(cb.x, jj), by = bcast(cb.y, jj), bz = bcast(cb.z, jj), bw = bcast(cb.w, jj);
+      const float sb = bcast(ca, jj);
       const float left = fmaxf(rb.x, bx), right = fminf(rb.z, bz);
       const float top = fmaxf(rb.y, by), bottom = fminf(rb.w, bw);
       const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
       const float inter = w * h;
       const float iou = inter / (ra + sb - inter);
-      if (j >= start && j < ncol && iou > thr) m |= 1ull << j;
+      if (j >= start && j < ncol && iou > thr) m |= 1u << jj;
     }
-    if (ri < K) b.mask[(so + ri) * b.words + c] = m;
+    part[cg][lane] = (unsigned short)m;
+    __syncthreads();
+    if (cg == 0 && ri < K) {
+      const unsigned long long full = (unsigned long long)part[0][lane] | ((unsigned long long)part[1][lane] << 16) |
+                                      ((unsigned long long)part[2][lane] << 32) | ((unsigned long long)part[3][lane] << 48);
+      b.mask[(so + ri) * b.words + c] = full;
+    }
+    __syncthreads();
   }
 }
 
@@ -387,64 +400,129 @@ struct ScanOut {
 
 constexpr int kScanThreads = 512;
 constexpr int kScanMaxWords = 4096;  // cap <= 262144 candidates per segment
+constexpr int kScanPfWords = 32;     // chunk-row prefetch through LDS when K <= 2048
 
+// dynamic LDS: remv[words] | pad | rowblk[4096 words]
+//   K <= 512  (nb <= 8):  rowblk = the WHOLE mask [K rows][8 words], loaded in one round trip
+//   K <= 2048 (nb <= 32): rowblk = two [64 rows][32 words] chunk blocks, filled one chunk ahead
+//   larger K: mask rows are read from global memory as needed
+// The diagonal-block resolve of chunk c runs on wave c % 8, which fetched that chunk's row payload
+// (box, score, label, ordinal, point) and diagonal word 8 chunks earlier, so no dependent global
+// load sits on the serial path.
 __global__ __launch_bounds__(kScanThreads) void k_scan(SegBuffers b, ScanOut o) {
-  __shared__ unsigned long long remv[kScanMaxWords];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long scan_smem[];
+  unsigned long long* remv = scan_smem;
+  unsigned long long* rowblk = scan_smem + b.words + 2;
   __shared__ unsigned long long s_keep;
   __shared__ int s_nkept;
+  __shared__ int s_list[64];
+  constexpr int NW = kScanThreads / 64;
   const int seg = blockIdx.x;
   const int K = seg_k(b, seg);
   const int nb = (K + 63) >> 6;
   const int64_t so = (int64_t)seg * b.cap;
   const int lane = lfd_lane();
-  const bool wave0 = threadIdx.x < 64;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mode = nb <= 8 ? 0 : (nb <= kScanPfWords ? 1 : 2);
   for (int w = threadIdx.x; w < nb; w += kScanThreads) remv[w] = 0ull;
   if (threadIdx.x == 0) s_nkept = 0;
-  __syncthreads();
   float step = 0.f;
   if (!b.class_agnostic && K > 0) step = lfd_ord_float(b.maxord[seg]) + 1.0f;
+
+  constexpr int PFN = (64 * kScanPfWords) / kScanThreads;   // 4 words per thread per chunk block
+  unsigned long long pfv[PFN];
+  auto pf_load = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+      const int idx = i * kScanThreads + threadIdx.x;
+      const int r = idx / kScanPfWords, w = idx % kScanPfWords;
+      const int row = c * 64 + r;
+      pfv[i] = (row < K && w < nb) ? b.mask[(so + row) * b.words + w] : 0ull;
+    }
+  };
+  auto pf_store = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) rowblk[(c & 1) * 64 * kScanPfWords + i * kScanThreads + threadIdx.x] = pfv[i];
+  };
+  if (mode == 0) {
+    unsigned long long v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {       // [512 rows][8 words] = 4096 words, 8 per thread, all in flight
+      const int idx = i * kScanThreads + threadIdx.x;
+      const int row = idx >> 3, w = idx & 7;
+      v[i] = (row < K && w < nb) ? b.mask[(so + row) * b.words + w] : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rowblk[i * kScanThreads + threadIdx.x] = v[i];
+  } else if (mode == 1) {
+    pf_load(0);
+    pf_store(0);
+  }
+  // row payload + diagonal word of this wave's next chunk
+  float4 nbx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float nsc = 0.f;
+  int nlab = 0, nci = 0, npt = 0;
+  unsigned long long ndiag = 0ull;
+  auto row_load = [&](int c) {
+    const int row = c * 64 + lane;
+    if (c < nb && row < K) {
+      nbx = b.s_box[so + row]; nsc = b.s_score[so + row]; nlab = b.s_label[so + row]; nci = b.s_idx[so + row];
+      npt = b.s_point ? b.s_point[so + row] : 0;
+      if (mode != 0) ndiag = b.mask[(so + row) * b.words + c];
+    }
+  };
+  row_load(wave);
+  __syncthreads();
   for (int c = 0; c < nb; ++c) {
-    if (wave0) {
+    if (mode == 1 && c + 1 < nb) pf_load(c + 1);
+    const unsigned long long* blk = rowblk + (c & 1) * 64 * kScanPfWords;
+    if (wave == (c % NW)) {
       const int row = c * 64 + lane;
-      const unsigned long long diag = row < K ? b.mask[(so + row) * b.words + c] : 0ull;
+      const unsigned long long diag = mode == 0 ? rowblk[row * 8 + c] : ndiag;
+      const float4 cbx = nbx;
+      const float csc = nsc;
+      const int clab = nlab, cci = nci, cpt = npt;
       const unsigned long long r = remv[c];
-      unsigned long long alive = __ballot(row < K && !((r >> lane) & 1ull));
-      unsigned long long kb = 0ull;
+      // Greedy resolve of the 64x64 diagonal block on the scalar unit.  Only rows whose mask is
+      // non-zero can suppress anything, so the serial walk visits just those (typically a handful):
+      // a row still alive when the walk reaches it is kept and clears its victims; every row that
+      // survives is kept.  Same result as visiting all 64 rows in order (nms_kernel.cu:117-127).
+      unsigned long long kb = __ballot(row < K && !((r >> lane) & 1ull));
+      unsigned long long pending = kb & __ballot(diag != 0ull);
       const int dlo = (int)(diag & 0xffffffffull), dhi = (int)(diag >> 32);
-      while (alive) {
-        const int bit = __builtin_ctzll(alive);
-        kb |= 1ull << bit;
+      while (pending) {
+        const int bit = __builtin_ctzll(pending);
         const unsigned long long m =
             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, bit) << 32) |
             (unsigned)__builtin_amdgcn_readlane(dlo, bit);
-        alive &= ~m;
-        alive &= ~(1ull << bit);
+        kb &= ~m;                 // victims of a kept row (m only has bits above `bit`)
+        pending &= kb;            // suppressed rows no longer suppress
+        pending &= ~(1ull << bit);
       }
-      // append the kept rows of this block, in order
       const int base = s_nkept;
-      if ((kb >> lane) & 1ull) {
+      if ((kb >> lane) & 1ull) {       // append the kept rows of this block, in order
         const int pos = base + __popcll(kb & ((1ull << lane) - 1ull));
         const int64_t oo = so + pos;
-        const int label = b.s_label[so + row];
-        const int ci = b.s_idx[so + row];
         if (o.dets) {
-          float4 bx = b.s_box[so + row];
+          float4 bx = cbx;
           if (!b.class_agnostic) {   // nms_bboxes[:, :4] - offsets[kept]   (nms.py:156)
-            const float off = (float)label * step;
+            const float off = (float)clab * step;
             bx.x = bx.x - off; bx.y = bx.y - off; bx.z = bx.z - off; bx.w = bx.w - off;
           }
           float* d = o.dets + oo * 5;
-          d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = b.s_score[so + row];
+          d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = csc;
         }
-        if (o.labels) o.labels[oo] = label;
-        if (o.cand) o.cand[oo] = ci;
-        if (o.point && b.cand_point) o.point[oo] = b.cand_point[so + ci];
-        if (o.keep64) o.keep64[pos] = (int64_t)ci;
+        if (o.labels) o.labels[oo] = clab;
+        if (o.cand) o.cand[oo] = cci;
+        if (o.point && b.s_point) o.point[oo] = cpt;
+        if (o.keep64) o.keep64[pos] = (int64_t)cci;
       }
+      if ((kb >> lane) & 1ull) s_list[__popcll(kb & ((1ull << lane) - 1ull))] = lane;   // kept rows, compacted
       if (lane == 0) {
         s_keep = kb;
         s_nkept = base + __popcll(kb);
       }
+      row_load(c + NW);                // this wave's next turn
     }
     __syncthreads();
     const unsigned long long kb = s_keep;
@@ -454,14 +532,15 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(SegBuffers b, ScanOut o) 
       const int total = nk * nw;
       for (int q = threadIdx.x; q < total; q += kScanThreads) {
         const int ki = q / nw, w = c + 1 + (q - ki * nw);
-        // ki-th set bit of kb
-        unsigned long long t = kb;
-        for (int s = 0; s < ki; ++s) t &= t - 1;
-        const int bit = __builtin_ctzll(t);
-        const unsigned long long v = b.mask[(so + c * 64 + bit) * b.words + w];
+        const int bit = s_list[ki];
+        unsigned long long v;
+        if (mode == 0) v = rowblk[(c * 64 + bit) * 8 + w];
+        else if (mode == 1) v = blk[bit * kScanPfWords + w];
+        else v = b.mask[(so + c * 64 + bit) * b.words + w];
         if (v) atomicOr(&remv[w], v);
       }
     }
+    if (mode == 1 && c + 1 < nb) pf_store(c + 1);   // other buffer: nobody reads it during this iteration
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -490,6 +569,7 @@ SegBuffers carve_seg(LfdCarver& cv, int nseg, int cap, bool need_point) {
   b.s_score = cv.take<float>(tot);
   b.s_label = cv.take<int>(tot);
   b.s_idx = cv.take<int>(tot);
+  b.s_point = need_point ? cv.take<int>(tot) : nullptr;
   b.mask = cv.take<unsigned long long>(tot * b.words);
   return b;
 }
@@ -506,13 +586,24 @@ int run_sort_mask_scan(const SegBuffers& b, const ScanOut& o, int nseg, hipStrea
   hipLaunchKernelGGL(k_rank_sort, gs, dim3(kBlock), 0, st, b);
   LFD_CHECK_LAUNCH();
   // enough waves to cover the tile list of the capacity, capped: waves loop over tiles
-  long long nb = b.words, tiles = nb * (nb + 1) / 2;
-  long long blocks = (tiles + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  // waves loop over the (data-dependent) tile list: a modest fixed grid per segment, sized so that the
+  // whole batch fills the chip once (launching capacity-many idle workgroups costs more than the work)
+  long long nb = b.words, tiles = nb * nb;
+  long long blocks = tiles;
+  const long long per_seg = nseg >= 8 ? 128 : 1024 / (nseg > 0 ? nseg : 1);
+  if (blocks > per_seg) blocks = per_seg;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_mask, dim3((unsigned)blocks, nseg), dim3(kBlock), 0, st, b);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan, dim3(nseg), dim3(kScanThreads), 0, st, b, o);
+  const size_t scan_lds = ((size_t)b.words + 2 + 2 * 64 * kScanPfWords) * sizeof(unsigned long long);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((kScanMaxWords + 2 + 2 * 64 * kScanPfWords) * sizeof(unsigned long long))) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_scan, dim3(nseg), dim3(kScanThreads), scan_lds, st, b, o);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

@@ -171,6 +171,7 @@ class EnginePlan(object):
             self.stem_fused = (c0,) + tuple(self.stem_first[1:]) + (cv.w, cv.b, cv.tail[0], cv.tail[1], cv.dst)
         # ---- stages
         self.taps = []
+        self.tap_ready_after = []
         for i, nblk in enumerate(bb._body_architecture):
             for j in range(nblk):
                 blk = getattr(bb, 'stage%d' % i)[j]
@@ -202,6 +203,7 @@ class EnginePlan(object):
                 cur = y
                 if (i, j) in [tuple(t) for t in bb._out_indices]:
                     self.taps.append(cur)
+                    self.tap_ready_after.append(len(self.convs))   # number of conv launches that must precede
         self.num_bufs = nbuf[0]
 
     def _add_conv(self, src, new_buf, cin, cout, ks, stride, relu, w, b, tail=None, res=None):
@@ -314,7 +316,8 @@ class EnginePlan(object):
         return st
 
     # ---- execution
-    def run_backbone(self, x, fmt, st):
+    def run_backbone(self, x, fmt, st, after=None):
+        """`after`: optional {number_of_convs_done: callable} hooks (used to fork the level-0 head)."""
         l = lib()
         sp = stream_ptr()
         if self.stem_fused is not None:
@@ -327,7 +330,9 @@ class EnginePlan(object):
             check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
                                       ptr(st.bufs[self.stem_out]), sp), 'lfd_stem_conv_f16')
         z = ops.zero_line(self.device)
-        for c in self.convs:
+        for ci, c in enumerate(self.convs):
+            if after and ci in after:
+                after[ci]()
             src = st.bufs[c.src]
             d = _lib.ConvDesc(st.n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                               c.cout if c.tail else 0, 1 if c.tail else 0)
@@ -335,26 +340,48 @@ class EnginePlan(object):
                                         ptr(st.bufs[c.res]) if c.res is not None else None,
                                         ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,
                                         ptr(z), sp), 'lfd_conv2d_nhwc_f16')
+        if after and len(self.convs) in after:
+            after[len(self.convs)]()
 
-    def run_head(self, st):
-        """5 launches per tower: pass 1, finalize, pass 2, finalize, pass 3 (all levels per launch)."""
+    def run_head(self, st, groups=None):
+        """5 launches per (level group, tower): pass 1, finalize, pass 2, finalize, pass 3."""
         l = lib()
-        sp = stream_ptr()
         z = ops.zero_line(self.device)
-        ntow = len(self.levels[0].towers)
-        nl = len(self.levels)
-        for ti in range(ntow):
-            hs = st.head_call[ti]
-            d, lv, ab1, ab2 = hs['desc'], hs['levels'], hs['ab1'], hs['ab2']
-            if self.head_gn:
-                for p, ab, gam, bet, eps in ((1, ab1, hs['g1'], hs['b1'], hs['eps1']), (2, ab2, hs['g2'], hs['b2'], hs['eps2'])):
-                    check(l.lfd_head_forward_f16(C.byref(d), p, lv, ptr(ab1), None, ptr(st.partial), None, None, ptr(z), sp),
-                          'lfd_head_forward_f16(pass %d)' % p)
-                    check(l.lfd_groupnorm_finalize(C.byref(d), ptr(st.partial), gam, bet, eps, ptr(ab), sp),
-                          'lfd_groupnorm_finalize')
-            check(l.lfd_head_forward_f16(C.byref(d), 3, lv, ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg), ptr(z), sp),
-                  'lfd_head_forward_f16(pass 3)')
-        del nl
+        for gi in (range(len(st.head_groups)) if groups is None else groups):
+            sp = stream_ptr()
+            for hs in st.head_groups[gi]:
+                d, lv, ab1, ab2, part = hs['desc'], hs['levels'], hs['ab1'], hs['ab2'], hs['partial']
+                if self.head_gn:
+                    for p, ab, gam, bet, eps in ((1, ab1, hs['g1'], hs['b1'], hs['eps1']), (2, ab2, hs['g2'], hs['b2'], hs['eps2'])):
+                        check(l.lfd_head_forward_f16(C.byref(d), p, lv, ptr(ab1), None, ptr(part), None, None, ptr(z), sp),
+                              'lfd_head_forward_f16(pass %d)' % p)
+                        check(l.lfd_groupnorm_finalize(C.byref(d), ptr(part), gam, bet, eps, ptr(ab), sp),
+                              'lfd_groupnorm_finalize')
+                check(l.lfd_head_forward_f16(C.byref(d), 3, lv, ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg), ptr(z), sp),
+                      'lfd_head_forward_f16(pass 3)')
+
+    def run_all(self, x, fmt, st):
+        """Whole forward.  The neck+head of the FIRST pyramid level (the largest, ~75 % of the head's
+        pixels) only depends on the first backbone tap: it is forked onto a side stream as soon as that
+        tap is written and overlaps with the remaining (small, latency-bound) backbone stages; the other
+        levels follow on the main stream; joined at the end.  Works eagerly and under graph capture."""
+        if self.head is None:
+            return self.run_backbone(x, fmt, st)
+        if not st.overlap or len(st.head_groups) < 2:
+            self.run_backbone(x, fmt, st)
+            return self.run_head(st)
+        main = torch.cuda.current_stream()
+
+        def fork():
+            st.ev_tap.record(main)
+            with torch.cuda.stream(st.side):
+                st.side.wait_event(st.ev_tap)
+                self.run_head(st, groups=[0])
+                st.ev_done.record(st.side)
+
+        self.run_backbone(x, fmt, st, after={self.tap_ready_after[0]: fork})
+        self.run_head(st, groups=range(1, len(st.head_groups)))
+        main.wait_event(st.ev_done)
 
 
 class _ShapeState(object):
@@ -387,42 +414,56 @@ class _ShapeState(object):
                 self.P = p
                 self.cls = torch.empty((n, p, plan.cls_channels), dtype=torch.float32, device=dev)
                 self.reg = torch.empty((n, p, 4), dtype=torch.float32, device=dev)
-                nl = len(plan.levels)
+                import os
                 ntow = len(plan.levels[0].towers)
-                self.head_call = []
-                npart = 0
-                for ti in range(ntow):
-                    t0 = plan.levels[0].towers[ti]
-                    d = _lib.HeadDesc()
-                    d.n, d.num_levels = n, nl
-                    for li, (lv, (hh, ww)) in enumerate(zip(plan.levels, self.sizes)):
-                        d.level_hw[li], d.level_cin[li], d.level_point_offset[li] = hh * ww, lv.cin, self.p_off[li]
-                    d.head_channels, d.num_groups, d.total_points = 128, plan.head_groups, p
-                    d.cls_channels, d.final_reg_rows, d.final_cls_rows = plan.cls_channels, t0.reg_rows, t0.cls_rows
-                    lvp = (_lib.HeadLevelPtrs * nl)()
-                    for li, lv in enumerate(plan.levels):
-                        t = lv.towers[ti]
-                        lvp[li].x = self.bufs[lv.src].data_ptr()
-                        lvp[li].wn_packed, lvp[li].bn = lv.wn.data_ptr(), lv.bn.data_ptr()
-                        lvp[li].w1_packed, lvp[li].w2_packed = t.w1.data_ptr(), t.w2.data_ptr()
-                        lvp[li].wf_packed, lvp[li].bf = t.wf.data_ptr(), t.bf.data_ptr()
-                        lvp[li].scale = t.scale.data_ptr() if t.scale is not None else None
-                    call = dict(desc=d, levels=lvp)
-                    if plan.head_gn:
-                        call['ab1'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
-                        call['ab2'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
-                        for tag, attr in (('1', 'norm1'), ('2', 'norm2')):
-                            g = (C.c_void_p * nl)(*[getattr(lv.towers[ti], attr).weight.data_ptr() for lv in plan.levels])
-                            b_ = (C.c_void_p * nl)(*[getattr(lv.towers[ti], attr).bias.data_ptr() for lv in plan.levels])
-                            call['g' + tag], call['b' + tag] = g, b_
-                            call['eps' + tag] = float(getattr(t0, attr).eps)
-                    else:      # BatchNorm / no norm: static per-channel affine, replicated per level / image
-                        for k in (0, 1):
-                            ab = torch.stack([torch.stack(lv.towers[ti].static_ab[k], -1).float() for lv in plan.levels], 0)
-                            call['ab%d' % (k + 1)] = ab[:, None].expand(nl, n, 128, 2).contiguous().to(dev)
-                    npart = max(npart, int(lib().lfd_head_partial_floats(C.byref(d))))
-                    self.head_call.append(call)
-                self.partial = torch.empty(max(npart, 1), dtype=torch.float32, device=dev)
+                nlv = len(plan.levels)
+                # side-stream fork of the level-0 head: measured neutral on MI355X (both kernel families are
+                # persistent and fill every CU), so it is opt-in
+                self.overlap = nlv > 1 and os.environ.get('LFD_OVERLAP') == '1'
+                level_groups = [[0], list(range(1, nlv))] if self.overlap else [list(range(nlv))]
+                self.head_groups = []
+                for lg in level_groups:
+                    calls = []
+                    for ti in range(ntow):
+                        t0 = plan.levels[0].towers[ti]
+                        nl = len(lg)
+                        d = _lib.HeadDesc()
+                        d.n, d.num_levels = n, nl
+                        for k, li in enumerate(lg):
+                            hh, ww = self.sizes[li]
+                            d.level_hw[k], d.level_cin[k], d.level_point_offset[k] = hh * ww, plan.levels[li].cin, self.p_off[li]
+                        d.head_channels, d.num_groups, d.total_points = 128, plan.head_groups, p
+                        d.cls_channels, d.final_reg_rows, d.final_cls_rows = plan.cls_channels, t0.reg_rows, t0.cls_rows
+                        lvp = (_lib.HeadLevelPtrs * nl)()
+                        for k, li in enumerate(lg):
+                            lv = plan.levels[li]
+                            t = lv.towers[ti]
+                            lvp[k].x = self.bufs[lv.src].data_ptr()
+                            lvp[k].wn_packed, lvp[k].bn = lv.wn.data_ptr(), lv.bn.data_ptr()
+                            lvp[k].w1_packed, lvp[k].w2_packed = t.w1.data_ptr(), t.w2.data_ptr()
+                            lvp[k].wf_packed, lvp[k].bf = t.wf.data_ptr(), t.bf.data_ptr()
+                            lvp[k].scale = t.scale.data_ptr() if t.scale is not None else None
+                        call = dict(desc=d, levels=lvp)
+                        if plan.head_gn:
+                            call['ab1'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
+                            call['ab2'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
+                            for tag, attr in (('1', 'norm1'), ('2', 'norm2')):
+                                g = (C.c_void_p * nl)(*[getattr(plan.levels[li].towers[ti], attr).weight.data_ptr() for li in lg])
+                                b_ = (C.c_void_p * nl)(*[getattr(plan.levels[li].towers[ti], attr).bias.data_ptr() for li in lg])
+                                call['g' + tag], call['b' + tag] = g, b_
+                                call['eps' + tag] = float(getattr(t0, attr).eps)
+                        else:      # BatchNorm / no norm: static per-channel affine, replicated per level / image
+                            for k in (0, 1):
+                                ab = torch.stack([torch.stack(plan.levels[li].towers[ti].static_ab[k], -1).float() for li in lg], 0)
+                                call['ab%d' % (k + 1)] = ab[:, None].expand(nl, n, 128, 2).contiguous().to(dev)
+                        call['partial'] = torch.empty(max(int(lib().lfd_head_partial_floats(C.byref(d))), 1),
+                                                      dtype=torch.float32, device=dev)
+                        calls.append(call)
+                    self.head_groups.append(calls)
+                if self.overlap:
+                    self.side = torch.cuda.Stream(device=dev)
+                    self.ev_tap = torch.cuda.Event()
+                    self.ev_done = torch.cuda.Event()
         self.graph = None
         self.graph_input = None
 
@@ -478,8 +519,7 @@ def lfd_forward(model, x, use_graph=False):
         if use_graph:
             _run_graphed(plan, st, x, fmt)
         else:
-            plan.run_backbone(x, fmt, st)
-            plan.run_head(st)
+            plan.run_all(x, fmt, st)
     return st.cls, st.reg, st.sizes
 
 
@@ -495,13 +535,11 @@ def _run_graphed(plan, st, x, fmt):
         if len(graphs) >= 4:
             graphs.pop(next(iter(graphs)))
         # warm-up outside capture (sets kernel attributes, sizes workspaces)
-        plan.run_backbone(x, fmt, st)
-        plan.run_head(st)
+        plan.run_all(x, fmt, st)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            plan.run_backbone(x, fmt, st)
-            plan.run_head(st)
+            plan.run_all(x, fmt, st)
         ent = (g, x)            # keep the captured input alive
         graphs[key] = ent
     ent[0].replay()

@@ -108,7 +108,7 @@ def detect_batched(desc, cls, reg, meta, out=None):
             out.labels = torch.empty((n, cap), dtype=torch.int32, device=dev)
             out.cand = torch.empty((n, cap), dtype=torch.int32, device=dev)
             out.point = torch.empty((n, cap), dtype=torch.int32, device=dev)
-            out.counts = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+            out.counts = torch.empty((n, 4), dtype=torch.int32, device=dev)   # fully written by k_count/k_scatter/k_scan
         wsb = lib().lfd_detect_workspace_bytes(C.byref(desc), n)
         ws = _workspace(wsb, dev)
         check(lib().lfd_detect_batched(C.byref(desc), n, ptr(cls), ptr(reg), _dtype_code(cls), ptr(meta),
