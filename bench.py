@@ -87,18 +87,28 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
         src, dst = st.bufs[c.src], st.bufs[c.dst]
         d = _lib.ConvDesc(n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                           c.cout if c.tail else 0, 1 if c.tail else 0)
-        fn = lambda: check(l.lfd_conv2d_nhwc_f16(C.byref(d), ptr(src), ptr(dst), ptr(c.w), ptr(c.b),  # noqa: E731
-                                                 ptr(st.bufs[c.res]) if c.res is not None else None,
-                                                 ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,
-                                                 ptr(z), stream_ptr()), 'conv')
+        if c.ds is not None:
+            fn = lambda: check(l.lfd_conv2d_downsample_nhwc_f16(C.byref(d), ptr(src), ptr(dst), ptr(c.w), ptr(c.b),  # noqa: E731
+                                                                ptr(c.ds[0]), ptr(c.ds[1]), ptr(st.bufs[c.ds[2]]), ptr(z),
+                                                                stream_ptr()), 'conv+ds')
+        else:
+            fn = lambda: check(l.lfd_conv2d_nhwc_f16(C.byref(d), ptr(src), ptr(dst), ptr(c.w), ptr(c.b),  # noqa: E731
+                                                     ptr(st.bufs[c.res]) if c.res is not None else None,
+                                                     ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,
+                                                     ptr(z), stream_ptr()), 'conv')
         us = timed(fn)
         fl = conv_flops(n, dst.shape[1], dst.shape[2], c.cin, c.cout, c.ks)
+        if c.ds is not None:
+            fl += conv_flops(n, dst.shape[1], dst.shape[2], c.cin, c.cout, 1)
         if c.tail:
             fl += conv_flops(n, dst.shape[1], dst.shape[2], c.cout, c.cout, 1)
         by = (src.numel() + dst.numel() + (dst.numel() if c.res is not None else 0)) * 2
         if c.ks == 1 and c.stride == 2:
             by = (src.numel() // 4 + dst.numel()) * 2
-        name = 'conv%dx%d_s%d_%dto%d%s (k_conv)' % (c.ks, c.ks, c.stride, c.cin, c.cout, '+1x1' if c.tail else '')
+        if c.ds is not None:
+            by += dst.numel() * 2
+        name = 'conv%dx%d_s%d_%dto%d%s (k_conv)' % (c.ks, c.ks, c.stride, c.cin, c.cout,
+                                                   '+1x1' if c.tail else ('+downsample1x1s2' if c.ds is not None else ''))
         add(name, us, fl, by)
     us = timed(lambda: plan.run_head(st))
     hf = 0.0

@@ -171,6 +171,13 @@ typedef struct lfd_conv_desc {
 } lfd_conv_desc_t;
 
 LFD_API size_t lfd_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t ks);
+/* First conv of a residual block together with its identity branch (lfd_resnet.py:458-468): the
+ * conv3x3 stride 2 (+BN+ReLU) -> out and the downsample conv1x1 stride 2 (+BN, no ReLU) -> ds_out are
+ * produced by ONE launch from the same input tile (the 1x1 s2 reads the 3x3's centre tap). */
+LFD_API int lfd_conv2d_downsample_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, void* out,
+                                           const void* w_packed, const float* bias,
+                                           const void* ds_w_packed, const float* ds_bias, void* ds_out,
+                                           const void* zeros, lfd_stream_t stream);
 LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, void* out,
                                 const void* w_packed, const float* bias, const void* residual,
                                 const void* tail_w_packed, const float* tail_bias,

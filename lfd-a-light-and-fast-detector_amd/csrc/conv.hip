@@ -34,6 +34,9 @@ struct ConvArgs {
   const _Float16* res;    // optional residual [N,OH,OW,COUT_OUT] (added before ReLU)
   const half8* w2;        // tail 1x1 packed weights [cout2_tile][CMID/16][64]
   const float* bias2;     // [COUT2]
+  const half8* wds;       // DS: packed 1x1 stride-2 downsample weights [cout/32][CIN/16][64]
+  const float* bds;       // DS: its bias [cout]
+  _Float16* out_ds;       // DS: identity-branch output [N,OH,OW,cout] (no ReLU)
   const _Float16* zeros;  // 4 KB line: bytes [0,2048) stay zero (source of out-of-image pixels),
                           // bytes [2048,4096) are a write-only trash area for masked stores
   int N, H, W, OH, OW;
@@ -84,8 +87,9 @@ __device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
+  static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES), "DS: the residual block's 1x1 s2 downsample rides on its 3x3 s2 conv");
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -113,6 +117,14 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   if (TAIL) {
 #pragma unroll
     for (int k = 0; k < C::NK2; ++k) w2reg[k] = a.w2[((size_t)ct * C::NK2 + k) * 64 + lane];
+  }
+
+  // DS: the identity branch conv1x1 stride 2 (lfd_resnet.py:458-468) reads exactly the centre tap
+  // (r = s = 1) of this 3x3 stride-2 conv's window: same LDS fragments, one extra MFMA each.
+  half8 wdsr[DS ? C::NQ : 1];
+  if constexpr (DS) {
+#pragma unroll
+    for (int q = 0; q < C::NQ; ++q) wdsr[q] = a.wds[((size_t)(cog * NCT + ct) * C::NQ + q) * 64 + lane];
   }
 
   // ---- per-lane LDS read offsets: one per (column tap s, 16-channel group q).  For 128 input
@@ -214,6 +226,18 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
       }
     }
 
+    f32x16 accd[DS ? C::PT : 1];
+    if constexpr (DS) {
+      const float* bp = a.bds + co_base + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < C::PT; ++pt) {
+          accd[pt][4 * g + 0] = b4.x; accd[pt][4 * g + 1] = b4.y; accd[pt][4 * g + 2] = b4.z; accd[pt][4 * g + 3] = b4.w;
+        }
+      }
+    }
     f32x16 acc[C::PT];
     {
       // accumulators start at the (BN-folded) bias of this lane's 16 channels
@@ -259,6 +283,13 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < C::PT; ++pt)
           acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
+        if constexpr (DS) {
+          if (k / C::NQ == 4) {     // centre tap
+#pragma unroll
+            for (int pt = 0; pt < C::PT; ++pt)
+              accd[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdsr[k % C::NQ], xq[k % (PD + 1)][pt], accd[pt], 0, 0, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -287,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
           for (int pt = 0; pt < C::PT; ++pt) {
             const half8 xf = *reinterpret_cast<const half8*>(xr + off + (pt * C::RPT * S) * C::IWs * C::PIXB);
             acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[pt], 0, 0, 0);
+            if constexpr (DS) {
+              if (r == 1 && s == 1) accd[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdsr[q], xf, accd[pt], 0, 0, 0);
+            }
           }
         }
       }
@@ -385,10 +419,39 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         *reinterpret_cast<uint4*>(dst) = v;
       }
     }
+    if constexpr (DS) {
+      // second output: the identity branch (bias already in accd, no ReLU), same staging tile
+      __syncthreads();
+#pragma unroll
+      for (int pt = 0; pt < C::PT; ++pt) {
+        const int pb = (pg * C::PT + pt) * 32 + pix;
+        const int fo = (pb / OPPR) % OCPP;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (_Float16)accd[pt][4 * g + j];
+          *reinterpret_cast<half4*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
+        }
+      }
+      __syncthreads();
+      const int cslice = cog * NCT * 32;
+      for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
+        const int pb = i / OCPP, c = i - pb * OCPP;
+        const int t32 = pb >> 5, p32 = pb & 31;
+        const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
+        const int ox = tx0 * C::TW + p32 % C::TW;
+        if (oy < a.OH && ox < a.OW) {
+          const int fo = (pb / OPPR) % OCPP;
+          const uint4 v = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
+          *reinterpret_cast<uint4*>(a.out_ds + (((size_t)n * a.OH + oy) * a.OW + ox) * a.cout + cslice + c * 8) = v;
+        }
+      }
+    }
   }
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS>
 int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   ConvArgs a = a0;
@@ -398,7 +461,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   const int cgroups = TAIL ? 1 : a.cout / (NCT * 32);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     attr_done = true;
@@ -406,7 +469,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   int blocks = 512 / cgroups;
   if (blocks > a.ntiles) blocks = a.ntiles;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES>), dim3(blocks, cgroups), dim3(256), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS>), dim3(blocks, cgroups), dim3(256), C::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -415,11 +478,16 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   if constexpr (KS == 3 && S == 1 && !TAIL) {
-    if (a.res) return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, true>(a, st);
+    if (a.res) return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, true, false>(a, st);
   } else {
     if (a.res) return LFD_ERR_UNSUPPORTED;
   }
-  return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, false>(a, st);
+  if constexpr (KS == 3 && S == 2 && !TAIL) {
+    if (a.wds) return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, false, true>(a, st);
+  } else {
+    if (a.wds) return LFD_ERR_UNSUPPORTED;
+  }
+  return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, false, false>(a, st);
 }
 
 }  // namespace
@@ -431,9 +499,29 @@ size_t lfd_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t ks) {
   return (size_t)(cout / 32) * (size_t)(ks * ks * cin / 16) * 64 * 8;
 }
 
+static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                         const float* bias, const void* residual, const void* tail_w_packed,
+                         const float* tail_bias, const void* ds_w_packed, const float* ds_bias, void* ds_out,
+                         const void* zeros, lfd_stream_t stream);
+
 int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
                         const float* bias, const void* residual, const void* tail_w_packed,
                         const float* tail_bias, const void* zeros, lfd_stream_t stream) {
+  return conv_dispatch(d, in, out, w_packed, bias, residual, tail_w_packed, tail_bias, nullptr, nullptr, nullptr, zeros,
+                       stream);
+}
+
+int lfd_conv2d_downsample_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                                   const float* bias, const void* ds_w_packed, const float* ds_bias, void* ds_out,
+                                   const void* zeros, lfd_stream_t stream) {
+  if (!ds_w_packed || !ds_bias || !ds_out || !d || d->ks != 3 || d->stride != 2 || d->tail_cout) return LFD_ERR_INVALID_ARGUMENT;
+  return conv_dispatch(d, in, out, w_packed, bias, nullptr, nullptr, nullptr, ds_w_packed, ds_bias, ds_out, zeros, stream);
+}
+
+static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                         const float* bias, const void* residual, const void* tail_w_packed,
+                         const float* tail_bias, const void* ds_w_packed, const float* ds_bias, void* ds_out,
+                         const void* zeros, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d || !in || !out || !w_packed || !bias || !zeros) return LFD_ERR_INVALID_ARGUMENT;
   if (d->n < 1 || d->h < 1 || d->w < 1) return LFD_ERR_INVALID_ARGUMENT;
@@ -443,6 +531,7 @@ int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, con
   a.in = (const _Float16*)in; a.out = (_Float16*)out; a.w = (const half8*)w_packed; a.bias = bias;
   a.res = (const _Float16*)residual; a.w2 = (const half8*)tail_w_packed; a.bias2 = tail_bias;
   a.zeros = (const _Float16*)zeros;
+  a.wds = (const half8*)ds_w_packed; a.bds = ds_bias; a.out_ds = (_Float16*)ds_out;
   a.N = d->n; a.H = d->h; a.W = d->w;
   const int pad = d->ks / 2;
   a.OH = (d->h + 2 * pad - d->ks) / d->stride + 1;

@@ -84,7 +84,7 @@ def _tail_supported(cin, cout, ks, stride):
 
 class _Conv(object):
     """one lfd_conv2d_nhwc_f16 launch"""
-    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res')
+    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds')
 
 
 class _HeadLevel(object):
@@ -177,11 +177,21 @@ class EnginePlan(object):
                 blk = getattr(bb, 'stage%d' % i)[j]
                 x_in = cur
                 ident = x_in
+                fuse_ds = None
                 if blk._downsample is not None:
                     dconv = blk._downsample[0]
                     dnorm = blk._downsample[1] if len(blk._downsample) > 1 else None
                     w, b = fold_conv_norm(dconv, dnorm)
-                    ident = self._add_conv(x_in, new_buf, dconv.in_channels, dconv.out_channels, 1, 2, False, w, b)
+                    c1 = blk._conv1
+                    if (c1.kernel_size[0] == 3 and c1.stride[0] == 2 and c1.out_channels == dconv.out_channels and
+                            c1.in_channels == dconv.in_channels and blk.num_convs == 2):
+                        # identity branch rides on the block's 3x3 stride-2 conv (one launch, one input read)
+                        ident = new_buf()
+                        self.buf_channels[ident] = dconv.out_channels
+                        self.buf_scale[ident] = self.buf_scale[x_in] * 2
+                        fuse_ds = (ops.pack_conv_weight(w).to(dev), b.to(dev).contiguous(), ident)
+                    else:
+                        ident = self._add_conv(x_in, new_buf, dconv.in_channels, dconv.out_channels, 1, 2, False, w, b)
                 nconv = blk.num_convs
                 y = x_in
                 ci = 1
@@ -198,7 +208,8 @@ class EnginePlan(object):
                             w2, b2 = fold_conv_norm(nxt, getattr(blk, '_norm%d' % (ci + 1), None))
                             tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True)   # FastBlock 3x3 -> 1x1
                     y = self._add_conv(y, new_buf, conv.in_channels, conv.out_channels, conv.kernel_size[0],
-                                       conv.stride[0], True, w, b, tail=tail, res=ident if last else None)
+                                       conv.stride[0], True, w, b, tail=tail, res=ident if last else None,
+                                       ds=fuse_ds if ci == 1 else None)
                     ci += 2 if tail is not None else 1
                 cur = y
                 if (i, j) in [tuple(t) for t in bb._out_indices]:
@@ -206,12 +217,13 @@ class EnginePlan(object):
                     self.tap_ready_after.append(len(self.convs))   # number of conv launches that must precede
         self.num_bufs = nbuf[0]
 
-    def _add_conv(self, src, new_buf, cin, cout, ks, stride, relu, w, b, tail=None, res=None):
+    def _add_conv(self, src, new_buf, cin, cout, ks, stride, relu, w, b, tail=None, res=None, ds=None):
         c = _Conv()
         c.cin, c.cout, c.ks, c.stride, c.relu = cin, cout, ks, stride, relu
         c.w = ops.pack_conv_weight(w).to(self.device)
         c.b = b.to(self.device).contiguous()
         c.tail = tail
+        c.ds = ds
         c.src = src
         c.dst = new_buf()
         c.res = res
@@ -336,6 +348,11 @@ class EnginePlan(object):
             src = st.bufs[c.src]
             d = _lib.ConvDesc(st.n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                               c.cout if c.tail else 0, 1 if c.tail else 0)
+            if c.ds is not None:
+                check(l.lfd_conv2d_downsample_nhwc_f16(C.byref(d), ptr(src), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b),
+                                                       ptr(c.ds[0]), ptr(c.ds[1]), ptr(st.bufs[c.ds[2]]), ptr(z), sp),
+                      'lfd_conv2d_downsample_nhwc_f16')
+                continue
             check(l.lfd_conv2d_nhwc_f16(C.byref(d), ptr(src), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b),
                                         ptr(st.bufs[c.res]) if c.res is not None else None,
                                         ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,

@@ -95,3 +95,58 @@ def test_stem_kernel_formats(c, fmt, tail):
     got = out.float().cpu().permute(0, 3, 1, 2).double()
     tol = 1.2e-3 * ref.abs().clamp(min=1.0)
     assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 64), (64, 128), (128, 128), (32, 64)])
+def test_conv_with_fused_downsample_branch(cin, cout):
+    """3x3 s2 (+ReLU) and the block's 1x1 s2 identity branch (no ReLU) from one launch."""
+    import ctypes as C
+    from lfd_amd import _lib
+    from lfd_amd._lib import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 2, 37, 45
+    x = (torch.randn(n, h, w, cin, generator=g) * 0.5).half()
+    w3 = (torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (cin * 9) ** 0.5)).half().float()
+    w1 = (torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)).half().float()
+    b3, b1 = torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1
+    xd = x.float().permute(0, 3, 1, 2).double()
+    ref = F.conv2d(xd, w3.double(), b3.double(), stride=2, padding=1).relu()
+    refd = F.conv2d(xd, w1.double(), b1.double(), stride=2)
+    xg = x.cuda()
+    out = torch.empty((n, ref.shape[2], ref.shape[3], cout), dtype=torch.float16).cuda()
+    outd = torch.empty_like(out)
+    w3p, w1p, b3g, b1g = ops.pack_conv_weight(w3).cuda(), ops.pack_conv_weight(w1).cuda(), b3.cuda(), b1.cuda()
+    d = _lib.ConvDesc(n, h, w, cin, cout, 3, 2, 1, 0, 0)
+    check(lib().lfd_conv2d_downsample_nhwc_f16(C.byref(d), ptr(xg), ptr(out), ptr(w3p), ptr(b3g), ptr(w1p), ptr(b1g),
+                                               ptr(outd), ptr(ops.zero_line(xg.device)), stream_ptr()), 'conv+ds')
+    torch.cuda.synchronize()
+    for got, exp in ((out, ref), (outd, refd)):
+        gd = got.float().cpu().permute(0, 3, 1, 2).double()
+        assert bool(((gd - exp).abs() <= 1.2e-3 * exp.abs().clamp(min=1.0)).all()), float((gd - exp).abs().max())
+
+
+@pytest.mark.parametrize('c', [32, 64])
+def test_whole_stem_fused_kernel(c):
+    """opt-in single-kernel 'faster' stem (csrc/stem_fused.hip) == the four convs applied in turn."""
+    from lfd_amd._lib import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(2)
+    n, h, w = 2, 70, 101
+    xf = (torch.rand(n, 3, h, w, generator=g) * 2 - 1).half().float()
+    ws = [(torch.randn(c, 3, 3, 3, generator=g) * 0.2), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5),
+          (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5)]
+    ws = [t.half().float() for t in ws]
+    bs = [torch.randn(c, generator=g) * 0.1 for _ in range(4)]
+    y = xf.double()
+    for wt, b, s, p in zip(ws, bs, (2, 1, 2, 1), (1, 0, 1, 0)):
+        y = F.conv2d(y, wt.double(), b.double(), stride=s, padding=p).relu().float().half().double()
+    packed = [engine.pack_stem_weight(ws[0]).cuda()] + [ops.pack_conv_weight(t).cuda() for t in ws[1:]]
+    bg = [b.cuda() for b in bs]
+    out = torch.empty((n, y.shape[2], y.shape[3], c), dtype=torch.float16).cuda()
+    xin = xf.permute(0, 2, 3, 1).contiguous().half().cuda()
+    check(lib().lfd_stem_faster_fused_f16(ptr(xin), 1, n, h, w, c, ptr(packed[0]), ptr(bg[0]), ptr(packed[1]), ptr(bg[1]),
+                                          ptr(packed[2]), ptr(bg[2]), ptr(packed[3]), ptr(bg[3]), ptr(out), stream_ptr()),
+          'fused stem')
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2).double()
+    # two fp16-rounded intermediates in the chain: allow a few ulp at the output magnitude
+    assert bool(((got - y).abs() <= 4e-3 * y.abs().clamp(min=1.0)).all()), float((got - y).abs().max())

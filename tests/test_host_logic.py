@@ -117,7 +117,8 @@ def test_engine_plan_structure_on_cpu():
     assert plan.convs[0].tail is not None and plan.convs[0].stride == 2 and plan.convs[0].ks == 3
     n3 = sum(1 for c in plan.convs if c.ks == 3)
     n1 = sum(1 for c in plan.convs if c.ks == 1)
-    assert (n3, n1) == (1 + 2 * 11, 4)          # 11 FasterBlocks, 4 downsample branches
+    assert (n3, n1) == (1 + 2 * 11, 0)          # 11 FasterBlocks; the 4 downsample branches ride on conv1
+    assert sum(1 for c in plan.convs if c.ds is not None) == 4
     assert len(plan.taps) == 5 and len(plan.levels) == 5
     assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
     assert all(len(lv.towers) == 1 and lv.towers[0].reg_rows == 4 and lv.towers[0].cls_rows == 1 for lv in plan.levels)
