@@ -79,12 +79,27 @@ struct Cfg {
   static constexpr int NK2 = CMID / 16;
   static constexpr int MID_BYTES = TAIL ? (PG * PT * 32 * MPIXB) : 0;
   static constexpr int WL_BYTES = WL * NCT * 1024;
-  static constexpr int LDS_BYTES = NBUF * IN_BYTES + MID_BYTES + WL_BYTES;
+  static constexpr int BIAS_OFF = NBUF * IN_BYTES + MID_BYTES + WL_BYTES;   // 3 x 128 floats: bias, ds bias, tail bias
+  static constexpr int LDS_BYTES = BIAS_OFF + 3 * 128 * 4;
 };
 
-__device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// global -> LDS DMA (16 B per lane; LDS destination = wave-uniform base in M0 + lane * 16).
+// Issued through inline asm ON PURPOSE: when the compiler sees the global_load_lds builtin it assumes every
+// later LDS read may alias the in-flight DMA and inserts s_waitcnt vmcnt(0) in front of the first one --
+// i.e. it waits for the NEXT tile's prefetch before starting this tile's contraction, which silently turns
+// the double buffer into a single buffer.  With the DMA opaque to the compiler the hand-placed vmcnt waits
+// at the tile boundary are the only synchronisation with it.
+__device__ __forceinline__ void dma16(const void* g, const void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory");
+}
+
+// workgroup barrier for LDS hand-offs: LDS operations drained, no fence on global memory (__syncthreads()
+// would add s_waitcnt vmcnt(0) and drain the prefetch and the previous tile's stores with it)
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS>
@@ -101,6 +116,15 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   const int oyl = pix / C::TW, oxl = pix % C::TW;
   const int cog = blockIdx.y;        // cout group (NCT*32 channels each)
   const int co_base = (cog * NCT + ct) * 32;
+
+  // ---- biases into LDS.  They are re-read for every tile; as global loads the compiler's wait for them
+  //      (vmcnt is in-order) would also wait for the just-issued DMA prefetch of the next tile.
+  float* sbias = reinterpret_cast<float*>(smem + C::BIAS_OFF);
+  if (threadIdx.x < NCT * 32) {
+    sbias[threadIdx.x] = a.bias[cog * NCT * 32 + threadIdx.x];
+    if constexpr (DS) sbias[128 + threadIdx.x] = a.bds[cog * NCT * 32 + threadIdx.x];
+    if constexpr (TAIL) sbias[256 + threadIdx.x] = a.bias2[threadIdx.x];
+  }
 
   // ---- stationary weights
   constexpr int NKR = WREG ? (C::NK - C::WL) : 1;   // fragments held in VGPRs
@@ -184,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 
   int t = t_begin + bix;
   int buf = 0;
+  bool first = true;
   if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
   for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1)) {
     if (C::NBUF == 2) {
@@ -193,15 +218,18 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
       // outstanding operations waits for the DMA but not for the stores' write latency.
       constexpr int NST = (C::PG * C::PT * 32 * NCT * 4) / 256;
       static_assert(NST == 2 || NST == 4, "copy-out stores per thread");
-      if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // (first tile: no stores behind the DMA yet -> everything must have landed)
+      if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      __syncthreads();  // tile t landed for every wave; everyone is done with buffer buf^1 and `mid`
+      first = false;
+      block_barrier();  // tile t landed for every wave; everyone is done with buffer buf^1 and `mid`
       if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
     } else {
-      __syncthreads();  // everyone is done reading the single buffer / `mid`
+      block_barrier();  // everyone is done reading the single buffer / `mid`
       issue_dma(t, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      block_barrier();
     }
 
     const int n = t / tiles_per_img;
@@ -228,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 
     f32x16 accd[DS ? C::PT : 1];
     if constexpr (DS) {
-      const float* bp = a.bds + co_base + 4 * h;
+      const float* bp = sbias + 128 + ct * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     f32x16 acc[C::PT];
     {
       // accumulators start at the (BN-folded) bias of this lane's 16 channels
-      const float* bp = a.bias + co_base + 4 * h;
+      const float* bp = sbias + ct * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
@@ -346,9 +374,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
           *reinterpret_cast<half4*>(mid + pb * C::MPIXB + ((cm ^ fm) * 16) + 8 * h) = v;
         }
       }
-      __syncthreads();
+      block_barrier();
       {
-        const float* bp = a.bias2 + ct * 32 + 4 * h;
+        const float* bp = sbias + 256 + ct * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     constexpr int OPX = C::PG * C::PT * 32;
     static_assert(OPX * OPIXB <= C::IN_BYTES, "output staging must fit the input buffer");
     char* sout = TAIL ? (smem + C::NBUF * C::IN_BYTES) : (smem + buf * C::IN_BYTES);
-    __syncthreads();   // every wave is done reading the input buffer / mid tile
+    block_barrier();   // every wave is done reading the input buffer / mid tile
 #pragma unroll
     for (int pt = 0; pt < C::PT; ++pt) {
       const int pb = (pg * C::PT + pt) * 32 + pix;
@@ -401,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         *reinterpret_cast<half4*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
       }
     }
-    __syncthreads();
+    block_barrier();
     {
       const int cslice = TAIL ? 0 : cog * NCT * 32;
       for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     }
     if constexpr (DS) {
       // second output: the identity branch (bias already in accd, no ReLU), same staging tile
-      __syncthreads();
+      block_barrier();
 #pragma unroll
       for (int pt = 0; pt < C::PT; ++pt) {
         const int pb = (pg * C::PT + pt) * 32 + pix;
@@ -434,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
           *reinterpret_cast<half4*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
         }
       }
-      __syncthreads();
+      block_barrier();
       const int cslice = cog * NCT * 32;
       for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
         const int pb = i / OCPP, c = i - pb * OCPP;
@@ -492,6 +520,10 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// conv64.hip: one-wave-per-SIMD kernel for the 64->64 3x3 stride-1 workhorse
+int lfd_conv3x3_c64_launch(const void* in, void* out, const void* w_packed, const float* bias, const void* residual,
+                           const void* zeros, int n, int h, int w, int relu, hipStream_t st);
+
 extern "C" {
 
 // Packed-weight sizes: [cout/32][NK][64 lanes] half8  (NK = ks*ks*cin/16).
@@ -542,7 +574,11 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
   const int key = d->cin * 10000 + d->ks * 1000 + d->stride * 100 + (d->cout / 32) * 10 + (tail ? 1 : 0);
   switch (key) {
     // ---- 64-channel backbone body
-    case 64 * 10000 + 3100 + 20: return launch_conv<64, 3, 1, 2, true, false>(a, st);
+    case 64 * 10000 + 3100 + 20: {
+      static const int use_c64 = [] { const char* e = getenv("LFD_CONV64"); return e ? atoi(e) : 0; }();
+      if (use_c64) return lfd_conv3x3_c64_launch(in, out, w_packed, bias, residual, zeros, d->n, d->h, d->w, d->relu, st);
+      return launch_conv<64, 3, 1, 2, true, false>(a, st);
+    }
     case 64 * 10000 + 3200 + 20: return launch_conv<64, 3, 2, 2, true, false>(a, st);
     case 64 * 10000 + 3200 + 21: return launch_conv<64, 3, 2, 2, true, true>(a, st);
     case 64 * 10000 + 3200 + 40: return launch_conv<64, 3, 2, 4, true, false>(a, st);
