@@ -41,7 +41,6 @@ constexpr int STAGE_BYTES = 4 * 64 * 128;        // per wave: its two 32-pixel o
 constexpr int BIAS_OFF = NBUF * IN_BYTES + STAGE_BYTES;
 constexpr int LDS_BYTES = BIAS_OFF + 256;               // 163,584 B of the CU's 163,840 (one workgroup per CU)
 constexpr int NK = 36;
-constexpr int NDMA = (NSLOT * 8 + 63) / 64;      // 43 wave-level DMA instructions per tile
 
 // global -> LDS DMA (16 B per lane, LDS destination = wave-uniform base in M0 + lane * 16).
 // Issued through inline asm ON PURPOSE: when the compiler sees the global_load_lds builtin it assumes every
@@ -61,6 +60,7 @@ __device__ __forceinline__ void block_barrier() {   // s_barrier without the fen
 
 #ifdef LFD_C64_TIMING
 __device__ unsigned long long g_c64_dbg[8 * 64];
+__device__ unsigned long long g_c64_span[256 * 2];
 #define C64_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && it < 8) g_c64_dbg[it * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define C64_T(i)
@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = lane >> 5, pix = lane & 31;
+#ifdef LFD_C64_TIMING
+  if (threadIdx.x == 0) g_c64_span[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int nblk = gridDim.x;
   const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
@@ -80,14 +83,26 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
   const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
   const int t_step = (nblk + 7 - xcd) / 8;
   const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const long rowpitch = (long)a.W * 128;
 
-  // One DMA instruction (8 halo pixels x 8 chunks) of a tile into ring slot `buf`.  Instruction j of this
-  // wave is global instruction i = wave + 4*j of the tile's 43.  Always issued, so that every wave's
-  // VMEM-operation count per tile is a constant: a tile index past the end reads the zero line into the
-  // (free) ring slot instead.  The tile's scalars are computed once per tile (TileSrc); the per-lane part
-  // is recomputed per instruction from an opaque copy of the lane id -- letting the compiler hoist it out
-  // of the tile loop would cost 30+ registers that the 288-register filter does not leave.
-  struct TileSrc { const _Float16* img; int gy0, gx0; bool live; };
+  // ---- input halo tile [10 rows][34 pixels][128 B] -> ring slot.  With one wave per SIMD every VALU
+  // instruction sits in the MFMA stream, so the per-instruction address work is reduced to one select:
+  //   * columns 0..31: DMA instruction j of wave w covers halo row j, columns 8w..8w+7 -- the lane's offset
+  //     within the row is a kernel-lifetime constant, the row base is scalar;
+  //   * columns 32..33 (2 x 10 pixels = 160 chunks): one ordinary 16-byte load per thread and tile, written
+  //     to LDS with ds_write a few k-steps later.
+  // Every wave issues exactly 10 DMAs per tile (a tile index past the end reads the zero line into the free
+  // ring slot), which keeps the counted vmcnt at the tile boundary a constant.
+  const int dl_px = wave * 8 + (lane >> 3);
+  const int dl_c = (lane & 7) ^ ((dl_px >> 1) & 7);
+  const unsigned dl_off = dl_px * 128 + dl_c * 16;
+  const char* zsrc = reinterpret_cast<const char*>(a.zeros) + dl_c * 16;
+  const int e_iy = threadIdx.x >> 4, e_px = 32 + ((threadIdx.x >> 3) & 1);
+  const int e_c = (threadIdx.x & 7) ^ ((e_px >> 1) & 7);
+  const bool e_act = threadIdx.x < 160;
+  const unsigned e_lds = (e_iy * IW + e_px) * 128 + (threadIdx.x & 7) * 16;
+
+  struct TileSrc { const char* row0; int gy0, gx0; bool live; };
   auto tile_src = [&](int t) {
     TileSrc ts;
     ts.live = t < t_end;
@@ -95,36 +110,38 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
     const int n = tt / tiles_per_img;
     const int tr = tt - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
-    ts.img = a.in + (size_t)n * a.H * a.W * 64;
     ts.gy0 = ty0 * TH - 1; ts.gx0 = tx0 * TW - 1;
+    // address of halo pixel (row 0, column 0); outside the image for border tiles, only formed, never read
+    ts.row0 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + ts.gy0) * rowpitch + (long)ts.gx0 * 128;
     return ts;
   };
-  auto dma_instr = [&](int j, const TileSrc& ts, int buf) {
-    const int i = wave + 4 * j;
-    if (i < NDMA) {
-      int l = lane;
-      asm volatile("" : "+v"(l));
-      const int pslot = i * 8 + (l >> 3);
-      if (pslot < NSLOT) {
-        const int iy = (pslot * 241) >> 13, ix = pslot - iy * IW;   // pslot / 34 for pslot < 4096
-        const int c = (l & 7) ^ ((ix >> 1) & 7);
-        const int gy = ts.gy0 + iy, gx = ts.gx0 + ix;
-        const bool valid = ts.live && (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
-        const unsigned off = ((unsigned)(gy * a.W + gx) * 64u + (unsigned)c * 8u) * 2u;   // bytes within the image
-        const char* src = valid ? reinterpret_cast<const char*>(ts.img) + off : reinterpret_cast<const char*>(a.zeros) + c * 16;
-        dma16(src, smem + buf * IN_BYTES + i * 8 * 128);
-      }
-    }
+  auto dma_row = [&](int j, const TileSrc& ts, bool xvalid, int buf) {
+    const int gy = ts.gy0 + j;
+    const bool rv = ts.live && gy >= 0 && gy < a.H;
+    const char* rowp = ts.row0 + j * rowpitch;
+    const char* src = (rv && xvalid) ? rowp + dl_off : zsrc;
+    dma16(src, smem + buf * IN_BYTES + (j * IW + wave * 8) * 128);
   };
-  constexpr int NDJ = (NDMA + 3) / 4;   // 11 DMA instructions per wave per tile (wave 3: 10)
+  auto extra_load = [&](const TileSrc& ts) {
+    const int gy = ts.gy0 + e_iy, gx = ts.gx0 + e_px;
+    const bool ok = e_act && ts.live && gy >= 0 && gy < a.H && gx < a.W;   // gx >= 31 always
+    const char* src = ok ? ts.row0 + e_iy * rowpitch + e_px * 128 + e_c * 16 : zsrc;
+    return *reinterpret_cast<const uint4*>(src);
+  };
+  auto extra_store = [&](const uint4& v, int buf) {
+    if (e_act) *reinterpret_cast<uint4*>(smem + buf * IN_BYTES + e_lds) = v;
+  };
+  auto xvalid_of = [&](const TileSrc& ts) { const int gx = ts.gx0 + dl_px; return gx >= 0 && gx < a.W; };
 
   int t = t_begin + bix;
   // ring slot of iteration `it` is (it + 2) % 3, so the first tile lands in slot 2 while the filter is
   // staged through slots 0-1
   {
     const TileSrc ts0 = tile_src(t);
-#pragma unroll 1
-    for (int j = 0; j < NDJ; ++j) dma_instr(j, ts0, 2);
+    const bool xv = xvalid_of(ts0);
+#pragma unroll
+    for (int j = 0; j < IH; ++j) dma_row(j, ts0, xv, 2);
+    extra_store(extra_load(ts0), 2);
   }
 
   // ---- filter: global -> LDS once per workgroup (coalesced), then every wave copies all 72 fragments
@@ -146,8 +163,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
   __syncthreads();   // filter staging area is free for the input ring
   {
     const TileSrc ts1 = tile_src(t + t_step);
-#pragma unroll 1
-    for (int j = 0; j < NDJ; ++j) dma_instr(j, ts1, 0);
+    const bool xv = xvalid_of(ts1);
+#pragma unroll
+    for (int j = 0; j < IH; ++j) dma_row(j, ts1, xv, 0);
+    extra_store(extra_load(ts1), 0);
   }
 
   // ---- per-lane LDS read offsets: (column tap s, 16-channel group q); pixel row = 2*wave + pt
@@ -161,41 +180,38 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
     for (int q = 0; q < 4; ++q) xoff[s][q] = rowbase * 128 + (((2 * q + h) ^ f) * 16);
   }
 
-  // wave-private staging: this wave's two output rows x 32 pixels x 128 B (whole lines, all 64 channels)
+  // wave-private staging: this wave's two output rows x 32 pixels x 128 B (whole lines, all 64 channels).
+  // Pixel p (0..63), logical 16-byte chunk c lives at p*128 + ((c ^ ((p >> 1) & 7)) * 16).
   char* wst = smem + NBUF * IN_BYTES + wave * (64 * 128);
-  // copy-out of the PREVIOUS tile (instruction j = 8 pixels x 8 chunks) is spread over the current tile's
-  // contraction; stores of masked pixels (and of "no previous tile") go to the trash line
-  _Float16* p_img = a.out;
-  int p_oy0 = 1 << 28, p_tx0 = 0;
-  auto copy_load = [&](int j) {
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    const int p64 = j * 8 + (l >> 3), c8 = l & 7;
-    return *reinterpret_cast<const uint4*>(wst + p64 * 128 + ((c8 ^ ((p64 >> 1) & 7)) * 16));
-  };
+  // copy-out of the PREVIOUS tile (instruction j = pixels 8j..8j+7 x 8 chunks) is spread over the current
+  // tile's contraction; lane constants: LDS offset for even / odd j, global offset lane*16
+  int cl_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) cl_off[e] = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 4)) ^ (4 * e)) * 16);
+  char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + lane * 16 + (wave & 1) * 1024;
+  char* p_base = reinterpret_cast<char*>(a.out);   // previous tile: address of its (row oy0, column 32*tx0) pixel
+  int p_oy0 = 1 << 28, p_ox0 = 0;
+  auto copy_load = [&](int j) { return *reinterpret_cast<const uint4*>(wst + j * 1024 + cl_off[j & 1]); };
   auto copy_store = [&](int j, const uint4& v) {
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    const int p64 = j * 8 + (l >> 3), c8 = l & 7;
-    const int oy = p_oy0 + (p64 >> 5), oxp = p_tx0 * TW + (p64 & 31);
-    const unsigned off = ((unsigned)(oy * a.W + oxp) * 64u + (unsigned)c8 * 8u) * 2u;
-    char* dst = (oy < a.H && oxp < a.W) ? reinterpret_cast<char*>(p_img) + off
-                                        : reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (l & 63) * 16 + (wave & 1) * 1024;
+    const int oy = p_oy0 + (j >> 2), ox = p_ox0 + (j & 3) * 8 + (lane >> 3);
+    char* dst = (oy < a.H && ox < a.W) ? p_base + (j >> 2) * rowpitch + (j & 3) * 1024 + lane * 16 : trash;
     *reinterpret_cast<uint4*>(dst) = v;
   };
+  // staging write offsets of this lane's 8 (channel tile c, group g) half4s for pixel `pix` (+ 4096 for pt 1)
+  const int fo = (pix >> 1) & 7;
 
-  const float lo = a.relu ? 0.f : -__builtin_inff();   // branch-free optional ReLU
+  const float lo = (a.relu & 1) ? 0.f : -__builtin_inff();   // branch-free optional ReLU
   int it = 0;
   for (; t < t_end; t += t_step, ++it) {
     const int buf = (it + 2) % NBUF;
     // This tile's DMA was issued one whole iteration ago.  Everything this wave issued after it -- the next
-    // tile's DMA (>= 10 instructions) and, from the second iteration on, 8 copy-out stores -- may still be in
-    // flight; vmcnt retires in order, so allowing that many outstanding operations waits for exactly this tile.
+    // tile's 10 DMAs and, from the second iteration on, 8 copy-out stores -- may still be in flight; vmcnt
+    // retires in order, so allowing that many outstanding operations waits for exactly this tile.
     C64_T(0);
     if (it == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     C64_T(1);
-    block_barrier();   // tile landed for every wave; ring slot (it+3)%3 of tile t+2 was consumed last iteration
+    block_barrier();   // tile landed for every wave; the ring slot of tile t+2 was consumed last iteration
 
     const int n = t / tiles_per_img;
     const int tr = t - n * tiles_per_img;
@@ -203,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
     const char* xb = smem + buf * IN_BYTES;
     const int oy0 = ty0 * TH + wave * PT, ox = tx0 * TW + pix;
     const TileSrc ts2 = tile_src(t + 2 * t_step);
+    const bool xv2 = xvalid_of(ts2);
     const int buf2 = (it + 1) % NBUF;
 
     half4 resv[RES ? PT : 1][2][4];
@@ -237,14 +254,14 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
       return *reinterpret_cast<const half8*>(xb + xoff[s][q] + (r + pt) * IW * 128);
     };
     {
-      // Contraction, 36 k-steps x 4 MFMAs, with all of the tile's memory traffic spread through it so that
-      // no wave ever issues a burst that fills the CU's memory queue (a wave stalled on VMEM issue cannot
-      // issue MFMAs either, and with one wave per SIMD nobody else would):
-      //   k  0..10  one DMA instruction of tile t+2 (and, RES, k 0..15: one residual load of this tile)
-      //   k 16..31  copy-out of tile t-1: LDS read on even k, 16-byte global store on the following odd k
+      // Contraction, 36 k-steps x 4 MFMAs, with all of the tile's memory traffic spread through it:
+      //   k = 3j+1     DMA row j of tile t+2                       (10 per wave)
+      //   k = 0 / 33   columns 32..33 of tile t+2: global load / ds_write
+      //   k = 4j, 4j+2 copy-out of tile t-1: LDS read, then the 16-byte global store (8 per lane)
+      //   k = 2i+1     residual load i of this tile (RES)           (16 per lane)
       constexpr int PD = 3;
       half8 xq[PD + 1][PT];
-      uint4 cv;
+      uint4 cv, ev;
 #pragma unroll
       for (int k = 0; k < PD; ++k)
 #pragma unroll
@@ -255,15 +272,31 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
         }
-        if (k < NDJ) dma_instr(k, ts2, buf2);
+#ifdef LFD_C64_SKIP
+        if (!(a.relu & 2))
+#endif
+        if (k % 3 == 1 && k / 3 < IH) dma_row(k / 3, ts2, xv2, buf2);
+        if (k == 0) ev = extra_load(ts2);
+        if (k == 33) extra_store(ev, buf2);
         if constexpr (RES) {
-          if (k < 16) resv[k >> 3][(k >> 2) & 1][k & 3] = *reinterpret_cast<const half4*>(resp[k >> 3] + ((k >> 2) & 1) * 32 + 8 * (k & 3));
+          if ((k & 1) && (k >> 1) < 16) {
+            const int i = k >> 1;
+            resv[i >> 3][(i >> 2) & 1][i & 3] = *reinterpret_cast<const half4*>(resp[i >> 3] + ((i >> 2) & 1) * 32 + 8 * (i & 3));
+          }
         }
-        if (k >= 16 && k < 32) {
-          if ((k & 1) == 0) cv = copy_load((k - 16) >> 1);
-          else copy_store((k - 16) >> 1, cv);
+        if (k < 32) {
+          if ((k & 3) == 0) cv = copy_load(k >> 2);
+          else if ((k & 3) == 2) {
+#ifdef LFD_C64_SKIP
+            if (!(a.relu & 4))
+#endif
+            copy_store(k >> 2, cv);
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // no scheduling fence between this k-step's memory/address work and its MFMAs: with a single wave
+        // per SIMD the only place that work can hide is in the 32-cycle shadow of each MFMA, so the
+        // scheduler must be free to interleave it with the four MFMAs (a fence per k-step keeps the
+        // prefetch loads from sinking to their use)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -278,8 +311,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
     //      rows (the previous tile's copy-out finished reading them during the contraction above)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int p64 = pt * 32 + pix;
-      const int fo = (p64 >> 1) & 7;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -292,12 +323,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
           x0 = fmaxf(x0, lo); x1 = fmaxf(x1, lo); x2 = fmaxf(x2, lo); x3 = fmaxf(x3, lo);
           half4 v;
           v[0] = (_Float16)x0; v[1] = (_Float16)x1; v[2] = (_Float16)x2; v[3] = (_Float16)x3;
-          *reinterpret_cast<half4*>(wst + p64 * 128 + (((c * 4 + g) ^ fo) * 16) + 8 * h) = v;
+          *reinterpret_cast<half4*>(wst + pt * 4096 + pix * 128 + (((c * 4 + g) ^ fo) * 16) + 8 * h) = v;
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    p_img = a.out + (size_t)n * a.H * a.W * 64; p_oy0 = oy0; p_tx0 = tx0;
+    p_base = reinterpret_cast<char*>(a.out) + ((long)n * a.H + oy0) * rowpitch + (long)tx0 * TW * 128;
+    p_oy0 = oy0; p_ox0 = tx0 * TW;
     C64_T(4);
   }
   // flush the last tile's copy-out
@@ -306,6 +338,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c64(C64Args a) {
     for (int j = 0; j < 8; ++j) copy_store(j, copy_load(j));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS DMA may outlive the workgroup
+#ifdef LFD_C64_TIMING
+  if (threadIdx.x == 0) g_c64_span[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <bool RES>
@@ -332,6 +367,9 @@ int launch_c64(C64Args a, hipStream_t st) {
 #ifdef LFD_C64_TIMING
 extern "C" __attribute__((visibility("default"))) int lfd_debug_c64_timing(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c64_dbg), sizeof(unsigned long long) * 8 * 64);
+}
+extern "C" __attribute__((visibility("default"))) int lfd_debug_c64_span(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c64_span), sizeof(unsigned long long) * 512);
 }
 #endif
 

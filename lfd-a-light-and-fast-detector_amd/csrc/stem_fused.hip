@@ -39,6 +39,7 @@ struct FusedArgs {
   int H1, W1;            // after pair 1
   int H2, W2;            // after pair 2 (output)
   int tiles_x, tiles_y, ntiles;
+  int dbg;               // timing builds only: bit mask of phase-A stages to skip
 };
 
 template <int FMT>
@@ -317,6 +318,481 @@ __global__ __launch_bounds__(256, 2) void k_stem_fused(FusedArgs a) {
   }
 }
 
+// =====================================================================================================
+// k_stem2x: second-generation fused stem for C = 64, NHWC fp16 frames ("one wave per SIMD" design).
+//
+//   * ONE 256-thread workgroup per CU, 512 registers per wave: every wave keeps ALL four filters resident
+//     (3x3 s2 64->64: 72 fragments = 288 registers; the three small ones: 20 fragments) and produces whole
+//     128-byte pixel lines, so nothing but the intermediate tile itself is exchanged between waves.
+//   * 4 x 32 output tile; its 9 x 65-pixel stride-2 halo of the 540x960x64 intermediate is computed into LDS
+//     (76 KB, column-de-interleaved + XOR-swizzled: exactly what the 3x3 s2 contraction reads) from a 19 x 131
+//     pixel copy of the raw frame.  Halo recompute: x1.14 on the (small) first pair.
+//   * chained 1x1s without an LDS round trip: the accumulator layout of one MFMA (lane = pixel, register =
+//     output row) IS a valid B operand of the next one if the next filter's K order is permuted to match --
+//     registers 8(q&1)..8(q&1)+7 of channel tile q>>1 are k-step q.  The permutation (and a row permutation
+//     that makes every lane own 8 consecutive output channels = one 16-byte chunk) is applied when the
+//     filters are loaded, from the standard packed layout.
+//   * raw frame rows arrive as ALIGNED 16-byte chunks (never cross a page, so the over-read at a row's ends
+//     is always safe), prefetched one tile ahead into registers; the row's sub-chunk misalignment stays in the
+//     LDS copy and is folded into the im2col read address (unaligned LDS reads are legal on gfx950).
+// =====================================================================================================
+struct X2 {
+  static constexpr int TH = 4, TW = 32;
+  static constexpr int IH = 9, IW = 65, IWh = 33, IWs = 66;   // intermediate region (+ de-interleaved row pitch)
+  static constexpr int R = IH * IW, NG = (R + 31) / 32;        // 585 pixels = 19 MFMA groups
+  static constexpr int RH = 19, RW = 131;                      // raw frame region
+  static constexpr int NCH = 51, RSB = NCH * 16 + 16;          // aligned 16-B chunks per raw row / bytes per raw LDS row (+ shift slack)
+  static constexpr int NCHUNK = RH * NCH;                      // 969
+  static constexpr int RAW_BYTES = ((RH * RSB + 255) / 256) * 256;
+  static constexpr int MID_BYTES = IH * IWs * 128;
+  static constexpr int STG_BYTES = 4 * 32 * 128;
+  static constexpr int OFF_MID = RAW_BYTES, OFF_STG = OFF_MID + MID_BYTES, OFF_B = OFF_STG + STG_BYTES;
+  static constexpr int OFF_W4 = OFF_B + 4 * 64 * 4;            // conv4 filter (permuted fragments), 8 KB
+  static constexpr int OFF_DUMMY = OFF_W4 + 8 * 1024;          // write target of the 23 lanes past the region's end
+  static constexpr int LDS_BYTES = OFF_DUMMY + 64 * 16;
+};
+
+#ifdef LFD_X2_TIMING
+__device__ unsigned long long g_x2_dbg[8 * 8];
+#define X2_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && itn < 8) g_x2_dbg[itn * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X2_T(i)
+#endif
+typedef uint32_t __attribute__((aligned(2))) u32_a2;
+typedef uint16_t __attribute__((aligned(2))) u16_a2;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(2))) u32x4_a2;
+
+// two fp32 -> packed fp16 (round to nearest even) with ReLU: v_cvt_pk_f16_f32 + v_pk_max_f16.
+// (Compiler-visible operations, not inline asm: the hazard recogniser has to see the reads of the MFMA
+// result registers to insert the wait states they need.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_relu_pk(float x, float y) {
+  f32x2 f; f[0] = x; f[1] = y;
+  half2v h = __builtin_convertvector(f, half2v);
+  half2v z; z[0] = (_Float16)0.f; z[1] = (_Float16)0.f;
+  h = __builtin_elementwise_max(h, z);
+  union { half2v v; uint32_t u; } r; r.v = h;
+  return r.u;
+}
+// registers [8*half .. 8*half+7] of an accumulator -> 8 fp16 (ReLU) = one B operand / one 16-byte chunk
+__device__ __forceinline__ half8 relu8(const f32x16& acc, int half) {
+  union { half8 v; uint32_t u[4]; } r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r.u[e] = cvt_relu_pk(acc[8 * half + 2 * e], acc[8 * half + 2 * e + 1]);
+  return r.v;
+}
+
+__global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_raw = smem;
+  char* s_mid = smem + X2::OFF_MID;
+  float* s_b = reinterpret_cast<float*>(smem + X2::OFF_B);   // [4][64]: b1 b2 b3 b4
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int hh = lane >> 5, pix = lane & 31;
+
+  // ---- filters.  conv1 / conv3 in the standard order; the two 1x1s with permuted K (to consume the previous
+  //      accumulator registers directly) and permuted rows (8 consecutive channels per lane).
+  half8 w1r[2][2], w2r[2][4], w3r[2][36];
+  half8* s_w4 = reinterpret_cast<half8*>(smem + X2::OFF_W4);   // [2][4][64]; only needed for 8 MFMAs per tile
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w1r[c][k] = a.w1[(c * 2 + k) * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) w3r[c][k] = a.w3[(c * 36 + k) * 64 + lane];
+  }
+  {
+    const int m = lane & 31, hk = lane >> 5;
+    const int g = m >> 3, hm = (m >> 2) & 1, j = m & 3;
+    const int row = 16 * (g >> 1) + 8 * hm + 4 * (g & 1) + j;   // output channel (within its tile of 32) of MFMA row m
+    auto perm = [&](const half8* wstd, int c, int q) {
+      const _Float16* base = reinterpret_cast<const _Float16*>(wstd + (c * 4 + q) * 64);
+      const half4 lo = *reinterpret_cast<const half4*>(base + row * 8 + 4 * hk);          // k = 16q + 4hk + 0..3
+      const half4 hi = *reinterpret_cast<const half4*>(base + (row + 32) * 8 + 4 * hk);   // k = 16q + 8 + 4hk + 0..3
+      half8 r;
+      r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+      return r;
+    };
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        w2r[c][q] = perm(a.w2, c, q);
+        if (wave == 0) s_w4[(c * 4 + q) * 64 + lane] = perm(a.w4, c, q);
+      }
+  }
+  if (threadIdx.x < 64) {
+    s_b[threadIdx.x] = a.b1[threadIdx.x]; s_b[64 + threadIdx.x] = a.b2[threadIdx.x];
+    s_b[128 + threadIdx.x] = a.b3[threadIdx.x]; s_b[192 + threadIdx.x] = a.b4[threadIdx.x];
+  }
+  // ---- biases of conv1 / conv2 ride on the MFMAs instead of being read from LDS for every 32-pixel group
+  //      (16 KB of LDS traffic per group and wave -- phase A was LDS-bandwidth bound on it): a K slot whose B
+  //      element is 1.0 and whose A element is the bias, split hi + lo in fp16 (exact to ~2^-22 relative).
+  //      conv1 has 5 unused K slots (27 -> 32): slots 27, 28 = elements 3, 4 of k-step 1, lane half 1.
+  //      conv2 gets a fifth k-step whose B fragment is {1, 1, 0, ...} in lane half 0.
+  half8 wb2[2];
+  {
+    const int m = lane & 31, hk = lane >> 5;
+    const int g = m >> 3, hm = (m >> 2) & 1, j = m & 3;
+    const int row = 16 * (g >> 1) + 8 * hm + 4 * (g & 1) + j;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float b1v = a.b1[c * 32 + m];
+      const _Float16 b1h = (_Float16)b1v, b1l = (_Float16)(b1v - (float)b1h);
+      if (hk) { w1r[c][1][3] = b1h; w1r[c][1][4] = b1l; }
+      const float b2v = a.b2[c * 32 + row];
+      const _Float16 b2h = (_Float16)b2v, b2l = (_Float16)(b2v - (float)b2h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wb2[c][e] = (_Float16)0.f;
+      if (!hk) { wb2[c][0] = b2h; wb2[c][1] = b2l; }
+    }
+  }
+  union { half8 v; uint32_t u[4]; } ones_f;
+  ones_f.u[0] = hh ? 0u : 0x3c003c00u; ones_f.u[1] = 0u; ones_f.u[2] = 0u; ones_f.u[3] = 0u;
+  const half8 ones = ones_f.v;
+
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int t_begin = xcd * per_xcd;
+  const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
+  const int t_step = (nblk + 7 - xcd) / 8;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const long rowbytes = (long)a.W * 6;
+  const int dsh = (int)(rowbytes & 15);          // change of a row's 16-byte misalignment from one row to the next
+
+  // ---- raw frame tile: 19 rows x 51 aligned chunks, chunk c = tid + 256u (row r = c / 51, i = c % 51)
+  struct TileGeo { long rs0; int n, ty0, tx0, gyr0, gxr0, sh0; bool live; };
+  auto geo = [&](int t) {
+    TileGeo g;
+    g.live = t < t_end;
+    const int tt = g.live ? t : t_begin;
+    g.n = tt / tiles_per_img;
+    const int tr = tt - g.n * tiles_per_img;
+    g.ty0 = tr / a.tiles_x; g.tx0 = tr - g.ty0 * a.tiles_x;
+    g.gyr0 = 4 * g.ty0 * X2::TH - 3; g.gxr0 = 4 * g.tx0 * X2::TW - 3;   // raw origin = 2 * (2 * out - 1) - 1
+    // byte address of raw pixel (gyr0, gxr0): outside the frame for border tiles -- only its low bits and
+    // rows / chunks that are inside the frame are ever used
+    g.rs0 = (long)reinterpret_cast<uintptr_t>(a.in) + (((long)g.n * a.H + g.gyr0) * a.W + g.gxr0) * 6;
+    g.sh0 = (int)(g.rs0 & 15);
+    return g;
+  };
+  // this thread's four chunks: c = tid + 256u -> row r = c / 51, chunk i = c % 51.  Recomputed where needed
+  // (a handful of VALU per tile) rather than held in 16 registers across the whole kernel.
+  struct Chunk { int r, e, off, rd; };
+  auto chunk_of = [&](int u) {
+    Chunk k;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // opaque: keeps the compiler from hoisting these out of the tile loop
+    const int c = tid + 256 * u;
+    const int r = (c * 1286) >> 16, i = c - r * X2::NCH;   // c / 51 for c < 1024
+    k.r = c < X2::NCHUNK ? r : -1;
+    k.e = 8 * i;
+    k.off = r * (int)rowbytes + 16 * i;
+    k.rd = (r * dsh) & 15;
+    return k;
+  };
+  const char* safe_src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(a.in) & ~(uintptr_t)15);
+  // chunk (row r, i) holds halfs [8i - sh/2, 8i - sh/2 + 8) of the row, counted from column gxr0; it is needed
+  // iff its row is inside the frame and it contains a half of an in-frame column
+  auto chunk_ok = [&](const TileGeo& g, const Chunk& k, int& e0, int& elo, int& ehi) {
+    const int shr = (g.sh0 + k.rd) & 15;
+    e0 = k.e - (shr >> 1);
+    elo = (g.gxr0 < 0 ? -g.gxr0 : 0) * 3;
+    ehi = ((a.W - g.gxr0) < X2::RW ? (a.W - g.gxr0) : X2::RW) * 3;
+    const int gy = g.gyr0 + k.r;
+    return g.live && k.r >= 0 && gy >= 0 && gy < a.H && e0 + 8 > elo && e0 < ehi;
+  };
+  uint4 rawv[4];
+  // The loads are unconditional (clamped address) and their results are NOT touched here: any use -- even the
+  // zero-select for skipped chunks -- would make the compiler wait for the load right away and serialise the
+  // four round trips.  The select happens a tile later, in raw_store.
+  auto raw_fetch = [&](const TileGeo& g) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int e0, elo, ehi;
+      const Chunk k = chunk_of(u);
+      const bool ok = chunk_ok(g, k, e0, elo, ehi);
+      const int shr = (g.sh0 + k.rd) & 15;
+      const char* src = ok ? reinterpret_cast<const char*>(g.rs0) + (k.off - shr) : safe_src;
+      const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(src));
+      rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto raw_store = [&](const TileGeo& g) {
+    const bool edge = g.gxr0 < 0 || g.gxr0 + X2::RW > a.W;   // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const Chunk k = chunk_of(u);
+      if (u < 3 || k.r >= 0) {   // only the 4th chunk of a thread can be past the end (969 = 3*256 + 201)
+        int e0, elo, ehi;
+        const bool ok = chunk_ok(g, k, e0, elo, ehi);
+        uint4 v = ok ? rawv[u] : make_uint4(0u, 0u, 0u, 0u);
+        if (edge) {   // zero the halfs of out-of-frame columns inside a partially valid chunk
+          asm volatile("; edge tile" ::: "memory");   // (keeps this a branch: if-converted it costs ~25 VALU per chunk on every tile)
+          uint32_t* d = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ea = e0 + 2 * k, eb = ea + 1;
+            const uint32_t m = ((ea >= elo && ea < ehi) ? 0xffffu : 0u) | ((eb >= elo && eb < ehi) ? 0xffff0000u : 0u);
+            d[k] &= m;
+          }
+        }
+        // rows whose misalignment is 2 mod 4 are stored 2 bytes further right, so that every pixel of the LDS
+        // copy starts on a dword boundary (12 bytes per column pair): the im2col reads, 9 per 32-pixel group,
+        // are then plain aligned dword reads instead of split unaligned ones (measured: 640 -> ~150 cycles/group)
+        const int shr_s = (g.sh0 + k.rd) & 15;
+        *reinterpret_cast<u32x4_a2*>(s_raw + (k.r < 0 ? 0 : k.r) * X2::RSB + 2 * k.e + (shr_s & 2)) =
+            u32x4{v.x, v.y, v.z, v.w};
+      }
+    }
+  };
+
+  int t = t_begin + bix;
+  TileGeo g_cur = geo(t);
+  raw_fetch(g_cur);
+  raw_store(g_cur);
+
+  char* wst = smem + X2::OFF_STG + wave * 4096;   // wave-private output staging: [32 px][128 B], XOR-swizzled
+  const int fo = (pix >> 1) & 7;
+
+  // ---- phase A works on one 32-pixel group of the intermediate region per call chain; the stages are
+  //      written branch-free so that two groups can be interleaved in one basic block (with a single wave per
+  //      SIMD the only latency hiding there is comes from independent instructions of the same wave)
+  struct Grp {
+    int A0, A1, A2;          // byte addresses of raw rows 2my, 2my+1, 2my+2 at column 2mx
+    int dst;                 // byte address of the pixel's 128-byte slot in the intermediate tile (or the dummy)
+    int fk;                  // its swizzle key
+    uint32_t vmask;          // ~0 inside the intermediate image, 0 = zero padding of conv3
+    half8 f0, f1;            // im2col fragments (K = 27 -> 32)
+    f32x16 acc[2];
+    half8 bq[4];
+  };
+  int itn = 0;
+  for (; t < t_end; t += t_step, ++itn) {
+    X2_T(0);
+    const int gy1_0 = 2 * g_cur.ty0 * X2::TH - 1, gx1_0 = 2 * g_cur.tx0 * X2::TW - 1;   // intermediate-image origin
+    const int sh0 = g_cur.sh0;
+    __syncthreads();   // raw tile of this tile is in LDS; every wave is done reading the previous intermediate tile
+    X2_T(1);
+
+    // ================= phase A: raw -> conv1 -> conv2 -> intermediate tile (all in this wave) =================
+    auto s_addr = [&](Grp& G, int grp) {
+      const int jl = grp * 32 + pix;
+      const bool inreg = jl < X2::R;
+      const int jj = inreg ? jl : 0;
+      const int my = (jj * 1009) >> 16, mx = jj - my * X2::IW;     // jj / 65 for jj < 4096
+      const int r0 = 2 * my;
+      const int shb = sh0 + r0 * dsh;
+      const int a0 = r0 * X2::RSB + 12 * mx;
+      const int s0 = shb & 15, s1 = (shb + dsh) & 15, s2 = (shb + 2 * dsh) & 15;
+      G.A0 = a0 + s0 + (s0 & 2); G.A1 = a0 + X2::RSB + s1 + (s1 & 2); G.A2 = a0 + 2 * X2::RSB + s2 + (s2 & 2);   // dword aligned
+      const int gy1 = gy1_0 + my, gx1 = gx1_0 + mx;
+      G.vmask = (gy1 >= 0 && gy1 < a.H1 && gx1 >= 0 && gx1 < a.W1) ? 0xffffffffu : 0u;
+      const int rem = (mx & 1) * X2::IWh + (mx >> 1);
+      G.fk = (rem >> 1) & 7;
+      G.dst = inreg ? X2::OFF_MID + (my * X2::IWs + rem) * 128 : X2::OFF_DUMMY - 64 * 16 * 0 + 0;
+      if (!inreg) { G.dst = X2::OFF_DUMMY; G.fk = 0; }
+    };
+    // im2col: k-step 0 = {h0: row0 e0..7 | h1: row1 e0..7}, k-step 1 = {h0: row2 e0..7 | h1: row0 e8, row1 e8,
+    // row2 e8, 0 x5}, e = 3 * s + c (pack_stem_weight).  Both halves execute both variants and select.
+    auto s_load = [&](Grp& G) {
+      union { half8 v; uint32_t u[4]; } f0, f1;
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A1 : G.A0));
+      f0.u[0] = p0[0]; f0.u[1] = p0[1]; f0.u[2] = p0[2]; f0.u[3] = p0[3];
+      const uint32_t* p2 = reinterpret_cast<const uint32_t*>(s_raw + G.A2);
+      const uint32_t e0 = *reinterpret_cast<const uint32_t*>(s_raw + G.A0 + 16) & 0xffffu;
+      const uint32_t e1 = *reinterpret_cast<const uint32_t*>(s_raw + G.A1 + 16) & 0xffffu;
+      const uint32_t e2 = *reinterpret_cast<const uint32_t*>(s_raw + G.A2 + 16) & 0xffffu;
+      f1.u[0] = hh ? (e0 | (e1 << 16)) : p2[0];
+      f1.u[1] = hh ? (e2 | 0x3c000000u) : p2[1];   // element 3 = 1.0: bias slot (hi)
+      f1.u[2] = hh ? 0x00003c00u : p2[2];          // element 4 = 1.0: bias slot (lo)
+      f1.u[3] = hh ? 0u : p2[3];
+      G.f0 = f0.v; G.f1 = f1.v;
+    };
+    auto s_conv1 = [&](Grp& G) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][0], G.f0, zero, 0, 0, 0);
+        G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][1], G.f1, G.acc[c], 0, 0, 0);
+      }
+    };
+    auto s_relu1 = [&](Grp& G) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { G.bq[2 * c] = relu8(G.acc[c], 0); G.bq[2 * c + 1] = relu8(G.acc[c], 1); }
+    };
+    auto s_conv2 = [&](Grp& G) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb2[c], ones, zero, 0, 0, 0);   // bias k-step
+#pragma unroll
+        for (int q = 0; q < 4; ++q) G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[c][q], G.bq[q], G.acc[c], 0, 0, 0);
+      }
+    };
+    auto s_write = [&](Grp& G) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          union { half8 v; uint32_t u[4]; } r;
+          r.v = relu8(G.acc[c], g2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r.u[e] &= G.vmask;   // pixels outside the intermediate image = conv3's zero padding
+          *reinterpret_cast<half8*>(smem + G.dst + (((4 * c + 2 * g2 + hh) ^ G.fk) * 16)) = r.v;
+        }
+    };
+#pragma unroll 1
+    for (int gp = 0; gp < 2; ++gp) {          // groups (w, w+4) and (w+8, w+12): every wave has all four
+      Grp GA, GB;
+      s_addr(GA, wave + 8 * gp); s_addr(GB, wave + 8 * gp + 4);
+#ifdef LFD_X2_TIMING
+      GA.f0 = ones; GA.f1 = ones; GB.f0 = ones; GB.f1 = ones;
+      GA.bq[0] = GA.bq[1] = GA.bq[2] = GA.bq[3] = ones; GB.bq[0] = GB.bq[1] = GB.bq[2] = GB.bq[3] = ones;
+      for (int c = 0; c < 2; ++c) for (int e = 0; e < 16; ++e) { GA.acc[c][e] = 1.f; GB.acc[c][e] = 2.f; }
+      if (!(a.dbg & 1)) { s_load(GA); s_load(GB); }
+      if (!(a.dbg & 2)) { s_conv1(GA); s_conv1(GB); }
+      if (!(a.dbg & 4)) { s_relu1(GA); s_relu1(GB); }
+      if (!(a.dbg & 8)) { s_conv2(GA); s_conv2(GB); }
+      if (!(a.dbg & 16)) { s_write(GA); s_write(GB); }
+#else
+      s_load(GA); s_load(GB);
+      s_conv1(GA); s_conv1(GB);
+      s_relu1(GA); s_relu1(GB);
+      s_conv2(GA); s_conv2(GB);
+      s_write(GA); s_write(GB);
+#endif
+    }
+    if (wave + 16 < X2::NG) {                 // group w+16 exists for waves 0..2
+      Grp GA;
+      s_addr(GA, wave + 16);
+      s_load(GA); s_conv1(GA); s_relu1(GA); s_conv2(GA); s_write(GA);
+    }
+    X2_T(2);
+    __syncthreads();   // intermediate tile complete; raw tile consumed
+    X2_T(3);
+
+    // next tile's raw frame region: fetched now (registers), written to LDS at the end of this tile -- behind
+    // the barrier above nobody reads the raw tile any more, and the round trip hides under phase B
+    const TileGeo g_out = g_cur;
+    g_cur = geo(t + t_step);
+    raw_fetch(g_cur);
+
+    // ================= phase B: conv3 (3x3 s2, 64 -> 64) over the intermediate tile, this wave = output row =====
+    // LDS read offsets: lane pix = output column; tap column s reads intermediate column 2*pix + s, i.e.
+    // de-interleaved slot (s & 1) * 33 + pix + (s >> 1)
+    int xoff[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int rem = (s & 1) * X2::IWh + pix + (s >> 1);
+      const int f = (rem >> 1) & 7;
+      const int rowbase = (2 * wave) * X2::IWs + rem;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xoff[s][q] = rowbase * 128 + (((2 * q + hh) ^ f) * 16);
+    }
+    f32x16 acc3[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float* bp = s_b + 128 + c * 32 + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+        acc3[c][4 * g] = b4.x; acc3[c][4 * g + 1] = b4.y; acc3[c][4 * g + 2] = b4.z; acc3[c][4 * g + 3] = b4.w;
+      }
+    }
+    X2_T(4);
+    auto xfrag = [&](int k) {
+      const int r = k / 12, s = (k / 4) % 3, q = k % 4;
+      return *reinterpret_cast<const half8*>(s_mid + xoff[s][q] + r * X2::IWs * 128);
+    };
+    {
+      constexpr int PD = 3;
+      half8 xq[PD + 1];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) xq[k] = xfrag(k);
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        if (k + PD < 36) xq[(k + PD) % (PD + 1)] = xfrag(k + PD);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3r[c][k], xq[k % (PD + 1)], acc3[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    X2_T(5);
+    // conv4 (1x1) straight from conv3's accumulators
+    half8 bq[4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { bq[2 * c] = relu8(acc3[c], 0); bq[2 * c + 1] = relu8(acc3[c], 1); }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x16 acc;
+      const float* bp = s_b + 192 + c * 32 + 8 * hh;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const float4 ba = *reinterpret_cast<const float4*>(bp + 16 * g2), bb = *reinterpret_cast<const float4*>(bp + 16 * g2 + 4);
+        acc[8 * g2] = ba.x; acc[8 * g2 + 1] = ba.y; acc[8 * g2 + 2] = ba.z; acc[8 * g2 + 3] = ba.w;
+        acc[8 * g2 + 4] = bb.x; acc[8 * g2 + 5] = bb.y; acc[8 * g2 + 6] = bb.z; acc[8 * g2 + 7] = bb.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w4[(c * 4 + q) * 64 + lane], bq[q], acc, 0, 0, 0);
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2)
+        *reinterpret_cast<half8*>(wst + pix * 128 + (((4 * c + 2 * g2 + hh) ^ fo) * 16)) = relu8(acc, g2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- this wave's output row leaves as whole 128-byte lines
+    {
+      const int oy = g_out.ty0 * X2::TH + wave;
+#pragma unroll
+      for (int jc = 0; jc < 4; ++jc) {
+        const int p = jc * 8 + (lane >> 3), c8 = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(wst + p * 128 + ((c8 ^ ((p >> 1) & 7)) * 16));
+        const int ox = g_out.tx0 * X2::TW + p;
+        if (oy < a.H2 && ox < a.W2)
+          *reinterpret_cast<uint4*>(a.out + (((size_t)g_out.n * a.H2 + oy) * a.W2 + ox) * 64 + c8 * 8) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    raw_store(g_cur);   // (a tile index past the end stores zeros; nobody reads them)
+    X2_T(6);
+  }
+}
+#ifdef LFD_X2_TIMING
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int lfd_debug_x2_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x2_dbg), sizeof(unsigned long long) * 64);
+}
+namespace {
+#endif
+
+int launch_stem2x(FusedArgs a, hipStream_t st) {
+  a.tiles_x = (a.W2 + X2::TW - 1) / X2::TW;
+  a.tiles_y = (a.H2 + X2::TH - 1) / X2::TH;
+  const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
+  if (nt > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
+  a.ntiles = (int)nt;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem2x), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            X2::LDS_BYTES) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    done = true;
+  }
+  const int blocks = a.ntiles < 256 ? a.ntiles : 256;
+  if (blocks < 1) return LFD_OK;
+#ifdef LFD_X2_TIMING
+  { const char* e = getenv("LFD_X2_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
+  hipLaunchKernelGGL(k_stem2x, dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
 template <int NCT, int FMT>
 int launch_fused(FusedArgs a, hipStream_t st) {
   using F = FCfg<NCT>;
@@ -370,6 +846,8 @@ int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int3
   a.N = n; a.H = h; a.W = w;
   a.H1 = (h - 1) / 2 + 1; a.W1 = (w - 1) / 2 + 1;
   a.H2 = (a.H1 - 1) / 2 + 1; a.W2 = (a.W1 - 1) / 2 + 1;
+  static const int use_x2 = [] { const char* e = getenv("LFD_STEM2X"); return e ? atoi(e) : 1; }();
+  if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) return launch_stem2x(a, st);
   return channels == 64 ? dispatch_fmt<2>(in_format, a, st) : dispatch_fmt<1>(in_format, a, st);
 }
 

@@ -163,11 +163,16 @@ class EnginePlan(object):
             idx += 1
         # ---- whole 'faster' stem in one kernel when it has the fusable shape
         self.stem_fused = None
+        self.stem_second = None
         import os
         if (bb._stem_mode == 'faster' and c0 in (32, 64) and self.stem_first[3] is not None and len(self.convs) == 1
                 and self.convs[0].tail is not None and self.convs[0].cin == c0 and self.convs[0].cout == c0
-                and os.environ.get('LFD_FUSED_STEM') == '1'):   # opt-in: measured slower than the two-kernel stem
+                and os.environ.get('LFD_FUSED_STEM', '1') == '1'):
+            # one kernel for the whole stem (csrc/stem_fused.hip, k_stem2x): the 540x960x64 intermediate never
+            # reaches HBM.  Used for NHWC fp16 frames with 64 stem channels; other inputs run the two-kernel stem
+            # (stem_second keeps its conv descriptor, its intermediate buffer is allocated on first use).
             cv = self.convs.pop(0)
+            self.stem_second = cv
             self.stem_fused = (c0,) + tuple(self.stem_first[1:]) + (cv.w, cv.b, cv.tail[0], cv.tail[1], cv.dst)
         # ---- stages
         self.taps = []
@@ -332,7 +337,18 @@ class EnginePlan(object):
         """`after`: optional {number_of_convs_done: callable} hooks (used to fork the level-0 head)."""
         l = lib()
         sp = stream_ptr()
-        if self.stem_fused is not None:
+        if self.stem_fused is not None and not (fmt == 1 and self.stem_fused[0] == 64):
+            # two-kernel stem for the formats / widths the fused kernel does not cover
+            c0, w1, b1, w2, b2 = self.stem_first
+            mid = st.stem_mid(self)
+            check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(mid), sp),
+                  'lfd_stem_conv_f16')
+            c = self.stem_second
+            d = _lib.ConvDesc(st.n, mid.shape[1], mid.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu), c.cout, 1)
+            check(l.lfd_conv2d_nhwc_f16(C.byref(d), ptr(mid), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b), None,
+                                        ptr(c.tail[0]), ptr(c.tail[1]), ptr(ops.zero_line(self.device)), sp),
+                  'lfd_conv2d_nhwc_f16')
+        elif self.stem_fused is not None:
             c0, w1, b1, w2, b2, w3, b3, w4, b4, dst = self.stem_fused
             check(l.lfd_stem_faster_fused_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
                                               ptr(w3), ptr(b3), ptr(w4), ptr(b4), ptr(st.bufs[dst]), sp),
@@ -404,6 +420,13 @@ class EnginePlan(object):
 class _ShapeState(object):
     """Activation buffers and outputs for one input shape."""
 
+    def stem_mid(self, plan):
+        """stride-2 stem intermediate, only materialised when the two-kernel stem has to run"""
+        if self._stem_mid is None:
+            self._stem_mid = torch.empty((self.n, (self.h + 1) // 2, (self.w + 1) // 2, plan.buf_channels[plan.stem_out]),
+                                         dtype=torch.float16, device=plan.device)
+        return self._stem_mid
+
     def __init__(self, plan, n, h, w):
         dev = plan.device
         self.n, self.h, self.w = n, h, w
@@ -421,6 +444,7 @@ class _ShapeState(object):
                 dims[b] = (hh, ww)
                 self.bufs[b] = torch.empty((n, hh, ww, plan.buf_channels[b]), dtype=torch.float16, device=dev)
             self.dims = dims
+            self._stem_mid = None
             if plan.head is not None:
                 self.sizes = [dims[t] for t in plan.taps]
                 self.p_off = []

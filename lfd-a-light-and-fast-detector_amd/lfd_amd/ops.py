@@ -231,7 +231,7 @@ def conv2d_nhwc(x, w_packed, bias, cin, cout, ks, stride, relu, residual=None, t
     pad = ks // 2
     oh = (h + 2 * pad - ks) // stride + 1
     ow = (w_ + 2 * pad - ks) // stride + 1
-    d = _lib.ConvDesc(n, h, w_, cin, cout, ks, stride, int(bool(relu)), cout if tail else 0,
+    d = _lib.ConvDesc(n, h, w_, cin, cout, ks, stride, int(relu), cout if tail else 0,
                       int(bool(tail[2])) if tail else 0)
     with torch.cuda.device(x.device):
         if out is None:

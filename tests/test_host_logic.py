@@ -112,12 +112,14 @@ def test_engine_plan_structure_on_cpu():
     m = configs.build_model('WIDERFACE_LFD_S')
     m.eval()
     plan = engine.EnginePlan(m._backbone, m._neck, m._head, torch.device('cpu'))
-    # stem pair 1 fused in the stem kernel, stem pair 2 = conv with a chained 1x1 tail
-    assert plan.stem_first[0] == 64 and plan.stem_first[3] is not None and plan.stem_fused is None
-    assert plan.convs[0].tail is not None and plan.convs[0].stride == 2 and plan.convs[0].ks == 3
+    # the whole 'faster' stem is one kernel for NHWC fp16 frames (stem_fused); for other input formats stem pair 1
+    # runs in the stem kernel and stem pair 2 (stem_second) as a conv with a chained 1x1 tail
+    assert plan.stem_first[0] == 64 and plan.stem_first[3] is not None
+    assert plan.stem_fused is not None and plan.stem_second is not None
+    assert plan.stem_second.tail is not None and plan.stem_second.stride == 2 and plan.stem_second.ks == 3
     n3 = sum(1 for c in plan.convs if c.ks == 3)
     n1 = sum(1 for c in plan.convs if c.ks == 1)
-    assert (n3, n1) == (1 + 2 * 11, 0)          # 11 FasterBlocks; the 4 downsample branches ride on conv1
+    assert (n3, n1) == (2 * 11, 0)              # 11 FasterBlocks; the 4 downsample branches ride on conv1
     assert sum(1 for c in plan.convs if c.ds is not None) == 4
     assert len(plan.taps) == 5 and len(plan.levels) == 5
     assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
