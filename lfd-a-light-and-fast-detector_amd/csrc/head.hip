@@ -65,9 +65,17 @@ struct HeadArgs {
   const _Float16* zeros;
 };
 
-__device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// global -> LDS DMA through inline asm and a fence-free barrier: see conv.hip.  (With the builtin, the compiler
+// put s_waitcnt vmcnt(0) in front of the first LDS read / every __syncthreads(), i.e. each tile waited for the
+// whole ring -- including the tiles it had just requested -- and the 4-deep prefetch bought nothing.)
+__device__ __forceinline__ void dma16(const void* g, const void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -253,9 +261,22 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
     const TileId t = tile_of(u);
     const HeadLevel& L = a.lv[t.l];
     if (t.l != cur_level || t.n != cur_n) {
-      // (level, image) switch: everything in flight is drained by the compiler's own waits here
-      __syncthreads();                      // previous tile's readers of s_ab / s_bf are done
-      if (t.l != cur_level) load_level(t.l);
+      // (level, image) switch: the ring stays in flight; the compiler waits for the filter loads it can see
+      block_barrier();                      // previous tile's readers of s_ab / s_bf are done
+      if (t.l != cur_level) {
+        load_level(t.l);
+        // Touch the freshly loaded filters HERE: the compiler then waits for them inside this (rare) branch.
+        // Otherwise it places conservative vmcnt(k..0) waits at their uses in every iteration, and since vmcnt
+        // counts the DMA ring too, every tile would drain the whole prefetch ring.
+#pragma unroll
+        for (int k = 0; k < NKN; ++k) asm volatile("" : "+v"(wn[k]));
+#pragma unroll
+        for (int k = 0; k < NKH; ++k) asm volatile("" : "+v"(w1[k]));
+        if constexpr (PASS >= 2) {
+#pragma unroll
+          for (int k = 0; k < NKH; ++k) asm volatile("" : "+v"(w2[k]));
+        }
+      }
       if constexpr (PASS >= 2) {
         for (int i = threadIdx.x; i < 256 * (PASS - 1); i += 256) {
           const float* src = (i < 256 ? a.ab1 : a.ab2) + ((size_t)t.l * a.N + t.n) * HC * 2;
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    block_barrier();
     static_assert((NB == 4 && KD == 2) || (NB == 2 && KD == 4), "vmcnt immediates above assume these");
 
     f32x16 acc[2];
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
     }
     stage(acc, wn, xring + slot * XBYTES, std::integral_constant<int, CPPX>{});
     store_tile(acc, bufA, nullptr);
-    __syncthreads();
+    block_barrier();
     // conv1 (no bias: norm follows, lfd_head.py:97)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
       write_stats(acc, t.tg, t.p0, L.hw);
     } else {
       store_tile(acc, bufB, s_ab);
-      __syncthreads();
+      block_barrier();
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
       stage(acc, w2, bufB, std::integral_constant<int, HC / 8>{});
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
         write_stats(acc, t.tg, t.p0, L.hw);
       } else {
         store_tile(acc, bufA, s_ab + 256);   // bufA's neck tile was fully consumed before the last barrier
-        __syncthreads();
+        block_barrier();
         if (f_active) {
           f32x16 fa;
           {

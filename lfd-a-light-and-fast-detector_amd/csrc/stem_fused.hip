@@ -39,7 +39,7 @@ struct FusedArgs {
   int H1, W1;            // after pair 1
   int H2, W2;            // after pair 2 (output)
   int tiles_x, tiles_y, ntiles;
-  int dbg;               // timing builds only: bit mask of phase-A stages to skip
+  int stagger;           // 1: de-phase the workgroups at start (k_stem2x)
 };
 
 template <int FMT>
@@ -349,12 +349,16 @@ struct X2 {
   static constexpr int OFF_MID = RAW_BYTES, OFF_STG = OFF_MID + MID_BYTES, OFF_B = OFF_STG + STG_BYTES;
   static constexpr int OFF_W4 = OFF_B + 4 * 64 * 4;            // conv4 filter (permuted fragments), 8 KB
   static constexpr int OFF_DUMMY = OFF_W4 + 8 * 1024;          // write target of the 23 lanes past the region's end
-  static constexpr int LDS_BYTES = OFF_DUMMY + 64 * 16;
+  // per-thread constant tables (with one wave per SIMD every dependent VALU instruction costs ~8 cycles and nothing
+  // else is there to hide it: a 16-byte LDS read replaces the 20-30 instruction chains that rebuild these values)
+  static constexpr int OFF_TCH = OFF_DUMMY + 64 * 16;          // [4 chunks][256 threads] int4 {row, first half, byte offset, drift}
+  static constexpr int OFF_TXO = OFF_TCH + 4 * 256 * 16;       // [3 taps][256 threads] int4: phase-B read offsets
+  static constexpr int LDS_BYTES = OFF_TXO + 3 * 256 * 16;
 };
 
 #ifdef LFD_X2_TIMING
-__device__ unsigned long long g_x2_dbg[8 * 8];
-#define X2_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && itn < 8) g_x2_dbg[itn * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_x2_dbg[8 * 16];
+#define X2_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && itn < 8) g_x2_dbg[itn * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define X2_T(i)
 #endif
@@ -368,19 +372,27 @@ typedef u32x4 __attribute__((aligned(2))) u32x4_a2;
 // result registers to insert the wait states they need.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t cvt_relu_pk(float x, float y) {
+__device__ __forceinline__ uint32_t cvt_pk(float x, float y) {
   f32x2 f; f[0] = x; f[1] = y;
-  half2v h = __builtin_convertvector(f, half2v);
-  half2v z; z[0] = (_Float16)0.f; z[1] = (_Float16)0.f;
-  h = __builtin_elementwise_max(h, z);
-  union { half2v v; uint32_t u; } r; r.v = h;
+  union { half2v v; uint32_t u; } r; r.v = __builtin_convertvector(f, half2v);
   return r.u;
 }
-// registers [8*half .. 8*half+7] of an accumulator -> 8 fp16 (ReLU) = one B operand / one 16-byte chunk
+__device__ __forceinline__ uint32_t relu_pk(uint32_t h) {
+  union { half2v v; uint32_t u; } r; r.u = h;
+  half2v z; z[0] = (_Float16)0.f; z[1] = (_Float16)0.f;
+  r.v = __builtin_elementwise_max(r.v, z);
+  return r.u;
+}
+// registers [8*half .. 8*half+7] of an accumulator -> 8 fp16 (ReLU) = one B operand / one 16-byte chunk.
+// All conversions first, then all maxes: with a single wave per SIMD a VALU instruction that depends on the one
+// right before it stalls ~4 extra cycles (scratch/ub/valu.hip: 4.4 vs 8.0 cycles), cvt/max/cvt/max would pay that
+// on every pair.
 __device__ __forceinline__ half8 relu8(const f32x16& acc, int half) {
   union { half8 v; uint32_t u[4]; } r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r.u[e] = cvt_relu_pk(acc[8 * half + 2 * e], acc[8 * half + 2 * e + 1]);
+  for (int e = 0; e < 4; ++e) r.u[e] = cvt_pk(acc[8 * half + 2 * e], acc[8 * half + 2 * e + 1]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r.u[e] = relu_pk(r.u[e]);
   return r.v;
 }
 
@@ -484,75 +496,147 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   // this thread's four chunks: c = tid + 256u -> row r = c / 51, chunk i = c % 51.  Recomputed where needed
   // (a handful of VALU per tile) rather than held in 16 registers across the whole kernel.
   struct Chunk { int r, e, off, rd; };
+  {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = threadIdx.x + 256 * u;
+      const int r = c / X2::NCH, i = c - r * X2::NCH;
+      int4 k;
+      k.x = c < X2::NCHUNK ? r : -1; k.y = 8 * i; k.z = r * (int)rowbytes + 16 * i; k.w = (r * dsh) & 15;
+      reinterpret_cast<int4*>(smem + X2::OFF_TCH)[u * 256 + threadIdx.x] = k;
+    }
+    // phase-B LDS read offsets: lane pix = output column; tap column s reads intermediate column 2*pix + s, i.e.
+    // de-interleaved slot (s & 1) * 33 + pix + (s >> 1); wave w = output row w
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int rem = (s3 & 1) * X2::IWh + pix + (s3 >> 1);
+      const int f = (rem >> 1) & 7;
+      const int rowbase = (2 * wave) * X2::IWs + rem;
+      int4 k;
+      k.x = rowbase * 128 + (((0 + hh) ^ f) * 16); k.y = rowbase * 128 + (((2 + hh) ^ f) * 16);
+      k.z = rowbase * 128 + (((4 + hh) ^ f) * 16); k.w = rowbase * 128 + (((6 + hh) ^ f) * 16);
+      reinterpret_cast<int4*>(smem + X2::OFF_TXO)[s3 * 256 + threadIdx.x] = k;
+    }
+  }
   auto chunk_of = [&](int u) {
-    Chunk k;
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));                 // opaque: keeps the compiler from hoisting these out of the tile loop
-    const int c = tid + 256 * u;
-    const int r = (c * 1286) >> 16, i = c - r * X2::NCH;   // c / 51 for c < 1024
-    k.r = c < X2::NCHUNK ? r : -1;
-    k.e = 8 * i;
-    k.off = r * (int)rowbytes + 16 * i;
-    k.rd = (r * dsh) & 15;
+    const int4 v = reinterpret_cast<const int4*>(smem + X2::OFF_TCH)[u * 256 + threadIdx.x];
+    Chunk k; k.r = v.x; k.e = v.y; k.off = v.z; k.rd = v.w;
     return k;
   };
   const char* safe_src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(a.in) & ~(uintptr_t)15);
   // chunk (row r, i) holds halfs [8i - sh/2, 8i - sh/2 + 8) of the row, counted from column gxr0; it is needed
   // iff its row is inside the frame and it contains a half of an in-frame column
-  auto chunk_ok = [&](const TileGeo& g, const Chunk& k, int& e0, int& elo, int& ehi) {
+  // chunk (row r, i) holds halfs [e0, e0 + 8) of the row, counted from column gxr0 (e0 = 8i - sh/2), the dword in
+  // front of it ends with half e0 - 1.  okv / okp: the chunk / that half has something inside the frame.
+  auto chunk_ok = [&](const TileGeo& g, const Chunk& k, int& e0, int& elo, int& ehi, bool& okp) {
     const int shr = (g.sh0 + k.rd) & 15;
     e0 = k.e - (shr >> 1);
     elo = (g.gxr0 < 0 ? -g.gxr0 : 0) * 3;
     ehi = ((a.W - g.gxr0) < X2::RW ? (a.W - g.gxr0) : X2::RW) * 3;
     const int gy = g.gyr0 + k.r;
-    return g.live && k.r >= 0 && gy >= 0 && gy < a.H && e0 + 8 > elo && e0 < ehi;
+    const bool rowok = g.live && k.r >= 0 && gy >= 0 && gy < a.H;
+    okp = rowok && e0 - 1 >= elo && e0 - 1 < ehi;
+    return rowok && e0 + 8 > elo && e0 < ehi;
   };
   uint4 rawv[4];
+  uint32_t rawp[4];   // the dword in front of each chunk (its upper half moves into the chunk when the row is shifted)
+  // tile whose 19 x 131 raw region lies completely inside the frame (84 % of the tiles of a 1080p frame): every
+  // chunk is needed and nothing has to be masked
+  auto interior = [&](const TileGeo& g) {
+    return g.live && g.gyr0 >= 0 && g.gyr0 + X2::RH <= a.H && g.gxr0 >= 0 && g.gxr0 + X2::RW <= a.W;
+  };
   // The loads are unconditional (clamped address) and their results are NOT touched here: any use -- even the
   // zero-select for skipped chunks -- would make the compiler wait for the load right away and serialise the
   // four round trips.  The select happens a tile later, in raw_store.
-  auto raw_fetch = [&](const TileGeo& g) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+  auto raw_fetch1 = [&](const TileGeo& g, bool inner, int u) {
+    const Chunk k = chunk_of(u);
+    const int shr = (g.sh0 + k.rd) & 15;
+    const char* real = reinterpret_cast<const char*>(g.rs0) + (k.off - shr);
+    const char* src;
+    const char* srp;
+    if (inner) {
+      src = (u < 3 || k.r >= 0) ? real : safe_src + 16;
+      srp = src - 4;
+    } else {
       int e0, elo, ehi;
-      const Chunk k = chunk_of(u);
-      const bool ok = chunk_ok(g, k, e0, elo, ehi);
-      const int shr = (g.sh0 + k.rd) & 15;
-      const char* src = ok ? reinterpret_cast<const char*>(g.rs0) + (k.off - shr) : safe_src;
-      const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(src));
-      rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
+      bool okp;
+      const bool ok = chunk_ok(g, k, e0, elo, ehi, okp);
+      src = ok ? real : safe_src;
+      srp = okp ? real - 4 : safe_src;
     }
+    const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(src));
+    rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
+    rawp[u] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(reinterpret_cast<uintptr_t>(srp));
+  };
+  auto raw_fetch = [&](const TileGeo& g) {
+    const bool inner = interior(g);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw_fetch1(g, inner, u);
+  };
+  // Rows whose misalignment is 2 mod 4 are stored 2 bytes further right, so that every pixel of the LDS copy starts
+  // on a dword boundary (12 bytes per column pair) and the im2col reads are plain aligned dword reads.  The shift
+  // is done in registers (funnel shift with the dword in front of the chunk): a 2-byte-misaligned 16-byte LDS
+  // write costs 100+ cycles, 400+ with four waves writing (scratch/ub/vmem3.hip).
+  auto raw_put = [&](const TileGeo& g, const Chunk& k, const uint4& v, uint32_t prev) {
+    const int shr_s = (g.sh0 + k.rd) & 15;
+    u32x4 o;
+    if (shr_s & 2) {
+      o[0] = __builtin_amdgcn_alignbit(v.x, prev, 16); o[1] = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+      o[2] = __builtin_amdgcn_alignbit(v.z, v.y, 16);  o[3] = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+    } else {
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    *reinterpret_cast<u32x4*>(s_raw + (k.r < 0 ? 0 : k.r) * X2::RSB + 2 * k.e) = o;
   };
   auto raw_store = [&](const TileGeo& g) {
-    const bool edge = g.gxr0 < 0 || g.gxr0 + X2::RW > a.W;   // wave-uniform
+    if (interior(g)) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const Chunk k = chunk_of(u);
-      if (u < 3 || k.r >= 0) {   // only the 4th chunk of a thread can be past the end (969 = 3*256 + 201)
-        int e0, elo, ehi;
-        const bool ok = chunk_ok(g, k, e0, elo, ehi);
-        uint4 v = ok ? rawv[u] : make_uint4(0u, 0u, 0u, 0u);
-        if (edge) {   // zero the halfs of out-of-frame columns inside a partially valid chunk
-          asm volatile("; edge tile" ::: "memory");   // (keeps this a branch: if-converted it costs ~25 VALU per chunk on every tile)
-          uint32_t* d = reinterpret_cast<uint32_t*>(&v);
+      for (int u = 0; u < 4; ++u) {
+        const Chunk k = chunk_of(u);
+        if (u < 3 || k.r >= 0) raw_put(g, k, rawv[u], rawp[u]);   // only the 4th chunk of a thread can be past the end (969 = 3*256 + 201)
+      }
+    } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int ea = e0 + 2 * k, eb = ea + 1;
-            const uint32_t m = ((ea >= elo && ea < ehi) ? 0xffffu : 0u) | ((eb >= elo && eb < ehi) ? 0xffff0000u : 0u);
-            d[k] &= m;
+      for (int u = 0; u < 4; ++u) {
+        const Chunk k = chunk_of(u);
+        if (u < 3 || k.r >= 0) {
+          int e0, elo, ehi;
+          bool okp;
+          const bool ok = chunk_ok(g, k, e0, elo, ehi, okp);
+          const uint4 v = ok ? rawv[u] : make_uint4(0u, 0u, 0u, 0u);
+          const uint32_t pv = okp ? rawp[u] : 0u;
+          // after the (optional) one-half shift position kk of the chunk holds half e0s + kk of the row: zero the
+          // ones that belong to out-of-frame columns
+          const int shr_s = (g.sh0 + k.rd) & 15;
+          const int e0s = e0 - ((shr_s >> 1) & 1);
+          u32x4 o;
+          if (shr_s & 2) {
+            o[0] = __builtin_amdgcn_alignbit(v.x, pv, 16); o[1] = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+            o[2] = __builtin_amdgcn_alignbit(v.z, v.y, 16); o[3] = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+          } else {
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
           }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int ea = e0s + 2 * kk, eb = ea + 1;
+            const uint32_t m = ((ea >= elo && ea < ehi) ? 0xffffu : 0u) | ((eb >= elo && eb < ehi) ? 0xffff0000u : 0u);
+            o[kk] &= m;
+          }
+          *reinterpret_cast<u32x4*>(s_raw + k.r * X2::RSB + 2 * k.e) = o;
         }
-        // rows whose misalignment is 2 mod 4 are stored 2 bytes further right, so that every pixel of the LDS
-        // copy starts on a dword boundary (12 bytes per column pair): the im2col reads, 9 per 32-pixel group,
-        // are then plain aligned dword reads instead of split unaligned ones (measured: 640 -> ~150 cycles/group)
-        const int shr_s = (g.sh0 + k.rd) & 15;
-        *reinterpret_cast<u32x4_a2*>(s_raw + (k.r < 0 ? 0 : k.r) * X2::RSB + 2 * k.e + (shr_s & 2)) =
-            u32x4{v.x, v.y, v.z, v.w};
       }
     }
   };
 
   int t = t_begin + bix;
+  // De-phase the workgroups.  All 256 of them run the same tile loop at the same speed; started together, they
+  // would all hit the memory system in the same few hundred cycles of every tile (raw-frame loads, output stores)
+  // and leave it idle for the rest -- and a wave stalled on a full memory queue cannot issue anything else.
+  // A one-off start delay of 0..15/16 of a tile time spreads those bursts evenly.
+  {
+    const int steps = (a.stagger ? (bix & 15) : 0);
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(14);   // 14 * 64 = 896 cycles
+  }
   TileGeo g_cur = geo(t);
   raw_fetch(g_cur);
   raw_store(g_cur);
@@ -581,11 +665,9 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     X2_T(1);
 
     // ================= phase A: raw -> conv1 -> conv2 -> intermediate tile (all in this wave) =================
-    auto s_addr = [&](Grp& G, int grp) {
-      const int jl = grp * 32 + pix;
-      const bool inreg = jl < X2::R;
-      const int jj = inreg ? jl : 0;
-      const int my = (jj * 1009) >> 16, mx = jj - my * X2::IW;     // jj / 65 for jj < 4096
+    // Group -> pixels: groups 0..17 are the two 32-column halves of the nine rows (row = grp >> 1 is wave-uniform,
+    // so nearly all of the address arithmetic is scalar); group 18 is the left-over 65th column (9 pixels).
+    auto s_addr_px = [&](Grp& G, int my, int mx, bool inreg) {
       const int r0 = 2 * my;
       const int shb = sh0 + r0 * dsh;
       const int a0 = r0 * X2::RSB + 12 * mx;
@@ -594,24 +676,31 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
       const int gy1 = gy1_0 + my, gx1 = gx1_0 + mx;
       G.vmask = (gy1 >= 0 && gy1 < a.H1 && gx1 >= 0 && gx1 < a.W1) ? 0xffffffffu : 0u;
       const int rem = (mx & 1) * X2::IWh + (mx >> 1);
-      G.fk = (rem >> 1) & 7;
-      G.dst = inreg ? X2::OFF_MID + (my * X2::IWs + rem) * 128 : X2::OFF_DUMMY - 64 * 16 * 0 + 0;
-      if (!inreg) { G.dst = X2::OFF_DUMMY; G.fk = 0; }
+      G.fk = inreg ? (rem >> 1) & 7 : 0;
+      G.dst = inreg ? X2::OFF_MID + (my * X2::IWs + rem) * 128 : X2::OFF_DUMMY;
+    };
+    auto s_addr = [&](Grp& G, int grp) {          // grp < 18, wave-uniform
+      s_addr_px(G, grp >> 1, ((grp & 1) << 5) + pix, true);
+    };
+    auto s_addr_last = [&](Grp& G) {              // group 18: column 64, row = lane
+      s_addr_px(G, pix < X2::IH ? pix : X2::IH - 1, X2::IW - 1, pix < X2::IH);
     };
     // im2col: k-step 0 = {h0: row0 e0..7 | h1: row1 e0..7}, k-step 1 = {h0: row2 e0..7 | h1: row0 e8, row1 e8,
     // row2 e8, 0 x5}, e = 3 * s + c (pack_stem_weight).  Both halves execute both variants and select.
     auto s_load = [&](Grp& G) {
+      // every lane issues the same four reads (addresses differ by lane half) -- no load sits behind a condition,
+      // so the compiler keeps this straight-line and can interleave two groups
       union { half8 v; uint32_t u[4]; } f0, f1;
       const uint32_t* p0 = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A1 : G.A0));
       f0.u[0] = p0[0]; f0.u[1] = p0[1]; f0.u[2] = p0[2]; f0.u[3] = p0[3];
-      const uint32_t* p2 = reinterpret_cast<const uint32_t*>(s_raw + G.A2);
-      const uint32_t e0 = *reinterpret_cast<const uint32_t*>(s_raw + G.A0 + 16) & 0xffffu;
-      const uint32_t e1 = *reinterpret_cast<const uint32_t*>(s_raw + G.A1 + 16) & 0xffffu;
-      const uint32_t e2 = *reinterpret_cast<const uint32_t*>(s_raw + G.A2 + 16) & 0xffffu;
-      f1.u[0] = hh ? (e0 | (e1 << 16)) : p2[0];
-      f1.u[1] = hh ? (e2 | 0x3c000000u) : p2[1];   // element 3 = 1.0: bias slot (hi)
-      f1.u[2] = hh ? 0x00003c00u : p2[2];          // element 4 = 1.0: bias slot (lo)
-      f1.u[3] = hh ? 0u : p2[3];
+      const uint32_t* px = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A0 + 16 : G.A2));   // h0: row2 e0..7 | h1: row0 e8 (+7 unused)
+      const uint32_t x0 = px[0], x1 = px[1], x2 = px[2], x3 = px[3];
+      const uint32_t y1 = *reinterpret_cast<const uint32_t*>(s_raw + G.A1 + 16);                 // row1 e8 (low half)
+      const uint32_t y2 = *reinterpret_cast<const uint32_t*>(s_raw + G.A2 + 16);                 // row2 e8 (low half)
+      f1.u[0] = hh ? ((x0 & 0xffffu) | (y1 << 16)) : x0;
+      f1.u[1] = hh ? ((y2 & 0xffffu) | 0x3c000000u) : x1;   // element 3 = 1.0: bias slot (hi)
+      f1.u[2] = hh ? 0x00003c00u : x2;                      // element 4 = 1.0: bias slot (lo)
+      f1.u[3] = hh ? 0u : x3;
       G.f0 = f0.v; G.f1 = f1.v;
     };
     auto s_conv1 = [&](Grp& G) {
@@ -651,26 +740,15 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     for (int gp = 0; gp < 2; ++gp) {          // groups (w, w+4) and (w+8, w+12): every wave has all four
       Grp GA, GB;
       s_addr(GA, wave + 8 * gp); s_addr(GB, wave + 8 * gp + 4);
-#ifdef LFD_X2_TIMING
-      GA.f0 = ones; GA.f1 = ones; GB.f0 = ones; GB.f1 = ones;
-      GA.bq[0] = GA.bq[1] = GA.bq[2] = GA.bq[3] = ones; GB.bq[0] = GB.bq[1] = GB.bq[2] = GB.bq[3] = ones;
-      for (int c = 0; c < 2; ++c) for (int e = 0; e < 16; ++e) { GA.acc[c][e] = 1.f; GB.acc[c][e] = 2.f; }
-      if (!(a.dbg & 1)) { s_load(GA); s_load(GB); }
-      if (!(a.dbg & 2)) { s_conv1(GA); s_conv1(GB); }
-      if (!(a.dbg & 4)) { s_relu1(GA); s_relu1(GB); }
-      if (!(a.dbg & 8)) { s_conv2(GA); s_conv2(GB); }
-      if (!(a.dbg & 16)) { s_write(GA); s_write(GB); }
-#else
       s_load(GA); s_load(GB);
       s_conv1(GA); s_conv1(GB);
       s_relu1(GA); s_relu1(GB);
       s_conv2(GA); s_conv2(GB);
       s_write(GA); s_write(GB);
-#endif
     }
-    if (wave + 16 < X2::NG) {                 // group w+16 exists for waves 0..2
+    if (wave < 3) {                           // groups 16, 17 (row 8) and the left-over column: waves 0, 1, 2
       Grp GA;
-      s_addr(GA, wave + 16);
+      if (wave < 2) s_addr(GA, wave + 16); else s_addr_last(GA);
       s_load(GA); s_conv1(GA); s_relu1(GA); s_conv2(GA); s_write(GA);
     }
     X2_T(2);
@@ -684,16 +762,11 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     raw_fetch(g_cur);
 
     // ================= phase B: conv3 (3x3 s2, 64 -> 64) over the intermediate tile, this wave = output row =====
-    // LDS read offsets: lane pix = output column; tap column s reads intermediate column 2*pix + s, i.e.
-    // de-interleaved slot (s & 1) * 33 + pix + (s >> 1)
     int xoff[3][4];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int rem = (s & 1) * X2::IWh + pix + (s >> 1);
-      const int f = (rem >> 1) & 7;
-      const int rowbase = (2 * wave) * X2::IWs + rem;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xoff[s][q] = rowbase * 128 + (((2 * q + hh) ^ f) * 16);
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int4 k = reinterpret_cast<const int4*>(smem + X2::OFF_TXO)[s3 * 256 + threadIdx.x];
+      xoff[s3][0] = k.x; xoff[s3][1] = k.y; xoff[s3][2] = k.z; xoff[s3][3] = k.w;
     }
     f32x16 acc3[2];
 #pragma unroll
@@ -745,27 +818,36 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
         *reinterpret_cast<half8*>(wst + pix * 128 + (((4 * c + 2 * g2 + hh) ^ fo) * 16)) = relu8(acc, g2);
     }
     __builtin_amdgcn_wave_barrier();
+    X2_T(5 + 3);   // slot 8 unused by the reader; keeps numbering simple
+#ifdef LFD_X2_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X2_T(9);
+#endif
     // ---- this wave's output row leaves as whole 128-byte lines
     {
+      // instruction jc: pixels 8jc..8jc+7 x 8 chunks = 1 KB contiguous in the output row -> scalar row base
+      // + lane * 16 + jc * 1024; LDS side: pixel p's chunk c8 sits at ((c8 ^ (p >> 1)) & 7) -- (p >> 1) & 7 =
+      // 4 * (jc & 1) + (lane >> 4), two lane constants
       const int oy = g_out.ty0 * X2::TH + wave;
+      char* ob = reinterpret_cast<char*>(a.out) + (((long)g_out.n * a.H2 + oy) * a.W2 + (long)g_out.tx0 * X2::TW) * 128 + lane * 16;
+      const int ox0 = g_out.tx0 * X2::TW + (lane >> 3);
+      const int lo0 = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 4)) ^ 0) * 16), lo1 = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 4)) ^ 4) * 16);
 #pragma unroll
       for (int jc = 0; jc < 4; ++jc) {
-        const int p = jc * 8 + (lane >> 3), c8 = lane & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(wst + p * 128 + ((c8 ^ ((p >> 1) & 7)) * 16));
-        const int ox = g_out.tx0 * X2::TW + p;
-        if (oy < a.H2 && ox < a.W2)
-          *reinterpret_cast<uint4*>(a.out + (((size_t)g_out.n * a.H2 + oy) * a.W2 + ox) * 64 + c8 * 8) = v;
+        const uint4 v = *reinterpret_cast<const uint4*>(wst + jc * 1024 + ((jc & 1) ? lo1 : lo0));
+        if (oy < a.H2 && ox0 + jc * 8 < a.W2) *reinterpret_cast<uint4*>(ob + jc * 1024) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
-    raw_store(g_cur);   // (a tile index past the end stores zeros; nobody reads them)
     X2_T(6);
+    raw_store(g_cur);   // (a tile index past the end stores zeros; nobody reads them)
+    X2_T(7);
   }
 }
 #ifdef LFD_X2_TIMING
 }  // namespace
 extern "C" __attribute__((visibility("default"))) int lfd_debug_x2_timing(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x2_dbg), sizeof(unsigned long long) * 64);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x2_dbg), sizeof(unsigned long long) * 128);
 }
 namespace {
 #endif
@@ -785,9 +867,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   }
   const int blocks = a.ntiles < 256 ? a.ntiles : 256;
   if (blocks < 1) return LFD_OK;
-#ifdef LFD_X2_TIMING
-  { const char* e = getenv("LFD_X2_DBG"); a.dbg = e ? atoi(e) : 0; }
-#endif
+  { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg; }
   hipLaunchKernelGGL(k_stem2x, dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
