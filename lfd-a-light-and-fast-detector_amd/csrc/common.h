@@ -32,6 +32,23 @@ struct LfdCarver {
 
 __device__ __forceinline__ int lfd_lane() { return threadIdx.x & 63; }
 
+// Epilogue helper: two fp32 -> packed fp16 (round to nearest even, v_cvt_pk_f16_f32), then max with a packed
+// lower bound (v_pk_max_f16): lo2 = 0x00000000 is ReLU, 0xfc00fc00 (-inf, -inf) is the identity.  Rounding is
+// monotone and 0 is exact, so max(round(x), 0) == round(max(x, 0)); two instructions per PAIR instead of the
+// three per ELEMENT that fmaxf + a scalar conversion compile to (fmaxf also canonicalises its input).
+typedef float lfd_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lfd_f16x2 __attribute__((ext_vector_type(2)));
+#define LFD_PK_RELU 0x00000000u
+#define LFD_PK_NONE 0xfc00fc00u
+__device__ __forceinline__ uint32_t lfd_cvt_pk_max(float x, float y, uint32_t lo2) {
+  lfd_f32x2 f; f[0] = x; f[1] = y;
+  union { lfd_f16x2 v; uint32_t u; } r, l;
+  r.v = __builtin_convertvector(f, lfd_f16x2);
+  l.u = lo2;
+  r.v = __builtin_elementwise_max(r.v, l.v);
+  return r.u;
+}
+
 // Monotone float -> uint32 map (a < b  <=>  ord(a) < ord(b) for non-NaN floats).
 __device__ __forceinline__ uint32_t lfd_float_ord(float f) {
   uint32_t u = __float_as_uint(f);

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     if constexpr (TAIL) sbias[256 + threadIdx.x] = a.bias2[threadIdx.x];
   }
 
+  const uint32_t lo_mid = a.relu ? LFD_PK_RELU : LFD_PK_NONE;   // activation between the conv and its chained 1x1
+
   // ---- stationary weights
   constexpr int NKR = WREG ? (C::NK - C::WL) : 1;   // fragments held in VGPRs
   half8 wreg[NKR];
@@ -363,15 +365,11 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         const int fm = (pb / C::MPPR) % C::MCPP;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          half4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x = acc[pt][4 * g + j];
-            if (a.relu) x = fmaxf(x, 0.f);
-            v[j] = (_Float16)x;
-          }
+          uint2 v;
+          v.x = lfd_cvt_pk_max(acc[pt][4 * g + 0], acc[pt][4 * g + 1], lo_mid);
+          v.y = lfd_cvt_pk_max(acc[pt][4 * g + 2], acc[pt][4 * g + 3], lo_mid);
           const int cm = ct * 4 + g;
-          *reinterpret_cast<half4*>(mid + pb * C::MPIXB + ((cm ^ fm) * 16) + 8 * h) = v;
+          *reinterpret_cast<uint2*>(mid + pb * C::MPIXB + ((cm ^ fm) * 16) + 8 * h) = v;
         }
       }
       block_barrier();
@@ -405,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     // 16-byte chunks of one pixel line.  The staging tile lives in storage that is dead by now: the
     // consumed input buffer (or the `mid` tile of the chained 1x1).
     const int cout_out = TAIL ? a.cout2 : a.cout;
-    const int do_relu = TAIL ? a.relu2 : a.relu;
+    const uint32_t lo_out = (TAIL ? a.relu2 : a.relu) ? LFD_PK_RELU : LFD_PK_NONE;
     constexpr int OCPP = NCT * 4;                         // 16-byte chunks per pixel of this block's channel slice
     constexpr int OPIXB = NCT * 64;
     constexpr int OPPR = (OCPP >= 16) ? 1 : 16 / OCPP;
@@ -423,10 +421,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         if constexpr (RES) {
           x0 += (float)resv[pt][g][0]; x1 += (float)resv[pt][g][1]; x2 += (float)resv[pt][g][2]; x3 += (float)resv[pt][g][3];
         }
-        if (do_relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
-        half4 v;
-        v[0] = (_Float16)x0; v[1] = (_Float16)x1; v[2] = (_Float16)x2; v[3] = (_Float16)x3;
-        *reinterpret_cast<half4*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
+        uint2 v;
+        v.x = lfd_cvt_pk_max(x0, x1, lo_out);
+        v.y = lfd_cvt_pk_max(x2, x3, lo_out);
+        *reinterpret_cast<uint2*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
       }
     }
     block_barrier();

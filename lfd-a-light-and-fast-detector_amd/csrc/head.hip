@@ -193,14 +193,16 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
       }
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
-        half4 v;
+        float x[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float x = acc[pt][4 * g + j];
-          if (ab) x = x * sc[j] + sh[j];
-          v[j] = (_Float16)fmaxf(x, 0.f);
+          x[j] = acc[pt][4 * g + j];
+          if (ab) x[j] = x[j] * sc[j] + sh[j];
         }
-        *reinterpret_cast<half4*>(dst + lds_addr<HC / 8>(pt * 32 + pix, ct * 4 + g) + 8 * h) = v;
+        uint2 v;
+        v.x = lfd_cvt_pk_max(x[0], x[1], LFD_PK_RELU);
+        v.y = lfd_cvt_pk_max(x[2], x[3], LFD_PK_RELU);
+        *reinterpret_cast<uint2*>(dst + lds_addr<HC / 8>(pt * 32 + pix, ct * 4 + g) + 8 * h) = v;
       }
     }
   };

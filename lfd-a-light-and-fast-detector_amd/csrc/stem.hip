@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
       const int fm = (pb / MPPR) % MCPP;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        half4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (_Float16)fmaxf(acc[pt][4 * g + j], 0.f);
-        *reinterpret_cast<half4*>(s_mid + pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h) = v;
+        uint2 v;
+        v.x = lfd_cvt_pk_max(acc[pt][4 * g + 0], acc[pt][4 * g + 1], LFD_PK_RELU);
+        v.y = lfd_cvt_pk_max(acc[pt][4 * g + 2], acc[pt][4 * g + 3], LFD_PK_RELU);
+        *reinterpret_cast<uint2*>(s_mid + pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h) = v;
       }
     }
     __syncthreads();
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
     const int fm = (pb / MPPR) % MCPP;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      half4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (_Float16)fmaxf(acc[pt][4 * g + j], 0.f);
-      *reinterpret_cast<half4*>(s_out + pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h) = v;
+      uint2 v;
+      v.x = lfd_cvt_pk_max(acc[pt][4 * g + 0], acc[pt][4 * g + 1], LFD_PK_RELU);
+      v.y = lfd_cvt_pk_max(acc[pt][4 * g + 2], acc[pt][4 * g + 3], LFD_PK_RELU);
+      *reinterpret_cast<uint2*>(s_out + pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h) = v;
     }
   }
   __syncthreads();

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fused(FusedArgs a) {
 struct X2 {
   static constexpr int TH = 4, TW = 32;
   static constexpr int IH = 9, IW = 65, IWh = 33, IWs = 66;   // intermediate region (+ de-interleaved row pitch)
-  static constexpr int R = IH * IW, NG = (R + 31) / 32;        // 585 pixels = 19 MFMA groups
+  // (585 pixels = 18 row-half groups of 32 + the 65th column)
   static constexpr int RH = 19, RW = 131;                      // raw frame region
   static constexpr int NCH = 51, RSB = NCH * 16 + 16;          // aligned 16-B chunks per raw row / bytes per raw LDS row (+ shift slack)
   static constexpr int NCHUNK = RH * NCH;                      // 969
