@@ -385,7 +385,7 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t h) {
 }
 // registers [8*half .. 8*half+7] of an accumulator -> 8 fp16 (ReLU) = one B operand / one 16-byte chunk.
 // All conversions first, then all maxes: with a single wave per SIMD a VALU instruction that depends on the one
-// right before it stalls ~4 extra cycles (scratch/ub/valu.hip: 4.4 vs 8.0 cycles), cvt/max/cvt/max would pay that
+// right before it stalls ~4 extra cycles (tools/ub/valu.hip: 4.4 vs 8.0 cycles), cvt/max/cvt/max would pay that
 // on every pair.
 __device__ __forceinline__ half8 relu8(const f32x16& acc, int half) {
   union { half8 v; uint32_t u[4]; } r;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   // Rows whose misalignment is 2 mod 4 are stored 2 bytes further right, so that every pixel of the LDS copy starts
   // on a dword boundary (12 bytes per column pair) and the im2col reads are plain aligned dword reads.  The shift
   // is done in registers (funnel shift with the dword in front of the chunk): a 2-byte-misaligned 16-byte LDS
-  // write costs 100+ cycles, 400+ with four waves writing (scratch/ub/vmem3.hip).
+  // write costs 100+ cycles, 400+ with four waves writing (tools/ub/vmem3.hip).
   auto raw_put = [&](const TileGeo& g, const Chunk& k, const uint4& v, uint32_t prev) {
     const int shr_s = (g.sh0 + k.rd) & 15;
     u32x4 o;
