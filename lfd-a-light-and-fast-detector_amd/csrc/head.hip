@@ -60,6 +60,9 @@ struct HeadArgs {
   int grp_levels[LFD_MAX_LEVELS];      // levels handled by this launch (same tap channel count)
   int grp_tile_start[LFD_MAX_LEVELS];  // first launch-local tile of each of them
   int grp_n, grp_ntiles;
+  int grp_gpi[LFD_MAX_LEVELS];         // k_head2: 32-pixel groups per image of each of them
+  int h2_item_start[LFD_MAX_LEVELS];   //          first work item (= 4 chunks of H2_CH groups) of each of them
+  int h2_nitems;
   int gshift;            // log2(channels per group)  (GroupNorm(16,128) -> 3)
   int ntiles;
   const _Float16* zeros;
@@ -360,9 +363,275 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
   }
 }
 
+// =====================================================================================================
+// k_head2 (64-channel taps): one WAVE carries 32 pixels through the whole chain, registers only.
+//
+// k_head above splits the 128 head channels over the four waves of a workgroup, so every stage ends in an LDS
+// exchange + workgroup barrier (5 per 64-pixel tile) -- the kernel is barrier / latency bound.  Here each wave owns
+// all 128 channels of its 32 pixels:
+//   * the accumulators of one stage (lane = pixel, register = channel) are the B operand of the next stage
+//     directly -- registers 8(q&1)..8(q&1)+7 of channel tile q>>1 are k-step q; the next filter's K order is permuted
+//     to match when it is loaded.  No LDS traffic for activations, no barrier, no tile staging;
+//   * GroupNorm's per-(image, channel) scale is folded into the rows of the conv that produced the tensor (the same
+//     kind of fold the host does for BatchNorm, done on the device once per image with one fp16 rounding), its
+//     shift and the neck / final biases ride on an extra MFMA k-step (B = 1, A = value split hi + lo in fp16);
+//     between stages only ReLU + the fp16 pack remain (2 instructions per pair of values);
+//   * one 256-thread workgroup per CU, 512 registers per wave: conv1 and conv2 filters resident (256 registers);
+//     the level's neck / final filters sit in LDS, shared by the workgroup (a workgroup only ever works on one level
+//     at a time);
+//   * work unit = chunk of CH consecutive 32-pixel groups of one image; its GroupNorm partial sums are accumulated
+//     per lane and reduced across lanes once per chunk.  The chunking depends on the level geometry only, so the
+//     statistics -- and therefore the outputs -- of an image do not depend on the batch it is in.
+// =====================================================================================================
+constexpr int H2_CH = 12;      // groups per chunk (384 pixels = 6 statistics tiles): 904 chunks for 8 x 1080p, one per wave of 256 CUs
+
+__device__ __forceinline__ uint32_t h2_cvt_pk(float x, float y) {
+  lfd_f32x2 f; f[0] = x; f[1] = y;
+  union { lfd_f16x2 v; uint32_t u; } r; r.v = __builtin_convertvector(f, lfd_f16x2);
+  return r.u;
+}
+__device__ __forceinline__ uint32_t h2_relu_pk(uint32_t h) {
+  union { lfd_f16x2 v; uint32_t u; } r, z; r.u = h; z.u = 0u;
+  r.v = __builtin_elementwise_max(r.v, z.v);
+  return r.u;
+}
+
+template <int PASS, int FT>
+__global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
+  constexpr int CIN = 64, NKN = CIN / 16, NKH = HC / 16;
+  constexpr int WN_FRAGS = 4 * (NKN + 1);                              // neck: 4 cout tiles x (4 k-steps + bias step)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half8* s_wn = reinterpret_cast<half8*>(smem);                         // [4][NKN + 1][64 lanes]
+  half8* s_wf = s_wn + WN_FRAGS * 64;                                   // [FT][NKH + 1][64 lanes]
+  half8* s_wb = s_wf + (PASS == 3 ? FT * (NKH + 1) : 0) * 64 + (threadIdx.x >> 6) * 8 * 64;   // wave-private: GN shift k-steps [2][4][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int hh = lane >> 5, pix = lane & 31;
+
+  half8 w1[4][NKH], w2[PASS >= 2 ? 4 : 1][NKH];
+  float scale = 1.f;
+  union { half8 v; uint32_t u[4]; } ones_f;
+  ones_f.u[0] = hh ? 0u : 0x3c003c00u; ones_f.u[1] = 0u; ones_f.u[2] = 0u; ones_f.u[3] = 0u;
+  const half8 ones = ones_f.v;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // K-permuted fragment of a [128 -> 32*T] 1x1 filter in the standard packing: element e of lane (m, hk) is
+  // W[m][16q + 8(e>>2) + 4hk + (e&3)] = standard lane (m, e>>2), element 4hk + (e&3); rows optionally scaled
+  auto perm = [&](const half8* wstd, int c, int q, float rs) {
+    const int m = lane & 31, hk = lane >> 5;
+    const _Float16* base = reinterpret_cast<const _Float16*>(wstd + (c * NKH + q) * 64);
+    const half4 lo = *reinterpret_cast<const half4*>(base + m * 8 + 4 * hk);
+    const half4 hi = *reinterpret_cast<const half4*>(base + (m + 32) * 8 + 4 * hk);
+    half8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (_Float16)((float)lo[e] * rs); r[4 + e] = (_Float16)((float)hi[e] * rs); }
+    return r;
+  };
+  // bias k-step fragment: lane (m, hk = 0) = {hi, lo, 0 ...}
+  auto bias_frag = [&](float v) {
+    const _Float16 bh = (_Float16)v, bl = (_Float16)(v - (float)bh);
+    half8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.f;
+    if (!(lane >> 5)) { r[0] = bh; r[1] = bl; }
+    return r;
+  };
+  // accumulator registers [8*half, 8*half+8) -> 8 fp16 after ReLU = one B operand of the next stage
+  auto to_b = [&](const f32x16& acc, int half) {
+    union { half8 v; uint32_t u[4]; } r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.u[e] = h2_cvt_pk(acc[8 * half + 2 * e], acc[8 * half + 2 * e + 1]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.u[e] = h2_relu_pk(r.u[e]);
+    return r.v;
+  };
+
+  int cur_j = -1;
+  for (int item = blockIdx.x; item < a.h2_nitems; item += gridDim.x) {
+    // work item = 4 consecutive chunks of one level (wave w takes chunk 4 * local + w)
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < LFD_MAX_LEVELS; ++i)
+      if (i < a.grp_n && item >= a.h2_item_start[i]) j = i;
+    const int l = a.grp_levels[j];
+    const HeadLevel& L = a.lv[l];
+    if (j != cur_j) {
+      __syncthreads();                       // everybody is done with the previous level's LDS filters
+      for (int i = threadIdx.x; i < 4 * NKN * 64; i += 256) {
+        const int c = i / (NKN * 64), r = i - c * (NKN * 64);
+        s_wn[c * (NKN + 1) * 64 + r] = L.wn[i];
+      }
+      {
+        const int c = wave;                  // neck bias step of cout tile `wave`
+        s_wn[(c * (NKN + 1) + NKN) * 64 + lane] = bias_frag(L.bn[c * 32 + (lane & 31)]);
+      }
+      if constexpr (PASS == 3) {
+        for (int fq = wave; fq < FT * NKH; fq += 4) s_wf[((fq / NKH) * (NKH + 1) + (fq % NKH)) * 64 + lane] = perm(L.wf, fq / NKH, fq % NKH, 1.f);
+        if (wave < FT) s_wf[(wave * (NKH + 1) + NKH) * 64 + lane] = bias_frag(L.bf[wave * 32 + (lane & 31)]);
+        scale = L.scale ? L.scale[0] : 1.f;
+      }
+      __syncthreads();
+      cur_j = j;
+    }
+    const int gpi = a.grp_gpi[j], cpi = (gpi + H2_CH - 1) / H2_CH;
+    const int c = (item - a.h2_item_start[j]) * 4 + wave;
+    if (c >= cpi * a.N) continue;            // (no workgroup barrier below this point in the iteration)
+    const int n = c / cpi, ci = c - n * cpi;
+    const int g0 = ci * H2_CH, g1 = (g0 + H2_CH) < gpi ? (g0 + H2_CH) : gpi;
+
+    // ---- this image's filters: GroupNorm scale folded into the rows, shift as a bias k-step
+    {
+      const int m = lane & 31;
+      const float* t1 = a.ab1 + ((size_t)l * a.N + n) * HC * 2;
+      const float* t2 = a.ab2 + ((size_t)l * a.N + n) * HC * 2;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float sc1 = PASS >= 2 ? t1[(ct * 32 + m) * 2] : 1.f;
+#pragma unroll
+        for (int k = 0; k < NKH; ++k) w1[ct][k] = perm(L.w1, ct, k, sc1);
+        if constexpr (PASS >= 2) {
+          s_wb[ct * 64 + lane] = bias_frag(t1[(ct * 32 + m) * 2 + 1]);
+          const float sc2 = PASS == 3 ? t2[(ct * 32 + m) * 2] : 1.f;
+#pragma unroll
+          for (int k = 0; k < NKH; ++k) w2[ct][k] = perm(L.w2, ct, k, sc2);
+          if constexpr (PASS == 3) s_wb[(4 + ct) * 64 + lane] = bias_frag(t2[(ct * 32 + m) * 2 + 1]);
+        }
+      }
+    }
+
+    float s[PASS < 3 ? 16 : 1], ss[PASS < 3 ? 16 : 1];
+#pragma unroll
+    for (int i = 0; i < (PASS < 3 ? 16 : 1); ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    auto add_stats = [&](const f32x16 (&acc)[4], float vm, bool masked) {
+      if constexpr (PASS < 3) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float y = masked ? acc[ct][r] * vm : acc[ct][r];
+            s[ct * 4 + (r >> 2)] += y;
+            ss[ct * 4 + (r >> 2)] += y * y;
+          }
+      }
+    };
+
+    // x fragments of a group: lane (pixel, hh) reads channels 16q + 8hh .. +7 of its pixel (clamped inside the level)
+    half8 xq[NKN];
+    const _Float16* ximg = L.x + (size_t)n * L.hw * CIN + 8 * hh;
+    auto load_x = [&](int g) {
+      int p = g * 32 + pix;
+      p = p < L.hw ? p : L.hw - 1;
+#pragma unroll
+      for (int q = 0; q < NKN; ++q) xq[q] = *reinterpret_cast<const half8*>(ximg + (size_t)p * CIN + 16 * q);
+    };
+    load_x(g0);
+    for (int g = g0; g < g1; ++g) {
+      const int p0 = g * 32;
+      const bool tail = p0 + 32 > L.hw;                 // wave-uniform
+      const bool lane_ok = p0 + pix < L.hw;
+      // ---- neck: relu(Wn x + bn)
+      f32x16 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + NKN) * 64 + lane], ones, zero, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NKN; ++q)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + q) * 64 + lane], xq[q], acc[ct], 0, 0, 0);
+      }
+      if (g + 1 < g1) load_x(g + 1);       // next group's pixels: requested now, consumed at the top of the next iteration
+      half8 bq[NKH];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) { bq[2 * ct] = to_b(acc[ct], 0); bq[2 * ct + 1] = to_b(acc[ct], 1); }
+      // ---- conv1 (no bias: norm follows, lfd_head.py:97; passes 2, 3: GN1 folded in, its shift on the bias step)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        if constexpr (PASS >= 2) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[ct * 64 + lane], ones, zero, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NKH; ++q)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ct][q], bq[q], (PASS >= 2 || q > 0) ? acc[ct] : zero, 0, 0, 0);
+      }
+      if constexpr (PASS == 1) {
+        add_stats(acc, lane_ok ? 1.f : 0.f, tail);
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { bq[2 * ct] = to_b(acc[ct], 0); bq[2 * ct + 1] = to_b(acc[ct], 1); }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if constexpr (PASS == 3) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[(4 + ct) * 64 + lane], ones, zero, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NKH; ++q)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ct][q], bq[q], (PASS == 3 || q > 0) ? acc[ct] : zero, 0, 0, 0);
+        }
+        if constexpr (PASS == 2) {
+          add_stats(acc, lane_ok ? 1.f : 0.f, tail);
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) { bq[2 * ct] = to_b(acc[ct], 0); bq[2 * ct + 1] = to_b(acc[ct], 1); }
+          const size_t row = (size_t)n * a.P + L.p_off + p0 + pix;
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+            f32x16 fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wf[(f * (NKH + 1) + NKH) * 64 + lane], ones, zero, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NKH; ++q)
+              fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wf[(f * (NKH + 1) + q) * 64 + lane], bq[q], fa, 0, 0, 0);
+            if (lane_ok) {
+              // final rows: [reg x reg_rows][cls x cls_rows]; lane (pixel, hh) holds rows 8g + 4hh + j
+              if (a.reg_rows == 4 && f == 0 && hh == 0)
+                *reinterpret_cast<float4*>(a.out_reg + row * 4) = make_float4(fa[0] * scale, fa[1] * scale, fa[2] * scale, fa[3] * scale);
+              if (a.reg_rows == 4 && a.cls_rows == 1) {
+                if (f == 0 && hh == 1) a.out_cls[row * a.CC] = fa[0];
+              } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                  const int ch = f * 32 + 8 * (i >> 2) + 4 * hh + (i & 3) - a.reg_rows;
+                  if (ch >= 0 && ch < a.cls_rows) a.out_cls[row * a.CC + ch] = fa[i];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- chunk statistics: reduce over the 64 lanes, one writer per (chunk, group) slot = the slot of the chunk's
+    //      first 64-pixel tile (H2_CH is even, so chunks start on tile boundaries; k_gn_finalize reads every
+    //      H2_CH/2-th slot of these levels)
+    if constexpr (PASS < 3) {
+      const int gg = 1 << (a.gshift - 3);      // 8-channel blocks per GroupNorm group
+      float* dst = a.part + ((size_t)L.tile_start + (size_t)n * L.tiles_per_img + (g0 >> 1)) * (HC >> a.gshift) * 2;
+      float x = 0.f, xx = 0.f;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        x += wave_sum_f(s[b]); xx += wave_sum_f(ss[b]);
+        if (((b + 1) & (gg - 1)) == 0) {
+          if (lane == 0) *reinterpret_cast<float2*>(dst + (b / gg) * 2) = make_float2(x, xx);
+          x = 0.f; xx = 0.f;
+        }
+      }
+    }
+  }
+}
+
+template <int PASS, int FT>
+int launch_head2(const HeadArgs& a, hipStream_t st) {
+  constexpr int LDS = (4 * 5 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    done = true;
+  }
+  int blocks = a.h2_nitems < 256 ? a.h2_nitems : 256;
+  if (blocks < 1) return LFD_OK;
+  hipLaunchKernelGGL((k_head2<PASS, FT>), dim3(blocks), dim3(256), LDS, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
 // per (level, image, group): combine tile partials in fp64 (fixed order), emit per-channel (scale, shift)
 struct FinalizeArgs {
   int tile_start[LFD_MAX_LEVELS], tiles_per_img[LFD_MAX_LEVELS], hw[LFD_MAX_LEVELS];
+  int tile_stride[LFD_MAX_LEVELS];   // 1, or H2_CH / 2 for levels whose partials come from k_head2 (one slot per chunk)
   const float* gamma[LFD_MAX_LEVELS];
   const float* beta[LFD_MAX_LEVELS];
   const float* part;
@@ -385,15 +654,16 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
     double acc = 0.0;
     if (v < nv) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      const int T = f.tiles_per_img[l];
+      const int st = f.tile_stride[l];
+      const int T = (f.tiles_per_img[l] + st - 1) / st;   // slots that carry data
       int t = tl;
       for (; t + 24 < T; t += 32) {     // 4 independent loads in flight per thread
-        a0 += (double)f.part[(size_t)(t0 + t) * nv + v];
-        a1 += (double)f.part[(size_t)(t0 + t + 8) * nv + v];
-        a2 += (double)f.part[(size_t)(t0 + t + 16) * nv + v];
-        a3 += (double)f.part[(size_t)(t0 + t + 24) * nv + v];
+        a0 += (double)f.part[(size_t)(t0 + t * st) * nv + v];
+        a1 += (double)f.part[(size_t)(t0 + (t + 8) * st) * nv + v];
+        a2 += (double)f.part[(size_t)(t0 + (t + 16) * st) * nv + v];
+        a3 += (double)f.part[(size_t)(t0 + (t + 24) * st) * nv + v];
       }
-      for (; t < T; t += 8) a0 += (double)f.part[(size_t)(t0 + t) * nv + v];
+      for (; t < T; t += 8) a0 += (double)f.part[(size_t)(t0 + t * st) * nv + v];
       acc = (a0 + a1) + (a2 + a3);
     }
     sm[tl][v0] = acc;
@@ -448,6 +718,16 @@ int dispatch_head(int pass, int ft, const HeadArgs& a, hipStream_t st) {
   if (pass == 2) return launch_head<CIN, 2, 1>(a, st);
   if (pass == 3) return ft == 2 ? launch_head<CIN, 3, 2>(a, st) : launch_head<CIN, 3, 1>(a, st);
   return LFD_ERR_INVALID_ARGUMENT;
+}
+
+// levels whose passes run in k_head2 (and whose statistics therefore occupy one slot per chunk)
+static bool head2_enabled() {
+  static const int use_head2 = [] { const char* e = getenv("LFD_HEAD2"); return e ? atoi(e) : 1; }();
+  return use_head2 != 0;
+}
+static bool head2_level(const lfd_head_desc_t* d, int i) {
+  const int gsize = d->num_groups > 0 ? HC / d->num_groups : 0;
+  return head2_enabled() && d->level_cin[i] == 64 && gsize >= 8;
 }
 
 int fill_levels(const lfd_head_desc_t* d, int* tile_start, int* tiles_per_img, int* ntiles) {
@@ -528,6 +808,22 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
         ++a.grp_n;
       }
     if (a.grp_ntiles == 0) continue;
+    if (cin == 64 && head2_enabled() && gshift >= 3) {
+      // wave-per-32-pixels kernel: work items = 4 consecutive chunks (H2_CH groups of 32 pixels) of one level
+      a.h2_nitems = 0;
+      for (int j = 0; j < a.grp_n; ++j) {
+        const int i = a.grp_levels[j];
+        a.grp_gpi[j] = (d->level_hw[i] + 31) / 32;
+        const int cpi = (a.grp_gpi[j] + H2_CH - 1) / H2_CH;
+        a.h2_item_start[j] = a.h2_nitems;
+        a.h2_nitems += (cpi * d->n + 3) / 4;
+      }
+      if (pass == 1) rc = launch_head2<1, 1>(a, st);
+      else if (pass == 2) rc = launch_head2<2, 1>(a, st);
+      else rc = ft == 2 ? launch_head2<3, 2>(a, st) : launch_head2<3, 1>(a, st);
+      if (rc != LFD_OK) return rc;
+      continue;
+    }
     rc = cin == 64 ? dispatch_head<64>(pass, ft, a, st) : dispatch_head<128>(pass, ft, a, st);
     if (rc != LFD_OK) return rc;
   }
@@ -546,6 +842,7 @@ int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const
   for (int i = 0; i < d->num_levels; ++i) {
     if (!gamma[i] || !beta[i]) return LFD_ERR_INVALID_ARGUMENT;
     f.hw[i] = d->level_hw[i]; f.gamma[i] = gamma[i]; f.beta[i] = beta[i];
+    f.tile_stride[i] = head2_level(d, i) ? H2_CH / 2 : 1;
   }
   f.part = partial; f.ab = ab; f.N = d->n; f.ngroups = d->num_groups; f.gsize = HC / d->num_groups; f.eps = eps;
   hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels), dim3(256), 0, st, f);
