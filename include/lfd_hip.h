@@ -153,6 +153,35 @@ LFD_API int lfd_iou_loss_bwd_f32(const float* pred, const float* target, const f
 
 
 /* ------------------------------------------------------------------------------------------
+ * Target assignment: LFD.annotation_to_target / _generate_target_for_single_image
+ *   (lfd/model/lfd.py:109-259; on the CPU with [P, G] broadcasts in the reference).
+ * Whole batch in one launch.  Points are generated on the fly (lfd.py:84-107: x = j*stride, y = i*stride,
+ * level-major, row-major).  Ground truth: gt_boxes [sumG,4] (x, y, w, h), gt_labels [sumG], image i owns rows
+ * [gt_offsets[i], gt_offsets[i+1]).  Outputs: cls_targets [n, P, num_classes] (score in (0,1], 0 = negative,
+ * -1 = gray / ignored), reg_targets [n, P, 4] (l, t, r, b deltas; divided by the level's upper range when
+ * `independent`).  assign_mode: 0 'longer', 1 'shorter', 2 'sqrt', 3 'dist' (lfd.py:206-215).
+ * fp32, reference expression order, IEEE divide / sqrt: decisions and regression targets identical to the
+ * reference, scores identical up to the last bit of the host's sqrt routine. */
+typedef struct {
+  int32_t n, num_levels;
+  int32_t level_h[LFD_MAX_LEVELS], level_w[LFD_MAX_LEVELS], stride[LFD_MAX_LEVELS];
+  int32_t reg_lo[LFD_MAX_LEVELS], reg_hi[LFD_MAX_LEVELS];     /* regression_ranges (lfd.py:43) */
+  int32_t gray_lo[LFD_MAX_LEVELS], gray_hi[LFD_MAX_LEVELS];   /* gray ranges (lfd.py:49-50) */
+  int32_t total_points, num_classes;
+  int32_t assign_mode, independent;
+} lfd_assign_desc_t;
+LFD_API int lfd_assign_targets_f32(const lfd_assign_desc_t* d, const float* gt_boxes, const int64_t* gt_labels,
+                           const int32_t* gt_offsets, float* cls_targets, float* reg_targets, lfd_stream_t stream);
+
+/* CrossEntropyLoss core (lfd/model/losses/cross_entropy_loss.py:12-50 -> F.cross_entropy(pred, label,
+ * reduction='none'); TT100K configs): loss[i] = logsumexp(logits[i,:]) - logits[i, labels[i]];
+ * bwd: d_logits[i,j] = d_loss[i] * (softmax(logits[i,:])[j] - [j == labels[i]]). */
+LFD_API int lfd_cross_entropy_fwd_f32(const float* logits, const int64_t* labels, int64_t m, int32_t channels, float* loss,
+                              lfd_stream_t stream);
+LFD_API int lfd_cross_entropy_bwd_f32(const float* logits, const int64_t* labels, const float* d_loss, int64_t m,
+                              int32_t channels, float* d_logits, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Inference conv stack, NHWC fp16, fp32 accumulate on MFMA.  Replaces the nn.Conv2d +
  * nn.BatchNorm2d (folded) + ReLU (+ residual add) units of LFDResNet
  *   (lfd/model/backbone/lfd_resnet.py:96-154 FasterBlock, :21-93 FastBlock, :157-215 FastestBlock,

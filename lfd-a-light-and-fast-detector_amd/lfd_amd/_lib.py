@@ -48,6 +48,16 @@ class HeadLevelPtrs(C.Structure):
                 ('w2_packed', C.c_void_p), ('wf_packed', C.c_void_p), ('bf', C.c_void_p), ('scale', C.c_void_p)]
 
 
+class AssignDesc(C.Structure):
+    """lfd_assign_desc_t"""
+    _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32),
+                ('level_h', C.c_int32 * MAX_LEVELS), ('level_w', C.c_int32 * MAX_LEVELS), ('stride', C.c_int32 * MAX_LEVELS),
+                ('reg_lo', C.c_int32 * MAX_LEVELS), ('reg_hi', C.c_int32 * MAX_LEVELS),
+                ('gray_lo', C.c_int32 * MAX_LEVELS), ('gray_hi', C.c_int32 * MAX_LEVELS),
+                ('total_points', C.c_int32), ('num_classes', C.c_int32),
+                ('assign_mode', C.c_int32), ('independent', C.c_int32)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
@@ -66,6 +76,9 @@ _SIGNATURES = {
     'lfd_sigmoid_focal_loss_sum_f32': (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _SZ, _P]),
     'lfd_iou_loss_fwd_f32': (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     'lfd_iou_loss_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
+    'lfd_assign_targets_f32': (C.c_int, [C.POINTER(AssignDesc), _P, _P, _P, _P, _P, _P]),
+    'lfd_cross_entropy_fwd_f32': (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    'lfd_cross_entropy_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),

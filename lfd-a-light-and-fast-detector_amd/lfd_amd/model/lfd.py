@@ -144,6 +144,15 @@ class LFD(nn.Module):
         """lfd.py:109-153 -> ([N,P,C] cls targets, [N,P,4] reg targets), computed on the device the
         annotations live on (the reference does it on the CPU with [P,G] broadcasts)."""
         dev = gt_bboxes_list[0].device if len(gt_bboxes_list) else torch.device('cpu')
+        if dev.type == 'cuda':
+            # device path: one launch of lfd_assign_targets_f32 for the whole batch (csrc/targets.hip); the point
+            # grid is regenerated on the fly from the recorded feature-map sizes (same values as the list passed in)
+            sizes = [self._head_indexes_to_feature_map_sizes[i] for i in range(self._num_heads)]
+            assert [p.size(0) for p in all_point_coordinates_list] == [h * w for h, w in sizes]
+            return ops.assign_targets(sizes, self._point_strides, self._regression_ranges, self._gray_ranges,
+                                      self._num_classes, self._range_assign_mode,
+                                      self._regression_loss_type == 'independent', gt_bboxes_list, gt_labels_list)
+        # CPU tensors (where the reference itself runs this function): the reference's tensor algebra
         pts = torch.cat(all_point_coordinates_list, 0).to(dev)
         n_per = [p.size(0) for p in all_point_coordinates_list]
         rr = torch.cat([torch.tensor(self._regression_ranges[i], dtype=torch.int64)[None].expand(n_per[i], 2)

@@ -1,14 +1,29 @@
 """CrossEntropyLoss -- mirror of lfd/model/losses/cross_entropy_loss.py:12-50 (TT100K configs)."""
 import torch.nn as nn
-import torch.nn.functional as F
+from torch.autograd import Function
 
+from ... import ops
 from .utils import weight_reduce_loss
 
 __all__ = ['CrossEntropyLoss']
 
 
+class _CrossEntropyFunction(Function):
+    """F.cross_entropy(pred, label, reduction='none') through liblfd_hip.so (lfd_cross_entropy_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, pred, label):
+        ctx.save_for_backward(pred, label)
+        return ops.cross_entropy_forward(pred, label)
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        pred, label = ctx.saved_tensors
+        return ops.cross_entropy_backward(pred, label, d_loss.contiguous()), None
+
+
 def cross_entropy(pred, label, weight=None, reduction='mean', avg_factor=None):
-    loss = F.cross_entropy(pred, label, reduction='none')
+    loss = _CrossEntropyFunction.apply(pred, label)
     if weight is not None:
         weight = weight.float()
     return weight_reduce_loss(loss, weight=weight, reduction=reduction, avg_factor=avg_factor)

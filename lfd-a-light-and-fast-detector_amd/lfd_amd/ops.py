@@ -195,6 +195,66 @@ def iou_loss_backward(pred, target, d_loss, eps):
     return out
 
 
+def cross_entropy_forward(logits, labels):
+    """F.cross_entropy(logits, labels, reduction='none') on the device (cross_entropy_loss.py:12-16)."""
+    require_cuda(logits, 'cross_entropy forward')
+    x = logits.contiguous().float()
+    t = labels.contiguous().long()
+    out = torch.empty(x.size(0), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_cross_entropy_fwd_f32(ptr(x), ptr(t), x.size(0), x.size(1), ptr(out), stream_ptr()),
+              'lfd_cross_entropy_fwd_f32')
+    return out
+
+
+def cross_entropy_backward(logits, labels, d_loss):
+    require_cuda(logits, 'cross_entropy backward')
+    x = logits.contiguous().float()
+    t = labels.contiguous().long()
+    g = d_loss.contiguous().float()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_cross_entropy_bwd_f32(ptr(x), ptr(t), ptr(g), x.size(0), x.size(1), ptr(out), stream_ptr()),
+              'lfd_cross_entropy_bwd_f32')
+    return out
+
+
+ASSIGN_MODES = {'longer': 0, 'shorter': 1, 'sqrt': 2, 'dist': 3}
+
+
+def assign_targets(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent, gt_bboxes_list,
+                   gt_labels_list):
+    """LFD.annotation_to_target (lfd.py:109-259) for a batch: -> cls targets [N,P,C], reg targets [N,P,4] (fp32,
+    device resident).  gt_bboxes_list[i]: [G_i,4] xywh cuda tensor, gt_labels_list[i]: [G_i] int64."""
+    n = len(gt_bboxes_list)
+    dev = gt_bboxes_list[0].device
+    require_cuda(gt_bboxes_list[0], 'assign_targets')
+    d = _lib.AssignDesc()
+    d.n, d.num_levels = n, len(sizes)
+    total = 0
+    for i, (h, w) in enumerate(sizes):
+        d.level_h[i], d.level_w[i], d.stride[i] = int(h), int(w), int(strides[i])
+        d.reg_lo[i], d.reg_hi[i] = int(reg_ranges[i][0]), int(reg_ranges[i][1])
+        d.gray_lo[i], d.gray_hi[i] = int(gray_ranges[i][0]), int(gray_ranges[i][1])
+        total += int(h) * int(w)
+    d.total_points, d.num_classes = total, int(num_classes)
+    d.assign_mode, d.independent = ASSIGN_MODES[assign_mode], int(bool(independent))
+    counts = [int(b.size(0)) for b in gt_bboxes_list]
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32).to(dev)
+    if sum(counts):
+        boxes = torch.cat([b.reshape(-1, 4) for b in gt_bboxes_list], 0).contiguous().float()
+        labels = torch.cat([l.reshape(-1) for l in gt_labels_list], 0).contiguous().long()
+    else:
+        boxes = torch.zeros((1, 4), dtype=torch.float32, device=dev)
+        labels = torch.zeros((1,), dtype=torch.int64, device=dev)
+    cls_t = torch.empty((n, total, int(num_classes)), dtype=torch.float32, device=dev)
+    reg_t = torch.empty((n, total, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().lfd_assign_targets_f32(C.byref(d), ptr(boxes), ptr(labels), ptr(offs), ptr(cls_t), ptr(reg_t), stream_ptr()),
+              'lfd_assign_targets_f32')
+    return cls_t, reg_t
+
+
 # ------------------------------------------------------------------ conv stack (NHWC fp16)
 def pack_conv_weight(w):
     """[Cout,Cin,k,k] float (BN already folded) -> MFMA fragment order [Cout/32][k*k*Cin/16][64][8] fp16.
