@@ -52,7 +52,9 @@ struct Cfg {
   // the 64-ch 3x3 s1 workhorse: 28 of 36 fragments stay in registers, 2 taps are LDS-resident)
   static constexpr int WL = (WREG && CIN == 64 && KS == 3 && S == 1) ? 8 : 0;
   static constexpr int PT = (S == 1) ? 2 : 1;       // 32-pixel MFMA tiles per wave
-  static constexpr int TW = (S == 1) ? 32 : 16;     // output tile width
+  // output tile width.  3x3 s1 64ch: 8 rows x 16 columns (2 x 16 pixels per MFMA tile) -- 135x240 maps needs 2040 tiles =
+  // 3.98 rounds of the 512 resident workgroups instead of 2176 = 4.25 -> 5 with 4 x 32, and the halo shrinks 1.59 -> 1.41
+  static constexpr int TW = (S == 1 && !(CIN == 64 && KS == 3)) ? 32 : 16;
   static constexpr int RPT = 32 / TW;               // output rows per MFMA pixel tile
   static constexpr int PG = 4 / NCT;                // pixel groups (waves along pixels) per block
   static constexpr int TH = PG * PT * RPT;          // output tile height
