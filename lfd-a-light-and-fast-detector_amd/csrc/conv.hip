@@ -54,6 +54,7 @@ struct Cfg {
   static constexpr int PT = (S == 1) ? 2 : 1;       // 32-pixel MFMA tiles per wave
   // output tile width.  3x3 s1 64ch: 8 rows x 16 columns (2 x 16 pixels per MFMA tile) -- 135x240 maps needs 2040 tiles =
   // 3.98 rounds of the 512 resident workgroups instead of 2176 = 4.25 -> 5 with 4 x 32, and the halo shrinks 1.59 -> 1.41
+  // (same-session A/B against 4 x 32: 27.3-28.3 us vs 31.7-32.0 us per 135x240 launch, 31-32 vs 33-34 with residual)
   static constexpr int TW = (S == 1 && !(CIN == 64 && KS == 3)) ? 32 : 16;
   static constexpr int RPT = 32 / TW;               // output rows per MFMA pixel tile
   static constexpr int PG = 4 / NCT;                // pixel groups (waves along pixels) per block

@@ -499,19 +499,36 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       }
     }
 
-    float s[PASS < 3 ? 16 : 1], ss[PASS < 3 ? 16 : 1];
+    // GroupNorm partial sums of this lane: block b = 4ct + g covers channels 8b .. 8b+7, of which this lane holds 4
+    // (registers 4g .. 4g+3 of tile ct).  Pass 1 has registers to spare and keeps two fp32 lanes per accumulator
+    // (v_pk_add_f32 / v_pk_fma_f32: half the instructions); pass 2 (conv2's filter resident as well) keeps one.
+    constexpr int SW = (PASS == 1) ? 2 : 1;
+    float s[PASS < 3 ? 16 * SW : 1], ss[PASS < 3 ? 16 * SW : 1];
 #pragma unroll
-    for (int i = 0; i < (PASS < 3 ? 16 : 1); ++i) { s[i] = 0.f; ss[i] = 0.f; }
+    for (int i = 0; i < (PASS < 3 ? 16 * SW : 1); ++i) { s[i] = 0.f; ss[i] = 0.f; }
     auto add_stats = [&](const f32x16 (&acc)[4], float vm, bool masked) {
       if constexpr (PASS < 3) {
+        if (masked) {        // wave-uniform: only the last group of an image has pixels past the end
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+          for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float y = masked ? acc[ct][r] * vm : acc[ct][r];
-            s[ct * 4 + (r >> 2)] += y;
-            ss[ct * 4 + (r >> 2)] += y * y;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float y = acc[ct][r] * vm;
+              const int i = (ct * 4 + (r >> 2)) * SW + (SW == 2 ? (r & 1) : 0);
+              s[i] += y;
+              ss[i] = __builtin_fmaf(y, y, ss[i]);
+            }
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float y = acc[ct][r];
+              const int i = (ct * 4 + (r >> 2)) * SW + (SW == 2 ? (r & 1) : 0);
+              s[i] += y;
+              ss[i] = __builtin_fmaf(y, y, ss[i]);
+            }
+        }
       }
     };
 
@@ -601,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       float x = 0.f, xx = 0.f;
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
-        x += wave_sum_f(s[b]); xx += wave_sum_f(ss[b]);
+        x += wave_sum_f(SW == 2 ? s[2 * b] + s[2 * b + 1] : s[b]); xx += wave_sum_f(SW == 2 ? ss[2 * b] + ss[2 * b + 1] : ss[b]);
         if (((b + 1) & (gg - 1)) == 0) {
           if (lane == 0) *reinterpret_cast<float2*>(dst + (b / gg) * 2) = make_float2(x, xx);
           x = 0.f; xx = 0.f;

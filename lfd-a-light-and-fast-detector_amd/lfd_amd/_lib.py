@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblfd_hip.so')
+# LFD_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get('LFD_HIP_LIB') or os.path.join(_HERE, 'liblfd_hip.so')
 MAX_LEVELS = 8
 F32, F16 = 0, 1
 
