@@ -105,6 +105,19 @@ __device__ __forceinline__ void block_barrier() {
   asm volatile("" ::: "memory");
 }
 
+#ifdef LFD_CONV_TIMING
+__device__ unsigned long long g_conv_dbg[8 * 16];
+#define CV_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && dbg_it < 8) g_conv_dbg[dbg_it * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CV_T(i)
+#endif
+#ifdef LFD_CONV_TIMING
+#define CV_END() do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_conv_dbg[122] = __builtin_readcyclecounter(); g_conv_dbg[123] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define CV_END()
+#endif
+
+
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES), "DS: the residual block's 1x1 s2 downsample rides on its 3x3 s2 conv");
@@ -118,6 +131,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   const int pix = lane & 31;
   const int oyl = pix / C::TW, oxl = pix % C::TW;
   const int cog = blockIdx.y;        // cout group (NCT*32 channels each)
+#ifdef LFD_CONV_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_conv_dbg[120] = __builtin_readcyclecounter(); g_conv_dbg[121] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   const int co_base = (cog * NCT + ct) * 32;
 
   // ---- biases into LDS.  They are re-read for every tile; as global loads the compiler's wait for them
@@ -183,7 +199,55 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   const int t_step = (nblk + 7 - xcd) / 8;  // blocks living on this XCD
   const int tiles_per_img = a.tiles_x * a.tiles_y;
 
+  // FAST (the 3x3 s1 64-channel workhorse, 8 x 16 tile, 10 x 18 halo): DMA instructions are aligned to halo rows --
+  // columns 0..15 of a row are two 64-lane instructions, columns 16..17 one 16-lane instruction -- so that the source
+  // address is a SCALAR row base + a per-lane constant and the only per-instruction vector work is the validity
+  // select.  (The generic slot walk below costs ~40 dependent VALU instructions per DMA -- integer divide, 64-bit
+  // multiply -- which measured 2.6 k cycles per tile, as long as the tile's whole contraction.)
+  constexpr bool FAST = (CIN == 64 && KS == 3 && S == 1 && !TAIL && !DS);
+  const long f_rowpitch = (long)a.W * (CIN * 2);
+  auto issue_dma_fast = [&](int t, int buf) {
+    int ol = lane;
+    asm volatile("" : "+v"(ol));     // opaque: the per-lane constants below are recomputed per tile (5 VALU) instead of
+                                     // being hoisted into registers this 256-VGPR kernel does not have
+    const int f_lpx = ol >> 3;
+    const int f_c0 = ((ol & 7) ^ (f_lpx >> 1)) * 16;                     // chunk offset for columns 0..7 (key = ix >> 1)
+    const int f_off0 = f_lpx * 128 + f_c0, f_off1 = 1024 + f_lpx * 128 + (f_c0 ^ 64);   // columns 8..15: key + 4
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * C::TH - 1, gx0 = tx0 * C::TW - 1;
+    // address of halo pixel (row 0, column 0) -- outside the image for border tiles, only formed
+    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * f_rowpitch + (long)gx0 * (CIN * 2);
+    const char* zsrc0 = reinterpret_cast<const char*>(a.zeros) + f_c0;
+    const char* zsrc1 = reinterpret_cast<const char*>(a.zeros) + (f_c0 ^ 64);
+    const bool xv0 = (gx0 + f_lpx >= 0) && (gx0 + f_lpx < a.W);
+    const bool xv1 = (gx0 + 8 + f_lpx < a.W);
+    char* lbase = smem + buf * C::IN_BYTES;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int m = wave + 4 * j;                  // 20 main instructions: row m >> 1, column half m & 1
+      const int iy = m >> 1, hf = m & 1;
+      const int gy = gy0 + iy;
+      const bool rv = gy >= 0 && gy < a.H;
+      const char* rowp = p00 + iy * f_rowpitch;
+      const char* src = hf ? ((rv && xv1) ? rowp + f_off1 : zsrc1) : ((rv && xv0) ? rowp + f_off0 : zsrc0);
+      dma16(src, lbase + (iy * C::IWs + 8 * hf) * C::PIXB);
+    }
+    // columns 16, 17 of row iy: 16 lanes (2 pixels x 8 chunks, key = 0); rows wave, wave + 4, wave + 8
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int iy = wave + 4 * j;
+      if (iy < C::IH && ol < 16) {
+        const int gy = gy0 + iy, gx = gx0 + 16 + (ol >> 3);
+        const bool ok = gy >= 0 && gy < a.H && gx < a.W;
+        const char* src = ok ? p00 + iy * f_rowpitch + 2048 + ol * 16 : reinterpret_cast<const char*>(a.zeros) + (ol & 7) * 16;
+        dma16(src, lbase + (iy * C::IWs + 16) * C::PIXB);
+      }
+    }
+  };
   auto issue_dma = [&](int t, int buf) {
+    if constexpr (FAST) { issue_dma_fast(t, buf); return; }
     const int n = t / tiles_per_img;
     const int tr = t - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
@@ -215,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   int buf = 0;
   bool first = true;
   if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
-  for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1)) {
+  int dbg_it = 0; (void)dbg_it;
+  for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1), ++dbg_it) {
+    bool has_next_tile = false; (void)has_next_tile;
+    CV_T(0);
     if (C::NBUF == 2) {
       // Tile t's DMA was issued one iteration ago; the only VMEM operations issued after it that can
       // still be in flight are the previous tile's NST copy-out stores (every lane issues exactly NST
@@ -228,8 +295,12 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
       else if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       first = false;
+      CV_T(1);
       block_barrier();  // tile t landed for every wave; everyone is done with buffer buf^1 and `mid`
-      if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
+      CV_T(2);
+      has_next_tile = t + t_step < t_end;
+      if (has_next_tile) issue_dma(t + t_step, buf ^ 1);
+      CV_T(3);
     } else {
       block_barrier();  // everyone is done reading the single buffer / `mid`
       issue_dma(t, 0);
@@ -400,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
       }
     }
 
+    CV_T(4);
     // ---- epilogue: (+ residual) -> ReLU -> fp16 -> LDS staging -> full-line 16-byte NHWC stores.
     // Straight from the accumulator layout every store instruction would touch 32 pixel lines with
     // 16 bytes each (store-issue bound); staged through LDS, consecutive lanes write consecutive
@@ -414,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     static_assert(OPX * OPIXB <= C::IN_BYTES, "output staging must fit the input buffer");
     char* sout = TAIL ? (smem + C::NBUF * C::IN_BYTES) : (smem + buf * C::IN_BYTES);
     block_barrier();   // every wave is done reading the input buffer / mid tile
+    CV_T(5);
 #pragma unroll
     for (int pt = 0; pt < C::PT; ++pt) {
       const int pb = (pg * C::PT + pt) * 32 + pix;
@@ -430,8 +503,27 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         *reinterpret_cast<uint2*>(sout + pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h) = v;
       }
     }
+    CV_T(6);
     block_barrier();
-    {
+    CV_T(7);
+    if constexpr (FAST) {
+      // iteration k of thread tid: staging pixel (tid >> 3) + 32k = MFMA tile k, pixel tid >> 3 -> output row
+      // 8 ty0 + 2k + (tid >> 7), column 16 tx0 + ((tid >> 3) & 15), chunk tid & 7: scalar row base + per-thread constant
+      int otid = threadIdx.x;
+      asm volatile("" : "+v"(otid));   // (opaque for the same reason as in issue_dma_fast)
+      const int trow = otid >> 7, tcol = (otid >> 3) & 15, tc = otid & 7;
+      const int lofs = (otid >> 3) * OPIXB + ((tc ^ ((otid >> 4) & 7)) * 16);
+      const long gofs = trow * f_rowpitch + tcol * 128 + tc * 16;
+      char* obase = reinterpret_cast<char*>(a.out) + ((long)n * a.OH + ty0 * C::TH) * f_rowpitch + (long)tx0 * C::TW * 128;
+      const bool colok = tx0 * C::TW + tcol < a.OW;
+      char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (otid & 127) * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sout + k * 4096 + lofs);
+        char* dst = (colok && ty0 * C::TH + 2 * k + trow < a.OH) ? obase + 2 * k * f_rowpitch + gofs : trash;
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+    } else {
       const int cslice = TAIL ? 0 : cog * NCT * 32;
       for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
         const int pb = i / OCPP, c = i - pb * OCPP;
@@ -448,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         *reinterpret_cast<uint4*>(dst) = v;
       }
     }
+    CV_T(8);
     if constexpr (DS) {
       // second output: the identity branch (bias already in accd, no ReLU), same staging tile
       block_barrier();
@@ -478,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
       }
     }
   }
+  CV_END();
 }
 
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS>
@@ -488,17 +582,19 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   a.tiles_y = (a.OH + C::TH - 1) / C::TH;
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   const int cgroups = TAIL ? 1 : a.cout / (NCT * 32);
+  constexpr int LDSB = C::LDS_BYTES;
+  static_assert(2 * LDSB <= 160 * 1024, "two workgroups per CU");
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     attr_done = true;
   }
   int blocks = 512 / cgroups;
   if (blocks > a.ntiles) blocks = a.ntiles;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS>), dim3(blocks, cgroups), dim3(256), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -524,6 +620,12 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 // conv64.hip: one-wave-per-SIMD kernel for the 64->64 3x3 stride-1 workhorse
 int lfd_conv3x3_c64_launch(const void* in, void* out, const void* w_packed, const float* bias, const void* residual,
                            const void* zeros, int n, int h, int w, int relu, hipStream_t st);
+
+#ifdef LFD_CONV_TIMING
+extern "C" __attribute__((visibility("default"))) int lfd_debug_conv_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_dbg), sizeof(unsigned long long) * 128);
+}
+#endif
 
 extern "C" {
 
