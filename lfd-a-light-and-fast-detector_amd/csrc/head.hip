@@ -506,28 +506,24 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
     float s[PASS < 3 ? 16 * SW : 1], ss[PASS < 3 ? 16 * SW : 1];
 #pragma unroll
     for (int i = 0; i < (PASS < 3 ? 16 * SW : 1); ++i) { s[i] = 0.f; ss[i] = 0.f; }
-    auto add_stats = [&](const f32x16 (&acc)[4], float vm, bool masked) {
+    auto add_stats = [&](const f32x16& acc, int ct, float vm, bool masked) {
       if constexpr (PASS < 3) {
         if (masked) {        // wave-uniform: only the last group of an image has pixels past the end
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float y = acc[ct][r] * vm;
-              const int i = (ct * 4 + (r >> 2)) * SW + (SW == 2 ? (r & 1) : 0);
-              s[i] += y;
-              ss[i] = __builtin_fmaf(y, y, ss[i]);
-            }
+          for (int r = 0; r < 16; ++r) {
+            const float y = acc[r] * vm;
+            const int i = (ct * 4 + (r >> 2)) * SW + (SW == 2 ? (r & 1) : 0);
+            s[i] += y;
+            ss[i] = __builtin_fmaf(y, y, ss[i]);
+          }
         } else {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float y = acc[ct][r];
-              const int i = (ct * 4 + (r >> 2)) * SW + (SW == 2 ? (r & 1) : 0);
-              s[i] += y;
-              ss[i] = __builtin_fmaf(y, y, ss[i]);
-            }
+          for (int r = 0; r < 16; ++r) {
+            const float y = acc[r];
+            const int i = (ct * 4 + (r >> 2)) * SW + (SW == 2 ? (r & 1) : 0);
+            s[i] += y;
+            ss[i] = __builtin_fmaf(y, y, ss[i]);
+          }
         }
       }
     };
@@ -546,44 +542,44 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       const int p0 = g * 32;
       const bool tail = p0 + 32 > L.hw;                 // wave-uniform
       const bool lane_ok = p0 + pix < L.hw;
+      // Each stage goes channel tile by channel tile: 9 MFMAs into one 16-register accumulator, which is consumed
+      // (statistics / ReLU + fp16 pack into the next stage's B operands) before the next tile starts -- at most
+      // bq (inputs) + bqn (outputs) + one accumulator are live, instead of four accumulators per stage.
+      half8 bq[NKH], bqn[NKH];
       // ---- neck: relu(Wn x + bn)
-      f32x16 acc[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + NKN) * 64 + lane], ones, zero, 0, 0, 0);
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + NKN) * 64 + lane], ones, zero, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < NKN; ++q)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + q) * 64 + lane], xq[q], acc[ct], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + q) * 64 + lane], xq[q], acc, 0, 0, 0);
+        bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1);
       }
       if (g + 1 < g1) load_x(g + 1);       // next group's pixels: requested now, consumed at the top of the next iteration
-      half8 bq[NKH];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) { bq[2 * ct] = to_b(acc[ct], 0); bq[2 * ct + 1] = to_b(acc[ct], 1); }
       // ---- conv1 (no bias: norm follows, lfd_head.py:97; passes 2, 3: GN1 folded in, its shift on the bias step)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        if constexpr (PASS >= 2) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[ct * 64 + lane], ones, zero, 0, 0, 0);
+        f32x16 acc;
+        if constexpr (PASS >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[ct * 64 + lane], ones, zero, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < NKH; ++q)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ct][q], bq[q], (PASS >= 2 || q > 0) ? acc[ct] : zero, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ct][q], bq[q], (PASS >= 2 || q > 0) ? acc : zero, 0, 0, 0);
+        if constexpr (PASS == 1) add_stats(acc, ct, lane_ok ? 1.f : 0.f, tail);
+        else { bqn[2 * ct] = to_b(acc, 0); bqn[2 * ct + 1] = to_b(acc, 1); }
       }
-      if constexpr (PASS == 1) {
-        add_stats(acc, lane_ok ? 1.f : 0.f, tail);
-      } else {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { bq[2 * ct] = to_b(acc[ct], 0); bq[2 * ct + 1] = to_b(acc[ct], 1); }
+      if constexpr (PASS >= 2) {
+        // ---- conv2 (pass 3: GN2 folded in)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          if constexpr (PASS == 3) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[(4 + ct) * 64 + lane], ones, zero, 0, 0, 0);
+          f32x16 acc;
+          if constexpr (PASS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[(4 + ct) * 64 + lane], ones, zero, 0, 0, 0);
 #pragma unroll
           for (int q = 0; q < NKH; ++q)
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ct][q], bq[q], (PASS == 3 || q > 0) ? acc[ct] : zero, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ct][q], bqn[q], (PASS == 3 || q > 0) ? acc : zero, 0, 0, 0);
+          if constexpr (PASS == 2) add_stats(acc, ct, lane_ok ? 1.f : 0.f, tail);
+          else { bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1); }
         }
-        if constexpr (PASS == 2) {
-          add_stats(acc, lane_ok ? 1.f : 0.f, tail);
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) { bq[2 * ct] = to_b(acc[ct], 0); bq[2 * ct + 1] = to_b(acc[ct], 1); }
+        if constexpr (PASS == 3) {
           const size_t row = (size_t)n * a.P + L.p_off + p0 + pix;
 #pragma unroll
           for (int f = 0; f < FT; ++f) {
