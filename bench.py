@@ -189,8 +189,7 @@ def main():
         model._nms_cfg = dict(type='nms', iou_thr=0.4)
 
         def step():
-            out = model.forward_resident(x)
-            return model.detect(out, meta)
+            return model.detect_resident(x, meta)      # forward + decode + NMS; one HIP graph per step unless --no-graph
 
         for _ in range(args.warmup):
             det = step()

@@ -97,6 +97,39 @@ class LFD(nn.Module):
             self._head_indexes_to_feature_map_sizes[i] = hw
         return cls, reg
 
+    def detect_resident(self, x, meta, score_thr=None, iou_thr=None, class_agnostic=None, max_candidates=None):
+        """Whole inference step for frames resident in device memory: forward + decode + threshold + NMS, results on the
+        device (ops.DetectOutputs, overwritten by the next call with the same buffers).  With `use_graph` the complete
+        step -- not only the forward -- is one HIP graph per (frame buffer, meta buffer, thresholds): one host call
+        per step, no launch gap between the head and the post-processing kernels."""
+        if not self.use_graph:
+            return self.detect(self.forward_resident(x), meta, score_thr, iou_thr, class_agnostic, max_candidates)
+        score_thr = self._classification_threshold if score_thr is None else score_thr
+        iou_thr = self._nms_cfg.get('iou_thr', 0.5) if iou_thr is None else iou_thr
+        agn = self._nms_cfg.get('class_agnostic', False) if class_agnostic is None else class_agnostic
+        cache = self.__dict__.setdefault('_step_graphs', {})
+        key = (x.data_ptr(), tuple(x.shape), x.dtype, meta.data_ptr(), float(score_thr), float(iou_thr), bool(agn), max_candidates)
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            self.use_graph = False
+            try:
+                with torch.cuda.device(x.device):
+                    out = self.detect(self.forward_resident(x), meta, score_thr, iou_thr, agn, max_candidates)   # warm-up, sizes buffers
+                    torch.cuda.synchronize()
+                    desc, _ = self._detect_desc(score_thr, iou_thr, agn, max_candidates)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        cls, reg = self.forward_resident(x)
+                        ops.detect_batched(desc, cls, reg, meta, out=out)
+            finally:
+                self.use_graph = True
+            ent = (g, out, x, meta)          # keep the captured buffers alive
+            cache[key] = ent
+        ent[0].replay()
+        return ent[1]
+
     def _forward_train(self, x):
         bb, neck, head = self._backbone, self._neck, self._head
         y = bb._stem(x)
