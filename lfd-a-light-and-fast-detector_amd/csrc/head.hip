@@ -384,6 +384,10 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
 //     statistics -- and therefore the outputs -- of an image do not depend on the batch it is in.
 // =====================================================================================================
 constexpr int H2_CH = 12;      // groups per chunk (384 pixels = 6 statistics tiles): 904 chunks for 8 x 1080p, one per wave of 256 CUs
+// smaller chunks for the small levels (their few chunks would otherwise be the longest-running work items of the launch);
+// a function of the level geometry only -> the statistics of an image stay independent of the batch.  8 x 1080p:
+// (85 + 22 + 8 + 4 + 2) chunks per image = 968 chunks = 242 work items on 256 CUs.
+__host__ __device__ inline int h2_chunk_groups(int gpi) { return gpi >= 128 ? H2_CH : (gpi >= 32 ? 8 : 4); }
 
 __device__ __forceinline__ uint32_t h2_cvt_pk(float x, float y) {
   lfd_f32x2 f; f[0] = x; f[1] = y;
@@ -398,10 +402,10 @@ __device__ __forceinline__ uint32_t h2_relu_pk(uint32_t h) {
 
 template <int PASS, int FT>
 __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
-  constexpr int CIN = 64, NKN = CIN / 16, NKH = HC / 16;
-  constexpr int WN_FRAGS = 4 * (NKN + 1);                              // neck: 4 cout tiles x (4 k-steps + bias step)
+  constexpr int NKN = 4, NKNX = 8, NKH = HC / 16;                      // neck k-steps per 64 input channels / maximum (128 channels)
+  constexpr int WN_FRAGS = 4 * (NKNX + 1);                             // neck: 4 cout tiles x (up to 8 k-steps + bias step)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half8* s_wn = reinterpret_cast<half8*>(smem);                         // [4][NKN + 1][64 lanes]
+  half8* s_wn = reinterpret_cast<half8*>(smem);                         // [4][NKNX + 1][64 lanes]; bias step at index NKNX
   half8* s_wf = s_wn + WN_FRAGS * 64;                                   // [FT][NKH + 1][64 lanes]
   half8* s_wb = s_wf + (PASS == 3 ? FT * (NKH + 1) : 0) * 64 + (threadIdx.x >> 6) * 8 * 64;   // wave-private: GN shift k-steps [2][4][64]
   const int lane = threadIdx.x & 63;
@@ -457,13 +461,14 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
     const HeadLevel& L = a.lv[l];
     if (j != cur_j) {
       __syncthreads();                       // everybody is done with the previous level's LDS filters
-      for (int i = threadIdx.x; i < 4 * NKN * 64; i += 256) {
-        const int c = i / (NKN * 64), r = i - c * (NKN * 64);
-        s_wn[c * (NKN + 1) * 64 + r] = L.wn[i];
+      const int nkl = L.cin / 16;            // 4 or 8 neck k-steps for this level
+      for (int i = threadIdx.x; i < 4 * nkl * 64; i += 256) {
+        const int c = i / (nkl * 64), r = i - c * (nkl * 64);
+        s_wn[c * (NKNX + 1) * 64 + r] = L.wn[i];
       }
       {
         const int c = wave;                  // neck bias step of cout tile `wave`
-        s_wn[(c * (NKN + 1) + NKN) * 64 + lane] = bias_frag(L.bn[c * 32 + (lane & 31)]);
+        s_wn[(c * (NKNX + 1) + NKNX) * 64 + lane] = bias_frag(L.bn[c * 32 + (lane & 31)]);
       }
       if constexpr (PASS == 3) {
         for (int fq = wave; fq < FT * NKH; fq += 4) s_wf[((fq / NKH) * (NKH + 1) + (fq % NKH)) * 64 + lane] = perm(L.wf, fq / NKH, fq % NKH, 1.f);
@@ -473,11 +478,11 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       __syncthreads();
       cur_j = j;
     }
-    const int gpi = a.grp_gpi[j], cpi = (gpi + H2_CH - 1) / H2_CH;
+    const int gpi = a.grp_gpi[j], chg = h2_chunk_groups(gpi), cpi = (gpi + chg - 1) / chg;
     const int c = (item - a.h2_item_start[j]) * 4 + wave;
     if (c >= cpi * a.N) continue;            // (no workgroup barrier below this point in the iteration)
     const int n = c / cpi, ci = c - n * cpi;
-    const int g0 = ci * H2_CH, g1 = (g0 + H2_CH) < gpi ? (g0 + H2_CH) : gpi;
+    const int g0 = ci * chg, g1 = (g0 + chg) < gpi ? (g0 + chg) : gpi;
 
     // ---- this image's filters: GroupNorm scale folded into the rows, shift as a bias k-step
     {
@@ -529,15 +534,18 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
     };
 
     // x fragments of a group: lane (pixel, hh) reads channels 16q + 8hh .. +7 of its pixel (clamped inside the level)
+    // (128-channel levels -- a few hundred pixels per image -- fetch their second 64 channels synchronously in the
+    //  neck stage: no extra registers for the big 64-channel levels, the stall lands on otherwise idle CUs)
     half8 xq[NKN];
-    const _Float16* ximg = L.x + (size_t)n * L.hw * CIN + 8 * hh;
-    auto load_x = [&](int g) {
+    const int cin = L.cin;
+    const _Float16* ximg = L.x + (size_t)n * L.hw * cin + 8 * hh;
+    auto load_x = [&](int g, int half) {
       int p = g * 32 + pix;
       p = p < L.hw ? p : L.hw - 1;
 #pragma unroll
-      for (int q = 0; q < NKN; ++q) xq[q] = *reinterpret_cast<const half8*>(ximg + (size_t)p * CIN + 16 * q);
+      for (int q = 0; q < NKN; ++q) xq[q] = *reinterpret_cast<const half8*>(ximg + (size_t)p * cin + 64 * half + 16 * q);
     };
-    load_x(g0);
+    load_x(g0, 0);
     for (int g = g0; g < g1; ++g) {
       const int p0 = g * 32;
       const bool tail = p0 + 32 > L.hw;                 // wave-uniform
@@ -547,15 +555,34 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       // bq (inputs) + bqn (outputs) + one accumulator are live, instead of four accumulators per stage.
       half8 bq[NKH], bqn[NKH];
       // ---- neck: relu(Wn x + bn)
+      if (cin == 64) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + NKN) * 64 + lane], ones, zero, 0, 0, 0);
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + NKNX) * 64 + lane], ones, zero, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < NKN; ++q)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKN + 1) + q) * 64 + lane], xq[q], acc, 0, 0, 0);
-        bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1);
+          for (int q = 0; q < NKN; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + q) * 64 + lane], xq[q], acc, 0, 0, 0);
+          bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1);
+        }
+      } else {
+        f32x16 acc4[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + NKNX) * 64 + lane], ones, zero, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NKN; ++q)
+            acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + q) * 64 + lane], xq[q], acc4[ct], 0, 0, 0);
+        }
+        load_x(g, 1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+          for (int q = 0; q < NKN; ++q)
+            acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + NKN + q) * 64 + lane], xq[q], acc4[ct], 0, 0, 0);
+          bq[2 * ct] = to_b(acc4[ct], 0); bq[2 * ct + 1] = to_b(acc4[ct], 1);
+        }
       }
-      if (g + 1 < g1) load_x(g + 1);       // next group's pixels: requested now, consumed at the top of the next iteration
+      if (g + 1 < g1) load_x(g + 1, 0);    // next group's pixels: requested now, consumed at the top of the next iteration
       // ---- conv1 (no bias: norm follows, lfd_head.py:97; passes 2, 3: GN1 folded in, its shift on the bias step)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
@@ -626,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 
 template <int PASS, int FT>
 int launch_head2(const HeadArgs& a, hipStream_t st) {
-  constexpr int LDS = (4 * 5 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
+  constexpr int LDS = (4 * 9 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -740,7 +767,8 @@ static bool head2_enabled() {
 }
 static bool head2_level(const lfd_head_desc_t* d, int i) {
   const int gsize = d->num_groups > 0 ? HC / d->num_groups : 0;
-  return head2_enabled() && d->level_cin[i] == 64 && gsize >= 8;
+  (void)i;
+  return head2_enabled() && gsize >= 8;
 }
 
 int fill_levels(const lfd_head_desc_t* d, int* tile_start, int* tiles_per_img, int* ntiles) {
@@ -809,6 +837,24 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
   const int ft = (d->final_reg_rows + d->final_cls_rows + 31) / 32;
   if (pass == 3 && (ft < 1 || ft > 2)) return LFD_ERR_UNSUPPORTED;
   if (pass < 1 || pass > 3) return LFD_ERR_INVALID_ARGUMENT;
+  if (head2_enabled() && gshift >= 3) {
+    // wave-per-32-pixels kernel, all levels in one launch: work items = 4 consecutive chunks (H2_CH groups of 32
+    // pixels) of one level
+    a.grp_n = 0;
+    a.h2_nitems = 0;
+    for (int i = 0; i < d->num_levels; ++i) {
+      const int j = a.grp_n++;
+      a.grp_levels[j] = i;
+      a.grp_gpi[j] = (d->level_hw[i] + 31) / 32;
+      const int chg = h2_chunk_groups(a.grp_gpi[j]);
+      const int cpi = (a.grp_gpi[j] + chg - 1) / chg;
+      a.h2_item_start[j] = a.h2_nitems;
+      a.h2_nitems += (cpi * d->n + 3) / 4;
+    }
+    if (pass == 1) return launch_head2<1, 1>(a, st);
+    if (pass == 2) return launch_head2<2, 1>(a, st);
+    return ft == 2 ? launch_head2<3, 2>(a, st) : launch_head2<3, 1>(a, st);
+  }
   // one launch per tap-channel class (64 / 128): homogeneous tiles, compile-time ring geometry
   for (int cin = 64; cin <= 128; cin += 64) {
     a.grp_n = 0;
@@ -821,22 +867,6 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
         ++a.grp_n;
       }
     if (a.grp_ntiles == 0) continue;
-    if (cin == 64 && head2_enabled() && gshift >= 3) {
-      // wave-per-32-pixels kernel: work items = 4 consecutive chunks (H2_CH groups of 32 pixels) of one level
-      a.h2_nitems = 0;
-      for (int j = 0; j < a.grp_n; ++j) {
-        const int i = a.grp_levels[j];
-        a.grp_gpi[j] = (d->level_hw[i] + 31) / 32;
-        const int cpi = (a.grp_gpi[j] + H2_CH - 1) / H2_CH;
-        a.h2_item_start[j] = a.h2_nitems;
-        a.h2_nitems += (cpi * d->n + 3) / 4;
-      }
-      if (pass == 1) rc = launch_head2<1, 1>(a, st);
-      else if (pass == 2) rc = launch_head2<2, 1>(a, st);
-      else rc = ft == 2 ? launch_head2<3, 2>(a, st) : launch_head2<3, 1>(a, st);
-      if (rc != LFD_OK) return rc;
-      continue;
-    }
     rc = cin == 64 ? dispatch_head<64>(pass, ft, a, st) : dispatch_head<128>(pass, ft, a, st);
     if (rc != LFD_OK) return rc;
   }
@@ -855,7 +885,7 @@ int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const
   for (int i = 0; i < d->num_levels; ++i) {
     if (!gamma[i] || !beta[i]) return LFD_ERR_INVALID_ARGUMENT;
     f.hw[i] = d->level_hw[i]; f.gamma[i] = gamma[i]; f.beta[i] = beta[i];
-    f.tile_stride[i] = head2_level(d, i) ? H2_CH / 2 : 1;
+    f.tile_stride[i] = head2_level(d, i) ? h2_chunk_groups((d->level_hw[i] + 31) / 32) / 2 : 1;
   }
   f.part = partial; f.ab = ab; f.N = d->n; f.ngroups = d->num_groups; f.gsize = HC / d->num_groups; f.eps = eps;
   hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels), dim3(256), 0, st, f);
