@@ -150,3 +150,40 @@ def test_whole_stem_fused_kernel(c):
     got = out.float().cpu().permute(0, 3, 1, 2).double()
     # two fp16-rounded intermediates in the chain: allow a few ulp at the output magnitude
     assert bool(((got - y).abs() <= 4e-3 * y.abs().clamp(min=1.0)).all()), float((got - y).abs().max())
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 8, 8), (1, 19, 24), (2, 33, 57), (1, 64, 96), (3, 47, 130), (1, 270, 481), (2, 135, 256)])
+def test_fused_stem_equals_two_kernel_stem(n, h, w):
+    """k_stem2x (whole 'faster' stem in one kernel, NHWC fp16 frames) against the two-kernel stem (k_stem + k_conv with
+    a chained 1x1) on the same packed weights: every frame size exercises another combination of tile clipping, raw-row
+    misalignment (W * 6 mod 16) and zero padding of the stride-2 intermediate.  Both paths round to fp16 at the same
+    three places; they differ only in how the biases enter (fp32 accumulator init vs an fp16 hi+lo MFMA k-step, exact
+    to 2^-22) and in summation order, so the outputs agree to about one fp16 ulp."""
+    import ctypes as C
+    from lfd_amd._lib import ConvDesc, check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    c = 64
+    ws = [(torch.randn(c, 3, 3, 3, generator=g) * 0.2), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5),
+          (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5)]
+    ws = [t.half().float() for t in ws]
+    bs = [(torch.randn(c, generator=g) * 0.1).cuda() for _ in range(4)]
+    packed = [engine.pack_stem_weight(ws[0]).cuda()] + [ops.pack_conv_weight(t).cuda() for t in ws[1:]]
+    x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half().cuda()
+    h1, w1 = (h + 1) // 2, (w + 1) // 2
+    h2, w2 = (h1 + 1) // 2, (w1 + 1) // 2
+    fused = torch.empty((n, h2, w2, c), dtype=torch.float16, device='cuda')
+    check(lib().lfd_stem_faster_fused_f16(ptr(x), 1, n, h, w, c, ptr(packed[0]), ptr(bs[0]), ptr(packed[1]), ptr(bs[1]),
+                                          ptr(packed[2]), ptr(bs[2]), ptr(packed[3]), ptr(bs[3]), ptr(fused), stream_ptr()), 'fused')
+    mid = torch.empty((n, h1, w1, c), dtype=torch.float16, device='cuda')
+    check(lib().lfd_stem_conv_f16(ptr(x), 1, n, h, w, c, ptr(packed[0]), ptr(bs[0]), ptr(packed[1]), ptr(bs[1]), ptr(mid), stream_ptr()), 'stem')
+    two = torch.empty_like(fused)
+    d = ConvDesc(n, h1, w1, c, c, 3, 2, 1, c, 1)
+    check(lib().lfd_conv2d_nhwc_f16(C.byref(d), ptr(mid), ptr(two), ptr(packed[2]), ptr(bs[2]), None, ptr(packed[3]), ptr(bs[3]),
+                                    ptr(ops.zero_line(x.device)), stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+    a, b = fused.float(), two.float()
+    assert torch.isfinite(a).all()
+    tol = 2e-3 * b.abs().clamp(min=1.0)          # 2 fp16 ulp at the value's magnitude
+    bad = ((a - b).abs() > tol)
+    assert int(bad.sum()) == 0, (int(bad.sum()), float((a - b).abs().max()))
+    assert float((a - b).abs().mean()) < 1e-4     # almost all elements identical
