@@ -86,6 +86,21 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
   return v;
 }
+// sum over the 64 lanes with DPP adds (6 VALU instructions; the result is valid in lane 63 only).  __shfl_xor goes
+// through the LDS crossbar (ds_bpermute): 32 reductions of 6 dependent steps cost ~9.7 k cycles per chunk in k_head2.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  int x = __float_as_int(v);
+#define LFD_DPP_ADD(ctrl, rmask)                                                                       \
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)))
+  LFD_DPP_ADD(0x111, 0xf);   // row_shr:1
+  LFD_DPP_ADD(0x112, 0xf);   // row_shr:2
+  LFD_DPP_ADD(0x114, 0xf);   // row_shr:4
+  LFD_DPP_ADD(0x118, 0xf);   // row_shr:8   -> lane 15 of every row of 16 holds its row's sum
+  LFD_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  LFD_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef LFD_DPP_ADD
+  return __int_as_float(x);
+}
 
 // swizzled LDS tile of [TPX pixels][C channels] fp16: byte address of (pixel, 16-byte chunk c)
 template <int CPP>
@@ -400,6 +415,13 @@ __device__ __forceinline__ uint32_t h2_relu_pk(uint32_t h) {
   return r.u;
 }
 
+#ifdef LFD_H2_TIMING
+__device__ unsigned long long g_h2_dbg[3 * 32];
+#define H2_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_h2_dbg[(PASS - 1) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define H2_T(i)
+#endif
+
 template <int PASS, int FT>
 __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
   constexpr int NKN = 4, NKNX = 8, NKH = HC / 16;                      // neck k-steps per 64 input channels / maximum (128 channels)
@@ -450,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
     return r.v;
   };
 
+  H2_T(0);
   int cur_j = -1;
   for (int item = blockIdx.x; item < a.h2_nitems; item += gridDim.x) {
     // work item = 4 consecutive chunks of one level (wave w takes chunk 4 * local + w)
@@ -459,31 +482,37 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       if (i < a.grp_n && item >= a.h2_item_start[i]) j = i;
     const int l = a.grp_levels[j];
     const HeadLevel& L = a.lv[l];
-    if (j != cur_j) {
-      __syncthreads();                       // everybody is done with the previous level's LDS filters
-      const int nkl = L.cin / 16;            // 4 or 8 neck k-steps for this level
-      for (int i = threadIdx.x; i < 4 * nkl * 64; i += 256) {
-        const int c = i / (nkl * 64), r = i - c * (nkl * 64);
-        s_wn[c * (NKNX + 1) * 64 + r] = L.wn[i];
+    // Level switch: the shared LDS filters (neck, final conv) are requested FIRST, into registers, and written to LDS
+    // only after this wave's own per-image filter setup below -- ~9 k cycles of loads and scaling that do not touch
+    // the shared area -- so their (cold) fetch latency and the two workgroup barriers overlap with useful work.
+    const bool new_level = j != cur_j;
+    const int nkl = L.cin / 16;              // 4 or 8 neck k-steps for this level
+    half8 t_wn[NKNX], t_wf[(PASS == 3) ? (FT * NKH + 3) / 4 : 1];
+    float t_bn = 0.f, t_bf = 0.f;
+    if (new_level) {
+#pragma unroll
+      for (int k = 0; k < NKNX; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < 4 * nkl * 64) t_wn[k] = L.wn[i];
       }
-      {
-        const int c = wave;                  // neck bias step of cout tile `wave`
-        s_wn[(c * (NKNX + 1) + NKNX) * 64 + lane] = bias_frag(L.bn[c * 32 + (lane & 31)]);
-      }
+      t_bn = L.bn[wave * 32 + (lane & 31)];
       if constexpr (PASS == 3) {
-        for (int fq = wave; fq < FT * NKH; fq += 4) s_wf[((fq / NKH) * (NKH + 1) + (fq % NKH)) * 64 + lane] = perm(L.wf, fq / NKH, fq % NKH, 1.f);
-        if (wave < FT) s_wf[(wave * (NKH + 1) + NKH) * 64 + lane] = bias_frag(L.bf[wave * 32 + (lane & 31)]);
+#pragma unroll
+        for (int k = 0; k < (FT * NKH + 3) / 4; ++k) {
+          const int fq = wave + 4 * k;
+          if (fq < FT * NKH) t_wf[k] = perm(L.wf, fq / NKH, fq % NKH, 1.f);
+        }
+        if (wave < FT) t_bf = L.bf[wave * 32 + (lane & 31)];
         scale = L.scale ? L.scale[0] : 1.f;
       }
-      __syncthreads();
-      cur_j = j;
     }
     const int gpi = a.grp_gpi[j], chg = h2_chunk_groups(gpi), cpi = (gpi + chg - 1) / chg;
     const int c = (item - a.h2_item_start[j]) * 4 + wave;
-    if (c >= cpi * a.N) continue;            // (no workgroup barrier below this point in the iteration)
-    const int n = c / cpi, ci = c - n * cpi;
+    const bool have_chunk = c < cpi * a.N;
+    const int n = have_chunk ? c / cpi : 0, ci = c - n * cpi;
     const int g0 = ci * chg, g1 = (g0 + chg) < gpi ? (g0 + chg) : gpi;
 
+    H2_T(1);
     // ---- this image's filters: GroupNorm scale folded into the rows, shift as a bias k-step
     {
       const int m = lane & 31;
@@ -503,6 +532,30 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
         }
       }
     }
+
+    if (new_level) {
+      __syncthreads();                       // everybody is done with the previous level's LDS filters
+#pragma unroll
+      for (int k = 0; k < NKNX; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < 4 * nkl * 64) {
+          const int cc = i / (nkl * 64), r = i - cc * (nkl * 64);
+          s_wn[cc * (NKNX + 1) * 64 + r] = t_wn[k];
+        }
+      }
+      s_wn[(wave * (NKNX + 1) + NKNX) * 64 + lane] = bias_frag(t_bn);     // neck bias step of cout tile `wave`
+      if constexpr (PASS == 3) {
+#pragma unroll
+        for (int k = 0; k < (FT * NKH + 3) / 4; ++k) {
+          const int fq = wave + 4 * k;
+          if (fq < FT * NKH) s_wf[((fq / NKH) * (NKH + 1) + (fq % NKH)) * 64 + lane] = t_wf[k];
+        }
+        if (wave < FT) s_wf[(wave * (NKH + 1) + NKH) * 64 + lane] = bias_frag(t_bf);
+      }
+      __syncthreads();
+      cur_j = j;
+    }
+    if (!have_chunk) continue;               // (no workgroup barrier below this point in the iteration)
 
     // GroupNorm partial sums of this lane: block b = 4ct + g covers channels 8b .. 8b+7, of which this lane holds 4
     // (registers 4g .. 4g+3 of tile ct).  Pass 1 has registers to spare and keeps two fp32 lanes per accumulator
@@ -545,8 +598,10 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
       for (int q = 0; q < NKN; ++q) xq[q] = *reinterpret_cast<const half8*>(ximg + (size_t)p * cin + 64 * half + 16 * q);
     };
+    H2_T(2);
     load_x(g0, 0);
     for (int g = g0; g < g1; ++g) {
+      if (g - g0 < 12) H2_T(3 + (g - g0));
       const int p0 = g * 32;
       const bool tail = p0 + 32 > L.hw;                 // wave-uniform
       const bool lane_ok = p0 + pix < L.hw;
@@ -632,6 +687,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
         }
       }
     }
+    H2_T(16);
     // ---- chunk statistics: reduce over the 64 lanes, one writer per (chunk, group) slot = the slot of the chunk's
     //      first 64-pixel tile (H2_CH is even, so chunks start on tile boundaries; k_gn_finalize reads every
     //      H2_CH/2-th slot of these levels)
@@ -641,15 +697,24 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       float x = 0.f, xx = 0.f;
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
-        x += wave_sum_f(SW == 2 ? s[2 * b] + s[2 * b + 1] : s[b]); xx += wave_sum_f(SW == 2 ? ss[2 * b] + ss[2 * b + 1] : ss[b]);
+        x += wave_sum_lane63(SW == 2 ? s[2 * b] + s[2 * b + 1] : s[b]); xx += wave_sum_lane63(SW == 2 ? ss[2 * b] + ss[2 * b + 1] : ss[b]);
         if (((b + 1) & (gg - 1)) == 0) {
-          if (lane == 0) *reinterpret_cast<float2*>(dst + (b / gg) * 2) = make_float2(x, xx);
+          if (lane == 63) *reinterpret_cast<float2*>(dst + (b / gg) * 2) = make_float2(x, xx);
           x = 0.f; xx = 0.f;
         }
       }
     }
+    H2_T(17);
   }
 }
+
+#ifdef LFD_H2_TIMING
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int lfd_debug_h2_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_h2_dbg), sizeof(unsigned long long) * 96);
+}
+namespace {
+#endif
 
 template <int PASS, int FT>
 int launch_head2(const HeadArgs& a, hipStream_t st) {
