@@ -182,6 +182,66 @@ LFD_API int lfd_cross_entropy_bwd_f32(const float* logits, const int64_t* labels
                               int32_t channels, float* d_logits, lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused LFD.get_loss (lfd/model/lfd.py:284-395): replaces the boolean gathers (green rows :309-315, positive
+ * rows :319-321), the label construction (:328), FocalLoss / CrossEntropyLoss + IoULoss on the gathered rows
+ * (:333-384, decode of prediction and target :360-377) and the three `.item()` syncs (:389-395) by
+ *   sums     : one pass over all N*P rows -> 8 doubles {cls_sum, reg_sum, n_pos, sum of positive scores,
+ *              n_green, 0, 0, 0} (fp64 block partials + fixed-order second stage: deterministic);
+ *   finalize : out[8] floats {classification_loss, regression_loss, loss, n_pos, avg_factor_cls,
+ *              avg_factor_reg, n_green(local), rank_scale}; `global_sums` are the sums all-reduced over the
+ *              image-parallel ranks (== local_sums on one GPU) because the reference normalises by the
+ *              global-batch n_pos (executor.py:198-200); rank_scale = world size when gradients are
+ *              averaged over ranks afterwards (1 otherwise);
+ *   bwd      : dense d loss / d pred_cls [N,P,channels], d loss / d pred_reg [N,P,4] for upstream
+ *              gradients grad_out[3] of {classification_loss, regression_loss, loss}.
+ * pred_cls has num_classes channels for cls_loss 0 (sigmoid focal) and num_classes + 1 for cls_loss 1
+ * (cross entropy, background = last channel).  No positives -> regression_loss 0 with zero gradient
+ * (lfd.py:386-387).  All tensors fp32, contiguous.
+ */
+typedef struct lfd_loss_desc {
+  int32_t n, num_levels;
+  int32_t level_h[LFD_MAX_LEVELS], level_w[LFD_MAX_LEVELS], stride[LFD_MAX_LEVELS];
+  float range_max[LFD_MAX_LEVELS];  /* max(regression_ranges[i]) ('sigmoid' decode, lfd.py:368-373) */
+  int32_t total_points, num_classes;
+  int32_t cls_loss;                 /* 0 FocalLoss (sigmoid), 1 CrossEntropyLoss */
+  int32_t decode_mode;              /* 0 sigmoid * range_max, 1 exp (lfd.py:366-374) */
+  float gamma, alpha, iou_eps;
+  float cls_loss_weight, reg_loss_weight;   /* loss_weight of the two loss modules */
+  int32_t cls_weighted, reg_weighted;       /* enable_classification_weight / enable_regression_weight */
+} lfd_loss_desc_t;
+LFD_API size_t lfd_get_loss_workspace_bytes(void);
+LFD_API int lfd_get_loss_sums_f32(const lfd_loss_desc_t* d, const float* pred_cls, const float* pred_reg,
+                          const float* cls_targets, const float* reg_targets, void* workspace, size_t workspace_bytes,
+                          double* sums, lfd_stream_t stream);
+LFD_API int lfd_get_loss_finalize_f32(const lfd_loss_desc_t* d, const double* local_sums, const double* global_sums,
+                              float rank_scale, float* out, lfd_stream_t stream);
+LFD_API int lfd_get_loss_bwd_f32(const lfd_loss_desc_t* d, const float* pred_cls, const float* pred_reg,
+                         const float* cls_targets, const float* reg_targets, const float* finalized,
+                         const float* grad_out, float* grad_cls, float* grad_reg, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameter update of a training iteration over one flat fp32 buffer (all tensors of a param group
+ * contiguous, 16-byte aligned).  Replaces OptimizerHook.after_train_iter's
+ *   clip_grad.clip_grad_norm_(params, max_norm, norm_type=2)   (lfd/execution/hooks/optimizer_hook.py:21-24,30-33)
+ *   optimizer.step() with torch.optim.SGD(lr, momentum, weight_decay) (optimizer_hook.py:36, WIDERFACE_LFD_S.py:216-226)
+ * lfd_grad_norm_clip_coef_f32: norm_and_coef[0] = ||grads||_2 (fp64 accumulation, deterministic),
+ *   norm_and_coef[1] = min(max_norm / (norm + 1e-6), 1).  extra_sumsq (nullable, device) is added to the
+ *   sum of squares before the root (several buffers sharing one norm); sumsq_out (nullable) receives the total.
+ * lfd_sgd_step_f32: g *= coef (when norm_and_coef != NULL; written back when write_clipped_grads, as
+ *   clip_grad_norm_ mutates .grad); d = g + wd * p; buf = first_step ? d : momentum * buf + (1 - dampening) * d;
+ *   d = nesterov ? d + momentum * buf : buf; p -= lr * d   (torch/optim/sgd.py _single_tensor_sgd).
+ */
+LFD_API size_t lfd_grad_norm_workspace_bytes(void);
+LFD_API int lfd_grad_norm_clip_coef_f32(const float* grads, int64_t n, float max_norm, const double* extra_sumsq,
+                                void* workspace, size_t workspace_bytes, float* norm_and_coef, double* sumsq_out,
+                                lfd_stream_t stream);
+/* grads *= norm_and_coef[1] (the in-place scaling of clip_grad_norm_ when the update is not fused with it) */
+LFD_API int lfd_scale_by_clip_coef_f32(float* grads, int64_t n, const float* norm_and_coef, lfd_stream_t stream);
+LFD_API int lfd_sgd_step_f32(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
+                     float dampening, float weight_decay, int32_t nesterov, int32_t first_step,
+                     const float* norm_and_coef, int32_t write_clipped_grads, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Inference conv stack, NHWC fp16, fp32 accumulate on MFMA.  Replaces the nn.Conv2d +
  * nn.BatchNorm2d (folded) + ReLU (+ residual add) units of LFDResNet
  *   (lfd/model/backbone/lfd_resnet.py:96-154 FasterBlock, :21-93 FastBlock, :157-215 FastestBlock,

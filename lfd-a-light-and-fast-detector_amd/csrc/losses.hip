@@ -7,6 +7,7 @@
 // wave64 shuffle reductions + fixed-order second stage for the fused sum (deterministic).
 #include <float.h>
 #include "common.h"
+#include "loss_elems.h"
 
 namespace {
 
@@ -19,37 +20,6 @@ template <> __device__ __forceinline__ float ldf<__half>(const __half* p, int64_
 template <typename T> __device__ __forceinline__ void stf(T* p, int64_t i, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, int64_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void stf<__half>(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
-
-// one element of SigmoidFocalLossForward (sigmoid_focal_loss_cuda.cu:31-57), fp32 math
-__device__ __forceinline__ float focal_fwd_elem(float x, int t, int d, float gamma, float alpha) {
-  const float c1 = (float)(t == d);
-  const float c2 = (float)((t >= 0) & (t != d));
-  const float zn = 1.0f - alpha, zp = alpha;
-  const float p = 1.f / (1.f + expf(-x));
-  const float term1 = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-  const float ge = (float)(x >= 0.f);
-  const float term2 = powf(p, gamma) * (-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge)));
-  float l = 0.f;
-  l += -c1 * term1 * zp;
-  l += -c2 * term2 * zn;
-  return l;
-}
-
-// one element of SigmoidFocalLossBackward (sigmoid_focal_loss_cuda.cu:69-95)
-__device__ __forceinline__ float focal_bwd_elem(float x, int t, int d, float gamma, float alpha, float g) {
-  const float c1 = (float)(t == d);
-  const float c2 = (float)((t >= 0) & (t != d));
-  const float zn = 1.0f - alpha, zp = alpha;
-  const float p = 1.f / (1.f + expf(-x));
-  const float term1 = powf(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
-  const float ge = (float)(x >= 0.f);
-  const float term2 =
-      powf(p, gamma) * ((-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge))) * (1.f - p) * gamma - p);
-  float r = 0.f;
-  r += -c1 * term1 * zp;
-  r += -c2 * term2 * zn;
-  return r * g;
-}
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_focal_fwd(const T* logits, const int64_t* targets, int64_t total,
@@ -115,57 +85,14 @@ __global__ __launch_bounds__(kThreads) void k_sum_final(const double* partials, 
 __global__ __launch_bounds__(kThreads) void k_iou_fwd(const float4* pred, const float4* target, int64_t n,
                                                       float eps, float* loss) {
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-    const float4 a = pred[i], b = target[i];
-    const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
-    const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
-    const float ov = w * h;
-    const float a1 = (a.z - a.x) * (a.w - a.y);
-    const float a2 = (b.z - b.x) * (b.w - b.y);
-    const float un = fmaxf(a1 + a2 - ov, 1e-6f);
-    const float iou = fmaxf(ov / un, eps);
-    loss[i] = -logf(iou);
+    loss[i] = iou_loss_elem(pred[i], target[i], eps);
   }
 }
 
-// d loss / d pred, following autograd through the same expression graph:
-//   loss = -log(q), q = max(ov/un, eps); un = max(a1+a2-ov, 1e-6); ov = w*h with clamps at 0;
-//   torch.max / torch.min route the gradient to the larger / smaller operand (ties: split evenly
-//   in ATen; ties have measure zero for float boxes and are resolved towards `pred` here).
 __global__ __launch_bounds__(kThreads) void k_iou_bwd(const float4* pred, const float4* target, const float* dl,
                                                       int64_t n, float eps, float4* dpred) {
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-    const float4 a = pred[i], b = target[i];
-    const float ltx = fmaxf(a.x, b.x), lty = fmaxf(a.y, b.y);
-    const float rbx = fminf(a.z, b.z), rby = fminf(a.w, b.w);
-    const float wr = rbx - ltx, hr = rby - lty;
-    const float w = fmaxf(wr, 0.f), h = fmaxf(hr, 0.f);
-    const float ov = w * h;
-    const float pw = a.z - a.x, ph = a.w - a.y;
-    const float a1 = pw * ph;
-    const float a2 = (b.z - b.x) * (b.w - b.y);
-    const float ur = a1 + a2 - ov;
-    const float un = fmaxf(ur, 1e-6f);
-    const float q = ov / un;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q > eps) {  // clamp(min=eps) passes gradient only above eps
-      const float dq = -dl[i] / q;
-      const float dov_direct = dq / un;
-      const float dun = (ur > 1e-6f) ? (-dq * ov / (un * un)) : 0.f;
-      const float dov = dov_direct - dun;  // un depends on -ov
-      const float da1 = dun;
-      // ov = w*h
-      const float dw = (wr > 0.f) ? dov * h : 0.f;
-      const float dh = (hr > 0.f) ? dov * w : 0.f;
-      // w = min(a.z,b.z) - max(a.x,b.x)
-      if (a.z <= b.z) g.z += dw;
-      if (a.x >= b.x) g.x -= dw;
-      if (a.w <= b.w) g.w += dh;
-      if (a.y >= b.y) g.y -= dh;
-      // a1 = (a.z-a.x)*(a.w-a.y)
-      g.z += da1 * ph; g.x -= da1 * ph;
-      g.w += da1 * pw; g.y -= da1 * pw;
-    }
-    dpred[i] = g;
+    dpred[i] = iou_loss_grad_elem(pred[i], target[i], eps, dl[i]);
   }
 }
 

@@ -65,6 +65,18 @@ class AssignDesc(C.Structure):
                 ('assign_mode', C.c_int32), ('independent', C.c_int32)]
 
 
+class LossDesc(C.Structure):
+    """lfd_loss_desc_t"""
+    _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32),
+                ('level_h', C.c_int32 * MAX_LEVELS), ('level_w', C.c_int32 * MAX_LEVELS), ('stride', C.c_int32 * MAX_LEVELS),
+                ('range_max', C.c_float * MAX_LEVELS),
+                ('total_points', C.c_int32), ('num_classes', C.c_int32),
+                ('cls_loss', C.c_int32), ('decode_mode', C.c_int32),
+                ('gamma', C.c_float), ('alpha', C.c_float), ('iou_eps', C.c_float),
+                ('cls_loss_weight', C.c_float), ('reg_loss_weight', C.c_float),
+                ('cls_weighted', C.c_int32), ('reg_weighted', C.c_int32)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
@@ -86,6 +98,14 @@ _SIGNATURES = {
     'lfd_assign_targets_f32': (C.c_int, [C.POINTER(AssignDesc), _P, _P, _P, _P, _P, _P]),
     'lfd_cross_entropy_fwd_f32': (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     'lfd_cross_entropy_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
+    'lfd_get_loss_workspace_bytes': (_SZ, []),
+    'lfd_get_loss_sums_f32': (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    'lfd_get_loss_finalize_f32': (C.c_int, [C.POINTER(LossDesc), _P, _P, _F, _P, _P]),
+    'lfd_get_loss_bwd_f32': (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_grad_norm_workspace_bytes': (_SZ, []),
+    'lfd_grad_norm_clip_coef_f32': (C.c_int, [_P, _I64, _F, _P, _P, _SZ, _P, _P, _P]),
+    'lfd_scale_by_clip_coef_f32': (C.c_int, [_P, _I64, _P, _P]),
+    'lfd_sgd_step_f32': (C.c_int, [_P, _P, _P, _I64, _F, _F, _F, _F, _I32, _I32, _P, _I32, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),

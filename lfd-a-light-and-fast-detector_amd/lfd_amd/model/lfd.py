@@ -16,17 +16,37 @@ parameters (per-replica BatchNorm batch statistics exactly like the reference). 
 hand-written dgrad/wgrad kernels are the next row of the scope table; this is stated in
 DESIGN.md, it is not a silent fallback of the inference path.
 """
+import os
+
 import numpy
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine, ops
+from .. import engine, ops, parallel
 from .utils import multiclass_nms  # noqa: F401  (kept importable like the reference module)
 
 __all__ = ['LFD']
 
 _UNION = ('IoULoss', 'GIoULoss', 'DIoULoss', 'CIoULoss')
+
+
+class _FusedLossFunction(torch.autograd.Function):
+    """get_loss as lfd_get_loss_{sums,finalize,bwd}_f32 (csrc/getloss.hip): -> [classification_loss,
+    regression_loss, loss]; backward writes the dense prediction gradients in one launch."""
+
+    @staticmethod
+    def forward(ctx, pred_cls, pred_reg, cls_t, reg_t, desc, reduce_sums, rank_scale):
+        fin = ops.get_loss_forward(desc, pred_cls, pred_reg, cls_t, reg_t, reduce_sums, rank_scale)
+        ctx.desc = desc
+        ctx.save_for_backward(pred_cls, pred_reg, cls_t, reg_t, fin)
+        return fin[:3].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred_cls, pred_reg, cls_t, reg_t, fin = ctx.saved_tensors
+        gc, gr = ops.get_loss_backward(ctx.desc, pred_cls, pred_reg, cls_t, reg_t, fin, g)
+        return gc.view_as(pred_cls).to(pred_cls.dtype), gr.view_as(pred_reg).to(pred_reg.dtype), None, None, None, None, None
 
 
 class LFD(nn.Module):
@@ -282,6 +302,8 @@ class LFD(nn.Module):
         N = pred_cls.size(0)
         C = self._num_classes
         ce = self._is_ce()
+        if self._fused_loss_supported(pred_cls):
+            return self._get_loss_fused(pred_cls, pred_reg, cls_t, reg_t)
         fc = pred_cls.reshape(-1, C + 1 if ce else C)
         fr = pred_reg.reshape(-1, 4)
         ct = cls_t.reshape(-1, C).to(dev)
@@ -322,6 +344,37 @@ class LFD(nn.Module):
         loss = cls_loss + reg_loss
         return dict(loss=loss, loss_values=dict(loss=loss.item(), classification_loss=cls_loss.item(),
                                                 regression_loss=reg_loss.item()))
+
+    def _fused_loss_supported(self, pred_cls):
+        """The three-launch device path (csrc/getloss.hip) covers what the shipped configs use: FocalLoss or
+        CrossEntropyLoss + IoULoss, 'mean' reduction; other loss modules take the op-by-op path above."""
+        if pred_cls.device.type != 'cuda' or os.environ.get('LFD_FUSED_LOSS', '1') == '0':
+            return False
+        cf, rf = self._classification_loss_func, self._regression_loss_func
+        if type(cf).__name__ == 'FocalLoss':
+            if not getattr(cf, 'use_sigmoid', True):
+                return False
+        elif type(cf).__name__ != 'CrossEntropyLoss':
+            return False
+        return type(rf).__name__ == 'IoULoss' and cf.reduction == 'mean' and rf.reduction == 'mean'
+
+    def _get_loss_fused(self, pred_cls, pred_reg, cls_t, reg_t):
+        cf, rf = self._classification_loss_func, self._regression_loss_func
+        sizes = [self._head_indexes_to_feature_map_sizes[i] for i in range(self._num_heads)]
+        desc = ops.make_loss_desc(pred_cls.size(0), sizes, self._point_strides, self._regression_ranges,
+                                  self._num_classes, self._is_ce(), self._distance_to_bbox_mode,
+                                  gamma=getattr(cf, 'gamma', 2.0), alpha=getattr(cf, 'alpha', 0.25), iou_eps=rf.eps,
+                                  cls_loss_weight=cf.loss_weight, reg_loss_weight=rf.loss_weight,
+                                  cls_weighted=self._enable_classification_weight,
+                                  reg_weighted=self._enable_regression_weight)
+        # image-parallel training: the reference normalises by the GLOBAL-batch n_pos (loss computed once over the
+        # gathered outputs, executor.py:198-200); gradients are averaged over ranks afterwards, hence the scale
+        dist_on = parallel.is_dist()
+        vals = _FusedLossFunction.apply(pred_cls, pred_reg, cls_t, reg_t, desc,
+                                        parallel.global_count if dist_on else None,
+                                        float(parallel.world_size()) if dist_on else 1.0)
+        c, r, t = vals.tolist()      # the one host sync of the step (the reference does three .item())
+        return dict(loss=vals[2], loss_values=dict(loss=t, classification_loss=c, regression_loss=r))
 
     # ------------------------------------------------------------------ post-processing
     def _detect_desc(self, score_thr, iou_thr, class_agnostic, max_candidates=None):

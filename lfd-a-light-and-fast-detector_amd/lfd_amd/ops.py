@@ -255,6 +255,68 @@ def assign_targets(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_
     return cls_t, reg_t
 
 
+def make_loss_desc(n, sizes, strides, reg_ranges, num_classes, cross_entropy, decode_mode, gamma=2.0, alpha=0.25,
+                   iou_eps=1e-6, cls_loss_weight=1.0, reg_loss_weight=1.0, cls_weighted=False, reg_weighted=False):
+    """lfd_loss_desc_t for the fused get_loss kernels (decode_mode: 'sigmoid' | 'exp', lfd.py:366-374)."""
+    d = _lib.LossDesc()
+    d.n, d.num_levels = int(n), len(sizes)
+    total = 0
+    for i, (h, w) in enumerate(sizes):
+        d.level_h[i], d.level_w[i], d.stride[i] = int(h), int(w), int(strides[i])
+        d.range_max[i] = float(max(reg_ranges[i]))
+        total += int(h) * int(w)
+    d.total_points, d.num_classes = total, int(num_classes)
+    d.cls_loss = 1 if cross_entropy else 0
+    d.decode_mode = {'sigmoid': 0, 'exp': 1}[decode_mode]
+    d.gamma, d.alpha, d.iou_eps = float(gamma), float(alpha), float(iou_eps)
+    d.cls_loss_weight, d.reg_loss_weight = float(cls_loss_weight), float(reg_loss_weight)
+    d.cls_weighted, d.reg_weighted = int(bool(cls_weighted)), int(bool(reg_weighted))
+    return d
+
+
+def _loss_inputs(desc, pred_cls, pred_reg, cls_t, reg_t):
+    require_cuda(pred_cls, 'get_loss')
+    ch = desc.num_classes + (1 if desc.cls_loss else 0)
+    rows = desc.n * desc.total_points
+    ts = [pred_cls.detach().contiguous().float(), pred_reg.detach().contiguous().float(),
+          cls_t.contiguous().float(), reg_t.contiguous().float()]
+    for t, c in zip(ts, (ch, 4, desc.num_classes, 4)):
+        if t.numel() != rows * c:
+            raise ValueError('get_loss: tensor with %d elements, expected %d rows x %d' % (t.numel(), rows, c))
+    return ts
+
+
+def get_loss_forward(desc, pred_cls, pred_reg, cls_t, reg_t, reduce_sums=None, rank_scale=1.0):
+    """Fused LFD.get_loss forward (lfd.py:284-395) -> float32[8] device tensor
+    {classification_loss, regression_loss, loss, n_pos, avg_cls, avg_reg, n_green, rank_scale}.
+    reduce_sums: optional callable mapping the local float64[8] sums tensor to the global one (the
+    all-reduce over image-parallel ranks, lfd_amd.parallel.global_count)."""
+    pc, pr, ct, rt = _loss_inputs(desc, pred_cls, pred_reg, cls_t, reg_t)
+    dev = pc.device
+    nbytes = lib().lfd_get_loss_workspace_bytes()
+    ws = _workspace(nbytes, dev)
+    sums = torch.empty(8, dtype=torch.float64, device=dev)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().lfd_get_loss_sums_f32(C.byref(desc), ptr(pc), ptr(pr), ptr(ct), ptr(rt), ptr(ws), nbytes, ptr(sums),
+                                          stream_ptr()), 'lfd_get_loss_sums_f32')
+        gsums = reduce_sums(sums) if reduce_sums is not None else sums
+        check(lib().lfd_get_loss_finalize_f32(C.byref(desc), ptr(sums), ptr(gsums), float(rank_scale), ptr(out),
+                                              stream_ptr()), 'lfd_get_loss_finalize_f32')
+    return out
+
+
+def get_loss_backward(desc, pred_cls, pred_reg, cls_t, reg_t, finalized, grad_out):
+    """-> (d pred_cls, d pred_reg), dense, for grad_out[3] = d/d{classification_loss, regression_loss, loss}."""
+    pc, pr, ct, rt = _loss_inputs(desc, pred_cls, pred_reg, cls_t, reg_t)
+    g = grad_out.contiguous().float()
+    gc, gr = torch.empty_like(pc), torch.empty_like(pr)
+    with torch.cuda.device(pc.device):
+        check(lib().lfd_get_loss_bwd_f32(C.byref(desc), ptr(pc), ptr(pr), ptr(ct), ptr(rt), ptr(finalized), ptr(g),
+                                         ptr(gc), ptr(gr), stream_ptr()), 'lfd_get_loss_bwd_f32')
+    return gc, gr
+
+
 # ------------------------------------------------------------------ conv stack (NHWC fp16)
 def pack_conv_weight(w):
     """[Cout,Cin,k,k] float (BN already folded) -> MFMA fragment order [Cout/32][k*k*Cin/16][64][8] fp16.

@@ -16,6 +16,10 @@ def is_dist():
     return dist.is_available() and dist.is_initialized()
 
 
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
 def shard_range(num_items, rank, world):
     """Contiguous, balanced partition of `num_items` images: first (num_items % world) ranks get one more."""
     base, rem = divmod(num_items, world)

@@ -30,6 +30,16 @@ assert float(parallel.global_count(n_pos)) == 8.0
 g = torch.full((4,), float(rank + 1))
 parallel.allreduce_mean_([g])
 assert torch.allclose(g, torch.full((4,), 1.5))
+# 4b. the flat gradient buffer of lfd_amd.optim.SGD is the all-reduce bucket (one collective, mean over ranks)
+from lfd_amd import optim
+torch.manual_seed(0)
+lin = torch.nn.Linear(5, 3)
+opt = optim.SGD(lin.parameters(), lr=0.1, momentum=0.9)
+opt.zero_grad()
+(lin(torch.ones(2, 5)).sum() * float(rank + 1)).backward()
+opt.allreduce_grads()
+assert torch.allclose(lin.weight.grad, torch.full((3, 5), 2.0 * 1.5)) and torch.allclose(lin.bias.grad, torch.full((3,), 2.0 * 1.5))
+assert lin.weight.grad.data_ptr() == opt._flat[0].g.data_ptr()
 # 5. throughput aggregation: max time over ranks
 t = parallel.max_over_ranks(1.0 + rank)
 assert t == 2.0

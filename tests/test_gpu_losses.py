@@ -96,10 +96,13 @@ def test_iou_loss_forward_backward():
     np.testing.assert_allclose(p.grad.cpu().numpy(), pc.grad.numpy(), rtol=2e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize('fused', ['1', '0'])
 @pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L'])
-def test_get_loss_vs_reference_golden(name):
+def test_get_loss_vs_reference_golden(name, fused, monkeypatch):
     """LFD.get_loss on the reference's own predictions + annotations: loss values and gradients
-    w.r.t. the predictions match the reference (its focal path ran through the C restatement)."""
+    w.r.t. the predictions match the reference (its focal path ran through the C restatement).
+    fused=1: the three-launch device path (csrc/getloss.hip, the default); fused=0: the op-by-op mirror."""
+    monkeypatch.setenv('LFD_FUSED_LOSS', fused)
     g = load_golden('ref_model_%s.npz' % name)
     m = configs.build_model(name).cuda()
     for i, s in enumerate(g['sizes'].tolist()):
@@ -119,7 +122,9 @@ def test_get_loss_vs_reference_golden(name):
     np.testing.assert_allclose(reg.grad.cpu().numpy(), g['grad_reg'], rtol=2e-3, atol=1e-7)
 
 
-def test_get_loss_no_positives():
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_get_loss_no_positives(fused, monkeypatch):
+    monkeypatch.setenv('LFD_FUSED_LOSS', fused)
     m = configs.build_model('WIDERFACE_LFD_XS').cuda()
     sizes = [(4, 4), (2, 2), (1, 1), (1, 1), (1, 1)]
     for i, s in enumerate(sizes):
@@ -131,6 +136,96 @@ def test_get_loss_no_positives():
     assert out['loss_values']['regression_loss'] == 0.0          # empty.sum() (lfd.py:386-387)
     out['loss'].backward()
     assert torch.isfinite(cls.grad).all()
+
+
+def _random_annotations(rng, n, hw, num_classes, max_boxes):
+    ann = []
+    for i in range(n):
+        k = int(rng.integers(0, max_boxes + 1)) if i else max_boxes      # image 0 always has boxes
+        wh = np.exp(rng.uniform(np.log(6), np.log(300), (k, 2)))
+        xy = rng.uniform(0, 1, (k, 2)) * (np.array([hw[1], hw[0]]) - wh).clip(1)
+        ann.append((np.concatenate([xy, wh], 1).astype(np.float32), rng.integers(0, num_classes, k).astype(np.int64)))
+    return ann
+
+
+@pytest.mark.parametrize('name,hw,n,variant', [
+    ('WIDERFACE_LFD_S', (640, 640), 4, 'plain'),
+    ('WIDERFACE_LFD_S', (480, 640), 3, 'weighted'),
+    ('WIDERFACE_LFD_XS', (320, 416), 2, 'exp'),
+    ('TT100K_LFD_L', (384, 512), 2, 'plain'),
+    ('TT100K_LFD_L', (256, 256), 2, 'weighted'),
+])
+def test_fused_get_loss_equals_op_by_op_path_and_oracle(name, hw, n, variant, monkeypatch):
+    """The fused device get_loss (no gathers, no syncs) against (a) the op-by-op mirror of lfd.py:284-395 running the
+    stand-alone HIP loss kernels and (b) the CPU oracle, at training-size point grids: losses to 2e-5 relative,
+    prediction gradients to 2e-4 / 2e-3 relative (fp32 summation order differs: fp64 partials here)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32((name + variant).encode()))
+    m = configs.build_model(name).cuda()
+    if variant == 'weighted':
+        m._enable_classification_weight = m._enable_regression_weight = True
+    if variant == 'exp':
+        m._distance_to_bbox_mode = 'exp'
+    arch = configs.ARCHS[name]
+    strides = m._point_strides
+    sizes = [(-(-hw[0] // s), -(-hw[1] // s)) for s in strides]
+    for i, sz in enumerate(sizes):
+        m._head_indexes_to_feature_map_sizes[i] = sz
+    P = sum(h * w for h, w in sizes)
+    C = m._num_classes
+    ch = C + 1 if m._is_ce() else C
+    ann = _random_annotations(rng, n, hw, C, 12)
+    cls0 = torch.from_numpy(rng.normal(-2, 2, (n, P, ch)).astype(np.float32)).cuda()
+    reg0 = torch.from_numpy(rng.normal(0, 1.0 if variant != 'exp' else 0.5, (n, P, 4)).astype(np.float32)).cuda()
+    if variant == 'exp':
+        reg0 += 3.0
+    res = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('LFD_FUSED_LOSS', fused)
+        cls, reg = cls0.clone().requires_grad_(True), reg0.clone().requires_grad_(True)
+        out = m.get_loss((cls, reg), ann)
+        (out['loss'] * 1.5).backward()
+        res[fused] = (out['loss_values'], cls.grad.cpu().numpy(), reg.grad.cpu().numpy())
+    a, b = res['1'], res['0']
+    assert a[0]['regression_loss'] > 0 and np.abs(a[2]).max() > 0
+    for k in ('loss', 'classification_loss', 'regression_loss'):
+        assert a[0][k] == pytest.approx(b[0][k], rel=2e-5), k
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(a[2], b[2], rtol=2e-3, atol=1e-9)
+    # gray and non-positive rows get exactly zero regression gradient, gray rows exactly zero class gradient
+    assert np.array_equal(a[2] == 0, b[2] == 0) or np.abs(a[2][(a[2] == 0) != (b[2] == 0)]).max() < 1e-12
+    if variant == 'plain':
+        import oracle.net_oracle as no
+        o = no.lfd_loss(dict(arch, distance_to_bbox_mode=m._distance_to_bbox_mode), cls0.cpu(), reg0.cpu(), sizes,
+                        list(strides), [torch.from_numpy(x) for x, _ in ann], [torch.from_numpy(y) for _, y in ann])
+        assert a[0]['loss'] == pytest.approx(o['loss'], rel=2e-5)
+        assert a[0]['classification_loss'] == pytest.approx(o['classification_loss'], rel=2e-5)
+        assert a[0]['regression_loss'] == pytest.approx(o['regression_loss'], rel=2e-5)
+
+
+def test_fused_get_loss_sums_are_deterministic_and_global_normaliser():
+    """Same inputs -> bit-identical sums (fixed-order fp64 reduction); the finalize stage divides by the GLOBAL sums
+    handed in (image-parallel ranks): feeding 2x the local sums as 'global' with rank_scale 2 halves nothing but the
+    +1 of the classification normaliser."""
+    rng = np.random.default_rng(5)
+    sizes, strides, ranges = [(40, 40), (20, 20)], [8, 16], [(4, 20), (20, 40)]
+    P, n, C = 2000, 3, 1
+    d = ops.make_loss_desc(n, sizes, strides, ranges, C, False, 'sigmoid')
+    ct = torch.from_numpy(np.where(rng.random((n, P, C)) < 0.05, rng.random((n, P, C)), 0).astype(np.float32)).cuda()
+    ct[0, :50] = -1
+    rt = torch.from_numpy(rng.uniform(1, 30, (n, P, 4)).astype(np.float32)).cuda()
+    pc = torch.from_numpy(rng.normal(0, 2, (n, P, C)).astype(np.float32)).cuda()
+    pr = torch.from_numpy(rng.normal(0, 1, (n, P, 4)).astype(np.float32)).cuda()
+    f1 = ops.get_loss_forward(d, pc, pr, ct, rt)
+    f2 = ops.get_loss_forward(d, pc, pr, ct, rt)
+    assert torch.equal(f1, f2)
+    n_pos = float(f1[3])
+    assert n_pos == float(((ct.max(-1)[0] >= 0.001) & (ct.min(-1)[0] >= 0)).sum())
+    assert float(f1[6]) == float((ct.min(-1)[0] >= 0).sum())
+    g = ops.get_loss_forward(d, pc, pr, ct, rt, reduce_sums=lambda s: s * 2, rank_scale=2.0)
+    assert float(g[3]) == 2 * n_pos
+    assert float(g[1]) == pytest.approx(float(f1[1]), rel=1e-6)                       # 2 * sum / (2 n_pos)
+    assert float(g[0]) == pytest.approx(float(f1[0]) * (n_pos + 1) * 2 / (2 * n_pos + 1), rel=1e-6)
 
 
 @pytest.mark.gpu

@@ -175,3 +175,59 @@ def test_target_assignment_and_loss_match_golden_on_cpu_tensors():
     ct, rt = m.annotation_to_target(pts, bb, ll)
     np.testing.assert_array_equal(ct.numpy(), g['cls_targets'])
     np.testing.assert_array_equal(rt.numpy(), g['reg_targets'])
+
+
+def test_flat_sgd_layout_and_loud_cpu_failure():
+    """lfd_amd.optim.SGD: parameters / gradients / momentum become views of one contiguous buffer per group (values and
+    state_dict unchanged, torch.optim.SGD's param_groups layout); the update itself is a HIP kernel and refuses CPU."""
+    from lfd_amd import optim
+    m = configs.build_model('WIDERFACE_LFD_XS')
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    o = optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ref = torch.optim.SGD(configs.build_model('WIDERFACE_LFD_XS').parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    assert all(torch.equal(before[k], v) for k, v in m.state_dict().items())
+    assert {k: v for k, v in o.state_dict()['param_groups'][0].items() if k in o.defaults} == \
+        {k: v for k, v in ref.state_dict()['param_groups'][0].items() if k in o.defaults}
+    assert o.state_dict()['param_groups'][0]['params'] == ref.state_dict()['param_groups'][0]['params']
+    assert o.state_dict()['state'] == {}
+    fg = o._flat[0]
+    assert fg.numel >= sum(p.numel() for p in m.parameters()) and fg.numel % 64 == 0
+    for p, off in zip(fg.params, fg.offsets):
+        assert off % 64 == 0 and p.data_ptr() == fg.p.data_ptr() + 4 * off and p.grad.data_ptr() == fg.g.data_ptr() + 4 * off
+    m.train()
+    c, r = m(torch.randn(2, 3, 128, 128))
+    (c.sum() + r.sum()).backward()                    # autograd accumulates into the flat views in place
+    assert float(fg.g.abs().sum()) > 0 and fg.adopt_grads()
+    assert all(p.grad.data_ptr() == fg.g.data_ptr() + 4 * off for p, off in zip(fg.params, fg.offsets))
+    o.zero_grad()
+    assert float(fg.g.abs().sum()) == 0 and all(p.grad is not None for p in fg.params)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        o.step()
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        optim.clip_grad_norm_(m.parameters(), 10)
+    with pytest.raises(ValueError):
+        optim.SGD(m.parameters(), lr=-1)
+    with pytest.raises(ValueError):
+        optim.SGD(m.parameters(), lr=0.1, nesterov=True)
+
+
+def test_optimizer_hook_mirror_reads_the_reference_config_keys():
+    """lfd_amd.train.OptimizerHook: same ctor as optimizer_hook.py:10-19 ('duration' popped, default = all epochs)
+    and the after_train_iter(executor) contract on executor.config_dict (:26-36), here with a torch optimizer on CPU
+    (the generic branch: torch clip_grad_norm_ + step)."""
+    from lfd_amd import train
+    h = train.OptimizerHook(dict(max_norm=10, norm_type=2, duration=5), training_epochs=100)
+    assert h._grad_clip_duration == 5 and h._grad_clip_cfg == dict(max_norm=10, norm_type=2)
+    assert train.OptimizerHook(dict(max_norm=1), training_epochs=7)._grad_clip_duration == 7
+    assert train.OptimizerHook(None, 3)._grad_clip_cfg is None
+    w = nn.Parameter(torch.tensor([3.0, 4.0]))
+    opt = torch.optim.SGD([w], lr=0.1)
+
+    class Ex(object):
+        config_dict = dict(optimizer=opt, loss=(w * torch.tensor([30.0, 40.0])).sum(), model=None, epoch=0)
+    h.after_train_iter(Ex)
+    assert float(Ex.config_dict['grad_norm']) == pytest.approx(50.0)
+    assert torch.allclose(w.detach(), torch.tensor([3.0 - 0.1 * 6.0, 4.0 - 0.1 * 8.0]), atol=1e-5)   # clipped to norm 10
+    Ex.config_dict.update(loss=(w * 2).sum(), epoch=5)                                      # past the duration
+    h.after_train_iter(Ex)
+    assert Ex.config_dict['grad_norm'] == 0
