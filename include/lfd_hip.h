@@ -309,6 +309,50 @@ LFD_API int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t
                                       lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode conv stack.  The reference trains through PyTorch autograd over
+ * nn.Conv2d(bias=False) + nn.BatchNorm2d + ReLU (+ residual add) units (lfd_resnet.py:96-154 blocks,
+ * :354-439 stem, :458-468 downsample; `loss.backward()` at optimizer_hook.py:28).  Here activations and
+ * activation gradients are NHWC fp16 (gradients multiplied by a power-of-two loss scale; `inv_scale`
+ * = 1/scale is applied where fp32 parameter gradients are written), statistics and parameter
+ * gradients fp32.  A conv unit's forward is lfd_conv2d_nhwc_f16 (bias NULL-equivalent: zero bias, no
+ * ReLU) -> lfd_bn_train_stats_f16 -> lfd_bn_train_apply_f16; its backward lfd_bn_train_bwd_f16 ->
+ * lfd_conv_wgrad_nhwc_f16 + lfd_conv2d_nhwc_f16 on the transposed, tap-flipped weights (stride 2:
+ * after lfd_zero_insert2_nhwc_f16).  channels: power of two in [8, 256].  Every reduction is per-block
+ * partials + a fixed-order final stage (deterministic).  `workspace`: lfd_train_workspace_bytes().
+ */
+LFD_API size_t lfd_train_workspace_bytes(void);
+/* batch statistics of y [pixels, channels]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(biased var + eps)
+ * (F.batch_norm training=True); running_mean / running_var (nullable) are updated with `momentum` and
+ * the unbiased variance like nn.BatchNorm2d. */
+LFD_API int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channels, float eps, float momentum,
+                           float* running_mean, float* running_var, void* workspace, size_t workspace_bytes,
+                           float* stats, lfd_stream_t stream);
+/* z = relu?( gamma * (y - mean) * rstd + beta (+ residual) ) */
+LFD_API int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, const float* stats, const float* gamma,
+                           const float* beta, const void* residual, int32_t relu, void* z, lfd_stream_t stream);
+/* backward of the above: g = dz * [z > 0] (z NULL: no ReLU), dgamma = inv_scale * sum g * xhat,
+ * dbeta = inv_scale * sum g, dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)); g_out (nullable)
+ * receives g, the gradient of the residual branch. */
+LFD_API int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t pixels, int32_t channels,
+                         const float* stats, const float* gamma, float inv_scale, void* workspace,
+                         size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
+                         lfd_stream_t stream);
+/* out[n, 2i, 2j, :] = in[n, i, j, :], zero elsewhere; ho in {2*hi-1, 2*hi}, wo likewise */
+LFD_API int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t channels, int32_t ho,
+                              int32_t wo, void* out, lfd_stream_t stream);
+/* dW [cout, cin, ks, ks] fp32 (OIHW, the nn.Conv2d.weight layout) = inv_scale * sum over pixels of
+ * dy (x) x for a conv with pad ks/2; x [n,h,w,cin], dy [n,ho,wo,cout]; cin, cout multiples of 8, <= 128. */
+LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                            int32_t ks, int32_t stride, float inv_scale, void* workspace, size_t workspace_bytes,
+                            float* dw, lfd_stream_t stream);
+/* first stem conv (3 -> channels, 3x3 stride 2 pad 1, lfd_resnet.py:358,:378) on the NCHW fp32 image batch:
+ * forward -> y NHWC fp16 (pre-norm), and its weight gradient (OIHW fp32); channels in {32, 64} */
+LFD_API int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
+                             const float* weight_oihw, void* y, lfd_stream_t stream);
+LFD_API int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t h, int32_t w, int32_t channels,
+                         float inv_scale, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Neck + head of ALL pyramid levels.  Replaces SimpleNeck.forward (simple_neck.py:67-74),
  * LFDHead.forward (lfd_head.py:164-185: GroupNorm towers + cls/reg convs + Scale) and the
  * NCHW -> [N,P,C] permute/concat of LFD.forward (lfd.py:526-542): writes the fp32 cls / reg rows of

@@ -205,7 +205,7 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   // address is a SCALAR row base + a per-lane constant and the only per-instruction vector work is the validity
   // select.  (The generic slot walk below costs ~40 dependent VALU instructions per DMA -- integer divide, 64-bit
   // multiply -- which measured 2.6 k cycles per tile, as long as the tile's whole contraction.)
-  constexpr bool FAST = (CIN == 64 && KS == 3 && S == 1 && !TAIL && !DS);
+  constexpr bool FAST = (CIN == 64 && KS == 3 && S == 1 && NCT == 2 && !TAIL && !DS);
   const long f_rowpitch = (long)a.W * (CIN * 2);
   auto issue_dma_fast = [&](int t, int buf) {
     int ol = lane;
@@ -654,7 +654,9 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   const int cgroups = TAIL ? 1 : a.cout / (NCT * 32);
   constexpr int LDSB = C::LDS_BYTES;
-  static_assert(2 * LDSB <= 160 * 1024, "two workgroups per CU");
+  // the inference shapes all fit two workgroups per CU; a few data-gradient shapes of the training path (few output
+  // channels -> tall tiles) only fit one
+  static_assert(LDSB <= 160 * 1024, "LDS capacity");
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS>),
@@ -670,10 +672,11 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   return LFD_OK;
 }
 
-// residual variants are only instantiated for the stride-1 3x3 convs that close a residual block
+// residual variants are only instantiated for stride-1 convs: the 3x3 that closes a residual block, and (training) the
+// data-gradient convs, whose "residual" is the gradient already collected for the same activation
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-  if constexpr (KS == 3 && S == 1 && !TAIL) {
+  if constexpr (S == 1 && !TAIL) {
     if (a.res) return launch_conv_<CIN, KS, S, NCT, WREG, TAIL, true, false>(a, st);
   } else {
     if (a.res) return LFD_ERR_UNSUPPORTED;
@@ -794,6 +797,8 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     case 64 * 10000 + 3200 + 20: return launch_conv<64, 3, 2, 2, true, false>(a, st);
     case 64 * 10000 + 3200 + 21: return launch_conv<64, 3, 2, 2, true, true>(a, st);
     case 64 * 10000 + 3200 + 40: return launch_conv<64, 3, 2, 4, true, false>(a, st);
+    case 64 * 10000 + 3100 + 10: return launch_conv<64, 3, 1, 1, true, false>(a, st);   // data gradient of 32->64 s2 (XS)
+    case 64 * 10000 + 1100 + 10: return launch_conv<64, 1, 1, 1, true, false>(a, st);   // data gradient of the 32->64 downsample
     case 64 * 10000 + 1100 + 20: return launch_conv<64, 1, 1, 2, true, false>(a, st);
     case 64 * 10000 + 1100 + 40: return launch_conv<64, 1, 1, 4, true, false>(a, st);
     case 64 * 10000 + 1200 + 20: return launch_conv<64, 1, 2, 2, true, false>(a, st);
@@ -801,6 +806,8 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     // ---- 128-channel stages (tiny maps): weights streamed from L2 per k-step
     case 128 * 10000 + 3100 + 40: return launch_conv<128, 3, 1, 4, false, false>(a, st);
     case 128 * 10000 + 3200 + 40: return launch_conv<128, 3, 2, 4, false, false>(a, st);
+    case 128 * 10000 + 3100 + 20: return launch_conv<128, 3, 1, 2, false, false>(a, st);  // data gradient of 64->128 s2
+    case 128 * 10000 + 1100 + 20: return launch_conv<128, 1, 1, 2, true, false>(a, st);   // data gradient of the 64->128 downsample
     case 128 * 10000 + 1100 + 40: return launch_conv<128, 1, 1, 4, true, false>(a, st);
     case 128 * 10000 + 1200 + 40: return launch_conv<128, 1, 2, 4, true, false>(a, st);
     // ---- 32-channel stem of the XS model

@@ -1,0 +1,636 @@
+// csrc/train.hip -- training-mode kernels of the LFDResNet conv stack (the reference runs
+// `loss.backward()` (lfd/execution/hooks/optimizer_hook.py:28) through cuDNN conv + ATen BatchNorm autograd for the
+// nn.Conv2d / nn.BatchNorm2d / ReLU (+ residual add) units of lfd/model/backbone/lfd_resnet.py:96-154, :354-439, :458-468).
+//
+// Activations and activation gradients are NHWC fp16 (gradients carry a power-of-two loss scale), parameters,
+// BatchNorm statistics and parameter gradients fp32.  Per conv unit:
+//   forward :  y = conv(x, W)            lfd_conv2d_nhwc_f16 (conv.hip, MFMA) / lfd_stem_conv0_train_fwd (3 input channels)
+//              batch statistics of y     lfd_bn_train_stats_f16      (+ running_mean / running_var update)
+//              z = relu?(bn(y) (+ res))  lfd_bn_train_apply_f16
+//   backward:  g = dz * [z > 0];  dgamma, dbeta;  dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))
+//                                        lfd_bn_train_bwd_f16        (2 reductions + 1 apply, deterministic)
+//              dW = x (*) dy             lfd_conv_wgrad_nhwc_f16     (MFMA, k = pixels, LDS transpose reads)
+//              dx = conv(dy, W^T flipped)  the forward conv kernel again (stride 2: after lfd_zero_insert2_nhwc_f16)
+// All reductions use per-block partials + a fixed-order final stage (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1024;
+constexpr int kMaxC = 256;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+union Vec16 {
+  uint4 u;
+  h8 h;
+};
+
+__device__ __forceinline__ h8 ld8(const __half* p, int64_t vec) {
+  Vec16 v;
+  v.u = reinterpret_cast<const uint4*>(p)[vec];
+  return v.h;
+}
+__device__ __forceinline__ void st8(__half* p, int64_t vec, h8 h) {
+  Vec16 v;
+  v.h = h;
+  reinterpret_cast<uint4*>(p)[vec] = v.u;
+}
+
+inline unsigned grid_for_vecs(int64_t vecs) {
+  int64_t b = (vecs + kThreads - 1) / kThreads;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline bool channels_ok(int c) { return c >= 8 && c <= kMaxC && (c & (c - 1)) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-channel reductions over an NHWC fp16 tensor [m][c]: every thread owns one 8-channel group (the grid stride is
+// a multiple of c/8), accumulates NQ quantities per channel in fp32, the block combines the threads of a group through
+// LDS and writes partial[block][NQ][c]; `k_channel_final` sums the partials in fp64 in block order.
+// ---------------------------------------------------------------------------------------------------------
+template <int NQ>
+__device__ __forceinline__ void block_channel_reduce(float (&acc)[NQ][8], int c, float* partial_out) {
+  __shared__ float red[kThreads][NQ * 8 + 1];
+  for (int q = 0; q < NQ; ++q)
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][q * 8 + e] = acc[q][e];
+  __syncthreads();
+  const int groups = c >> 3;
+  for (int o = threadIdx.x; o < NQ * c; o += kThreads) {
+    const int q = o / c, ch = o - q * c;
+    const int cg = ch >> 3, e = ch & 7;
+    float s = 0.f;
+    for (int t = cg; t < kThreads; t += groups) s += red[t][q * 8 + e];
+    partial_out[(size_t)blockIdx.x * NQ * c + o] = s;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_stats_partial(const __half* __restrict__ y, int64_t vecs, int c,
+                                                              float* partials) {
+  float acc[2][8];
+  for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+    const h8 h = ld8(y, v);
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)h[e];
+      acc[0][e] += f;
+      acc[1][e] += f * f;
+    }
+  }
+  block_channel_reduce<2>(acc, c, partials);
+}
+
+// stats[0][c] = mean, stats[1][c] = 1/sqrt(var + eps) (biased variance, as F.batch_norm normalises in training);
+// running_mean / running_var updated with `momentum` and the unbiased variance (torch BatchNorm semantics)
+__global__ __launch_bounds__(kThreads) void k_bn_stats_final(const float* partials, int nblocks, int c, double m,
+                                                            float eps, float momentum, float* running_mean,
+                                                            float* running_var, float* stats) {
+  for (int ch = threadIdx.x; ch < c; ch += kThreads) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+      s += (double)partials[(size_t)b * 2 * c + ch];
+      ss += (double)partials[(size_t)b * 2 * c + c + ch];
+    }
+    const double mean = s / m;
+    double var = ss / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[ch] = (float)mean;
+    stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = m > 1.0 ? var * m / (m - 1.0) : var;
+      running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
+      running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict__ y, int64_t vecs, int c,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const __half* __restrict__ res, int relu,
+                                                      __half* __restrict__ z) {
+  const int groups = c >> 3;
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  float a[8], b[8];
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cg * 8 + e;
+    a[e] = gamma[ch] * stats[c + ch];
+    b[e] = beta[ch] - stats[ch] * a[e];
+  }
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+    const h8 h = ld8(y, v);
+    h8 r, o;
+    if (res) r = ld8(res, v);
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)h[e] * a[e] + b[e];
+      if (res) f += (float)r[e];
+      if (relu) f = fmaxf(f, 0.f);
+      o[e] = (_Float16)f;
+    }
+    st8(z, v, o);
+  }
+}
+
+// sums of g and g * xhat, g = dz * [z > 0] (z == nullptr: no ReLU behind this norm)
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __restrict__ dz,
+                                                            const __half* __restrict__ y,
+                                                            const __half* __restrict__ z, int64_t vecs, int c,
+                                                            const float* __restrict__ stats, float* partials) {
+  const int groups = c >> 3;
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  float mean[8], rstd[8], acc[2][8];
+  for (int e = 0; e < 8; ++e) {
+    mean[e] = stats[cg * 8 + e];
+    rstd[e] = stats[c + cg * 8 + e];
+    acc[0][e] = acc[1][e] = 0.f;
+  }
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+    const h8 d = ld8(dz, v), yy = ld8(y, v);
+    h8 zz;
+    if (z) zz = ld8(z, v);
+    for (int e = 0; e < 8; ++e) {
+      float g = (float)d[e];
+      if (z && !((float)zz[e] > 0.f)) g = 0.f;
+      acc[0][e] += g;
+      acc[1][e] += g * (((float)yy[e] - mean[e]) * rstd[e]);
+    }
+  }
+  block_channel_reduce<2>(acc, c, partials);
+}
+
+// sums[0][c] = sum g (= dbeta * scale), sums[1][c] = sum g*xhat (= dgamma * scale); parameter gradients unscaled
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_final(const float* partials, int nblocks, int c, float inv_scale,
+                                                          float* sums, float* dgamma, float* dbeta) {
+  for (int ch = threadIdx.x; ch < c; ch += kThreads) {
+    double s = 0.0, sx = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+      s += (double)partials[(size_t)b * 2 * c + ch];
+      sx += (double)partials[(size_t)b * 2 * c + c + ch];
+    }
+    sums[ch] = (float)s;
+    sums[c + ch] = (float)sx;
+    if (dbeta) dbeta[ch] = (float)(s * (double)inv_scale);
+    if (dgamma) dgamma[ch] = (float)(sx * (double)inv_scale);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restrict__ dz,
+                                                          const __half* __restrict__ y,
+                                                          const __half* __restrict__ z, int64_t vecs, int c,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ sums, float inv_m,
+                                                          __half* __restrict__ dy, __half* __restrict__ g_out) {
+  const int groups = c >> 3;
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  float mean[8], rstd[8], a[8], mg[8], mgx[8];
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cg * 8 + e;
+    mean[e] = stats[ch];
+    rstd[e] = stats[c + ch];
+    a[e] = gamma[ch] * rstd[e];
+    mg[e] = sums[ch] * inv_m;
+    mgx[e] = sums[c + ch] * inv_m;
+  }
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+    const h8 d = ld8(dz, v), yy = ld8(y, v);
+    h8 zz, o, go;
+    if (z) zz = ld8(z, v);
+    for (int e = 0; e < 8; ++e) {
+      float g = (float)d[e];
+      if (z && !((float)zz[e] > 0.f)) g = 0.f;
+      const float xh = ((float)yy[e] - mean[e]) * rstd[e];
+      o[e] = (_Float16)(a[e] * (g - mg[e] - xh * mgx[e]));
+      go[e] = (_Float16)g;
+    }
+    st8(dy, v, o);
+    if (g_out) st8(g_out, v, go);
+  }
+}
+
+// out[n, 2i, 2j, :] = in[n, i, j, :], zero elsewhere (the gradient of a stride-2 subsampling)
+__global__ __launch_bounds__(kThreads) void k_zero_insert2(const __half* __restrict__ in, int n, int hi, int wi,
+                                                          int c, int ho, int wo, __half* __restrict__ out) {
+  const int groups = c >> 3;
+  const int64_t vecs = (int64_t)n * ho * wo * groups;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+    const int cg = (int)(v % groups);
+    int64_t p = v / groups;
+    const int x = (int)(p % wo);
+    p /= wo;
+    const int yy = (int)(p % ho);
+    const int img = (int)(p / ho);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (!(x & 1) && !(yy & 1) && (yy >> 1) < hi && (x >> 1) < wi)
+      val = reinterpret_cast<const uint4*>(in)[(((int64_t)img * hi + (yy >> 1)) * wi + (x >> 1)) * groups + cg];
+    reinterpret_cast<uint4*>(out)[v] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// First stem conv in training: conv3x3 stride 2 pad 1, 3 -> c channels, NCHW fp32 image -> NHWC fp16 pre-norm output
+// (lfd_resnet.py:358 / :378 `nn.Conv2d(input_channels, stem_channels, 3, 2, 1, bias=False)`).  27 taps on the VALU in
+// fp32 (0.5 % of the network's FLOPs); one thread = one output pixel x 8 channels, weights [27][c] in LDS.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_conv0_fwd(const float* __restrict__ x, int n, int h, int w, int c,
+                                                       const float* __restrict__ wt, __half* __restrict__ y) {
+  __shared__ float sw[27 * 64];
+  for (int i = threadIdx.x; i < 27 * c; i += kThreads) {
+    const int co = i / 27, t = i - co * 27;  // OIHW: wt[co][ci][ky][kx], t = ci*9 + ky*3 + kx
+    sw[t * c + co] = wt[i];
+  }
+  __syncthreads();
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2, groups = c >> 3;
+  const int64_t vecs = (int64_t)n * ho * wo * groups;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+    const int cg = (int)(v % groups);
+    int64_t p = v / groups;
+    const int ox = (int)(p % wo);
+    p /= wo;
+    const int oy = (int)(p % ho);
+    const int img = (int)(p / ho);
+    float acc[8];
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int ci = 0; ci < 3; ++ci)
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = 2 * ox + kx - 1;
+          float xv = 0.f;
+          if (iy >= 0 && iy < h && ix >= 0 && ix < w) xv = x[(((int64_t)img * 3 + ci) * h + iy) * w + ix];
+          const float* wr = sw + (ci * 9 + ky * 3 + kx) * c + cg * 8;
+          for (int e = 0; e < 8; ++e) acc[e] += xv * wr[e];
+        }
+      }
+    h8 o;
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
+    st8(y, v, o);
+  }
+}
+
+// dW[co][t] = sum over output pixels of dy[p][co] * x[tap t of p]; thread = (co, pixel sub-slice), all lanes of a wave
+// read the same 27 input values (one broadcast transaction each).  partial[block][27][c]
+__global__ __launch_bounds__(kThreads) void k_conv0_wgrad_partial(const float* __restrict__ x,
+                                                                 const __half* __restrict__ dy, int n, int h, int w,
+                                                                 int c, int pixels_per_block, float* partials) {
+  __shared__ float red[kThreads][28];
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int64_t total = (int64_t)n * ho * wo;
+  const int subs = kThreads / c;               // c = 32: 8 sub-slices, c = 64: 4
+  const int co = threadIdx.x % c, sub = threadIdx.x / c;
+  float acc[27];
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  const int64_t p0 = (int64_t)blockIdx.x * pixels_per_block;
+  int64_t p1 = p0 + pixels_per_block;
+  if (p1 > total) p1 = total;
+  for (int64_t p = p0 + sub; p < p1; p += subs) {
+    const int ox = (int)(p % wo);
+    const int64_t q = p / wo;
+    const int oy = (int)(q % ho);
+    const int img = (int)(q / ho);
+    const float g = __half2float(dy[p * c + co]);
+    for (int ci = 0; ci < 3; ++ci)
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = 2 * ox + kx - 1;
+          float xv = 0.f;
+          if (iy >= 0 && iy < h && ix >= 0 && ix < w) xv = x[(((int64_t)img * 3 + ci) * h + iy) * w + ix];
+          acc[ci * 9 + ky * 3 + kx] += g * xv;
+        }
+      }
+  }
+  for (int t = 0; t < 27; ++t) red[threadIdx.x][t] = acc[t];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 27 * c; o += kThreads) {
+    const int t = o / c, ch = o - t * c;
+    float s = 0.f;
+    for (int k = 0; k < subs; ++k) s += red[k * c + ch][t];
+    partials[(size_t)blockIdx.x * 27 * c + o] = s;
+  }
+}
+
+// generic fixed-order sum of partial[block][count] -> out[perm(i)] * inv_scale; perm: 0 identity,
+// 1: i = t*c + co -> co*taps + t (OIHW of the first conv)
+__global__ __launch_bounds__(kThreads) void k_sum_partials(const float* partials, int nblocks, int count, float inv_scale,
+                                                          int perm, int c, int taps, float* out) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partials[(size_t)b * count + i];
+  int o = i;
+  if (perm == 1) {
+    const int t = i / c, co = i - t * c;
+    o = co * taps + t;
+  }
+  out[o] = (float)(s * (double)inv_scale);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of a conv (ks 1|3, stride 1|2, pad ks/2) on MFMA:
+//   dW[co][tap][ci] = sum over output pixels p of dy[p][co] * x[pixel of tap at p][ci]
+// is a GEMM whose contraction index is the PIXEL, while both operands are channel-contiguous (NHWC).  The tiles
+// (8 x 16 output pixels of dy, the matching input halo of x; 64 channels each, 144-byte pixel pitch) are staged in LDS
+// as they lie in memory and the MFMA operands (row = channel, 8 consecutive k = pixels) are fetched with gfx950's
+// transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block, lane i receives
+// channel i of the 4 pixels); the per-lane pixel address makes the stride-2 gather free.
+// One workgroup = one 64(cout) x 64(cin) block of dW for all taps, persistent over pixel tiles with the accumulators
+// (ks*ks 32x32 tiles per wave) resident; wave = (cout half, cin half).  partial[wg][tap][co 64][ci 64] fp32, summed in
+// block order by k_wgrad_final (deterministic).
+// ---------------------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
+template <int KS, int S>
+struct WgradCfg {
+  static constexpr int TH = 8, TW = 16, PAD = KS / 2;
+  static constexpr int XH = (TH - 1) * S + KS, XW = (TW - 1) * S + KS;
+  static constexpr int PITCH = 144;
+  static constexpr int DY_BYTES = TH * TW * PITCH;
+  static constexpr int X_BYTES = XH * XW * PITCH;
+  static constexpr int LDS_BYTES = DY_BYTES + X_BYTES;
+};
+
+struct WgradArgs {
+  const __half* x;
+  const __half* dy;
+  int n, h, w, ho, wo, cin, cout;
+  int tiles_y, tiles_x;
+  float* partials;
+};
+
+__device__ __forceinline__ h8 tr_frag(const char* base, uint32_t off0, uint32_t off1) {
+  union { s4v s[2]; h8 h; } u;
+  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(base + off0));
+  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(base + off1));
+  return u.h;
+}
+
+template <int KS, int S>
+__global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
+  using C = WgradCfg<KS, S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sdy = smem;
+  char* sx = smem + C::DY_BYTES;
+  const int nib = (a.cin + 63) / 64;
+  const int cb = blockIdx.y / nib, ib = blockIdx.y - cb * nib;
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+  const int ch = wave >> 1, ih = wave & 1;
+  const bool active = (cb * 64 + ch * 32 < a.cout) && (ib * 64 + ih * 32 < a.cin);
+  f16v acc[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // lane constants of the transposing reads: read r in {0,1} covers k = 8*(l>>5) + 4r + ((l&15)>>2)
+  const int i16 = l & 15, grp = (l >> 4) & 1, kh = l >> 5;
+  uint32_t a_off[2], b_off[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int kp = 8 * kh + 4 * r + (i16 >> 2);
+    a_off[r] = kp * C::PITCH + (ch * 32 + 16 * grp + 4 * (i16 & 3)) * 2;
+    b_off[r] = kp * S * C::PITCH + (ih * 32 + 16 * grp + 4 * (i16 & 3)) * 2;
+  }
+  const int tiles = a.n * a.tiles_y * a.tiles_x;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int tx = t % a.tiles_x;
+    const int q = t / a.tiles_x;
+    const int ty = q % a.tiles_y;
+    const int img = q / a.tiles_y;
+    // ---- stage dy tile [TH*TW][64] and x halo tile [XH*XW][64] (zero outside the maps / channel range)
+    for (int i = tid; i < C::TH * C::TW * 8; i += kThreads) {
+      const int c8 = i & 7, p = i >> 3;
+      const int oy = ty * C::TH + p / C::TW, ox = tx * C::TW + p % C::TW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int co = cb * 64 + c8 * 8;
+      if (oy < a.ho && ox < a.wo && co < a.cout)
+        v = *reinterpret_cast<const uint4*>(a.dy + (((int64_t)img * a.ho + oy) * a.wo + ox) * a.cout + co);
+      *reinterpret_cast<uint4*>(sdy + p * C::PITCH + c8 * 16) = v;
+    }
+    for (int i = tid; i < C::XH * C::XW * 8; i += kThreads) {
+      const int c8 = i & 7, p = i >> 3;
+      const int iy = ty * C::TH * S - C::PAD + p / C::XW, ix = tx * C::TW * S - C::PAD + p % C::XW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int ci = ib * 64 + c8 * 8;
+      if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w && ci < a.cin)
+        v = *reinterpret_cast<const uint4*>(a.x + (((int64_t)img * a.h + iy) * a.w + ix) * a.cin + ci);
+      *reinterpret_cast<uint4*>(sx + p * C::PITCH + c8 * 16) = v;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int py = 0; py < C::TH; ++py) {
+        const uint32_t arow = py * C::TW * C::PITCH;
+        const h8 af = tr_frag(sdy, arow + a_off[0], arow + a_off[1]);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const uint32_t brow = ((py * S + ky) * C::XW + kx) * C::PITCH;
+            const h8 bf = tr_frag(sx, brow + b_off[0], brow + b_off[1]);
+            acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[ky * KS + kx], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partial[wg][block][tap][co 64][ci 64]: D layout lane = column (ci), reg r -> row (co) 8*(r>>2) + 4*(l>>5) + (r&3)
+  float* out = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (KS * KS * 64 * 64);
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = ch * 32 + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+      const int ci = ih * 32 + (l & 31);
+      out[(t * 64 + co) * 64 + ci] = active ? acc[t][r] : 0.f;
+    }
+}
+
+// dW (fp32, OIHW [cout][cin][ks][ks]) = inv_scale * sum over workgroups of the partials
+__global__ __launch_bounds__(kThreads) void k_wgrad_final(const float* partials, int nwg, int nblk, int cin, int cout,
+                                                         int taps, float inv_scale, float* dw) {
+  const int per_blk = taps * 64 * 64;
+  const int i = blockIdx.x * kThreads + threadIdx.x;   // over nblk * per_blk
+  if (i >= nblk * per_blk) return;
+  const int blk = i / per_blk, j = i - blk * per_blk;
+  const int t = j / 4096, co_l = (j >> 6) & 63, ci_l = j & 63;
+  const int nib = (cin + 63) / 64;
+  const int co = (blk / nib) * 64 + co_l, ci = (blk % nib) * 64 + ci_l;
+  if (co >= cout || ci >= cin) return;
+  double s = 0.0;
+  for (int g = 0; g < nwg; ++g) s += (double)partials[((size_t)g * nblk + blk) * per_blk + j];
+  dw[((size_t)co * cin + ci) * taps + t] = (float)(s * (double)inv_scale);
+}
+
+template <int KS, int S>
+int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
+  using C = WgradCfg<KS, S>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<KS, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    attr_set = true;
+  }
+  WgradArgs a = a0;
+  a.tiles_y = (a.ho + C::TH - 1) / C::TH;
+  a.tiles_x = (a.wo + C::TW - 1) / C::TW;
+  hipLaunchKernelGGL((k_wgrad<KS, S>), dim3(nwg, nblk), dim3(kThreads), C::LDS_BYTES, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+constexpr int kWgradMaxWg = 256;   // persistent workgroups per (cout, cin) block
+
+}  // namespace
+
+extern "C" {
+
+size_t lfd_train_workspace_bytes(void) {
+  // the largest user: wgrad partials, 256 workgroups x 4 blocks (128 x 128 channels) x 9 taps x 64 x 64 floats
+  return (size_t)kWgradMaxWg * 4 * 9 * 64 * 64 * sizeof(float) + 4096;
+}
+
+int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channels, float eps, float momentum,
+                           float* running_mean, float* running_var, void* workspace, size_t workspace_bytes,
+                           float* stats, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!y || !stats || !workspace || pixels < 1 || !channels_ok(channels)) return LFD_ERR_INVALID_ARGUMENT;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t vecs = pixels * (channels / 8);
+  const unsigned g = grid_for_vecs(vecs);
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_bn_stats_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)y, vecs, channels, partials);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_stats_final, dim3(1), dim3(kThreads), 0, st, partials, (int)g, channels, (double)pixels, eps,
+                     momentum, running_mean, running_var, stats);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, const float* stats, const float* gamma,
+                           const float* beta, const void* residual, int32_t relu, void* z, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!y || !stats || !gamma || !beta || !z || pixels < 1 || !channels_ok(channels)) return LFD_ERR_INVALID_ARGUMENT;
+  const int64_t vecs = pixels * (channels / 8);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
+                     stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t pixels, int32_t channels,
+                         const float* stats, const float* gamma, float inv_scale, void* workspace,
+                         size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
+                         lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!dz || !y || !stats || !gamma || !dy || !workspace || pixels < 1 || !channels_ok(channels))
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t vecs = pixels * (channels / 8);
+  const unsigned g = grid_for_vecs(vecs);
+  float* partials = reinterpret_cast<float*>(workspace);
+  float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, vecs, channels, stats, partials);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(kThreads), 0, st, partials, (int)g, channels, inv_scale, sums, dgamma,
+                     dbeta);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, vecs, channels, stats, gamma, sums, (float)(1.0 / (double)pixels), (__half*)dy,
+                     (__half*)g_out);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t channels, int32_t ho,
+                              int32_t wo, void* out, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!in || !out || n < 1 || hi < 1 || wi < 1 || ho < 2 * hi - 1 || wo < 2 * wi - 1 || ho > 2 * hi || wo > 2 * wi ||
+      !channels_ok(channels))
+    return LFD_ERR_INVALID_ARGUMENT;
+  const int64_t vecs = (int64_t)n * ho * wo * (channels / 8);
+  hipLaunchKernelGGL(k_zero_insert2, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)in, n, hi, wi,
+                     channels, ho, wo, (__half*)out);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                            int32_t ks, int32_t stride, float inv_scale, void* workspace, size_t workspace_bytes,
+                            float* dw, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!x || !dy || !dw || !workspace || n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return LFD_ERR_INVALID_ARGUMENT;
+  if (cin < 8 || cout < 8 || (cin & 7) || (cout & 7) || cin > 128 || cout > 128) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int pad = ks / 2;
+  WgradArgs a{};
+  a.x = (const __half*)x;
+  a.dy = (const __half*)dy;
+  a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+  a.ho = (h + 2 * pad - ks) / stride + 1;
+  a.wo = (w + 2 * pad - ks) / stride + 1;
+  a.partials = reinterpret_cast<float*>(workspace);
+  const int nblk = ((cout + 63) / 64) * ((cin + 63) / 64);
+  const int tiles = n * ((a.ho + 7) / 8) * ((a.wo + 15) / 16);
+  int nwg = tiles < kWgradMaxWg ? tiles : kWgradMaxWg;
+  int rc;
+  if (ks == 3 && stride == 1) rc = launch_wgrad<3, 1>(a, nwg, nblk, st);
+  else if (ks == 3) rc = launch_wgrad<3, 2>(a, nwg, nblk, st);
+  else if (stride == 1) rc = launch_wgrad<1, 1>(a, nwg, nblk, st);
+  else rc = launch_wgrad<1, 2>(a, nwg, nblk, st);
+  if (rc != LFD_OK) return rc;
+  const int taps = ks * ks, total = nblk * taps * 64 * 64;
+  hipLaunchKernelGGL(k_wgrad_final, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, a.partials, nwg, nblk,
+                     cin, cout, taps, inv_scale, dw);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
+                             const float* weight_oihw, void* y, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!x_nchw || !weight_oihw || !y || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
+    return LFD_ERR_INVALID_ARGUMENT;
+  const int64_t vecs = (int64_t)n * ((h + 1) / 2) * ((w + 1) / 2) * (channels / 8);
+  int64_t b = (vecs + kThreads - 1) / kThreads;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(k_conv0_fwd, dim3((unsigned)b), dim3(kThreads), 0, st, x_nchw, n, h, w, channels, weight_oihw,
+                     (__half*)y);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t h, int32_t w, int32_t channels,
+                         float inv_scale, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!x_nchw || !dy || !dw || !workspace || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t total = (int64_t)n * ((h + 1) / 2) * ((w + 1) / 2);
+  int blocks = 2048;
+  int ppb = (int)((total + blocks - 1) / blocks);
+  if (ppb < 64) ppb = 64;
+  blocks = (int)((total + ppb - 1) / ppb);
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_conv0_wgrad_partial, dim3(blocks), dim3(kThreads), 0, st, x_nchw, (const __half*)dy, n, h, w,
+                     channels, ppb, partials);
+  LFD_CHECK_LAUNCH();
+  const int count = 27 * channels;
+  hipLaunchKernelGGL(k_sum_partials, dim3((count + kThreads - 1) / kThreads), dim3(kThreads), 0, st, partials, blocks,
+                     count, inv_scale, 1, channels, 27, dw);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+}  // extern "C"

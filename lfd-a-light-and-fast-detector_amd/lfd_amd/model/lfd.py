@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine, ops, parallel
+from .. import engine, ops, parallel, train_engine
 from .utils import multiclass_nms  # noqa: F401  (kept importable like the reference module)
 
 __all__ = ['LFD']
@@ -151,7 +151,30 @@ class LFD(nn.Module):
         return ent[1]
 
     def _forward_train(self, x):
-        bb, neck, head = self._backbone, self._neck, self._head
+        """Train-mode forward (batch-statistic BatchNorm, autograd graph).  The backbone -- ~90 % of the FLOPs -- runs
+        forward AND backward on the hand-written kernels (train_engine.py, one autograd node); neck and head still
+        go through PyTorch-ROCm modules on the same parameters (their training kernels are the next round's row).
+        LFD_HIP_TRAIN=0 or an unsupported backbone configuration: the whole forward through PyTorch-ROCm autograd."""
+        neck, head = self._neck, self._head
+        if x.is_cuda and os.environ.get('LFD_HIP_TRAIN', '1') != '0' and train_engine.supported(self._backbone):
+            feats = list(train_engine.backbone_train_forward(self._backbone, x))
+        else:
+            feats = self._backbone_train_torch(x)
+        cls_l, reg_l = [], []
+        for i, f in enumerate(feats):
+            t = getattr(neck, 'neck%d' % i)(f)
+            t = getattr(head, 'head%d_merge_path' % i)(t)
+            c = getattr(head, 'head%d_classification_path' % i)(t)
+            r = getattr(head, 'head%d_regression_path' % i)(t)
+            if head._regression_loss_type in _UNION:
+                r = head._scales[i](r)
+            self._head_indexes_to_feature_map_sizes[i] = (c.shape[2], c.shape[3])
+            cls_l.append(c.permute(0, 2, 3, 1).reshape(c.shape[0], -1, c.shape[1]))
+            reg_l.append(r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, 4))
+        return torch.cat(cls_l, 1), torch.cat(reg_l, 1)
+
+    def _backbone_train_torch(self, x):
+        bb = self._backbone
         y = bb._stem(x)
         feats = []
         taps = [tuple(t) for t in bb._out_indices]
@@ -169,18 +192,7 @@ class LFD(nn.Module):
                 y = F.relu(o + ident)
                 if (i, j) in taps:
                     feats.append(y)
-        cls_l, reg_l = [], []
-        for i, f in enumerate(feats):
-            t = getattr(neck, 'neck%d' % i)(f)
-            t = getattr(head, 'head%d_merge_path' % i)(t)
-            c = getattr(head, 'head%d_classification_path' % i)(t)
-            r = getattr(head, 'head%d_regression_path' % i)(t)
-            if head._regression_loss_type in _UNION:
-                r = head._scales[i](r)
-            self._head_indexes_to_feature_map_sizes[i] = (c.shape[2], c.shape[3])
-            cls_l.append(c.permute(0, 2, 3, 1).reshape(c.shape[0], -1, c.shape[1]))
-            reg_l.append(r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, 4))
-        return torch.cat(cls_l, 1), torch.cat(reg_l, 1)
+        return feats
 
     # ------------------------------------------------------------------ point grid / targets
     def generate_point_coordinates(self, feature_map_sizes):

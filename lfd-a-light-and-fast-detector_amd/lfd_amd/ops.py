@@ -362,3 +362,110 @@ def conv2d_nhwc(x, w_packed, bias, cin, cout, ks, stride, relu, residual=None, t
                                         ptr(tail[0]) if tail else None, ptr(tail[1]) if tail else None,
                                         ptr(zero_line(x.device)), stream_ptr()), 'lfd_conv2d_nhwc_f16')
     return out
+
+
+# ------------------------------------------------------------------ training-mode conv stack (csrc/train.hip)
+_train_ws = {}
+
+
+def train_workspace(device):
+    key = (device.type, device.index)
+    ws = _train_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib().lfd_train_workspace_bytes(), dtype=torch.uint8, device=device)
+        _train_ws[key] = ws
+    return ws
+
+
+def _nhwc16(t, what):
+    require_cuda(t, what)
+    if t.dtype != torch.float16 or not t.is_contiguous() or t.dim() != 4:
+        raise RuntimeError('%s: contiguous fp16 NHWC tensor expected' % what)
+    return t
+
+
+def bn_train_stats(y, eps, momentum, running_mean=None, running_var=None):
+    """Batch statistics of y [N,H,W,C] -> float32[2*C] (mean, rstd); updates the running statistics in place."""
+    _nhwc16(y, 'bn_train_stats')
+    c = y.size(3)
+    stats = torch.empty(2 * c, dtype=torch.float32, device=y.device)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_bn_train_stats_f16(ptr(y), y.numel() // c, c, float(eps), float(momentum), ptr(running_mean),
+                                           ptr(running_var), ptr(ws), ws.numel(), ptr(stats), stream_ptr()),
+              'lfd_bn_train_stats_f16')
+    return stats
+
+
+def bn_train_apply(y, stats, gamma, beta, residual=None, relu=True):
+    _nhwc16(y, 'bn_train_apply')
+    c = y.size(3)
+    z = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_bn_train_apply_f16(ptr(y), y.numel() // c, c, ptr(stats), ptr(gamma), ptr(beta), ptr(residual),
+                                           int(bool(relu)), ptr(z), stream_ptr()), 'lfd_bn_train_apply_f16')
+    return z
+
+
+def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=False):
+    """-> (dy, g).  z=None: no ReLU behind the norm.  dgamma / dbeta: float32[C] outputs (unscaled)."""
+    _nhwc16(dz, 'bn_train_backward')
+    c = y.size(3)
+    dy = torch.empty_like(y)
+    g = torch.empty_like(y) if want_g else None
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_bn_train_bwd_f16(ptr(dz), ptr(y), ptr(z), y.numel() // c, c, ptr(stats), ptr(gamma),
+                                         float(inv_scale), ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta), ptr(dy), ptr(g),
+                                         stream_ptr()), 'lfd_bn_train_bwd_f16')
+    return dy, g
+
+
+def zero_insert2(t, ho, wo):
+    _nhwc16(t, 'zero_insert2')
+    n, hi, wi, c = t.shape
+    out = torch.empty((n, ho, wo, c), dtype=torch.float16, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib().lfd_zero_insert2_nhwc_f16(ptr(t), n, hi, wi, c, ho, wo, ptr(out), stream_ptr()),
+              'lfd_zero_insert2_nhwc_f16')
+    return out
+
+
+def conv_wgrad(x, dy, ks, stride, inv_scale, out=None):
+    """dW [cout,cin,ks,ks] fp32 of conv(x, W) with pad ks//2 given dL/dy (scaled by 1/inv_scale)."""
+    _nhwc16(x, 'conv_wgrad')
+    _nhwc16(dy, 'conv_wgrad')
+    n, h, w_, cin = x.shape
+    cout = dy.size(3)
+    if out is None:
+        out = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=x.device)
+    ws = train_workspace(x.device)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_conv_wgrad_nhwc_f16(ptr(x), ptr(dy), n, h, w_, cin, cout, ks, stride, float(inv_scale), ptr(ws),
+                                            ws.numel(), ptr(out), stream_ptr()), 'lfd_conv_wgrad_nhwc_f16')
+    return out
+
+
+def stem_conv0_train_fwd(x_nchw, weight):
+    require_cuda(x_nchw, 'stem_conv0_train_fwd')
+    x = x_nchw.contiguous().float()
+    n, _, h, w_ = x.shape
+    c = weight.size(0)
+    y = torch.empty((n, (h + 1) // 2, (w_ + 1) // 2, c), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_stem_conv0_train_fwd(ptr(x), n, h, w_, c, ptr(weight.detach().contiguous().float()), ptr(y),
+                                             stream_ptr()), 'lfd_stem_conv0_train_fwd')
+    return y
+
+
+def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None):
+    x = x_nchw.contiguous().float()
+    n, _, h, w_ = x.shape
+    c = dy.size(3)
+    if out is None:
+        out = torch.empty((c, 3, 3, 3), dtype=torch.float32, device=x.device)
+    ws = train_workspace(x.device)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_stem_conv0_wgrad(ptr(x), ptr(dy), n, h, w_, c, float(inv_scale), ptr(ws), ws.numel(), ptr(out),
+                                         stream_ptr()), 'lfd_stem_conv0_wgrad')
+    return out
