@@ -337,6 +337,17 @@ LFD_API int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, i
                          const float* stats, const float* gamma, float inv_scale, void* workspace,
                          size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
                          lfd_stream_t stream);
+/* GroupNorm of the head towers in training (nn.GroupNorm(groups, channels) + ReLU, lfd_head.py:97-105), groups of
+ * exactly 8 channels (128 / 16): stats[img][0][g] = mean, [1][g] = rstd over hw x 8 elements; apply; backward
+ * (dgamma / dbeta are `+=` when accumulate != 0: the towers are shared by all pyramid levels, lfd_head.py:67-82). */
+LFD_API int lfd_gn_train_stats_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, float eps,
+                           void* workspace, size_t workspace_bytes, float* stats, lfd_stream_t stream);
+LFD_API int lfd_gn_train_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, const float* stats,
+                           const float* gamma, const float* beta, int32_t relu, void* z, lfd_stream_t stream);
+LFD_API int lfd_gn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t n, int64_t hw, int32_t channels,
+                         int32_t groups, const float* stats, const float* gamma, float inv_scale, int32_t accumulate,
+                         void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy,
+                         lfd_stream_t stream);
 /* out[n, 2i, 2j, :] = in[n, i, j, :], zero elsewhere; ho in {2*hi-1, 2*hi}, wo likewise */
 LFD_API int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t channels, int32_t ho,
                               int32_t wo, void* out, lfd_stream_t stream);

@@ -817,6 +817,7 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     case 32 * 10000 + 3100 + 10: return launch_conv<32, 3, 1, 1, true, false>(a, st);
     case 32 * 10000 + 1100 + 10: return launch_conv<32, 1, 1, 1, true, false>(a, st);
     case 32 * 10000 + 1200 + 20: return launch_conv<32, 1, 2, 2, true, false>(a, st);
+    case 32 * 10000 + 1100 + 40: return launch_conv<32, 1, 1, 4, true, false>(a, st);   // data gradient of the head's output convs (<= 32 padded channels -> 128)
     default: return LFD_ERR_UNSUPPORTED;
   }
 }

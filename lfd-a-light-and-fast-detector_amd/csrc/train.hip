@@ -234,6 +234,174 @@ __global__ __launch_bounds__(kThreads) void k_zero_insert2(const __half* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GroupNorm in training (the head towers: nn.GroupNorm(16, 128) behind every 1x1 conv, lfd_head.py:97-105): statistics
+// per (image, group) over h*w pixels x 8 channels -- a group is exactly one 16-byte vector of an NHWC pixel.
+// grid = (blocks per image, images); a thread owns one group (the stride is a multiple of the group count).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_gn_stats_partial(const __half* __restrict__ y, int64_t vecs_per_img, int g,
+                                                              float* partials) {
+  __shared__ float red[kThreads][2];
+  const __half* yi = y + (size_t)blockIdx.y * vecs_per_img * 8;
+  float s = 0.f, ss = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
+    const h8 h = ld8(yi, v);
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)h[e];
+      s += f;
+      ss += f * f;
+    }
+  }
+  red[threadIdx.x][0] = s;
+  red[threadIdx.x][1] = ss;
+  __syncthreads();
+  if (threadIdx.x < 2 * g) {
+    const int q = threadIdx.x / g, cg = threadIdx.x - q * g;
+    float a = 0.f;
+    for (int t = cg; t < kThreads; t += g) a += red[t][q];
+    partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * g + threadIdx.x] = a;
+  }
+}
+
+// stats[img][0][g] = mean, stats[img][1][g] = rstd
+__global__ __launch_bounds__(64) void k_gn_stats_final(const float* partials, int nblocks, int g, double m, float eps,
+                                                      float* stats) {
+  const int cg = threadIdx.x;
+  if (cg >= g) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    const float* p = partials + ((size_t)blockIdx.x * nblocks + b) * 2 * g;
+    s += (double)p[cg];
+    ss += (double)p[g + cg];
+  }
+  const double mean = s / m;
+  double var = ss / m - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[(size_t)blockIdx.x * 2 * g + cg] = (float)mean;
+  stats[(size_t)blockIdx.x * 2 * g + g + cg] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict__ y, int64_t vecs_per_img, int g,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int relu,
+                                                      __half* __restrict__ z) {
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
+  const float mean = stats[(size_t)blockIdx.y * 2 * g + cg], rstd = stats[(size_t)blockIdx.y * 2 * g + g + cg];
+  float a[8], b[8];
+  for (int e = 0; e < 8; ++e) {
+    a[e] = gamma[cg * 8 + e] * rstd;
+    b[e] = beta[cg * 8 + e] - mean * a[e];
+  }
+  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
+    const h8 h = ld8(y, base + v);
+    h8 o;
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)h[e] * a[e] + b[e];
+      if (relu) f = fmaxf(f, 0.f);
+      o[e] = (_Float16)f;
+    }
+    st8(z, base + v, o);
+  }
+}
+
+// per (image, group): sum g*gamma, sum g*gamma*xhat;  per (image, channel): sum g*xhat, sum g
+__global__ __launch_bounds__(kThreads) void k_gn_bwd_partial(const __half* __restrict__ dz,
+                                                            const __half* __restrict__ y,
+                                                            const __half* __restrict__ z, int64_t vecs_per_img, int g,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, float* pgroup,
+                                                            float* pchan) {
+  __shared__ float red[kThreads][18];
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
+  const float mean = stats[(size_t)blockIdx.y * 2 * g + cg], rstd = stats[(size_t)blockIdx.y * 2 * g + g + cg];
+  float gam[8], acc[18];
+  for (int e = 0; e < 8; ++e) gam[e] = gamma[cg * 8 + e];
+  for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
+    const h8 d = ld8(dz, base + v), yy = ld8(y, base + v);
+    h8 zz;
+    if (z) zz = ld8(z, base + v);
+    for (int e = 0; e < 8; ++e) {
+      float gr = (float)d[e];
+      if (z && !((float)zz[e] > 0.f)) gr = 0.f;
+      const float xh = ((float)yy[e] - mean) * rstd;
+      acc[0] += gr * gam[e];
+      acc[1] += gr * gam[e] * xh;
+      acc[2 + e] += gr * xh;
+      acc[10 + e] += gr;
+    }
+  }
+  for (int i = 0; i < 18; ++i) red[threadIdx.x][i] = acc[i];
+  __syncthreads();
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int c = g * 8;
+  for (int o = threadIdx.x; o < 2 * g + 2 * c; o += kThreads) {
+    int col, grp;
+    if (o < 2 * g) {
+      col = o / g;             // 0: sum g*gamma, 1: sum g*gamma*xhat
+      grp = o - col * g;
+    } else {
+      const int q = (o - 2 * g) / c, ch = (o - 2 * g) - q * c;   // q 0: dgamma, 1: dbeta
+      grp = ch >> 3;
+      col = 2 + q * 8 + (ch & 7);
+    }
+    float a = 0.f;
+    for (int t = grp; t < kThreads; t += g) a += red[t][col];
+    if (o < 2 * g) pgroup[blk * 2 * g + o] = a;
+    else pchan[blk * 2 * c + (o - 2 * g)] = a;
+  }
+}
+
+// gsums[img][2][g] (per image), and dgamma / dbeta over all images (+= when accumulate: heads shared by the levels)
+__global__ __launch_bounds__(kThreads) void k_gn_bwd_final(const float* pgroup, const float* pchan, int n, int nblocks,
+                                                          int g, float inv_scale, int accumulate, float* gsums,
+                                                          float* dgamma, float* dbeta) {
+  const int c = g * 8;
+  for (int o = threadIdx.x; o < n * 2 * g; o += kThreads) {
+    const int img = o / (2 * g), j = o - img * 2 * g;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)pgroup[((size_t)img * nblocks + b) * 2 * g + j];
+    gsums[o] = (float)s;
+  }
+  for (int o = threadIdx.x; o < 2 * c; o += kThreads) {
+    double s = 0.0;
+    for (int b = 0; b < n * nblocks; ++b) s += (double)pchan[(size_t)b * 2 * c + o];
+    float* dst = o < c ? dgamma + o : dbeta + (o - c);
+    const float v = (float)(s * (double)inv_scale);
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_gn_bwd_apply(const __half* __restrict__ dz,
+                                                          const __half* __restrict__ y,
+                                                          const __half* __restrict__ z, int64_t vecs_per_img, int g,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ gsums, float inv_m,
+                                                          __half* __restrict__ dy) {
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
+  const float mean = stats[(size_t)blockIdx.y * 2 * g + cg], rstd = stats[(size_t)blockIdx.y * 2 * g + g + cg];
+  const float m1 = gsums[(size_t)blockIdx.y * 2 * g + cg] * inv_m, m2 = gsums[(size_t)blockIdx.y * 2 * g + g + cg] * inv_m;
+  float gam[8];
+  for (int e = 0; e < 8; ++e) gam[e] = gamma[cg * 8 + e];
+  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
+    const h8 d = ld8(dz, base + v), yy = ld8(y, base + v);
+    h8 zz, o;
+    if (z) zz = ld8(z, base + v);
+    for (int e = 0; e < 8; ++e) {
+      float gr = (float)d[e];
+      if (z && !((float)zz[e] > 0.f)) gr = 0.f;
+      const float xh = ((float)yy[e] - mean) * rstd;
+      o[e] = (_Float16)(rstd * (gr * gam[e] - m1 - xh * m2));
+    }
+    st8(dy, base + v, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // First stem conv in training: conv3x3 stride 2 pad 1, 3 -> c channels, NCHW fp32 image -> NHWC fp16 pre-norm output
 // (lfd_resnet.py:358 / :378 `nn.Conv2d(input_channels, stem_channels, 3, 2, 1, bias=False)`).  27 taps on the VALU in
 // fp32 (0.5 % of the network's FLOPs); one thread = one output pixel x 8 channels, weights [27][c] in LDS.
@@ -548,6 +716,70 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t p
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vecs, channels, stats, gamma, sums, (float)(1.0 / (double)pixels), (__half*)dy,
                      (__half*)g_out);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+static inline unsigned gn_blocks(int64_t vecs_per_img, int n) {
+  int64_t b = (vecs_per_img + kThreads - 1) / kThreads;
+  int64_t cap = 1024 / (n < 1 ? 1 : n);
+  if (cap < 1) cap = 1;
+  if (cap > 64) cap = 64;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+static inline bool gn_ok(int n, int64_t hw, int c, int g) {
+  return n >= 1 && n <= 1024 && hw >= 1 && g >= 1 && g <= 32 && (g & (g - 1)) == 0 && c == 8 * g;
+}
+
+int lfd_gn_train_stats_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, float eps,
+                           void* workspace, size_t workspace_bytes, float* stats, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!y || !stats || !workspace || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t vpi = hw * groups;
+  const unsigned b = gn_blocks(vpi, n);
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_gn_stats_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, partials);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gn_stats_final, dim3(n), dim3(64), 0, st, partials, (int)b, groups, (double)hw * 8.0, eps, stats);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_gn_train_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, const float* stats,
+                           const float* gamma, const float* beta, int32_t relu, void* z, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!y || !stats || !gamma || !beta || !z || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
+  const int64_t vpi = hw * groups;
+  hipLaunchKernelGGL(k_gn_apply, dim3(gn_blocks(vpi, n), n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, stats,
+                     gamma, beta, relu, (__half*)z);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_gn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t n, int64_t hw, int32_t channels,
+                         int32_t groups, const float* stats, const float* gamma, float inv_scale, int32_t accumulate,
+                         void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy,
+                         lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!dz || !y || !stats || !gamma || !dgamma || !dbeta || !dy || !workspace || !gn_ok(n, hw, channels, groups))
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t vpi = hw * groups;
+  const unsigned b = gn_blocks(vpi, n);
+  float* pgroup = reinterpret_cast<float*>(workspace);
+  float* pchan = pgroup + (size_t)1024 * 2 * 32;
+  float* gsums = pchan + (size_t)1024 * 2 * 256;
+  hipLaunchKernelGGL(k_gn_bwd_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, vpi, groups, stats, gamma, pgroup, pchan);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gn_bwd_final, dim3(1), dim3(kThreads), 0, st, pgroup, pchan, n, (int)b, groups, inv_scale,
+                     accumulate, gsums, dgamma, dbeta);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(b, n), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, vpi, groups, stats, gamma, gsums, (float)(1.0 / ((double)hw * 8.0)), (__half*)dy);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

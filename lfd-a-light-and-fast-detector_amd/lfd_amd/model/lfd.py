@@ -151,12 +151,19 @@ class LFD(nn.Module):
         return ent[1]
 
     def _forward_train(self, x):
-        """Train-mode forward (batch-statistic BatchNorm, autograd graph).  The backbone -- ~90 % of the FLOPs -- runs
-        forward AND backward on the hand-written kernels (train_engine.py, one autograd node); neck and head still
-        go through PyTorch-ROCm modules on the same parameters (their training kernels are the next round's row).
-        LFD_HIP_TRAIN=0 or an unsupported backbone configuration: the whole forward through PyTorch-ROCm autograd."""
+        """Train-mode forward (batch-statistic BatchNorm, per-image GroupNorm, autograd graph).  For the shipped
+        configurations the WHOLE network -- backbone, neck, head towers, output convs -- runs forward and backward on the
+        hand-written kernels as one autograd node (train_engine.NetworkTrainFunction); a supported backbone under an
+        unsupported neck / head runs as its own node with PyTorch-ROCm modules behind it.  LFD_HIP_TRAIN=0 or an
+        unsupported backbone: everything through PyTorch-ROCm autograd (same parameters, same semantics)."""
         neck, head = self._neck, self._head
-        if x.is_cuda and os.environ.get('LFD_HIP_TRAIN', '1') != '0' and train_engine.supported(self._backbone):
+        hip = x.is_cuda and os.environ.get('LFD_HIP_TRAIN', '1') != '0'
+        if hip and train_engine.network_supported(self):
+            cls, reg, sizes = train_engine.network_train_forward(self, x)
+            for i, sz in enumerate(sizes):
+                self._head_indexes_to_feature_map_sizes[i] = sz
+            return cls, reg
+        if hip and train_engine.supported(self._backbone):
             feats = list(train_engine.backbone_train_forward(self._backbone, x))
         else:
             feats = self._backbone_train_torch(x)

@@ -421,6 +421,39 @@ def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=F
     return dy, g
 
 
+def gn_train_stats(y, groups, eps):
+    _nhwc16(y, 'gn_train_stats')
+    n, h, w_, c = y.shape
+    stats = torch.empty(n * 2 * groups, dtype=torch.float32, device=y.device)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_gn_train_stats_f16(ptr(y), n, h * w_, c, groups, float(eps), ptr(ws), ws.numel(), ptr(stats),
+                                           stream_ptr()), 'lfd_gn_train_stats_f16')
+    return stats
+
+
+def gn_train_apply(y, groups, stats, gamma, beta, relu=True):
+    _nhwc16(y, 'gn_train_apply')
+    n, h, w_, c = y.shape
+    z = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_gn_train_apply_f16(ptr(y), n, h * w_, c, groups, ptr(stats), ptr(gamma), ptr(beta), int(bool(relu)),
+                                           ptr(z), stream_ptr()), 'lfd_gn_train_apply_f16')
+    return z
+
+
+def gn_train_backward(dz, y, z, groups, stats, gamma, inv_scale, dgamma, dbeta, accumulate=False):
+    _nhwc16(dz, 'gn_train_backward')
+    n, h, w_, c = y.shape
+    dy = torch.empty_like(y)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_gn_train_bwd_f16(ptr(dz), ptr(y), ptr(z), n, h * w_, c, groups, ptr(stats), ptr(gamma),
+                                         float(inv_scale), int(bool(accumulate)), ptr(ws), ws.numel(), ptr(dgamma),
+                                         ptr(dbeta), ptr(dy), stream_ptr()), 'lfd_gn_train_bwd_f16')
+    return dy
+
+
 def zero_insert2(t, ho, wo):
     _nhwc16(t, 'zero_insert2')
     n, hi, wi, c = t.shape

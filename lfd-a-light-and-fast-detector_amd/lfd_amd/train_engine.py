@@ -23,6 +23,16 @@ class _Unit(object):
     __slots__ = ('conv', 'norm', 'relu', 'src', 'res', 'dst', 'first')
 
 
+class _Out(object):
+    """Output convs of one pyramid level: cls conv1x1 (+bias) and reg conv1x1 (+bias) x Scale (lfd_head.py:107-111,
+    :176-180).  With a merged tower both read the same activation and run as ONE conv (rows concatenated, padded to 32)."""
+    __slots__ = ('level', 'convs', 'src', 'scale')
+
+
+def _conv_ok(m):
+    return m.in_channels == 3 or (m.in_channels in (32, 64, 128) and m.out_channels in (32, 64, 128))
+
+
 def supported(backbone):
     """The HIP training path covers BatchNorm2d + ReLU backbones with 32/64/128-channel convs, nothing frozen."""
     if backbone._norm_cfg is None or backbone._norm_cfg.get('type') != 'BatchNorm2d':
@@ -32,31 +42,50 @@ def supported(backbone):
     if backbone._input_channels != 3:
         return False
     for m in backbone.modules():
-        if isinstance(m, nn.Conv2d) and m.in_channels != 3:
-            if m.in_channels not in (32, 64, 128) or m.out_channels not in (32, 64, 128):
-                return False
+        if isinstance(m, nn.Conv2d) and not _conv_ok(m):
+            return False
         if isinstance(m, nn.BatchNorm2d) and (m.momentum is None or not m.affine or not m.track_running_stats):
             return False
     first = backbone._stem[0]
     return first.out_channels in (32, 64) and first.kernel_size == (3, 3) and first.stride == (2, 2)
 
 
-def build_units(backbone):
-    """-> (units, tap activation indices).  Activation 0 is the input image."""
-    units, n_act = [], 1
+def network_supported(model):
+    """+ SimpleNeck with BatchNorm2d, LFDHead with 1x1 convs and GroupNorm groups of 8 channels, <= 60 output channels."""
+    bb, neck, head = model._backbone, model._neck, model._head
+    if not supported(bb):
+        return False
+    if neck._norm_cfg is None or neck._norm_cfg.get('type') != 'BatchNorm2d' or neck._activation_cfg.get('type') != 'ReLU':
+        return False
+    if head._norm_cfg is None or head._norm_cfg.get('type') != 'GroupNorm' or head._activation_cfg.get('type') != 'ReLU':
+        return False
+    if head._conv_kernel_size != 1 or head._num_head_channels != 8 * head._norm_cfg.get('num_groups', 0):
+        return False
+    if neck._num_neck_channels not in (64, 128) or head._num_head_channels not in (64, 128):
+        return False
+    for m in head.modules():
+        if isinstance(m, nn.GroupNorm) and not m.affine:
+            return False
+    return head.num_cls_channels + 4 <= 64
 
-    def add(conv, norm, relu, src, res=None):
-        nonlocal n_act
+
+class _Builder(object):
+    def __init__(self):
+        self.units, self.n_act = [], 1
+
+    def add(self, conv, norm, relu, src, res=None):
         u = _Unit()
-        u.conv, u.norm, u.relu, u.src, u.res, u.dst, u.first = conv, norm, relu, src, res, n_act, src == 0
-        units.append(u)
-        n_act += 1
+        u.conv, u.norm, u.relu, u.src, u.res, u.dst, u.first = conv, norm, relu, src, res, self.n_act, src == 0
+        self.units.append(u)
+        self.n_act += 1
         return u.dst
 
+
+def _build_backbone(b, backbone):
     cur = 0
     mods = list(backbone._stem)
     for i in range(0, len(mods), 3):          # (conv, norm, activation) triples
-        cur = add(mods[i], mods[i + 1], True, cur)
+        cur = b.add(mods[i], mods[i + 1], True, cur)
     taps = {}
     want = [tuple(t) for t in backbone._out_indices]
     for si, nblk in enumerate(backbone._body_architecture):
@@ -64,22 +93,81 @@ def build_units(backbone):
             blk = getattr(backbone, 'stage%d' % si)[bi]
             ident = cur
             if blk._downsample is not None:
-                ident = add(blk._downsample[0], blk._downsample[1], False, cur)
+                ident = b.add(blk._downsample[0], blk._downsample[1], False, cur)
             a = cur
             for ci in range(1, blk.num_convs + 1):
                 last = ci == blk.num_convs
-                a = add(getattr(blk, '_conv%d' % ci), getattr(blk, '_norm%d' % ci), True, a, ident if last else None)
+                a = b.add(getattr(blk, '_conv%d' % ci), getattr(blk, '_norm%d' % ci), True, a, ident if last else None)
             cur = a
             if (si, bi) in want:
                 taps[(si, bi)] = cur
-    return units, [taps[t] for t in want]
+    return [taps[t] for t in want]
+
+
+def build_units(backbone):
+    """-> (units, tap activation indices).  Activation 0 is the input image."""
+    b = _Builder()
+    taps = _build_backbone(b, backbone)
+    return b.units, taps
+
+
+def build_network(model):
+    """-> (units, outs): backbone + neck + head towers as conv/norm/ReLU units, and the per-level output convs."""
+    b = _Builder()
+    taps = _build_backbone(b, model._backbone)
+    neck, head = model._neck, model._head
+    outs = []
+
+    def tower(path, cur):
+        mods = list(path)
+        n3 = len(mods) - (1 if mods and isinstance(mods[-1], nn.Conv2d) else 0)
+        for i in range(0, n3, 3):
+            cur = b.add(mods[i], mods[i + 1], True, cur)
+        return cur
+
+    for i, tap in enumerate(taps):
+        nk = getattr(neck, 'neck%d' % i)
+        cur = b.add(nk[0], nk[1], True, tap)
+        cur = tower(getattr(head, 'head%d_merge_path' % i), cur)
+        cpath, rpath = getattr(head, 'head%d_classification_path' % i), getattr(head, 'head%d_regression_path' % i)
+        csrc, rsrc = tower(cpath, cur), tower(rpath, cur)
+        scale = head._scales[i] if hasattr(head, '_scales') else None
+        if csrc == rsrc:
+            o = _Out()
+            o.level, o.convs, o.src, o.scale = i, [('cls', cpath[-1]), ('reg', rpath[-1])], csrc, scale
+            outs.append(o)
+        else:
+            for kind, conv, src in (('cls', cpath[-1], csrc), ('reg', rpath[-1], rsrc)):
+                o = _Out()
+                o.level, o.convs, o.src, o.scale = i, [(kind, conv)], src, scale
+                outs.append(o)
+    return b.units, outs
+
+
+def _unique(params):
+    seen, out = set(), []
+    for p in params:
+        if id(p) not in seen:
+            seen.add(id(p))
+            out.append(p)
+    return out
 
 
 def backbone_params(units):
     ps = []
     for u in units:
         ps += [u.conv.weight, u.norm.weight, u.norm.bias]
-    return ps
+    return _unique(ps)
+
+
+def network_params(units, outs):
+    ps = backbone_params(units)
+    for o in outs:
+        for _, conv in o.convs:
+            ps += [conv.weight, conv.bias]
+        if o.scale is not None:
+            ps.append(o.scale._scale)
+    return _unique(ps)
 
 
 def _dgrad_weight(w):
@@ -87,12 +175,21 @@ def _dgrad_weight(w):
     return ops.pack_conv_weight(w.detach().permute(1, 0, 2, 3).flip(2, 3))
 
 
+class _Zeros(object):
+    def __init__(self, dev):
+        self.dev, self.z = dev, {}
+
+    def __call__(self, n):
+        if n not in self.z:
+            self.z[n] = torch.zeros(n, dtype=torch.float32, device=self.dev)
+        return self.z[n]
+
+
 def forward(units, tap_ids, x):
-    """x: NCHW fp32 image batch (as LFD.forward receives it, lfd.py:511).  -> (tap tensors NHWC fp16, tape)."""
+    """x: NCHW fp32 image batch (as LFD.forward receives it, lfd.py:511).  -> (requested activations NHWC fp16, saved)."""
     acts = {0: x}
     tape = []
-    dev = x.device
-    zero_bias = {}
+    zeros = _Zeros(x.device)
     for u in units:
         conv, norm = u.conv, u.norm
         xin = acts[u.src]
@@ -101,33 +198,51 @@ def forward(units, tap_ids, x):
             y = ops.stem_conv0_train_fwd(xin, conv.weight)
         else:
             cout = conv.out_channels
-            if cout not in zero_bias:
-                zero_bias[cout] = torch.zeros(cout, dtype=torch.float32, device=dev)
-            y = ops.conv2d_nhwc(xin, ops.pack_conv_weight(conv.weight), zero_bias[cout], conv.in_channels, cout, ks, st,
-                                False)
-        stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
-        z = ops.bn_train_apply(y, stats, norm.weight.detach(), norm.bias.detach(),
-                               acts[u.res] if u.res is not None else None, u.relu)
+            y = ops.conv2d_nhwc(xin, ops.pack_conv_weight(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, False)
+        if isinstance(norm, nn.GroupNorm):
+            stats = ops.gn_train_stats(y, norm.num_groups, norm.eps)
+            z = ops.gn_train_apply(y, norm.num_groups, stats, norm.weight.detach(), norm.bias.detach(), u.relu)
+        else:
+            stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
+            z = ops.bn_train_apply(y, stats, norm.weight.detach(), norm.bias.detach(),
+                                   acts[u.res] if u.res is not None else None, u.relu)
         acts[u.dst] = z
         tape.append((y, stats))
-    torch._foreach_add_([u.norm.num_batches_tracked for u in units], 1)
+    torch._foreach_add_([u.norm.num_batches_tracked for u in units if isinstance(u.norm, nn.BatchNorm2d)], 1)
     return [acts[t] for t in tap_ids], (acts, tape)
 
 
-def backward(units, tap_ids, saved, tap_grads, scale=LOSS_SCALE, trace=None):
-    """tap_grads: dL/dtap, NHWC fp16 already multiplied by `scale` (None for unused taps).
-    -> list of fp32 parameter gradients in backbone_params(units) order (None where nothing flowed).
+class _GradStore(object):
+    """fp32 parameter gradients by parameter identity; shared modules (the head towers of all levels) accumulate."""
+
+    def __init__(self):
+        self.g = {}
+
+    def add(self, p, grad):
+        k = id(p)
+        self.g[k] = grad if k not in self.g else self.g[k] + grad
+
+    def buffer(self, p):
+        """zero-initialised gradient buffer the kernels accumulate into (GroupNorm dgamma / dbeta)"""
+        k = id(p)
+        if k not in self.g:
+            self.g[k] = torch.zeros_like(p, dtype=torch.float32)
+        return self.g[k]
+
+    def get(self, p):
+        return self.g.get(id(p))
+
+
+def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
+    """grads: {activation index: dL/dact NHWC fp16 multiplied by `scale`} for the activations consumed outside the units
+    (taps for the backbone alone, tower outputs for the whole network).  -> _GradStore of fp32 parameter gradients.
     trace: optional list that receives the per-unit tensors (tests check every unit against PyTorch given the same
     inputs)."""
     acts, tape = saved
     inv = 1.0 / scale
-    grads = {}
-    for t, g in zip(tap_ids, tap_grads):
-        if g is not None:
-            grads[t] = g if t not in grads else grads[t] + g
-    out = [None] * (3 * len(units))
-    dev = acts[0].device
-    zero_bias = {}
+    grads = dict(grads)
+    store = store if store is not None else _GradStore()
+    zeros = _Zeros(acts[0].device)
     for ui in range(len(units) - 1, -1, -1):
         u = units[ui]
         dz = grads.pop(u.dst, None)
@@ -136,9 +251,16 @@ def backward(units, tap_ids, saved, tap_grads, scale=LOSS_SCALE, trace=None):
         conv, norm = u.conv, u.norm
         y, stats = tape[ui]
         z = acts[u.dst] if u.relu else None
-        dgamma = torch.empty_like(norm.weight, dtype=torch.float32)
-        dbeta = torch.empty_like(norm.bias, dtype=torch.float32)
-        dy, g = ops.bn_train_backward(dz, y, z, stats, norm.weight.detach(), inv, dgamma, dbeta, want_g=u.res is not None)
+        g = None
+        if isinstance(norm, nn.GroupNorm):
+            dgamma, dbeta = store.buffer(norm.weight), store.buffer(norm.bias)
+            dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, dgamma, dbeta, True)
+        else:
+            dgamma = torch.empty_like(norm.weight, dtype=torch.float32)
+            dbeta = torch.empty_like(norm.bias, dtype=torch.float32)
+            dy, g = ops.bn_train_backward(dz, y, z, stats, norm.weight.detach(), inv, dgamma, dbeta, want_g=u.res is not None)
+            store.add(norm.weight, dgamma)
+            store.add(norm.bias, dbeta)
         if u.res is not None:
             grads[u.res] = g if u.res not in grads else grads[u.res] + g
         xin = acts[u.src]
@@ -151,21 +273,96 @@ def backward(units, tap_ids, saved, tap_grads, scale=LOSS_SCALE, trace=None):
             if st == 2:
                 dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
             cin = conv.in_channels
-            if cin not in zero_bias:
-                zero_bias[cin] = torch.zeros(cin, dtype=torch.float32, device=dev)
-            grads[u.src] = ops.conv2d_nhwc(dy, _dgrad_weight(conv.weight), zero_bias[cin], conv.out_channels, cin, ks, 1,
+            grads[u.src] = ops.conv2d_nhwc(dy, _dgrad_weight(conv.weight), zeros(cin), conv.out_channels, cin, ks, 1,
                                            False, residual=grads.get(u.src))
             if rec is not None:
                 rec['dx'] = grads[u.src]
+        store.add(conv.weight, dw)
         if rec is not None:
             rec.update(dw=dw, dgamma=dgamma, dbeta=dbeta)
             trace.append(rec)
-        out[3 * ui], out[3 * ui + 1], out[3 * ui + 2] = dw, dgamma, dbeta
-    return out
+    return store
+
+
+# ---------------------------------------------------------------------------------------------- output convs
+def _out_weight(o):
+    """rows of the level's output convs concatenated and zero-padded to 64 (the narrowest 1x1 conv shape instantiated
+    for 128 input channels, forward and data gradient): [64, C, 1, 1], bias [64]"""
+    w = torch.cat([c.weight.detach() for _, c in o.convs], 0)
+    bias = torch.cat([c.bias.detach() for _, c in o.convs], 0)
+    rows = -(-w.size(0) // 64) * 64
+    wp = torch.zeros((rows,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+    wp[:w.size(0)] = w
+    bp = torch.zeros(rows, dtype=torch.float32, device=w.device)
+    bp[:bias.numel()] = bias
+    return wp, bp
+
+
+def outputs_forward(outs, acts, num_levels):
+    """-> (cls [N,P,C'], reg [N,P,4]) fp32 in the level-concatenated layout of LFD.forward (lfd.py:526-542), sizes per level,
+    and what the backward needs."""
+    cls_l, reg_l, sizes, saved = [None] * num_levels, [None] * num_levels, [None] * num_levels, []
+    for o in outs:
+        x = acts[o.src]
+        n, h, w_, c = x.shape
+        wp, bp = _out_weight(o)
+        y = ops.conv2d_nhwc(x, ops.pack_conv_weight(wp), bp, c, wp.size(0), 1, 1, False).view(n, h * w_, wp.size(0))
+        r0 = 0
+        raw = None
+        for kind, conv in o.convs:
+            t = y[..., r0:r0 + conv.out_channels].float()
+            r0 += conv.out_channels
+            if kind == 'cls':
+                cls_l[o.level] = t
+            else:
+                raw = t
+                reg_l[o.level] = t * o.scale._scale.detach() if o.scale is not None else t
+        sizes[o.level] = (h, w_)
+        saved.append((wp, raw))
+    return torch.cat(cls_l, 1), torch.cat(reg_l, 1), sizes, saved
+
+
+def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=LOSS_SCALE):
+    """-> {activation index: scaled fp16 gradient} for the tower outputs; parameter gradients go to `store`."""
+    grads = {}
+    inv = 1.0 / scale
+    starts, p = [], 0
+    for h, w_ in sizes:
+        starts.append(p)
+        p += h * w_
+    zeros = _Zeros(dcls.device)
+    for o, (wp, raw) in zip(outs, saved):
+        x = acts[o.src]
+        n, h, w_, c = x.shape
+        lo, hi = starts[o.level], starts[o.level] + h * w_
+        parts = []
+        for kind, conv in o.convs:
+            if kind == 'cls':
+                d = dcls[:, lo:hi]
+            else:
+                d = dreg[:, lo:hi]
+                if o.scale is not None:
+                    store.add(o.scale._scale, (d * raw).sum())
+                    d = d * o.scale._scale.detach()
+            store.add(conv.bias, d.sum((0, 1)))
+            parts.append(d)
+        rows = wp.size(0)
+        dy = torch.zeros((n, h, w_, rows), dtype=torch.float16, device=x.device)
+        r0 = 0
+        for d in parts:
+            dy.view(n, h * w_, rows)[..., r0:r0 + d.size(2)] = (d * scale).half()
+            r0 += d.size(2)
+        dw = ops.conv_wgrad(x, dy, 1, 1, inv)
+        r0 = 0
+        for _, conv in o.convs:
+            store.add(conv.weight, dw[r0:r0 + conv.out_channels])
+            r0 += conv.out_channels
+        grads[o.src] = ops.conv2d_nhwc(dy, _dgrad_weight(wp), zeros(c), rows, c, 1, 1, False, residual=grads.get(o.src))
+    return grads
 
 
 class BackboneTrainFunction(torch.autograd.Function):
-    """taps (NCHW fp32, what the torch neck consumes) = backbone(x); one autograd node for the whole backbone."""
+    """taps (NCHW fp32) = backbone(x) as one autograd node (used when neck / head are not covered by network_supported)."""
 
     @staticmethod
     def forward(ctx, plan, x, *params):
@@ -177,10 +374,43 @@ class BackboneTrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *tap_grads):
         units, tap_ids = ctx.plan
-        gs = [None if g is None else (g * LOSS_SCALE).permute(0, 2, 3, 1).contiguous().half() for g in tap_grads]
-        pg = backward(units, tap_ids, ctx.saved, gs)
+        grads = {}
+        for t, g in zip(tap_ids, tap_grads):
+            if g is not None:
+                g16 = (g * LOSS_SCALE).permute(0, 2, 3, 1).contiguous().half()
+                grads[t] = g16 if t not in grads else grads[t] + g16
+        store = backward(units, ctx.saved, grads)
         ctx.saved = None
-        return (None, None) + tuple(pg)
+        return (None, None) + tuple(store.get(p) for p in backbone_params(units))
+
+
+class NetworkTrainFunction(torch.autograd.Function):
+    """(cls [N,P,C'], reg [N,P,4]) = LFD.forward(x) in train mode as ONE autograd node: every conv / norm / ReLU of
+    backbone, neck and head runs forward and backward on the hand-written kernels."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        units, outs, num_levels = plan
+        _, saved = forward(units, [], x)
+        cls, reg, sizes, osaved = outputs_forward(outs, saved[0], num_levels)
+        ctx.plan, ctx.saved, ctx.osaved, ctx.sizes = plan, saved, osaved, sizes
+        ctx.shapes = (cls.shape, reg.shape)
+        NetworkTrainFunction.last_sizes = sizes
+        return cls, reg
+
+    @staticmethod
+    def backward(ctx, dcls, dreg):
+        units, outs, _ = ctx.plan
+        store = _GradStore()
+        dev = ctx.saved[0][0].device
+        if dcls is None:
+            dcls = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+        if dreg is None:
+            dreg = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
+        grads = outputs_backward(outs, ctx.saved[0], ctx.osaved, ctx.sizes, dcls.contiguous(), dreg.contiguous(), store)
+        backward(units, ctx.saved, grads, store=store)
+        ctx.saved = ctx.osaved = None
+        return (None, None) + tuple(store.get(p) for p in network_params(units, outs))
 
 
 def backbone_train_forward(backbone, x):
@@ -189,3 +419,14 @@ def backbone_train_forward(backbone, x):
         plan = build_units(backbone)
         backbone.__dict__['_lfd_train_plan'] = plan
     return BackboneTrainFunction.apply(plan, x, *backbone_params(plan[0]))
+
+
+def network_train_forward(model, x):
+    """-> (cls, reg, [(h, w)] per level)"""
+    plan = model.__dict__.get('_lfd_train_plan')
+    if plan is None:
+        units, outs = build_network(model)
+        plan = (units, outs, model._num_heads)
+        model.__dict__['_lfd_train_plan'] = plan
+    cls, reg = NetworkTrainFunction.apply(plan, x, *network_params(plan[0], plan[1]))
+    return cls, reg, NetworkTrainFunction.last_sizes
