@@ -319,8 +319,15 @@ LFD_API int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t
  * lfd_conv_wgrad_nhwc_f16 + lfd_conv2d_nhwc_f16 on the transposed, tap-flipped weights (stride 2:
  * after lfd_zero_insert2_nhwc_f16).  channels: power of two in [8, 256].  Every reduction is per-block
  * partials + a fixed-order final stage (deterministic).  `workspace`: lfd_train_workspace_bytes().
+ * Parameter-gradient outputs (dgamma, dbeta, dw) are `+=` when `accumulate` != 0 -- they can be the
+ * zeroed .grad buffers themselves (autograd's AccumulateGrad semantics without a temporary + add per tensor).
  */
 LFD_API size_t lfd_train_workspace_bytes(void);
+/* nn.Conv2d.weight [cout, cin, ks, ks] fp32 -> the fp16 MFMA fragment order lfd_conv2d_nhwc_f16 consumes
+ * (lfd_conv_packed_weight_halfs).  mode 0: the forward conv, rows >= rows_valid zero-filled (cout must already be the
+ * padded row count, multiple of 32); mode 1: the data-gradient conv (channel roles swapped, taps flipped). */
+LFD_API int lfd_pack_conv_weight_train_f16(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ks, int32_t mode,
+                                   int32_t rows_valid, void* packed, lfd_stream_t stream);
 /* batch statistics of y [pixels, channels]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(biased var + eps)
  * (F.batch_norm training=True); running_mean / running_var (nullable) are updated with `momentum` and
  * the unbiased variance like nn.BatchNorm2d. */
@@ -334,7 +341,7 @@ LFD_API int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channe
  * dbeta = inv_scale * sum g, dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)); g_out (nullable)
  * receives g, the gradient of the residual branch. */
 LFD_API int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t pixels, int32_t channels,
-                         const float* stats, const float* gamma, float inv_scale, void* workspace,
+                         const float* stats, const float* gamma, float inv_scale, int32_t accumulate, void* workspace,
                          size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
                          lfd_stream_t stream);
 /* GroupNorm of the head towers in training (nn.GroupNorm(groups, channels) + ReLU, lfd_head.py:97-105), groups of
@@ -354,14 +361,14 @@ LFD_API int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int
 /* dW [cout, cin, ks, ks] fp32 (OIHW, the nn.Conv2d.weight layout) = inv_scale * sum over pixels of
  * dy (x) x for a conv with pad ks/2; x [n,h,w,cin], dy [n,ho,wo,cout]; cin, cout multiples of 8, <= 128. */
 LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                            int32_t ks, int32_t stride, float inv_scale, void* workspace, size_t workspace_bytes,
-                            float* dw, lfd_stream_t stream);
+                            int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
+                            size_t workspace_bytes, float* dw, lfd_stream_t stream);
 /* first stem conv (3 -> channels, 3x3 stride 2 pad 1, lfd_resnet.py:358,:378) on the NCHW fp32 image batch:
  * forward -> y NHWC fp16 (pre-norm), and its weight gradient (OIHW fp32); channels in {32, 64} */
 LFD_API int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
                              const float* weight_oihw, void* y, lfd_stream_t stream);
 LFD_API int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t h, int32_t w, int32_t channels,
-                         float inv_scale, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream);
+                         float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neck + head of ALL pyramid levels.  Replaces SimpleNeck.forward (simple_neck.py:67-74),

@@ -129,14 +129,14 @@ __global__ __launch_bounds__(kThreads) void k_loss_partial(lfd_loss_desc_t d, co
   }
 }
 
-// fixed-order reduction of the block partials: thread k sums component k
-__global__ __launch_bounds__(64) void k_loss_sums(const double* partials, int nblocks, double* sums) {
-  const int k = threadIdx.x;
-  if (k >= kSums) return;
+// reduction of the block partials: wave k sums component k (lanes stride over the blocks, fixed butterfly)
+__global__ __launch_bounds__(64 * kSums) void k_loss_sums(const double* partials, int nblocks, double* sums) {
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0.0;
   if (k < 5)
-    for (int i = 0; i < nblocks; ++i) s += partials[(size_t)i * kSums + k];
-  sums[k] = s;
+    for (int i = lane; i < nblocks; i += 64) s += partials[(size_t)i * kSums + k];
+  s = wave_sum_d(s);
+  if (lane == 0) sums[k] = s;
 }
 
 // out: [0] classification loss, [1] regression loss, [2] their sum, [3] global n_pos, [4] avg_factor cls,
@@ -256,7 +256,7 @@ int lfd_get_loss_sums_f32(const lfd_loss_desc_t* d, const float* pred_cls, const
   hipLaunchKernelGGL(k_loss_partial, dim3(g), dim3(kThreads), 0, st, *d, pred_cls, pred_reg, cls_targets,
                      reg_targets, (double*)workspace);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(64), 0, st, (const double*)workspace, (int)g, sums);
+  hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(64 * kSums), 0, st, (const double*)workspace, (int)g, sums);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

@@ -40,11 +40,45 @@ __device__ __forceinline__ void st8(__half* p, int64_t vec, h8 h) {
   reinterpret_cast<uint4*>(p)[vec] = v.u;
 }
 
+// nn.Conv2d weight [cout][cin][ks][ks] fp32 -> MFMA fragment order of conv.hip, fp16:
+//   out[ct][kstep][lane][e],  lane = 32*half + co_l,  kstep = (r*ks + s)*(cin/16) + q,  ci = 16q + 8*half + e.
+// mode 1 packs the data-gradient conv instead: W'[co'][ci'][r][s] = W[ci'][co'][ks-1-r][ks-1-s] (co' over the forward
+// conv's input channels).  Rows >= rows_valid of the LOGICAL conv are zero (output convs padded to 64 rows).
+__global__ __launch_bounds__(kThreads) void k_pack_weight(const float* __restrict__ w, int cout, int cin, int ks,
+                                                         int mode, int rows_valid, __half* __restrict__ out) {
+  const int lc = mode ? cin : cout, li = mode ? cout : cin;     // logical conv: lc output rows, li input channels
+  const int nq = li / 16, nk = ks * ks * nq;
+  const int total = (lc / 32) * nk * 64;
+  const int v = blockIdx.x * kThreads + threadIdx.x;
+  if (v >= total) return;
+  const int lane = v & 63, kstep = (v >> 6) % nk, ct = (v >> 6) / nk;
+  const int half = lane >> 5, co = ct * 32 + (lane & 31);
+  const int q = kstep % nq, tap = kstep / nq, r = tap / ks, sx = tap - r * ks;
+  h8 o;
+  for (int e = 0; e < 8; ++e) {
+    const int ci = 16 * q + 8 * half + e;
+    float f = 0.f;
+    if (co < rows_valid) {
+      if (mode == 0) f = w[(((size_t)co * cin + ci) * ks + r) * ks + sx];
+      else f = w[(((size_t)ci * cin + co) * ks + (ks - 1 - r)) * ks + (ks - 1 - sx)];
+    }
+    o[e] = (_Float16)f;
+  }
+  st8(out, v, o);
+}
+
 inline unsigned grid_for_vecs(int64_t vecs) {
   int64_t b = (vecs + kThreads - 1) / kThreads;
   if (b > kMaxBlocks) b = kMaxBlocks;
   if (b < 1) b = 1;
   return (unsigned)b;
+}
+
+// fixed-pattern butterfly: every lane ends with the same, order-independent-of-scheduling sum
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
 }
 
 inline bool channels_ok(int c) { return c >= 8 && c <= kMaxC && (c & (c - 1)) == 0; }
@@ -87,25 +121,27 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats_partial(const __half* __r
 
 // stats[0][c] = mean, stats[1][c] = 1/sqrt(var + eps) (biased variance, as F.batch_norm normalises in training);
 // running_mean / running_var updated with `momentum` and the unbiased variance (torch BatchNorm semantics)
-__global__ __launch_bounds__(kThreads) void k_bn_stats_final(const float* partials, int nblocks, int c, double m,
-                                                            float eps, float momentum, float* running_mean,
-                                                            float* running_var, float* stats) {
-  for (int ch = threadIdx.x; ch < c; ch += kThreads) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-      s += (double)partials[(size_t)b * 2 * c + ch];
-      ss += (double)partials[(size_t)b * 2 * c + c + ch];
-    }
-    const double mean = s / m;
-    double var = ss / m - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[ch] = (float)mean;
-    stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-      const double unb = m > 1.0 ? var * m / (m - 1.0) : var;
-      running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
-      running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
-    }
+__global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, int nblocks, int c, double m,
+                                                      float eps, float momentum, float* running_mean,
+                                                      float* running_var, float* stats) {
+  const int ch = blockIdx.x;           // one wave per channel: lanes stride over the block partials
+  double s = 0.0, ss = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
+    s += (double)partials[(size_t)b * 2 * c + ch];
+    ss += (double)partials[(size_t)b * 2 * c + c + ch];
+  }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if (threadIdx.x != 0) return;
+  const double mean = s / m;
+  double var = ss / m - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[ch] = (float)mean;
+  stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = m > 1.0 ? var * m / (m - 1.0) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
+    running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
   }
 }
 
@@ -165,19 +201,21 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
 }
 
 // sums[0][c] = sum g (= dbeta * scale), sums[1][c] = sum g*xhat (= dgamma * scale); parameter gradients unscaled
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_final(const float* partials, int nblocks, int c, float inv_scale,
-                                                          float* sums, float* dgamma, float* dbeta) {
-  for (int ch = threadIdx.x; ch < c; ch += kThreads) {
-    double s = 0.0, sx = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-      s += (double)partials[(size_t)b * 2 * c + ch];
-      sx += (double)partials[(size_t)b * 2 * c + c + ch];
-    }
-    sums[ch] = (float)s;
-    sums[c + ch] = (float)sx;
-    if (dbeta) dbeta[ch] = (float)(s * (double)inv_scale);
-    if (dgamma) dgamma[ch] = (float)(sx * (double)inv_scale);
+__global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int nblocks, int c, float inv_scale,
+                                                    int accumulate, float* sums, float* dgamma, float* dbeta) {
+  const int ch = blockIdx.x;
+  double s = 0.0, sx = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
+    s += (double)partials[(size_t)b * 2 * c + ch];
+    sx += (double)partials[(size_t)b * 2 * c + c + ch];
   }
+  s = wave_sum_d(s);
+  sx = wave_sum_d(sx);
+  if (threadIdx.x != 0) return;
+  sums[ch] = (float)s;
+  sums[c + ch] = (float)sx;
+  if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)(s * (double)inv_scale);
+  if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)(sx * (double)inv_scale);
 }
 
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restrict__ dz,
@@ -355,22 +393,26 @@ __global__ __launch_bounds__(kThreads) void k_gn_bwd_partial(const __half* __res
 }
 
 // gsums[img][2][g] (per image), and dgamma / dbeta over all images (+= when accumulate: heads shared by the levels)
-__global__ __launch_bounds__(kThreads) void k_gn_bwd_final(const float* pgroup, const float* pchan, int n, int nblocks,
-                                                          int g, float inv_scale, int accumulate, float* gsums,
-                                                          float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(64) void k_gn_bwd_final(const float* pgroup, const float* pchan, int n, int nblocks,
+                                                    int g, float inv_scale, int accumulate, float* gsums,
+                                                    float* dgamma, float* dbeta) {
   const int c = g * 8;
-  for (int o = threadIdx.x; o < n * 2 * g; o += kThreads) {
+  const int o = blockIdx.x;              // one wave per output: [0, n*2g) group sums, then 2c channel sums
+  double s = 0.0;
+  if (o < n * 2 * g) {
     const int img = o / (2 * g), j = o - img * 2 * g;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)pgroup[((size_t)img * nblocks + b) * 2 * g + j];
-    gsums[o] = (float)s;
-  }
-  for (int o = threadIdx.x; o < 2 * c; o += kThreads) {
-    double s = 0.0;
-    for (int b = 0; b < n * nblocks; ++b) s += (double)pchan[(size_t)b * 2 * c + o];
-    float* dst = o < c ? dgamma + o : dbeta + (o - c);
-    const float v = (float)(s * (double)inv_scale);
-    *dst = accumulate ? *dst + v : v;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)pgroup[((size_t)img * nblocks + b) * 2 * g + j];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) gsums[o] = (float)s;
+  } else {
+    const int j = o - n * 2 * g;
+    for (int b = threadIdx.x; b < n * nblocks; b += 64) s += (double)pchan[(size_t)b * 2 * c + j];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) {
+      float* dst = j < c ? dgamma + j : dbeta + (j - c);
+      const float v = (float)(s * (double)inv_scale);
+      *dst = accumulate ? *dst + v : v;
+    }
   }
 }
 
@@ -484,22 +526,22 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_partial(const float* _
   }
 }
 
-// generic fixed-order sum of partial[block][count] -> out[perm(i)] * inv_scale; perm: 0 identity,
+// generic sum of partial[block][count] -> out[perm(i)] * inv_scale, one wave per output; perm: 0 identity,
 // 1: i = t*c + co -> co*taps + t (OIHW of the first conv)
-__global__ __launch_bounds__(kThreads) void k_sum_partials(const float* partials, int nblocks, int count, float inv_scale,
-                                                          int perm, int c, int taps, float* out) {
-  const int i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= count) return;
+__global__ __launch_bounds__(64) void k_sum_partials(const float* partials, int nblocks, int count, float inv_scale,
+                                                    int perm, int c, int taps, int accumulate, float* out) {
+  const int i = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partials[(size_t)b * count + i];
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)partials[(size_t)b * count + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x != 0) return;
   int o = i;
   if (perm == 1) {
     const int t = i / c, co = i - t * c;
     o = co * taps + t;
   }
-  out[o] = (float)(s * (double)inv_scale);
+  out[o] = (accumulate ? out[o] : 0.f) + (float)(s * (double)inv_scale);
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight gradient of a conv (ks 1|3, stride 1|2, pad ks/2) on MFMA:
@@ -623,18 +665,24 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 
 // dW (fp32, OIHW [cout][cin][ks][ks]) = inv_scale * sum over workgroups of the partials
 __global__ __launch_bounds__(kThreads) void k_wgrad_final(const float* partials, int nwg, int nblk, int cin, int cout,
-                                                         int taps, float inv_scale, float* dw) {
+                                                         int taps, float inv_scale, int accumulate, float* dw) {
+  __shared__ double red[4][64];
   const int per_blk = taps * 64 * 64;
-  const int i = blockIdx.x * kThreads + threadIdx.x;   // over nblk * per_blk
-  if (i >= nblk * per_blk) return;
-  const int blk = i / per_blk, j = i - blk * per_blk;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);   // 64 consecutive outputs per block, 4 slices of the wg loop
+  const int slice = threadIdx.x >> 6;
+  const int blk = i / per_blk, j = i - blk * per_blk;    // per_blk is a multiple of 64: a block never straddles
+  double s = 0.0;
+  for (int g = slice; g < nwg; g += 4) s += (double)partials[((size_t)g * nblk + blk) * per_blk + j];
+  red[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice != 0) return;
+  s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   const int t = j / 4096, co_l = (j >> 6) & 63, ci_l = j & 63;
   const int nib = (cin + 63) / 64;
   const int co = (blk / nib) * 64 + co_l, ci = (blk % nib) * 64 + ci_l;
   if (co >= cout || ci >= cin) return;
-  double s = 0.0;
-  for (int g = 0; g < nwg; ++g) s += (double)partials[((size_t)g * nblk + blk) * per_blk + j];
-  dw[((size_t)co * cin + ci) * taps + t] = (float)(s * (double)inv_scale);
+  float* dst = dw + ((size_t)co * cin + ci) * taps + t;
+  *dst = (accumulate ? *dst : 0.f) + (float)(s * (double)inv_scale);
 }
 
 template <int KS, int S>
@@ -666,6 +714,21 @@ size_t lfd_train_workspace_bytes(void) {
   return (size_t)kWgradMaxWg * 4 * 9 * 64 * 64 * sizeof(float) + 4096;
 }
 
+int lfd_pack_conv_weight_train_f16(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ks, int32_t mode,
+                                   int32_t rows_valid, void* packed, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!weight_oihw || !packed || (ks != 1 && ks != 3) || (mode != 0 && mode != 1)) return LFD_ERR_INVALID_ARGUMENT;
+  const int lc = mode ? cin : cout, li = mode ? cout : cin;
+  if (lc < 32 || (lc & 31) || li < 16 || (li & 15)) return LFD_ERR_INVALID_ARGUMENT;
+  if (mode == 1 && rows_valid != lc) return LFD_ERR_INVALID_ARGUMENT;   // padding only for forward packs
+  if (mode == 0 && (rows_valid < 1 || rows_valid > lc)) return LFD_ERR_INVALID_ARGUMENT;
+  const int total = (lc / 32) * ks * ks * (li / 16) * 64;
+  hipLaunchKernelGGL(k_pack_weight, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, weight_oihw, cout, cin,
+                     ks, mode, rows_valid, (__half*)packed);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
 int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channels, float eps, float momentum,
                            float* running_mean, float* running_var, void* workspace, size_t workspace_bytes,
                            float* stats, lfd_stream_t stream) {
@@ -678,7 +741,7 @@ int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channels, floa
   float* partials = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(k_bn_stats_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)y, vecs, channels, partials);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_stats_final, dim3(1), dim3(kThreads), 0, st, partials, (int)g, channels, (double)pixels, eps,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, (double)pixels, eps,
                      momentum, running_mean, running_var, stats);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
@@ -696,7 +759,7 @@ int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, cons
 }
 
 int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t pixels, int32_t channels,
-                         const float* stats, const float* gamma, float inv_scale, void* workspace,
+                         const float* stats, const float* gamma, float inv_scale, int32_t accumulate, void* workspace,
                          size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
                          lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -710,8 +773,8 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t p
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vecs, channels, stats, partials);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(kThreads), 0, st, partials, (int)g, channels, inv_scale, sums, dgamma,
-                     dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
+                     dgamma, dbeta);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vecs, channels, stats, gamma, sums, (float)(1.0 / (double)pixels), (__half*)dy,
@@ -775,7 +838,7 @@ int lfd_gn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t n
   hipLaunchKernelGGL(k_gn_bwd_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vpi, groups, stats, gamma, pgroup, pchan);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_gn_bwd_final, dim3(1), dim3(kThreads), 0, st, pgroup, pchan, n, (int)b, groups, inv_scale,
+  hipLaunchKernelGGL(k_gn_bwd_final, dim3(n * 2 * groups + 2 * channels), dim3(64), 0, st, pgroup, pchan, n, (int)b, groups, inv_scale,
                      accumulate, gsums, dgamma, dbeta);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_gn_bwd_apply, dim3(b, n), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
@@ -798,8 +861,8 @@ int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi,
 }
 
 int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                            int32_t ks, int32_t stride, float inv_scale, void* workspace, size_t workspace_bytes,
-                            float* dw, lfd_stream_t stream) {
+                            int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
+                            size_t workspace_bytes, float* dw, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!x || !dy || !dw || !workspace || n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
   if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return LFD_ERR_INVALID_ARGUMENT;
@@ -823,8 +886,8 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
   else rc = launch_wgrad<1, 2>(a, nwg, nblk, st);
   if (rc != LFD_OK) return rc;
   const int taps = ks * ks, total = nblk * taps * 64 * 64;
-  hipLaunchKernelGGL(k_wgrad_final, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, a.partials, nwg, nblk,
-                     cin, cout, taps, inv_scale, dw);
+  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 64), dim3(kThreads), 0, st, a.partials, nwg, nblk,
+                     cin, cout, taps, inv_scale, accumulate, dw);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -844,7 +907,7 @@ int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t 
 }
 
 int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t h, int32_t w, int32_t channels,
-                         float inv_scale, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream) {
+                         float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!x_nchw || !dy || !dw || !workspace || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
     return LFD_ERR_INVALID_ARGUMENT;
@@ -859,8 +922,8 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
                      channels, ppb, partials);
   LFD_CHECK_LAUNCH();
   const int count = 27 * channels;
-  hipLaunchKernelGGL(k_sum_partials, dim3((count + kThreads - 1) / kThreads), dim3(kThreads), 0, st, partials, blocks,
-                     count, inv_scale, 1, channels, 27, dw);
+  hipLaunchKernelGGL(k_sum_partials, dim3(count), dim3(64), 0, st, partials, blocks,
+                     count, inv_scale, 1, channels, 27, accumulate, dw);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

@@ -109,14 +109,15 @@ _SIGNATURES = {
     'lfd_train_workspace_bytes': (_SZ, []),
     'lfd_bn_train_stats_f16': (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_bn_train_apply_f16': (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I32, _P, _P]),
-    'lfd_bn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _F, _P, _SZ, _P, _P, _P, _P, _P]),
+    'lfd_bn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P, _P]),
+    'lfd_pack_conv_weight_train_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_gn_train_stats_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _F, _P, _SZ, _P, _P]),
     'lfd_gn_train_apply_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
     'lfd_gn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_zero_insert2_nhwc_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
-    'lfd_conv_wgrad_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _SZ, _P, _P]),
+    'lfd_conv_wgrad_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_train_fwd': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
-    'lfd_stem_conv0_wgrad': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _P, _SZ, _P, _P]),
+    'lfd_stem_conv0_wgrad': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),

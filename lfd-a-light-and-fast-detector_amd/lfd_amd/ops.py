@@ -407,8 +407,8 @@ def bn_train_apply(y, stats, gamma, beta, residual=None, relu=True):
     return z
 
 
-def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=False):
-    """-> (dy, g).  z=None: no ReLU behind the norm.  dgamma / dbeta: float32[C] outputs (unscaled)."""
+def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=False, accumulate=False):
+    """-> (dy, g).  z=None: no ReLU behind the norm.  dgamma / dbeta: float32[C] outputs (unscaled; += if accumulate)."""
     _nhwc16(dz, 'bn_train_backward')
     c = y.size(3)
     dy = torch.empty_like(y)
@@ -416,7 +416,8 @@ def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=F
     ws = train_workspace(y.device)
     with torch.cuda.device(y.device):
         check(lib().lfd_bn_train_bwd_f16(ptr(dz), ptr(y), ptr(z), y.numel() // c, c, ptr(stats), ptr(gamma),
-                                         float(inv_scale), ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta), ptr(dy), ptr(g),
+                                         float(inv_scale), int(bool(accumulate)), ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta),
+                                         ptr(dy), ptr(g),
                                          stream_ptr()), 'lfd_bn_train_bwd_f16')
     return dy, g
 
@@ -464,8 +465,30 @@ def zero_insert2(t, ho, wo):
     return out
 
 
-def conv_wgrad(x, dy, ks, stride, inv_scale, out=None):
-    """dW [cout,cin,ks,ks] fp32 of conv(x, W) with pad ks//2 given dL/dy (scaled by 1/inv_scale)."""
+def pack_conv_weight_train(weight, data_gradient=False, rows=None):
+    """nn.Conv2d.weight (fp32 OIHW) -> packed fp16 fragments in one launch (csrc/train.hip k_pack_weight): the forward
+    conv (optionally zero-padded to `rows` output rows) or the data-gradient conv (roles swapped, taps flipped)."""
+    require_cuda(weight, 'pack_conv_weight_train')
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.contiguous().float()
+    cout, cin, ks, _ = w.shape
+    rows = cout if rows is None else int(rows)
+    lc, li = (cin, cout) if data_gradient else (rows, cin)
+    out = torch.empty((lc // 32, ks * ks * (li // 16), 64, 8), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        if data_gradient:
+            check(lib().lfd_pack_conv_weight_train_f16(ptr(w), cout, cin, ks, 1, lc, ptr(out), stream_ptr()),
+                  'lfd_pack_conv_weight_train_f16')
+        else:
+            check(lib().lfd_pack_conv_weight_train_f16(ptr(w), rows, cin, ks, 0, cout, ptr(out), stream_ptr()),
+                  'lfd_pack_conv_weight_train_f16')
+    return out
+
+
+def conv_wgrad(x, dy, ks, stride, inv_scale, out=None, accumulate=False):
+    """dW [cout,cin,ks,ks] fp32 of conv(x, W) with pad ks//2 given dL/dy (scaled by 1/inv_scale); += into `out` if
+    accumulate."""
     _nhwc16(x, 'conv_wgrad')
     _nhwc16(dy, 'conv_wgrad')
     n, h, w_, cin = x.shape
@@ -474,8 +497,9 @@ def conv_wgrad(x, dy, ks, stride, inv_scale, out=None):
         out = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=x.device)
     ws = train_workspace(x.device)
     with torch.cuda.device(x.device):
-        check(lib().lfd_conv_wgrad_nhwc_f16(ptr(x), ptr(dy), n, h, w_, cin, cout, ks, stride, float(inv_scale), ptr(ws),
-                                            ws.numel(), ptr(out), stream_ptr()), 'lfd_conv_wgrad_nhwc_f16')
+        check(lib().lfd_conv_wgrad_nhwc_f16(ptr(x), ptr(dy), n, h, w_, cin, cout, ks, stride, float(inv_scale),
+                                            int(bool(accumulate)), ptr(ws), ws.numel(), ptr(out), stream_ptr()),
+              'lfd_conv_wgrad_nhwc_f16')
     return out
 
 
@@ -491,7 +515,7 @@ def stem_conv0_train_fwd(x_nchw, weight):
     return y
 
 
-def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None):
+def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None, accumulate=False):
     x = x_nchw.contiguous().float()
     n, _, h, w_ = x.shape
     c = dy.size(3)
@@ -499,6 +523,6 @@ def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None):
         out = torch.empty((c, 3, 3, 3), dtype=torch.float32, device=x.device)
     ws = train_workspace(x.device)
     with torch.cuda.device(x.device):
-        check(lib().lfd_stem_conv0_wgrad(ptr(x), ptr(dy), n, h, w_, c, float(inv_scale), ptr(ws), ws.numel(), ptr(out),
-                                         stream_ptr()), 'lfd_stem_conv0_wgrad')
+        check(lib().lfd_stem_conv0_wgrad(ptr(x), ptr(dy), n, h, w_, c, float(inv_scale), int(bool(accumulate)), ptr(ws),
+                                         ws.numel(), ptr(out), stream_ptr()), 'lfd_stem_conv0_wgrad')
     return out

@@ -172,7 +172,20 @@ def network_params(units, outs):
 
 def _dgrad_weight(w):
     """weights of the conv that maps dL/dy to dL/dx: swap the channel roles, flip the taps"""
-    return ops.pack_conv_weight(w.detach().permute(1, 0, 2, 3).flip(2, 3))
+    return ops.pack_conv_weight_train(w, data_gradient=True)
+
+
+class _Packs(object):
+    """fp16 fragment packs of the conv weights, one launch each, shared by the pyramid levels within a pass"""
+
+    def __init__(self):
+        self.c = {}
+
+    def __call__(self, w, data_gradient=False):
+        k = (id(w), data_gradient)
+        if k not in self.c:
+            self.c[k] = ops.pack_conv_weight_train(w, data_gradient=data_gradient)
+        return self.c[k]
 
 
 class _Zeros(object):
@@ -190,6 +203,7 @@ def forward(units, tap_ids, x):
     acts = {0: x}
     tape = []
     zeros = _Zeros(x.device)
+    packs = _Packs()
     for u in units:
         conv, norm = u.conv, u.norm
         xin = acts[u.src]
@@ -198,7 +212,7 @@ def forward(units, tap_ids, x):
             y = ops.stem_conv0_train_fwd(xin, conv.weight)
         else:
             cout = conv.out_channels
-            y = ops.conv2d_nhwc(xin, ops.pack_conv_weight(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, False)
+            y = ops.conv2d_nhwc(xin, packs(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, False)
         if isinstance(norm, nn.GroupNorm):
             stats = ops.gn_train_stats(y, norm.num_groups, norm.eps)
             z = ops.gn_train_apply(y, norm.num_groups, stats, norm.weight.detach(), norm.bias.detach(), u.relu)
@@ -213,24 +227,30 @@ def forward(units, tap_ids, x):
 
 
 class _GradStore(object):
-    """fp32 parameter gradients by parameter identity; shared modules (the head towers of all levels) accumulate."""
+    """Where the fp32 parameter gradients go.  in_place: straight into `p.grad` (created zeroed when missing) -- the
+    kernels `+=` into it, which is autograd's AccumulateGrad semantics without one temporary + one add per tensor (the
+    autograd node then reports no gradient for the parameters).  Otherwise: private zero-initialised buffers by
+    parameter identity (tests).  Shared modules (the head towers of all levels) accumulate either way."""
 
-    def __init__(self):
-        self.g = {}
+    def __init__(self, in_place=False):
+        self.g, self.in_place = {}, in_place
 
-    def add(self, p, grad):
-        k = id(p)
-        self.g[k] = grad if k not in self.g else self.g[k] + grad
-
-    def buffer(self, p):
-        """zero-initialised gradient buffer the kernels accumulate into (GroupNorm dgamma / dbeta)"""
+    def target(self, p):
+        """the buffer every kernel accumulates this parameter's gradient into"""
+        if self.in_place:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+            return p.grad
         k = id(p)
         if k not in self.g:
-            self.g[k] = torch.zeros_like(p, dtype=torch.float32)
+            self.g[k] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
         return self.g[k]
 
+    def add(self, p, grad):
+        self.target(p).add_(grad.reshape(p.shape))
+
     def get(self, p):
-        return self.g.get(id(p))
+        return p.grad if self.in_place else self.g.get(id(p))
 
 
 def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
@@ -243,6 +263,7 @@ def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
     grads = dict(grads)
     store = store if store is not None else _GradStore()
     zeros = _Zeros(acts[0].device)
+    packs = _Packs()
     for ui in range(len(units) - 1, -1, -1):
         u = units[ui]
         dz = grads.pop(u.dst, None)
@@ -252,34 +273,31 @@ def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
         y, stats = tape[ui]
         z = acts[u.dst] if u.relu else None
         g = None
+        dgamma, dbeta, dw = store.target(norm.weight), store.target(norm.bias), store.target(conv.weight)
+        snap = [t.clone() for t in (dgamma, dbeta, dw)] if trace is not None else None
         if isinstance(norm, nn.GroupNorm):
-            dgamma, dbeta = store.buffer(norm.weight), store.buffer(norm.bias)
             dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, dgamma, dbeta, True)
         else:
-            dgamma = torch.empty_like(norm.weight, dtype=torch.float32)
-            dbeta = torch.empty_like(norm.bias, dtype=torch.float32)
-            dy, g = ops.bn_train_backward(dz, y, z, stats, norm.weight.detach(), inv, dgamma, dbeta, want_g=u.res is not None)
-            store.add(norm.weight, dgamma)
-            store.add(norm.bias, dbeta)
+            dy, g = ops.bn_train_backward(dz, y, z, stats, norm.weight.detach(), inv, dgamma, dbeta, want_g=u.res is not None,
+                                          accumulate=True)
         if u.res is not None:
             grads[u.res] = g if u.res not in grads else grads[u.res] + g
         xin = acts[u.src]
         ks, st = conv.kernel_size[0], conv.stride[0]
         rec = dict(ui=ui, dz=dz, dy=dy, g=g, dx_prev=grads.get(u.src), dx=None) if trace is not None else None
         if u.first:
-            dw = ops.stem_conv0_wgrad(xin, dy, inv)
+            ops.stem_conv0_wgrad(xin, dy, inv, out=dw, accumulate=True)
         else:
-            dw = ops.conv_wgrad(xin, dy, ks, st, inv)
+            ops.conv_wgrad(xin, dy, ks, st, inv, out=dw, accumulate=True)
             if st == 2:
                 dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
             cin = conv.in_channels
-            grads[u.src] = ops.conv2d_nhwc(dy, _dgrad_weight(conv.weight), zeros(cin), conv.out_channels, cin, ks, 1,
+            grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, ks, 1,
                                            False, residual=grads.get(u.src))
             if rec is not None:
                 rec['dx'] = grads[u.src]
-        store.add(conv.weight, dw)
-        if rec is not None:
-            rec.update(dw=dw, dgamma=dgamma, dbeta=dbeta)
+        if rec is not None:      # this unit's own contribution (the buffers accumulate over shared modules)
+            rec.update(dgamma=dgamma - snap[0], dbeta=dbeta - snap[1], dw=dw - snap[2])
             trace.append(rec)
     return store
 
@@ -302,11 +320,16 @@ def outputs_forward(outs, acts, num_levels):
     """-> (cls [N,P,C'], reg [N,P,4]) fp32 in the level-concatenated layout of LFD.forward (lfd.py:526-542), sizes per level,
     and what the backward needs."""
     cls_l, reg_l, sizes, saved = [None] * num_levels, [None] * num_levels, [None] * num_levels, []
+    cache = {}
     for o in outs:
         x = acts[o.src]
         n, h, w_, c = x.shape
-        wp, bp = _out_weight(o)
-        y = ops.conv2d_nhwc(x, ops.pack_conv_weight(wp), bp, c, wp.size(0), 1, 1, False).view(n, h * w_, wp.size(0))
+        key = tuple(id(cv) for _, cv in o.convs)           # shared heads: one concatenation + pack for all levels
+        if key not in cache:
+            wp, bp = _out_weight(o)
+            cache[key] = (wp, bp, ops.pack_conv_weight_train(wp))
+        wp, bp, wpk = cache[key]
+        y = ops.conv2d_nhwc(x, wpk, bp, c, wp.size(0), 1, 1, False).view(n, h * w_, wp.size(0))
         r0 = 0
         raw = None
         for kind, conv in o.convs:
@@ -331,6 +354,7 @@ def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=LOSS_SCA
         starts.append(p)
         p += h * w_
     zeros = _Zeros(dcls.device)
+    packs = _Packs()
     for o, (wp, raw) in zip(outs, saved):
         x = acts[o.src]
         n, h, w_, c = x.shape
@@ -357,7 +381,7 @@ def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=LOSS_SCA
         for _, conv in o.convs:
             store.add(conv.weight, dw[r0:r0 + conv.out_channels])
             r0 += conv.out_channels
-        grads[o.src] = ops.conv2d_nhwc(dy, _dgrad_weight(wp), zeros(c), rows, c, 1, 1, False, residual=grads.get(o.src))
+        grads[o.src] = ops.conv2d_nhwc(dy, packs(wp, True), zeros(c), rows, c, 1, 1, False, residual=grads.get(o.src))
     return grads
 
 
@@ -379,9 +403,9 @@ class BackboneTrainFunction(torch.autograd.Function):
             if g is not None:
                 g16 = (g * LOSS_SCALE).permute(0, 2, 3, 1).contiguous().half()
                 grads[t] = g16 if t not in grads else grads[t] + g16
-        store = backward(units, ctx.saved, grads)
+        backward(units, ctx.saved, grads, store=_GradStore(in_place=True))
         ctx.saved = None
-        return (None, None) + tuple(store.get(p) for p in backbone_params(units))
+        return (None, None) + (None,) * len(backbone_params(units))     # gradients were accumulated into .grad directly
 
 
 class NetworkTrainFunction(torch.autograd.Function):
@@ -401,7 +425,7 @@ class NetworkTrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcls, dreg):
         units, outs, _ = ctx.plan
-        store = _GradStore()
+        store = _GradStore(in_place=True)
         dev = ctx.saved[0][0].device
         if dcls is None:
             dcls = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
@@ -410,7 +434,7 @@ class NetworkTrainFunction(torch.autograd.Function):
         grads = outputs_backward(outs, ctx.saved[0], ctx.osaved, ctx.sizes, dcls.contiguous(), dreg.contiguous(), store)
         backward(units, ctx.saved, grads, store=store)
         ctx.saved = ctx.osaved = None
-        return (None, None) + tuple(store.get(p) for p in network_params(units, outs))
+        return (None, None) + (None,) * len(network_params(units, outs))   # accumulated into .grad directly
 
 
 def backbone_train_forward(backbone, x):

@@ -112,6 +112,18 @@ def test_gn_train_forward_backward_vs_autograd(relu):
     assert _rel(dgamma - 2.0, gr.grad) < 3e-3 and _rel(dbeta + 1.0, br.grad) < 3e-3      # += into the existing buffers
 
 
+@pytest.mark.parametrize('cout,cin,ks', [(64, 64, 3), (128, 64, 3), (64, 128, 1), (32, 32, 3), (128, 128, 1)])
+def test_pack_kernel_equals_host_pack(cout, cin, ks):
+    w = torch.randn(cout, cin, ks, ks, device='cuda')
+    assert torch.equal(ops.pack_conv_weight_train(w), ops.pack_conv_weight(w))
+    assert torch.equal(ops.pack_conv_weight_train(w, data_gradient=True),
+                       ops.pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3).contiguous()))
+    if ks == 1:
+        wp = torch.zeros(64 if cout <= 64 else 128, cin, 1, 1, device='cuda')
+        wp[:5] = w[:5]
+        assert torch.equal(ops.pack_conv_weight_train(w[:5].contiguous(), rows=wp.size(0)), ops.pack_conv_weight(wp))
+
+
 def test_zero_insert2_exact():
     for hi, wi, ho, wo in [(5, 7, 10, 14), (5, 7, 9, 13), (1, 1, 1, 1), (34, 60, 68, 120)]:
         t = _rand16((2, hi, wi, 64), hi)
