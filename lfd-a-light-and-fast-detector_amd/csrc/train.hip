@@ -526,6 +526,151 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_partial(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same two first-conv kernels on MFMA (default): the 27 taps (ci, ky, kx) are the contraction index padded to 32,
+//   forward :  y[px][co]  = sum_t W[co][t] * patch[px][t]      A = W (rows = co), B = patches (cols = 32 pixels)
+//   wgrad   :  dW[co][t]  = sum_px dy[px][co] * patch[px][t]   A = dy^T (rows = co, k = pixels; transposing LDS read),
+//                                                              B = patches (cols = 32 taps, k = 8 consecutive pixels)
+// patches are gathered straight from the NCHW fp32 image (L1/L2-resident: every input value is used by ~7 taps) and
+// rounded to fp16; accumulation fp32.
+// ---------------------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
+__device__ __forceinline__ h8 tr_frag(const char* base, uint32_t off0, uint32_t off1) {
+  union { s4v s[2]; h8 h; } u;
+  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(base + off0));
+  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(base + off1));
+  return u.h;
+}
+
+struct TapTab {
+  int off[16];     // ci*h*w + (ky-1)*w + (kx-1), relative to (2*oy, 2*ox)
+  int kyx[16];     // (ky << 8) | kx, or -1 for the padding taps >= 27
+};
+
+__device__ __forceinline__ void tap_of(int t, int h, int w, int& off, int& kyx) {
+  if (t >= 27) { off = 0; kyx = -1; return; }
+  const int ci = t / 9, r = t - ci * 9, ky = r / 3, kx = r - ky * 3;
+  off = ci * h * w + (ky - 1) * w + (kx - 1);
+  kyx = (ky << 8) | kx;
+}
+
+__global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __restrict__ x, int n, int h, int w, int c,
+                                                            const float* __restrict__ wt, __half* __restrict__ y) {
+  const int l = threadIdx.x & 63, hk = l >> 5;
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int64_t total = (int64_t)n * ho * wo;
+  const int nct = c / 32;
+  // A fragments: W[ct*32 + (l&31)][16*ks + 8*hk + j]
+  h8 wa[2][2];
+  for (int ct = 0; ct < 2; ++ct)
+    for (int ks = 0; ks < 2; ++ks)
+      for (int j = 0; j < 8; ++j) {
+        const int t = 16 * ks + 8 * hk + j, co = ct * 32 + (l & 31);
+        wa[ct][ks][j] = (_Float16)((t < 27 && co < c) ? wt[co * 27 + t] : 0.f);
+      }
+  TapTab tab;
+  for (int s = 0; s < 16; ++s) tap_of(16 * (s >> 3) + 8 * hk + (s & 7), h, w, tab.off[s], tab.kyx[s]);
+  const int64_t wave0 = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * 32;
+  const int64_t stride = (int64_t)gridDim.x * (kThreads / 64) * 32;
+  for (int64_t p0 = wave0; p0 < total; p0 += stride) {
+    const int64_t p = p0 + (l & 31);
+    const bool pv = p < total;
+    const int64_t pc = pv ? p : 0;
+    const int ox = (int)(pc % wo);
+    const int64_t q = pc / wo;
+    const int oy = (int)(q % ho);
+    const int img = (int)(q / ho);
+    const float* xb = x + ((int64_t)img * 3 * h + 2 * oy) * w + 2 * ox;
+    h8 b[2];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int ky = tab.kyx[s] >> 8, kx = tab.kyx[s] & 255;
+      const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+      const bool ok = pv && tab.kyx[s] >= 0 && iy >= 0 && iy < h && ix >= 0 && ix < w;
+      const float v = ok ? xb[tab.off[s]] : 0.f;
+      b[s >> 3][s & 7] = (_Float16)v;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      if (ct >= nct) break;
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ct][0], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ct][1], b[1], acc, 0, 0, 0);
+      if (pv) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // rows 8g + 4hk + 0..3 of this pixel: 4 consecutive channels
+          h4 o;
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[4 * g + e];
+          *reinterpret_cast<h4*>(y + p * c + ct * 32 + 8 * g + 4 * hk) = o;
+        }
+      }
+    }
+  }
+}
+
+// partial[block][co 64][t 32]
+__global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __restrict__ x,
+                                                              const __half* __restrict__ dy, int n, int h, int w,
+                                                              int c, float* partials) {
+  __shared__ __attribute__((aligned(16))) char sdy[4][16 * 144];
+  __shared__ float red[4][64 * 32];
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hk = l >> 5;
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int segs = (wo + 15) / 16;                       // k-step = 16 consecutive output pixels of one row
+  const int64_t total = (int64_t)n * ho * segs;
+  const int t = l & 31;                                   // this lane's tap (B column)
+  int toff, tkyx;
+  tap_of(t, h, w, toff, tkyx);
+  const int ky = tkyx >> 8, kx = tkyx & 255;
+  f16v acc[2];
+  for (int ct = 0; ct < 2; ++ct)
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  const int i16 = l & 15, grp = (l >> 4) & 1;
+  uint32_t a_off[2];
+  for (int r = 0; r < 2; ++r) a_off[r] = (8 * hk + 4 * r + (i16 >> 2)) * 144 + (16 * grp + 4 * (i16 & 3)) * 2;
+  char* my = sdy[wave];
+  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < total; s += (int64_t)gridDim.x * 4) {
+    const int seg = (int)(s % segs);
+    const int64_t q = s / segs;
+    const int oy = (int)(q % ho);
+    const int img = (int)(q / ho);
+    const int ox0 = seg * 16;
+    // stage dy[16 px][64 ch] (zero beyond the row / channel range): 128 16-byte chunks, 2 per lane
+    for (int i = l; i < 128; i += 64) {
+      const int px = i >> 3, c8 = i & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ox0 + px < wo && c8 * 8 < c)
+        v = *reinterpret_cast<const uint4*>(dy + (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8);
+      *reinterpret_cast<uint4*>(my + px * 144 + c8 * 16) = v;
+    }
+    // B: patch[ox0 + 8hk + j][t], j = 0..7
+    h8 b;
+    const int iy = 2 * oy + ky - 1;
+    const float* xr = x + ((int64_t)img * 3 * h + 2 * oy) * w + toff;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ox = ox0 + 8 * hk + j, ix = 2 * ox + kx - 1;
+      const bool ok = tkyx >= 0 && ox < wo && iy >= 0 && iy < h && ix >= 0 && ix < w;
+      b[j] = (_Float16)(ok ? xr[2 * ox] : 0.f);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const h8 af = tr_frag(my, a_off[0] + ct * 64, a_off[1] + ct * 64);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b, acc[ct], 0, 0, 0);
+    }
+  }
+  // combine the 4 waves in fixed order; D layout: lane = column (tap), reg r -> row (co) 8*(r>>2) + 4*hk + (r&3)
+  for (int ct = 0; ct < 2; ++ct)
+    for (int r = 0; r < 16; ++r) red[wave][(ct * 32 + 8 * (r >> 2) + 4 * hk + (r & 3)) * 32 + t] = acc[ct][r];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 64 * 32; o += kThreads)
+    partials[(size_t)blockIdx.x * 2048 + o] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+}
+
 // generic sum of partial[block][count] -> out[perm(i)] * inv_scale, one wave per output; perm: 0 identity,
 // 1: i = t*c + co -> co*taps + t (OIHW of the first conv)
 __global__ __launch_bounds__(64) void k_sum_partials(const float* partials, int nblocks, int count, float inv_scale,
@@ -538,6 +683,10 @@ __global__ __launch_bounds__(64) void k_sum_partials(const float* partials, int 
   int o = i;
   if (perm == 1) {
     const int t = i / c, co = i - t * c;
+    o = co * taps + t;
+  } else if (perm == 2) {          // i = co*32 + t (taps padded to 32) -> co*taps + t
+    const int co = i >> 5, t = i & 31;
+    if (t >= taps || co >= c) return;
     o = co * taps + t;
   }
   out[o] = (accumulate ? out[o] : 0.f) + (float)(s * (double)inv_scale);
@@ -555,9 +704,6 @@ __global__ __launch_bounds__(64) void k_sum_partials(const float* partials, int 
 // (ks*ks 32x32 tiles per wave) resident; wave = (cout half, cin half).  partial[wg][tap][co 64][ci 64] fp32, summed in
 // block order by k_wgrad_final (deterministic).
 // ---------------------------------------------------------------------------------------------------------
-typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
-typedef __attribute__((address_space(3))) s4v lds_s4v;
-
 template <int KS, int S>
 struct WgradCfg {
   static constexpr int TH = 8, TW = 16, PAD = KS / 2;
@@ -575,13 +721,6 @@ struct WgradArgs {
   int tiles_y, tiles_x;
   float* partials;
 };
-
-__device__ __forceinline__ h8 tr_frag(const char* base, uint32_t off0, uint32_t off1) {
-  union { s4v s[2]; h8 h; } u;
-  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(base + off0));
-  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(base + off1));
-  return u.h;
-}
 
 template <int KS, int S>
 __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
@@ -897,6 +1036,14 @@ int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!x_nchw || !weight_oihw || !y || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
     return LFD_ERR_INVALID_ARGUMENT;
+  static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
+  if (!use_valu) {
+    const int64_t groups = ((int64_t)n * ((h + 1) / 2) * ((w + 1) / 2) + 127) / 128;   // 4 waves x 32 pixels per block pass
+    hipLaunchKernelGGL(k_conv0_fwd_mfma, dim3((unsigned)(groups < 2048 ? groups : 2048)), dim3(kThreads), 0, st, x_nchw, n, h,
+                       w, channels, weight_oihw, (__half*)y);
+    LFD_CHECK_LAUNCH();
+    return LFD_OK;
+  }
   const int64_t vecs = (int64_t)n * ((h + 1) / 2) * ((w + 1) / 2) * (channels / 8);
   int64_t b = (vecs + kThreads - 1) / kThreads;
   if (b > 8192) b = 8192;
@@ -912,12 +1059,24 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
   if (!x_nchw || !dy || !dw || !workspace || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
     return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  float* partials = reinterpret_cast<float*>(workspace);
+  static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
+  if (!use_valu) {
+    const int64_t ksteps = (int64_t)n * ((h + 1) / 2) * (((w + 1) / 2 + 15) / 16);
+    const int nb = (int)(ksteps / 4 < 1 ? 1 : (ksteps / 4 > 1024 ? 1024 : ksteps / 4));
+    hipLaunchKernelGGL(k_conv0_wgrad_mfma, dim3(nb), dim3(kThreads), 0, st, x_nchw, (const __half*)dy, n, h, w, channels,
+                       partials);
+    LFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_partials, dim3(2048), dim3(64), 0, st, partials, nb, 2048, inv_scale, 2, channels, 27,
+                       accumulate, dw);
+    LFD_CHECK_LAUNCH();
+    return LFD_OK;
+  }
   const int64_t total = (int64_t)n * ((h + 1) / 2) * ((w + 1) / 2);
   int blocks = 2048;
   int ppb = (int)((total + blocks - 1) / blocks);
   if (ppb < 64) ppb = 64;
   blocks = (int)((total + ppb - 1) / ppb);
-  float* partials = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(k_conv0_wgrad_partial, dim3(blocks), dim3(kThreads), 0, st, x_nchw, (const __half*)dy, n, h, w,
                      channels, ppb, partials);
   LFD_CHECK_LAUNCH();

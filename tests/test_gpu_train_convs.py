@@ -166,11 +166,11 @@ def test_first_stem_conv_forward_and_wgrad(c):
     ref = F.conv2d(x, wt, None, 2, 1)
     y = ops.stem_conv0_train_fwd(x, wt)
     assert y.shape == (3, 31, 39, c)
-    torch.testing.assert_close(_nchw(y), ref, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(_nchw(y), ref, rtol=3e-3, atol=4e-3)      # image and weights rounded to fp16 for the MFMA
     dy = _rand16((3, 31, 39, c), 7, 0.05)
     ref.backward(_nchw(dy))
     dw = ops.stem_conv0_wgrad(x, dy, 0.5)
-    assert float((dw * 2 - wt.grad).abs().max() / wt.grad.abs().max()) < 1e-4
+    assert float((dw * 2 - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize('ks,stride,cin,cout', [(3, 1, 64, 64), (3, 2, 64, 128), (1, 2, 64, 64), (3, 2, 128, 128),
