@@ -231,3 +231,36 @@ def test_optimizer_hook_mirror_reads_the_reference_config_keys():
     Ex.config_dict.update(loss=(w * 2).sum(), epoch=5)                                      # past the duration
     h.after_train_iter(Ex)
     assert Ex.config_dict['grad_norm'] == 0
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    """lfd_amd.checkpoint: files in the reference's layout (utils.py:90-122) incl. the DataParallel 'module.' prefix and
+    the duplicated keys of the shared head load with strict=True; optimizer / scheduler state ride along."""
+    from lfd_amd import checkpoint, optim
+    m = configs.build_model('WIDERFACE_LFD_S')
+    configs.perturb_weights(m, seed=3)
+    sd = m.state_dict()
+    assert sd['_head.head0_merge_path.0.weight'].data_ptr() == sd['_head.head3_merge_path.0.weight'].data_ptr()   # aliases
+    opt = optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[5, 7], gamma=0.1)
+    path = str(tmp_path / 'sub' / 'epoch_1.pth')
+    checkpoint.save_checkpoint(m, path, optimizer=opt, lr_scheduler=sched, meta=dict(epoch=1))
+    ck = torch.load(path, map_location='cpu')
+    assert set(ck) == {'meta', 'state_dict', 'optimizer_state_dict', 'lr_scheduler_state_dict'}
+    assert ck['meta']['epoch'] == 1 and 'time' in ck['meta'] and list(ck['state_dict']) == list(sd)
+    # a DataParallel-style file (what the reference's Executor writes, executor.py:39,126-132)
+    ck['state_dict'] = {'module.' + k: v for k, v in ck['state_dict'].items()}
+    path2 = str(tmp_path / 'dp.pth')
+    torch.save(ck, path2)
+    fresh = configs.build_model('WIDERFACE_LFD_S', seed=1)
+    out = checkpoint.load_checkpoint(fresh, path2, strict=True)
+    assert out['meta']['epoch'] == 1
+    for (k, a), b in zip(fresh.state_dict().items(), sd.values()):
+        assert torch.equal(a, b), k
+    with pytest.raises(IOError):
+        checkpoint.load_checkpoint(fresh, str(tmp_path / 'nope.pth'))
+    torch.save({'weights': 1}, str(tmp_path / 'bad.pth'))
+    with pytest.raises(RuntimeError, match='No state_dict'):
+        checkpoint.load_checkpoint(fresh, str(tmp_path / 'bad.pth'))
+    with pytest.raises(TypeError):
+        checkpoint.save_checkpoint(m, path, meta=3)
