@@ -805,17 +805,19 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
 // dW (fp32, OIHW [cout][cin][ks][ks]) = inv_scale * sum over workgroups of the partials
 __global__ __launch_bounds__(kThreads) void k_wgrad_final(const float* partials, int nwg, int nblk, int cin, int cout,
                                                          int taps, float inv_scale, int accumulate, float* dw) {
-  __shared__ double red[4][64];
+  __shared__ double red[8][32];
   const int per_blk = taps * 64 * 64;
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);   // 64 consecutive outputs per block, 4 slices of the wg loop
-  const int slice = threadIdx.x >> 6;
-  const int blk = i / per_blk, j = i - blk * per_blk;    // per_blk is a multiple of 64: a block never straddles
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31);   // 32 consecutive outputs per block, 8 slices of the wg loop
+  const int slice = threadIdx.x >> 5;
+  const int blk = i / per_blk, j = i - blk * per_blk;    // per_blk is a multiple of 32: a block never straddles
   double s = 0.0;
-  for (int g = slice; g < nwg; g += 4) s += (double)partials[((size_t)g * nblk + blk) * per_blk + j];
-  red[slice][threadIdx.x & 63] = s;
+  for (int g = slice; g < nwg; g += 8) s += (double)partials[((size_t)g * nblk + blk) * per_blk + j];
+  red[slice][threadIdx.x & 31] = s;
   __syncthreads();
   if (slice != 0) return;
-  s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
   const int t = j / 4096, co_l = (j >> 6) & 63, ci_l = j & 63;
   const int nib = (cin + 63) / 64;
   const int co = (blk / nib) * 64 + co_l, ci = (blk % nib) * 64 + ci_l;
@@ -842,7 +844,8 @@ int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
   return LFD_OK;
 }
 
-constexpr int kWgradMaxWg = 256;   // persistent workgroups per (cout, cin) block
+constexpr int kWgradMaxWg = 256;   // sizes the partial buffer: 256 x 4 blocks x 9 taps x 64 x 64 floats
+constexpr int kWgradWgCap = 1024;  // most persistent workgroups per (cout, cin) block
 
 }  // namespace
 
@@ -1017,7 +1020,12 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
   a.partials = reinterpret_cast<float*>(workspace);
   const int nblk = ((cout + 63) / 64) * ((cin + 63) / 64);
   const int tiles = n * ((a.ho + 7) / 8) * ((a.wo + 15) / 16);
-  int nwg = tiles < kWgradMaxWg ? tiles : kWgradMaxWg;
+  // as many workgroups as the partial buffer holds (1x1: 2048, 3x3 64x64: 1024, 3x3 128x128: 256): several per CU hide
+  // the synchronous tile staging behind each other's MFMAs
+  int nwg = (kWgradMaxWg * 4 * 9) / (nblk * ks * ks);
+  if (ks == 3 && nwg > 512) nwg = 512;   // the fixed-order sum of the partials costs 147 KB of traffic per workgroup
+  if (nwg > kWgradWgCap) nwg = kWgradWgCap;
+  if (nwg > tiles) nwg = tiles;
   int rc;
   if (ks == 3 && stride == 1) rc = launch_wgrad<3, 1>(a, nwg, nblk, st);
   else if (ks == 3) rc = launch_wgrad<3, 2>(a, nwg, nblk, st);
@@ -1025,7 +1033,7 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
   else rc = launch_wgrad<1, 2>(a, nwg, nblk, st);
   if (rc != LFD_OK) return rc;
   const int taps = ks * ks, total = nblk * taps * 64 * 64;
-  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 64), dim3(kThreads), 0, st, a.partials, nwg, nblk,
+  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 32), dim3(kThreads), 0, st, a.partials, nwg, nblk,
                      cin, cout, taps, inv_scale, accumulate, dw);
   LFD_CHECK_LAUNCH();
   return LFD_OK;

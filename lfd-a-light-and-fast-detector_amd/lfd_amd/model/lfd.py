@@ -312,6 +312,14 @@ class LFD(nn.Module):
         """lfd.py:284-395.  Returns {'loss': Tensor, 'loss_values': {...floats}}."""
         pred_cls, pred_reg = predict_outputs
         dev = pred_cls.device
+        if dev.type == 'cuda' and self._fused_loss_supported(pred_cls):
+            # device path end to end: annotations concatenated on the host and uploaded once, targets by
+            # lfd_assign_targets_f32, loss by the fused get_loss kernels; no per-image tensors, one host sync
+            sizes = [self._head_indexes_to_feature_map_sizes[i] for i in range(self._num_heads)]
+            cls_t, reg_t = ops.assign_targets_from_host(sizes, self._point_strides, self._regression_ranges,
+                                                        self._gray_ranges, self._num_classes, self._range_assign_mode,
+                                                        self._regression_loss_type == 'independent', annotation_batch, dev)
+            return self._get_loss_fused(pred_cls, pred_reg, cls_t, reg_t)
         gt_b, gt_l = [], []
         for bboxes_numpy, labels_numpy in annotation_batch:
             gt_b.append(torch.as_tensor(bboxes_numpy).to(dev))

@@ -247,6 +247,39 @@ def assign_targets(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_
     else:
         boxes = torch.zeros((1, 4), dtype=torch.float32, device=dev)
         labels = torch.zeros((1,), dtype=torch.int64, device=dev)
+    return _assign_launch(d, n, total, num_classes, boxes, labels, offs, dev)
+
+
+def assign_targets_from_host(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent,
+                             annotation_batch, device):
+    """Same as assign_targets for the annotation_batch LFD.get_loss receives (list of (bboxes numpy [G,4] xywh, labels
+    numpy [G]) per image, lfd.py:290-297): concatenated on the host and uploaded with three copies instead of two per image."""
+    import numpy as np
+    n = len(annotation_batch)
+    d = _lib.AssignDesc()
+    d.n, d.num_levels = n, len(sizes)
+    total = 0
+    for i, (h, w) in enumerate(sizes):
+        d.level_h[i], d.level_w[i], d.stride[i] = int(h), int(w), int(strides[i])
+        d.reg_lo[i], d.reg_hi[i] = int(reg_ranges[i][0]), int(reg_ranges[i][1])
+        d.gray_lo[i], d.gray_hi[i] = int(gray_ranges[i][0]), int(gray_ranges[i][1])
+        total += int(h) * int(w)
+    d.total_points, d.num_classes = total, int(num_classes)
+    d.assign_mode, d.independent = ASSIGN_MODES[assign_mode], int(bool(independent))
+    bl = [np.asarray(b, dtype=np.float32).reshape(-1, 4) for b, _ in annotation_batch]
+    ll = [np.asarray(l, dtype=np.int64).reshape(-1) for _, l in annotation_batch]
+    counts = [b.shape[0] for b in bl]
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(device)
+    if sum(counts):
+        boxes = torch.from_numpy(np.ascontiguousarray(np.concatenate(bl, 0))).to(device)
+        labels = torch.from_numpy(np.ascontiguousarray(np.concatenate(ll, 0))).to(device)
+    else:
+        boxes = torch.zeros((1, 4), dtype=torch.float32, device=device)
+        labels = torch.zeros((1,), dtype=torch.int64, device=device)
+    return _assign_launch(d, n, total, num_classes, boxes, labels, offs, device)
+
+
+def _assign_launch(d, n, total, num_classes, boxes, labels, offs, dev):
     cls_t = torch.empty((n, total, int(num_classes)), dtype=torch.float32, device=dev)
     reg_t = torch.empty((n, total, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

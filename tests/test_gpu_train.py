@@ -145,7 +145,7 @@ def test_train_step_matches_op_by_op_composition(monkeypatch):
         assert float(na) == pytest.approx(float(nb), rel=1e-3)
         for (k, pa), pb, p0 in zip(ma.named_parameters(), mb.parameters(), start):
             upd = float((pb.detach() - p0).abs().max())
-            assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-3 * upd + 1e-7, (it, k, upd)
+            assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-3 * upd + 2.5e-7, (it, k, upd)      # + 2 ulp at 1.0 (norm weights)
 
 
 def test_inference_plan_sees_the_updated_parameters():
