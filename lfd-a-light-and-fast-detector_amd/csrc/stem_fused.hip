@@ -396,6 +396,10 @@ __device__ __forceinline__ half8 relu8(const f32x16& acc, int half) {
   return r.v;
 }
 
+// U8: the frame is NHWC uint8 and simple_normalize ((x/255 - 0.5)/0.5, augmentation_pipeline.py:31-36) is applied while the
+// raw tile is staged: the LDS image is the one the fp16 path builds for a frame at a 16-byte aligned (virtual) address, so
+// everything after the staging is shared.
+template <bool U8>
 __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_raw = smem;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     g.gyr0 = 4 * g.ty0 * X2::TH - 3; g.gxr0 = 4 * g.tx0 * X2::TW - 3;   // raw origin = 2 * (2 * out - 1) - 1
     // byte address of raw pixel (gyr0, gxr0): outside the frame for border tiles -- only its low bits and
     // rows / chunks that are inside the frame are ever used
-    g.rs0 = (long)reinterpret_cast<uintptr_t>(a.in) + (((long)g.n * a.H + g.gyr0) * a.W + g.gxr0) * 6;
+    g.rs0 = (U8 ? 0L : (long)reinterpret_cast<uintptr_t>(a.in)) + (((long)g.n * a.H + g.gyr0) * a.W + g.gxr0) * 6;
     g.sh0 = (int)(g.rs0 & 15);
     return g;
   };
@@ -548,9 +552,39 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   // The loads are unconditional (clamped address) and their results are NOT touched here: any use -- even the
   // zero-select for skipped chunks -- would make the compiler wait for the load right away and serialise the
   // four round trips.  The select happens a tile later, in raw_store.
+  // U8: a chunk = 8 consecutive bytes of the frame at byte offset (virtual fp16 byte address) / 2, plus the byte in front
+  // of it.  Fetched as three ALIGNED dwords starting at the dword that holds the byte in front (clamped into the frame
+  // buffer: a clamped dword only ever supplies bytes of out-of-frame columns, which raw_store masks), realigned in
+  // raw_put with v_alignbyte.
+  const long u8_last = U8 ? (((long)a.N * a.H * a.W * 3 - 1) & ~3L) : 0;
   auto raw_fetch1 = [&](const TileGeo& g, bool inner, int u) {
     const Chunk k = chunk_of(u);
     const int shr = (g.sh0 + k.rd) & 15;
+    if constexpr (U8) {
+      long b = (g.rs0 + (k.off - shr)) / 2 - 1;             // byte offset of the byte in front of the chunk
+      bool ok = true;
+      if (!inner) {
+        int e0, elo, ehi;
+        bool okp;
+        ok = chunk_ok(g, k, e0, elo, ehi, okp);
+        ok = ok || okp;      // the byte in front can be the last in-frame element of a row whose chunk is all padding
+      } else {
+        ok = (u < 3 || k.r >= 0);
+      }
+      if (!ok) b = 0;
+      long d0 = b & ~3L;
+      const char* base = reinterpret_cast<const char*>(a.in);
+      uint32_t w[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        long d = d0 + 4 * j;
+        d = d < 0 ? 0 : (d > u8_last ? u8_last : d);
+        w[j] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(reinterpret_cast<uintptr_t>(base + d));
+      }
+      rawv[u] = make_uint4(w[0], w[1], w[2], (uint32_t)(b & 3));
+      rawp[u] = 0;
+      return;
+    }
     const char* real = reinterpret_cast<const char*>(g.rs0) + (k.off - shr);
     const char* src;
     const char* srp;
@@ -568,6 +602,26 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
     rawp[u] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(reinterpret_cast<uintptr_t>(srp));
   };
+  // U8: bytes [prev, c0..c7] realigned to the low end of (lo, hi, top): lo = prev c0 c1 c2, hi = c3..c6, top = c7;
+  // converted to the 8 halfs of the chunk (-> v) and the half in front of it (-> upper half of prev)
+  auto u8_expand = [&](const uint4& raw, uint4& v, uint32_t& prev) {
+    const uint32_t sh = raw.w;   // 0..3: position of the byte in front inside the first dword
+    uint32_t lo = raw.x, hi = raw.y, top = raw.z;
+    if (sh == 1) { lo = __builtin_amdgcn_alignbyte(raw.y, raw.x, 1); hi = __builtin_amdgcn_alignbyte(raw.z, raw.y, 1); top = raw.z >> 8; }
+    else if (sh == 2) { lo = __builtin_amdgcn_alignbyte(raw.y, raw.x, 2); hi = __builtin_amdgcn_alignbyte(raw.z, raw.y, 2); top = raw.z >> 16; }
+    else if (sh == 3) { lo = __builtin_amdgcn_alignbyte(raw.y, raw.x, 3); hi = __builtin_amdgcn_alignbyte(raw.z, raw.y, 3); top = raw.z >> 24; }
+    auto cv = [](uint32_t byte) {
+      // fp16(f * (2/255) - 1) == fp16((f/255 - 0.5)/0.5) for all 256 inputs (tests/test_host_logic.py checks the table)
+      const float f = (float)(byte & 255u);
+      const _Float16 h = (_Float16)(f * (2.0f / 255.0f) - 1.0f);
+      return (uint32_t)__builtin_bit_cast(unsigned short, h);
+    };
+    prev = cv(lo) << 16;
+    v.x = cv(lo >> 8) | (cv(lo >> 16) << 16);
+    v.y = cv(lo >> 24) | (cv(hi) << 16);
+    v.z = cv(hi >> 8) | (cv(hi >> 16) << 16);
+    v.w = cv(hi >> 24) | (cv(top) << 16);
+  };
   auto raw_fetch = [&](const TileGeo& g) {
     const bool inner = interior(g);
 #pragma unroll
@@ -577,7 +631,10 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   // on a dword boundary (12 bytes per column pair) and the im2col reads are plain aligned dword reads.  The shift
   // is done in registers (funnel shift with the dword in front of the chunk): a 2-byte-misaligned 16-byte LDS
   // write costs 100+ cycles, 400+ with four waves writing (tools/ub/vmem3.hip).
-  auto raw_put = [&](const TileGeo& g, const Chunk& k, const uint4& v, uint32_t prev) {
+  auto raw_put = [&](const TileGeo& g, const Chunk& k, const uint4& v0, uint32_t prev0) {
+    uint4 v = v0;
+    uint32_t prev = prev0;
+    if constexpr (U8) u8_expand(v0, v, prev);
     const int shr_s = (g.sh0 + k.rd) & 15;
     u32x4 o;
     if (shr_s & 2) {
@@ -603,8 +660,11 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
           int e0, elo, ehi;
           bool okp;
           const bool ok = chunk_ok(g, k, e0, elo, ehi, okp);
-          const uint4 v = ok ? rawv[u] : make_uint4(0u, 0u, 0u, 0u);
-          const uint32_t pv = okp ? rawp[u] : 0u;
+          uint4 vx = rawv[u];
+          uint32_t px = rawp[u];
+          if constexpr (U8) u8_expand(rawv[u], vx, px);
+          const uint4 v = ok ? vx : make_uint4(0u, 0u, 0u, 0u);
+          const uint32_t pv = okp ? px : 0u;
           // after the (optional) one-half shift position kk of the chunk holds half e0s + kk of the row: zero the
           // ones that belong to out-of-frame columns
           const int shr_s = (g.sh0 + k.rd) & 15;
@@ -852,6 +912,7 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_x2_timing(unsign
 namespace {
 #endif
 
+template <bool U8>
 int launch_stem2x(FusedArgs a, hipStream_t st) {
   a.tiles_x = (a.W2 + X2::TW - 1) / X2::TW;
   a.tiles_y = (a.H2 + X2::TH - 1) / X2::TH;
@@ -860,7 +921,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   a.ntiles = (int)nt;
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem2x), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem2x<U8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             X2::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
@@ -868,7 +929,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   const int blocks = a.ntiles < 256 ? a.ntiles : 256;
   if (blocks < 1) return LFD_OK;
   { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg; }
-  hipLaunchKernelGGL(k_stem2x, dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(k_stem2x<U8>, dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -927,7 +988,8 @@ int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int3
   a.H1 = (h - 1) / 2 + 1; a.W1 = (w - 1) / 2 + 1;
   a.H2 = (a.H1 - 1) / 2 + 1; a.W2 = (a.W1 - 1) / 2 + 1;
   static const int use_x2 = [] { const char* e = getenv("LFD_STEM2X"); return e ? atoi(e) : 1; }();
-  if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) return launch_stem2x(a, st);
+  if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) return launch_stem2x<false>(a, st);
+  if (use_x2 && channels == 64 && in_format == IN_NHWC_U8) return launch_stem2x<true>(a, st);
   return channels == 64 ? dispatch_fmt<2>(in_format, a, st) : dispatch_fmt<1>(in_format, a, st);
 }
 

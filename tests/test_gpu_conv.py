@@ -189,6 +189,35 @@ def test_fused_stem_equals_two_kernel_stem(n, h, w):
     assert float((a - b).abs().mean()) < 1e-4     # almost all elements identical
 
 
+@pytest.mark.parametrize('n,h,w', [(1, 8, 8), (1, 19, 24), (2, 33, 57), (1, 64, 96), (3, 47, 130), (1, 270, 481), (2, 135, 256),
+                                   (1, 1080, 1920), (2, 123, 341)])
+def test_fused_stem_uint8_frames_equal_normalised_fp16_frames(n, h, w):
+    """k_stem2x<U8>: NHWC uint8 frames with simple_normalize fused into the raw-tile staging == the same kernel on the
+    frame normalised on the host ((x/255 - 0.5)/0.5 -> fp16), bit for bit: both build the same LDS image.  Sizes cover
+    every byte misalignment of the rows (W * 3 mod 4), clipped tiles and a full 1080p frame (whose byte size is an exact
+    multiple of the allocator granule: the clamped edge loads must not run past the buffer)."""
+    from lfd_amd._lib import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    c = 64
+    ws = [(torch.randn(c, 3, 3, 3, generator=g) * 0.2), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5),
+          (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5)]
+    bs = [(torch.randn(c, generator=g) * 0.1).cuda() for _ in range(4)]
+    packed = [engine.pack_stem_weight(ws[0]).cuda()] + [ops.pack_conv_weight(t).cuda() for t in ws[1:]]
+    img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    xh = ((img.float() / 255 - 0.5) / 0.5).half().cuda()
+    xu = img.cuda()
+    h2, w2 = ((h + 1) // 2 + 1) // 2, ((w + 1) // 2 + 1) // 2
+    outs = []
+    for x, code in ((xh, 1), (xu, 2)):
+        o = torch.full((n, h2, w2, c), float('nan'), dtype=torch.float16, device='cuda')
+        check(lib().lfd_stem_faster_fused_f16(ptr(x), code, n, h, w, c, ptr(packed[0]), ptr(bs[0]), ptr(packed[1]), ptr(bs[1]),
+                                              ptr(packed[2]), ptr(bs[2]), ptr(packed[3]), ptr(bs[3]), ptr(o), stream_ptr()), 'fused')
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_chained_conv_launch_equals_single_launches():
     """lfd_conv3x3_c64_chain_nhwc_f16 (one persistent kernel, device-wide barrier between layers) == the same layers
     as separate lfd_conv2d_nhwc_f16 launches, bit for bit (same tiles, same arithmetic), incl. residual layers."""

@@ -264,3 +264,12 @@ def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
         checkpoint.load_checkpoint(fresh, str(tmp_path / 'bad.pth'))
     with pytest.raises(TypeError):
         checkpoint.save_checkpoint(m, path, meta=3)
+
+
+def test_uint8_normalisation_shortcut_is_exact_for_all_256_inputs():
+    """k_stem2x<U8> converts frame bytes with fp16(f * (2/255) - 1) (one multiply + one subtract in fp32) instead of the
+    reference's (f/255 - 0.5)/0.5 (simple_normalize, augmentation_pipeline.py:31-36): identical fp16 for every byte value."""
+    f = np.arange(256, dtype=np.float32)
+    ref = ((f / np.float32(255) - np.float32(0.5)) / np.float32(0.5)).astype(np.float16)
+    fast = ((f * (np.float32(2) / np.float32(255))) - np.float32(1)).astype(np.float16)
+    assert np.array_equal(ref.view(np.uint16), fast.view(np.uint16))
