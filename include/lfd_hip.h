@@ -337,11 +337,13 @@ LFD_API int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channe
 /* z = relu?( gamma * (y - mean) * rstd + beta (+ residual) ) */
 LFD_API int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, const float* stats, const float* gamma,
                            const float* beta, const void* residual, int32_t relu, void* z, lfd_stream_t stream);
-/* backward of the above: g = dz * [z > 0] (z NULL: no ReLU), dgamma = inv_scale * sum g * xhat,
+/* backward of the above: g = dz * [ReLU passed] (relu == 0: no ReLU; z given: mask = [z > 0]; z NULL: the mask is
+ * recomputed from y as [gamma * xhat + beta > 0], only valid without a residual input), dgamma = inv_scale * sum g * xhat,
  * dbeta = inv_scale * sum g, dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)); g_out (nullable)
  * receives g, the gradient of the residual branch. */
-LFD_API int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t pixels, int32_t channels,
-                         const float* stats, const float* gamma, float inv_scale, int32_t accumulate, void* workspace,
+LFD_API int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t relu, int64_t pixels, int32_t channels,
+                         const float* stats, const float* gamma, const float* beta, float inv_scale,
+                         int32_t accumulate, void* workspace,
                          size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
                          lfd_stream_t stream);
 /* GroupNorm of the head towers in training (nn.GroupNorm(groups, channels) + ReLU, lfd_head.py:97-105), groups of

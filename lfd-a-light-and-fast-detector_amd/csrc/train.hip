@@ -173,17 +173,23 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
   }
 }
 
-// sums of g and g * xhat, g = dz * [z > 0] (z == nullptr: no ReLU behind this norm)
+// sums of g and g * xhat, g = dz * [ReLU passed]: mask from the stored output z when given (units with a residual
+// input), else -- relu_y -- recomputed from y as [gamma * xhat + beta > 0] (saves reading z), else no ReLU
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __restrict__ dz,
                                                             const __half* __restrict__ y,
                                                             const __half* __restrict__ z, int64_t vecs, int c,
-                                                            const float* __restrict__ stats, float* partials) {
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu_y,
+                                                            float* partials) {
   const int groups = c >> 3;
   const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
-  float mean[8], rstd[8], acc[2][8];
+  float mean[8], rstd[8], acc[2][8], ga[8], be[8];
   for (int e = 0; e < 8; ++e) {
     mean[e] = stats[cg * 8 + e];
     rstd[e] = stats[c + cg * 8 + e];
+    ga[e] = relu_y ? gamma[cg * 8 + e] : 0.f;
+    be[e] = relu_y ? beta[cg * 8 + e] : 0.f;
     acc[0][e] = acc[1][e] = 0.f;
   }
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
@@ -192,9 +198,11 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
     if (z) zz = ld8(z, v);
     for (int e = 0; e < 8; ++e) {
       float g = (float)d[e];
+      const float xh = ((float)yy[e] - mean[e]) * rstd[e];
       if (z && !((float)zz[e] > 0.f)) g = 0.f;
+      if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
       acc[0][e] += g;
-      acc[1][e] += g * (((float)yy[e] - mean[e]) * rstd[e]);
+      acc[1][e] += g * xh;
     }
   }
   block_channel_reduce<2>(acc, c, partials);
@@ -223,15 +231,18 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
                                                           const __half* __restrict__ z, int64_t vecs, int c,
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu_y,
                                                           const float* __restrict__ sums, float inv_m,
                                                           __half* __restrict__ dy, __half* __restrict__ g_out) {
   const int groups = c >> 3;
   const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
-  float mean[8], rstd[8], a[8], mg[8], mgx[8];
+  float mean[8], rstd[8], a[8], mg[8], mgx[8], ga[8], be[8];
   for (int e = 0; e < 8; ++e) {
     const int ch = cg * 8 + e;
     mean[e] = stats[ch];
     rstd[e] = stats[c + ch];
+    ga[e] = gamma[ch];
+    be[e] = relu_y ? beta[ch] : 0.f;
     a[e] = gamma[ch] * rstd[e];
     mg[e] = sums[ch] * inv_m;
     mgx[e] = sums[c + ch] * inv_m;
@@ -242,8 +253,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     if (z) zz = ld8(z, v);
     for (int e = 0; e < 8; ++e) {
       float g = (float)d[e];
-      if (z && !((float)zz[e] > 0.f)) g = 0.f;
       const float xh = ((float)yy[e] - mean[e]) * rstd[e];
+      if (z && !((float)zz[e] > 0.f)) g = 0.f;
+      if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
       o[e] = (_Float16)(a[e] * (g - mg[e] - xh * mgx[e]));
       go[e] = (_Float16)g;
     }
@@ -900,27 +912,31 @@ int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, cons
   return LFD_OK;
 }
 
-int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int64_t pixels, int32_t channels,
-                         const float* stats, const float* gamma, float inv_scale, int32_t accumulate, void* workspace,
+int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t relu, int64_t pixels, int32_t channels,
+                         const float* stats, const float* gamma, const float* beta, float inv_scale,
+                         int32_t accumulate, void* workspace,
                          size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
                          lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!dz || !y || !stats || !gamma || !dy || !workspace || pixels < 1 || !channels_ok(channels))
     return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int relu_y = (relu && !z) ? 1 : 0;       // no stored output given: the ReLU mask is recomputed from y
+  if (relu_y && !beta) return LFD_ERR_INVALID_ARGUMENT;
+  if (!relu) z = nullptr;
   const int64_t vecs = pixels * (channels / 8);
   const unsigned g = grid_for_vecs(vecs);
   float* partials = reinterpret_cast<float*>(workspace);
   float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vecs, channels, stats, partials);
+                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
                      dgamma, dbeta);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vecs, channels, stats, gamma, sums, (float)(1.0 / (double)pixels), (__half*)dy,
-                     (__half*)g_out);
+                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
+                     (__half*)dy, (__half*)g_out);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

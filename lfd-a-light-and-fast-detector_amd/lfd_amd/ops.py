@@ -440,17 +440,21 @@ def bn_train_apply(y, stats, gamma, beta, residual=None, relu=True):
     return z
 
 
-def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=False, accumulate=False):
-    """-> (dy, g).  z=None: no ReLU behind the norm.  dgamma / dbeta: float32[C] outputs (unscaled; += if accumulate)."""
+def bn_train_backward(dz, y, z, stats, gamma, inv_scale, dgamma, dbeta, want_g=False, accumulate=False, relu=None,
+                      beta=None):
+    """-> (dy, g).  relu (default: z is not None): a ReLU follows the norm; its mask comes from the stored output z, or --
+    z=None with relu=True and beta given, units without a residual input -- is recomputed from y.
+    dgamma / dbeta: float32[C] outputs (unscaled; += if accumulate)."""
+    relu = (z is not None) if relu is None else bool(relu)
     _nhwc16(dz, 'bn_train_backward')
     c = y.size(3)
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
     ws = train_workspace(y.device)
     with torch.cuda.device(y.device):
-        check(lib().lfd_bn_train_bwd_f16(ptr(dz), ptr(y), ptr(z), y.numel() // c, c, ptr(stats), ptr(gamma),
-                                         float(inv_scale), int(bool(accumulate)), ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta),
-                                         ptr(dy), ptr(g),
+        check(lib().lfd_bn_train_bwd_f16(ptr(dz), ptr(y), ptr(z), int(relu), y.numel() // c, c, ptr(stats), ptr(gamma),
+                                         ptr(beta), float(inv_scale), int(bool(accumulate)), ptr(ws), ws.numel(), ptr(dgamma),
+                                         ptr(dbeta), ptr(dy), ptr(g),
                                          stream_ptr()), 'lfd_bn_train_bwd_f16')
     return dy, g
 

@@ -278,8 +278,10 @@ def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
         if isinstance(norm, nn.GroupNorm):
             dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, dgamma, dbeta, True)
         else:
-            dy, g = ops.bn_train_backward(dz, y, z, stats, norm.weight.detach(), inv, dgamma, dbeta, want_g=u.res is not None,
-                                          accumulate=True)
+            # without a residual input the ReLU mask is recomputed from y (one tensor less to read in both passes)
+            dy, g = ops.bn_train_backward(dz, y, z if u.res is not None else None, stats, norm.weight.detach(), inv, dgamma,
+                                          dbeta, want_g=u.res is not None, accumulate=True, relu=u.relu,
+                                          beta=norm.bias.detach())
         if u.res is not None:
             grads[u.res] = g if u.res not in grads else grads[u.res] + g
         xin = acts[u.src]

@@ -82,6 +82,13 @@ def test_bn_train_backward_vs_autograd(c, relu, with_res):
     torch.testing.assert_close(dbeta, br.grad, rtol=3e-3, atol=3e-3 * float(br.grad.abs().max()))
     if with_res:
         torch.testing.assert_close(_nchw(g), rr.grad * scale, rtol=2e-3, atol=1e-4)
+    if relu and not with_res:      # the same backward with the ReLU mask recomputed from y instead of read from z
+        dg2, db2 = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+        dy2, _ = ops.bn_train_backward((dz.float() * scale).half(), y, None, stats, gamma, 1 / scale, dg2, db2, relu=True,
+                                       beta=beta)
+        assert float((_nchw(dy2) - ref_dy).abs().max() / ref_dy.abs().max()) < 3e-3
+        torch.testing.assert_close(dg2, gr.grad, rtol=3e-3, atol=3e-3 * float(gr.grad.abs().max()))
+        torch.testing.assert_close(db2, br.grad, rtol=3e-3, atol=3e-3 * float(br.grad.abs().max()))
 
 
 @pytest.mark.parametrize('relu', [True, False])
