@@ -44,8 +44,9 @@ def supported(backbone):
     for m in backbone.modules():
         if isinstance(m, nn.Conv2d) and not _conv_ok(m):
             return False
-        if isinstance(m, nn.BatchNorm2d) and (m.momentum is None or not m.affine or not m.track_running_stats):
-            return False
+        if isinstance(m, nn.BatchNorm2d) and (m.momentum is None or not m.affine or not m.track_running_stats
+                                              or not m.training):
+            return False          # incl. norm layers switched to eval() inside a training model: batch statistics only here
     first = backbone._stem[0]
     return first.out_channels in (32, 64) and first.kernel_size == (3, 3) and first.stride == (2, 2)
 
@@ -65,6 +66,12 @@ def network_supported(model):
         return False
     for m in head.modules():
         if isinstance(m, nn.GroupNorm) and not m.affine:
+            return False
+    for m in neck.modules():
+        if isinstance(m, nn.BatchNorm2d) and (m.momentum is None or not m.affine or not m.track_running_stats
+                                              or not m.training):
+            return False
+        if isinstance(m, nn.Conv2d) and not _conv_ok(m):
             return False
     return head.num_cls_channels + 4 <= 64
 

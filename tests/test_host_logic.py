@@ -273,3 +273,39 @@ def test_uint8_normalisation_shortcut_is_exact_for_all_256_inputs():
     ref = ((f / np.float32(255) - np.float32(0.5)) / np.float32(0.5)).astype(np.float16)
     fast = ((f * (np.float32(2) / np.float32(255))) - np.float32(1)).astype(np.float16)
     assert np.array_equal(ref.view(np.uint16), fast.view(np.uint16))
+
+
+def test_training_schedule_covers_every_parameter_once():
+    """train_engine.build_network: the hand-written training schedule (conv / norm / ReLU units + per-level output convs)
+    touches every parameter of the six shipped configurations exactly once (shared head towers deduplicated), taps and
+    residual wiring follow lfd_resnet.py:96-154 / :458-468; configurations outside its coverage are refused."""
+    from lfd_amd import train_engine as te
+    for name in configs.ARCHS:
+        m = configs.build_model(name).train()
+        assert te.network_supported(m), name
+        units, outs = te.build_network(m)
+        ps = te.network_params(units, outs)
+        assert len({id(p) for p in ps}) == len(ps)
+        assert {id(p) for p in ps} == {id(p) for p in m.parameters()}, name
+        acts = {0}
+        for u in units:
+            assert u.src in acts and (u.res is None or u.res in acts) and u.dst not in acts
+            acts.add(u.dst)
+        assert all(o.src in acts for o in outs)
+        assert sorted({o.level for o in outs}) == list(range(m._num_heads))
+    m = configs.build_model('WIDERFACE_LFD_S').train()
+    units, _ = te.build_network(m)
+    blk = [u for u in units if u.conv is m._backbone.stage0[0]._conv2][0]
+    ds = [u for u in units if u.conv is m._backbone.stage0[0]._downsample[0]][0]
+    assert blk.res == ds.dst and ds.relu is False and blk.relu is True          # identity = norm(conv1x1 s2(x)), no ReLU
+    plain = [u for u in units if u.conv is m._backbone.stage0[1]._conv2][0]
+    first = [u for u in units if u.conv is m._backbone.stage0[1]._conv1][0]
+    assert plain.res == first.src                                               # identity = the block input
+    m.eval()
+    assert not te.network_supported(m)            # BatchNorm in eval mode: running statistics, not this path
+    m.train()
+    m._backbone._stem[1].eval()
+    assert not te.supported(m._backbone)
+    m._backbone._stem[1].train()
+    m._head._conv_kernel_size = 3
+    assert not te.network_supported(m)
