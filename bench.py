@@ -198,6 +198,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
+    ap.add_argument('--max-candidates', type=int, default=8192)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -216,6 +217,8 @@ def main():
     configs.perturb_weights(model)
     model.eval().to(dev)
     model.use_graph = not args.no_graph
+    # candidate capacity per image (an image with more candidates raises its overflow flag in `counts`, checked below)
+    model.max_candidates = args.max_candidates
     gen = torch.Generator(device=dev).manual_seed(rank)
     x = (torch.rand(BATCH, H, W, 3, device=dev, generator=gen) * 2 - 1).half()      # resident NHWC fp16 frames
     meta = torch.tensor([[float(W), float(H), 1.0]] * BATCH, dtype=torch.float32, device=dev)
@@ -249,6 +252,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         counts = det.counts.cpu().numpy()
+        assert int(counts[:, 2].max()) == 0, 'candidate capacity overflow: raise --max-candidates'
 
         result = None
         if rank == 0:
@@ -262,7 +266,7 @@ def main():
                                        'backbone+neck+head (HIP MFMA convs) + decode + threshold + NMS, results on device',
                            'global_batch': world * BATCH, 'points_per_image': int(cls.shape[1]),
                            'candidates_per_image': float(counts[:, 0].mean()), 'kept_per_image': float(counts[:, 1].mean()),
-                           'score_thr': thr, 'iou_thr': 0.4, 'parallelism': 'image-parallel x%d, no collective' % world,
+                           'score_thr': thr, 'iou_thr': 0.4, 'max_candidates': int(model.max_candidates), 'parallelism': 'image-parallel x%d, no collective' % world,
                            'hip_graph': bool(model.use_graph),
                            'weights': 'random init (seed 666) + synthetic BN/GN/Scale perturbation (no checkpoints offline)'},
             }

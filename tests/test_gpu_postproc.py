@@ -216,3 +216,77 @@ def test_detect_zero_candidates_and_capacity_overflow():
                                  configs.WIDERFACE_RANGES, 'sigmoid', 'union', (64, 64), 1.0)
     dets, labels, _, K = oracle.multiclass_nms(bx, sc, 0.5, 0.4, False)
     assert K == P and len(res[1]) == len(labels)
+
+
+def _detect_both_paths(desc, cls, reg, meta, monkeypatch):
+    outs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('LFD_DETECT_FUSED', fused)
+        o = ops.detect_batched(desc, cls, reg, meta)
+        torch.cuda.synchronize()
+        outs.append(o)
+    return outs
+
+
+@pytest.mark.parametrize('C,agn,score_mode', [(1, False, 0), (6, False, 0), (6, True, 0), (5, False, 1)])
+def test_single_workgroup_detection_tail_equals_general_path_and_oracle(C, agn, score_mode, monkeypatch):
+    """k_detect_fused (opt-in LFD_DETECT_FUSED=1, capacity <= 512: whole tail of an image in one workgroup, intermediates in
+    LDS -- a measured negative result performance-wise, kept because its LDS-resident sort / mask / scan phases are the
+    building block of the planned two-launch tail) against the
+    five-kernel general path with the same capacity -- every output array bit for bit, incl. capacity overflow -- and
+    against the C oracle's multiclass_nms where nothing overflows.  Thresholds sweep the candidate count from 0 through
+    the 64-row block boundaries to beyond the capacity."""
+    rng = np.random.default_rng(40 + C + score_mode)
+    sizes, strides, ranges = [(40, 60), (20, 30), (10, 15)], [8, 16, 32], ((4, 20), (20, 40), (40, 80))
+    P = sum(h * w for h, w in sizes)
+    N = 4
+    Cc = C + 1 if score_mode == 1 else C
+    cls = torch.from_numpy(rng.normal(0, 2, (N, P, Cc)).astype(np.float32)).half().cuda()
+    reg = torch.from_numpy(rng.uniform(0.05, 1.5, (N, P, 4)).astype(np.float32)).half().cuda()
+    meta = torch.tensor([[480., 320., 1.0], [480., 320., 2.0], [300., 320., 1.0], [480., 200., 0.5]]).cuda()
+    sc_all = torch.sigmoid(cls.float()) if score_mode == 0 else torch.softmax(cls.float(), -1)[..., :C]
+    flat = np.sort(sc_all[0].cpu().numpy().reshape(-1))[::-1]
+    for target in (0, 1, 63, 64, 65, 200, 511, 512, 513, 900):
+        thr = float(flat[target]) if target < flat.size else 0.0
+        thr = min(thr, 0.999) if target else 1.5
+        desc = ops.make_detect_desc(sizes, strides, ranges, C, Cc, score_mode, 2, agn, 512, thr, 0.35)
+        a, b = _detect_both_paths(desc, cls, reg, meta, monkeypatch)
+        ca, cb = a.counts.cpu().numpy(), b.counts.cpu().numpy()
+        np.testing.assert_array_equal(ca, cb)
+        for n in range(N):
+            k = ca[n, 1]
+            for name in ('dets', 'labels', 'cand', 'point'):
+                assert torch.equal(getattr(a, name)[n, :k], getattr(b, name)[n, :k]), (target, n, name)
+        if score_mode == 0 and (ca[:, 2] == 0).all():
+            boxes, scores = ops.decode_all(desc, cls, reg, meta)
+            for n in range(N):
+                dets, labels, cand, K = oracle.multiclass_nms(boxes[n].cpu().numpy(), scores[n].cpu().numpy(), thr, 0.35, agn)
+                assert ca[n, 0] == K and ca[n, 1] == len(labels)
+                np.testing.assert_array_equal(a.cand[n, :len(labels)].cpu().numpy(), cand)
+                if len(labels):
+                    np.testing.assert_array_equal(a.dets[n, :len(labels)].cpu().numpy(), dets)
+
+
+def test_single_workgroup_tail_on_the_benchmark_shape(monkeypatch):
+    """WIDERFACE_LFD_S 1080p point grid (P = 43,620), 8 frames, ~256 candidates each, clustered boxes (heavy
+    suppression): both paths identical."""
+    rng = np.random.default_rng(9)
+    sizes = [(135, 240), (68, 120), (34, 60), (17, 30), (17, 30)]
+    strides, ranges = [8, 16, 32, 64, 64], configs.WIDERFACE_RANGES
+    P = sum(h * w for h, w in sizes)
+    cls = torch.from_numpy(rng.normal(-6, 1.5, (8, P, 1)).astype(np.float32))
+    hot = rng.integers(0, P - 40, 30)
+    for h in hot:                                  # clusters of neighbouring high-score points -> overlapping boxes
+        cls[:, h:h + 9] += 7.0
+    cls = cls.half().cuda()
+    reg = torch.from_numpy(rng.normal(0.0, 0.4, (8, P, 4)).astype(np.float32)).half().cuda()
+    meta = torch.tensor([[1920., 1080., 1.0]] * 8).cuda()
+    desc = ops.make_detect_desc(sizes, strides, ranges, 1, 1, 0, 0, False, 512, 0.5, 0.4)
+    a, b = _detect_both_paths(desc, cls, reg, meta, monkeypatch)
+    ca = a.counts.cpu().numpy()
+    np.testing.assert_array_equal(ca, b.counts.cpu().numpy())
+    assert (ca[:, 0] > 100).all() and (ca[:, 2] == 0).all() and (ca[:, 1] < ca[:, 0]).all()
+    for n in range(8):
+        k = ca[n, 1]
+        for name in ('dets', 'labels', 'cand', 'point'):
+            assert torch.equal(getattr(a, name)[n, :k], getattr(b, name)[n, :k]), (n, name)

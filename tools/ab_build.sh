@@ -7,7 +7,7 @@ set -e
 OUT=$(realpath -m "$1"); shift
 cd "$(dirname "$0")/../lfd-a-light-and-fast-detector_amd/csrc"
 B=$(mktemp -d)
-for f in api postproc losses targets conv conv64 stem stem_fused head; do
+for f in $(sed -n 's/^SRCS *= *//p' Makefile | sed 's/\.hip//g'); do
   extra=""
   [ $f = stem_fused ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   [ $f = head ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
