@@ -337,8 +337,8 @@ class EnginePlan(object):
         """`after`: optional {number_of_convs_done: callable} hooks (used to fork the level-0 head)."""
         l = lib()
         sp = stream_ptr()
-        if self.stem_fused is not None and not (fmt == 1 and self.stem_fused[0] == 64):
-            # two-kernel stem for the formats / widths the fused kernel does not cover
+        if self.stem_fused is not None and not (fmt in (1, 2) and self.stem_fused[0] == 64):
+            # two-kernel stem for the formats / widths k_stem2x does not cover (NCHW fp32 frames, 32-channel stems)
             c0, w1, b1, w2, b2 = self.stem_first
             mid = st.stem_mid(self)
             check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(mid), sp),
