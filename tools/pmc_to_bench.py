@@ -5,10 +5,11 @@ raw = json.load(open(sys.argv[1]))
 def wavg(keys):
     n = sum(raw[k]['launches_sampled'] for k in keys if k in raw)
     return round(sum(raw[k]['hbm_bytes_per_launch'] * raw[k]['launches_sampled'] for k in keys if k in raw) / n) if n else None
-fwd = raw['k_stem2x']['launches_sampled'] if 'k_stem2x' in raw else None
+stem = [k for k in raw if k.startswith('k_stem2x')]      # k_stem2x<false> (fp16 frames) / k_stem2x<true> (uint8 frames)
+fwd = sum(raw[k]['launches_sampled'] for k in stem) or None
 out = {
     'conv3x3_s1_64to64 (k_conv)': wavg(['k_conv<cin=64,k=3,s=1,nct=2>', 'k_conv<cin=64,k=3,s=1,nct=2,res>']),
-    'whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem_fused)': wavg(['k_stem2x']),
+    'whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem_fused)': wavg(stem),
     'conv3x3_s2_64to64+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=2,ds>']),
     'conv3x3_s2_64to128+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=4,ds>']),
     'conv3x3_s1_128to128 (k_conv)': wavg(['k_conv<cin=128,k=3,s=1,nct=4>', 'k_conv<cin=128,k=3,s=1,nct=4,res>']),
