@@ -100,6 +100,7 @@ struct DecodeParams {
   const void* cls;
   const void* reg;
   const float* meta;  // [N,3] = clampW, clampH, resize_scale
+  int lds_stride;     // > 0: softmax rows of a block are staged through LDS with this (odd) float stride
 };
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
@@ -154,14 +155,47 @@ __device__ __forceinline__ float4 decode_box(const DecodeParams& d, int n, int p
   return make_float4(x1 / sc, y1 / sc, x2 / sc, y2 / sc);
 }
 
+// Softmax models (46 channels for TT100K): a thread-per-point sweep reads its 184-byte row with a 184-byte lane stride --
+// every load instruction touches 64 cache lines.  The rows of a block's 256 points are one contiguous region: load it
+// coalesced into LDS (odd float stride: conflict-free thread-per-row reads), then evaluate exactly the expressions of
+// softmax_stats / score_of (same order, same expf / divide) from there.
+__device__ __forceinline__ const float* stage_rows(const DecodeParams& d, int n, int blk, float* s_rows) {
+  const int base_p = blk * kBlock;
+  const int rows = (d.P - base_p) < kBlock ? (d.P - base_p) : kBlock;
+  const int64_t g0 = ((int64_t)n * d.P + base_p) * d.Cc;
+  const int total = rows * d.Cc;
+  for (int i = threadIdx.x; i < total; i += kBlock) {
+    const int r = i / d.Cc, c = i - r * d.Cc;
+    s_rows[r * d.lds_stride + c] = lfd_load_f(d.cls, g0 + i, d.in_dtype);
+  }
+  __syncthreads();
+  return s_rows + threadIdx.x * d.lds_stride;
+}
+__device__ __forceinline__ void softmax_stats_row(const DecodeParams& d, const float* row, float* mx, float* sum) {
+  float m = -INFINITY;
+  for (int c = 0; c < d.Cc; ++c) m = fmaxf(m, row[c]);
+  float s = 0.f;
+  for (int c = 0; c < d.Cc; ++c) s += expf(row[c] - m);
+  *mx = m;
+  *sum = s;
+}
+
 // ------------------------------------------------------------------ count / scatter
 __global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcounts, int nblk,
                                                   uint32_t* maxord, int* counts) {
+  extern __shared__ float s_rows[];
   __shared__ int smem[8];
   const int n = blockIdx.y, blk = blockIdx.x;
   const int p = blk * kBlock + threadIdx.x;
   int cnt = 0;
-  if (p < d.P) {
+  if (d.lds_stride > 0) {
+    const float* rowp = stage_rows(d, n, blk, s_rows);
+    if (p < d.P) {
+      float mx, sum;
+      softmax_stats_row(d, rowp, &mx, &sum);
+      for (int c = 0; c < d.C; ++c) cnt += (expf(rowp[c] - mx) / sum) > d.score_thr;
+    }
+  } else if (p < d.P) {
     const int64_t row = (int64_t)n * d.P + p;
     float mx = 0.f, sum = 1.f;
     if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
@@ -180,6 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcoun
 
 __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* blockcounts, int nblk,
                                                     SegBuffers b, int* counts) {
+  extern __shared__ float s_rows[];
   __shared__ int smem[8];
   __shared__ uint32_t smax[kBlock / 64];
   const int n = blockIdx.y, blk = blockIdx.x;
@@ -203,7 +238,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
   int cnt = 0;
   float mx = 0.f, sum = 1.f;
   int64_t row = 0;
-  if (p < d.P) {
+  const float* rowp = nullptr;
+  if (d.lds_stride > 0) {
+    rowp = stage_rows(d, n, blk, s_rows);
+    if (p < d.P) {
+      softmax_stats_row(d, rowp, &mx, &sum);
+      for (int c = 0; c < d.C; ++c) cnt += (expf(rowp[c] - mx) / sum) > d.score_thr;
+    }
+  } else if (p < d.P) {
     row = (int64_t)n * d.P + p;
     if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
     for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
@@ -215,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
     const float4 box = decode_box(d, n, p);
     bool wrote = false;
     for (int c = 0; c < d.C; ++c) {
-      const float s = score_of(d, row, c, mx, sum);
+      const float s = rowp ? expf(rowp[c] - mx) / sum : score_of(d, row, c, mx, sum);
       if (s > d.score_thr) {
         if (off < b.cap) {
           const int64_t o = (int64_t)n * b.cap + off;
@@ -867,6 +909,8 @@ int fill_decode_params(const lfd_detect_desc_t* desc, int32_t in_dtype, const vo
   d->cls = cls;
   d->reg = reg;
   d->meta = meta;
+  // softmax score maps: stage the class rows of a block through LDS (odd stride; 256 rows must fit 64 KB)
+  d->lds_stride = (desc->score_mode == 1 && (desc->num_cls_channels | 1) * kBlock * 4 <= 64 * 1024) ? (desc->num_cls_channels | 1) : 0;
   return LFD_OK;
 }
 
@@ -999,9 +1043,10 @@ int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void*
   b.k_host = 0;
   b.class_agnostic = desc->class_agnostic ? 1 : 0;
   b.iou_thr = desc->iou_thr;
-  hipLaunchKernelGGL(k_count, dim3(nblk, batch), dim3(kBlock), 0, st, d, blockcounts, nblk, b.maxord, out_counts);
+  const size_t rows_lds = d.lds_stride > 0 ? (size_t)d.lds_stride * kBlock * sizeof(float) : 0;
+  hipLaunchKernelGGL(k_count, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b.maxord, out_counts);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scatter, dim3(nblk, batch), dim3(kBlock), 0, st, d, blockcounts, nblk, b, out_counts);
+  hipLaunchKernelGGL(k_scatter, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b, out_counts);
   LFD_CHECK_LAUNCH();
   ScanOut o{};
   o.dets = out_dets;
