@@ -760,31 +760,60 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
     b_off[r] = kp * S * C::PITCH + (ih * 32 + 16 * grp + 4 * (i16 & 3)) * 2;
   }
   const int tiles = a.n * a.tiles_y * a.tiles_x;
-  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+  // Staging in two halves: global -> registers (tile_load) and registers -> LDS (tile_store).  Stride-1 variants keep the
+  // NEXT tile's loads in flight while the current tile is contracted (4 + 6 uint4 per thread); the stride-2 halo tile is
+  // 18 uint4 per thread -- too many registers next to the 144 accumulators -- and stays synchronous.
+  constexpr int NDY = (C::TH * C::TW * 8 + kThreads - 1) / kThreads;
+  constexpr int NX = (C::XH * C::XW * 8 + kThreads - 1) / kThreads;
+  constexpr bool PF = (S == 1);
+  uint4 rdy[NDY], rx[NX];
+  auto tile_load = [&](int t) {
     const int tx = t % a.tiles_x;
     const int q = t / a.tiles_x;
     const int ty = q % a.tiles_y;
     const int img = q / a.tiles_y;
-    // ---- stage dy tile [TH*TW][64] and x halo tile [XH*XW][64] (zero outside the maps / channel range)
-    for (int i = tid; i < C::TH * C::TW * 8; i += kThreads) {
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+      const int i = tid + j * kThreads;
       const int c8 = i & 7, p = i >> 3;
       const int oy = ty * C::TH + p / C::TW, ox = tx * C::TW + p % C::TW;
-      uint4 v = make_uint4(0, 0, 0, 0);
       const int co = cb * 64 + c8 * 8;
-      if (oy < a.ho && ox < a.wo && co < a.cout)
-        v = *reinterpret_cast<const uint4*>(a.dy + (((int64_t)img * a.ho + oy) * a.wo + ox) * a.cout + co);
-      *reinterpret_cast<uint4*>(sdy + p * C::PITCH + c8 * 16) = v;
+      const bool ok = i < C::TH * C::TW * 8 && oy < a.ho && ox < a.wo && co < a.cout;
+      const int64_t off = ok ? ((((int64_t)img * a.ho + oy) * a.wo + ox) * a.cout + co) : 0;
+      const uint4 v = *reinterpret_cast<const uint4*>(a.dy + off);       // unconditional (clamped) load: no branch
+      rdy[j] = ok ? v : make_uint4(0, 0, 0, 0);
     }
-    for (int i = tid; i < C::XH * C::XW * 8; i += kThreads) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + j * kThreads;
       const int c8 = i & 7, p = i >> 3;
       const int iy = ty * C::TH * S - C::PAD + p / C::XW, ix = tx * C::TW * S - C::PAD + p % C::XW;
-      uint4 v = make_uint4(0, 0, 0, 0);
       const int ci = ib * 64 + c8 * 8;
-      if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w && ci < a.cin)
-        v = *reinterpret_cast<const uint4*>(a.x + (((int64_t)img * a.h + iy) * a.w + ix) * a.cin + ci);
-      *reinterpret_cast<uint4*>(sx + p * C::PITCH + c8 * 16) = v;
+      const bool ok = i < C::XH * C::XW * 8 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w && ci < a.cin;
+      const int64_t off = ok ? ((((int64_t)img * a.h + iy) * a.w + ix) * a.cin + ci) : 0;
+      const uint4 v = *reinterpret_cast<const uint4*>(a.x + off);
+      rx[j] = ok ? v : make_uint4(0, 0, 0, 0);
     }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < C::TH * C::TW * 8) *reinterpret_cast<uint4*>(sdy + (i >> 3) * C::PITCH + (i & 7) * 16) = rdy[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < C::XH * C::XW * 8) *reinterpret_cast<uint4*>(sx + (i >> 3) * C::PITCH + (i & 7) * 16) = rx[j];
+    }
+  };
+  int t = blockIdx.x;
+  if (PF && t < tiles) tile_load(t);
+  for (; t < tiles; t += gridDim.x) {
+    if (!PF) tile_load(t);
+    tile_store();
     __syncthreads();
+    if (PF && t + (int)gridDim.x < tiles) tile_load(t + gridDim.x);     // in flight during the contraction
     if (active) {
 #pragma unroll 1
       for (int py = 0; py < C::TH; ++py) {
@@ -1039,7 +1068,8 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
   // as many workgroups as the partial buffer holds (1x1: 2048, 3x3 64x64: 1024, 3x3 128x128: 256): several per CU hide
   // the synchronous tile staging behind each other's MFMAs
   int nwg = (kWgradMaxWg * 4 * 9) / (nblk * ks * ks);
-  if (ks == 3 && nwg > 512) nwg = 512;   // the fixed-order sum of the partials costs 147 KB of traffic per workgroup
+  if (ks == 3 && nwg > (stride == 1 ? 256 : 512)) nwg = stride == 1 ? 256 : 512;   // the fixed-order sum of the partials costs 147 KB of traffic per workgroup;
+                                                                                  // stride 1 prefetches the next tile in registers and needs no second workgroup per CU
   if (nwg > kWgradWgCap) nwg = kWgradWgCap;
   if (nwg > tiles) nwg = tiles;
   int rc;
