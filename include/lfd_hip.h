@@ -328,6 +328,16 @@ LFD_API size_t lfd_train_workspace_bytes(void);
  * padded row count, multiple of 32); mode 1: the data-gradient conv (channel roles swapped, taps flipped). */
 LFD_API int lfd_pack_conv_weight_train_f16(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ks, int32_t mode,
                                    int32_t rows_valid, void* packed, lfd_stream_t stream);
+/* The same for many convs in one launch (the weights change every iteration: all forward packs at the start of the
+ * forward, all data-gradient packs at the start of the backward).  `jobs_device`: table in device memory, sorted by
+ * first_vec (= running sum of the jobs' output vectors of 8 halfs); fields as in lfd_pack_conv_weight_train_f16. */
+typedef struct lfd_pack_job {
+  const float* w;
+  void* out;
+  int32_t cout, cin, ks, mode, rows_valid, first_vec;
+} lfd_pack_job_t;
+LFD_API int lfd_pack_conv_weights_train_f16(const lfd_pack_job_t* jobs_device, int32_t njobs, int32_t total_vecs,
+                                    lfd_stream_t stream);
 /* batch statistics of y [pixels, channels]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(biased var + eps)
  * (F.batch_norm training=True); running_mean / running_var (nullable) are updated with `momentum` and
  * the unbiased variance like nn.BatchNorm2d. */

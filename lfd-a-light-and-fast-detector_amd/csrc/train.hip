@@ -44,13 +44,10 @@ __device__ __forceinline__ void st8(__half* p, int64_t vec, h8 h) {
 //   out[ct][kstep][lane][e],  lane = 32*half + co_l,  kstep = (r*ks + s)*(cin/16) + q,  ci = 16q + 8*half + e.
 // mode 1 packs the data-gradient conv instead: W'[co'][ci'][r][s] = W[ci'][co'][ks-1-r][ks-1-s] (co' over the forward
 // conv's input channels).  Rows >= rows_valid of the LOGICAL conv are zero (output convs padded to 64 rows).
-__global__ __launch_bounds__(kThreads) void k_pack_weight(const float* __restrict__ w, int cout, int cin, int ks,
-                                                         int mode, int rows_valid, __half* __restrict__ out) {
-  const int lc = mode ? cin : cout, li = mode ? cout : cin;     // logical conv: lc output rows, li input channels
+__device__ __forceinline__ void pack_vec(const float* __restrict__ w, int cout, int cin, int ks, int mode, int rows_valid,
+                                         __half* __restrict__ out, int v) {
+  const int li = mode ? cout : cin;                              // logical conv: input channels
   const int nq = li / 16, nk = ks * ks * nq;
-  const int total = (lc / 32) * nk * 64;
-  const int v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= total) return;
   const int lane = v & 63, kstep = (v >> 6) % nk, ct = (v >> 6) / nk;
   const int half = lane >> 5, co = ct * 32 + (lane & 31);
   const int q = kstep % nq, tap = kstep / nq, r = tap / ks, sx = tap - r * ks;
@@ -65,6 +62,27 @@ __global__ __launch_bounds__(kThreads) void k_pack_weight(const float* __restric
     o[e] = (_Float16)f;
   }
   st8(out, v, o);
+}
+
+__global__ __launch_bounds__(kThreads) void k_pack_weight(const float* __restrict__ w, int cout, int cin, int ks,
+                                                         int mode, int rows_valid, __half* __restrict__ out) {
+  const int lc = mode ? cin : cout, li = mode ? cout : cin;     // logical conv: lc output rows, li input channels
+  const int total = (lc / 32) * ks * ks * (li / 16) * 64;
+  const int v = blockIdx.x * kThreads + threadIdx.x;
+  if (v < total) pack_vec(w, cout, cin, ks, mode, rows_valid, out, v);
+}
+
+// all packs of a pass in ONE launch: job table in device memory (first_vec ascending), binary search per thread
+__global__ __launch_bounds__(kThreads) void k_pack_weights(const lfd_pack_job_t* __restrict__ jobs, int njobs, int total) {
+  const int v = blockIdx.x * kThreads + threadIdx.x;
+  if (v >= total) return;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_vec <= v) lo = mid; else hi = mid - 1;
+  }
+  const lfd_pack_job_t j = jobs[lo];
+  pack_vec(j.w, j.cout, j.cin, j.ks, j.mode, j.rows_valid, (__half*)j.out, v - j.first_vec);
 }
 
 inline unsigned grid_for_vecs(int64_t vecs) {
@@ -908,6 +926,18 @@ int lfd_pack_conv_weight_train_f16(const float* weight_oihw, int32_t cout, int32
   const int total = (lc / 32) * ks * ks * (li / 16) * 64;
   hipLaunchKernelGGL(k_pack_weight, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, weight_oihw, cout, cin,
                      ks, mode, rows_valid, (__half*)packed);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_pack_conv_weights_train_f16(const lfd_pack_job_t* jobs_device, int32_t njobs, int32_t total_vecs,
+                                    lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (njobs < 0 || total_vecs < 0) return LFD_ERR_INVALID_ARGUMENT;
+  if (njobs == 0 || total_vecs == 0) return LFD_OK;
+  if (!jobs_device) return LFD_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_pack_weights, dim3((total_vecs + kThreads - 1) / kThreads), dim3(kThreads), 0, st, jobs_device, njobs,
+                     total_vecs);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

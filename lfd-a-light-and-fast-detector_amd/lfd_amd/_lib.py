@@ -77,6 +77,12 @@ class LossDesc(C.Structure):
                 ('cls_weighted', C.c_int32), ('reg_weighted', C.c_int32)]
 
 
+class PackJob(C.Structure):
+    """lfd_pack_job_t"""
+    _fields_ = [('w', C.c_void_p), ('out', C.c_void_p), ('cout', C.c_int32), ('cin', C.c_int32), ('ks', C.c_int32),
+                ('mode', C.c_int32), ('rows_valid', C.c_int32), ('first_vec', C.c_int32)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
@@ -110,6 +116,7 @@ _SIGNATURES = {
     'lfd_bn_train_stats_f16': (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_bn_train_apply_f16': (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     'lfd_bn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P, _P]),
+    'lfd_pack_conv_weights_train_f16': (C.c_int, [_P, _I32, _I32, _P]),
     'lfd_pack_conv_weight_train_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_gn_train_stats_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _F, _P, _SZ, _P, _P]),
     'lfd_gn_train_apply_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),

@@ -523,6 +523,44 @@ def pack_conv_weight_train(weight, data_gradient=False, rows=None):
     return out
 
 
+class PackBatch(object):
+    """All weight packs of a pass in ONE launch (lfd_pack_conv_weights_train_f16): the job table (weight pointer, output
+    pointer, shape) is built and uploaded once -- the parameters live in a flat buffer, their addresses do not change --
+    and `run()` re-packs the current values.  outs[i] is the packed fp16 tensor of weights[i]."""
+
+    def __init__(self, weights, data_gradient):
+        dev = weights[0].device
+        require_cuda(weights[0], 'PackBatch')
+        self.key = tuple(w.data_ptr() for w in weights)
+        self.outs = []
+        jobs = (_lib.PackJob * len(weights))()
+        first = 0
+        for i, w in enumerate(weights):
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise RuntimeError('PackBatch: contiguous float32 OIHW weights expected')
+            cout, cin, ks, _ = w.shape
+            lc, li = (cin, cout) if data_gradient else (cout, cin)
+            out = torch.empty((lc // 32, ks * ks * (li // 16), 64, 8), dtype=torch.float16, device=dev)
+            j = jobs[i]
+            j.w, j.out = w.data_ptr(), out.data_ptr()
+            j.cout, j.cin, j.ks, j.mode = cout, cin, ks, int(bool(data_gradient))
+            j.rows_valid, j.first_vec = (lc if data_gradient else cout), first
+            first += out.numel() // 8
+            self.outs.append(out)
+        self.total, self.njobs = first, len(weights)
+        self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.device = dev
+
+    def matches(self, weights):
+        return self.key == tuple(w.data_ptr() for w in weights)
+
+    def run(self):
+        with torch.cuda.device(self.device):
+            check(lib().lfd_pack_conv_weights_train_f16(ptr(self.table), self.njobs, self.total, stream_ptr()),
+                  'lfd_pack_conv_weights_train_f16')
+        return self.outs
+
+
 def conv_wgrad(x, dy, ks, stride, inv_scale, out=None, accumulate=False):
     """dW [cout,cin,ks,ks] fp32 of conv(x, W) with pad ks//2 given dL/dy (scaled by 1/inv_scale); += into `out` if
     accumulate."""

@@ -182,14 +182,36 @@ def _dgrad_weight(w):
     return ops.pack_conv_weight_train(w, data_gradient=True)
 
 
-class _Packs(object):
-    """fp16 fragment packs of the conv weights, one launch each, shared by the pyramid levels within a pass"""
+_pack_batches = {}
 
-    def __init__(self):
+
+class _Packs(object):
+    """fp16 fragment packs of the conv weights of a pass.  With `units` given, every distinct conv weight of the schedule
+    is packed by ONE launch up front (ops.PackBatch, job table cached per schedule); other weights (the concatenated
+    output convs) are packed individually on first use.  Shared by the pyramid levels within a pass."""
+
+    def __init__(self, units=None, data_gradient=False):
         self.c = {}
+        if units:
+            ws, seen = [], set()
+            for u in units:
+                w = u.conv.weight
+                if not u.first and id(w) not in seen:
+                    seen.add(id(w))
+                    ws.append(w.detach())
+            if ws:
+                key = (id(units), data_gradient)
+                pb = _pack_batches.get(key)
+                if pb is None or not pb.matches(ws):
+                    if len(_pack_batches) > 32:
+                        _pack_batches.clear()
+                    pb = ops.PackBatch(ws, data_gradient)
+                    _pack_batches[key] = pb
+                for w, out in zip(ws, pb.run()):
+                    self.c[(w.data_ptr(), data_gradient)] = out
 
     def __call__(self, w, data_gradient=False):
-        k = (id(w), data_gradient)
+        k = (w.data_ptr(), data_gradient)
         if k not in self.c:
             self.c[k] = ops.pack_conv_weight_train(w, data_gradient=data_gradient)
         return self.c[k]
@@ -210,7 +232,7 @@ def forward(units, tap_ids, x):
     acts = {0: x}
     tape = []
     zeros = _Zeros(x.device)
-    packs = _Packs()
+    packs = _Packs(units, False)
     for u in units:
         conv, norm = u.conv, u.norm
         xin = acts[u.src]
@@ -270,7 +292,7 @@ def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
     grads = dict(grads)
     store = store if store is not None else _GradStore()
     zeros = _Zeros(acts[0].device)
-    packs = _Packs()
+    packs = _Packs(units, True)
     for ui in range(len(units) - 1, -1, -1):
         u = units[ui]
         dz = grads.pop(u.dst, None)
