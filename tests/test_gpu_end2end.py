@@ -3,6 +3,7 @@ own fp32 forward.  The forwards differ by fp16 storage, so detections are matche
 where a score sits within the forward tolerance of the threshold the candidate set may differ --
 those are counted and bounded, not hidden."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -93,3 +94,31 @@ def test_train_step_runs_and_decreases_loss():
         losses.append(lo['loss_values']['loss'])
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     del rng
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py (the driver's entry point): exactly one JSON line on stdout with the contract's keys, the roofline object of
+    the dominant kernel and -- at N = 1 -- the CPU baseline and the bs-1 latency objects."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'latency_bs1'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f16' and d['data'] == 'synthetic'
+    assert d['value'] > 0 and abs(d['value'] - 8 / d['ms_per_step'] * 1e3) < 0.01 * d['value']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and 0 < r['frac'] < 1
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 2e-3 and 'traffic' in r
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and c['sample']
+    assert d['latency_bs1']['forward_ms']['p50'] > 0 and d['latency_bs1']['end_to_end_ms']['p50'] > 0
