@@ -75,7 +75,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
                                                              stream_ptr()), 'stem'))
         fl = (conv_flops(n, h1, w1_, 3, c0, 3) + conv_flops(n, h1, w1_, c0, c0, 1) +
               conv_flops(n, so.shape[1], so.shape[2], c0, c0, 3) + conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1))
-        add('whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem_fused)', us, fl, x.numel() * x.element_size() + so.numel() * 2)
+        add('whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem2x)', us, fl, x.numel() * x.element_size() + so.numel() * 2)
     else:
         c0, w1, b1, w2, b2 = plan.stem_first
         so = st.bufs[plan.stem_out]
@@ -118,7 +118,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
         per_tower = 3 * 2 * px * lv.cin * 128 + (3 + 2) * 2 * px * 128 * 128 + 2 * px * 128 * 32
         hf += per_tower * len(lv.towers)
         hb += (3 * px * lv.cin * 2) * len(lv.towers) + px * (plan.cls_channels + 4) * 4
-    add('neck+head 3-pass GN recompute (k_head x3 + finalize x2 per level)', us, hf, hb)
+    add('neck+head 3-pass GN recompute (k_head2 x3 + k_gn_finalize x2)', us, hf, hb)
     return classes
 
 

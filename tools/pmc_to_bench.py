@@ -9,13 +9,13 @@ stem = [k for k in raw if k.startswith('k_stem2x')]      # k_stem2x<false> (fp16
 fwd = sum(raw[k]['launches_sampled'] for k in stem) or None
 out = {
     'conv3x3_s1_64to64 (k_conv)': wavg(['k_conv<cin=64,k=3,s=1,nct=2>', 'k_conv<cin=64,k=3,s=1,nct=2,res>']),
-    'whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem_fused)': wavg(stem),
+    'whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem2x)': wavg(stem),
     'conv3x3_s2_64to64+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=2,ds>']),
     'conv3x3_s2_64to128+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=4,ds>']),
     'conv3x3_s1_128to128 (k_conv)': wavg(['k_conv<cin=128,k=3,s=1,nct=4>', 'k_conv<cin=128,k=3,s=1,nct=4,res>']),
 }
 if fwd:   # the head is one bench "launch" = all k_head / k_gn_finalize launches of a forward
-    out['neck+head 3-pass GN recompute (k_head x3 + finalize x2 per level)'] = round(sum(
+    out['neck+head 3-pass GN recompute (k_head2 x3 + k_gn_finalize x2)'] = round(sum(
         v['hbm_bytes_per_launch'] * v['launches_sampled'] for k, v in raw.items() if k.startswith('k_head') or k == 'k_gn_finalize') / fwd)
 out['_note'] = ('HBM bytes per launch = 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE, separate --pmc '
                 'passes of `bench.py --steps 4 --no-graph`, averaged over the launches of each kernel class; raw per-kernel numbers in '
