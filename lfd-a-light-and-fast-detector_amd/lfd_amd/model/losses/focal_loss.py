@@ -1,46 +1,54 @@
-"""FocalLoss -- mirror of lfd/model/losses/focal_loss.py:12-92 over the HIP focal kernels."""
+"""FocalLoss -- host-side mirror of the reference's operator interface (lfd/model/losses/focal_loss.py:12-92):
+`FocalLoss(use_sigmoid, gamma, alpha, reduction, loss_weight)`, `sigmoid_focal_loss(pred, target, weight, ...)` and the
+autograd function over the extension module's forward / backward -- which here are the HIP kernels of csrc/losses.hip
+behind liblfd_hip.so (no CPU implementation, like the reference's CUDA-only extension).
+"""
+import torch
 import torch.nn as nn
-from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .libs import sigmoid_focal_loss_ext
+from .libs import sigmoid_focal_loss_ext as _ext
 from .utils import weight_reduce_loss
 
 __all__ = ['FocalLoss', 'sigmoid_focal_loss']
 
 
-class SigmoidFocalLossFunction(Function):
+class SigmoidFocalLossFunction(torch.autograd.Function):
+    """elementwise loss [N, C] of logits [N, C] against integer labels [N] (label C = background)"""
+
     @staticmethod
-    def forward(ctx, input, target, gamma=2.0, alpha=0.25):
-        ctx.save_for_backward(input, target)
-        ctx.num_classes, ctx.gamma, ctx.alpha = input.shape[1], gamma, alpha
-        return sigmoid_focal_loss_ext.forward(input, target, input.shape[1], gamma, alpha)
+    def forward(ctx, logits, labels, gamma=2.0, alpha=0.25):
+        channels = logits.shape[1]
+        ctx.hyper = (channels, gamma, alpha)
+        ctx.save_for_backward(logits, labels)
+        return _ext.forward(logits, labels, channels, gamma, alpha)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, d_loss):
-        input, target = ctx.saved_tensors
-        d_input = sigmoid_focal_loss_ext.backward(input, target, d_loss.contiguous(), ctx.num_classes, ctx.gamma,
-                                                  ctx.alpha)
-        return d_input, None, None, None, None
+    def backward(ctx, grad_losses):
+        channels, gamma, alpha = ctx.hyper
+        logits, labels = ctx.saved_tensors
+        grad_logits = _ext.backward(logits, labels, grad_losses.contiguous(), channels, gamma, alpha)
+        return grad_logits, None, None, None, None
 
 
 def sigmoid_focal_loss(pred, target, weight=None, gamma=2.0, alpha=0.25, reduction='mean', avg_factor=None):
-    loss = SigmoidFocalLossFunction.apply(pred, target, gamma, alpha)
-    if weight is not None:
-        weight = weight.view(-1, 1)
-    return weight_reduce_loss(loss, weight, reduction, avg_factor)
+    per_element = SigmoidFocalLossFunction.apply(pred, target, gamma, alpha)
+    per_row_weight = None if weight is None else weight.view(-1, 1)
+    return weight_reduce_loss(per_element, per_row_weight, reduction, avg_factor)
 
 
 class FocalLoss(nn.Module):
     def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0):
         super().__init__()
         assert use_sigmoid is True, 'Only sigmoid focal loss supported now.'
-        self.use_sigmoid, self.gamma, self.alpha = use_sigmoid, gamma, alpha
+        self.use_sigmoid = use_sigmoid
+        self.gamma, self.alpha = gamma, alpha
         self.reduction, self.loss_weight = reduction, loss_weight
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         assert reduction_override in (None, 'none', 'mean', 'sum')
-        reduction = reduction_override if reduction_override else self.reduction
-        return self.loss_weight * sigmoid_focal_loss(pred, target, weight, gamma=self.gamma, alpha=self.alpha,
-                                                     reduction=reduction, avg_factor=avg_factor)
+        how = self.reduction if not reduction_override else reduction_override
+        loss = sigmoid_focal_loss(pred, target, weight, gamma=self.gamma, alpha=self.alpha, reduction=how,
+                                  avg_factor=avg_factor)
+        return self.loss_weight * loss

@@ -23,24 +23,27 @@ class SimpleNeck(nn.Module):
         self._num_input_strides_list = num_input_strides_list
         self._norm_cfg, self._activation_cfg = norm_cfg, activation_cfg
         self._num_inputs = len(num_input_channels_list)
-        for i, cin in enumerate(num_input_channels_list):
-            layers = [nn.Conv2d(cin, num_neck_channels, kernel_size=1, stride=1, padding=0, bias=norm_cfg is None)]
-            if norm_cfg is not None:
-                layers.append(build_norm(norm_cfg, num_neck_channels))
-            layers.append(build_activation(activation_cfg))
-            setattr(self, 'neck%d' % i, nn.Sequential(*layers))
+        for level, cin in enumerate(num_input_channels_list):
+            self.add_module('neck%d' % level, self._level(cin))
         self._init_weights()
 
+    def _level(self, cin):
+        """conv1x1 (bias only without a norm) -> norm -> activation, as one nn.Sequential (keys `neck{i}.0.weight`, ...)"""
+        mods = [nn.Conv2d(cin, self._num_neck_channels, kernel_size=1, stride=1, padding=0, bias=self._norm_cfg is None)]
+        if self._norm_cfg is not None:
+            mods.append(build_norm(self._norm_cfg, self._num_neck_channels))
+        mods.append(build_activation(self._activation_cfg))
+        return nn.Sequential(*mods)
+
     def _init_weights(self):
-        """simple_neck.py:51-61."""
+        """simple_neck.py:51-61: kaiming_normal_(fan_out, relu) convs with zero bias, (1, 0) norms."""
         for m in self.modules():
-            if isinstance(m, nn.Conv2d):
+            if isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                for t, v in ((m.weight, 1), (m.bias, 0)):
+                    if t is not None:
+                        nn.init.constant_(t, v)
+            elif isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
-                if m.weight is not None:
-                    nn.init.constant_(m.weight, 1)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
