@@ -55,3 +55,33 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_nms_f32(None, -1, 0.5, None, None, None, 0, None) == -1
     assert l.lfd_conv2d_nhwc_f16(None, None, None, None, None, None, None, None, None, None) == -1
     assert l.lfd_sigmoid_focal_loss_fwd(None, None, 4, 0, 2.0, 0.25, None, 0, None) == -1
+
+
+def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
+    """Every struct of include/lfd_hip.h that crosses the ABI by pointer: sizeof and the offset of every field as gcc sees
+    them == the ctypes mirrors in lfd_amd/_lib.py (a drifted mirror would silently scramble descriptors)."""
+    import ctypes as C
+    import subprocess
+    from conftest import ROOT
+    from lfd_amd import _lib
+    pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc, 'lfd_conv_chain_layer_t': _lib.ConvChainLayer,
+             'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
+             'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob}
+    header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lfd_hip.h"', 'int main(void) {']
+    for cname, mirror in pairs.items():
+        assert cname in header, cname
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in mirror._fields_:
+            cfield = 'in' if fname == 'in_' else fname
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, cfield))
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, mirror in pairs.items():
+        assert int(got[cname]) == C.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert int(got['%s.%s' % (cname, fname)]) == getattr(mirror, fname).offset, (cname, fname)
