@@ -181,6 +181,13 @@ LFD_API int lfd_cross_entropy_fwd_f32(const float* logits, const int64_t* labels
 LFD_API int lfd_cross_entropy_bwd_f32(const float* logits, const int64_t* labels, const float* d_loss, int64_t m,
                               int32_t channels, float* d_logits, lfd_stream_t stream);
 
+/* GIoU / DIoU / CIoU losses of aligned box pairs (lfd/model/losses/iou_loss.py:127-169, :172-223, :226-283; the other
+ * members of LFD's IoU-type regression-loss family, lfd.py:64-66): kind 1 | 2 | 3; loss[n] and -- when
+ * d_loss_d_pred != NULL -- the gradient [n,4] w.r.t. the predicted xyxy box, obtained by forward-mode
+ * differentiation of the reference expression inside the kernel (max / min / clamp route like autograd). */
+LFD_API int lfd_box_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float eps, float* loss,
+                     float* d_loss_d_pred, lfd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused LFD.get_loss (lfd/model/lfd.py:284-395): replaces the boolean gathers (green rows :309-315, positive
  * rows :319-321), the label construction (:328), FocalLoss / CrossEntropyLoss + IoULoss on the gathered rows

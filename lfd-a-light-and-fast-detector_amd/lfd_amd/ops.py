@@ -195,6 +195,26 @@ def iou_loss_backward(pred, target, d_loss, eps):
     return out
 
 
+BOX_LOSS_KINDS = {'giou': 1, 'diou': 2, 'ciou': 3}
+
+
+def box_loss(pred, target, kind, eps, want_grad=True):
+    """GIoU / DIoU / CIoU loss of aligned xyxy box pairs [n,4] -> (loss [n], d loss / d pred [n,4] or None), one launch
+    (lfd_box_loss_f32: the gradient comes from forward-mode differentiation inside the kernel)."""
+    require_cuda(pred, 'box_loss')
+    p = pred.detach().contiguous().float()
+    t = target.detach().contiguous().float()
+    if p.shape != t.shape or p.dim() != 2 or p.size(1) != 4:
+        raise ValueError('box_loss: pred / target must both be [n, 4]')
+    n = p.size(0)
+    loss = torch.empty(n, dtype=torch.float32, device=p.device)
+    grad = torch.empty_like(p) if want_grad else None
+    with torch.cuda.device(p.device):
+        check(lib().lfd_box_loss_f32(ptr(p), ptr(t), n, BOX_LOSS_KINDS[kind], float(eps), ptr(loss), ptr(grad), stream_ptr()),
+              'lfd_box_loss_f32')
+    return loss, grad
+
+
 def cross_entropy_forward(logits, labels):
     """F.cross_entropy(logits, labels, reduction='none') on the device (cross_entropy_loss.py:12-16)."""
     require_cuda(logits, 'cross_entropy forward')

@@ -341,3 +341,92 @@ def test_cross_entropy_kernel_vs_torch():
     out.backward()
     assert float(out) == pytest.approx(float(ref), rel=2e-6)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.float().numpy(), rtol=2e-5, atol=1e-8)
+
+
+def _ref_union_losses(pred, target, kind, eps):
+    """GIoU / DIoU / CIoU of aligned xyxy boxes as plain PyTorch expressions (the published formulas the reference follows,
+    iou_loss.py:127-283), for autograd"""
+    import math
+    lt, rb = torch.max(pred[:, :2], target[:, :2]), torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    union = ap + ag - overlap + eps
+    iou = overlap / union
+    e1, e2 = torch.min(pred[:, :2], target[:, :2]), torch.max(pred[:, 2:], target[:, 2:])
+    ewh = (e2 - e1).clamp(min=0)
+    if kind == 'giou':
+        area = ewh[:, 0] * ewh[:, 1] + eps
+        return 1 - (iou - (area - union) / area)
+    c2 = ewh[:, 0] ** 2 + ewh[:, 1] ** 2 + eps
+    rho2 = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4 + \
+           ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
+    if kind == 'diou':
+        return 1 - (iou - rho2 / c2)
+    w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
+    w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
+    v = 4 / math.pi ** 2 * (torch.atan(w2 / h2) - torch.atan(w1 / h1)) ** 2
+    return 1 - (iou - (rho2 / c2 + v ** 2 / (1 - iou + v)))
+
+
+@pytest.mark.parametrize('kind', ['giou', 'diou', 'ciou'])
+def test_giou_diou_ciou_losses_and_gradients(kind):
+    """lfd_box_loss_f32 (gradient by forward-mode differentiation inside the kernel) vs autograd of the same expression in
+    float64: overlapping, disjoint, nested and nearly identical pairs; then the loss modules (weights, avg_factor)."""
+    from lfd_amd.model.losses import CIoULoss, DIoULoss, GIoULoss
+    rng = np.random.default_rng({'giou': 1, 'diou': 2, 'ciou': 3}[kind])
+    n = 4096
+    c = rng.uniform(20, 400, (n, 2)); s = np.exp(rng.uniform(np.log(4), np.log(200), (n, 2)))
+    tgt = np.concatenate([c - s / 2, c + s / 2], 1)
+    shift = rng.normal(0, 1, (n, 2)) * s * rng.choice([0.05, 0.5, 3.0], (n, 1))      # near, overlapping, disjoint
+    ps = s * np.exp(rng.normal(0, 0.5, (n, 2)))
+    pred = np.concatenate([c + shift - ps / 2, c + shift + ps / 2], 1)
+    pred[:64] = tgt[:64] + rng.normal(0, 1e-3, (64, 4))                                # nearly identical
+    pred[64:128, :2] = tgt[64:128, :2] + 1.0; pred[64:128, 2:] = tgt[64:128, 2:] - 1.0  # nested
+    pred, tgt = pred.astype(np.float32), tgt.astype(np.float32)
+    p64 = torch.from_numpy(pred).double().requires_grad_(True)
+    ref = _ref_union_losses(p64, torch.from_numpy(tgt).double(), kind, 1e-7)
+    g = torch.from_numpy(rng.normal(0, 1, n)).double()
+    (ref * g).sum().backward()
+    loss, grad = ops.box_loss(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), kind, 1e-7)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    gk = (grad.cpu().double() * g[:, None]).numpy()
+    gr = p64.grad.numpy()
+    bad = np.abs(gk - gr) > 2e-3 * np.abs(gr) + 2e-5 * np.abs(gr).max()
+    assert bad.mean() < 2e-3, bad.mean()          # fp32 kernel vs fp64 autograd; a few ill-conditioned (near-tie) pairs allowed
+    mod = {'giou': GIoULoss, 'diou': DIoULoss, 'ciou': CIoULoss}[kind](eps=1e-6, loss_weight=2.0)
+    pred, tgt = pred[128:], tgt[128:]           # the module check skips the ill-conditioned (nearly identical / nested) pairs
+    pc = torch.from_numpy(pred[:300]).cuda().requires_grad_(True)
+    w = torch.from_numpy(rng.uniform(0, 1, 300).astype(np.float32)).cuda()
+    out = mod(pc, torch.from_numpy(tgt[:300]).cuda(), weight=w, avg_factor=37.0)
+    out.backward()
+    pr = torch.from_numpy(pred[:300]).double().requires_grad_(True)
+    ref2 = 2.0 * (_ref_union_losses(pr, torch.from_numpy(tgt[:300]).double(), kind, 1e-6) * w.cpu().double()).sum() / 37.0
+    ref2.backward()
+    assert float(out.detach()) == pytest.approx(float(ref2.detach()), rel=1e-4)
+    assert float((pc.grad.cpu().double() - pr.grad).abs().max()) < 2e-3 * float(pr.grad.abs().max())
+    zero = mod(pc, torch.from_numpy(tgt[:300]).cuda(), weight=torch.zeros(300, 4).cuda())
+    assert float(zero) == 0.0          # all-zero weights: (pred * weight).sum() (iou_loss.py:339-340; [n,4] weights broadcast)
+
+
+def test_get_loss_with_a_giou_regression_loss_runs_the_op_by_op_path():
+    """LFD accepts the whole IoU-loss family (lfd.py:64-66); only IoULoss has the fused get_loss kernels, the others go
+    through the op-by-op mirror with the box-loss kernel behind the module."""
+    from lfd_amd.model.losses import GIoULoss
+    m = configs.build_model('WIDERFACE_LFD_XS').cuda()
+    m._regression_loss_func = GIoULoss(eps=1e-6, reduction='mean', loss_weight=1.0)
+    sizes = [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)]
+    for i, s in enumerate(sizes):
+        m._head_indexes_to_feature_map_sizes[i] = s
+    P = sum(h * w for h, w in sizes)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    cls = torch.randn(2, P, 1, generator=g, device='cuda').requires_grad_(True)
+    reg = torch.randn(2, P, 4, generator=g, device='cuda').requires_grad_(True)
+    ann = [(np.array([[8., 8., 20., 24.]], np.float32), np.zeros(1, np.int64)),
+           (np.array([[20., 10., 30., 30.]], np.float32), np.zeros(1, np.int64))]
+    assert not m._fused_loss_supported(cls)
+    out = m.get_loss((cls, reg), ann)
+    assert out['loss_values']['regression_loss'] > 0
+    out['loss'].backward()
+    assert torch.isfinite(reg.grad).all() and float(reg.grad.abs().sum()) > 0
