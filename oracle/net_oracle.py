@@ -286,6 +286,35 @@ def lfd_targets(arch, sizes, strides, gt_bboxes_list, gt_labels_list):
     return torch.stack(cl), torch.stack(rg), points, rr
 
 
+def union_box_loss(pred, target, kind, eps):
+    """GIoU / DIoU / CIoU of aligned xyxy boxes [n,4] -> loss [n] (reference lfd/model/losses/iou_loss.py: giou_loss
+    :127-169, diou_loss :172-223, ciou_loss :226-283), as plain torch expressions (differentiable: the tests take
+    autograd gradients of it).  Pinned against the reference's own outputs in tests/golden/ref_box_losses.npz."""
+    import math
+    lt, rb = torch.max(pred[:, :2], target[:, :2]), torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    union = ap + ag - overlap + eps
+    iou = overlap / union
+    e1, e2 = torch.min(pred[:, :2], target[:, :2]), torch.max(pred[:, 2:], target[:, 2:])
+    ewh = (e2 - e1).clamp(min=0)
+    if kind == 'giou':
+        area = ewh[:, 0] * ewh[:, 1] + eps
+        return 1 - (iou - (area - union) / area)
+    c2 = ewh[:, 0] ** 2 + ewh[:, 1] ** 2 + eps
+    rho2 = (((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4
+            + ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4)
+    if kind == 'diou':
+        return 1 - (iou - rho2 / c2)
+    assert kind == 'ciou'
+    w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
+    w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
+    v = 4 / math.pi ** 2 * (torch.atan(w2 / h2) - torch.atan(w1 / h1)) ** 2
+    return 1 - (iou - (rho2 / c2 + v ** 2 / (1 - iou + v)))
+
+
 def focal_loss_sum(pred, label, gamma=2.0, alpha=0.25):
     """FocalLoss forward via the C restatement (focal_loss.py:39-53), elementwise [N,C]."""
     return torch.from_numpy(c_oracle.sigmoid_focal_loss_fwd(pred.detach().numpy(), label.numpy(), gamma, alpha))

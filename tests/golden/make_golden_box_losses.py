@@ -1,0 +1,53 @@
+"""tests/golden/make_golden_box_losses.py -- golden vectors of the GIoU / DIoU / CIoU losses from the REAL reference
+(lfd/model/losses/iou_loss.py:127-430, imported from /root/reference through oracle/ref_import.py; build container only):
+
+    python tests/golden/make_golden_box_losses.py   ->  tests/golden/ref_box_losses.npz
+
+Per kind: the per-pair loss of the reference module (reduction 'none', eps 1e-6, fp32) and d(sum of losses)/d(pred) from
+the reference's own autograd graph, for 768 seeded pairs (overlapping, disjoint, nested, distant).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings('ignore')
+
+from oracle import ref_import  # noqa: E402
+
+
+def pairs(seed=7, n=768):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(20, 400, (n, 2))
+    s = np.exp(rng.uniform(np.log(4), np.log(200), (n, 2)))
+    tgt = np.concatenate([c - s / 2, c + s / 2], 1)
+    shift = rng.normal(0, 1, (n, 2)) * s * rng.choice([0.05, 0.5, 3.0], (n, 1))
+    ps = s * np.exp(rng.normal(0, 0.5, (n, 2)))
+    pred = np.concatenate([c + shift - ps / 2, c + shift + ps / 2], 1)
+    pred[:32, :2] = tgt[:32, :2] + 1.0
+    pred[:32, 2:] = tgt[:32, 2:] - 1.0          # nested
+    return pred.astype(np.float32), tgt.astype(np.float32)
+
+
+def main():
+    ref_import.import_reference()
+    import lfd.model.losses as RL
+    pred, tgt = pairs()
+    out = dict(pred=pred, target=tgt, eps=np.float32(1e-6))
+    for kind, cls in (('giou', RL.GIoULoss), ('diou', RL.DIoULoss), ('ciou', RL.CIoULoss)):
+        p = torch.from_numpy(pred).clone().requires_grad_(True)
+        loss = cls(eps=1e-6, reduction='none', loss_weight=1.0)(p, torch.from_numpy(tgt))
+        loss.sum().backward()
+        out['loss_' + kind] = loss.detach().numpy()
+        out['grad_' + kind] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'ref_box_losses.npz'), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

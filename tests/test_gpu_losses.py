@@ -344,30 +344,20 @@ def test_cross_entropy_kernel_vs_torch():
 
 
 def _ref_union_losses(pred, target, kind, eps):
-    """GIoU / DIoU / CIoU of aligned xyxy boxes as plain PyTorch expressions (the published formulas the reference follows,
-    iou_loss.py:127-283), for autograd"""
-    import math
-    lt, rb = torch.max(pred[:, :2], target[:, :2]), torch.min(pred[:, 2:], target[:, 2:])
-    wh = (rb - lt).clamp(min=0)
-    overlap = wh[:, 0] * wh[:, 1]
-    ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
-    ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
-    union = ap + ag - overlap + eps
-    iou = overlap / union
-    e1, e2 = torch.min(pred[:, :2], target[:, :2]), torch.max(pred[:, 2:], target[:, 2:])
-    ewh = (e2 - e1).clamp(min=0)
-    if kind == 'giou':
-        area = ewh[:, 0] * ewh[:, 1] + eps
-        return 1 - (iou - (area - union) / area)
-    c2 = ewh[:, 0] ** 2 + ewh[:, 1] ** 2 + eps
-    rho2 = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4 + \
-           ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
-    if kind == 'diou':
-        return 1 - (iou - rho2 / c2)
-    w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
-    w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
-    v = 4 / math.pi ** 2 * (torch.atan(w2 / h2) - torch.atan(w1 / h1)) ** 2
-    return 1 - (iou - (rho2 / c2 + v ** 2 / (1 - iou + v)))
+    from oracle import net_oracle
+    return net_oracle.union_box_loss(pred, target, kind, eps)
+
+
+@pytest.mark.parametrize('kind', ['giou', 'diou', 'ciou'])
+def test_box_loss_kernel_vs_reference_golden(kind):
+    """lfd_box_loss_f32 on the reference-generated vectors (tests/golden/ref_box_losses.npz): loss and d(sum loss)/d(pred)
+    of the real reference modules, both computed in fp32 -- agreement to fp32 rounding of the same expression."""
+    g = load_golden('ref_box_losses.npz')
+    loss, grad = ops.box_loss(torch.from_numpy(g['pred']).cuda(), torch.from_numpy(g['target']).cuda(), kind, float(g['eps']))
+    np.testing.assert_allclose(loss.cpu().numpy(), g['loss_' + kind], rtol=5e-5, atol=5e-6)
+    gk, gr = grad.cpu().numpy(), g['grad_' + kind]
+    bad = np.abs(gk - gr) > 1e-3 * np.abs(gr) + 1e-5 * np.abs(gr).max()
+    assert bad.mean() < 2e-3, bad.mean()
 
 
 @pytest.mark.parametrize('kind', ['giou', 'diou', 'ciou'])
