@@ -187,6 +187,11 @@ LFD_API int lfd_cross_entropy_bwd_f32(const float* logits, const int64_t* labels
  * differentiation of the reference expression inside the kernel (max / min / clamp route like autograd). */
 LFD_API int lfd_box_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float eps, float* loss,
                      float* d_loss_d_pred, lfd_stream_t stream);
+/* LFD's "independent" regression losses (lfd.py:61-66), elementwise over n values: kind 1 smooth-L1 with `beta`
+ * (lfd/model/losses/smooth_l1_loss.py:11-22), 2 L1 (:25-30), 3 MSE (mse_loss.py:11-13); loss[n] and, when
+ * d_loss_d_pred != NULL, the derivative w.r.t. pred. */
+LFD_API int lfd_pointwise_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float beta, float* loss,
+                           float* d_loss_d_pred, lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused LFD.get_loss (lfd/model/lfd.py:284-395): replaces the boolean gathers (green rows :309-315, positive

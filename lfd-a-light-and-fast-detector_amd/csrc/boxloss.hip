@@ -95,9 +95,48 @@ __global__ __launch_bounds__(kThreads) void k_box_loss(const float4* __restrict_
   }
 }
 
+// Elementwise regression losses of LFD's "independent" family (lfd.py:61-66): smooth-L1 (smooth_l1_loss.py:11-22:
+// 0.5 d^2 / beta below beta, d - 0.5 beta above), L1 (:25-30) and MSE (mse_loss.py:11-13), loss and d loss / d pred
+// in one pass.  kind: 1 smooth-L1, 2 L1, 3 MSE.  |x| has derivative sign(x) with sign(0) = 0, like torch.abs.
+__global__ __launch_bounds__(kThreads) void k_pointwise_loss(const float* __restrict__ pred,
+                                                            const float* __restrict__ target, int64_t n, int kind,
+                                                            float beta, float* __restrict__ loss,
+                                                            float* __restrict__ dpred) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const float x = pred[i] - target[i];
+    const float d = fabsf(x);
+    const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+    float l, g;
+    if (kind == 1) {
+      if (d < beta) { l = 0.5f * d * d / beta; g = sg * (d / beta); }
+      else { l = d - 0.5f * beta; g = sg; }
+    } else if (kind == 2) {
+      l = d; g = sg;
+    } else {
+      l = x * x; g = 2.f * x;
+    }
+    loss[i] = l;
+    if (dpred) dpred[i] = g;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int lfd_pointwise_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float beta, float* loss,
+                           float* d_loss_d_pred, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n < 0 || kind < 1 || kind > 3 || (kind == 1 && !(beta > 0.f))) return LFD_ERR_INVALID_ARGUMENT;
+  if (n == 0) return LFD_OK;
+  if (!pred || !target || !loss) return LFD_ERR_INVALID_ARGUMENT;
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  hipLaunchKernelGGL(k_pointwise_loss, dim3((unsigned)b), dim3(kThreads), 0, st, pred, target, n, kind, beta, loss,
+                     d_loss_d_pred);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
 
 int lfd_box_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float eps, float* loss,
                      float* d_loss_d_pred, lfd_stream_t stream) {

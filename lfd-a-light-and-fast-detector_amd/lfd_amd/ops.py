@@ -215,6 +215,24 @@ def box_loss(pred, target, kind, eps, want_grad=True):
     return loss, grad
 
 
+POINTWISE_LOSS_KINDS = {'smooth_l1': 1, 'l1': 2, 'mse': 3}
+
+
+def pointwise_loss(pred, target, kind, beta=1.0, want_grad=True):
+    """smooth-L1 / L1 / MSE of same-shaped tensors -> (loss, d loss / d pred or None), same shape, one launch."""
+    require_cuda(pred, 'pointwise_loss')
+    p = pred.detach().contiguous().float()
+    t = target.detach().contiguous().float()
+    if p.shape != t.shape:
+        raise ValueError('pointwise_loss: pred / target shapes differ')
+    loss = torch.empty_like(p)
+    grad = torch.empty_like(p) if want_grad else None
+    with torch.cuda.device(p.device):
+        check(lib().lfd_pointwise_loss_f32(ptr(p), ptr(t), p.numel(), POINTWISE_LOSS_KINDS[kind], float(beta), ptr(loss),
+                                           ptr(grad), stream_ptr()), 'lfd_pointwise_loss_f32')
+    return loss, grad
+
+
 def cross_entropy_forward(logits, labels):
     """F.cross_entropy(logits, labels, reduction='none') on the device (cross_entropy_loss.py:12-16)."""
     require_cuda(logits, 'cross_entropy forward')

@@ -315,6 +315,18 @@ def union_box_loss(pred, target, kind, eps):
     return 1 - (iou - (rho2 / c2 + v ** 2 / (1 - iou + v)))
 
 
+def pointwise_reg_loss(pred, target, kind, beta=1.0):
+    """smooth-L1 / L1 / MSE, elementwise (reference lfd/model/losses/smooth_l1_loss.py:11-30, mse_loss.py:11-13): LFD's
+    "independent" regression losses.  Differentiable torch expressions; pinned in tests/golden/ref_box_losses.npz."""
+    d = (pred - target).abs()
+    if kind == 'smooth_l1':
+        return torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+    if kind == 'l1':
+        return d
+    assert kind == 'mse'
+    return (pred - target) ** 2
+
+
 def focal_loss_sum(pred, label, gamma=2.0, alpha=0.25):
     """FocalLoss forward via the C restatement (focal_loss.py:39-53), elementwise [N,C]."""
     return torch.from_numpy(c_oracle.sigmoid_focal_loss_fwd(pred.detach().numpy(), label.numpy(), gamma, alpha))

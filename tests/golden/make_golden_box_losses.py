@@ -3,6 +3,7 @@
 
     python tests/golden/make_golden_box_losses.py   ->  tests/golden/ref_box_losses.npz
 
+Also SmoothL1Loss (beta 1 and 0.11) / L1Loss / MSELoss elementwise on the same pairs scaled by 1/100.
 Per kind: the per-pair loss of the reference module (reduction 'none', eps 1e-6, fp32) and d(sum of losses)/d(pred) from
 the reference's own autograd graph, for 768 seeded pairs (overlapping, disjoint, nested, distant).
 """
@@ -42,6 +43,18 @@ def main():
     for kind, cls in (('giou', RL.GIoULoss), ('diou', RL.DIoULoss), ('ciou', RL.CIoULoss)):
         p = torch.from_numpy(pred).clone().requires_grad_(True)
         loss = cls(eps=1e-6, reduction='none', loss_weight=1.0)(p, torch.from_numpy(tgt))
+        loss.sum().backward()
+        out['loss_' + kind] = loss.detach().numpy()
+        out['grad_' + kind] = p.grad.numpy()
+    # LFD's "independent" regression losses (smooth_l1_loss.py, mse_loss.py) on the same pairs scaled to O(1) distances
+    a, b = (pred / 100.0).astype(np.float32), (tgt / 100.0).astype(np.float32)
+    b[:16] = a[:16]                                   # exact zeros: |x| derivative at 0
+    out['pw_pred'], out['pw_target'] = a, b
+    for kind, mod in (('smooth_l1', RL.SmoothL1Loss(beta=1.0, reduction='none')),
+                      ('smooth_l1_b011', RL.SmoothL1Loss(beta=0.11, reduction='none')),
+                      ('l1', RL.L1Loss(reduction='none')), ('mse', RL.MSELoss(reduction='none'))):
+        p = torch.from_numpy(a).clone().requires_grad_(True)
+        loss = mod(p, torch.from_numpy(b))
         loss.sum().backward()
         out['loss_' + kind] = loss.detach().numpy()
         out['grad_' + kind] = p.grad.numpy()

@@ -420,3 +420,52 @@ def test_get_loss_with_a_giou_regression_loss_runs_the_op_by_op_path():
     assert out['loss_values']['regression_loss'] > 0
     out['loss'].backward()
     assert torch.isfinite(reg.grad).all() and float(reg.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('key,kind,beta', [('smooth_l1', 'smooth_l1', 1.0), ('smooth_l1_b011', 'smooth_l1', 0.11),
+                                           ('l1', 'l1', 1.0), ('mse', 'mse', 1.0)])
+def test_pointwise_regression_losses_vs_reference_golden(key, kind, beta):
+    """lfd_pointwise_loss_f32 (SmoothL1 / L1 / MSE, LFD's "independent" regression losses) on the reference-generated
+    vectors: loss and derivative, incl. exact zeros (sign(0) = 0 like torch.abs) -- fp32 expressions of the same shape, so
+    agreement to 1 ulp; then the modules with weight / avg_factor against the oracle."""
+    from lfd_amd.model.losses import L1Loss, MSELoss, SmoothL1Loss
+    from oracle import net_oracle
+    g = load_golden('ref_box_losses.npz')
+    a, b = torch.from_numpy(g['pw_pred']).cuda(), torch.from_numpy(g['pw_target']).cuda()
+    loss, grad = ops.pointwise_loss(a, b, kind, beta)
+    np.testing.assert_allclose(loss.cpu().numpy(), g['loss_' + key], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(grad.cpu().numpy(), g['grad_' + key], rtol=3e-7, atol=1e-9)
+    assert float(grad[:16].abs().max()) == 0.0
+    mod = {'smooth_l1': SmoothL1Loss(beta=beta, loss_weight=0.5), 'l1': L1Loss(loss_weight=0.5), 'mse': MSELoss(loss_weight=0.5)}[kind]
+    ar = a.clone().requires_grad_(True)
+    w = torch.linspace(0.1, 2.0, a.size(0), device='cuda')[:, None].expand_as(a)
+    out = mod(ar, b, weight=w, avg_factor=11.0)
+    out.backward()
+    ac = a.cpu().double().requires_grad_(True)
+    ref = 0.5 * (net_oracle.pointwise_reg_loss(ac, b.cpu().double(), kind, beta) * w.cpu().double()).sum() / 11.0
+    ref.backward()
+    assert float(out.detach()) == pytest.approx(float(ref.detach()), rel=1e-5)
+    np.testing.assert_allclose(ar.grad.cpu().numpy(), ac.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_get_loss_independent_regression_mode_runs_on_the_device():
+    """LFD with a SmoothL1Loss regression loss ('independent' family, lfd.py:61-66,354-358): targets in independent mode
+    from the device assignment kernel, regression loss on the raw predictions."""
+    from lfd_amd.model.losses import SmoothL1Loss
+    arch = dict(configs.ARCHS['WIDERFACE_LFD_XS'])
+    m = configs.build_model(arch).cuda()
+    m._regression_loss_func = SmoothL1Loss(beta=1.0)
+    m._regression_loss_type = 'independent'
+    sizes = [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)]
+    for i, s in enumerate(sizes):
+        m._head_indexes_to_feature_map_sizes[i] = s
+    P = sum(h * w for h, w in sizes)
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    cls = torch.randn(2, P, 1, generator=gen, device='cuda').requires_grad_(True)
+    reg = torch.randn(2, P, 4, generator=gen, device='cuda').requires_grad_(True)
+    ann = [(np.array([[8., 8., 20., 24.]], np.float32), np.zeros(1, np.int64)),
+           (np.array([[20., 10., 30., 30.]], np.float32), np.zeros(1, np.int64))]
+    out = m.get_loss((cls, reg), ann)
+    assert out['loss_values']['regression_loss'] > 0
+    out['loss'].backward()
+    assert torch.isfinite(reg.grad).all() and float(reg.grad.abs().sum()) > 0
