@@ -187,6 +187,15 @@ LFD_API int lfd_cross_entropy_bwd_f32(const float* logits, const int64_t* labels
  * differentiation of the reference expression inside the kernel (max / min / clamp route like autograd). */
 LFD_API int lfd_box_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float eps, float* loss,
                      float* d_loss_d_pred, lfd_stream_t stream);
+/* The remaining classification losses LFD accepts (lfd.py:52-56).  lfd_bce_with_logits_f32: elementwise
+ * F.binary_cross_entropy_with_logits(logits, targets, reduction='none') over n values (bce_with_logits_loss.py:28-44) and
+ * its derivative sigmoid(x) - t.  lfd_quality_focal_loss_f32 (gfocal_loss.py:11-52): per row the sum over classes of
+ * BCE(x, t) |t - sigmoid(x)|^beta with t = scores[row] at class labels[row] (if it is a foreground label) and 0 elsewhere;
+ * d_logits [rows, channels] (nullable) = its derivative. */
+LFD_API int lfd_bce_with_logits_f32(const float* logits, const float* targets, int64_t n, float* loss, float* d_logits,
+                            lfd_stream_t stream);
+LFD_API int lfd_quality_focal_loss_f32(const float* logits, const int64_t* labels, const float* scores, int64_t rows,
+                               int32_t channels, float beta, float* loss, float* d_logits, lfd_stream_t stream);
 /* LFD's "independent" regression losses (lfd.py:61-66), elementwise over n values: kind 1 smooth-L1 with `beta`
  * (lfd/model/losses/smooth_l1_loss.py:11-22), 2 L1 (:25-30), 3 MSE (mse_loss.py:11-13); loss[n] and, when
  * d_loss_d_pred != NULL, the derivative w.r.t. pred. */

@@ -120,9 +120,80 @@ __global__ __launch_bounds__(kThreads) void k_pointwise_loss(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The two remaining classification losses LFD accepts (lfd.py:52-56): binary cross-entropy with logits against float
+// targets (bce_with_logits_loss.py:28-44 -> F.binary_cross_entropy_with_logits, reduction 'none') and Quality Focal Loss
+// (gfocal_loss.py:11-52).  B(x, t) = max(x, 0) - x t + log(1 + exp(-|x|)),  dB/dx = sigmoid(x) - t.
+// QFL row n, class c:  t = score[n] if c == label[n] (a foreground label) else 0;  l = B(x, t) |t - s|^beta, s = sigmoid(x);
+//   dl/dx = (s - t) |t - s|^beta - B beta |t - s|^(beta-1) sign(t - s) s (1 - s);  the row loss is the sum over classes.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_logits(float x, float t) {
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(kThreads) void k_bce_logits(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                                        float* __restrict__ loss, float* __restrict__ dx) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const float xv = x[i], tv = t[i];
+    loss[i] = bce_logits(xv, tv);
+    if (dx) dx[i] = 1.f / (1.f + expf(-xv)) - tv;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_qfl(const float* __restrict__ x, const int64_t* __restrict__ label,
+                                                 const float* __restrict__ score, int64_t rows, int c, float beta,
+                                                 float* __restrict__ loss, float* __restrict__ dx) {
+  for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kThreads) {
+    const int64_t lab = label[r];
+    const float sc = score[r];
+    float sum = 0.f;
+    for (int j = 0; j < c; ++j) {
+      const float xv = x[r * c + j];
+      const float t = (lab == j) ? sc : 0.f;            // labels outside [0, c) are background: no positive class
+      const float s = 1.f / (1.f + expf(-xv));
+      const float u = t - s, m = fabsf(u);
+      const float b = bce_logits(xv, t);
+      const float mb = powf(m, beta);
+      sum += b * mb;
+      if (dx) {
+        const float sg = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+        dx[r * c + j] = (s - t) * mb - b * beta * powf(m, beta - 1.f) * sg * s * (1.f - s);
+      }
+    }
+    loss[r] = sum;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int lfd_bce_with_logits_f32(const float* logits, const float* targets, int64_t n, float* loss, float* d_logits,
+                            lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n < 0) return LFD_ERR_INVALID_ARGUMENT;
+  if (n == 0) return LFD_OK;
+  if (!logits || !targets || !loss) return LFD_ERR_INVALID_ARGUMENT;
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  hipLaunchKernelGGL(k_bce_logits, dim3((unsigned)b), dim3(kThreads), 0, st, logits, targets, n, loss, d_logits);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_quality_focal_loss_f32(const float* logits, const int64_t* labels, const float* scores, int64_t rows,
+                               int32_t channels, float beta, float* loss, float* d_logits, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (rows < 0 || channels < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (rows == 0) return LFD_OK;
+  if (!logits || !labels || !scores || !loss) return LFD_ERR_INVALID_ARGUMENT;
+  int64_t b = (rows + kThreads - 1) / kThreads;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  hipLaunchKernelGGL(k_qfl, dim3((unsigned)b), dim3(kThreads), 0, st, logits, labels, scores, rows, channels, beta, loss,
+                     d_logits);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
 
 int lfd_pointwise_loss_f32(const float* pred, const float* target, int64_t n, int32_t kind, float beta, float* loss,
                            float* d_loss_d_pred, lfd_stream_t stream) {

@@ -101,6 +101,8 @@ _SIGNATURES = {
     'lfd_sigmoid_focal_loss_sum_f32': (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _SZ, _P]),
     'lfd_iou_loss_fwd_f32': (C.c_int, [_P, _P, _I64, _F, _P, _P]),
     'lfd_iou_loss_bwd_f32': (C.c_int, [_P, _P, _P, _I64, _F, _P, _P]),
+    'lfd_bce_with_logits_f32': (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    'lfd_quality_focal_loss_f32': (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P, _P, _P]),
     'lfd_pointwise_loss_f32': (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _P]),
     'lfd_box_loss_f32': (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _P]),
     'lfd_assign_targets_f32': (C.c_int, [C.POINTER(AssignDesc), _P, _P, _P, _P, _P, _P]),

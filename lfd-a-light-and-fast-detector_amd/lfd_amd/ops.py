@@ -215,6 +215,37 @@ def box_loss(pred, target, kind, eps, want_grad=True):
     return loss, grad
 
 
+def bce_with_logits(logits, targets, want_grad=True):
+    """elementwise BCE-with-logits against float targets -> (loss, d loss / d logits or None), same shape"""
+    require_cuda(logits, 'bce_with_logits')
+    x = logits.detach().contiguous().float()
+    t = targets.detach().contiguous().float()
+    if x.shape != t.shape:
+        raise ValueError('bce_with_logits: logits / targets shapes differ')
+    loss = torch.empty_like(x)
+    grad = torch.empty_like(x) if want_grad else None
+    with torch.cuda.device(x.device):
+        check(lib().lfd_bce_with_logits_f32(ptr(x), ptr(t), x.numel(), ptr(loss), ptr(grad), stream_ptr()),
+              'lfd_bce_with_logits_f32')
+    return loss, grad
+
+
+def quality_focal_loss(logits, labels, scores, beta, want_grad=True):
+    """QFL: logits [N,C], labels [N] int64 (label outside [0, C) = background), scores [N] -> (loss [N], grad [N,C])"""
+    require_cuda(logits, 'quality_focal_loss')
+    x = logits.detach().contiguous().float()
+    lab = labels.detach().contiguous().long()
+    sc = scores.detach().contiguous().float()
+    if x.dim() != 2 or lab.shape != (x.size(0),) or sc.shape != (x.size(0),):
+        raise ValueError('quality_focal_loss: logits [N,C], labels [N], scores [N] expected')
+    loss = torch.empty(x.size(0), dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x) if want_grad else None
+    with torch.cuda.device(x.device):
+        check(lib().lfd_quality_focal_loss_f32(ptr(x), ptr(lab), ptr(sc), x.size(0), x.size(1), float(beta), ptr(loss),
+                                               ptr(grad), stream_ptr()), 'lfd_quality_focal_loss_f32')
+    return loss, grad
+
+
 POINTWISE_LOSS_KINDS = {'smooth_l1': 1, 'l1': 2, 'mse': 3}
 
 

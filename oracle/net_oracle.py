@@ -327,6 +327,22 @@ def pointwise_reg_loss(pred, target, kind, beta=1.0):
     return (pred - target) ** 2
 
 
+def bce_with_logits(pred, target):
+    """elementwise binary cross-entropy with logits against float targets (reference bce_with_logits_loss.py:28-44 ->
+    F.binary_cross_entropy_with_logits, reduction 'none'), written out: max(x,0) - x t + log(1 + exp(-|x|))."""
+    return pred.clamp(min=0) - pred * target + torch.log1p(torch.exp(-pred.abs()))
+
+
+def quality_focal_loss_rows(pred, label, score, beta=2.0):
+    """Quality Focal Loss per row (reference gfocal_loss.py:11-52): sum over classes of BCE(x, t) |t - sigmoid(x)|^beta,
+    t = score at the row's foreground label, 0 elsewhere (labels outside [0, C) are background)."""
+    n, c = pred.shape
+    t = torch.zeros_like(pred)
+    fg = (label >= 0) & (label < c)
+    t[fg, label[fg]] = score[fg].to(pred.dtype)
+    return (bce_with_logits(pred, t) * (t - pred.sigmoid()).abs().pow(beta)).sum(1)
+
+
 def focal_loss_sum(pred, label, gamma=2.0, alpha=0.25):
     """FocalLoss forward via the C restatement (focal_loss.py:39-53), elementwise [N,C]."""
     return torch.from_numpy(c_oracle.sigmoid_focal_loss_fwd(pred.detach().numpy(), label.numpy(), gamma, alpha))

@@ -58,6 +58,25 @@ def main():
         loss.sum().backward()
         out['loss_' + kind] = loss.detach().numpy()
         out['grad_' + kind] = p.grad.numpy()
+    # the two other classification losses LFD accepts: BCEWithLogitsLoss (float targets, as LFD.get_loss passes them, and
+    # 1-based integer labels with per-row weights) and QualityFocalLoss (beta 2, 6 classes, label 6 = background)
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 2.5, (640, 6)).astype(np.float32)
+    soft = np.where(rng.random((640, 6)) < 0.2, rng.random((640, 6)), 0).astype(np.float32)
+    lab1 = rng.integers(0, 7, 640).astype(np.int64)            # BCE label path: 0 = background, k -> channel k - 1
+    roww = rng.uniform(0.2, 2.0, 640).astype(np.float32)
+    qlab = rng.integers(0, 7, 640).astype(np.int64)            # QFL: 6 = background
+    qsc = rng.uniform(0.05, 1.0, 640).astype(np.float32)
+    out.update(cls_logits=x, bce_soft=soft, bce_labels=lab1, bce_row_weight=roww, qfl_labels=qlab, qfl_scores=qsc)
+
+    def run(key, fn):
+        p = torch.from_numpy(x).clone().requires_grad_(True)
+        loss = fn(p)
+        loss.sum().backward()
+        out['loss_' + key], out['grad_' + key] = loss.detach().numpy(), p.grad.numpy()
+    run('bce_soft', lambda p: RL.BCEWithLogitsLoss(reduction='none')(p, torch.from_numpy(soft)))
+    run('bce_labels', lambda p: RL.BCEWithLogitsLoss(reduction='none')(p, torch.from_numpy(lab1), weight=torch.from_numpy(roww)))
+    run('qfl', lambda p: RL.QualityFocalLoss(beta=2.0, reduction='none')(p, (torch.from_numpy(qlab), torch.from_numpy(qsc))))
     np.savez_compressed(os.path.join(HERE, 'ref_box_losses.npz'), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -469,3 +469,39 @@ def test_get_loss_independent_regression_mode_runs_on_the_device():
     assert out['loss_values']['regression_loss'] > 0
     out['loss'].backward()
     assert torch.isfinite(reg.grad).all() and float(reg.grad.abs().sum()) > 0
+
+
+def test_bce_with_logits_and_quality_focal_loss_vs_reference_golden():
+    """lfd_bce_with_logits_f32 / lfd_quality_focal_loss_f32 through the host modules (BCEWithLogitsLoss with float targets
+    and with 1-based labels + row weights; QualityFocalLoss) on the reference-generated vectors: per-element / per-row loss
+    and gradient; then LFD.get_loss with a QualityFocalLoss classification loss runs on the device."""
+    from lfd_amd.model.losses import BCEWithLogitsLoss, QualityFocalLoss
+    g = load_golden('ref_box_losses.npz')
+    x = torch.from_numpy(g['cls_logits']).cuda()
+
+    def check(key, fn):
+        p = x.clone().requires_grad_(True)
+        loss = fn(p)
+        loss.sum().backward()
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g['loss_' + key], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g['grad_' + key], rtol=1e-4, atol=2e-6)
+    check('bce_soft', lambda p: BCEWithLogitsLoss(reduction='none')(p, torch.from_numpy(g['bce_soft']).cuda()))
+    check('bce_labels', lambda p: BCEWithLogitsLoss(reduction='none')(p, torch.from_numpy(g['bce_labels']).cuda(),
+                                                                      weight=torch.from_numpy(g['bce_row_weight']).cuda()))
+    check('qfl', lambda p: QualityFocalLoss(beta=2.0, reduction='none')(
+        p, (torch.from_numpy(g['qfl_labels']).cuda(), torch.from_numpy(g['qfl_scores']).cuda())))
+    m = configs.build_model('WIDERFACE_LFD_XS').cuda()
+    m._classification_loss_func = QualityFocalLoss(beta=2.0)
+    sizes = [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)]
+    for i, sz in enumerate(sizes):
+        m._head_indexes_to_feature_map_sizes[i] = sz
+    P = sum(h * w for h, w in sizes)
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    cls = torch.randn(2, P, 1, generator=gen, device='cuda').requires_grad_(True)
+    reg = torch.randn(2, P, 4, generator=gen, device='cuda').requires_grad_(True)
+    ann = [(np.array([[8., 8., 20., 24.]], np.float32), np.zeros(1, np.int64)),
+           (np.array([[20., 10., 30., 30.]], np.float32), np.zeros(1, np.int64))]
+    out = m.get_loss((cls, reg), ann)
+    assert out['loss_values']['classification_loss'] > 0
+    out['loss'].backward()
+    assert torch.isfinite(cls.grad).all() and float(cls.grad.abs().sum()) > 0
