@@ -309,3 +309,29 @@ def test_training_schedule_covers_every_parameter_once():
     m._backbone._stem[1].train()
     m._head._conv_kernel_size = 3
     assert not te.network_supported(m)
+
+
+def test_every_loss_the_lfd_constructor_accepts_is_provided():
+    """lfd.py:52-66: classification loss in {BCEWithLogitsLoss, FocalLoss, CrossEntropyLoss, QualityFocalLoss}, regression
+    loss in {SmoothL1Loss, MSELoss} ('independent') or {IoULoss, GIoULoss, DIoULoss, CIoULoss} ('union'): all importable
+    from lfd_amd.model with the reference's constructor arguments, and accepted by LFD."""
+    import lfd_amd.model as M
+    arch = configs.ARCHS['WIDERFACE_LFD_XS']
+    base = configs.build_model('WIDERFACE_LFD_XS')
+    cls_losses = [M.BCEWithLogitsLoss(reduction='mean', loss_weight=1.0), M.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25),
+                  M.CrossEntropyLoss(reduction='mean', loss_weight=1.0), M.QualityFocalLoss(use_sigmoid=True, beta=2.0)]
+    reg_losses = [(M.SmoothL1Loss(beta=1.0), 'independent'), (M.MSELoss(), 'independent'), (M.IoULoss(eps=1e-6), 'union'),
+                  (M.GIoULoss(eps=1e-6), 'union'), (M.DIoULoss(eps=1e-6), 'union'), (M.CIoULoss(eps=1e-6), 'union')]
+    for cl in cls_losses:
+        for rl, kind in reg_losses:
+            m = M.LFD(backbone=base._backbone, neck=base._neck, head=base._head, num_classes=1,
+                      regression_ranges=arch['regression_ranges'], point_strides=base._point_strides,
+                      classification_loss_func=cl, regression_loss_func=rl, distance_to_bbox_mode='exp')
+            assert m._regression_loss_type == kind
+    assert hasattr(M, 'L1Loss')
+    with pytest.raises(AssertionError):
+        M.QualityFocalLoss(use_sigmoid=False)
+    with pytest.raises(AssertionError):
+        M.LFD(backbone=base._backbone, neck=base._neck, head=base._head, num_classes=1,
+              regression_ranges=arch['regression_ranges'], point_strides=base._point_strides,
+              classification_loss_func=M.FocalLoss(), regression_loss_func=M.L1Loss())     # not in LFD's accepted set
