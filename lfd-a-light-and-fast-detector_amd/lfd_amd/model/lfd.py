@@ -346,11 +346,20 @@ class LFD(nn.Module):
             tgt = [label, mx] if cname == 'QualityFocalLoss' else label
         else:
             tgt = ct
-        avg_c = weight.sum() if self._enable_classification_weight else pos.nelement() + 1
+        # normalisers: global-batch quantities in the reference (the loss is computed once over the gathered outputs of all
+        # replicas, executor.py:198-200); under image-parallel training they are all-reduced and the rank's loss is scaled
+        # by the world size so that the averaged gradients equal the reference's (same convention as the fused path)
+        n_pos_g, w_sum_g, rank_scale = pos.nelement(), weight.sum(), 1.0
+        if parallel.is_dist():
+            t = parallel.global_count(torch.stack([weight.new_tensor(float(pos.nelement())), weight.sum().float()]))
+            n_pos_g, w_sum_g, rank_scale = t[0], t[1], float(parallel.world_size())
+        avg_c = w_sum_g if self._enable_classification_weight else n_pos_g + 1
         cls_loss = self._classification_loss_func(fc, tgt, avg_factor=avg_c)
+        if rank_scale != 1.0:
+            cls_loss = cls_loss * rank_scale
         frp, rtp = fr[pos], rt[pos]
         if pos.nelement() > 0:
-            avg_r = weight.sum() if self._enable_regression_weight else pos.nelement()
+            avg_r = w_sum_g if self._enable_regression_weight else n_pos_g
             w_r = weight if self._enable_regression_weight else None
             if self._regression_loss_type == 'independent':
                 reg_loss = self._regression_loss_func(frp, rtp, avg_factor=avg_r, weight=w_r)
@@ -366,6 +375,8 @@ class LFD(nn.Module):
                     d = frp.sigmoid() * rmax[..., None]
                 pred_xyxy = self.distance2bbox(allp, d)
                 reg_loss = self._regression_loss_func(pred_xyxy, tgt_xyxy, avg_factor=avg_r, weight=w_r)
+            if rank_scale != 1.0:
+                reg_loss = reg_loss * rank_scale
         else:
             reg_loss = frp.sum()
         loss = cls_loss + reg_loss

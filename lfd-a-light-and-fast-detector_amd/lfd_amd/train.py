@@ -3,7 +3,7 @@ OptimizerHook.after_train_iter (lfd/execution/hooks/optimizer_hook.py:26-36), im
 nn.DataParallel (executor.py:39): forward -> get_loss (global-batch normalisers) -> zero_grad -> backward ->
 one all-reduce of the flat gradient buffer -> clip_grad_norm_ (first `duration` epochs) + SGD update.
 """
-from . import optim
+from . import optim, parallel
 
 
 def train_step(model, optimizer, image_batch, annotation_batch, grad_clip_cfg=None, clip_active=True):
@@ -21,6 +21,8 @@ def backward_and_update(optimizer, loss, grad_clip_cfg=None, clip_active=True):
     fused = isinstance(optimizer, optim.SGD)
     if fused:
         optimizer.allreduce_grads()
+    elif parallel.is_dist():      # any other optimizer: average the gradients over the ranks as one flat bucket
+        parallel.allreduce_mean_([p.grad for g in optimizer.param_groups for p in g['params'] if p.grad is not None])
     grad_norm = 0
     if grad_clip_cfg is not None and clip_active:
         if fused and float(grad_clip_cfg.get('norm_type', 2)) == 2.0:

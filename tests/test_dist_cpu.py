@@ -40,6 +40,12 @@ opt.zero_grad()
 opt.allreduce_grads()
 assert torch.allclose(lin.weight.grad, torch.full((3, 5), 2.0 * 1.5)) and torch.allclose(lin.bias.grad, torch.full((3,), 2.0 * 1.5))
 assert lin.weight.grad.data_ptr() == opt._flat[0].g.data_ptr()
+# 4c. lfd_amd.train.backward_and_update with a plain torch optimizer: gradients are averaged over the ranks before the step
+from lfd_amd import train
+w = torch.nn.Parameter(torch.zeros(3))
+topt = torch.optim.SGD([w], lr=1.0)
+train.backward_and_update(topt, (w * torch.tensor([1.0, 2.0, 3.0]) * float(rank + 1)).sum())
+assert torch.allclose(w.detach(), -1.5 * torch.tensor([1.0, 2.0, 3.0])), w
 # 5. throughput aggregation: max time over ranks
 t = parallel.max_over_ranks(1.0 + rank)
 assert t == 2.0

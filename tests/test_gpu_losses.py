@@ -505,3 +505,50 @@ def test_bce_with_logits_and_quality_focal_loss_vs_reference_golden():
     assert out['loss_values']['classification_loss'] > 0
     out['loss'].backward()
     assert torch.isfinite(cls.grad).all() and float(cls.grad.abs().sum()) > 0
+
+
+def test_image_parallel_normalisers_fused_and_op_by_op_paths_agree(monkeypatch):
+    """Simulated world of 2 (lfd_amd.parallel patched: the "other rank" contributes 7 positives with score sum 3.5): both
+    get_loss paths must use the GLOBAL n_pos (+1) / score-sum normalisers and scale the rank's loss by the world size --
+    and therefore agree with each other and with the hand-computed rescaling of the single-process loss."""
+    from lfd_amd import parallel
+    m = configs.build_model('WIDERFACE_LFD_S').cuda()
+    sizes = [(20, 24), (10, 12), (5, 6), (3, 3), (3, 3)]
+    for i, sz in enumerate(sizes):
+        m._head_indexes_to_feature_map_sizes[i] = sz
+    P = sum(h * w for h, w in sizes)
+    rng = np.random.default_rng(3)
+    ann = _random_annotations(rng, 2, (160, 192), 1, 6)
+    cls0 = torch.from_numpy(rng.normal(-2, 2, (2, P, 1)).astype(np.float32)).cuda()
+    reg0 = torch.from_numpy(rng.normal(0, 1, (2, P, 4)).astype(np.float32)).cuda()
+
+    def run(fused):
+        monkeypatch.setenv('LFD_FUSED_LOSS', fused)
+        c, r = cls0.clone().requires_grad_(True), reg0.clone().requires_grad_(True)
+        out = m.get_loss((c, r), ann)
+        out['loss'].backward()
+        return out['loss_values'], c.grad.clone(), r.grad.clone()
+    single = run('1')
+    other_npos, other_w = 7.0, 3.5
+
+    def fake_count(t):
+        add = torch.zeros_like(t)
+        if t.numel() == 8:            # fused path: {cls_sum, reg_sum, n_pos, score_sum, n_green, ...}
+            add[2], add[3] = other_npos, other_w
+        else:                         # op-by-op path: {n_pos, score_sum}
+            add[0], add[1] = other_npos, other_w
+        return t + add
+    monkeypatch.setattr(parallel, 'is_dist', lambda: True)
+    monkeypatch.setattr(parallel, 'world_size', lambda: 2)
+    monkeypatch.setattr(parallel, 'global_count', fake_count)
+    a, b = run('1'), run('0')
+    for k in ('loss', 'classification_loss', 'regression_loss'):
+        assert a[0][k] == pytest.approx(b[0][k], rel=2e-5), k
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(a[2].cpu().numpy(), b[2].cpu().numpy(), rtol=2e-3, atol=1e-9)
+    # cls_single = S / (n + 1), cls_dist = 2 S / (n + 7 + 1): solve for the local positive count n
+    cs, cd = single[0]['classification_loss'], a[0]['classification_loss']
+    n = (2 * cs - 8 * cd) / (cd - 2 * cs) if abs(cd - 2 * cs) > 1e-12 else 0.0   # from cd (n + 8) = 2 cs (n + 1)
+    assert n > 0 and abs(n - round(n)) < 1e-2, n                                 # an integer number of local positives
+    rs, rd = single[0]['regression_loss'], a[0]['regression_loss']
+    assert rd == pytest.approx(2 * rs * round(n) / (round(n) + 7), rel=1e-4)
