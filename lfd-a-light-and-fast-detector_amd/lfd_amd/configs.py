@@ -19,8 +19,8 @@ def _wf(stem_mode, stem_channels, body_architecture, body_channels, out_indices)
                 range_assign_mode='dist', distance_to_bbox_mode='sigmoid')
 
 
-def _tt(body_architecture, body_channels, out_indices):
-    return dict(block_mode='faster', stem_mode='fast', stem_channels=64, body_architecture=body_architecture,
+def _tt(stem_mode, body_architecture, body_channels, out_indices):
+    return dict(block_mode='faster', stem_mode=stem_mode, stem_channels=64, body_architecture=body_architecture,
                 body_channels=body_channels, out_indices=out_indices, num_neck_channels=128, num_classes=45,
                 num_head_channels=128, num_conv_layers=2, conv_kernel_size=1, gn_groups=16, share_head_flag=True,
                 merge_path_flag=False, classification_loss_type='CrossEntropyLoss', regression_loss_type='IoULoss',
@@ -33,8 +33,8 @@ ARCHS = {
     'WIDERFACE_LFD_M': _wf('fast', 64, [3, 2, 1, 1, 1], [64, 64, 64, 128, 128], ((0, 2), (1, 1), (2, 0), (3, 0), (4, 0))),
     'WIDERFACE_LFD_S': _wf('faster', 64, [4, 2, 2, 3], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 1), (3, 0), (3, 2))),
     'WIDERFACE_LFD_XS': _wf('faster', 32, [4, 2, 2, 3], [64, 64, 64, 64], ((0, 3), (1, 1), (2, 1), (3, 0), (3, 2))),
-    'TT100K_LFD_L': _tt([5, 3, 2, 2], [64, 64, 128, 128], ((0, 4), (1, 2), (2, 1), (3, 1))),
-    'TT100K_LFD_S': _tt([4, 2, 1, 1], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 0), (3, 0))),
+    'TT100K_LFD_L': _tt('fast', [5, 3, 2, 2], [64, 64, 128, 128], ((0, 4), (1, 2), (2, 1), (3, 1))),
+    'TT100K_LFD_S': _tt('faster', [4, 2, 1, 1], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 0), (3, 0))),
 }
 
 
@@ -95,9 +95,6 @@ def perturb_weights(model, seed=1):
             if v.data_ptr() in seen:     # shared head: duplicated keys alias one tensor
                 continue
             seen.add(v.data_ptr())
-            is_norm = (k.endswith('running_mean') or k.endswith('running_var') or
-                       (v.dim() == 1 and ('_norm' in k or '_stem.' in k or '_downsample.1' in k or
-                                          k.split('.')[-2].isdigit() and not k.endswith('num_batches_tracked'))))
             if k.endswith('num_batches_tracked'):
                 continue
             if k.endswith('running_mean'):
@@ -112,5 +109,4 @@ def perturb_weights(model, seed=1):
                 v.copy_(torch.randn(v.shape, generator=g) * 0.1)
             elif v.dim() == 4 and k.startswith('_head.'):
                 v.copy_(torch.randn(v.shape, generator=g) * 0.1)
-            del is_norm
     return model

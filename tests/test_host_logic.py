@@ -335,3 +335,43 @@ def test_every_loss_the_lfd_constructor_accepts_is_provided():
         M.LFD(backbone=base._backbone, neck=base._neck, head=base._head, num_classes=1,
               regression_ranges=arch['regression_ranges'], point_strides=base._point_strides,
               classification_loss_func=M.FocalLoss(), regression_loss_func=M.L1Loss())     # not in LFD's accepted set
+
+
+def test_archs_match_reference_configs(known_answers):
+    """configs.ARCHS is a transcription of the six reference config scripts; the kwargs every constructor receives
+    in the reference's prepare_model() were recorded by tests/golden/make_golden_configs.py (executed from the
+    reference's own source).  Ctor defaults the configs rely on: LFD.range_assign_mode='dist' (lfd.py:23),
+    LFDHead.conv_kernel_size=1 (lfd_head.py:37)."""
+    from lfd_amd import configs
+    ref = known_answers['reference_model_configs']
+    assert sorted(ref) == sorted(configs.ARCHS)
+    for name, arch in configs.ARCHS.items():
+        r = ref[name]
+        bb, neck, head, lfd = r['LFDResNet'], r['SimpleNeck'], r['LFDHead'], r['LFD']
+        as_list = lambda v: [list(e) if isinstance(e, (list, tuple)) else e for e in v]
+        got = dict(block_mode=bb['block_mode'], stem_mode=bb['stem_mode'], stem_channels=bb['stem_channels'],
+                   body_architecture=bb['body_architecture'], body_channels=bb['body_channels'], out_indices=bb['out_indices'],
+                   num_neck_channels=neck['num_neck_channels'], num_classes=lfd['num_classes'],
+                   num_head_channels=head['num_head_channels'], num_conv_layers=head['num_conv_layers'],
+                   conv_kernel_size=head.get('conv_kernel_size', 1), gn_groups=head['norm_cfg']['num_groups'],
+                   share_head_flag=head['share_head_flag'], merge_path_flag=head['merge_path_flag'],
+                   classification_loss_type=head['classification_loss_type'], regression_loss_type=head['regression_loss_type'],
+                   regression_ranges=lfd['regression_ranges'], gray_range_factors=lfd['gray_range_factors'],
+                   range_assign_mode=lfd.get('range_assign_mode', 'dist'), distance_to_bbox_mode=lfd['distance_to_bbox_mode'])
+        assert sorted(got) == sorted(arch), name
+        for k, v in got.items():
+            mine = arch[k]
+            if isinstance(mine, (list, tuple)):
+                mine = as_list(mine)
+            assert mine == v, (name, k, mine, v)
+        # the fixed kwargs configs.build_modules passes
+        assert bb['body_mode'] is None and bb['input_channels'] == 3 and bb['frozen_stages'] == -1 and bb['norm_eval'] is False
+        assert bb['norm_cfg'] == dict(type='BatchNorm2d') and bb['activation_cfg'] == dict(type='ReLU', inplace=True)
+        assert neck['norm_cfg'] == dict(type='BatchNorm2d') and head['norm_cfg']['type'] == 'GroupNorm'
+        assert head['num_classes'] == lfd['num_classes'] and head['num_heads'] == len(arch['out_indices'])
+        assert head['num_input_channels'] == neck['num_neck_channels']
+        assert r['IoULoss'] == dict(eps=1e-6, reduction='mean', loss_weight=1.0)
+        if arch['classification_loss_type'] == 'FocalLoss':
+            assert r['FocalLoss'] == dict(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0)
+        else:
+            assert r['CrossEntropyLoss'] == dict(reduction='mean', loss_weight=1.0)
