@@ -289,26 +289,17 @@ LFD_API int lfd_conv2d_downsample_nhwc_f16(const lfd_conv_desc_t* desc, const vo
                                            const void* ds_w_packed, const float* ds_bias, void* ds_out,
                                            const void* zeros, lfd_stream_t stream);
 
-/* Chained launch of up to 8 consecutive conv3x3 stride-1 64->64 layers on the same [n,h,w] maps -- the 3x3 convs of the
- * FasterBlocks of one backbone stage (lfd_resnet.py:96-154; the reference launches one cuDNN conv per layer) -- in ONE
- * persistent kernel with a device-wide barrier between layers.  Layer i computes
- *   out = relu?(conv3x3(in, w_packed) + bias (+ residual)),   residual may be NULL;
- * results are identical to num_layers calls of lfd_conv2d_nhwc_f16.  `sync_words`: two zero-initialised uint32 in
- * device memory owned by the caller (left zero on return; not to be shared by launches that may run concurrently). */
-typedef struct {
-  const void* in;
-  void* out;
-  const void* w_packed;
-  const float* bias;
-  const void* residual;
-  int32_t relu;
-} lfd_conv_chain_layer_t;
-LFD_API int lfd_conv3x3_c64_chain_nhwc_f16(int32_t n, int32_t h, int32_t w, int32_t num_layers, const lfd_conv_chain_layer_t* layers,
-                                   const void* zeros, void* sync_words, lfd_stream_t stream);
 LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, void* out,
                                 const void* w_packed, const float* bias, const void* residual,
                                 const void* tail_w_packed, const float* tail_bias,
                                 const void* zeros /* 4096-byte line: [0,2048) zero (read), [2048,4096) trash (written) */, lfd_stream_t stream);
+
+/* Parity instrument (not on the product path): the same MFMA conv kernels with the fp32 accumulators (conv + bias, no
+ * activation, no fp16 rounding) written to out_f32 [n, oh, ow, cout].  Used by the engine's G1 mode (SURVEY 8d gate G1:
+ * fp32 inter-layer storage, operands split into fp16 hi + lo parts, three launches per conv).  desc->relu / tail_* ignored
+ * (tail_cout must be 0). */
+LFD_API int lfd_conv2d_nhwc_f16_acc32(const lfd_conv_desc_t* desc, const void* in, float* out_f32, const void* w_packed,
+                                      const float* bias, const void* zeros, lfd_stream_t stream);
 
 /* First stem unit: conv3x3 s2 (3 -> C) + BN + ReLU chained with conv1x1 (C -> C) + BN + ReLU
  * (lfd_resnet.py:356-374 'fast' stem; first half of the 'faster' stem :376-395).

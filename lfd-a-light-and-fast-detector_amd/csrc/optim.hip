@@ -88,6 +88,10 @@ __device__ __forceinline__ void sgd_elem(const SgdArgs& a, float coef, float& p,
 __global__ __launch_bounds__(kThreads) void k_sgd(SgdArgs a) {
   const float coef = a.coef ? a.coef[1] : 1.0f;
   const bool clip = a.coef != nullptr;
+  // overflow guard of the fp16 activation-gradient path (train.hip stores dz as fp16 with a loss scale): a non-finite
+  // total norm gives a NaN coefficient, and torch's clip_grad_norm_ + SGD would write it into every weight.  Skip the
+  // whole update instead (parameters and momentum untouched); the caller sees the non-finite norm in norm_and_coef[0].
+  if (clip && !(coef >= 0.0f && coef <= 1.0f)) return;
   const int64_t n4 = a.n >> 2;
   float4* p4 = reinterpret_cast<float4*>(a.p);
   float4* g4 = reinterpret_cast<float4*>(a.g);

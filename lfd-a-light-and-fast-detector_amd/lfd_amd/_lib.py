@@ -35,12 +35,6 @@ class ConvDesc(C.Structure):
                 ('tail_relu', C.c_int32)]
 
 
-class ConvChainLayer(C.Structure):
-    """lfd_conv_chain_layer_t"""
-    _fields_ = [('in_', C.c_void_p), ('out', C.c_void_p), ('w_packed', C.c_void_p), ('bias', C.c_void_p),
-                ('residual', C.c_void_p), ('relu', C.c_int32)]
-
-
 class HeadDesc(C.Structure):
     """lfd_head_desc_t"""
     _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32), ('level_hw', C.c_int32 * MAX_LEVELS),
@@ -136,7 +130,7 @@ _SIGNATURES = {
     'lfd_groupnorm_finalize': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P, _P]),
     'lfd_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'lfd_conv3x3_c64_chain_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(ConvChainLayer), _P, _P, _P]),
+    'lfd_conv2d_nhwc_f16_acc32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'lfd_conv2d_downsample_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -84,7 +84,7 @@ def _tail_supported(cin, cout, ks, stride):
 
 class _Conv(object):
     """one lfd_conv2d_nhwc_f16 launch"""
-    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds')
+    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w')
 
 
 class _HeadLevel(object):
@@ -128,6 +128,7 @@ class EnginePlan(object):
             norm = bb._stem[i * step + 1] if has_norm else None
             stem_convs.append((k, s, cin, cout) + fold_conv_norm(conv, norm))
         self.stem_first = None   # (C, w1, b1, w2|None, b2|None)
+        self.stem_ref = [(k, s, w, b) for (k, s, _ci, _co, w, b) in stem_convs]   # folded fp32 stem convs, in order
         self.convs = []          # list of _Conv over symbolic buffer ids
         nbuf = [0]
 
@@ -157,7 +158,7 @@ class EnginePlan(object):
             if (idx + 1 < len(stem_convs) and stem_convs[idx + 1][0] == 1 and stem_convs[idx + 1][3] == cout and
                     _tail_supported(cin, cout, k, s)):
                 _, _, _, _, w2, b2 = stem_convs[idx + 1]
-                tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True)
+                tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True, w2)
                 idx += 1
             cur = self._add_conv(cur, new_buf, cin, cout, k, s, True, w, b, tail=tail)
             idx += 1
@@ -194,7 +195,7 @@ class EnginePlan(object):
                         ident = new_buf()
                         self.buf_channels[ident] = dconv.out_channels
                         self.buf_scale[ident] = self.buf_scale[x_in] * 2
-                        fuse_ds = (ops.pack_conv_weight(w).to(dev), b.to(dev).contiguous(), ident)
+                        fuse_ds = (ops.pack_conv_weight(w).to(dev), b.to(dev).contiguous(), ident, w)
                     else:
                         ident = self._add_conv(x_in, new_buf, dconv.in_channels, dconv.out_channels, 1, 2, False, w, b)
                 nconv = blk.num_convs
@@ -211,7 +212,7 @@ class EnginePlan(object):
                         if (nxt.kernel_size[0] == 1 and nxt.out_channels == conv.out_channels and
                                 _tail_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0])):
                             w2, b2 = fold_conv_norm(nxt, getattr(blk, '_norm%d' % (ci + 1), None))
-                            tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True)   # FastBlock 3x3 -> 1x1
+                            tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True, w2)   # FastBlock 3x3 -> 1x1
                     y = self._add_conv(y, new_buf, conv.in_channels, conv.out_channels, conv.kernel_size[0],
                                        conv.stride[0], True, w, b, tail=tail, res=ident if last else None,
                                        ds=fuse_ds if ci == 1 else None)
@@ -226,6 +227,7 @@ class EnginePlan(object):
         c = _Conv()
         c.cin, c.cout, c.ks, c.stride, c.relu = cin, cout, ks, stride, relu
         c.w = ops.pack_conv_weight(w).to(self.device)
+        c.ref_w = w          # folded fp32 OIHW weight (tests re-derive every layer from the tensors the engine stored)
         c.b = b.to(self.device).contiguous()
         c.tail = tail
         c.ds = ds
@@ -358,17 +360,7 @@ class EnginePlan(object):
             check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
                                       ptr(st.bufs[self.stem_out]), sp), 'lfd_stem_conv_f16')
         z = ops.zero_line(self.device)
-        chains = {} if after else st.conv_chains(self)
-        skip_until = -1
         for ci, c in enumerate(self.convs):
-            if ci <= skip_until:
-                continue
-            if ci in chains:
-                # consecutive 3x3 s1 64->64 convs of a stage: one persistent launch (lfd_conv3x3_c64_chain_nhwc_f16)
-                layers, nl, (n_, h_, w_), sync = chains[ci]
-                check(l.lfd_conv3x3_c64_chain_nhwc_f16(n_, h_, w_, nl, layers, ptr(z), ptr(sync), sp), 'lfd_conv3x3_c64_chain_nhwc_f16')
-                skip_until = ci + nl - 1
-                continue
             if after and ci in after:
                 after[ci]()
             src = st.bufs[c.src]
@@ -441,41 +433,6 @@ class EnginePlan(object):
 class _ShapeState(object):
     """Activation buffers and outputs for one input shape."""
 
-    def conv_chains(self, plan):
-        """{first conv index: (ctypes layer array, count, (n, h, w), sync words)} for the runs of >= 2 consecutive
-        conv3x3 s1 64->64 launches on the same maps (the 3x3 convs of one backbone stage) -- they go out as one
-        persistent kernel with device-wide barriers between layers (csrc/conv.hip k_conv_chain).  Opt-in
-        (LFD_CONV_CHAIN=1): measured 1.13 ms vs 0.79 ms per step -- on this 8-XCD part a device-wide barrier inside a
-        kernel (L2 write-back + invalidate per workgroup, 512 pollers on one line) costs ~35 us, a kernel boundary ~6."""
-        if self._chains is None:
-            import os
-            self._chains = {}
-            if os.environ.get('LFD_CONV_CHAIN', '0') == '1':
-                def ok(c):
-                    return (c.cin == 64 and c.cout == 64 and c.ks == 3 and c.stride == 1 and c.tail is None and c.ds is None)
-                i, convs = 0, plan.convs
-                while i < len(convs):
-                    j = i
-                    while (j < len(convs) and ok(convs[j]) and j - i < 8 and
-                           self.bufs[convs[j].src].shape == self.bufs[convs[i].src].shape and (j == i or convs[j].src == convs[j - 1].dst)):
-                        j += 1
-                    if j - i >= 2:
-                        arr = (_lib.ConvChainLayer * (j - i))()
-                        for k in range(i, j):
-                            c = convs[k]
-                            e = arr[k - i]
-                            e.in_, e.out = self.bufs[c.src].data_ptr(), self.bufs[c.dst].data_ptr()
-                            e.w_packed, e.bias = c.w.data_ptr(), c.b.data_ptr()
-                            e.residual = self.bufs[c.res].data_ptr() if c.res is not None else None
-                            e.relu = int(c.relu)
-                        shp = self.bufs[convs[i].src].shape
-                        sync = torch.zeros(2, dtype=torch.int32, device=plan.device)
-                        self._chains[i] = (arr, j - i, (shp[0], shp[1], shp[2]), sync)
-                        i = j
-                    else:
-                        i += 1
-        return self._chains
-
     def stem_mid(self, plan):
         """stride-2 stem intermediate, only materialised when the two-kernel stem has to run"""
         if self._stem_mid is None:
@@ -501,7 +458,6 @@ class _ShapeState(object):
                 self.bufs[b] = torch.empty((n, hh, ww, plan.buf_channels[b]), dtype=torch.float16, device=dev)
             self.dims = dims
             self._stem_mid = None
-            self._chains = None
             if plan.head is not None:
                 self.sizes = [dims[t] for t in plan.taps]
                 self.p_off = []

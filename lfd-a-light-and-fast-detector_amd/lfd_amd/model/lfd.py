@@ -8,13 +8,14 @@ fp32, `head_indexes_to_feature_map_sizes`, `get_results`, `predict_for_single_im
                             per-class NMS, csrc/postproc.hip) instead of the reference's
                             per-image Python loop with ~20 tiny ATen kernels per level and a
                             blocking D2H of the NMS mask per image (lfd.py:412-431, nms_kernel.cu:105-111)
-  get_loss               -> HIP focal / IoU kernels; target assignment stays tensor algebra on the
-                            device for now (next row)
+  get_loss               -> device target assignment (csrc/targets.hip) + the three-launch fused loss
+                            (csrc/getloss.hip); other loss modules take the op-by-op path on the HIP loss kernels
 
-Train-mode forward (`self.training`): autograd through PyTorch-ROCm conv/norm ops on the same
-parameters (per-replica BatchNorm batch statistics exactly like the reference).  The
-hand-written dgrad/wgrad kernels are the next row of the scope table; this is stated in
-DESIGN.md, it is not a silent fallback of the inference path.
+Train-mode forward (`self.training`): for the shipped configurations the whole network runs forward and
+backward on the hand-written kernels as one autograd node (train_engine.NetworkTrainFunction, csrc/train.hip;
+per-replica BatchNorm batch statistics exactly like the reference).  `LFD_HIP_TRAIN=0`, or a module
+configuration train_engine does not cover (none of the six named configs), routes the same parameters through
+PyTorch-ROCm autograd instead -- a documented training-only fallback; inference has none.
 """
 import os
 
@@ -128,6 +129,13 @@ class LFD(nn.Module):
         iou_thr = self._nms_cfg.get('iou_thr', 0.5) if iou_thr is None else iou_thr
         agn = self._nms_cfg.get('class_agnostic', False) if class_agnostic is None else class_agnostic
         cache = self.__dict__.setdefault('_step_graphs', {})
+        # the captured graph reads the packed weights of ONE EnginePlan: a parameter change (optimizer step,
+        # load_state_dict, .to()) makes get_plan build a new plan, and every graph captured against the old one is
+        # dropped here (replaying it would silently use the old weights -- or freed memory)
+        plan = engine.get_plan(self, self._backbone, self._neck, self._head, x.device)
+        if self.__dict__.get('_step_graphs_plan') is not plan:
+            cache.clear()
+            self.__dict__['_step_graphs_plan'] = plan
         key = (x.data_ptr(), tuple(x.shape), x.dtype, meta.data_ptr(), float(score_thr), float(iou_thr), bool(agn), max_candidates)
         ent = cache.get(key)
         if ent is None:

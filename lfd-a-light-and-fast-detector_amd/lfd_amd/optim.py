@@ -45,6 +45,7 @@ class _FlatGroup(object):
         self.norm_and_coef = torch.zeros(2, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.ws = None   # norm workspace, allocated on first use (needs liblfd_hip.so)
+        self.rebound = False   # set when adopt_params() had to move / re-bind the buffers (SGD re-binds its state views)
         with torch.no_grad():
             for p, off in zip(params, self.offsets):
                 v = self.view(self.p, p, off)
@@ -69,16 +70,48 @@ class _FlatGroup(object):
     def view(flat, p, off):
         return flat[off:off + p.numel()].view(p.shape)
 
+    def adopt_params(self):
+        """Make sure every parameter is (still) the view of the flat parameter buffer.  `model.cuda()` / `.to()` /
+        an assign-style load AFTER the optimizer was constructed (the reference builds the optimizer in
+        prepare_optimizer() on CPU parameters and Executor moves the model afterwards, executor.py:36-39) replaces
+        p.data behind the optimizer's back: the kernels would then update a buffer the model no longer reads.
+        Re-flatten instead: the flat buffers follow the parameters to their device, the current values are copied
+        in and the parameters are re-bound.  Returns True if anything had to be re-bound."""
+        dev = self.params[0].device
+        base = self.p.data_ptr()
+        if dev == self.device and all(p.device == dev and p.data_ptr() == base + 4 * off and p.is_contiguous()
+                                      for p, off in zip(self.params, self.offsets)):
+            return False
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise RuntimeError('lfd_amd.optim.SGD needs float32 parameters on one device (got %s on %s)'
+                                   % (p.dtype, p.device))
+        with torch.no_grad():
+            if dev != self.device:
+                self.p = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+                self.g, self.m = self.g.to(dev), self.m.to(dev)
+                self.norm_and_coef, self.sumsq = self.norm_and_coef.to(dev), self.sumsq.to(dev)
+                self.ws = None
+                self.device = dev
+            for p, off in zip(self.params, self.offsets):
+                v = self.view(self.p, p, off)
+                if p.data_ptr() != v.data_ptr():
+                    v.copy_(p.data)
+                    p.data = v
+        return True
+
     def adopt_grads(self):
         """Make sure every .grad is (still) the view of the flat gradient buffer; gradients that were replaced
         (zero_grad(set_to_none=True) followed by backward) are copied in.  Returns False if some are None."""
+        if self.adopt_params():
+            self.rebound = True
         complete = True
         for p, off in zip(self.params, self.offsets):
             g = p.grad
             if g is None:
                 complete = False
                 continue
-            if g.data_ptr() != self.g.data_ptr() + 4 * off or not g.is_contiguous():
+            if g.device != self.device or g.data_ptr() != self.g.data_ptr() + 4 * off or not g.is_contiguous():
                 v = self.view(self.g, p, off)
                 v.copy_(g)
                 p.grad = v
@@ -174,10 +207,22 @@ class SGD(torch.optim.Optimizer):
             dist.all_reduce(fg.g, op=dist.ReduceOp.SUM)
             fg.g /= dist.get_world_size()
 
+    def _rebind_state(self, fg):
+        """after _FlatGroup.adopt_params() moved the buffers: momentum buffers become views of the moved buffer again"""
+        if not fg.rebound:
+            return
+        fg.rebound = False
+        for p, off in zip(fg.params, fg.offsets):
+            st = self.state.get(p)
+            if st is not None and st.get('momentum_buffer') is not None:
+                st['momentum_buffer'] = fg.view(fg.m, p, off)
+
     # -- update ------------------------------------------------------------------------------------------------
     def _step(self, clip):
         for group, fg in zip(self.param_groups, self._flat):
-            if not fg.adopt_grads():
+            ok = fg.adopt_grads()
+            self._rebind_state(fg)
+            if not ok:
                 raise RuntimeError('lfd_amd.optim.SGD.step: a parameter has no gradient (call optimizer.zero_grad(), '
                                    'which keeps the flat gradient views, rather than setting .grad = None)')
             mom = float(group['momentum'])

@@ -407,19 +407,19 @@ def _fold(sd, conv, norm):
     return _h(w.float()), b.float()
 
 
-def lfd_forward_fp16(sd, arch, x):
-    """Same network as lfd_forward but with the ENGINE's numerics emulated on the CPU: BatchNorm
-    folded, weights rounded to fp16, fp32 accumulation, activations rounded to fp16 at every
-    fused-unit boundary (after each conv(+residual)+ReLU, the downsample branch, the neck and the
-    GroupNorm+ReLU outputs); GroupNorm statistics and the final cls/reg convs stay fp32.
-    Gate G2 of SURVEY 8d: the HIP path must match THIS within accumulation-order noise."""
+def backbone_forward_fp16(sd, arch, x, return_all=False):
+    """Backbone half of lfd_forward_fp16: the tapped maps (fp16-valued fp32 tensors).  return_all: additionally the
+    list of every fused unit's stored output in execution order (stem convs, then per block: [downsample], conv1, block
+    output) -- what the engine keeps in HBM, for per-layer comparisons."""
     pf = '_backbone.'
     seq = {'fast': [(0, 1, 2, 1), (3, 4, 1, 0)], 'faster': [(0, 1, 2, 1), (3, 4, 1, 0), (6, 7, 2, 1), (9, 10, 1, 0)],
            'fastest': [(0, 1, 2, 1), (3, 4, 2, 1)]}[arch['stem_mode']]
     y = _h(x)
+    units = []
     for ci, ni, s, p in seq:
         w, b = _fold(sd, f'{pf}_stem.{ci}', f'{pf}_stem.{ni}')
         y = _h(F.relu(F.conv2d(y, w, b, stride=s, padding=p)))
+        units.append(('stem%d' % ci, y))
     feats = []
     oi = sorted(tuple(t) for t in arch['out_indices'])
     for i in range(max(s for s, _ in oi) + 1):
@@ -430,6 +430,7 @@ def lfd_forward_fp16(sd, arch, x):
             if j == 0:
                 w, b = _fold(sd, bl + '_downsample.0', bl + '_downsample.1')
                 ident = _h(F.conv2d(y, w, b, stride=2))
+                units.append(('stage%d.%d.ds' % (i, j), ident))
             nconv = 3 if arch['block_mode'] == 'fast' else 2
             o = y
             for c in range(1, nconv + 1):
@@ -438,9 +439,16 @@ def lfd_forward_fp16(sd, arch, x):
                 o = F.conv2d(o, w, b, stride=stride if c == 1 else 1, padding=k // 2)
                 if c < nconv:
                     o = _h(F.relu(o))
+                    units.append(('stage%d.%d.conv%d' % (i, j, c), o))
             y = _h(F.relu(o + ident))
+            units.append(('stage%d.%d' % (i, j), y))
             if (i, j) in oi:
                 feats.append(y)
+    return (feats, units) if return_all else feats
+
+
+def head_forward_fp16(sd, arch, feats):
+    """Neck + head half of lfd_forward_fp16 from given tapped maps -> (cls [N,P,C'], reg [N,P,4], sizes)."""
     G = arch['gn_groups']
     cls_l, reg_l = [], []
     for i, f in enumerate(feats):
@@ -471,3 +479,12 @@ def lfd_forward_fp16(sd, arch, x):
     cls = torch.cat([c.permute(0, 2, 3, 1).reshape(c.shape[0], -1, c.shape[1]) for c in cls_l], 1)
     reg = torch.cat([r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, 4) for r in reg_l], 1)
     return cls, reg, sizes
+
+
+def lfd_forward_fp16(sd, arch, x):
+    """Same network as lfd_forward but with the ENGINE's numerics emulated on the CPU: BatchNorm
+    folded, weights rounded to fp16, fp32 accumulation, activations rounded to fp16 at every
+    fused-unit boundary (after each conv(+residual)+ReLU, the downsample branch, the neck and the
+    GroupNorm+ReLU outputs); GroupNorm statistics and the final cls/reg convs stay fp32.
+    Gate G2 of SURVEY 8d: the HIP path must match THIS within accumulation-order noise."""
+    return head_forward_fp16(sd, arch, backbone_forward_fp16(sd, arch, x))

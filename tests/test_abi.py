@@ -64,7 +64,7 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
     import subprocess
     from conftest import ROOT
     from lfd_amd import _lib
-    pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc, 'lfd_conv_chain_layer_t': _lib.ConvChainLayer,
+    pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc,
              'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
              'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob}
     header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()

@@ -216,36 +216,3 @@ def test_fused_stem_uint8_frames_equal_normalised_fp16_frames(n, h, w):
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
-
-
-def test_chained_conv_launch_equals_single_launches():
-    """lfd_conv3x3_c64_chain_nhwc_f16 (one persistent kernel, device-wide barrier between layers) == the same layers
-    as separate lfd_conv2d_nhwc_f16 launches, bit for bit (same tiles, same arithmetic), incl. residual layers."""
-    import ctypes as C
-    from lfd_amd._lib import ConvChainLayer, check, lib, ptr, stream_ptr
-    g = torch.Generator().manual_seed(11)
-    n, h, w, nl = 2, 37, 53, 4
-    x0 = (torch.randn(n, h, w, 64, generator=g) * 0.5).half().cuda()
-    ws = [ops.pack_conv_weight((torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()).cuda() for _ in range(nl)]
-    bs = [(torch.randn(64, generator=g) * 0.1).cuda() for _ in range(nl)]
-    # reference: single launches  y1 = conv(x0); y2 = conv(y1) + x0; y3 = conv(y2); y4 = conv(y3) + y2
-    ref, cur = [], x0
-    for i in range(nl):
-        res = None if i % 2 == 0 else (x0 if i == 1 else ref[1])
-        cur = ops.conv2d_nhwc(cur, ws[i], bs[i], 64, 64, 3, 1, True, residual=res)
-        ref.append(cur)
-    outs = [torch.empty_like(x0) for _ in range(nl)]
-    arr = (ConvChainLayer * nl)()
-    for i in range(nl):
-        arr[i].in_ = (x0 if i == 0 else outs[i - 1]).data_ptr()
-        arr[i].out = outs[i].data_ptr()
-        arr[i].w_packed, arr[i].bias = ws[i].data_ptr(), bs[i].data_ptr()
-        arr[i].residual = None if i % 2 == 0 else (x0 if i == 1 else outs[1]).data_ptr()
-        arr[i].relu = 1
-    sync = torch.zeros(2, dtype=torch.int32, device='cuda')
-    for _ in range(2):      # twice: the kernel must leave its counters zero
-        check(lib().lfd_conv3x3_c64_chain_nhwc_f16(n, h, w, nl, arr, ptr(ops.zero_line(x0.device)), ptr(sync), stream_ptr()), 'chain')
-    torch.cuda.synchronize()
-    assert sync.tolist() == [0, 0]
-    for a, b in zip(outs, ref):
-        assert torch.equal(a, b)

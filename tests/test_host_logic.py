@@ -375,3 +375,21 @@ def test_archs_match_reference_configs(known_answers):
             assert r['FocalLoss'] == dict(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0)
         else:
             assert r['CrossEntropyLoss'] == dict(reduction='mean', loss_weight=1.0)
+
+
+def test_flat_sgd_rebinds_parameters_replaced_behind_its_back():
+    """The reference builds the optimizer on CPU parameters and moves the model afterwards (executor.py:36-39);
+    Module._apply then replaces p.data.  The flat groups must notice and re-bind (here: same device, storage replaced)."""
+    from lfd_amd import optim
+    m = configs.build_model('WIDERFACE_LFD_XS')
+    o = optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    fg = o._flat[0]
+    with torch.no_grad():
+        for p in m.parameters():
+            p.data = p.data.clone() * 2.0          # what .to() / an assign-style load does
+    assert any(p.data_ptr() != fg.p.data_ptr() + 4 * off for p, off in zip(fg.params, fg.offsets))
+    vals = [p.detach().clone() for p in m.parameters()]
+    assert fg.adopt_grads() and fg.rebound
+    for p, off, v in zip(fg.params, fg.offsets, vals):
+        assert p.data_ptr() == fg.p.data_ptr() + 4 * off and torch.equal(p.detach(), v)
+    assert not fg.adopt_params()
