@@ -122,34 +122,108 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
     return classes
 
 
-def cpu_baseline():
-    """oracle port of the reference CPU path on ONE 1080p frame (bounded sample)."""
-    from oracle import net_oracle
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(reps=5):
+    """The reference's CPU path on THIS host, bounded sample: 1 warm-up + `reps` timed 1920x1080 frames (bs 1), median.
+    Forward = oracle/net_oracle.py (the reference's modules restated functionally: PyTorch fp32 eager NCHW conv /
+    BatchNorm / GroupNorm -- `kind: port`); post-processing = sigmoid, decode, strict threshold (torch ops as in
+    lfd.py:449-499) + greedy NMS through the REFERENCE's own compiled nms_cpu.cpp (oracle/_ref, nms_cpu.cpp:7-66) when the
+    prebuilt module is present (`nms_leg: reference`), else the C port.  Reported next to the GPU number; not a target."""
+    from oracle import build_ref, net_oracle
     from lfd_amd import configs
     arch = configs.ARCHS[MODEL]
     m = configs.build_model(MODEL)
     configs.perturb_weights(m)
     m.eval()
     sd = {k: v.clone() for k, v in m.state_dict().items()}
-    # torch's CPU conv does not scale past a few tens of threads on this class of host (a 256-thread
-    # run of one 1080p frame takes > 40 s, 16 threads measured fastest on the MI355X box's host)
-    cores = min(os.cpu_count() or 1, int(os.environ.get('LFD_CPU_BASELINE_THREADS', '16')))
+    host = os.cpu_count() or 1
+    # torch's CPU conv does not scale past a few tens of threads on this class of host (a 256-thread run of one 1080p
+    # frame measured > 40 s, 16 threads fastest on the MI355X box's host): threads used are stated as `cores`
+    cores = min(host, int(os.environ.get('LFD_CPU_BASELINE_THREADS', '16')))
     torch.set_num_threads(cores)
+    ref_ext = None
+    try:
+        ref_ext = build_ref.load_ref()
+    except Exception:
+        ref_ext = None
     x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(0)) * 2 - 1
     strides = net_oracle.strides_of(arch)
-    times = []
+    t_fwd, t_all, kept = [], [], 0
     with torch.no_grad():
-        for i in range(4):
-            t0 = time.time()
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
             cls, reg, sizes = net_oracle.lfd_forward(sd, arch, x)
-            sc = cls[0].sigmoid().numpy()
-            thr = float(np.partition(sc.reshape(-1), -TARGET_K)[-TARGET_K])
-            net_oracle.get_results_single(cls[0].numpy(), reg[0].numpy(), sizes, strides, arch, thr, 0.4, False, (H, W), 1.0)
-            times.append(time.time() - t0)
-    t = float(np.median(times[1:]))
-    return dict(value=round(1.0 / t, 3), unit='images/s', cores=cores, kind='port',
-                sample='1 warm-up + 3 timed 1920x1080 frames (bs 1), median; torch %s fp32 eager NCHW forward '
-                       '(oracle/net_oracle.py) + decode + C greedy NMS at K=%d candidates' % (torch.__version__, TARGET_K))
+            t1 = time.perf_counter()
+            if i == 0:
+                thr = float(np.partition(cls[0].sigmoid().numpy().reshape(-1), -TARGET_K)[-TARGET_K])
+                t1 = time.perf_counter()
+            if ref_ext is not None:
+                sc = cls[0].sigmoid()
+                bx = torch.from_numpy(net_oracle.decode_boxes(reg[0], sizes, strides, arch['regression_ranges'], 'sigmoid',
+                                                              'union', (H, W), 1.0))
+                idx = torch.nonzero(sc[:, 0] > thr)[:, 0]
+                dets = torch.cat([bx[idx], sc[idx]], 1).contiguous()
+                keep = ref_ext.nms(dets, 0.4)                 # the reference's nms_cpu_kernel, one class -> offsets are 0
+                kept = int(keep.numel())
+            else:
+                d, l, _, _ = net_oracle.get_results_single(cls[0].numpy(), reg[0].numpy(), sizes, strides, arch, thr, 0.4, False,
+                                                           (H, W), 1.0)
+                kept = len(l)
+            t2 = time.perf_counter()
+            if i:
+                t_fwd.append(t1 - t0)
+                t_all.append(t2 - t0)
+    tf, ta = float(np.median(t_fwd)), float(np.median(t_all))
+    return dict(value=round(1.0 / ta, 3), unit='images/s', cores=cores, kind='port',
+                forward_only=round(1.0 / tf, 3), nms_leg='reference' if ref_ext is not None else 'port',
+                host_cores=host, cpu_model=_cpu_model(), reps=reps, kept=kept,
+                sample='1 warm-up + %d timed 1920x1080 frames (bs 1), median; value = forward + sigmoid + decode + threshold + '
+                       'greedy NMS at K=%d candidates, forward_only = network alone; torch %s fp32 eager NCHW on %d of the '
+                       'host\'s %d hardware threads' % (reps, TARGET_K, torch.__version__, cores, host))
+
+
+def train_bench(dev, steps=10, warmup=3):
+    """BASELINE.json configs[4] on one GPU: WIDERFACE_LFD_S train-from-scratch iteration, synthetic 640x640, bs 32 --
+    forward + device targets + fused get_loss + hand-written backward + clip_grad_norm_ + SGD (lfd_amd.train.train_step).
+    826 GFLOP per iteration = 3 x the 8.606 GFLOP/img forward x 32.  Extra key of the bench line so that the
+    driver records it; the headline `value` is the inference metric."""
+    from lfd_amd import configs, optim, train
+    torch.manual_seed(0)
+    m = configs.build_model(MODEL).to(dev).train()
+    opt = optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    rng = np.random.default_rng(0)
+    bs, size = 32, 640
+    x = torch.randn(bs, 3, size, size, device=dev)
+    ann = []
+    for _ in range(bs):
+        wh = np.exp(rng.uniform(np.log(8), np.log(200), (6, 2)))
+        xy = rng.uniform(0, 1, (6, 2)) * (np.array([size, size]) - wh).clip(1)
+        ann.append((np.concatenate([xy, wh], 1).astype(np.float32), np.zeros(6, np.int64)))
+    clip = dict(max_norm=10, norm_type=2)
+    for _ in range(warmup):
+        lv, _ = train.train_step(m, opt, x, ann, clip, True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        lv, _ = train.train_step(m, opt, x, ann, clip, True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    gf = 3 * 8.606 * bs
+    return dict(workload='WIDERFACE_LFD_S train step 640x640 bs 32 (forward + targets + loss + backward + clip + SGD), fp16 '
+                         'activations / fp32 accumulate + parameters', ms_per_iter=round(dt * 1e3, 3),
+                images_per_s=round(bs / dt, 1), gflop_per_iter=round(gf, 1), tflops=round(gf / dt / 1e3, 1),
+                frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup, loss=lv['loss'])
 
 
 def latency_bs1(model, dev, iters=200):
@@ -198,6 +272,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
+    ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--max-candidates', type=int, default=8192)
     args = ap.parse_args()
 
@@ -253,6 +328,16 @@ def main():
             dt = float(t.item())
         counts = det.counts.cpu().numpy()
         assert int(counts[:, 2].max()) == 0, 'candidate capacity overflow: raise --max-candidates'
+        # per-step distribution with HIP events on the launch stream (SURVEY 8d protocol: >= 100 iterations, median + p95);
+        # outside the contract's timed region
+        nev = max(100, args.steps)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
+        for e0, e1 in evs:
+            e0.record()
+            step()
+            e1.record()
+        torch.cuda.synchronize()
+        ev_ms = np.sort(np.array([e0.elapsed_time(e1) for e0, e1 in evs]))
 
         result = None
         if rank == 0:
@@ -260,7 +345,10 @@ def main():
             result = {
                 'metric': 'images/sec WIDERFACE-S 1920x1080 bs=8 end-to-end inference (forward + decode + NMS)',
                 'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-                'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+                'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+                'step_ms_hip_events': {'median': round(float(ev_ms[len(ev_ms) // 2]), 4), 'p95': round(float(ev_ms[int(len(ev_ms) * 0.95)]), 4),
+                                       'min': round(float(ev_ms[0]), 4), 'iterations': int(len(ev_ms))},
+                'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
                 'config': {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16 NHWC resident in HBM: '
                                        'backbone+neck+head (HIP MFMA convs) + decode + threshold + NMS, results on device',
@@ -308,6 +396,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_latency:
         with torch.no_grad():
             result['latency_bs1'] = latency_bs1(model, dev)
+    if rank == 0 and world == 1 and not args.no_train:
+        try:
+            result['train'] = train_bench(dev)
+        except Exception as e:       # the inference line must not be lost to the extra key
+            result['train'] = {'error': repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline()
