@@ -200,3 +200,57 @@ def test_training_on_a_fixed_batch_reduces_the_loss_like_the_pytorch_path(monkey
     assert h[0] == pytest.approx(t[0], rel=2e-2)                     # same start (fp16 vs fp32 forward)
     assert np.mean(h[-5:]) < 0.6 * h[0], h                           # it learns
     assert np.mean(h[-5:]) < 1.25 * np.mean(t[-5:]) + 0.05, (h[-5:], t[-5:])
+
+
+def test_config5_widerface_s_640_loss_curve_vs_fp32_autograd(monkeypatch):
+    """BASELINE config 5 protocol on one GPU's share, reduced batch: WIDERFACE_LFD_S from scratch (reference init, seed of
+    the config), synthetic 640x640 frames, G ~ U{1..20} boxes per image with w, h ~ logU[6, 300], a FRESH batch
+    of 8 every iteration, SGD momentum 0.9 / weight decay 1e-4 / lr 0.1 with the config's linear warm-up (ratio 0.1 over 200
+    iterations, WIDERFACE_LFD_S.py:218-241), clip_grad_norm_(10) -- 24 iterations.  The all-HIP iteration (fp16 activations,
+    loss scale 1024, fp32 accumulate / parameters) against the same nn.Modules through PyTorch-ROCm fp32 autograd + the
+    op-by-op loss + torch.optim.SGD from identical initial weights: the loss CURVES must agree (tolerance on the loss, not
+    on bits: two fp32 runs with different reduction orders drift apart at the same rate)."""
+    import json
+    import os
+    from conftest import ROOT
+    steps, bs, size = 24, 8, 640
+    rng = np.random.default_rng(55)
+    batches = []
+    for _ in range(steps):
+        x = torch.from_numpy(rng.normal(0, 1, (bs, 3, size, size)).astype(np.float32))
+        ann = []
+        for _ in range(bs):
+            g = int(rng.integers(1, 21))
+            wh = np.exp(rng.uniform(np.log(6), np.log(300), (g, 2)))
+            xy = rng.uniform(0, 1, (g, 2)) * (size - wh).clip(1)
+            ann.append((np.concatenate([xy, wh], 1).astype(np.float32), np.zeros(g, np.int64)))
+        batches.append((x, ann))
+    clip = dict(max_norm=10, norm_type=2)
+    curves, norms = {}, {}
+    for mode in ('hip', 'torch'):
+        monkeypatch.setenv('LFD_HIP_TRAIN', '1' if mode == 'hip' else '0')
+        monkeypatch.setenv('LFD_FUSED_LOSS', '1' if mode == 'hip' else '0')
+        m = configs.build_model('WIDERFACE_LFD_S', seed=666).cuda().train()
+        kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-4)
+        opt = optim.SGD(m.parameters(), **kw) if mode == 'hip' else torch.optim.SGD(m.parameters(), **kw)
+        losses, gns = [], []
+        for it, (x, ann) in enumerate(batches):
+            lr = 0.1 * (0.1 + (1 - 0.1) * it / 200.0)          # LrSchedulerHook linear warm-up (lr_scheduler_hook.py:80-99)
+            for gr in opt.param_groups:
+                gr['lr'] = lr
+            lv, gn = train.train_step(m, opt, x.cuda(), ann, clip, clip_active=True)
+            assert np.isfinite(lv['loss']) and np.isfinite(float(gn)), (mode, it)
+            losses.append(float(lv['loss']))
+            gns.append(float(gn))
+        curves[mode], norms[mode] = losses, gns
+    h, t = np.array(curves['hip']), np.array(curves['torch'])
+    rel = np.abs(h - t) / np.abs(t)
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    json.dump(dict(hip=curves['hip'], torch=curves['torch'], grad_norm_hip=norms['hip'], grad_norm_torch=norms['torch'],
+                   rel=rel.tolist()), open(os.path.join(out, 'train_curve_config5.json'), 'w'), indent=1)
+    print('config 5 loss curve: hip %s\n torch %s\n max rel diff %.3e (first step %.3e)' % (np.round(h, 4).tolist(), np.round(t, 4).tolist(),
+                                                                                        rel.max(), rel[0]))
+    assert rel[0] < 5e-3                                  # same start: only the fp16 forward differs
+    assert rel[:8].max() < 3e-2 and rel.max() < 1e-1      # the curves stay together over the 24 iterations
+    assert np.mean(h[-4:]) < h[0]                         # and go down
