@@ -87,7 +87,10 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
         src, dst = st.bufs[c.src], st.bufs[c.dst]
         d = _lib.ConvDesc(n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                           c.cout if c.tail else 0, 1 if c.tail else 0)
-        if c.ds is not None:
+        if c.blk is not None:
+            fn = lambda: check(l.lfd_fasterblock_fused_f16(n, src.shape[1], src.shape[2], ptr(src), ptr(dst), ptr(c.w), ptr(c.b),  # noqa: E731
+                                                           ptr(c.blk[0]), ptr(c.blk[1]), ptr(z), stream_ptr()), 'block')
+        elif c.ds is not None:
             fn = lambda: check(l.lfd_conv2d_downsample_nhwc_f16(C.byref(d), ptr(src), ptr(dst), ptr(c.w), ptr(c.b),  # noqa: E731
                                                                 ptr(c.ds[0]), ptr(c.ds[1]), ptr(st.bufs[c.ds[2]]), ptr(z),
                                                                 stream_ptr()), 'conv+ds')
@@ -109,6 +112,12 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             by += dst.numel() * 2
         name = 'conv%dx%d_s%d_%dto%d%s (k_conv)' % (c.ks, c.ks, c.stride, c.cin, c.cout,
                                                    '+1x1' if c.tail else ('+downsample1x1s2' if c.ds is not None else ''))
+        if c.blk is not None:
+            # whole residual block: two 3x3 convs; algorithmic bytes = the map read once + written once (the identity is
+            # the same tensor as the input; the intermediate never reaches HBM)
+            fl *= 2
+            by = (src.numel() + dst.numel()) * 2
+            name = 'fasterblock_fused_2x_conv3x3_s1_64to64 (k_block64)'
         add(name, us, fl, by)
     us = timed(lambda: plan.run_head(st))
     hf = 0.0
@@ -372,7 +381,15 @@ def main():
                              'share': round(c['time_us'] / tot, 3), 'tflops': round(tf, 1), 'gbs': round(gb, 0),
                              'frac_mfma': round(tf / MFMA_PEAK_TFLOPS, 3), 'frac_hbm': round(gb / HBM_PEAK_GBS, 3)})
             dom = rows[0]
-            k33 = [r for r in rows if r['kernel'].startswith('conv3x3_s1_64to64')]
+            # every 3x3 stride-1 64->64 conv of the backbone: the fused residual blocks + the stand-alone launches
+            k33c = [c for nm, c in br.items() if nm.startswith('conv3x3_s1_64to64') or nm.startswith('fasterblock_fused')]
+            k33 = []
+            if k33c:
+                t33 = sum(c['time_us'] for c in k33c)
+                f33 = sum(c['flops'] for c in k33c)
+                k33 = [{'kernel': 'all conv3x3 s1 64->64 (k_block64 fused blocks + k_conv)', 'tflops': round(f33 / t33 / 1e6, 1),
+                        'frac_mfma': round(f33 / t33 / 1e6 / MFMA_PEAK_TFLOPS, 3), 'time_us_per_forward': round(t33, 1),
+                        'launches': sum(c['launches'] for c in k33c)}]
             pmc = {}
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))

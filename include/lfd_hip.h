@@ -294,6 +294,16 @@ LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, voi
                                 const void* tail_w_packed, const float* tail_bias,
                                 const void* zeros /* 4096-byte line: [0,2048) zero (read), [2048,4096) trash (written) */, lfd_stream_t stream);
 
+/* A whole residual block of the backbone without downsample branch (FasterBlock, lfd_resnet.py:96-154; every block of a
+ * stage but the first) in ONE launch:   out = relu( conv3x3(relu(conv3x3(in, w1) + b1), w2) + b2 + in ),  64 -> 64 -> 64
+ * channels, stride 1, BN folded into (w, b), NHWC fp16 [n, h, w, 64].  The intermediate map lives in LDS tile by tile
+ * (csrc/block.hip: producer / consumer wave specialisation, both filters register-stationary); results are bit-identical
+ * to two lfd_conv2d_nhwc_f16 launches.  w1_packed / w2_packed: lfd_conv_packed_weight_halfs(64, 64, 3) halfs each;
+ * `in` must not alias `out`; zeros: the 4096-byte line of lfd_conv2d_nhwc_f16. */
+LFD_API int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
+                                      const float* b1, const void* w2_packed, const float* b2, const void* zeros,
+                                      lfd_stream_t stream);
+
 /* Parity instrument (not on the product path): the same MFMA conv kernels with the fp32 accumulators (conv + bias, no
  * activation, no fp16 rounding) written to out_f32 [n, oh, ow, cout].  Used by the engine's G1 mode (SURVEY 8d gate G1:
  * fp32 inter-layer storage, operands split into fp16 hi + lo parts, three launches per conv).  desc->relu / tail_* ignored

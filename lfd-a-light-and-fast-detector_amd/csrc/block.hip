@@ -1,0 +1,376 @@
+// csrc/block.hip -- lfd_fasterblock_fused_f16: one launch per residual block of the LFD backbone.
+//
+// Reference: FasterBlock.forward (lfd/model/backbone/lfd_resnet.py:96-154) for the blocks WITHOUT a downsample branch
+// (every block of a stage but the first):      y = ReLU( BN2(conv3x3(ReLU(BN1(conv3x3(x))))) + x ),   64 -> 64 -> 64 channels.
+// The reference runs two cuDNN convolutions plus BatchNorm / ReLU / add kernels with the 64-channel intermediate map going
+// through memory; the two-launch path of this library (conv_impl.h) still writes and re-reads it once.  Here the
+// intermediate never leaves the CU: per 8 x 16 output tile its 10 x 18 halo tile is produced into LDS and consumed in place
+// (HBM traffic of a block = one read + one write of the map + the residual re-read served by L2).
+//
+// MI355X-first structure -- PRODUCER / CONSUMER WAVE SPECIALISATION on the register file:
+//   * one 512-thread workgroup per CU = two waves per SIMD.  Waves 0-3 are conv1 PRODUCERS, waves 4-7 conv2 CONSUMERS; the
+//     hardware places wave w and wave w+4 on the same SIMD, so every SIMD's matrix pipe is shared by one producer and
+//     one consumer whose non-MFMA phases (LDS-DMA issue, epilogues, stores) hide under the partner's MFMAs.
+//   * both filters are STATIONARY: a wave owns a 32-output-channel slab of ONE of the two convolutions (36 MFMA fragments =
+//     36 KB) for the lifetime of the persistent workgroup -- the 512 KB register file of a CU is what holds the 144 KB of
+//     filters; nothing is re-fetched per tile.  (Producers keep 22 fragments in VGPRs and 14 in LDS -- they carry three
+//     accumulator tiles -- consumers all 36 in VGPRs.)
+//   * software pipeline over tiles with ONE s_barrier per step: in step s the producers contract tile s (input halo tile
+//     fetched by global->LDS DMA one step ahead, double buffered) into mid[s & 1] while the consumers contract tile s-1 from
+//     mid[(s-1) & 1], add the identity (fp16 loads of x, L2-hot: the producers' DMA just pulled the same lines), and store.
+//   * v_mfma_f32_32x32x16_f16, A = filters, B = pixels (lane = pixel): bias / residual / ReLU / fp16 pack are lane-local;
+//     the mid tile is written pixel-major with a 144-byte pitch (conflict-free ds_write_b64 and ds_read_b128, no swizzle
+//     arithmetic on the consumer side: one address register, every tap an immediate offset).
+//   * conv1 covers the 180 halo pixels of the mid tile as 6 x 32 LINEARLY numbered pixels (m -> row m / 18, column m % 18):
+//     93.75 % of the MFMA slots do useful work; halo recompute factor (192 + 128) / (2 x 128) = 1.25.
+//   * results are BIT-IDENTICAL to the two-launch path: same operand rounding points (fp16 intermediate after ReLU), same
+//     k order, bias in the accumulator, one rounding of acc + residual (tests/test_gpu_block.py).
+#include "conv_impl.h"
+
+namespace {
+
+struct BlockArgs {
+  const _Float16* in;    // [N,H,W,64]
+  _Float16* out;         // [N,H,W,64]
+  const half8* w1;       // packed [2][36][64] half8 (ops.pack_conv_weight of the BN-folded conv1)
+  const float* b1;       // [64]
+  const half8* w2;
+  const float* b2;
+  const _Float16* zeros;  // 4 KB line: [0,2048) zero, [2048,4096) trash
+  int N, H, W;
+  int tiles_x, tiles_y, ntiles;
+};
+
+struct BK {
+  static constexpr int TH = 8, TW = 16;                 // output tile
+  static constexpr int MH = TH + 2, MW = TW + 2;        // mid tile (conv1 output with conv2's halo): 10 x 18 = 180 pixels
+  static constexpr int MPIX = MH * MW;
+  static constexpr int IH = TH + 4, IW = TW + 4;        // input halo tile 12 x 20
+  static constexpr int IN_PIXB = 144;                   // input tile: same padded pixel pitch as the mid tile (see issue_dma)
+  static constexpr int IN_ROWB = IW * IN_PIXB;          // 2880
+  static constexpr int IN_BYTES = IH * IN_ROWB;         // 34560
+  static constexpr int MID_PIXB = 144;                  // 128 + 16: pixel pitch that spreads 16 consecutive pixels over all banks
+  static constexpr int MID_ROWB = 2816;                 // 18 * 144 = 2592 padded to a multiple of 256 (row pairs stay conflict-free)
+  static constexpr int MID_BYTES = MH * MID_ROWB;       // 28160
+  static constexpr int STG_WAVE = 64 * 64;              // consumer-private staging: 64 pixels x 32 channels fp16
+  static constexpr int NK = 36;                         // k-steps of a 3x3x64 contraction
+  static constexpr int WLP = 10;                        // producer weight fragments living in LDS (per cout tile)
+  static constexpr int NKRP = NK - WLP;                 // ... and in VGPRs
+  static constexpr int OFF_IN = 0;
+  static constexpr int OFF_MID = OFF_IN + 2 * IN_BYTES;          // 69120
+  static constexpr int OFF_STG = OFF_MID + 2 * MID_BYTES;        // 125440
+  static constexpr int OFF_WP = OFF_STG + 4 * STG_WAVE;          // 141824
+  static constexpr int OFF_BIAS = OFF_WP + 2 * WLP * 1024;       // 162304
+  static constexpr int LDS_BYTES = OFF_BIAS + 2 * 64 * 4;        // 162816 <= 163840
+};
+static_assert(BK::LDS_BYTES <= 160 * 1024, "LDS capacity");
+
+__device__ __forceinline__ void tile_coords(const BlockArgs& a, int t, int& n, int& ty0, int& tx0) {
+  const int per_img = a.tiles_x * a.tiles_y;
+  n = t / per_img;
+  const int tr = t - n * per_img;
+  ty0 = tr / a.tiles_x;
+  tx0 = tr - ty0 * a.tiles_x;
+}
+
+// ------------------------------------------------------------------------------------------------ producer (conv1)
+__device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw, int t_first, int t_end, int t_step) {
+  const int lane = threadIdx.x & 63;
+  const int ct = pw & 1, pgp = pw >> 1;
+  const int h = lane >> 5, pix = lane & 31;
+  const float* sbias = reinterpret_cast<const float*>(smem + BK::OFF_BIAS);
+
+  // ---- stationary conv1 filter slab: 22 fragments in VGPRs, 14 in LDS (shared by the two producers of this cout tile)
+  half8 wreg[BK::NKRP];
+  const half8* wsrc = a.w1 + (size_t)ct * BK::NK * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < BK::NKRP; ++k) wreg[k] = wsrc[(size_t)k * 64];
+  half8* wlds = reinterpret_cast<half8*>(smem + BK::OFF_WP) + (ct * BK::WLP) * 64 + lane;
+  if (pgp == 0) {
+#pragma unroll
+    for (int k = 0; k < BK::WLP; ++k) wlds[k * 64] = wsrc[(size_t)(BK::NKRP + k) * 64];   // visible after the first barrier
+  }
+
+  // ---- per-lane geometry of this wave's three 32-pixel MFMA tiles: mid pixel m = (3 pgp + pt) * 32 + pix, linear over 10 x 18
+  int pbase[3], mwoff[3], mrc[3];
+  bool mval[3];
+#pragma unroll
+  for (int pt = 0; pt < 3; ++pt) {
+    const int m = (pgp * 3 + pt) * 32 + pix;
+    mval[pt] = m < BK::MPIX;
+    const int mm = mval[pt] ? m : BK::MPIX - 1;
+    const int row = mm / BK::MW, col = mm - row * BK::MW;
+    pbase[pt] = row * BK::IN_ROWB + col * BK::IN_PIXB + h * 16;
+    mwoff[pt] = row * BK::MID_ROWB + col * BK::MID_PIXB + ct * 64 + h * 8;
+    mrc[pt] = (row << 8) | col;
+  }
+
+  // ---- input halo DMA: 12 rows x 20 pixels, pixel pitch 144 B in LDS (8 chunks of 16 B + one 16-byte gap), so that the
+  // MFMA B-fragment reads are conflict-free WITHOUT a swizzle and every tap / k-step is an immediate offset from one address
+  // register per pixel tile.  A DMA instruction writes lane-linear (LDS byte 16 L of its 1 KB window), so the gaps are made on
+  // the SOURCE side: lane L carries chunk L % 9 of pixel L / 9 (chunk 8 = the gap: masked off together with lane 63, whose
+  // 16 bytes would land in the next window).  A 2880-byte row is three windows of 7 + 7 + 6 pixels; rows pw, pw + 4, pw + 8
+  // belong to producer wave pw; out-of-image pixels come from the zero line.
+  const long rowpitch = (long)a.W * 128;
+  auto issue_dma = [&](int t, int buf) {
+    int ol = lane;
+    asm volatile("" : "+v"(ol));          // recompute the per-lane constants per tile instead of pinning registers
+    const int lpx = (ol * 57) >> 9;       // ol / 9 for ol < 64
+    const int ck = ol - 9 * lpx;
+    int n, ty0, tx0;
+    tile_coords(a, t, n, ty0, tx0);
+    const int gy0 = ty0 * BK::TH - 2, gx0 = tx0 * BK::TW - 2;
+    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * rowpitch + (long)gx0 * 128 + ck * 16;
+    const char* zsrc = reinterpret_cast<const char*>(a.zeros) + (ck & 7) * 16;
+    char* lbase = smem + BK::OFF_IN + buf * BK::IN_BYTES;
+    if (ck < 8 && ol < 63) {
+#pragma unroll
+      for (int seg = 0; seg < 3; ++seg) {
+        const int col = 7 * seg + lpx;
+        const bool xv = (gx0 + col >= 0) && (gx0 + col < a.W) && (col < BK::IW);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int iy = pw + 4 * i;
+          const int gy = gy0 + iy;
+          const char* src = (xv && gy >= 0 && gy < a.H) ? p00 + iy * rowpitch + col * 128 : zsrc;
+          if (seg < 2 || col < BK::IW) dma16(src, lbase + iy * BK::IN_ROWB + seg * 1008);
+        }
+      }
+    }
+  };
+
+  int t = t_first;
+  if (t < t_end) issue_dma(t, 0);
+  int buf = 0;
+  for (;; t += t_step, buf ^= 1) {
+    const bool active = t < t_end;
+    // tile t's DMA (issued one step ago) is the only VMEM traffic of a producer wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    block_barrier();       // in[buf] landed for everybody; the consumers are done with mid[buf] (tile t - 2 t_step)
+    if (!active) break;    // (the consumers run one more step and meet nobody: the workgroup's barrier count stays equal, see k_block)
+    if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
+
+    int n, ty0, tx0;
+    tile_coords(a, t, n, ty0, tx0);
+    const char* xin = smem + BK::OFF_IN;
+    const int pb0 = pbase[0] + buf * BK::IN_BYTES, pb1 = pbase[1] + buf * BK::IN_BYTES, pb2 = pbase[2] + buf * BK::IN_BYTES;
+    f32x16 acc[3];
+    {
+      const float* bp = sbias + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+          acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y; acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
+        }
+      }
+    }
+    auto xfrag = [&](int k, int pt) {
+      const int r = k / 12, s = (k / 4) % 3, q = k % 4;
+      return *reinterpret_cast<const half8*>(xin + (pt == 0 ? pb0 : (pt == 1 ? pb1 : pb2)) + (r * BK::IN_ROWB + s * BK::IN_PIXB + q * 32));
+    };
+    constexpr int PD = 2;
+    half8 xq[PD + 1][3];
+    half8 wq[PD + 1];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt) xq[k][pt] = xfrag(k, pt);
+      if (k >= BK::NKRP) wq[k] = wlds[(k - BK::NKRP) * 64];
+    }
+#pragma unroll
+    for (int k = 0; k < BK::NK; ++k) {
+      if (k + PD < BK::NK) {
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
+        if (k + PD >= BK::NKRP) wq[(k + PD) % (PD + 1)] = wlds[(k + PD - BK::NKRP) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const half8 wf = (k < BK::NKRP) ? wreg[k < BK::NKRP ? k : 0] : wq[k % (PD + 1)];
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: ReLU -> fp16 -> mid[buf]; halo pixels OUTSIDE THE IMAGE are conv2's zero padding, not conv1 outputs
+    char* mid = smem + BK::OFF_MID + buf * BK::MID_BYTES;
+#pragma unroll
+    for (int pt = 0; pt < 3; ++pt) {
+      if (mval[pt]) {
+        const int my = ty0 * BK::TH - 1 + (mrc[pt] >> 8), mx = tx0 * BK::TW - 1 + (mrc[pt] & 255);
+        const bool inimg = my >= 0 && my < a.H && mx >= 0 && mx < a.W;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 v;
+          v.x = lfd_cvt_pk_max(acc[pt][4 * g + 0], acc[pt][4 * g + 1], LFD_PK_RELU);
+          v.y = lfd_cvt_pk_max(acc[pt][4 * g + 2], acc[pt][4 * g + 3], LFD_PK_RELU);
+          if (!inimg) { v.x = 0u; v.y = 0u; }
+          *reinterpret_cast<uint2*>(mid + mwoff[pt] + 16 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ consumer (conv2)
+__device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw, int t_first, int t_end, int t_step) {
+  const int lane = threadIdx.x & 63;
+  const int ct = cw & 1, pgc = cw >> 1;
+  const int h = lane >> 5, pix = lane & 31;
+  const float* sbias = reinterpret_cast<const float*>(smem + BK::OFF_BIAS) + 64;
+  const int co_base = ct * 32;
+
+  half8 wreg[BK::NK];
+  const half8* wsrc = a.w2 + (size_t)ct * BK::NK * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < BK::NK; ++k) wreg[k] = wsrc[(size_t)k * 64];
+
+  // mid pixel of output pixel (row 4 pgc + 2 pt + (pix >> 4), column pix & 15) at tap (0, 0); taps / pt / q are immediates
+  const int cbase = (pgc * 4 + (pix >> 4)) * BK::MID_ROWB + (pix & 15) * BK::MID_PIXB + h * 16;
+  char* stg = smem + BK::OFF_STG + cw * BK::STG_WAVE;
+  const long rowpitch = (long)a.W * 128;
+
+  int t = t_first;        // the tile the PRODUCERS work on in this step; this wave consumes the previous one
+  int buf = 0;
+  int tp = -1;
+  for (;; t += t_step, buf ^= 1) {
+    block_barrier();       // mid[buf ^ 1] (tile tp) is complete
+    if (tp >= 0) {
+      int n, ty0, tx0;
+      tile_coords(a, tp, n, ty0, tx0);
+      const char* mid = smem + BK::OFF_MID + (buf ^ 1) * BK::MID_BYTES;
+      f32x16 acc[2];
+      {
+        const float* bp = sbias + ct * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y; acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
+          }
+        }
+      }
+      auto xfrag = [&](int k, int pt) {
+        const int r = k / 12, s = (k / 4) % 3, q = k % 4;
+        return *reinterpret_cast<const half8*>(mid + cbase + (pt * 2 * BK::MID_ROWB + r * BK::MID_ROWB + s * BK::MID_PIXB + q * 32));
+      };
+      // identity branch: requested two thirds into the contraction (its ~L2 latency hides under the last 12 k-steps
+      // without holding 16 registers across the whole loop)
+      half4 resv[2][4];
+      constexpr int RES_K = 22;
+      constexpr int PD = 3;
+      half8 xq[PD + 1][2];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) xq[k][pt] = xfrag(k, pt);
+      }
+#pragma unroll
+      for (int k = 0; k < BK::NK; ++k) {
+        if (k + PD < BK::NK) {
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
+        }
+        if (k == RES_K) {
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            const int oy = ty0 * BK::TH + pgc * 4 + pt * 2 + (pix >> 4);
+            const int ox = tx0 * BK::TW + (pix & 15);
+            const bool ok = oy < a.H && ox < a.W;
+            const _Float16* rp = a.in + (((size_t)n * a.H + (ok ? oy : 0)) * a.W + (ok ? ox : 0)) * 64 + co_base + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) resv[pt][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[k], xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- epilogue: + identity -> ReLU -> fp16 -> wave-private staging (64 pixels x 64 B, chunk XOR (p >> 2) & 3) ->
+      // 16-byte stores: four lanes write the 64-byte half line of one pixel (the other cout tile's wave writes the other half)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int p = pt * 32 + pix;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float x0 = acc[pt][4 * g + 0] + (float)resv[pt][g][0], x1 = acc[pt][4 * g + 1] + (float)resv[pt][g][1];
+          const float x2 = acc[pt][4 * g + 2] + (float)resv[pt][g][2], x3 = acc[pt][4 * g + 3] + (float)resv[pt][g][3];
+          uint2 v;
+          v.x = lfd_cvt_pk_max(x0, x1, LFD_PK_RELU);
+          v.y = lfd_cvt_pk_max(x2, x3, LFD_PK_RELU);
+          *reinterpret_cast<uint2*>(stg + p * 64 + ((g ^ ((p >> 2) & 3)) << 4) + 8 * h) = v;
+        }
+      }
+      char* obase = reinterpret_cast<char*>(a.out) + ((long)n * a.H + ty0 * BK::TH + pgc * 4) * rowpitch + (long)tx0 * BK::TW * 128 + ct * 64;
+      char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (threadIdx.x & 127) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = j * 64 + lane;
+        const int p = idx >> 2, c = idx & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + p * 64 + ((c ^ ((p >> 2) & 3)) << 4));
+        const int orow = (p >> 5) * 2 + ((p >> 4) & 1), ocol = p & 15;       // p = pt * 32 + pix
+        const bool ok = (ty0 * BK::TH + pgc * 4 + orow < a.H) && (tx0 * BK::TW + ocol < a.W);
+        char* dst = ok ? obase + orow * rowpitch + ocol * 128 + c * 16 : trash;
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+    if (t >= t_end) break;   // the producers had no tile in this step: tp was the last one
+    tp = t;
+  }
+}
+
+__global__ __launch_bounds__(512) void k_block64(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (threadIdx.x < 128) {
+    float* sb = reinterpret_cast<float*>(smem + BK::OFF_BIAS);
+    sb[threadIdx.x] = threadIdx.x < 64 ? a.b1[threadIdx.x] : a.b2[threadIdx.x - 64];   // visible after the first barrier
+  }
+  // persistent tile walk, XCD-contiguous ranges (block b runs on XCD b % 8): same mapping as conv_impl.h
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int t_begin = xcd * per_xcd;
+  const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
+  const int t_step = (nblk + 7 - xcd) / 8;
+  // Both roles execute exactly (tiles of this workgroup + 1) barriers: the producers one per tile plus the one they leave
+  // on, the consumers one per step of the producers plus the step in which they drain the last tile.
+  if (wave < 4) producer(a, smem, wave, t_begin + bix, t_end, t_step);
+  else consumer(a, smem, wave - 4, t_begin + bix, t_end, t_step);
+}
+
+}  // namespace
+
+extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
+                                         const float* b1, const void* w2_packed, const float* b2, const void* zeros,
+                                         lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!in || !out || !w1_packed || !b1 || !w2_packed || !b2 || !zeros || in == out) return LFD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  BlockArgs a{};
+  a.in = (const _Float16*)in; a.out = (_Float16*)out;
+  a.w1 = (const half8*)w1_packed; a.b1 = b1; a.w2 = (const half8*)w2_packed; a.b2 = b2;
+  a.zeros = (const _Float16*)zeros;
+  a.N = n; a.H = h; a.W = w;
+  a.tiles_x = (w + BK::TW - 1) / BK::TW;
+  a.tiles_y = (h + BK::TH - 1) / BK::TH;
+  a.ntiles = n * a.tiles_x * a.tiles_y;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            BK::LDS_BYTES) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1)
+      return LFD_ERR_LAUNCH_FAILED;
+    cus = c;
+  }
+  int blocks = a.ntiles < cus ? a.ntiles : cus;      // one 512-thread workgroup per CU (LDS: 159.5 KB each)
+  hipLaunchKernelGGL(k_block64, dim3(blocks), dim3(512), BK::LDS_BYTES, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}

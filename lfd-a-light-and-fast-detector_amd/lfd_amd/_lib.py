@@ -130,6 +130,7 @@ _SIGNATURES = {
     'lfd_groupnorm_finalize': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P, _P]),
     'lfd_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_fasterblock_fused_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_conv2d_nhwc_f16_acc32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'lfd_conv2d_downsample_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

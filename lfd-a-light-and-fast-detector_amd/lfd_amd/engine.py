@@ -84,7 +84,7 @@ def _tail_supported(cin, cout, ks, stride):
 
 class _Conv(object):
     """one lfd_conv2d_nhwc_f16 launch"""
-    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w')
+    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w', 'blk')
 
 
 class _HeadLevel(object):
@@ -127,6 +127,8 @@ class EnginePlan(object):
             conv = bb._stem[i * step]
             norm = bb._stem[i * step + 1] if has_norm else None
             stem_convs.append((k, s, cin, cout) + fold_conv_norm(conv, norm))
+        import os
+        self.fuse_blocks = os.environ.get('LFD_FUSED_BLOCK', '1') == '1'
         self.stem_first = None   # (C, w1, b1, w2|None, b2|None)
         self.stem_ref = [(k, s, w, b) for (k, s, _ci, _co, w, b) in stem_convs]   # folded fp32 stem convs, in order
         self.convs = []          # list of _Conv over symbolic buffer ids
@@ -201,6 +203,16 @@ class EnginePlan(object):
                 nconv = blk.num_convs
                 y = x_in
                 ci = 1
+                if (self.fuse_blocks and blk._downsample is None and nconv == 2 and
+                        all(getattr(blk, '_conv%d' % q).kernel_size[0] == 3 and getattr(blk, '_conv%d' % q).stride[0] == 1 and
+                            getattr(blk, '_conv%d' % q).in_channels == 64 and getattr(blk, '_conv%d' % q).out_channels == 64
+                            for q in (1, 2))):
+                    # whole residual block in one launch (csrc/block.hip): the intermediate map never reaches HBM
+                    w1, b1 = fold_conv_norm(blk._conv1, getattr(blk, '_norm1', None))
+                    w2, b2 = fold_conv_norm(blk._conv2, getattr(blk, '_norm2', None))
+                    y = self._add_conv(x_in, new_buf, 64, 64, 3, 1, True, w1, b1, res=x_in)
+                    self.convs[-1].blk = (ops.pack_conv_weight(w2).to(dev), b2.to(dev).contiguous(), w2)
+                    ci = nconv + 1
                 while ci <= nconv:
                     conv = getattr(blk, '_conv%d' % ci)
                     norm = getattr(blk, '_norm%d' % ci, None)
@@ -227,6 +239,7 @@ class EnginePlan(object):
         c = _Conv()
         c.cin, c.cout, c.ks, c.stride, c.relu = cin, cout, ks, stride, relu
         c.w = ops.pack_conv_weight(w).to(self.device)
+        c.blk = None         # (w2 packed, b2, w2 folded fp32): this launch is a whole fused FasterBlock (conv, conv2, + src)
         c.ref_w = w          # folded fp32 OIHW weight (tests re-derive every layer from the tensors the engine stored)
         c.b = b.to(self.device).contiguous()
         c.tail = tail
@@ -364,6 +377,10 @@ class EnginePlan(object):
             if after and ci in after:
                 after[ci]()
             src = st.bufs[c.src]
+            if c.blk is not None:
+                check(l.lfd_fasterblock_fused_f16(st.n, src.shape[1], src.shape[2], ptr(src), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b),
+                                                  ptr(c.blk[0]), ptr(c.blk[1]), ptr(z), sp), 'lfd_fasterblock_fused_f16')
+                continue
             d = _lib.ConvDesc(st.n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                               c.cout if c.tail else 0, 1 if c.tail else 0)
             if c.ds is not None:

@@ -466,6 +466,20 @@ def conv2d_nhwc(x, w_packed, bias, cin, cout, ks, stride, relu, residual=None, t
     return out
 
 
+def fasterblock_fused(x, w1_packed, b1, w2_packed, b2, out=None):
+    """relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2 + x) for NHWC fp16 [N,H,W,64] in one launch (csrc/block.hip)."""
+    require_cuda(x, 'fasterblock_fused')
+    if x.dtype != torch.float16 or not x.is_contiguous() or x.dim() != 4 or x.shape[3] != 64:
+        raise RuntimeError('fasterblock_fused: x must be contiguous fp16 NHWC with 64 channels')
+    n, h, w_, _ = x.shape
+    with torch.cuda.device(x.device):
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib().lfd_fasterblock_fused_f16(n, h, w_, ptr(x), ptr(out), ptr(w1_packed), ptr(b1), ptr(w2_packed), ptr(b2),
+                                              ptr(zero_line(x.device)), stream_ptr()), 'lfd_fasterblock_fused_f16')
+    return out
+
+
 # ------------------------------------------------------------------ training-mode conv stack (csrc/train.hip)
 _train_ws = {}
 

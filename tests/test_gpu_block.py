@@ -1,0 +1,84 @@
+"""lfd_fasterblock_fused_f16 (csrc/block.hip): a whole FasterBlock without downsample branch in one launch.
+Gate 1: BIT-IDENTICAL to the two-launch path (lfd_conv2d_nhwc_f16 twice: same rounding points, same k order) for every
+shape class -- single pixel, tile-boundary sizes, odd sizes, the backbone's 135x240 / 68x120 / 34x60 maps at batch 8.
+Gate 2: against a float64 convolution of the same fp16 operands (independent of the other kernel)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lfd_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _operands(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, h, w, 64, generator=g) * 0.5).half()
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().float()
+    b1 = torch.randn(64, generator=g) * 0.1
+    b2 = torch.randn(64, generator=g) * 0.1
+    return x, w1, b1, w2, b2
+
+
+def _both(x, w1, b1, w2, b2):
+    xc = x.cuda()
+    p1, p2 = ops.pack_conv_weight(w1).cuda(), ops.pack_conv_weight(w2).cuda()
+    mid = ops.conv2d_nhwc(xc, p1, b1.cuda(), 64, 64, 3, 1, True)
+    two = ops.conv2d_nhwc(mid, p2, b2.cuda(), 64, 64, 3, 1, True, residual=xc)
+    one = ops.fasterblock_fused(xc, p1, b1.cuda(), p2, b2.cuda())
+    torch.cuda.synchronize()
+    return one, two
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (1, 2, 3), (3, 5, 7), (1, 8, 16), (1, 9, 17), (2, 16, 32), (1, 7, 15), (2, 37, 45),
+                                   (1, 17, 30), (8, 34, 60), (8, 68, 120), (8, 135, 240), (2, 180, 320), (1, 270, 480)])
+def test_fused_block_is_bit_identical_to_two_launches(shape):
+    one, two = _both(*_operands(*shape, seed=sum(shape)))
+    assert torch.isfinite(one.float()).all()
+    bad = (one != two)
+    assert not bool(bad.any()), 'mismatches: %d of %d, first at %s' % (int(bad.sum()), bad.numel(), bad.nonzero()[0].tolist())
+
+
+def test_fused_block_is_deterministic_and_repeatable():
+    ops_ = _operands(4, 68, 120, 3)
+    a, _ = _both(*ops_)
+    b, _ = _both(*ops_)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 45), (1, 68, 120)])
+def test_fused_block_vs_float64(shape):
+    x, w1, b1, w2, b2 = _operands(*shape, seed=9)
+    one, _ = _both(x, w1, b1, w2, b2)
+    x64 = x.float().permute(0, 3, 1, 2).double()
+    mid = F.conv2d(x64, w1.double(), b1.double(), padding=1).relu().float().half().double()
+    ref = (F.conv2d(mid, w2.double(), b2.double(), padding=1) + x64).relu()
+    got = one.float().cpu().permute(0, 3, 1, 2).double()
+    tol = 1.2e-3 * ref.abs().clamp(min=1.0)
+    assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+
+
+def test_fused_block_rejects_aliasing_and_bad_shapes():
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.float16).cuda()
+    w = torch.zeros(2, 36, 64, 8, dtype=torch.float16).cuda()
+    b = torch.zeros(64).cuda()
+    with pytest.raises(RuntimeError):
+        ops.fasterblock_fused(x, w, b, w, b, out=x)
+    with pytest.raises(RuntimeError):
+        ops.fasterblock_fused(torch.zeros(1, 8, 8, 32, dtype=torch.float16).cuda(), w, b, w, b)
+
+
+def test_engine_with_and_without_block_fusion_agree(monkeypatch):
+    """whole network: LFD_FUSED_BLOCK=0 (two launches per block) and the default give identical logits"""
+    from lfd_amd import configs
+    outs = []
+    x = (torch.rand(2, 200, 312, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).half().cuda()
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LFD_FUSED_BLOCK', flag)
+        m = configs.build_model('WIDERFACE_LFD_S')
+        configs.perturb_weights(m)
+        m.eval().cuda()
+        with torch.no_grad():
+            outs.append([t.clone() for t in m.forward_resident(x)])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

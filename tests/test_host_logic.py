@@ -117,9 +117,12 @@ def test_engine_plan_structure_on_cpu():
     assert plan.stem_first[0] == 64 and plan.stem_first[3] is not None
     assert plan.stem_fused is not None and plan.stem_second is not None
     assert plan.stem_second.tail is not None and plan.stem_second.stride == 2 and plan.stem_second.ks == 3
-    n3 = sum(1 for c in plan.convs if c.ks == 3)
+    n3 = sum(2 if c.blk is not None else 1 for c in plan.convs if c.ks == 3)
     n1 = sum(1 for c in plan.convs if c.ks == 1)
     assert (n3, n1) == (2 * 11, 0)              # 11 FasterBlocks; the 4 downsample branches ride on conv1
+    # the 64-channel blocks without a downsample branch are ONE launch each (csrc/block.hip): 3 + 1 + 1 of them
+    assert sum(1 for c in plan.convs if c.blk is not None) == 5 and len(plan.convs) == 22 - 5
+    assert all(c.res == c.src and c.cin == c.cout == 64 for c in plan.convs if c.blk is not None)
     assert sum(1 for c in plan.convs if c.ds is not None) == 4
     assert len(plan.taps) == 5 and len(plan.levels) == 5
     assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
