@@ -13,7 +13,7 @@
 //     one consumer whose non-MFMA phases (LDS-DMA issue, epilogues, stores) hide under the partner's MFMAs.
 //   * both filters are STATIONARY: a wave owns a 32-output-channel slab of ONE of the two convolutions (36 MFMA fragments =
 //     36 KB) for the lifetime of the persistent workgroup -- the 512 KB register file of a CU is what holds the 144 KB of
-//     filters; nothing is re-fetched per tile.  (Producers keep 22 fragments in VGPRs and 14 in LDS -- they carry three
+//     filters; nothing is re-fetched per tile.  (Producers keep 25 fragments in VGPRs and 11 in LDS -- they carry three
 //     accumulator tiles -- consumers all 36 in VGPRs.)
 //   * software pipeline over tiles with ONE s_barrier per step: in step s the producers contract tile s (input halo tile
 //     fetched by global->LDS DMA one step ahead, double buffered) into mid[s & 1] while the consumers contract tile s-1 from
@@ -47,31 +47,61 @@ struct BK {
   static constexpr int MPIX = MH * MW;
   static constexpr int IH = TH + 4, IW = TW + 4;        // input halo tile 12 x 20
   static constexpr int IN_PIXB = 144;                   // input tile: same padded pixel pitch as the mid tile (see issue_dma)
-  static constexpr int IN_ROWB = IW * IN_PIXB;          // 2880
-  static constexpr int IN_BYTES = IH * IN_ROWB;         // 34560
+  static constexpr int IN_ROWB = 3104;                  // 20 * 144 = 2880 padded so that ROWB / 16 = 2 (mod 16): with the 18-wide linear
+                                                        // pixel numbering of conv1 the step from column 17 to column 0 of the next row is
+                                                        // then +9 sixteen-byte units like every other step -> conflict-free ds_read_b128
+  static constexpr int IN_BYTES = IH * IN_ROWB;         // 37248
   static constexpr int MID_PIXB = 144;                  // 128 + 16: pixel pitch that spreads 16 consecutive pixels over all banks
   static constexpr int MID_ROWB = 2816;                 // 18 * 144 = 2592 padded to a multiple of 256 (row pairs stay conflict-free)
   static constexpr int MID_BYTES = MH * MID_ROWB;       // 28160
-  static constexpr int STG_WAVE = 64 * 64;              // consumer-private staging: 64 pixels x 32 channels fp16
+  static constexpr int STG_WAVE = 32 * 64;              // consumer-private staging: 32 pixels x 32 channels fp16 (one MFMA tile at a time)
   static constexpr int NK = 36;                         // k-steps of a 3x3x64 contraction
-  static constexpr int WLP = 10;                        // producer weight fragments living in LDS (per cout tile)
+  static constexpr int WLP = 11;                        // producer weight fragments living in LDS (per cout tile)
   static constexpr int NKRP = NK - WLP;                 // ... and in VGPRs
   static constexpr int OFF_IN = 0;
-  static constexpr int OFF_MID = OFF_IN + 2 * IN_BYTES;          // 69120
-  static constexpr int OFF_STG = OFF_MID + 2 * MID_BYTES;        // 125440
-  static constexpr int OFF_WP = OFF_STG + 4 * STG_WAVE;          // 141824
-  static constexpr int OFF_BIAS = OFF_WP + 2 * WLP * 1024;       // 162304
-  static constexpr int LDS_BYTES = OFF_BIAS + 2 * 64 * 4;        // 162816 <= 163840
+  static constexpr int OFF_MID = OFF_IN + 2 * IN_BYTES;          // 74496
+  static constexpr int OFF_STG = OFF_MID + 2 * MID_BYTES;        // 130816
+  static constexpr int OFF_WP = OFF_STG + 4 * STG_WAVE;          // 139008
+  static constexpr int OFF_BIAS = OFF_WP + 2 * WLP * 1024;       // 161536
+  static constexpr int LDS_BYTES = OFF_BIAS + 2 * 64 * 4;        // 162048 <= 163840
 };
 static_assert(BK::LDS_BYTES <= 160 * 1024, "LDS capacity");
 
-__device__ __forceinline__ void tile_coords(const BlockArgs& a, int t, int& n, int& ty0, int& tx0) {
-  const int per_img = a.tiles_x * a.tiles_y;
-  n = t / per_img;
-  const int tr = t - n * per_img;
-  ty0 = tr / a.tiles_x;
-  tx0 = tr - ty0 * a.tiles_x;
-}
+#ifdef LFD_BLOCK_TIMING
+// phase stamps of workgroup 0: [role 0 = producer wave 0, 1 = consumer wave 4][step < 16][stamp < 8] (shader clock)
+__device__ unsigned long long g_blk_dbg[2 * 16 * 8];
+#define BT(role, i) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && dbg_step < 16) { g_blk_dbg[((role) * 16 + dbg_step) * 8 + (i)] = __builtin_readcyclecounter(); \
+    if ((i) == 0) g_blk_dbg[((role) * 16 + dbg_step) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define BT(role, i)
+#endif
+
+// (image, tile row, tile column) of a workgroup's tiles t_first, t_first + t_step, ...: the integer divisions are done once,
+// every further tile is three scalar add-and-wrap steps (a division per tile and wave measured ~250 cycles of dependent SALU).
+struct TileWalk {
+  int n, ty, tx;        // current tile
+  int dn, dty, dtx;     // t_step decomposed the same way
+  int tiles_x, tiles_y;
+  __device__ __forceinline__ void init(const BlockArgs& a, int t, int t_step) {
+    tiles_x = a.tiles_x; tiles_y = a.tiles_y;
+    const int per_img = a.tiles_x * a.tiles_y;
+    n = t / per_img;
+    int tr = t - n * per_img;
+    ty = tr / a.tiles_x;
+    tx = tr - ty * a.tiles_x;
+    dn = t_step / per_img;
+    tr = t_step - dn * per_img;
+    dty = tr / a.tiles_x;
+    dtx = tr - dty * a.tiles_x;
+  }
+  __device__ __forceinline__ void advance() {
+    tx += dtx;
+    if (tx >= tiles_x) { tx -= tiles_x; ty += 1; }
+    ty += dty;
+    if (ty >= tiles_y) { ty -= tiles_y; n += 1; }
+    n += dn;
+  }
+};
 
 // ------------------------------------------------------------------------------------------------ producer (conv1)
 __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw, int t_first, int t_end, int t_step) {
@@ -80,7 +110,7 @@ __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw,
   const int h = lane >> 5, pix = lane & 31;
   const float* sbias = reinterpret_cast<const float*>(smem + BK::OFF_BIAS);
 
-  // ---- stationary conv1 filter slab: 22 fragments in VGPRs, 14 in LDS (shared by the two producers of this cout tile)
+  // ---- stationary conv1 filter slab: 25 fragments in VGPRs, 11 in LDS (shared by the two producers of this cout tile)
   half8 wreg[BK::NKRP];
   const half8* wsrc = a.w1 + (size_t)ct * BK::NK * 64 + lane;
 #pragma unroll
@@ -105,53 +135,20 @@ __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw,
     mrc[pt] = (row << 8) | col;
   }
 
-  // ---- input halo DMA: 12 rows x 20 pixels, pixel pitch 144 B in LDS (8 chunks of 16 B + one 16-byte gap), so that the
-  // MFMA B-fragment reads are conflict-free WITHOUT a swizzle and every tap / k-step is an immediate offset from one address
-  // register per pixel tile.  A DMA instruction writes lane-linear (LDS byte 16 L of its 1 KB window), so the gaps are made on
-  // the SOURCE side: lane L carries chunk L % 9 of pixel L / 9 (chunk 8 = the gap: masked off together with lane 63, whose
-  // 16 bytes would land in the next window).  A 2880-byte row is three windows of 7 + 7 + 6 pixels; rows pw, pw + 4, pw + 8
-  // belong to producer wave pw; out-of-image pixels come from the zero line.
-  const long rowpitch = (long)a.W * 128;
-  auto issue_dma = [&](int t, int buf) {
-    int ol = lane;
-    asm volatile("" : "+v"(ol));          // recompute the per-lane constants per tile instead of pinning registers
-    const int lpx = (ol * 57) >> 9;       // ol / 9 for ol < 64
-    const int ck = ol - 9 * lpx;
-    int n, ty0, tx0;
-    tile_coords(a, t, n, ty0, tx0);
-    const int gy0 = ty0 * BK::TH - 2, gx0 = tx0 * BK::TW - 2;
-    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * rowpitch + (long)gx0 * 128 + ck * 16;
-    const char* zsrc = reinterpret_cast<const char*>(a.zeros) + (ck & 7) * 16;
-    char* lbase = smem + BK::OFF_IN + buf * BK::IN_BYTES;
-    if (ck < 8 && ol < 63) {
-#pragma unroll
-      for (int seg = 0; seg < 3; ++seg) {
-        const int col = 7 * seg + lpx;
-        const bool xv = (gx0 + col >= 0) && (gx0 + col < a.W) && (col < BK::IW);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int iy = pw + 4 * i;
-          const int gy = gy0 + iy;
-          const char* src = (xv && gy >= 0 && gy < a.H) ? p00 + iy * rowpitch + col * 128 : zsrc;
-          if (seg < 2 || col < BK::IW) dma16(src, lbase + iy * BK::IN_ROWB + seg * 1008);
-        }
-      }
-    }
-  };
-
   int t = t_first;
-  if (t < t_end) issue_dma(t, 0);
   int buf = 0;
-  for (;; t += t_step, buf ^= 1) {
+  TileWalk cur;
+  cur.init(a, t_first, t_step);
+  int dbg_step = 0; (void)dbg_step;
+  for (;; t += t_step, buf ^= 1, ++dbg_step, cur.advance()) {
     const bool active = t < t_end;
-    // tile t's DMA (issued one step ago) is the only VMEM traffic of a producer wave
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    block_barrier();       // in[buf] landed for everybody; the consumers are done with mid[buf] (tile t - 2 t_step)
+    BT(0, 0);
+    block_barrier();       // in[buf] landed (the consumers issue and await the DMA); they are done with mid[buf] (tile t - 2 t_step)
+    BT(0, 2);
     if (!active) break;    // (the consumers run one more step and meet nobody: the workgroup's barrier count stays equal, see k_block)
-    if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
+    BT(0, 3);
 
-    int n, ty0, tx0;
-    tile_coords(a, t, n, ty0, tx0);
+    const int ty0 = cur.ty, tx0 = cur.tx;
     const char* xin = smem + BK::OFF_IN;
     const int pb0 = pbase[0] + buf * BK::IN_BYTES, pb1 = pbase[1] + buf * BK::IN_BYTES, pb2 = pbase[2] + buf * BK::IN_BYTES;
     f32x16 acc[3];
@@ -193,6 +190,7 @@ __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw,
         acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    BT(0, 4);
     // ---- epilogue: ReLU -> fp16 -> mid[buf]; halo pixels OUTSIDE THE IMAGE are conv2's zero padding, not conv1 outputs
     char* mid = smem + BK::OFF_MID + buf * BK::MID_BYTES;
 #pragma unroll
@@ -210,10 +208,14 @@ __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw,
         }
       }
     }
+    BT(0, 5);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ consumer (conv2)
+// The consumers also feed the producers: they carry a third fewer MFMAs (72 vs 108 per step), so the LDS-DMA of the NEXT
+// input halo tile is issued by them at the top of every step (measured on the first version, where the producers issued
+// it: ~2000 cycles of address arithmetic + 9 DMA instructions per wave and step in front of the longer MFMA chain).
 __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw, int t_first, int t_end, int t_step) {
   const int lane = threadIdx.x & 63;
   const int ct = cw & 1, pgc = cw >> 1;
@@ -231,14 +233,72 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
   char* stg = smem + BK::OFF_STG + cw * BK::STG_WAVE;
   const long rowpitch = (long)a.W * 128;
 
+  // ---- input halo DMA: 12 rows x 20 pixels, pixel pitch 144 B in LDS (8 chunks of 16 B + one 16-byte gap), so that the
+  // MFMA B-fragment reads are conflict-free WITHOUT a swizzle and every tap / k-step is an immediate offset from one address
+  // register per pixel tile.  A DMA instruction writes lane-linear (LDS byte 16 L of its 1 KB window), so the gaps are made on
+  // the SOURCE side: lane L carries chunk L % 9 of pixel L / 9 (chunk 8 = the gap: masked off together with lane 63, whose
+  // 16 bytes would land in the next window).  A row is three windows of 7 + 7 + 6 pixels; rows cw, cw + 4, cw + 8 belong to
+  // consumer wave cw.  Out-of-image pixels come from the zero line: a lane whose COLUMN is outside the image points at the
+  // zero line with a row pitch of 0, a ROW outside the image is a wave-uniform case -- one 64-bit multiply-add per DMA.
+  auto issue_dma = [&](const TileWalk& tw, int buf) {
+    int ol = lane;
+    asm volatile("" : "+v"(ol));          // recompute the per-lane constants per tile instead of pinning registers
+    const int lpx = (ol * 57) >> 9;       // ol / 9 for ol < 64
+    const int ck = ol - 9 * lpx;
+    const int n = tw.n;
+    const int gy0 = tw.ty * BK::TH - 2, gx0 = tw.tx * BK::TW - 2;
+    const char* img = reinterpret_cast<const char*>(a.in) + (long)n * a.H * rowpitch;
+    const char* zsrc = reinterpret_cast<const char*>(a.zeros) + (ck & 7) * 16;
+    char* lbase = smem + BK::OFF_IN + buf * BK::IN_BYTES;
+    if (ck < 8 && ol < 63) {
+#pragma unroll
+      for (int seg = 0; seg < 3; ++seg) {
+        const int col = 7 * seg + lpx;
+        const int gx = gx0 + col;
+        const bool xv = (gx >= 0) && (gx < a.W);
+        const char* cbase_p = xv ? img + (long)gx * 128 + ck * 16 : zsrc;      // row 0 of the image at this lane's column
+        const unsigned rp = xv ? (unsigned)rowpitch : 0u;
+        if (seg < 2 || col < BK::IW) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int iy = cw + 4 * i;
+            const int gy = gy0 + iy;                                           // wave-uniform
+            const char* src = (gy >= 0 && gy < a.H) ? cbase_p + (unsigned long)rp * (unsigned)gy : zsrc;
+            dma16(src, lbase + iy * BK::IN_ROWB + seg * 1008);
+          }
+        }
+      }
+    }
+  };
+
   int t = t_first;        // the tile the PRODUCERS work on in this step; this wave consumes the previous one
   int buf = 0;
   int tp = -1;
-  for (;; t += t_step, buf ^= 1) {
-    block_barrier();       // mid[buf ^ 1] (tile tp) is complete
+  bool stored = false;     // the previous step ended with this wave's 4 copy-out stores
+  TileWalk prv, cur, nxt;  // tiles tp (consumed here), t (the producers'), t + t_step (whose input is fetched now)
+  cur.init(a, t_first, t_step);
+  prv = cur;
+  nxt = cur;
+  nxt.advance();
+  if (t < t_end) issue_dma(cur, 0);
+  int dbg_step = 0; (void)dbg_step;
+  for (;; t += t_step, buf ^= 1, ++dbg_step, prv = cur, cur = nxt, nxt.advance()) {
+    BT(1, 0);
+    // The DMA of tile t (issued one step ago) must have landed.  VMEM retires in order and the only operations issued after
+    // it are this wave's residual loads (consumed already) and the 4 copy-out stores of the previous tile (every lane issues
+    // exactly 4, masked lanes into the trash line): allow those 4 to stay in flight.
+    if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stored = false;
+    BT(1, 1);
+    block_barrier();       // in[buf] landed for everybody; mid[buf ^ 1] (tile tp) is complete; the producers are done with in[buf ^ 1]
+    BT(1, 2);
+#ifndef BK_NO_DMA
+    if (t + t_step < t_end) issue_dma(nxt, buf ^ 1);
+#endif
+    BT(1, 3);
     if (tp >= 0) {
-      int n, ty0, tx0;
-      tile_coords(a, tp, n, ty0, tx0);
+      const int n = prv.n, ty0 = prv.ty, tx0 = prv.tx;
       const char* mid = smem + BK::OFF_MID + (buf ^ 1) * BK::MID_BYTES;
       f32x16 acc[2];
       {
@@ -274,6 +334,12 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
           for (int pt = 0; pt < 2; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
         }
         if (k == RES_K) {
+#ifdef BK_NO_RES
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) resv[pt][g] = half4{0, 0, 0, 0};
+#else
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt) {
             const int oy = ty0 * BK::TH + pgc * 4 + pt * 2 + (pix >> 4);
@@ -283,6 +349,7 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
 #pragma unroll
             for (int g = 0; g < 4; ++g) resv[pt][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
           }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -290,11 +357,15 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
           acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[k], xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- epilogue: + identity -> ReLU -> fp16 -> wave-private staging (64 pixels x 64 B, chunk XOR (p >> 2) & 3) ->
-      // 16-byte stores: four lanes write the 64-byte half line of one pixel (the other cout tile's wave writes the other half)
+      BT(1, 4);
+      // ---- epilogue, one MFMA tile (32 pixels = 2 output rows x 16) at a time: + identity -> ReLU -> fp16 -> wave-private
+      // staging (32 pixels x 64 B, chunk XOR (p >> 2) & 3) -> 16-byte stores; four lanes write the 64-byte half line of one
+      // pixel (the other cout tile's wave writes the other half).  LDS operations of one wave execute in order: the second
+      // tile may overwrite the staging area right after the first tile's reads were issued.
+      char* obase = reinterpret_cast<char*>(a.out) + ((long)n * a.H + ty0 * BK::TH + pgc * 4) * rowpitch + (long)tx0 * BK::TW * 128 + ct * 64;
+      char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (threadIdx.x & 127) * 16;
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
-        const int p = pt * 32 + pix;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float x0 = acc[pt][4 * g + 0] + (float)resv[pt][g][0], x1 = acc[pt][4 * g + 1] + (float)resv[pt][g][1];
@@ -302,21 +373,24 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
           uint2 v;
           v.x = lfd_cvt_pk_max(x0, x1, LFD_PK_RELU);
           v.y = lfd_cvt_pk_max(x2, x3, LFD_PK_RELU);
-          *reinterpret_cast<uint2*>(stg + p * 64 + ((g ^ ((p >> 2) & 3)) << 4) + 8 * h) = v;
+          *reinterpret_cast<uint2*>(stg + pix * 64 + ((g ^ ((pix >> 2) & 3)) << 4) + 8 * h) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int idx = j * 64 + lane;
+          const int p = idx >> 2, c = idx & 3;                              // p = pixel of this MFMA tile
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + p * 64 + ((c ^ ((p >> 2) & 3)) << 4));
+          const int orow = pt * 2 + (p >> 4), ocol = p & 15;
+          const bool ok = (ty0 * BK::TH + pgc * 4 + orow < a.H) && (tx0 * BK::TW + ocol < a.W);
+          char* dst = ok ? obase + orow * rowpitch + ocol * 128 + c * 16 : trash;
+#ifdef BK_NO_STORE
+          if (a.N < 0)
+#endif
+          *reinterpret_cast<uint4*>(dst) = v;
         }
       }
-      char* obase = reinterpret_cast<char*>(a.out) + ((long)n * a.H + ty0 * BK::TH + pgc * 4) * rowpitch + (long)tx0 * BK::TW * 128 + ct * 64;
-      char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (threadIdx.x & 127) * 16;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = j * 64 + lane;
-        const int p = idx >> 2, c = idx & 3;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + p * 64 + ((c ^ ((p >> 2) & 3)) << 4));
-        const int orow = (p >> 5) * 2 + ((p >> 4) & 1), ocol = p & 15;       // p = pt * 32 + pix
-        const bool ok = (ty0 * BK::TH + pgc * 4 + orow < a.H) && (tx0 * BK::TW + ocol < a.W);
-        char* dst = ok ? obase + orow * rowpitch + ocol * 128 + c * 16 : trash;
-        *reinterpret_cast<uint4*>(dst) = v;
-      }
+      stored = true;
+      BT(1, 5);
     }
     if (t >= t_end) break;   // the producers had no tile in this step: tp was the last one
     tp = t;
@@ -339,11 +413,20 @@ __global__ __launch_bounds__(512) void k_block64(BlockArgs a) {
   const int t_step = (nblk + 7 - xcd) / 8;
   // Both roles execute exactly (tiles of this workgroup + 1) barriers: the producers one per tile plus the one they leave
   // on, the consumers one per step of the producers plus the step in which they drain the last tile.
+#ifdef BK_SETPRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // the second-dispatched half loses every arbitration otherwise
+#endif
   if (wave < 4) producer(a, smem, wave, t_begin + bix, t_end, t_step);
   else consumer(a, smem, wave - 4, t_begin + bix, t_end, t_step);
 }
 
 }  // namespace
+
+#ifdef LFD_BLOCK_TIMING
+extern "C" __attribute__((visibility("default"))) int lfd_debug_block_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_blk_dbg), sizeof(unsigned long long) * 2 * 16 * 8);
+}
+#endif
 
 extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
                                          const float* b1, const void* w2_packed, const float* b2, const void* zeros,

@@ -560,6 +560,22 @@ def _param_signature(*mods):
     return tuple(sig)
 
 
+def version_sum(model):
+    """Cheap change detector for the replay fast path: (number of tensors, sum of their in-place version counters) over the
+    parameters and buffers of an LFD.  Versions only increase, so the sum changes iff a tensor was written in place."""
+    ts = model.__dict__.get('_lfd_tensors')
+    if ts is None:
+        ts = []
+        for m in (model._backbone, model._neck, model._head):
+            if m is not None:
+                ts += list(m.parameters()) + list(m.buffers())
+        model.__dict__['_lfd_tensors'] = ts
+    v = 0
+    for t in ts:
+        v += t._version
+    return (len(ts), v)
+
+
 # ---------------------------------------------------------------------------- entry points
 def get_plan(owner, backbone, neck, head, device):
     """Plan cache on `owner` keyed by device; rebuilt when any parameter/buffer changed

@@ -92,6 +92,13 @@ class LFD(nn.Module):
         self.max_candidates = 8192   # per-image capacity of the fused post-processing pass
         self.use_graph = False       # capture the forward into a HIP graph per input shape
 
+    def _apply(self, fn, recurse=True):
+        # .to() / .cuda() / .half(): parameter storage is replaced -> forget the cached tensor list and captured graphs
+        self.__dict__.pop('_lfd_tensors', None)
+        self.__dict__['_step_graphs_ver'] = None
+        self.__dict__.get('_step_graphs', {}).clear()
+        return super()._apply(fn, recurse)
+
     @property
     def head_indexes_to_feature_map_sizes(self):
         return self._head_indexes_to_feature_map_sizes
@@ -132,10 +139,16 @@ class LFD(nn.Module):
         # the captured graph reads the packed weights of ONE EnginePlan: a parameter change (optimizer step,
         # load_state_dict, .to()) makes get_plan build a new plan, and every graph captured against the old one is
         # dropped here (replaying it would silently use the old weights -- or freed memory)
-        plan = engine.get_plan(self, self._backbone, self._neck, self._head, x.device)
-        if self.__dict__.get('_step_graphs_plan') is not plan:
-            cache.clear()
-            self.__dict__['_step_graphs_plan'] = plan
+        # The full check (engine.get_plan: data_ptr + version of every tensor) costs ~0.15 ms of Python -- as much as a
+        # whole bs-1 step; in-place version counters only ever increase, so their SUM changes iff some tensor was written
+        # in place (optimizer step, load_state_dict, .copy_); storage moves (.to / .cuda / .half) go through _apply below.
+        ver = engine.version_sum(self)
+        if self.__dict__.get('_step_graphs_ver') != ver:
+            plan = engine.get_plan(self, self._backbone, self._neck, self._head, x.device)
+            if self.__dict__.get('_step_graphs_plan') is not plan:
+                cache.clear()
+                self.__dict__['_step_graphs_plan'] = plan
+            self.__dict__['_step_graphs_ver'] = ver
         key = (x.data_ptr(), tuple(x.shape), x.dtype, meta.data_ptr(), float(score_thr), float(iou_thr), bool(agn), max_candidates)
         ent = cache.get(key)
         if ent is None:

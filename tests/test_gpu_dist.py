@@ -68,5 +68,5 @@ def test_sharded_inference_tool_config4_one_rank_through_rccl():
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     import json
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith('{')][-1])     # (RCCL prints its own lines)
     assert rec['frames'] == 4 and rec['ranks'] == 1 and rec['detections'] > 0 and rec['backend'] == 'nccl'
