@@ -141,8 +141,8 @@ def _nchw64(t):
 def test_every_backbone_launch_rederived_from_the_stored_tensors(key):
     """For one frame of the batch: each conv launch of the plan, recomputed in float64 from the fp16 tensors the engine
     itself stored as that launch's inputs (folded fp16 weights, fp32 bias, residual, ReLU), must equal the stored output up
-    to ONE fp16 ulp (the final rounding + fp32 accumulation noise); the fused 4-conv stem, which rounds to fp16 three times
-    inside the launch, within a few ulps.  Together with G1 this pins where the end-to-end 1-2e-3 comes from: nowhere but
+    to the final fp16 rounding + fp32 accumulation noise (tolerance spelled out in `compare`); >= 99.9 % of the outputs of
+    a single-conv launch are bit-identical to the rounded float64 value.  Together with G1 this pins where the end-to-end 1-2e-3 comes from: nowhere but
     the rounding of operands."""
     cs = _case(key)
     m, img = cs['model'], cs['imgs'][0]
@@ -154,59 +154,77 @@ def test_every_backbone_launch_rederived_from_the_stored_tensors(key):
     st = plan.state_for(n, h, w)
     rows = []
 
-    def compare(tag, got16, ref64, max_ulp, floor=2.0 ** -10, min_exact=0.98):
-        """single-rounding launches: <= 1 ulp at the value's own magnitude.  Launches that round to fp16 INSIDE (fused stem:
-        3 times, fused block: once) carry 1-ulp flips of their intermediates into the output, i.e. an ABSOLUTE error of the
-        size of an ulp of the typical activation (~0.5), which is many ulps of an output that happens to be near zero:
-        those are judged with the ulp floored at the spacing of 0.5 (2^-11)."""
+    def compare(tag, got16, ref64, mag64, flips=0.0, min_exact=0.98):
+        """accept |got - ref| <= half an fp16 ulp of the reference (the final rounding)
+                               + 2^-19 x sum |x||w|   (fp32 accumulation noise of the MFMA contraction: ~sqrt(K) 2^-24 relative to
+                                                       the magnitude of the terms, K <= 1152)
+                               + `flips`              (launches that round to fp16 INSIDE -- fused stem 3 x, fused block / tail once --
+                                                       carry 1-ulp flips of ~0.5 % of their intermediate values into the output).
+        Reported: the worst ratio to that tolerance and the fraction of bit-identical outputs."""
         got = _nchw64(got16)
-        ulp = _ulp16(ref64, floor)
-        d = ((got - ref64).abs() / ulp)
+        tol = 0.5005 * _ulp16(ref64, 2.0 ** -14) + 2.0 ** -19 * mag64 + flips
+        d = ((got - ref64).abs() / tol)
         exact = float((got == ref64.float().half().double()).double().mean())
-        rows.append((tag, float(d.max()), exact))
-        assert float(d.max()) <= max_ulp, (tag, float(d.max()))
-        assert exact > min_exact, (tag, exact)
+        rows.append((tag, float(d.max()), exact, 1.0, min_exact))
+        _record('per-launch %s' % key, rows=[list(r) for r in rows])
+
+    def conv_mag(x, wt, b, **kw):
+        return F.conv2d(x.abs(), wt.abs(), b.abs(), **kw)
 
     # ---- stem (one fused launch for the 'faster' stem, or the first pair for 'fast')
     x64 = cs['x'][img:img + 1].float().permute(0, 3, 1, 2).double()
     y = x64
     first_dst = plan.stem_fused[-1] if plan.stem_fused is not None else plan.stem_out
     nstem = 4 if plan.stem_fused is not None else 2
-    for (k, s, wt, b) in plan.stem_ref[:nstem]:
-        y = F.conv2d(y, wt.cpu().half().double(), b.cpu().double(), stride=s, padding=k // 2).relu()
-        y = y.float().half().double()
-    compare('stem', st.bufs[first_dst][img:img + 1].cpu(), y, 4.0, floor=0.5, min_exact=0.9)
+    flips, mag = 0.0, None
+    for li, (k, s, wt, b) in enumerate(plan.stem_ref[:nstem]):
+        w64, b64 = wt.cpu().half().double(), b.cpu().double()
+        if li:      # an ulp of the incoming intermediate, through this layer's largest weights, a handful of times
+            flips = flips * float(w64.abs().sum((1, 2, 3)).max()) + 4 * 2.0 ** -11 * float(y.abs().max()) * float(w64.abs().max())
+        mag = conv_mag(y, w64, b64, stride=s, padding=k // 2)
+        y = F.conv2d(y, w64, b64, stride=s, padding=k // 2).relu()
+        if li + 1 < nstem:
+            y = y.float().half().double()
+    compare('stem', st.bufs[first_dst][img:img + 1].cpu(), y, mag, flips=flips, min_exact=0.9)
     # ---- every conv launch
     for c in plan.convs:
         xin = _nchw64(st.bufs[c.src][img:img + 1].cpu())
-        ref = F.conv2d(xin, c.ref_w.cpu().half().double(), c.b.cpu().double(), stride=c.stride, padding=c.ks // 2)
-        if c.tail is not None:
-            ref = ref.relu().float().half().double()
-            ref = F.conv2d(ref, c.tail[3].cpu().half().double(), c.tail[1].cpu().double())
-        if c.blk is not None:      # fused FasterBlock: conv -> ReLU -> fp16 -> conv2 (+ block input) -> ReLU
-            ref = ref.relu().float().half().double()
-            ref = F.conv2d(ref, c.blk[2].cpu().half().double(), c.blk[1].cpu().double(), padding=1)
+        w64, b64 = c.ref_w.cpu().half().double(), c.b.cpu().double()
+        ref = F.conv2d(xin, w64, b64, stride=c.stride, padding=c.ks // 2)
+        mag = conv_mag(xin, w64, b64, stride=c.stride, padding=c.ks // 2)
+        flips = 0.0
+        second = c.tail[3:0:-2] if c.tail is not None else (c.blk[2:0:-1] if c.blk is not None else None)   # (w2 folded, b2)
+        if second is not None:       # chained 1x1 tail / fused FasterBlock: conv -> ReLU -> fp16 -> second conv
+            mid = ref.relu().float().half().double()
+            w2, b2 = second[0].cpu().half().double(), second[1].cpu().double()
+            pad2 = w2.shape[-1] // 2
+            ref = F.conv2d(mid, w2, b2, padding=pad2)
+            mag = conv_mag(mid, w2, b2, padding=pad2)
+            flips = 4 * 2.0 ** -11 * float(mid.abs().max()) * float(w2.abs().max())
         if c.res is not None:
-            ref = ref + _nchw64(st.bufs[c.res][img:img + 1].cpu())
+            r64 = _nchw64(st.bufs[c.res][img:img + 1].cpu())
+            ref = ref + r64
+            mag = mag + r64.abs()
         if c.relu:
             ref = ref.relu()
         compare('%s%dx%d s%d %d->%d @%dx%d' % ('block 2 x conv' if c.blk is not None else 'conv', c.ks, c.ks, c.stride, c.cin,
                                               c.cout, ref.shape[2], ref.shape[3]),
-                st.bufs[c.dst][img:img + 1].cpu(), ref, 2.0 if (c.blk is not None or c.tail is not None) else 1.0,
-                floor=0.5 if (c.blk is not None or c.tail is not None) else 2.0 ** -10,
-                min_exact=0.9 if (c.blk is not None or c.tail is not None) else 0.98)
+                st.bufs[c.dst][img:img + 1].cpu(), ref, mag, flips=flips, min_exact=0.9 if second is not None else 0.98)
         if c.ds is not None:
-            rd = F.conv2d(xin, c.ds[3].cpu().half().double(), c.ds[1].cpu().double(), stride=2)
-            compare('downsample 1x1 s2 %d->%d' % (c.cin, c.cout), st.bufs[c.ds[2]][img:img + 1].cpu(), rd, 1.0)
+            wd, bd = c.ds[3].cpu().half().double(), c.ds[1].cpu().double()
+            compare('downsample 1x1 s2 %d->%d' % (c.cin, c.cout), st.bufs[c.ds[2]][img:img + 1].cpu(),
+                    F.conv2d(xin, wd, bd, stride=2), conv_mag(xin, wd, bd, stride=2))
     # ---- neck + head from the stored taps (emulated rounding points; three fp16 roundings deep)
     taps = [st.bufs[t][img:img + 1].cpu().float().permute(0, 3, 1, 2).contiguous() for t in plan.taps]
     with torch.no_grad():
         hc, hr, _ = net_oracle.head_forward_fp16(cs['sd'], cs['arch'], taps)
     dc = float((cs['cls'][img] - hc[0]).abs().max())
     dr = float((cs['reg'][img] - hr[0]).abs().max())
-    _record('per-launch %s' % key, worst_ulp=max(r[1] for r in rows[1:]), stem_ulp=rows[0][1], rows=[list(r) for r in rows],
+    bad = [r for r in rows if r[1] > r[3] or r[2] <= r[4]]
+    assert not bad, bad
+    _record('per-launch %s' % key, worst_ulp=max(r[1] for r in rows[1:]), stem_ulp=rows[0][1],
             min_exact_fraction=min(r[2] for r in rows), head_raw_cls=dc, head_raw_reg=dr, launches=len(rows))
-    print('%s: %d launches, worst %.2f ulp, stem %.2f ulp, >= %.4f bit-identical; head from stored taps: cls %.2e reg %.2e'
+    print('%s: %d launches, worst %.2f x tolerance, stem %.2f, >= %.4f bit-identical; head from stored taps: cls %.2e reg %.2e'
           % (key, len(rows), max(r[1] for r in rows[1:]), rows[0][1], min(r[2] for r in rows), dc, dr))
     assert dc < 4e-3 and dr < 4e-3
     # ---- error growth against the fp32 oracle, per tapped map (relative L2)
