@@ -49,6 +49,18 @@ LFD_API const char* lfd_hip_status_string(int status);
 /* "gfx950;<compiler>;<build date>" */
 LFD_API const char* lfd_hip_build_info(void);
 
+/* HOST-side members of the nms_ext surface, for CPU tensors / numpy arrays (host pointers, no stream): the reference's
+ * module dispatches `nms` on the tensor's device (nms_ext.cpp:18-27 -> cpu/nms_cpu.cpp:7-66) and has `soft_nms`
+ * (nms_cpu.cpp:76-206) and `nms_match` (:220-283) for CPU tensors only.  Not a fallback of the device path.
+ *   lfd_nms_cpu_f32:       keep[<= n] original indices, score-descending (ties: input order); suppress when IoU > thr
+ *   lfd_soft_nms_cpu_f32:  method 1 linear / 2 gaussian / else hard; out[<= n][6] = x1,y1,x2,y2,score,index(as float)
+ *   lfd_nms_match_cpu_f32: members[n] grouped (kept box first, then the boxes it matched with IoU >= thr), group_sizes[<= n] */
+LFD_API int lfd_nms_cpu_f32(const float* dets, int64_t n, float iou_thr, int64_t* keep, int64_t* num_keep);
+LFD_API int lfd_soft_nms_cpu_f32(const float* dets, int64_t n, float iou_thr, int32_t method, float sigma, float min_score,
+                                 float* out, int64_t* num_out);
+LFD_API int lfd_nms_match_cpu_f32(const float* dets, int64_t n, float iou_thr, int32_t* members, int32_t* group_sizes,
+                                  int64_t* num_groups);
+
 /* ------------------------------------------------------------------------------------------
  * NMS.  Replaces nms_ext.nms(dets[n,5] f32, thr) -> LongTensor[k]
  *   (lfd/model/utils/build/nms/src/nms_ext.cpp:18-27,45-49; CUDA path

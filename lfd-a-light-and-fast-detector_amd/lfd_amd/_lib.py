@@ -82,6 +82,9 @@ _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
     'lfd_hip_status_string': (C.c_char_p, [C.c_int]),
     'lfd_hip_build_info': (C.c_char_p, []),
+    'lfd_nms_cpu_f32': (C.c_int, [_P, _I64, _F, _P, _P]),
+    'lfd_soft_nms_cpu_f32': (C.c_int, [_P, _I64, _F, _I32, _F, _F, _P, _P]),
+    'lfd_nms_match_cpu_f32': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
     'lfd_nms_workspace_bytes': (_SZ, [_I64]),
     'lfd_nms_f32': (C.c_int, [_P, _I64, _F, _P, _P, _P, _SZ, _P]),
     'lfd_batched_nms_workspace_bytes': (_SZ, [_I64]),

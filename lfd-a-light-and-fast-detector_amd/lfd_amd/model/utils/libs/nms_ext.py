@@ -1,29 +1,109 @@
 """Drop-in for the reference's pybind module `lfd.model.utils.libs.nms_ext`
-(lfd/model/utils/build/nms/src/nms_ext.cpp:45-49): same three functions, same argument
-meaning and error behaviour (RuntimeError), implemented over liblfd_hip.so's C ABI.
+(lfd/model/utils/build/nms/src/nms_ext.cpp:45-49): same three functions, same argument meaning and error behaviour
+(RuntimeError), implemented over liblfd_hip.so's C ABI with ctypes ONLY -- this file imports nothing from lfd_amd, so it
+can be copied to lfd/model/utils/libs/nms_ext.py of the reference tree as it is.  The library
+is looked up in $LFD_HIP_LIB, next to this file, then in the lfd_amd package directory.
 
-  nms(dets[n,5] f32 {x1,y1,x2,y2,score}, thr) -> LongTensor[k]   kept indices, score-descending
-  soft_nms / nms_match: CPU-only in the reference (nms_ext.cpp:29-43 raise on GPU tensors) and
-  not on any shipped config's path; kept as "not implemented on GPU" errors here.
+  nms(dets[n,5] f32 {x1,y1,x2,y2,score}, thr) -> LongTensor[k]   kept indices, score-descending, on dets' device
+        GPU tensor: lfd_nms_f32 (csrc/postproc.hip: device sort + 64x64 IoU bitmask + device greedy scan)
+        CPU tensor: lfd_nms_cpu_f32 (csrc/nms_host.hip), like nms_ext.cpp:18-27 dispatches to cpu/nms_cpu.cpp:7-66
+  soft_nms(dets, thr, method, sigma, min_score) -> Tensor[k,6]   CPU tensors only (nms_ext.cpp:29-36)
+  nms_match(dets, thr) -> list[list[int]]                        CPU tensors only (nms_ext.cpp:38-43)
 """
+import ctypes as C
+import os
+
 import torch
 
-from ....ops import nms_indices
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        cands = [os.environ.get('LFD_HIP_LIB'), os.path.join(here, 'liblfd_hip.so'),
+                 os.path.join(here, '..', '..', '..', 'liblfd_hip.so')]
+        path = next((p for p in cands if p and os.path.exists(p)), None)
+        if path is None:
+            raise RuntimeError('nms_ext: liblfd_hip.so not found (set LFD_HIP_LIB or build it with `python __graft_entry__.py`)')
+        l = C.CDLL(path)
+        l.lfd_nms_workspace_bytes.restype = C.c_size_t
+        l.lfd_nms_workspace_bytes.argtypes = [C.c_int64]
+        l.lfd_nms_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.lfd_nms_cpu_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
+        l.lfd_soft_nms_cpu_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        l.lfd_nms_match_cpu_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (status %d)' % (what, rc))
+
+
+def _host_dets(dets, what):
+    if dets.dim() != 2 or dets.size(1) != 5:
+        raise RuntimeError('%s: dets must be [n,5]' % what)
+    return dets.detach().contiguous().float()
 
 
 def nms(dets, threshold):
     if not isinstance(dets, torch.Tensor):
         raise TypeError('dets must be a Tensor')
-    if not dets.is_cuda:
-        raise RuntimeError('nms: this build provides the MI355X (HIP) implementation only; got a CPU tensor')
     if dets.numel() == 0:
-        return torch.empty(0, dtype=torch.long)   # nms_cuda.cpp:10-11 returns an empty CPU long
-    return nms_indices(dets, threshold)
+        return torch.empty(0, dtype=torch.long)          # nms_cuda.cpp:10-11 / nms_cpu.cpp:11-13: empty CPU long
+    if dets.dim() != 2 or dets.size(1) != 5:
+        raise RuntimeError('nms: dets must be [n,5]')
+    l = _load()
+    n = dets.size(0)
+    if not dets.is_cuda:
+        d = _host_dets(dets, 'nms')
+        keep = torch.empty(n, dtype=torch.long)
+        num = C.c_int64(0)
+        _check(l.lfd_nms_cpu_f32(d.data_ptr(), n, float(threshold), keep.data_ptr(), C.byref(num)), 'lfd_nms_cpu_f32')
+        return keep[:num.value]
+    d = dets.detach().contiguous().float()
+    with torch.cuda.device(d.device):
+        keep = torch.empty(n, dtype=torch.long, device=d.device)
+        num = torch.zeros(1, dtype=torch.int32, device=d.device)
+        ws = torch.empty(max(int(l.lfd_nms_workspace_bytes(n)), 1), dtype=torch.uint8, device=d.device)
+        _check(l.lfd_nms_f32(d.data_ptr(), n, float(threshold), keep.data_ptr(), num.data_ptr(), ws.data_ptr(), ws.numel(),
+                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'lfd_nms_f32')
+        k = int(num.item())       # data-dependent output length: the reference's GPU path synchronises too (nms_kernel.cu:105-111)
+    return keep[:k]
 
 
 def soft_nms(dets, threshold, method, sigma, min_score):
-    raise RuntimeError('soft_nms is not implemented on GPU')   # nms_ext.cpp:33
+    if dets.is_cuda:
+        raise RuntimeError('soft_nms is not implemented on GPU')       # nms_ext.cpp:33
+    if dets.numel() == 0:
+        return torch.empty(0, dtype=torch.long)                        # nms_cpu.cpp:83-85
+    d = _host_dets(dets, 'soft_nms')
+    n = d.size(0)
+    out = torch.empty((n, 6), dtype=torch.float32)
+    num = C.c_int64(0)
+    _check(_load().lfd_soft_nms_cpu_f32(d.data_ptr(), n, float(threshold), int(method), float(sigma), float(min_score),
+                                        out.data_ptr(), C.byref(num)), 'lfd_soft_nms_cpu_f32')
+    return out[:num.value].to(dets.dtype)
 
 
 def nms_match(dets, threshold):
-    raise RuntimeError('nms_match is not implemented on GPU')  # nms_ext.cpp:40
+    if dets.is_cuda:
+        raise RuntimeError('nms_match is not implemented on GPU')      # nms_ext.cpp:40
+    if dets.numel() == 0:
+        return []
+    d = _host_dets(dets, 'nms_match')
+    n = d.size(0)
+    members = torch.empty(n, dtype=torch.int32)
+    sizes = torch.empty(n, dtype=torch.int32)
+    num = C.c_int64(0)
+    _check(_load().lfd_nms_match_cpu_f32(d.data_ptr(), n, float(threshold), members.data_ptr(), sizes.data_ptr(), C.byref(num)),
+           'lfd_nms_match_cpu_f32')
+    out, o = [], 0
+    mem = members.tolist()
+    for s in sizes[:num.value].tolist():
+        out.append(mem[o:o + s])
+        o += s
+    return out

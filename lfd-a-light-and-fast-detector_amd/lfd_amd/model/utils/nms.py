@@ -1,7 +1,8 @@
 """NMS API -- mirror of lfd/model/utils/nms.py (nms :7-59, batched_nms :119-158,
-multiclass_nms :161-220) over the HIP kernels.  Tensors must live on the MI355X; the
-arithmetic (sort, IoU bitmask, greedy scan, class-offset trick incl. its fp32 rounding) is
-in csrc/postproc.hip."""
+multiclass_nms :161-220) over liblfd_hip.so.  batched_nms / multiclass_nms are the hot path and
+need tensors on the MI355X (sort, IoU bitmask, greedy scan, class-offset trick incl. its fp32
+rounding: csrc/postproc.hip); plain nms also serves CPU tensors / numpy arrays and soft_nms is
+CPU-only, exactly like the reference's extension (host routines: csrc/nms_host.hip)."""
 import numpy as np
 import torch
 
@@ -12,14 +13,15 @@ __all__ = ['nms', 'soft_nms', 'batched_nms', 'multiclass_nms']
 
 
 def nms(dets, iou_thr, device_id=None):
-    """Returns (dets[inds], inds) like the reference (:58-59).  numpy input requires
-    `device_id` (the reference would run its CPU kernel otherwise; there is none here)."""
+    """Returns (dets[inds], inds) like the reference (:7-59): tensors are processed on the device they live on -- GPU
+    tensors by the HIP kernels, CPU tensors by the host routine of the same library (nms_ext.cpp:18-27 dispatches the same
+    way); numpy arrays on the CPU unless `device_id` is given (:36-47)."""
     if isinstance(dets, torch.Tensor):
         is_numpy, dets_th = False, dets
     elif isinstance(dets, np.ndarray):
-        if device_id is None:
-            raise RuntimeError('nms: numpy input needs device_id (no CPU implementation in lfd_amd)')
-        is_numpy, dets_th = True, torch.from_numpy(dets).to('cuda:{}'.format(device_id))
+        is_numpy = True
+        device = 'cpu' if device_id is None else 'cuda:{}'.format(device_id)
+        dets_th = torch.from_numpy(dets).to(device)
     else:
         raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(type(dets)))
     if dets_th.shape[0] == 0:
@@ -32,10 +34,21 @@ def nms(dets, iou_thr, device_id=None):
 
 
 def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
-    """CPU-only in the reference (:62-116) and unused by the shipped LFD configs."""
-    if method not in ('linear', 'gaussian'):
+    """CPU-only in the reference (:62-116): tensors are moved to the host, results returned in the input's type / device."""
+    if isinstance(dets, torch.Tensor):
+        is_tensor, dets_t = True, dets.detach().cpu()
+    elif isinstance(dets, np.ndarray):
+        is_tensor, dets_t = False, torch.from_numpy(dets)
+    else:
+        raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(type(dets)))
+    method_codes = {'linear': 1, 'gaussian': 2}
+    if method not in method_codes:
         raise ValueError('Invalid method for SoftNMS: {}'.format(method))
-    return nms_ext.soft_nms(dets, iou_thr, {'linear': 1, 'gaussian': 2}[method], sigma, min_score)
+    results = nms_ext.soft_nms(dets_t, iou_thr, method_codes[method], sigma, min_score)
+    new_dets, inds = results[:, :5], results[:, 5]
+    if is_tensor:
+        return new_dets.to(device=dets.device, dtype=dets.dtype), inds.to(device=dets.device, dtype=torch.long)
+    return new_dets.numpy().astype(dets.dtype), inds.numpy().astype(np.int64)
 
 
 def batched_nms(bboxes, scores, inds, nms_cfg, class_agnostic=False):

@@ -3,7 +3,7 @@
 
     python tests/golden/make_golden.py
 
-Outputs (committed): known_answers.json, ref_nms.npz, ref_multiclass_nms.npz,
+Outputs (committed): known_answers.json, ref_nms.npz, ref_nms_cpu_extra.npz, ref_multiclass_nms.npz,
 ref_model_<ARCH>.npz.  The GPU box has no /root/reference: tests only read these files.
 Model weights are NOT stored: they are regenerated from torch.manual_seed(666) + the
 deterministic perturbation (lfd_amd.configs.perturb_weights); the sha256 of the reference
@@ -108,6 +108,23 @@ def main():
     cases.append((5, 0.5))
     out['cases'] = np.array(cases, np.float64)
     np.savez_compressed(os.path.join(HERE, 'ref_nms.npz'), **out)
+
+    # ---------------------------------------------------------------- 2b. reference CPU soft_nms / nms_match (nms_cpu.cpp:76-283)
+    out = {}
+    ci = 0
+    rng_x = np.random.default_rng(4321)     # own stream: this fixture can be regenerated alone
+    for k, thr, method, sigma, min_score in [(6, 0.6, 1, 0.5, 1e-3), (50, 0.3, 1, 0.5, 0.05), (50, 0.3, 2, 0.5, 0.05), (300, 0.4, 2, 0.3, 0.1),
+                                             (300, 0.5, 0, 0.5, 0.2), (1, 0.5, 1, 0.5, 1e-3)]:
+        b, s = synth_boxes(rng_x, k, 640, 480)
+        dets = np.concatenate([b, s[:, None]], 1).astype(np.float32)
+        soft = ext.soft_nms(torch.from_numpy(dets), float(thr), int(method), float(sigma), float(min_score)).numpy()
+        match = ext.nms_match(torch.from_numpy(dets), float(thr))
+        out['dets_%d' % ci], out['params_%d' % ci], out['soft_%d' % ci] = dets, np.array([thr, method, sigma, min_score], np.float64), soft
+        out['match_sizes_%d' % ci] = np.array([len(m) for m in match], np.int64)
+        out['match_members_%d' % ci] = np.array([i for m in match for i in m], np.int64)
+        ci += 1
+    out['num_cases'] = np.array(ci)
+    np.savez_compressed(os.path.join(HERE, 'ref_nms_cpu_extra.npz'), **out)
 
     # ---------------------------------------------------------------- 3. reference python multiclass_nms
     out = {}

@@ -2,6 +2,7 @@
 weight folding / packing, plan construction (all on CPU tensors -- no kernel launches)."""
 import numpy as np
 import pytest
+import os
 import torch
 import torch.nn as nn
 
@@ -145,9 +146,9 @@ def test_no_cpu_fallback():
     m = configs.build_model('WIDERFACE_LFD_XS').eval()
     with pytest.raises(RuntimeError, match='MI355X only'):
         m(torch.zeros(1, 3, 64, 64))
-    from lfd_amd.model.utils import nms
-    with pytest.raises(RuntimeError):
-        nms(torch.zeros(3, 5), 0.5)
+    from lfd_amd.model.utils import batched_nms
+    with pytest.raises(RuntimeError):          # the hot-path NMS (class offsets on the device) has no CPU implementation
+        batched_nms(torch.zeros(3, 4), torch.zeros(3), torch.zeros(3, dtype=torch.long), dict(type='nms', iou_thr=0.5))
     from lfd_amd.model.losses.libs import sigmoid_focal_loss_ext as ext
     with pytest.raises(RuntimeError, match='not implemented on the CPU'):   # reference: sigmoid_focal_loss_ext.cpp:32
         ext.forward(torch.zeros(2, 1), torch.zeros(2, dtype=torch.long), 1, 2.0, 0.25)
@@ -396,3 +397,76 @@ def test_flat_sgd_rebinds_parameters_replaced_behind_its_back():
     for p, off, v in zip(fg.params, fg.offsets, vals):
         assert p.data_ptr() == fg.p.data_ptr() + 4 * off and torch.equal(p.detach(), v)
     assert not fg.adopt_params()
+
+
+def test_extension_modules_are_self_contained_and_serve_cpu_tensors_like_the_reference(tmp_path, known_answers):
+    """lfd_amd/model/utils/libs/nms_ext.py and model/losses/libs/sigmoid_focal_loss_ext.py are copied
+    into a fresh package tree under the REFERENCE's module names (lfd.model.utils.libs.nms_ext, nms.py:4;
+    lfd.model.losses.libs.sigmoid_focal_loss_ext, focal_loss.py:6) and imported in a subprocess that has no lfd_amd on its
+    path.  CPU tensors: nms == the reference's compiled nms_cpu (golden ref_nms.npz), soft_nms / nms_match == vectors
+    generated with the reference extension (golden ref_nms_cpu_extra.npz); the focal loss refuses CPU tensors like the
+    reference (sigmoid_focal_loss_ext.cpp:32,49)."""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import GOLDEN, PKG
+    from lfd_amd import _lib
+    for sub in ('lfd', 'lfd/model', 'lfd/model/utils', 'lfd/model/utils/libs', 'lfd/model/losses', 'lfd/model/losses/libs'):
+        os.makedirs(str(tmp_path / sub))
+        (tmp_path / sub / '__init__.py').write_text('')
+    shutil.copy(os.path.join(PKG, 'lfd_amd', 'model', 'utils', 'libs', 'nms_ext.py'), str(tmp_path / 'lfd/model/utils/libs/nms_ext.py'))
+    shutil.copy(os.path.join(PKG, 'lfd_amd', 'model', 'losses', 'libs', 'sigmoid_focal_loss_ext.py'),
+                str(tmp_path / 'lfd/model/losses/libs/sigmoid_focal_loss_ext.py'))
+    script = tmp_path / 'run.py'
+    script.write_text('''
+import sys, json, numpy as np, torch
+sys.path = [p for p in sys.path if 'lfd-a-light-and-fast-detector_amd' not in p]
+sys.path.insert(0, sys.argv[1])
+from lfd.model.utils.libs import nms_ext
+from lfd.model.losses.libs import sigmoid_focal_loss_ext as fl
+assert 'lfd_amd' not in sys.modules
+g = np.load(sys.argv[2] + '/ref_nms.npz')
+for ci in range(len(g['cases'])):
+    keep = nms_ext.nms(torch.from_numpy(g['dets_%d' % ci]), float(g['cases'][ci][1]))
+    assert keep.dtype == torch.long and not keep.is_cuda
+    np.testing.assert_array_equal(keep.numpy(), g['keep_%d' % ci])
+e = np.load(sys.argv[2] + '/ref_nms_cpu_extra.npz')
+for ci in range(int(e['num_cases'])):
+    d = torch.from_numpy(e['dets_%d' % ci])
+    thr, method, sigma, min_score = [float(v) for v in e['params_%d' % ci]]
+    out = nms_ext.soft_nms(d, thr, int(method), sigma, min_score)
+    np.testing.assert_array_equal(out.numpy(), e['soft_%d' % ci])
+    groups = nms_ext.nms_match(d, thr)
+    assert [len(x) for x in groups] == e['match_sizes_%d' % ci].tolist()
+    assert [i for x in groups for i in x] == e['match_members_%d' % ci].tolist()
+assert nms_ext.nms(torch.zeros((0, 5)), 0.5).numel() == 0
+for fn, args in ((fl.forward, (torch.zeros(2, 1), torch.zeros(2, dtype=torch.long), 1, 2.0, 0.25)),
+                 (fl.backward, (torch.zeros(2, 1), torch.zeros(2, dtype=torch.long), torch.zeros(2, 1), 1, 2.0, 0.25))):
+    try:
+        fn(*args)
+        raise SystemExit('CPU focal loss did not raise')
+    except RuntimeError as ex:
+        assert 'not implemented on the CPU' in str(ex)
+print('ext ok')
+''')
+    env = dict(os.environ, LFD_HIP_LIB=_lib.LIB_PATH)
+    out = subprocess.run([sys.executable, str(script), str(tmp_path), GOLDEN], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'ext ok' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_python_nms_api_on_cpu_tensors_and_numpy(known_answers):
+    """lfd_amd.model.utils.nms / soft_nms keep the reference's host behaviour (nms.py:7-116): numpy in -> numpy out, CPU
+    tensors stay on the CPU, docstring vectors reproduce."""
+    from lfd_amd.model.utils import nms, soft_nms
+    ka = known_answers['nms_docstring']
+    d = np.array(ka['dets'], np.float32)
+    sup, inds = nms(d, ka['iou_thr'])
+    assert isinstance(inds, np.ndarray) and inds.tolist() == ka['keep'] and sup.shape == (3, 5)
+    sup_t, inds_t = nms(torch.from_numpy(d), ka['iou_thr'])
+    assert inds_t.tolist() == ka['keep'] and not inds_t.is_cuda and torch.equal(sup_t, torch.from_numpy(d)[inds_t])
+    ks = known_answers['soft_nms_docstring']
+    nd, ni = soft_nms(np.array(ks['dets'], np.float32), ks['iou_thr'], sigma=ks['sigma'])
+    assert ni.dtype == np.int64 and ni.tolist() == ks['inds'] and len(nd) == ks['expected_len']
+    np.testing.assert_allclose(nd, np.array(ks['new_dets'], np.float32), rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        soft_nms(np.zeros((1, 5), np.float32), 0.5, method='nope')
