@@ -185,3 +185,26 @@ def test_config4_tt100k_l_multiclass_end_to_end():
         if len(a) == len(b):
             assert [r[0] for r in a] == [r[0] for r in b]
             np.testing.assert_allclose(np.array(a)[:, 1:], np.array(b)[:, 1:], rtol=1e-4, atol=2e-3)
+
+
+def test_checkpoint_from_the_reference_runs_on_the_engine():
+    """a checkpoint file written by the reference's save_checkpoint (tests/golden/ref_checkpoint_tiny.pth,
+    generated by make_golden_checkpoint.py from the reference's own modules) -> lfd_amd.checkpoint.load_checkpoint(strict)
+    -> HIP engine; outputs against the reference's fp32 outputs stored next to it."""
+    import os
+    from conftest import GOLDEN
+    from lfd_amd import checkpoint
+    arch = dict(configs.ARCHS['WIDERFACE_LFD_XS'], body_architecture=[1], body_channels=[64], out_indices=((0, 0),),
+                regression_ranges=((4, 320),))
+    m = configs.build_model(arch, seed=5)
+    checkpoint.load_checkpoint(m, os.path.join(GOLDEN, 'ref_checkpoint_tiny.pth'), strict=True)
+    g = load_golden('ref_checkpoint_tiny.npz')
+    n, h, w = [int(v) for v in g['shape']]
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(int(g['x_seed']))) * 2 - 1
+    m.eval().cuda()
+    with torch.no_grad():
+        cls, reg = m(x.cuda())
+    rc, rr = torch.from_numpy(g['cls']), torch.from_numpy(g['reg'])
+    assert cls.shape == rc.shape and reg.shape == rr.shape
+    assert float((cls.cpu().sigmoid() - rc.sigmoid()).abs().max()) < 2.5e-3
+    assert float((reg.cpu().sigmoid() - rr.sigmoid()).abs().max()) < 2.5e-3

@@ -470,3 +470,33 @@ def test_python_nms_api_on_cpu_tensors_and_numpy(known_answers):
     np.testing.assert_allclose(nd, np.array(ks['new_dets'], np.float32), rtol=0, atol=0)
     with pytest.raises(ValueError):
         soft_nms(np.zeros((1, 5), np.float32), 0.5, method='nope')
+
+
+def _tiny_arch():
+    return dict(configs.ARCHS['WIDERFACE_LFD_XS'], body_architecture=[1], body_channels=[64], out_indices=((0, 0),),
+                regression_ranges=((4, 320),))
+
+
+def test_checkpoint_written_by_the_reference_loads_strictly():
+    """tests/golden/ref_checkpoint_tiny.pth was written by the REFERENCE's save_checkpoint (execution/utils.py:90-122) from
+    the reference's modules wrapped in nn.DataParallel (make_golden_checkpoint.py).  lfd_amd.checkpoint.load_checkpoint
+    must take it with strict=True into this package's modules, tensor for tensor, and the optimizer / scheduler states
+    must resume in lfd_amd.optim.SGD."""
+    from conftest import GOLDEN
+    from lfd_amd import checkpoint, optim
+    path = os.path.join(GOLDEN, 'ref_checkpoint_tiny.pth')
+    m = configs.build_model(_tiny_arch(), seed=123)          # different init: everything must come from the file
+    ck = checkpoint.load_checkpoint(m, path, strict=True)
+    assert set(ck) == {'meta', 'state_dict', 'optimizer_state_dict', 'lr_scheduler_state_dict'} and ck['meta']['epoch'] == 7
+    expect = configs.build_model(_tiny_arch(), seed=666)
+    configs.perturb_weights(expect, seed=2)
+    assert list(m.state_dict()) == list(ck['state_dict']) == list(expect.state_dict())
+    for (k, a), b in zip(m.state_dict().items(), expect.state_dict().values()):
+        assert torch.equal(a, b), k
+    opt = optim.SGD(m.parameters(), lr=0.5, momentum=0.0)
+    opt.load_state_dict(ck['optimizer_state_dict'])
+    g = opt.param_groups[0]
+    assert (g['lr'], g['momentum'], g['weight_decay']) == (0.1, 0.9, 1e-4)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.5)
+    sched.load_state_dict(ck['lr_scheduler_state_dict'])
+    assert sorted(sched.milestones) == [60, 90] and sched.gamma == 0.1
