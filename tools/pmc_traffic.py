@@ -9,9 +9,9 @@ for db in sys.argv[1:3]:
     for name, cname, val, did in c.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
         raw[name][(cname, did)].append(val)
 def cls(name):
-    m = re.search(r'k_conv<(\d+), (\d), (\d), (\d), (true|false), (true|false), (true|false), (true|false)>', name)
+    m = re.search(r'k_conv<(\d+), (\d), (\d), (\d), (true|false), (true|false), (true|false), (true|false)(?:, (?:true|false))?>', name)
     if m:
-        cin, ks, s, nct, wreg, tail, res, ds = m.groups()
+        cin, ks, s, nct, wreg, tail, res, ds = m.groups()[:8]
         return 'k_conv<cin=%s,k=%s,s=%s,nct=%s%s%s%s>' % (cin, ks, s, nct, ',tail' if tail == 'true' else '', ',res' if res == 'true' else '', ',ds' if ds == 'true' else '')
     m = re.search(r'(k_[a-z0-9_]+)(<[^>]*>)?', name)
     return (m.group(1) + (m.group(2) or '')) if m else None
