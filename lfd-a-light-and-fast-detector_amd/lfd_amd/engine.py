@@ -339,8 +339,10 @@ class EnginePlan(object):
         return s, (bias - norm.running_mean.detach().double()) * s + norm.bias.detach().double()
 
     # ---- shape-dependent state
-    def state_for(self, n, h, w):
-        key = (n, h, w)
+    def state_for(self, n, h, w, slot=0):
+        """`slot`: independent sets of activation / output buffers for the same shape, so that several batches can be in
+        flight at once (one per HIP stream; bench.py keeps two)."""
+        key = (n, h, w, slot)
         st = self._shape_cache.get(key)
         if st is None:
             st = _ShapeState(self, n, h, w)
@@ -603,16 +605,16 @@ def _input_format(x):
     raise RuntimeError('unsupported input: NCHW float32 [N,3,H,W], NHWC float16 [N,H,W,3] or NHWC uint8 [N,H,W,3]')
 
 
-def lfd_forward(model, x, use_graph=False):
+def lfd_forward(model, x, use_graph=False, slot=0):
     """Full LFD forward on the engine.  Returns (cls [N,P,C'] fp32, reg [N,P,4] fp32, sizes).
     The returned tensors are engine-owned buffers, overwritten by the next forward of the same
-    input shape (clone() to keep them)."""
+    input shape and slot (clone() to keep them)."""
     _lib.require_cuda(x, 'LFD.forward')
     if not x.is_contiguous():
         x = x.contiguous()
     fmt, n, h, w = _input_format(x)
     plan = get_plan(model, model._backbone, model._neck, model._head, x.device)
-    st = plan.state_for(n, h, w)
+    st = plan.state_for(n, h, w, slot)
     with torch.cuda.device(x.device):
         if use_graph:
             _run_graphed(plan, st, x, fmt)

@@ -117,21 +117,24 @@ class LFD(nn.Module):
             self._head_indexes_to_feature_map_sizes[i] = hw
         return cls.clone(), reg.clone()
 
-    def forward_resident(self, x):
+    def forward_resident(self, x, slot=0):
         """Fast path: same as forward() in eval mode but returns the engine-owned output buffers
-        (no copy, valid until the next forward of the same input shape)."""
-        cls, reg, sizes = engine.lfd_forward(self, x, use_graph=self.use_graph)
+        (no copy, valid until the next forward of the same input shape and `slot`)."""
+        cls, reg, sizes = engine.lfd_forward(self, x, use_graph=self.use_graph, slot=slot)
         for i, hw in enumerate(sizes):
             self._head_indexes_to_feature_map_sizes[i] = hw
         return cls, reg
 
-    def detect_resident(self, x, meta, score_thr=None, iou_thr=None, class_agnostic=None, max_candidates=None):
+    def detect_resident(self, x, meta, score_thr=None, iou_thr=None, class_agnostic=None, max_candidates=None, slot=0):
         """Whole inference step for frames resident in device memory: forward + decode + threshold + NMS, results on the
         device (ops.DetectOutputs, overwritten by the next call with the same buffers).  With `use_graph` the complete
-        step -- not only the forward -- is one HIP graph per (frame buffer, meta buffer, thresholds): one host call
-        per step, no launch gap between the head and the post-processing kernels."""
+        step -- not only the forward -- is one HIP graph per (frame buffer, meta buffer, thresholds, slot): one host call
+        per step, no launch gap between the head and the post-processing kernels.  `slot` selects an independent set of
+        activation / output / workspace buffers: steps of DIFFERENT slots may be enqueued on different HIP streams and
+        overlap on the device (the small-map stages, the post-processing kernels and the launch gaps of one batch leave most
+        CUs idle -- a second batch in flight fills them: 0.75 -> 0.61 ms per batch of 8 at depth 2, tools/ab_pipeline.py)."""
         if not self.use_graph:
-            return self.detect(self.forward_resident(x), meta, score_thr, iou_thr, class_agnostic, max_candidates)
+            return self.detect(self.forward_resident(x, slot), meta, score_thr, iou_thr, class_agnostic, max_candidates)
         score_thr = self._classification_threshold if score_thr is None else score_thr
         iou_thr = self._nms_cfg.get('iou_thr', 0.5) if iou_thr is None else iou_thr
         agn = self._nms_cfg.get('class_agnostic', False) if class_agnostic is None else class_agnostic
@@ -149,20 +152,20 @@ class LFD(nn.Module):
                 cache.clear()
                 self.__dict__['_step_graphs_plan'] = plan
             self.__dict__['_step_graphs_ver'] = ver
-        key = (x.data_ptr(), tuple(x.shape), x.dtype, meta.data_ptr(), float(score_thr), float(iou_thr), bool(agn), max_candidates)
+        key = (x.data_ptr(), tuple(x.shape), x.dtype, meta.data_ptr(), float(score_thr), float(iou_thr), bool(agn), max_candidates, slot)
         ent = cache.get(key)
         if ent is None:
-            if len(cache) >= 4:
+            if len(cache) >= 8:
                 cache.pop(next(iter(cache)))
             self.use_graph = False
             try:
                 with torch.cuda.device(x.device):
-                    out = self.detect(self.forward_resident(x), meta, score_thr, iou_thr, agn, max_candidates)   # warm-up, sizes buffers
+                    out = self.detect(self.forward_resident(x, slot), meta, score_thr, iou_thr, agn, max_candidates)   # warm-up, sizes buffers
                     torch.cuda.synchronize()
                     desc, _ = self._detect_desc(score_thr, iou_thr, agn, max_candidates)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        cls, reg = self.forward_resident(x)
+                        cls, reg = self.forward_resident(x, slot)
                         ops.detect_batched(desc, cls, reg, meta, out=out)
             finally:
                 self.use_graph = True

@@ -88,7 +88,7 @@ def make_detect_desc(sizes, strides, ranges, num_classes, num_cls_channels, scor
 
 
 class DetectOutputs(object):
-    __slots__ = ('dets', 'labels', 'cand', 'point', 'counts')
+    __slots__ = ('dets', 'labels', 'cand', 'point', 'counts', 'ws')
 
 
 def detect_batched(desc, cls, reg, meta, out=None):
@@ -109,8 +109,13 @@ def detect_batched(desc, cls, reg, meta, out=None):
             out.cand = torch.empty((n, cap), dtype=torch.int32, device=dev)
             out.point = torch.empty((n, cap), dtype=torch.int32, device=dev)
             out.counts = torch.empty((n, 4), dtype=torch.int32, device=dev)   # fully written by k_count/k_scatter/k_scan
+            out.ws = None
         wsb = lib().lfd_detect_workspace_bytes(C.byref(desc), n)
-        ws = _workspace(wsb, dev)
+        # the workspace belongs to the output set (not the process-wide scratch): passes of different output sets may run
+        # concurrently on different streams
+        if getattr(out, 'ws', None) is None or out.ws.numel() < wsb:
+            out.ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+        ws = out.ws
         check(lib().lfd_detect_batched(C.byref(desc), n, ptr(cls), ptr(reg), _dtype_code(cls), ptr(meta),
                                        ptr(out.dets), ptr(out.labels), ptr(out.cand), ptr(out.point),
                                        ptr(out.counts), ptr(ws), ws.numel(), stream_ptr()), 'lfd_detect_batched')
