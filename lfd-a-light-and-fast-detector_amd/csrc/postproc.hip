@@ -591,237 +591,6 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(SegBuffers b, ScanOut o) 
   }
 }
 
-// ------------------------------------------------------------------ single-workgroup detection tail
-// The whole tail of one image -- threshold + ordered compaction, rank sort, suppression bitmask, greedy scan, outputs --
-// in ONE workgroup with every intermediate in LDS, for the sparse regime (capacity <= 512 candidates per image and a
-// score map small enough for one workgroup to sweep twice).  Same arithmetic, same order and same outputs as
-// k_count / k_scatter / k_rank_sort / k_mask / k_scan.  Idea: at 8 x 1080p the five launches of the general path cost more
-// in launch latency (~6 us each) than in work.  Outcome: slower (see lfd_detect_batched) -- kept as a tested opt-in.
-constexpr int kFT = 512;     // threads (8 waves)
-constexpr int kFCap = 512;   // candidate capacity per image on this path
-constexpr int kFWords = kFCap / 64;
-
-struct FusedLds {
-  float4 c_box[kFCap];
-  float4 s_box[kFCap];
-  unsigned long long keys[kFCap];
-  unsigned long long mask[kFCap * kFWords];
-  unsigned long long remv[kFWords];
-  float c_score[kFCap], s_area[kFCap], s_score[kFCap];
-  int c_label[kFCap], c_point[kFCap], s_label[kFCap], s_idx[kFCap], s_point[kFCap];
-  int wave_cnt[kFT / 64];
-  uint32_t wave_max[kFT / 64];
-  unsigned long long keep;
-  int nkept;
-  int list[64];
-};
-
-__global__ __launch_bounds__(kFT) void k_detect_fused(DecodeParams d, int cap, int class_agnostic, float iou_thr,
-                                                     ScanOut o) {
-  extern __shared__ __attribute__((aligned(16))) char fused_smem[];
-  FusedLds& L = *reinterpret_cast<FusedLds*>(fused_smem);
-  const int n = blockIdx.x;
-  const int lane = lfd_lane();
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  constexpr int NW = kFT / 64;
-  // ---- phase 1: count, then ordered compaction (== `nonzero` order: point-major, class-minor).  Wave w owns a
-  //      contiguous range of points, swept 64 at a time (coalesced); scores are evaluated twice instead of stored.
-  const int per_wave = (((d.P + NW - 1) / NW + 63) / 64) * 64;
-  const int p_lo = wave * per_wave, p_hi = (p_lo + per_wave) < d.P ? (p_lo + per_wave) : d.P;
-  int wtotal = 0;
-  for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-    const int p = p0 + lane;
-    int cnt = 0;
-    if (p < p_hi) {
-      const int64_t row = (int64_t)n * d.P + p;
-      float mx = 0.f, sum = 1.f;
-      if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
-      for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
-    }
-    wtotal += wave_incl_scan(cnt);   // lane 63 ends up with the wave total
-  }
-  if (lane == 63) L.wave_cnt[wave] = wtotal;
-  __syncthreads();
-  int base = 0, all = 0;
-  for (int i = 0; i < NW; ++i) {
-    const int v = L.wave_cnt[i];
-    if (i < wave) base += v;
-    all += v;
-  }
-  const int K = all < cap ? all : cap;
-  uint32_t mo = 0u;
-  int run = base;
-  for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-    const int p = p0 + lane;
-    int cnt = 0;
-    float mx = 0.f, sum = 1.f;
-    int64_t row = 0;
-    if (p < p_hi) {
-      row = (int64_t)n * d.P + p;
-      if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
-      for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
-    }
-    const int inc = wave_incl_scan(cnt);
-    int off = run + inc - cnt;
-    run += __shfl(inc, 63, 64);
-    if (cnt > 0) {
-      const float4 box = decode_box(d, n, p);
-      bool wrote = false;
-      for (int c = 0; c < d.C; ++c) {
-        const float s = score_of(d, row, c, mx, sum);
-        if (s > d.score_thr) {
-          if (off < cap) {
-            L.c_box[off] = box;
-            L.c_score[off] = s;
-            L.c_label[off] = c;
-            L.c_point[off] = p;
-            wrote = true;
-          }
-          ++off;
-        }
-      }
-      if (wrote) mo = lfd_float_ord(fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
-    }
-  }
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {
-    const uint32_t t = __shfl_xor(mo, s, 64);
-    mo = t > mo ? t : mo;
-  }
-  if (lane == 0) L.wave_max[wave] = mo;
-  if (threadIdx.x < kFWords) L.remv[threadIdx.x] = 0ull;
-  if (threadIdx.x == 0) L.nkept = 0;
-  __syncthreads();
-  uint32_t maxord = 0u;
-  for (int i = 0; i < NW; ++i) maxord = L.wave_max[i] > maxord ? L.wave_max[i] : maxord;
-  if (threadIdx.x == 0 && o.counts) {
-    o.counts[n * 4 + 0] = K;
-    o.counts[n * 4 + 2] = all > cap;
-    o.counts[n * 4 + 3] = all;
-  }
-  // ---- phase 2: rank sort on the unique (score desc, ordinal asc) key; sorted, class-offset boxes (nms.py:148-150)
-  const int i = threadIdx.x;
-  const bool live = i < K;
-  const float my_score = live ? L.c_score[i] : 0.f;
-  const unsigned long long my = live ? sort_key(my_score, i) : ~0ull;
-  L.keys[i] = my;
-  __syncthreads();
-  if (live) {
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < K; ++j) rank += L.keys[j] < my;
-    const float4 bx = L.c_box[i];
-    const int label = L.c_label[i];
-    float4 sb = bx;
-    if (!class_agnostic) {
-      const float step = lfd_ord_float(maxord) + 1.0f;
-      const float off = (float)label * step;
-      sb.x = bx.x + off; sb.y = bx.y + off; sb.z = bx.z + off; sb.w = bx.w + off;
-    }
-    L.s_idx[rank] = i;
-    L.s_point[rank] = L.c_point[i];
-    L.s_score[rank] = my_score;
-    L.s_label[rank] = label;
-    L.s_box[rank] = sb;
-    L.s_area[rank] = (sb.z - sb.x) * (sb.w - sb.y);
-  }
-  __syncthreads();
-  // ---- phase 3: suppression bitmask.  Task = (64x64 tile (r, c >= r), quarter q): lane = row box, 16 column boxes
-  //      read from LDS (same address for all lanes: broadcast); the 16-bit piece lands in its place of the 64-bit word.
-  const int nb = (K + 63) >> 6;
-  {
-    unsigned short* m16 = reinterpret_cast<unsigned short*>(L.mask);
-    const int ntask = nb * nb * 4;
-    for (int t = wave; t < ntask; t += NW) {
-      const int q = t & 3, tile = t >> 2;
-      const int r = tile / nb, c = tile - r * nb;
-      if (c < r) continue;
-      const int ri = r * 64 + lane;
-      float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
-      float ra = 0.f;
-      if (ri < K) { rb = L.s_box[ri]; ra = L.s_area[ri]; }
-      const int ncol = K - c * 64;
-      const int start = (r == c) ? lane + 1 : 0;
-      unsigned m = 0u;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = q * 16 + jj;
-        const int ci = c * 64 + j;
-        const float4 cb = ci < K ? L.s_box[ci] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float sb = ci < K ? L.s_area[ci] : 0.f;
-        const float left = fmaxf(rb.x, cb.x), right = fminf(rb.z, cb.z);
-        const float top = fmaxf(rb.y, cb.y), bottom = fminf(rb.w, cb.w);
-        const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
-        const float inter = w * h;
-        const float iou = inter / (ra + sb - inter);
-        if (j >= start && j < ncol && iou > iou_thr) m |= 1u << jj;
-      }
-      if (ri < K) m16[(ri * kFWords + c) * 4 + q] = (unsigned short)m;
-    }
-  }
-  __syncthreads();
-  // ---- phase 4: greedy scan over the 64-row blocks (k_scan, whole mask resident) + outputs
-  float step = 0.f;
-  if (!class_agnostic && K > 0) step = lfd_ord_float(maxord) + 1.0f;
-  const int64_t so = (int64_t)n * cap;
-  for (int c = 0; c < nb; ++c) {
-    if (wave == 0) {
-      const int row = c * 64 + lane;
-      const unsigned long long diag = row < K ? L.mask[row * kFWords + c] : 0ull;
-      const unsigned long long r = L.remv[c];
-      unsigned long long kb = __ballot(row < K && !((r >> lane) & 1ull));
-      unsigned long long pending = kb & __ballot(diag != 0ull);
-      const int dlo = (int)(diag & 0xffffffffull), dhi = (int)(diag >> 32);
-      while (pending) {
-        const int bit = __builtin_ctzll(pending);
-        const unsigned long long m =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, bit) << 32) |
-            (unsigned)__builtin_amdgcn_readlane(dlo, bit);
-        kb &= ~m;
-        pending &= kb;
-        pending &= ~(1ull << bit);
-      }
-      const int basek = L.nkept;
-      if ((kb >> lane) & 1ull) {
-        const int pos = basek + __popcll(kb & ((1ull << lane) - 1ull));
-        const int64_t oo = so + pos;
-        const int clab = L.s_label[row];
-        if (o.dets) {
-          float4 bx = L.s_box[row];
-          if (!class_agnostic) {
-            const float off = (float)clab * step;
-            bx.x = bx.x - off; bx.y = bx.y - off; bx.z = bx.z - off; bx.w = bx.w - off;
-          }
-          float* dd = o.dets + oo * 5;
-          dd[0] = bx.x; dd[1] = bx.y; dd[2] = bx.z; dd[3] = bx.w; dd[4] = L.s_score[row];
-        }
-        if (o.labels) o.labels[oo] = clab;
-        if (o.cand) o.cand[oo] = L.s_idx[row];
-        if (o.point) o.point[oo] = L.s_point[row];
-        L.list[__popcll(kb & ((1ull << lane) - 1ull))] = lane;
-      }
-      if (lane == 0) {
-        L.keep = kb;
-        L.nkept = basek + __popcll(kb);
-      }
-    }
-    __syncthreads();
-    const unsigned long long kb = L.keep;
-    const int nw = nb - c - 1;
-    if (nw > 0 && kb) {
-      const int nk = __popcll(kb);
-      const int total = nk * nw;
-      for (int qq = threadIdx.x; qq < total; qq += kFT) {
-        const int ki = qq / nw, w = c + 1 + (qq - ki * nw);
-        const unsigned long long v = L.mask[(c * 64 + L.list[ki]) * kFWords + w];
-        if (v) atomicOr(&L.remv[w], v);
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && o.counts) o.counts[n * 4 + 1] = L.nkept;
-}
-
 // ------------------------------------------------------------------ host-side plumbing
 struct SegLayout {
   size_t bytes;
@@ -1007,32 +776,6 @@ int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void*
   if (workspace_bytes < lfd_detect_workspace_bytes(desc, batch)) return LFD_ERR_WORKSPACE_TOO_SMALL;
   if (d.P == 0) {
     if (hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 4 * batch, st) != hipSuccess) return LFD_ERR_LAUNCH_FAILED;
-    return LFD_OK;
-  }
-  // MEASURED NEGATIVE RESULT, opt-in (LFD_DETECT_FUSED=1; read per call so that tests compare both paths in one
-  // process): identical outputs, but 8 x 1080p takes 0.963 ms per step instead of 0.790 -- one workgroup per image
-  // sweeps the 43,620-point score map in ~170 dependent wave iterations (global load -> expf -> wave scan), a ~180 us
-  // latency chain, where the general path spreads the same sweep over 171 workgroups per image.  The LDS-resident
-  // sort / mask / scan phases themselves are ~10 us; merging them behind a multi-workgroup compaction is the follow-up.
-  const char* fused_env = getenv("LFD_DETECT_FUSED");
-  const int use_fused = fused_env ? atoi(fused_env) : 0;
-  if (use_fused && desc->max_candidates <= kFCap && (long long)d.P * d.Cc <= (1 << 17)) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_detect_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sizeof(FusedLds)) != hipSuccess)
-        return LFD_ERR_LAUNCH_FAILED;
-      attr_done = true;
-    }
-    ScanOut o{};
-    o.dets = out_dets;
-    o.labels = out_labels;
-    o.cand = out_cand;
-    o.point = out_point;
-    o.counts = out_counts;
-    hipLaunchKernelGGL(k_detect_fused, dim3(batch), dim3(kFT), sizeof(FusedLds), st, d, desc->max_candidates,
-                       desc->class_agnostic ? 1 : 0, desc->iou_thr, o);
-    LFD_CHECK_LAUNCH();
     return LFD_OK;
   }
   const int nblk = (d.P + kBlock - 1) / kBlock;
