@@ -1,6 +1,6 @@
 """Named model configurations = the model sections of the reference's config scripts
-(`prepare_model()` in WIDERFACE_train/WIDERFACE_LFD_{L,M,S,XS}.py:76-158 and
-TT100K_train/TT100K_LFD_{L,S}.py:76-157), expressed as plain kwargs so the same dict drives
+(`prepare_model()` in WIDERFACE_train/WIDERFACE_LFD_{L,M,S,XS}.py:76-158,
+TT100K_train/TT100K_LFD_{L,S}.py:76-157 and TrafficLight_train/TL_LFD_{L,S}.py:76-150), expressed as plain kwargs so the same dict drives
 this package's modules, the oracle (oracle/net_oracle.py `arch`) and the reference modules
 (tests/golden/make_golden.py).
 """
@@ -28,6 +28,16 @@ def _tt(stem_mode, body_architecture, body_channels, out_indices):
                 distance_to_bbox_mode='sigmoid')
 
 
+def _tl(stem_channels, body_architecture, body_channels, out_indices, ranges):
+    """TrafficLight_train/TL_LFD_{L,S}.py:76-150: LFD with a norm-free shared head and QualityFocalLoss (loss_weight 2)."""
+    return dict(block_mode='faster', stem_mode='fast', stem_channels=stem_channels, body_architecture=body_architecture,
+                body_channels=body_channels, out_indices=out_indices, num_neck_channels=128, num_classes=1,
+                num_head_channels=128, num_conv_layers=2, conv_kernel_size=1, gn_groups=None, share_head_flag=True,
+                merge_path_flag=True, classification_loss_type='QualityFocalLoss', regression_loss_type='IoULoss',
+                regression_ranges=ranges, gray_range_factors=(0.9, 1.1), range_assign_mode='dist',
+                distance_to_bbox_mode='sigmoid')
+
+
 ARCHS = {
     'WIDERFACE_LFD_L': _wf('fast', 64, [4, 2, 2, 1, 1], [64, 64, 64, 128, 128], ((0, 3), (1, 1), (2, 1), (3, 0), (4, 0))),
     'WIDERFACE_LFD_M': _wf('fast', 64, [3, 2, 1, 1, 1], [64, 64, 64, 128, 128], ((0, 2), (1, 1), (2, 0), (3, 0), (4, 0))),
@@ -35,16 +45,24 @@ ARCHS = {
     'WIDERFACE_LFD_XS': _wf('faster', 32, [4, 2, 2, 3], [64, 64, 64, 64], ((0, 3), (1, 1), (2, 1), (3, 0), (3, 2))),
     'TT100K_LFD_L': _tt('fast', [5, 3, 2, 2], [64, 64, 128, 128], ((0, 4), (1, 2), (2, 1), (3, 1))),
     'TT100K_LFD_S': _tt('faster', [4, 2, 1, 1], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 0), (3, 0))),
+    'TL_LFD_L': _tl(64, [5, 3, 2, 2, 2], [64, 64, 128, 128, 128], ((0, 4), (1, 2), (2, 1), (3, 1), (4, 1)),
+                    ((4, 32), (32, 64), (64, 128), (128, 256), (256, 512))),
+    # 48-channel stem / first stage: module tree, checkpoints, losses and training through PyTorch-ROCm work; the MFMA conv
+    # kernels are instantiated for 32 / 64 / 128 channels, so the inference engine refuses this one loudly
+    'TL_LFD_S': _tl(48, [4, 2, 1, 1, 1], [48, 64, 64, 128, 128], ((0, 3), (1, 1), (2, 0), (3, 0), (4, 0)),
+                    ((0, 16), (16, 32), (32, 64), (64, 128), (128, 256))),
 }
 
 
-def build_modules(arch, backbone_cls, neck_cls, head_cls, lfd_cls, focal_cls, iou_cls, ce_cls, seed=666):
+def build_modules(arch, backbone_cls, neck_cls, head_cls, lfd_cls, focal_cls, iou_cls, ce_cls, seed=666, qfl_cls=None):
     """Instantiates (backbone, neck, head, LFD) from `arch` with the given classes (this package's
     or the reference's -- identical kwargs), under torch.manual_seed(seed) (= the config seed,
     WIDERFACE_LFD_S.py:51)."""
     torch.manual_seed(seed)
     if arch['classification_loss_type'] == 'CrossEntropyLoss':
         cls_loss = ce_cls(reduction='mean', loss_weight=1.0)
+    elif arch['classification_loss_type'] == 'QualityFocalLoss':
+        cls_loss = qfl_cls(use_sigmoid=True, beta=2.0, reduction='mean', loss_weight=2.0)       # TL_LFD_L.py:79-84
     else:
         cls_loss = focal_cls(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0)
     reg_loss = iou_cls(eps=1e-6, reduction='mean', loss_weight=1.0)
@@ -59,7 +77,7 @@ def build_modules(arch, backbone_cls, neck_cls, head_cls, lfd_cls, focal_cls, io
     head = head_cls(num_classes=arch['num_classes'], num_heads=len(neck.num_output_strides_list),
                     num_input_channels=arch['num_neck_channels'], num_head_channels=arch['num_head_channels'],
                     num_conv_layers=arch['num_conv_layers'], activation_cfg=dict(type='ReLU', inplace=True),
-                    norm_cfg=dict(type='GroupNorm', num_groups=arch['gn_groups']),
+                    norm_cfg=dict(type='GroupNorm', num_groups=arch['gn_groups']) if arch['gn_groups'] else None,
                     share_head_flag=arch['share_head_flag'], merge_path_flag=arch['merge_path_flag'],
                     classification_loss_type=type(cls_loss).__name__, regression_loss_type=type(reg_loss).__name__)
     model = lfd_cls(backbone=bb, neck=neck, head=head, num_classes=arch['num_classes'],
@@ -75,10 +93,10 @@ def build_model(name_or_arch, seed=666):
     from .model.backbone import LFDResNet
     from .model.head import LFDHead
     from .model.lfd import LFD
-    from .model.losses import CrossEntropyLoss, FocalLoss, IoULoss
+    from .model.losses import CrossEntropyLoss, FocalLoss, IoULoss, QualityFocalLoss
     from .model.neck import SimpleNeck
     arch = ARCHS[name_or_arch] if isinstance(name_or_arch, str) else name_or_arch
-    return build_modules(arch, LFDResNet, SimpleNeck, LFDHead, LFD, FocalLoss, IoULoss, CrossEntropyLoss, seed)
+    return build_modules(arch, LFDResNet, SimpleNeck, LFDHead, LFD, FocalLoss, IoULoss, CrossEntropyLoss, seed, QualityFocalLoss)
 
 
 def perturb_weights(model, seed=1):
@@ -86,10 +104,12 @@ def perturb_weights(model, seed=1):
     init has gamma=1, beta=0, mean=0, var=1 and head std 0.01, which would hide BN-fold /
     GroupNorm / Scale bugs and give near-constant logits.  Deterministic given the state_dict key
     order: BN running_mean~N(0,.1), running_var~U(.5,1.5); every norm weight~U(.5,1.5),
-    bias~N(0,.1); Scale~U(.8,1.2); head conv weights re-drawn with std 0.1."""
+    bias~N(0,.1); Scale~U(.8,1.2); head conv weights re-drawn with std 0.1 (0.03 for norm-free heads)."""
     g = torch.Generator().manual_seed(seed)
     sd = model.state_dict()
     seen = set()
+    # a norm-free head (TrafficLight configs) has nothing that re-normalises its towers: std 0.1 would give |logits| ~ 100
+    head_std = 0.1 if any(k.startswith('_head.') and v.dim() == 1 and k.endswith('.weight') for k, v in sd.items()) else 0.03
     with torch.no_grad():
         for k, v in sd.items():
             if v.data_ptr() in seen:     # shared head: duplicated keys alias one tensor
@@ -108,5 +128,5 @@ def perturb_weights(model, seed=1):
             elif v.dim() == 1 and k.endswith('.bias'):
                 v.copy_(torch.randn(v.shape, generator=g) * 0.1)
             elif v.dim() == 4 and k.startswith('_head.'):
-                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+                v.copy_(torch.randn(v.shape, generator=g) * head_std)
     return model

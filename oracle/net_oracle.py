@@ -91,14 +91,16 @@ def neck_forward(sd, arch, feats, pfx='_neck.'):
 
 def head_forward(sd, arch, feats, pfx='_head.'):
     """LFDHead.forward (lfd_head.py:164-185)."""
-    G = arch['gn_groups']
+    G = arch['gn_groups']            # None: norm-free head (TrafficLight configs, lfd_head.py:100-117: conv(bias) + activation)
     k = arch.get('conv_kernel_size', 1)
     nl = arch.get('num_conv_layers', 2)
+    ls = 3 if G else 2               # modules per tower layer: conv, [norm], activation
 
     def tower(name, x):
         for l in range(nl):
-            x = _conv(sd, f'{name}.{3 * l}', x, 1, k // 2)
-            x = F.group_norm(x, G, sd[f'{name}.{3 * l + 1}.weight'], sd[f'{name}.{3 * l + 1}.bias'], GN_EPS)
+            x = _conv(sd, f'{name}.{ls * l}', x, 1, k // 2)
+            if G:
+                x = F.group_norm(x, G, sd[f'{name}.{ls * l + 1}.weight'], sd[f'{name}.{ls * l + 1}.bias'], GN_EPS)
             x = F.relu(x)
         return x
 
@@ -111,8 +113,8 @@ def head_forward(sd, arch, feats, pfx='_head.'):
             c = _conv(sd, h + 'classification_path.0', t)
             r = _conv(sd, h + 'regression_path.0', t)
         else:
-            c = _conv(sd, h + f'classification_path.{3 * nl}', tower(h + 'classification_path', f))
-            r = _conv(sd, h + f'regression_path.{3 * nl}', tower(h + 'regression_path', f))
+            c = _conv(sd, h + f'classification_path.{ls * nl}', tower(h + 'classification_path', f))
+            r = _conv(sd, h + f'regression_path.{ls * nl}', tower(h + 'regression_path', f))
         if union:
             r = r * sd[f'{pfx}_scales.{i}._scale']
         cls_out.append(c)
@@ -367,6 +369,8 @@ def lfd_loss(arch, cls, reg, sizes, strides, gt_bboxes_list, gt_labels_list):
     label = mi * (mx >= 0.001) + C * (mx < 0.001)
     if ce:
         cl_el = F.cross_entropy(fc, label, reduction='none')
+    elif arch['classification_loss_type'] == 'QualityFocalLoss':      # lfd.py:330-335: targets = [label, max score]
+        cl_el = quality_focal_loss_rows(fc, label, mx, 2.0) * 2.0     # TL_LFD_L.py:79-84: beta 2, loss_weight 2
     else:
         cl_el = focal_loss_sum(fc, label)
     cls_loss = cl_el.sum() / (pos.nelement() + 1)
@@ -456,10 +460,13 @@ def head_forward_fp16(sd, arch, feats):
         t = _h(F.relu(F.conv2d(f, w, b)))
         hp = f'_head.head{i}_'
 
+        ls = 3 if G else 2
+
         def tower(name, t):
             for l in range(2):
-                yv = F.conv2d(t, _h(sd[f'{name}.{3 * l}.weight']))
-                yv = F.group_norm(yv, G, sd[f'{name}.{3 * l + 1}.weight'], sd[f'{name}.{3 * l + 1}.bias'], GN_EPS)
+                yv = F.conv2d(t, _h(sd[f'{name}.{ls * l}.weight']), sd.get(f'{name}.{ls * l}.bias'))
+                if G:
+                    yv = F.group_norm(yv, G, sd[f'{name}.{ls * l + 1}.weight'], sd[f'{name}.{ls * l + 1}.bias'], GN_EPS)
                 t = _h(F.relu(yv))
             return t
 
@@ -468,10 +475,10 @@ def head_forward_fp16(sd, arch, feats):
             c = F.conv2d(tt, _h(sd[hp + 'classification_path.0.weight']), sd[hp + 'classification_path.0.bias'])
             r = F.conv2d(tt, _h(sd[hp + 'regression_path.0.weight']), sd[hp + 'regression_path.0.bias'])
         else:
-            c = F.conv2d(tower(hp + 'classification_path', t), _h(sd[hp + 'classification_path.6.weight']),
-                         sd[hp + 'classification_path.6.bias'])
-            r = F.conv2d(tower(hp + 'regression_path', t), _h(sd[hp + 'regression_path.6.weight']),
-                         sd[hp + 'regression_path.6.bias'])
+            c = F.conv2d(tower(hp + 'classification_path', t), _h(sd[hp + f'classification_path.{2 * ls}.weight']),
+                         sd[hp + f'classification_path.{2 * ls}.bias'])
+            r = F.conv2d(tower(hp + 'regression_path', t), _h(sd[hp + f'regression_path.{2 * ls}.weight']),
+                         sd[hp + f'regression_path.{2 * ls}.bias'])
         r = r * sd[f'_head._scales.{i}._scale']
         cls_l.append(c)
         reg_l.append(r)

@@ -48,6 +48,7 @@ def synth_boxes(rng, k, W=1920, H=1080):
 
 
 def main():
+    only_model = sys.argv[sys.argv.index('--only-model') + 1] if '--only-model' in sys.argv else None
     M = ref_import.import_reference()
     import lfd.model.backbone as RB
     import lfd.model.head as RH
@@ -87,7 +88,10 @@ def main():
                                          mean=float(l1_loss(p, t)), weighted_mean=float(l1_loss(p, t, w)),
                                          none=l1_loss(p, t, reduction='none').tolist(),
                                          avg_factor_2=float(l1_loss(p, t, w, avg_factor=2)))
-    json.dump(ka, open(os.path.join(HERE, 'known_answers.json'), 'w'), indent=1)
+    if only_model is None:
+        prev = json.load(open(os.path.join(HERE, 'known_answers.json')))
+        ka.update({k: v for k, v in prev.items() if k not in ka})      # keys owned by other generators (reference_model_configs)
+        json.dump(ka, open(os.path.join(HERE, 'known_answers.json'), 'w'), indent=1)
 
     # ---------------------------------------------------------------- 2. reference CPU nms_ext on seeded boxes
     rng = np.random.default_rng(1234)
@@ -107,7 +111,8 @@ def main():
     out['keep_%d' % len(cases)] = ext.nms(torch.from_numpy(dets), 0.5).numpy()
     cases.append((5, 0.5))
     out['cases'] = np.array(cases, np.float64)
-    np.savez_compressed(os.path.join(HERE, 'ref_nms.npz'), **out)
+    if only_model is None:
+        np.savez_compressed(os.path.join(HERE, 'ref_nms.npz'), **out)
 
     # ---------------------------------------------------------------- 2b. reference CPU soft_nms / nms_match (nms_cpu.cpp:76-283)
     out = {}
@@ -124,7 +129,8 @@ def main():
         out['match_members_%d' % ci] = np.array([i for m in match for i in m], np.int64)
         ci += 1
     out['num_cases'] = np.array(ci)
-    np.savez_compressed(os.path.join(HERE, 'ref_nms_cpu_extra.npz'), **out)
+    if only_model is None:
+        np.savez_compressed(os.path.join(HERE, 'ref_nms_cpu_extra.npz'), **out)
 
     # ---------------------------------------------------------------- 3. reference python multiclass_nms
     out = {}
@@ -143,14 +149,17 @@ def main():
         out['dets_%d' % ci], out['labels_%d' % ci] = dets.numpy(), labels.numpy()
         mc.append((n, C, sthr, ithr, int(agn)))
     out['cases'] = np.array(mc, np.float64)
-    np.savez_compressed(os.path.join(HERE, 'ref_multiclass_nms.npz'), **out)
+    if only_model is None:
+        np.savez_compressed(os.path.join(HERE, 'ref_multiclass_nms.npz'), **out)
 
     # ---------------------------------------------------------------- 4. reference model runs
     for name, (N, H, W) in (('WIDERFACE_LFD_XS', (2, 96, 128)), ('WIDERFACE_LFD_S', (1, 72, 104)),
-                            ('TT100K_LFD_L', (1, 64, 96))):
+                            ('TT100K_LFD_L', (1, 64, 96)), ('TL_LFD_L', (1, 64, 128))):
+        if only_model is not None and name != only_model:
+            continue
         arch = configs.ARCHS[name]
         model = configs.build_modules(arch, RB.LFDResNet, RN.SimpleNeck, RH.LFDHead, M.LFD, RL.FocalLoss,
-                                      RL.IoULoss, RL.CrossEntropyLoss, seed=666)
+                                      RL.IoULoss, RL.CrossEntropyLoss, seed=666, qfl_cls=RL.QualityFocalLoss)
         sha_init = state_sha(model.state_dict())
         configs.perturb_weights(model, seed=1)
         sha = state_sha(model.state_dict())

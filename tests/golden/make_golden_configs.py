@@ -2,8 +2,9 @@
 
     python tests/golden/make_golden_configs.py          (build container only: reads /root/reference)
 
-For each of the six shipped model configurations the script takes the source of `prepare_model()` out of the
-reference's config file (WIDERFACE_train/WIDERFACE_LFD_{L,M,S,XS}.py, TT100K_train/TT100K_LFD_{L,S}.py), executes that
+For each of the eight shipped model configurations the script takes the source of `prepare_model()` out of the
+reference's config file (WIDERFACE_train/WIDERFACE_LFD_{L,M,S,XS}.py, TT100K_train/TT100K_LFD_{L,S}.py,
+TrafficLight_train/TL_LFD_{L,S}.py), executes that
 function body with RECORDING stand-ins for the classes it instantiates (LFDResNet, SimpleNeck, LFDHead, LFD and the
 loss classes), and stores the keyword arguments every constructor received under
 known_answers.json['reference_model_configs'].  Nothing of the reference is imported (the config files pull the whole
@@ -20,6 +21,7 @@ FILES = {
     'WIDERFACE_LFD_L': 'WIDERFACE_train/WIDERFACE_LFD_L.py', 'WIDERFACE_LFD_M': 'WIDERFACE_train/WIDERFACE_LFD_M.py',
     'WIDERFACE_LFD_S': 'WIDERFACE_train/WIDERFACE_LFD_S.py', 'WIDERFACE_LFD_XS': 'WIDERFACE_train/WIDERFACE_LFD_XS.py',
     'TT100K_LFD_L': 'TT100K_train/TT100K_LFD_L.py', 'TT100K_LFD_S': 'TT100K_train/TT100K_LFD_S.py',
+    'TL_LFD_L': 'TrafficLight_train/TL_LFD_L.py', 'TL_LFD_S': 'TrafficLight_train/TL_LFD_S.py',
 }
 
 

@@ -72,7 +72,7 @@ def _scores(arch, t):
 # ------------------------------------------------------------------------------------------------ (a) G1
 @pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_XS', (1, 96, 128)), ('WIDERFACE_LFD_S', (2, 135, 241)),
                                         ('WIDERFACE_LFD_M', (1, 64, 96)), ('WIDERFACE_LFD_L', (1, 100, 156)),
-                                        ('TT100K_LFD_S', (1, 64, 64)), ('TT100K_LFD_L', (1, 90, 161)),
+                                        ('TT100K_LFD_S', (1, 64, 64)), ('TT100K_LFD_L', (1, 90, 161)), ('TL_LFD_L', (1, 128, 192)),
                                         ('WIDERFACE_LFD_S', (1, 1080, 1920)), ('TT100K_LFD_L', (1, 720, 1280))])
 def test_g1_fp32_storage_on_the_mfma_kernels_matches_the_fp32_oracle(name, shape):
     """Gate G1: <= 1e-4 max-abs on raw cls / reg logits (measured ~1e-5)."""

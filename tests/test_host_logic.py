@@ -284,7 +284,14 @@ def test_training_schedule_covers_every_parameter_once():
     touches every parameter of the six shipped configurations exactly once (shared head towers deduplicated), taps and
     residual wiring follow lfd_resnet.py:96-154 / :458-468; configurations outside its coverage are refused."""
     from lfd_amd import train_engine as te
+    # TrafficLight configs (norm-free head; TL_LFD_S also a 48-channel stem): the documented training fallback -- backbone on
+    # the HIP training kernels where its channel counts allow, neck / head through PyTorch-ROCm autograd
+    tl = {n: configs.build_model(n).train() for n in ('TL_LFD_L', 'TL_LFD_S')}
+    assert not te.network_supported(tl['TL_LFD_L']) and not te.network_supported(tl['TL_LFD_S'])
+    assert te.supported(tl['TL_LFD_L']._backbone) and not te.supported(tl['TL_LFD_S']._backbone)
     for name in configs.ARCHS:
+        if name.startswith('TL_'):
+            continue
         m = configs.build_model(name).train()
         assert te.network_supported(m), name
         units, outs = te.build_network(m)
@@ -357,7 +364,7 @@ def test_archs_match_reference_configs(known_answers):
                    body_architecture=bb['body_architecture'], body_channels=bb['body_channels'], out_indices=bb['out_indices'],
                    num_neck_channels=neck['num_neck_channels'], num_classes=lfd['num_classes'],
                    num_head_channels=head['num_head_channels'], num_conv_layers=head['num_conv_layers'],
-                   conv_kernel_size=head.get('conv_kernel_size', 1), gn_groups=head['norm_cfg']['num_groups'],
+                   conv_kernel_size=head.get('conv_kernel_size', 1), gn_groups=head['norm_cfg']['num_groups'] if head['norm_cfg'] else None,
                    share_head_flag=head['share_head_flag'], merge_path_flag=head['merge_path_flag'],
                    classification_loss_type=head['classification_loss_type'], regression_loss_type=head['regression_loss_type'],
                    regression_ranges=lfd['regression_ranges'], gray_range_factors=lfd['gray_range_factors'],
@@ -371,12 +378,14 @@ def test_archs_match_reference_configs(known_answers):
         # the fixed kwargs configs.build_modules passes
         assert bb['body_mode'] is None and bb['input_channels'] == 3 and bb['frozen_stages'] == -1 and bb['norm_eval'] is False
         assert bb['norm_cfg'] == dict(type='BatchNorm2d') and bb['activation_cfg'] == dict(type='ReLU', inplace=True)
-        assert neck['norm_cfg'] == dict(type='BatchNorm2d') and head['norm_cfg']['type'] == 'GroupNorm'
+        assert neck['norm_cfg'] == dict(type='BatchNorm2d') and (head['norm_cfg'] is None or head['norm_cfg']['type'] == 'GroupNorm')
         assert head['num_classes'] == lfd['num_classes'] and head['num_heads'] == len(arch['out_indices'])
         assert head['num_input_channels'] == neck['num_neck_channels']
         assert r['IoULoss'] == dict(eps=1e-6, reduction='mean', loss_weight=1.0)
         if arch['classification_loss_type'] == 'FocalLoss':
             assert r['FocalLoss'] == dict(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0)
+        elif arch['classification_loss_type'] == 'QualityFocalLoss':
+            assert r['QualityFocalLoss'] == dict(use_sigmoid=True, beta=2.0, reduction='mean', loss_weight=2.0)
         else:
             assert r['CrossEntropyLoss'] == dict(reduction='mean', loss_weight=1.0)
 
