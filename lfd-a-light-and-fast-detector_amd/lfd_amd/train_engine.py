@@ -41,6 +41,10 @@ def supported(backbone):
         return False
     if backbone._input_channels != 3:
         return False
+    # the hand-written backward accumulates into EVERY covered parameter's .grad: a frozen parameter (requires_grad=False,
+    # however it was frozen) sends the module through PyTorch-ROCm autograd instead
+    if not all(p.requires_grad for p in backbone.parameters()):
+        return False
     for m in backbone.modules():
         if isinstance(m, nn.Conv2d) and not _conv_ok(m):
             return False
@@ -55,6 +59,8 @@ def network_supported(model):
     """+ SimpleNeck with BatchNorm2d, LFDHead with 1x1 convs and GroupNorm groups of 8 channels, <= 60 output channels."""
     bb, neck, head = model._backbone, model._neck, model._head
     if not supported(bb):
+        return False
+    if not all(p.requires_grad for p in list(neck.parameters()) + list(head.parameters())):
         return False
     if neck._norm_cfg is None or neck._norm_cfg.get('type') != 'BatchNorm2d' or neck._activation_cfg.get('type') != 'ReLU':
         return False

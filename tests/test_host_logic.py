@@ -304,6 +304,11 @@ def test_training_schedule_covers_every_parameter_once():
             acts.add(u.dst)
         assert all(o.src in acts for o in outs)
         assert sorted({o.level for o in outs}) == list(range(m._num_heads))
+    frozen = configs.build_model('WIDERFACE_LFD_XS').train()
+    frozen._neck.neck0[0].weight.requires_grad_(False)
+    assert not te.network_supported(frozen) and te.supported(frozen._backbone)     # frozen parameter -> autograd path
+    frozen._backbone._stem[0].weight.requires_grad_(False)
+    assert not te.supported(frozen._backbone)
     m = configs.build_model('WIDERFACE_LFD_S').train()
     units, _ = te.build_network(m)
     blk = [u for u in units if u.conv is m._backbone.stage0[0]._conv2][0]
