@@ -7,7 +7,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w /tmp/p_sq1 /tmp/p_sq2
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -o kt -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-latency --no-train > $OUT/${TAG}_bench_under_rocprof.json 2>/tmp/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -o kt -- python $R/bench.py --steps 30 --warmup 5 --pipeline 1 --no-cpu-baseline --no-latency --no-train > $OUT/${TAG}_bench_under_rocprof.json 2>/tmp/kt.err
 find /tmp/p_kt -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f -o f -- python $R/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-latency --no-train > /tmp/f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w -o w -- python $R/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-latency --no-train > /tmp/w.log 2>&1
