@@ -61,7 +61,8 @@ struct HeadArgs {
   int grp_tile_start[LFD_MAX_LEVELS];  // first launch-local tile of each of them
   int grp_n, grp_ntiles;
   int grp_gpi[LFD_MAX_LEVELS];         // k_head2: 32-pixel groups per image of each of them
-  int h2_item_start[LFD_MAX_LEVELS];   //          first work item (= 4 chunks of H2_CH groups) of each of them
+  int h2_chg[LFD_MAX_LEVELS];          //          groups per work chunk (even: whole statistics tiles)
+  int h2_item_start[LFD_MAX_LEVELS];   //          first work item (= 4 consecutive chunks) of each of them
   int h2_nitems;
   int gshift;            // log2(channels per group)  (GroupNorm(16,128) -> 3)
   int ntiles;
@@ -100,6 +101,31 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   LFD_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
 #undef LFD_DPP_ADD
   return __int_as_float(x);
+}
+
+// Sums of 32 per-lane values over the 64 lanes in ~100 VALU instead of 32 x 6: a butterfly in which every step
+// halves the number of values a lane carries (lane bit k decides which of a pair it keeps; the other one goes to
+// the partner lane, whose bit k differs) -- quad permutes for bits 0/1, row rotations for bits 2/3 (the source
+// lane i -+ 4 / 8 has that bit flipped and the lower bits equal), the LDS crossbar for bits 4/5.  Returns, in
+// lane l, the total of v[l & 31].  Fixed order -> deterministic.
+__device__ __forceinline__ float wave_sum_transpose32(const float (&v)[32], int lane) {
+  float a[16], b[8], c[4], d[2];
+#define LFD_TR_STEP(dst, src, n, bit, ctrl)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < n; ++i) {                                                                 \
+    const bool up = (lane >> bit) & 1;                                                                            \
+    const float keep = up ? src[2 * i + 1] : src[2 * i], give = up ? src[2 * i] : src[2 * i + 1];                  \
+    dst[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), ctrl, 0xf, 0xf, false));   \
+  }
+  LFD_TR_STEP(a, v, 16, 0, 0xB1);    // quad_perm [1,0,3,2]
+  LFD_TR_STEP(b, a, 8, 1, 0x4E);     // quad_perm [2,3,0,1]
+  LFD_TR_STEP(c, b, 4, 2, 0x124);    // row_ror:4
+  LFD_TR_STEP(d, c, 2, 3, 0x128);    // row_ror:8
+#undef LFD_TR_STEP
+  const bool up = (lane >> 4) & 1;
+  const float keep = up ? d[1] : d[0], give = up ? d[0] : d[1];
+  float r = keep + __shfl_xor(give, 16, 64);
+  r += __shfl_xor(r, 32, 64);
+  return r;
 }
 
 // swizzled LDS tile of [TPX pixels][C channels] fp16: byte address of (pixel, 16-byte chunk c)
@@ -394,15 +420,29 @@ __global__ __launch_bounds__(256, 2) void k_head(HeadArgs a) {
 //   * one 256-thread workgroup per CU, 512 registers per wave: conv1 and conv2 filters resident (256 registers);
 //     the level's neck / final filters sit in LDS, shared by the workgroup (a workgroup only ever works on one level
 //     at a time);
-//   * work unit = chunk of CH consecutive 32-pixel groups of one image; its GroupNorm partial sums are accumulated
-//     per lane and reduced across lanes once per chunk.  The chunking depends on the level geometry only, so the
-//     statistics -- and therefore the outputs -- of an image do not depend on the batch it is in.
+//   * work unit = chunk of consecutive 32-pixel groups of one image.  GroupNorm partial sums are accumulated per
+//     lane over ONE 64-pixel statistics tile (2 groups), reduced across the lanes and written to that tile's slot:
+//     the statistics -- and therefore the outputs -- of an image depend neither on the batch it is in nor on the
+//     chunk length, which the host is free to choose for load balance (h2_plan_chunks).
 // =====================================================================================================
-constexpr int H2_CH = 12;      // groups per chunk (384 pixels = 6 statistics tiles): 904 chunks for 8 x 1080p, one per wave of 256 CUs
-// smaller chunks for the small levels (their few chunks would otherwise be the longest-running work items of the launch);
-// a function of the level geometry only -> the statistics of an image stay independent of the batch.  8 x 1080p:
-// (85 + 22 + 8 + 4 + 2) chunks per image = 968 chunks = 242 work items on 256 CUs.
-__host__ __device__ inline int h2_chunk_groups(int gpi) { return gpi >= 128 ? H2_CH : (gpi >= 32 ? 8 : 4); }
+constexpr int H2_CH = 12;      // longest chunk (384 pixels): 904 chunks for 8 x 1080p, one per wave of 256 CUs
+// Chunk length per level.  Every chunk pays ~9 k cycles of per-image filter setup, a 32-pixel group costs ~7 k:
+// long chunks amortise the setup, short ones fill the chip when the batch is small (1 x 1080p has 1353 groups:
+// 12-group chunks would keep 31 of 256 CUs busy).  Target: about one chunk per wave of the chip (1024), at most
+// H2_CH groups; the small levels get shorter chunks (their few chunks would otherwise be the longest-running
+// work items of the launch).  8 x 1080p: (85 + 22 + 8 + 4 + 2) chunks per image = 968 chunks = 242 work items.
+inline void h2_plan_chunks(int n, int nlev, const int* gpi, int* chg) {
+  static const int forced = [] { const char* e = getenv("LFD_H2_CHUNK"); return e ? atoi(e) : 0; }();   // tests: any even value
+  long total = 0;
+  for (int j = 0; j < nlev; ++j) total += (long)gpi[j] * n;
+  int c = 2 * (int)((total + 2047) / 2048);
+  c = c < 2 ? 2 : (c > H2_CH ? H2_CH : c);
+  if (forced >= 2) c = forced & ~1;
+  for (int j = 0; j < nlev; ++j) {
+    const int cap = gpi[j] >= 128 ? H2_CH : (gpi[j] >= 32 ? 8 : 4);
+    chg[j] = (forced >= 2 || c < cap) ? c : cap;
+  }
+}
 
 __device__ __forceinline__ uint32_t h2_cvt_pk(float x, float y) {
   lfd_f32x2 f; f[0] = x; f[1] = y;
@@ -506,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
         scale = L.scale ? L.scale[0] : 1.f;
       }
     }
-    const int gpi = a.grp_gpi[j], chg = h2_chunk_groups(gpi), cpi = (gpi + chg - 1) / chg;
+    const int gpi = a.grp_gpi[j], chg = a.h2_chg[j], cpi = (gpi + chg - 1) / chg;
     const int c = (item - a.h2_item_start[j]) * 4 + wave;
     const bool have_chunk = c < cpi * a.N;
     const int n = have_chunk ? c / cpi : 0, ci = c - n * cpi;
@@ -686,24 +726,28 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
           }
         }
       }
-    }
-    H2_T(16);
-    // ---- chunk statistics: reduce over the 64 lanes, one writer per (chunk, group) slot = the slot of the chunk's
-    //      first 64-pixel tile (H2_CH is even, so chunks start on tile boundaries; k_gn_finalize reads every
-    //      H2_CH/2-th slot of these levels)
-    if constexpr (PASS < 3) {
-      const int gg = 1 << (a.gshift - 3);      // 8-channel blocks per GroupNorm group
-      float* dst = a.part + ((size_t)L.tile_start + (size_t)n * L.tiles_per_img + (g0 >> 1)) * (HC >> a.gshift) * 2;
-      float x = 0.f, xx = 0.f;
+      // ---- statistics tile complete (second group of the tile, or the image's last group): transpose-reduce the
+      //      32 per-lane sums over the 64 lanes and write the tile's slot (chunks start on tile boundaries: g0 even)
+      if constexpr (PASS < 3) {
+        if (((g - g0) & 1) || g + 1 == g1) {
+          float v[32];
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        x += wave_sum_lane63(SW == 2 ? s[2 * b] + s[2 * b + 1] : s[b]); xx += wave_sum_lane63(SW == 2 ? ss[2 * b] + ss[2 * b + 1] : ss[b]);
-        if (((b + 1) & (gg - 1)) == 0) {
-          if (lane == 63) *reinterpret_cast<float2*>(dst + (b / gg) * 2) = make_float2(x, xx);
-          x = 0.f; xx = 0.f;
+          for (int b = 0; b < 16; ++b) {
+            v[2 * b] = SW == 2 ? s[2 * b] + s[2 * b + 1] : s[b];
+            v[2 * b + 1] = SW == 2 ? ss[2 * b] + ss[2 * b + 1] : ss[b];
+          }
+          const float tot = wave_sum_transpose32(v, lane);      // lane l (and l + 32): total of v[l & 31]
+          const int gg = 1 << (a.gshift - 3);                   // 8-channel blocks per GroupNorm group
+          float r = tot;
+          for (int m = 1; m < gg; m <<= 1) r += __shfl_xor(r, 2 * m, 64);
+          float* dst = a.part + ((size_t)L.tile_start + (size_t)n * L.tiles_per_img + (g >> 1)) * (HC >> a.gshift) * 2;
+          if (lane < 32 && (((lane >> 1) & (gg - 1)) == 0)) dst[((lane >> 1) >> (a.gshift - 3)) * 2 + (lane & 1)] = r;
+#pragma unroll
+          for (int i = 0; i < 16 * SW; ++i) { s[i] = 0.f; ss[i] = 0.f; }
         }
       }
     }
+    H2_T(16);
     H2_T(17);
   }
 }
@@ -736,7 +780,7 @@ int launch_head2(const HeadArgs& a, hipStream_t st) {
 // per (level, image, group): combine tile partials in fp64 (fixed order), emit per-channel (scale, shift)
 struct FinalizeArgs {
   int tile_start[LFD_MAX_LEVELS], tiles_per_img[LFD_MAX_LEVELS], hw[LFD_MAX_LEVELS];
-  int tile_stride[LFD_MAX_LEVELS];   // 1, or H2_CH / 2 for levels whose partials come from k_head2 (one slot per chunk)
+  int tile_stride[LFD_MAX_LEVELS];   // 1 (every 64-pixel tile has its own slot)
   const float* gamma[LFD_MAX_LEVELS];
   const float* beta[LFD_MAX_LEVELS];
   const float* part;
@@ -830,12 +874,6 @@ static bool head2_enabled() {
   static const int use_head2 = [] { const char* e = getenv("LFD_HEAD2"); return e ? atoi(e) : 1; }();
   return use_head2 != 0;
 }
-static bool head2_level(const lfd_head_desc_t* d, int i) {
-  const int gsize = d->num_groups > 0 ? HC / d->num_groups : 0;
-  (void)i;
-  return head2_enabled() && gsize >= 8;
-}
-
 int fill_levels(const lfd_head_desc_t* d, int* tile_start, int* tiles_per_img, int* ntiles) {
   if (!d || d->num_levels < 1 || d->num_levels > LFD_MAX_LEVELS || d->n < 1) return LFD_ERR_INVALID_ARGUMENT;
   int t = 0;
@@ -903,16 +941,16 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
   if (pass == 3 && (ft < 1 || ft > 2)) return LFD_ERR_UNSUPPORTED;
   if (pass < 1 || pass > 3) return LFD_ERR_INVALID_ARGUMENT;
   if (head2_enabled() && gshift >= 3) {
-    // wave-per-32-pixels kernel, all levels in one launch: work items = 4 consecutive chunks (H2_CH groups of 32
-    // pixels) of one level
+    // wave-per-32-pixels kernel, all levels in one launch: work items = 4 consecutive chunks of one level
     a.grp_n = 0;
     a.h2_nitems = 0;
     for (int i = 0; i < d->num_levels; ++i) {
-      const int j = a.grp_n++;
-      a.grp_levels[j] = i;
-      a.grp_gpi[j] = (d->level_hw[i] + 31) / 32;
-      const int chg = h2_chunk_groups(a.grp_gpi[j]);
-      const int cpi = (a.grp_gpi[j] + chg - 1) / chg;
+      a.grp_levels[a.grp_n] = i;
+      a.grp_gpi[a.grp_n++] = (d->level_hw[i] + 31) / 32;
+    }
+    h2_plan_chunks(d->n, a.grp_n, a.grp_gpi, a.h2_chg);
+    for (int j = 0; j < a.grp_n; ++j) {
+      const int cpi = (a.grp_gpi[j] + a.h2_chg[j] - 1) / a.h2_chg[j];
       a.h2_item_start[j] = a.h2_nitems;
       a.h2_nitems += (cpi * d->n + 3) / 4;
     }
@@ -950,7 +988,7 @@ int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const
   for (int i = 0; i < d->num_levels; ++i) {
     if (!gamma[i] || !beta[i]) return LFD_ERR_INVALID_ARGUMENT;
     f.hw[i] = d->level_hw[i]; f.gamma[i] = gamma[i]; f.beta[i] = beta[i];
-    f.tile_stride[i] = head2_level(d, i) ? h2_chunk_groups((d->level_hw[i] + 31) / 32) / 2 : 1;
+    f.tile_stride[i] = 1;
   }
   f.part = partial; f.ab = ab; f.N = d->n; f.ngroups = d->num_groups; f.gsize = HC / d->num_groups; f.eps = eps;
   hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels), dim3(256), 0, st, f);

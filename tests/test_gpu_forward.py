@@ -136,6 +136,29 @@ def test_full_size_properties_1080p():
     assert torch.equal(c1[0], cls[5]) and torch.equal(r1[0], reg[5])
 
 
+def test_head_chunk_length_does_not_change_outputs():
+    """k_head2's work-chunk length is a load-balance knob chosen from the batch size (h2_plan_chunks, csrc/head.hip).
+    GroupNorm partial sums are kept per 64-pixel statistics tile whatever the chunk, so every even chunk length must
+    give bit-identical logits (LFD_H2_CHUNK forces one; it is read once per process -> subprocesses)."""
+    import hashlib, os, subprocess, sys
+    code = (
+        "import sys, hashlib, torch; sys.path[:0] = [%r, %r]\n"
+        "from lfd_amd import configs\n"
+        "m = configs.build_model('WIDERFACE_LFD_S'); configs.perturb_weights(m); m.eval().cuda()\n"
+        "x = (torch.rand(3, 360, 648, 3, generator=torch.Generator().manual_seed(3)) * 2 - 1).half().cuda()\n"
+        "with torch.no_grad(): c, r = m.forward_resident(x)\n"
+        "print('HASH', hashlib.sha256(c.cpu().numpy().tobytes() + r.cpu().numpy().tobytes()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lfd-a-light-and-fast-detector_amd'))
+    hashes = {}
+    for chunk in (0, 2, 6, 12):
+        env = dict(os.environ, LFD_H2_CHUNK=str(chunk))
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes[chunk] = [l for l in out.stdout.splitlines() if l.startswith('HASH')][-1]
+    assert len(set(hashes.values())) == 1, hashes
+
+
 def test_config3_widerface_l_4k_properties():
     """BASELINE config 3: WIDERFACE_LFD_L, one 3840x2160 frame (P = 690,600; the stride-4 level is
     540x960x128).  Properties: shapes, finiteness, and the top-left 1080p crop agrees with running the
