@@ -15,6 +15,7 @@
 //   -> fp16 -> mid1[slot(iy,ix)] (zero outside the intermediate image = the 3x3's zero padding)
 // Phase B: identical to k_conv<C,3,2,NCT,true,true> (conv.hip) with its input tile = mid1.
 #include "common.h"
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -348,12 +349,13 @@ struct X2 {
   static constexpr int STG_BYTES = 4 * 32 * 128;
   static constexpr int OFF_MID = RAW_BYTES, OFF_STG = OFF_MID + MID_BYTES, OFF_B = OFF_STG + STG_BYTES;
   static constexpr int OFF_W4 = OFF_B + 4 * 64 * 4;            // conv4 filter (permuted fragments), 8 KB
-  static constexpr int OFF_DUMMY = OFF_W4 + 8 * 1024;          // write target of the 23 lanes past the region's end
+  static constexpr int OFF_DUMMY = OFF_W4 + 8 * 1024;          // write target of lanes / groups past the region's end: [32 px][128 B]
   // per-thread constant tables (with one wave per SIMD every dependent VALU instruction costs ~8 cycles and nothing
   // else is there to hide it: a 16-byte LDS read replaces the 20-30 instruction chains that rebuild these values)
-  static constexpr int OFF_TCH = OFF_DUMMY + 64 * 16;          // [4 chunks][256 threads] int4 {row, first half, byte offset, drift}
+  static constexpr int OFF_TCH = OFF_DUMMY + 32 * 128;         // [4 chunks][256 threads] int4 {row, first half, byte offset, drift}
   static constexpr int OFF_TXO = OFF_TCH + 4 * 256 * 16;       // [3 taps][256 threads] int4: phase-B read offsets
-  static constexpr int LDS_BYTES = OFF_TXO + 3 * 256 * 16;
+  static constexpr int OFF_WB4 = OFF_TXO + 3 * 256 * 16;       // conv3 / conv4 bias k-step fragments [4][64]
+  static constexpr int LDS_BYTES = OFF_WB4 + 4 * 64 * 16;
 };
 
 #ifdef LFD_X2_TIMING
@@ -399,7 +401,12 @@ __device__ __forceinline__ half8 relu8(const f32x16& acc, int half) {
 // U8: the frame is NHWC uint8 and simple_normalize ((x/255 - 0.5)/0.5, augmentation_pipeline.py:31-36) is applied while the
 // raw tile is staged: the LDS image is the one the fp16 path builds for a frame at a 16-byte aligned (virtual) address, so
 // everything after the staging is shared.
-template <bool U8>
+// ALN: the frame's rows are 16-byte aligned (W % 8 == 0, 16-byte aligned base: every video format): all rows of all
+// tiles have the same sub-chunk misalignment (14 bytes: tiles start 3 pixels = 18 bytes left of a 128-pixel boundary),
+// so the realignment shift, the LDS read offsets and the global addresses of a tile's chunks are compile-time / per-thread
+// constants instead of ~90 instructions per chunk -- with one wave per SIMD nothing hides them (fetch + store of the raw
+// tile were 2.4 k of the 14.3 k cycles of a tile).
+template <bool U8, bool ALN>
 __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_raw = smem;
@@ -450,13 +457,23 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   //      element is 1.0 and whose A element is the bias, split hi + lo in fp16 (exact to ~2^-22 relative).
   //      conv1 has 5 unused K slots (27 -> 32): slots 27, 28 = elements 3, 4 of k-step 1, lane half 1.
   //      conv2 gets a fifth k-step whose B fragment is {1, 1, 0, ...} in lane half 0.
+  //      conv3 / conv4: the same (one extra MFMA instead of 16 LDS-fed register moves per accumulator).
   half8 wb2[2];
+  half8* s_wb4 = reinterpret_cast<half8*>(smem + X2::OFF_WB4);   // [4][64]: conv3 c0, c1, conv4 c0, c1
   {
     const int m = lane & 31, hk = lane >> 5;
     const int g = m >> 3, hm = (m >> 2) & 1, j = m & 3;
     const int row = 16 * (g >> 1) + 8 * hm + 4 * (g & 1) + j;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+      const float b3v = a.b3[c * 32 + m], b4v = a.b4[c * 32 + row];
+      const _Float16 b3h = (_Float16)b3v, b3l = (_Float16)(b3v - (float)b3h);
+      const _Float16 b4h = (_Float16)b4v, b4l = (_Float16)(b4v - (float)b4h);
+      half8 f3, f4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { f3[e] = (_Float16)0.f; f4[e] = (_Float16)0.f; }
+      if (!hk) { f3[0] = b3h; f3[1] = b3l; f4[0] = b4h; f4[1] = b4l; }
+      if (wave == 0) { s_wb4[c * 64 + lane] = f3; s_wb4[(2 + c) * 64 + lane] = f4; }
       const float b1v = a.b1[c * 32 + m];
       const _Float16 b1h = (_Float16)b1v, b1l = (_Float16)(b1v - (float)b1h);
       if (hk) { w1r[c][1][3] = b1h; w1r[c][1][4] = b1l; }
@@ -479,22 +496,37 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   const int t_step = (nblk + 7 - xcd) / 8;
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const long rowbytes = (long)a.W * 6;
-  const int dsh = (int)(rowbytes & 15);          // change of a row's 16-byte misalignment from one row to the next
+  const int dsh = ALN ? 0 : (int)(rowbytes & 15);   // change of a row's 16-byte misalignment from one row to the next
 
   // ---- raw frame tile: 19 rows x 51 aligned chunks, chunk c = tid + 256u (row r = c / 51, i = c % 51)
   struct TileGeo { long rs0; int n, ty0, tx0, gyr0, gxr0, sh0; bool live; };
-  auto geo = [&](int t) {
+  // tile walk: (image, tile row, tile column) of tile t advance by the decomposed stride -- no divisions in the loop
+  struct Walk { int n, ty, tx; };
+  Walk w_first, w_cur;
+  {
+    const int t0 = t_begin + bix < a.ntiles ? t_begin + bix : 0;
+    w_first.n = t0 / tiles_per_img;
+    const int tr = t0 - w_first.n * tiles_per_img;
+    w_first.ty = tr / a.tiles_x; w_first.tx = tr - w_first.ty * a.tiles_x;
+    w_cur = w_first;
+  }
+  const int st_n = t_step / tiles_per_img, st_r = t_step - st_n * tiles_per_img;
+  const int st_y = st_r / a.tiles_x, st_x = st_r - st_y * a.tiles_x;
+  auto walk_advance = [&]() {
+    w_cur.tx += st_x; w_cur.ty += st_y; w_cur.n += st_n;
+    if (w_cur.tx >= a.tiles_x) { w_cur.tx -= a.tiles_x; ++w_cur.ty; }
+    if (w_cur.ty >= a.tiles_y) { w_cur.ty -= a.tiles_y; ++w_cur.n; }
+  };
+  auto geo = [&](int t) {       // t must be the tile w_cur stands on
     TileGeo g;
     g.live = t < t_end;
-    const int tt = g.live ? t : t_begin;
-    g.n = tt / tiles_per_img;
-    const int tr = tt - g.n * tiles_per_img;
-    g.ty0 = tr / a.tiles_x; g.tx0 = tr - g.ty0 * a.tiles_x;
+    const Walk wk = g.live ? w_cur : w_first;      // past the end: any valid tile (its loads are discarded)
+    g.n = wk.n; g.ty0 = wk.ty; g.tx0 = wk.tx;
     g.gyr0 = 4 * g.ty0 * X2::TH - 3; g.gxr0 = 4 * g.tx0 * X2::TW - 3;   // raw origin = 2 * (2 * out - 1) - 1
     // byte address of raw pixel (gyr0, gxr0): outside the frame for border tiles -- only its low bits and
     // rows / chunks that are inside the frame are ever used
     g.rs0 = (U8 ? 0L : (long)reinterpret_cast<uintptr_t>(a.in)) + (((long)g.n * a.H + g.gyr0) * a.W + g.gxr0) * 6;
-    g.sh0 = (int)(g.rs0 & 15);
+    g.sh0 = ALN ? 14 : (int)(g.rs0 & 15);
     return g;
   };
   // this thread's four chunks: c = tid + 256u -> row r = c / 51, chunk i = c % 51.  Recomputed where needed
@@ -506,7 +538,8 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
       const int c = threadIdx.x + 256 * u;
       const int r = c / X2::NCH, i = c - r * X2::NCH;
       int4 k;
-      k.x = c < X2::NCHUNK ? r : -1; k.y = 8 * i; k.z = r * (int)rowbytes + 16 * i; k.w = (r * dsh) & 15;
+      k.x = c < X2::NCHUNK ? r : -1; k.y = 8 * i; k.z = c < X2::NCHUNK ? r * (int)rowbytes + 16 * i : 0;
+      k.w = ALN ? (c < X2::NCHUNK ? r * X2::RSB + 16 * i : 0) : (r * dsh) & 15;     // ALN: LDS address of the chunk
       reinterpret_cast<int4*>(smem + X2::OFF_TCH)[u * 256 + threadIdx.x] = k;
     }
     // phase-B LDS read offsets: lane pix = output column; tap column s reads intermediate column 2*pix + s, i.e.
@@ -533,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   // chunk (row r, i) holds halfs [e0, e0 + 8) of the row, counted from column gxr0 (e0 = 8i - sh/2), the dword in
   // front of it ends with half e0 - 1.  okv / okp: the chunk / that half has something inside the frame.
   auto chunk_ok = [&](const TileGeo& g, const Chunk& k, int& e0, int& elo, int& ehi, bool& okp) {
-    const int shr = (g.sh0 + k.rd) & 15;
+    const int shr = ALN ? 14 : (g.sh0 + k.rd) & 15;
     e0 = k.e - (shr >> 1);
     elo = (g.gxr0 < 0 ? -g.gxr0 : 0) * 3;
     ehi = ((a.W - g.gxr0) < X2::RW ? (a.W - g.gxr0) : X2::RW) * 3;
@@ -559,7 +592,18 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   const long u8_last = U8 ? (((long)a.N * a.H * a.W * 3 - 1) & ~3L) : 0;
   auto raw_fetch1 = [&](const TileGeo& g, bool inner, int u) {
     const Chunk k = chunk_of(u);
-    const int shr = (g.sh0 + k.rd) & 15;
+    const int shr = ALN ? 14 : (g.sh0 + k.rd) & 15;
+    if constexpr (ALN && !U8) {
+      if (inner) {
+        // scalar tile base + per-thread constant 32-bit offset (the table holds offset 0 for the chunks past the end)
+        const char* tb = reinterpret_cast<const char*>(g.rs0 - 14);
+        const char* src = tb + (uint32_t)k.off;
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(src));
+        rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
+        rawp[u] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(reinterpret_cast<uintptr_t>(src - 4));
+        return;
+      }
+    }
     if constexpr (U8) {
       long b = (g.rs0 + (k.off - shr)) / 2 - 1;             // byte offset of the byte in front of the chunk
       bool ok = true;
@@ -635,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     uint4 v = v0;
     uint32_t prev = prev0;
     if constexpr (U8) u8_expand(v0, v, prev);
-    const int shr_s = (g.sh0 + k.rd) & 15;
+    const int shr_s = ALN ? 14 : (g.sh0 + k.rd) & 15;
     u32x4 o;
     if (shr_s & 2) {
       o[0] = __builtin_amdgcn_alignbit(v.x, prev, 16); o[1] = __builtin_amdgcn_alignbit(v.y, v.x, 16);
@@ -643,7 +687,8 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     } else {
       o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
-    *reinterpret_cast<u32x4*>(s_raw + (k.r < 0 ? 0 : k.r) * X2::RSB + 2 * k.e) = o;
+    if constexpr (ALN) *reinterpret_cast<u32x4*>(s_raw + k.rd) = o;
+    else *reinterpret_cast<u32x4*>(s_raw + (k.r < 0 ? 0 : k.r) * X2::RSB + 2 * k.e) = o;
   };
   auto raw_store = [&](const TileGeo& g) {
     if (interior(g)) {
@@ -667,7 +712,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
           const uint32_t pv = okp ? px : 0u;
           // after the (optional) one-half shift position kk of the chunk holds half e0s + kk of the row: zero the
           // ones that belong to out-of-frame columns
-          const int shr_s = (g.sh0 + k.rd) & 15;
+          const int shr_s = ALN ? 14 : (g.sh0 + k.rd) & 15;
           const int e0s = e0 - ((shr_s >> 1) & 1);
           u32x4 o;
           if (shr_s & 2) {
@@ -720,97 +765,127 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   for (; t < t_end; t += t_step, ++itn) {
     X2_T(0);
     const int gy1_0 = 2 * g_cur.ty0 * X2::TH - 1, gx1_0 = 2 * g_cur.tx0 * X2::TW - 1;   // intermediate-image origin
-    const int sh0 = g_cur.sh0;
+    const int sh0 = ALN ? 14 : g_cur.sh0;
     __syncthreads();   // raw tile of this tile is in LDS; every wave is done reading the previous intermediate tile
     X2_T(1);
 
     // ================= phase A: raw -> conv1 -> conv2 -> intermediate tile (all in this wave) =================
     // Group -> pixels: groups 0..17 are the two 32-column halves of the nine rows (row = grp >> 1 is wave-uniform,
     // so nearly all of the address arithmetic is scalar); group 18 is the left-over 65th column (9 pixels).
-    auto s_addr_px = [&](Grp& G, int my, int mx, bool inreg) {
-      const int r0 = 2 * my;
-      const int shb = sh0 + r0 * dsh;
-      const int a0 = r0 * X2::RSB + 12 * mx;
-      const int s0 = shb & 15, s1 = (shb + dsh) & 15, s2 = (shb + 2 * dsh) & 15;
-      G.A0 = a0 + s0 + (s0 & 2); G.A1 = a0 + X2::RSB + s1 + (s1 & 2); G.A2 = a0 + 2 * X2::RSB + s2 + (s2 & 2);   // dword aligned
-      const int gy1 = gy1_0 + my, gx1 = gx1_0 + mx;
-      G.vmask = (gy1 >= 0 && gy1 < a.H1 && gx1 >= 0 && gx1 < a.W1) ? 0xffffffffu : 0u;
-      const int rem = (mx & 1) * X2::IWh + (mx >> 1);
-      G.fk = inreg ? (rem >> 1) & 7 : 0;
-      G.dst = inreg ? X2::OFF_MID + (my * X2::IWs + rem) * 128 : X2::OFF_DUMMY;
-    };
-    auto s_addr = [&](Grp& G, int grp) {          // grp < 18, wave-uniform
-      s_addr_px(G, grp >> 1, ((grp & 1) << 5) + pix, true);
-    };
-    auto s_addr_last = [&](Grp& G) {              // group 18: column 64, row = lane
-      s_addr_px(G, pix < X2::IH ? pix : X2::IH - 1, X2::IW - 1, pix < X2::IH);
-    };
-    // im2col: k-step 0 = {h0: row0 e0..7 | h1: row1 e0..7}, k-step 1 = {h0: row2 e0..7 | h1: row0 e8, row1 e8,
-    // row2 e8, 0 x5}, e = 3 * s + c (pack_stem_weight).  Both halves execute both variants and select.
-    auto s_load = [&](Grp& G) {
-      // every lane issues the same four reads (addresses differ by lane half) -- no load sits behind a condition,
-      // so the compiler keeps this straight-line and can interleave two groups
-      union { half8 v; uint32_t u[4]; } f0, f1;
-      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A1 : G.A0));
-      f0.u[0] = p0[0]; f0.u[1] = p0[1]; f0.u[2] = p0[2]; f0.u[3] = p0[3];
-      const uint32_t* px = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A0 + 16 : G.A2));   // h0: row2 e0..7 | h1: row0 e8 (+7 unused)
-      const uint32_t x0 = px[0], x1 = px[1], x2 = px[2], x3 = px[3];
-      const uint32_t y1 = *reinterpret_cast<const uint32_t*>(s_raw + G.A1 + 16);                 // row1 e8 (low half)
-      const uint32_t y2 = *reinterpret_cast<const uint32_t*>(s_raw + G.A2 + 16);                 // row2 e8 (low half)
-      f1.u[0] = hh ? ((x0 & 0xffffu) | (y1 << 16)) : x0;
-      f1.u[1] = hh ? ((y2 & 0xffffu) | 0x3c000000u) : x1;   // element 3 = 1.0: bias slot (hi)
-      f1.u[2] = hh ? 0x00003c00u : x2;                      // element 4 = 1.0: bias slot (lo)
-      f1.u[3] = hh ? 0u : x3;
-      G.f0 = f0.v; G.f1 = f1.v;
-    };
-    auto s_conv1 = [&](Grp& G) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][0], G.f0, zero, 0, 0, 0);
-        G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][1], G.f1, G.acc[c], 0, 0, 0);
-      }
-    };
-    auto s_relu1 = [&](Grp& G) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) { G.bq[2 * c] = relu8(G.acc[c], 0); G.bq[2 * c + 1] = relu8(G.acc[c], 1); }
-    };
-    auto s_conv2 = [&](Grp& G) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb2[c], ones, zero, 0, 0, 0);   // bias k-step
-#pragma unroll
-        for (int q = 0; q < 4; ++q) G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[c][q], G.bq[q], G.acc[c], 0, 0, 0);
-      }
-    };
-    auto s_write = [&](Grp& G) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          union { half8 v; uint32_t u[4]; } r;
-          r.v = relu8(G.acc[c], g2);
+    // MASKED = false: the whole 9 x 65 region lies inside the intermediate image (all tiles but the frame's border
+    // ones) -- no zero-padding mask to compute and apply (22 instructions per group)
+    auto phase_a = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // Group -> pixels: groups 0..17 are the two 32-column halves of the nine rows (row = grp >> 1 is wave-uniform,
+      // so nearly all of the address arithmetic is scalar); group 18 is the left-over 65th column (9 pixels).
+      // Every wave runs FIVE groups: wave w has w, w+4, w+8, w+12, then 16 / 17 / 18 for waves 0 / 1 / 2 and a dummy
+      // (valid reads, results into the dummy area) for wave 3 -- the pipeline below is straight-line code.
+      auto s_addr_px = [&](Grp& G, int my, int mx, bool inreg) {
+        const int r0 = 2 * my;
+        const int shb = sh0 + r0 * dsh;
+        const int a0 = r0 * X2::RSB + 12 * mx;
+        const int s0 = shb & 15, s1 = (shb + dsh) & 15, s2 = (shb + 2 * dsh) & 15;
+        G.A0 = a0 + s0 + (s0 & 2); G.A1 = a0 + X2::RSB + s1 + (s1 & 2); G.A2 = a0 + 2 * X2::RSB + s2 + (s2 & 2);   // dword aligned
+        const int gy1 = gy1_0 + my, gx1 = gx1_0 + mx;
+        G.vmask = (!MASKED || (gy1 >= 0 && gy1 < a.H1 && gx1 >= 0 && gx1 < a.W1)) ? 0xffffffffu : 0u;
+        const int rem = (mx & 1) * X2::IWh + (mx >> 1);
+        G.fk = inreg ? (rem >> 1) & 7 : 0;
+        G.dst = inreg ? X2::OFF_MID + (my * X2::IWs + rem) * 128 : X2::OFF_DUMMY + pix * 128;
+      };
+      auto s_addr_k = [&](Grp& G, int k) {
+        if (k < 4) {                               // wave-uniform row / half
+          const int grp = wave + 4 * k;
+          s_addr_px(G, grp >> 1, ((grp & 1) << 5) + pix, true);
+        } else {                                   // selects, no branches
+          const int my = wave < 2 ? X2::IH - 1 : (wave == 2 ? (pix < X2::IH ? pix : X2::IH - 1) : 0);
+          const int mx = wave < 2 ? (wave << 5) + pix : (wave == 2 ? X2::IW - 1 : pix);
+          s_addr_px(G, my, mx, wave < 2 || (wave == 2 && pix < X2::IH));
+        }
+      };
+      // im2col: k-step 0 = {h0: row0 e0..7 | h1: row1 e0..7}, k-step 1 = {h0: row2 e0..7 | h1: row0 e8, row1 e8,
+      // row2 e8, 1, 1(bias slots), 0 x3}, e = 3 * s + c (pack_stem_weight).  Every lane issues the same reads
+      // (addresses differ by lane half); issue and use are separate steps of the pipeline.
+      struct Raw { uint32_t f[4], x[4], y1, y2; };
+      auto s_load_issue = [&](const Grp& G, Raw& R) {
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A1 : G.A0));
+        R.f[0] = p0[0]; R.f[1] = p0[1]; R.f[2] = p0[2]; R.f[3] = p0[3];
+        const uint32_t* px = reinterpret_cast<const uint32_t*>(s_raw + (hh ? G.A0 + 16 : G.A2));   // h0: row2 e0..7 | h1: row0 e8 (+7 unused)
+        R.x[0] = px[0]; R.x[1] = px[1]; R.x[2] = px[2]; R.x[3] = px[3];
+        R.y1 = *reinterpret_cast<const uint32_t*>(s_raw + G.A1 + 16);                               // row1 e8 (low half)
+        R.y2 = *reinterpret_cast<const uint32_t*>(s_raw + G.A2 + 16);                               // row2 e8 (low half)
+      };
+      auto s_load_finish = [&](Grp& G, const Raw& R) {
+        union { half8 v; uint32_t u[4]; } f0, f1;
+        f0.u[0] = R.f[0]; f0.u[1] = R.f[1]; f0.u[2] = R.f[2]; f0.u[3] = R.f[3];
+        f1.u[0] = hh ? ((R.x[0] & 0xffffu) | (R.y1 << 16)) : R.x[0];
+        f1.u[1] = hh ? ((R.y2 & 0xffffu) | 0x3c000000u) : R.x[1];   // element 3 = 1.0: bias slot (hi)
+        f1.u[2] = hh ? 0x00003c00u : R.x[2];                        // element 4 = 1.0: bias slot (lo)
+        f1.u[3] = hh ? 0u : R.x[3];
+        G.f0 = f0.v; G.f1 = f1.v;
+      };
+      // the four stages, one MFMA / one 8-channel octet at a time
+      auto conv1_m = [&](Grp& G, int i) {          // i = 0..3: cout tile i >> 1, k-step i & 1
+        const int c = i >> 1;
+        if ((i & 1) == 0) G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][0], G.f0, zero, 0, 0, 0);
+        else G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][1], G.f1, G.acc[c], 0, 0, 0);
+      };
+      auto relu1_o = [&](Grp& G, int o) { G.bq[o] = relu8(G.acc[o >> 1], o & 1); };   // o = 0..3
+      auto conv2_m = [&](Grp& G, int i) {          // i = 0..9: cout tile i / 5; step 0 = bias k-step
+        const int c = i / 5, q = i % 5;
+        if (q == 0) G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb2[c], ones, zero, 0, 0, 0);
+        else G.acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2r[c][q - 1], G.bq[q - 1], G.acc[c], 0, 0, 0);
+      };
+      auto write_o = [&](Grp& G, int o) {          // o = 0..3: 16-byte chunk 2o + hh of the pixel's line
+        union { half8 v; uint32_t u[4]; } r;
+        r.v = relu8(G.acc[o >> 1], o & 1);
+        if constexpr (MASKED) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) r.u[e] &= G.vmask;   // pixels outside the intermediate image = conv3's zero padding
-          *reinterpret_cast<half8*>(smem + G.dst + (((4 * c + 2 * g2 + hh) ^ G.fk) * 16)) = r.v;
         }
-    };
-#pragma unroll 1
-    for (int gp = 0; gp < 2; ++gp) {          // groups (w, w+4) and (w+8, w+12): every wave has all four
-      Grp GA, GB;
-      s_addr(GA, wave + 8 * gp); s_addr(GB, wave + 8 * gp + 4);
-      s_load(GA); s_load(GB);
-      s_conv1(GA); s_conv1(GB);
-      s_relu1(GA); s_relu1(GB);
-      s_conv2(GA); s_conv2(GB);
-      s_write(GA); s_write(GB);
-    }
-    if (wave < 3) {                           // groups 16, 17 (row 8) and the left-over column: waves 0, 1, 2
-      Grp GA;
-      if (wave < 2) s_addr(GA, wave + 16); else s_addr_last(GA);
-      s_load(GA); s_conv1(GA); s_relu1(GA); s_conv2(GA); s_write(GA);
-    }
+        *reinterpret_cast<half8*>(smem + G.dst + (((2 * o + hh) ^ G.fk) * 16)) = r.v;
+      };
+      // ---- software pipeline over the five groups.  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles and the
+      //      wave can issue ~7 independent VALU instructions in its shadow -- but only if they are THERE: the stages
+      //      of one group depend on each other (conv1 -> ReLU/pack -> conv2 -> ReLU/pack/store), so each step pairs
+      //      the MFMAs of one group with the VALU work of another (left to itself the compiler emits all of conv2's
+      //      MFMAs back to back and then 70 VALU instructions with an idle matrix pipe: 1300 cycles per group).
+      //        step A_k: conv2(G_k)   [10 MFMA]  ||  ReLU1(G_k+1), im2col loads of G_k+2
+      //        step B_k: conv1(G_k+2) [ 4 MFMA]  ||  ReLU2 + store of G_k
+      //      sched_barrier(0) pins one {MFMA, VALU octet} slot after the other.
+#define X2_SB() __builtin_amdgcn_sched_barrier(0)
+      Grp G[5];
+      Raw R[2];
+      s_addr_k(G[0], 0); s_load_issue(G[0], R[0]);
+      s_addr_k(G[1], 1); s_load_issue(G[1], R[1]);
+      s_load_finish(G[0], R[0]);
+      X2_SB();
+      conv1_m(G[0], 0); conv1_m(G[0], 1); X2_SB();
+      s_load_finish(G[1], R[1]); X2_SB();
+      conv1_m(G[0], 2); conv1_m(G[0], 3); X2_SB();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { conv1_m(G[1], i); X2_SB(); relu1_o(G[0], i); X2_SB(); }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        // step A_k
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          conv2_m(G[k], i); X2_SB();
+          if (i < 4 && k + 1 < 5) { relu1_o(G[k + 1], i); X2_SB(); }
+          if (i == 4 && k + 2 < 5) { s_addr_k(G[k + 2], k + 2); s_load_issue(G[k + 2], R[k & 1]); X2_SB(); }
+          if (i == 8 && k + 2 < 5) { s_load_finish(G[k + 2], R[k & 1]); X2_SB(); }
+        }
+        // step B_k
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (k + 2 < 5) { conv1_m(G[k + 2], i); X2_SB(); }
+          write_o(G[k], i); X2_SB();
+        }
+      }
+#undef X2_SB
+    };   // phase_a
+    if (gy1_0 >= 0 && gy1_0 + X2::IH <= a.H1 && gx1_0 >= 0 && gx1_0 + X2::IW <= a.W1) phase_a(std::false_type{});
+    else phase_a(std::true_type{});
     X2_T(2);
     __syncthreads();   // intermediate tile complete; raw tile consumed
     X2_T(3);
@@ -818,6 +893,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     // next tile's raw frame region: fetched now (registers), written to LDS at the end of this tile -- behind
     // the barrier above nobody reads the raw tile any more, and the round trip hides under phase B
     const TileGeo g_out = g_cur;
+    walk_advance();
     g_cur = geo(t + t_step);
     raw_fetch(g_cur);
 
@@ -829,14 +905,10 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
       xoff[s3][0] = k.x; xoff[s3][1] = k.y; xoff[s3][2] = k.z; xoff[s3][3] = k.w;
     }
     f32x16 acc3[2];
+    {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float* bp = s_b + 128 + c * 32 + 4 * hh;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
-        acc3[c][4 * g] = b4.x; acc3[c][4 * g + 1] = b4.y; acc3[c][4 * g + 2] = b4.z; acc3[c][4 * g + 3] = b4.w;
-      }
+      for (int c = 0; c < 2; ++c) acc3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb4[c * 64 + lane], ones, zero, 0, 0, 0);   // bias k-step
     }
     X2_T(4);
     auto xfrag = [&](int k) {
@@ -863,14 +935,8 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     for (int c = 0; c < 2; ++c) { bq[2 * c] = relu8(acc3[c], 0); bq[2 * c + 1] = relu8(acc3[c], 1); }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      f32x16 acc;
-      const float* bp = s_b + 192 + c * 32 + 8 * hh;
-#pragma unroll
-      for (int g2 = 0; g2 < 2; ++g2) {
-        const float4 ba = *reinterpret_cast<const float4*>(bp + 16 * g2), bb = *reinterpret_cast<const float4*>(bp + 16 * g2 + 4);
-        acc[8 * g2] = ba.x; acc[8 * g2 + 1] = ba.y; acc[8 * g2 + 2] = ba.z; acc[8 * g2 + 3] = ba.w;
-        acc[8 * g2 + 4] = bb.x; acc[8 * g2 + 5] = bb.y; acc[8 * g2 + 6] = bb.z; acc[8 * g2 + 7] = bb.w;
-      }
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb4[(2 + c) * 64 + lane], ones, zero, 0, 0, 0);   // bias k-step
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w4[(c * 4 + q) * 64 + lane], bq[q], acc, 0, 0, 0);
 #pragma unroll
@@ -912,7 +978,7 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_x2_timing(unsign
 namespace {
 #endif
 
-template <bool U8>
+template <bool U8, bool ALN>
 int launch_stem2x(FusedArgs a, hipStream_t st) {
   a.tiles_x = (a.W2 + X2::TW - 1) / X2::TW;
   a.tiles_y = (a.H2 + X2::TH - 1) / X2::TH;
@@ -921,7 +987,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   a.ntiles = (int)nt;
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem2x<U8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem2x<U8, ALN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             X2::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
@@ -929,7 +995,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   const int blocks = a.ntiles < 256 ? a.ntiles : 256;
   if (blocks < 1) return LFD_OK;
   { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg; }
-  hipLaunchKernelGGL(k_stem2x<U8>, dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_stem2x<U8, ALN>), dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -988,8 +1054,15 @@ int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int3
   a.H1 = (h - 1) / 2 + 1; a.W1 = (w - 1) / 2 + 1;
   a.H2 = (a.H1 - 1) / 2 + 1; a.W2 = (a.W1 - 1) / 2 + 1;
   static const int use_x2 = [] { const char* e = getenv("LFD_STEM2X"); return e ? atoi(e) : 1; }();
-  if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) return launch_stem2x<false>(a, st);
-  if (use_x2 && channels == 64 && in_format == IN_NHWC_U8) return launch_stem2x<true>(a, st);
+  // aligned rows: W % 8 == 0 pixels (16-byte row pitch in fp16 / in the virtual fp16 image of a uint8 frame) and, for
+  // fp16 frames, a 16-byte aligned base (LFD_X2_ALN=0 forces the general kernel: tests compare the two bit for bit)
+  static const int use_aln = [] { const char* e = getenv("LFD_X2_ALN"); return e ? atoi(e) : 1; }();
+  const bool aln = use_aln && (w % 8) == 0;
+  if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) {
+    if (aln && (reinterpret_cast<uintptr_t>(in) & 15) == 0) return launch_stem2x<false, true>(a, st);
+    return launch_stem2x<false, false>(a, st);
+  }
+  if (use_x2 && channels == 64 && in_format == IN_NHWC_U8) return aln ? launch_stem2x<true, true>(a, st) : launch_stem2x<true, false>(a, st);
   return channels == 64 ? dispatch_fmt<2>(in_format, a, st) : dispatch_fmt<1>(in_format, a, st);
 }
 

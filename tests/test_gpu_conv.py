@@ -189,6 +189,35 @@ def test_fused_stem_equals_two_kernel_stem(n, h, w):
     assert float((a - b).abs().mean()) < 1e-4     # almost all elements identical
 
 
+@pytest.mark.parametrize('n,h,w', [(1, 8, 8), (1, 19, 24), (1, 64, 96), (2, 135, 256), (3, 200, 312), (1, 1080, 1920)])
+def test_fused_stem_aligned_fast_path_equals_general_kernel(n, h, w):
+    """k_stem2x<ALN>: frames with 16-byte aligned rows (W % 8 == 0, aligned base) take a kernel whose raw-tile staging
+    has the realignment shift and the chunk addresses as constants; the same frame at a 2-byte-misaligned base takes
+    the general kernel.  Same arithmetic -> bit-identical outputs (interior and border tiles, tile walk included)."""
+    from lfd_amd._lib import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(h * 1000 + w + 7)
+    c = 64
+    ws = [(torch.randn(c, 3, 3, 3, generator=g) * 0.2), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5),
+          (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5), (torch.randn(c, c, 1, 1, generator=g) / c ** 0.5)]
+    bs = [(torch.randn(c, generator=g) * 0.1).cuda() for _ in range(4)]
+    packed = [engine.pack_stem_weight(ws[0]).cuda()] + [ops.pack_conv_weight(t).cuda() for t in ws[1:]]
+    x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half().cuda()
+    buf = torch.zeros(x.numel() + 64, dtype=torch.float16, device='cuda')
+    xm = buf[1:1 + x.numel()].view_as(x)
+    xm.copy_(x)
+    assert x.data_ptr() % 16 == 0 and xm.data_ptr() % 16 == 2
+    h2, w2 = ((h + 1) // 2 + 1) // 2, ((w + 1) // 2 + 1) // 2
+    outs = []
+    for t in (x, xm):
+        o = torch.full((n, h2, w2, c), float('nan'), dtype=torch.float16, device='cuda')
+        check(lib().lfd_stem_faster_fused_f16(ptr(t), 1, n, h, w, c, ptr(packed[0]), ptr(bs[0]), ptr(packed[1]), ptr(bs[1]),
+                                              ptr(packed[2]), ptr(bs[2]), ptr(packed[3]), ptr(bs[3]), ptr(o), stream_ptr()), 'fused')
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('n,h,w', [(1, 8, 8), (1, 19, 24), (2, 33, 57), (1, 64, 96), (3, 47, 130), (1, 270, 481), (2, 135, 256),
                                    (1, 1080, 1920), (2, 123, 341)])
 def test_fused_stem_uint8_frames_equal_normalised_fp16_frames(n, h, w):
