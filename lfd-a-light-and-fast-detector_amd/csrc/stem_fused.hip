@@ -355,7 +355,8 @@ struct X2 {
   static constexpr int OFF_TCH = OFF_DUMMY + 32 * 128;         // [4 chunks][256 threads] int4 {row, first half, byte offset, drift}
   static constexpr int OFF_TXO = OFF_TCH + 4 * 256 * 16;       // [3 taps][256 threads] int4: phase-B read offsets
   static constexpr int OFF_WB4 = OFF_TXO + 3 * 256 * 16;       // conv3 / conv4 bias k-step fragments [4][64]
-  static constexpr int LDS_BYTES = OFF_WB4 + 4 * 64 * 16;
+  static constexpr int OFF_W3T = OFF_WB4 + 4 * 64 * 16;        // conv3 filter, k-steps 34, 35 of both cout tiles
+  static constexpr int LDS_BYTES = OFF_W3T + 4 * 64 * 16;
 };
 
 #ifdef LFD_X2_TIMING
@@ -419,14 +420,22 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
 
   // ---- filters.  conv1 / conv3 in the standard order; the two 1x1s with permuted K (to consume the previous
   //      accumulator registers directly) and permuted rows (8 consecutive channels per lane).
-  half8 w1r[2][2], w2r[2][4], w3r[2][36];
+  // (the last W3L k-steps of conv3's filter live in LDS: 4 reads per tile buy back 16 registers -- with everything
+  //  resident the aligned-frame kernel was a handful of registers over 512 and spilled a filter fragment to scratch)
+  constexpr int W3L = 2, W3R = 36 - W3L;
+  half8 w1r[2][2], w2r[2][4], w3r[2][W3R];
+  half8* s_w3t = reinterpret_cast<half8*>(smem + X2::OFF_W3T);   // [2][W3L][64]
   half8* s_w4 = reinterpret_cast<half8*>(smem + X2::OFF_W4);   // [2][4][64]; only needed for 8 MFMAs per tile
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) w1r[c][k] = a.w1[(c * 2 + k) * 64 + lane];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) w3r[c][k] = a.w3[(c * 36 + k) * 64 + lane];
+    for (int k = 0; k < W3R; ++k) w3r[c][k] = a.w3[(c * 36 + k) * 64 + lane];
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < W3L; ++k) s_w3t[(c * W3L + k) * 64 + lane] = a.w3[(c * 36 + W3R + k) * 64 + lane];
+    }
   }
   {
     const int m = lane & 31, hk = lane >> 5;
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
       const int r = c / X2::NCH, i = c - r * X2::NCH;
       int4 k;
       k.x = c < X2::NCHUNK ? r : -1; k.y = 8 * i; k.z = c < X2::NCHUNK ? r * (int)rowbytes + 16 * i : 0;
-      k.w = ALN ? (c < X2::NCHUNK ? r * X2::RSB + 16 * i : 0) : (r * dsh) & 15;     // ALN: LDS address of the chunk
+      k.w = ALN ? (c < X2::NCHUNK ? r * X2::RSB + 16 * i : X2::OFF_DUMMY + 16 * (int)(threadIdx.x & 63)) : (r * dsh) & 15;   // ALN: LDS address of the chunk
       reinterpret_cast<int4*>(smem + X2::OFF_TCH)[u * 256 + threadIdx.x] = k;
     }
     // phase-B LDS read offsets: lane pix = output column; tap column s reads intermediate column 2*pix + s, i.e.
@@ -593,17 +602,6 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   auto raw_fetch1 = [&](const TileGeo& g, bool inner, int u) {
     const Chunk k = chunk_of(u);
     const int shr = ALN ? 14 : (g.sh0 + k.rd) & 15;
-    if constexpr (ALN && !U8) {
-      if (inner) {
-        // scalar tile base + per-thread constant 32-bit offset (the table holds offset 0 for the chunks past the end)
-        const char* tb = reinterpret_cast<const char*>(g.rs0 - 14);
-        const char* src = tb + (uint32_t)k.off;
-        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(src));
-        rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
-        rawp[u] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(reinterpret_cast<uintptr_t>(src - 4));
-        return;
-      }
-    }
     if constexpr (U8) {
       long b = (g.rs0 + (k.off - shr)) / 2 - 1;             // byte offset of the byte in front of the chunk
       bool ok = true;
@@ -668,6 +666,24 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   };
   auto raw_fetch = [&](const TileGeo& g) {
     const bool inner = interior(g);
+    if constexpr (ALN && !U8) {
+      if (inner) {
+        // one basic block: the four table reads first (one LDS round trip instead of four), then the eight loads from
+        // a scalar tile base + per-thread constant 32-bit offsets (offset 0 for the chunk slots past the region's end)
+        const char* tb = reinterpret_cast<const char*>(g.rs0 - 14);
+        uint32_t off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) off[u] = (uint32_t)reinterpret_cast<const int4*>(smem + X2::OFF_TCH)[u * 256 + threadIdx.x].z;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const char* src = tb + off[u];
+          const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(src));
+          rawv[u] = make_uint4(v[0], v[1], v[2], v[3]);
+          rawp[u] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(reinterpret_cast<uintptr_t>(src - 4));
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) raw_fetch1(g, inner, u);
   };
@@ -692,10 +708,22 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
   };
   auto raw_store = [&](const TileGeo& g) {
     if (interior(g)) {
+      if constexpr (ALN) {
+        // unconditional: the table sends the chunk slots past the region's end to the dummy area
+        int dst[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const Chunk k = chunk_of(u);
-        if (u < 3 || k.r >= 0) raw_put(g, k, rawv[u], rawp[u]);   // only the 4th chunk of a thread can be past the end (969 = 3*256 + 201)
+        for (int u = 0; u < 4; ++u) dst[u] = reinterpret_cast<const int4*>(smem + X2::OFF_TCH)[u * 256 + threadIdx.x].w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          Chunk k; k.r = 0; k.e = 0; k.off = 0; k.rd = dst[u];
+          raw_put(g, k, rawv[u], rawp[u]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const Chunk k = chunk_of(u);
+          if (u < 3 || k.r >= 0) raw_put(g, k, rawv[u], rawp[u]);   // only the 4th chunk of a thread can be past the end (969 = 3*256 + 201)
+        }
       }
     } else {
 #pragma unroll
@@ -893,17 +921,18 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     // next tile's raw frame region: fetched now (registers), written to LDS at the end of this tile -- behind
     // the barrier above nobody reads the raw tile any more, and the round trip hides under phase B
     const TileGeo g_out = g_cur;
-    walk_advance();
-    g_cur = geo(t + t_step);
-    raw_fetch(g_cur);
-
-    // ================= phase B: conv3 (3x3 s2, 64 -> 64) over the intermediate tile, this wave = output row =====
+    // phase-B read offsets: requested before the raw fetch so that their LDS round trip hides under its address work
     int xoff[3][4];
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
       const int4 k = reinterpret_cast<const int4*>(smem + X2::OFF_TXO)[s3 * 256 + threadIdx.x];
       xoff[s3][0] = k.x; xoff[s3][1] = k.y; xoff[s3][2] = k.z; xoff[s3][3] = k.w;
     }
+    walk_advance();
+    g_cur = geo(t + t_step);
+    raw_fetch(g_cur);
+
+    // ================= phase B: conv3 (3x3 s2, 64 -> 64) over the intermediate tile, this wave = output row =====
     f32x16 acc3[2];
     {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -917,14 +946,20 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
     };
     {
       constexpr int PD = 3;
-      half8 xq[PD + 1];
+      half8 xq[PD + 1], w3t[2][W3L];
 #pragma unroll
       for (int k = 0; k < PD; ++k) xq[k] = xfrag(k);
 #pragma unroll
       for (int k = 0; k < 36; ++k) {
         if (k + PD < 36) xq[(k + PD) % (PD + 1)] = xfrag(k + PD);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) acc3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3r[c][k], xq[k % (PD + 1)], acc3[c], 0, 0, 0);
+        for (int c = 0; c < 2; ++c) {
+          if (k == W3R - 8) {                     // the LDS-resident tail of the filter: requested eight k-steps ahead
+#pragma unroll
+            for (int kk = 0; kk < W3L; ++kk) w3t[c][kk] = s_w3t[(c * W3L + kk) * 64 + lane];
+          }
+          acc3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < W3R ? w3r[c][k < W3R ? k : 0] : w3t[c][k < W3R ? 0 : k - W3R], xq[k % (PD + 1)], acc3[c], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
