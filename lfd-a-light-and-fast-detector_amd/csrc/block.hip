@@ -452,7 +452,8 @@ extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const 
       return LFD_ERR_LAUNCH_FAILED;
     cus = c;
   }
-  int blocks = a.ntiles < cus ? a.ntiles : cus;      // one 512-thread workgroup per CU (LDS: 159.5 KB each)
+  // one 512-thread workgroup per CU (LDS: 159.5 KB each); small launches: one workgroup per tile of every XCD's range
+  int blocks = 8 * ((a.ntiles + 7) / 8) < cus ? 8 * ((a.ntiles + 7) / 8) : cus;
   hipLaunchKernelGGL(k_block64, dim3(blocks), dim3(512), BK::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;

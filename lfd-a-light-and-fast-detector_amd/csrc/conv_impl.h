@@ -622,8 +622,10 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
       return LFD_ERR_LAUNCH_FAILED;
     attr_done = true;
   }
+  // workgroup b works on XCD b % 8's contiguous tile range [xcd * ceil(ntiles / 8), ...): a small launch needs
+  // 8 * ceil(ntiles / 8) workgroups for every tile to have its own (17 tiles on 17 workgroups = two rounds on five XCDs)
   int blocks = 512 / cgroups;
-  if (blocks > a.ntiles) blocks = a.ntiles;
+  if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
   LFD_CHECK_LAUNCH();

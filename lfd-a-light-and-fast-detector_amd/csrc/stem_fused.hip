@@ -1027,7 +1027,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
-  const int blocks = a.ntiles < 256 ? a.ntiles : 256;
+  const int blocks = 8 * ((a.ntiles + 7) / 8) < 256 ? 8 * ((a.ntiles + 7) / 8) : 256;   // (XCD-contiguous tile ranges)
   if (blocks < 1) return LFD_OK;
   { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg; }
   hipLaunchKernelGGL((k_stem2x<U8, ALN>), dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
@@ -1050,7 +1050,7 @@ int launch_fused(FusedArgs a, hipStream_t st) {
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
-  int blocks = a.ntiles < 512 ? a.ntiles : 512;
+  int blocks = 8 * ((a.ntiles + 7) / 8) < 512 ? 8 * ((a.ntiles + 7) / 8) : 512;
   if (blocks < 1) return LFD_OK;
   hipLaunchKernelGGL((k_stem_fused<NCT, FMT>), dim3(blocks), dim3(256), F::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
