@@ -450,7 +450,13 @@ typedef struct lfd_head_level_ptrs {
   const void* wf_packed;   /* final conv (rows padded to a multiple of 32), packed */
   const float* bf;         /* final bias */
   const float* scale;      /* per-level Scale (device scalar) or NULL */
+  /* optional scratch, LFD_HEAD_FOLDED_HALFS halfs per image each ([n] images): tower conv 1 / 2 with the GroupNorm scale
+   * of (level, image) folded into the rows and the shift as a bias fragment, in the kernel's register layout -- written
+   * by lfd_groupnorm_finalize_fold(which = 1 / 2), read by passes 2-3 / pass 3.  NULL: every work chunk folds on its own. */
+  void* w1_folded;
+  void* w2_folded;
 } lfd_head_level_ptrs_t;
+#define LFD_HEAD_FOLDED_HALFS (4 * 9 * 64 * 8)
 
 LFD_API size_t lfd_head_partial_floats(const lfd_head_desc_t* desc);
 LFD_API int lfd_head_forward_f16(const lfd_head_desc_t* desc, int32_t pass,
@@ -462,6 +468,11 @@ LFD_API int lfd_head_forward_f16(const lfd_head_desc_t* desc, int32_t pass,
 LFD_API int lfd_groupnorm_finalize(const lfd_head_desc_t* desc, const float* partial,
                                    const float* const* gamma, const float* const* beta, float eps,
                                    float* ab, lfd_stream_t stream);
+/* the same, and -- for every level whose w{which}_folded is not NULL -- the folded copy of tower conv `which` (1 | 2)
+ * for each image (lfd_head_level_ptrs_t).  Same rounding as the in-kernel fold: fp16(fp32(w) * scale). */
+LFD_API int lfd_groupnorm_finalize_fold(const lfd_head_desc_t* desc, const float* partial,
+                                        const float* const* gamma, const float* const* beta, float eps, float* ab,
+                                        const lfd_head_level_ptrs_t* levels, int32_t which, lfd_stream_t stream);
 
 #ifdef __cplusplus
 }

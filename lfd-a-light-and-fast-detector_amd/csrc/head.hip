@@ -41,6 +41,8 @@ struct HeadLevel {
   const half8* wf;       // final conv   [FT][8][64]  (cout padded to FT*32)
   const float* bf;       // final bias   [FT*32]
   const float* scale;    // per-level Scale parameter (device scalar) or nullptr
+  const half8* w1f;      // [N][4][9][64] tower conv 1 / 2 with GroupNorm folded in (k_gn_finalize), K-permuted fragments,
+  const half8* w2f;      //               k-step 8 = the shift as a bias fragment; or nullptr (fold per work chunk)
   int cin, hw, p_off;    // tap channels, pixels per image, first point of the level
   int tile_start;        // first global tile of this level
   int tiles_per_img;
@@ -558,17 +560,33 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       const int m = lane & 31;
       const float* t1 = a.ab1 + ((size_t)l * a.N + n) * HC * 2;
       const float* t2 = a.ab2 + ((size_t)l * a.N + n) * HC * 2;
+      // (folded copies written once per (level, image) by k_gn_finalize: 36 plain 16-byte loads per filter instead of
+      //  ~600 instructions of permute + scale + round -- 9.8 k cycles per chunk, 40 % of a two-group chunk at batch 1)
+      const half8* f1 = (PASS >= 2 && L.w1f) ? L.w1f + (size_t)n * (4 * 9 * 64) : nullptr;
+      const half8* f2 = (PASS == 3 && L.w2f) ? L.w2f + (size_t)n * (4 * 9 * 64) : nullptr;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const float sc1 = PASS >= 2 ? t1[(ct * 32 + m) * 2] : 1.f;
+        if (f1) {
 #pragma unroll
-        for (int k = 0; k < NKH; ++k) w1[ct][k] = perm(L.w1, ct, k, sc1);
+          for (int k = 0; k < NKH; ++k) w1[ct][k] = f1[(ct * 9 + k) * 64 + lane];
+          s_wb[ct * 64 + lane] = f1[(ct * 9 + 8) * 64 + lane];
+        } else {
+          const float sc1 = PASS >= 2 ? t1[(ct * 32 + m) * 2] : 1.f;
+#pragma unroll
+          for (int k = 0; k < NKH; ++k) w1[ct][k] = perm(L.w1, ct, k, sc1);
+          if constexpr (PASS >= 2) s_wb[ct * 64 + lane] = bias_frag(t1[(ct * 32 + m) * 2 + 1]);
+        }
         if constexpr (PASS >= 2) {
-          s_wb[ct * 64 + lane] = bias_frag(t1[(ct * 32 + m) * 2 + 1]);
-          const float sc2 = PASS == 3 ? t2[(ct * 32 + m) * 2] : 1.f;
+          if (f2) {
 #pragma unroll
-          for (int k = 0; k < NKH; ++k) w2[ct][k] = perm(L.w2, ct, k, sc2);
-          if constexpr (PASS == 3) s_wb[(4 + ct) * 64 + lane] = bias_frag(t2[(ct * 32 + m) * 2 + 1]);
+            for (int k = 0; k < NKH; ++k) w2[ct][k] = f2[(ct * 9 + k) * 64 + lane];
+            s_wb[(4 + ct) * 64 + lane] = f2[(ct * 9 + 8) * 64 + lane];
+          } else {
+            const float sc2 = PASS == 3 ? t2[(ct * 32 + m) * 2] : 1.f;
+#pragma unroll
+            for (int k = 0; k < NKH; ++k) w2[ct][k] = perm(L.w2, ct, k, sc2);
+            if constexpr (PASS == 3) s_wb[(4 + ct) * 64 + lane] = bias_frag(t2[(ct * 32 + m) * 2 + 1]);
+          }
         }
       }
     }
@@ -787,6 +805,8 @@ struct FinalizeArgs {
   float* ab;   // [L][N][128][2]
   int N, ngroups, gsize;
   float eps;
+  const _Float16* wsrc[LFD_MAX_LEVELS];   // fold: packed tower conv (standard layout) of each level, or nullptr
+  half8* wdst[LFD_MAX_LEVELS];            //       [N][4][9][64] folded, K-permuted fragments (see k_head2)
 };
 
 __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
@@ -794,6 +814,7 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
   // [tiles][ngroups*2] partial rows (ngroups*2 <= 256/8 ... handled by looping v): coalesced row
   // reads, 8 tile lanes in flight, fp64 accumulation, fixed-order LDS combine -> deterministic.
   __shared__ double sm[8][64];
+  __shared__ float s_ab[HC][2];
   const int n = blockIdx.x, l = blockIdx.y;
   const int nv = f.ngroups * 2;                  // values per tile row
   const int t0 = f.tile_start[l] + n * f.tiles_per_img[l];
@@ -838,9 +859,36 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
         float* o = f.ab + (((size_t)l * f.N + n) * HC + c) * 2;
         o[0] = (float)sc;
         o[1] = (float)((double)f.beta[l][c] - mean * sc);
+        s_ab[c][0] = o[0]; s_ab[c][1] = o[1];
       }
     }
     __syncthreads();
+  }
+  // ---- fold: this (level, image)'s copy of the tower conv with the scale in its rows (one fp16 rounding, the same
+  //      arithmetic as k_head2's own fold) and the shift as a bias fragment, in k_head2's K-permuted register layout:
+  //      element e of lane (m, hk) of fragment (ct, k) = W[32ct + m][16k + 8(e >> 2) + 4hk + (e & 3)]
+  if (f.wsrc[l] && f.wdst[l]) {
+    half8* dst = f.wdst[l] + (size_t)n * (4 * 9 * 64);
+    for (int i = threadIdx.x; i < 4 * 9 * 64; i += 256) {
+      const int ct = i / (9 * 64), k = (i / 64) % 9, lane = i & 63;
+      const int m = lane & 31, hk = lane >> 5;
+      half8 r;
+      if (k < 8) {
+        const float rs = s_ab[ct * 32 + m][0];
+        const _Float16* base = f.wsrc[l] + (size_t)(ct * 8 + k) * 64 * 8;
+        const half4 lo = *reinterpret_cast<const half4*>(base + m * 8 + 4 * hk);
+        const half4 hi = *reinterpret_cast<const half4*>(base + (m + 32) * 8 + 4 * hk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] = (_Float16)((float)lo[e] * rs); r[4 + e] = (_Float16)((float)hi[e] * rs); }
+      } else {
+        const float v = s_ab[ct * 32 + m][1];
+        const _Float16 bh = (_Float16)v, bl = (_Float16)(v - (float)bh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.f;
+        if (!hk) { r[0] = bh; r[1] = bl; }
+      }
+      dst[i] = r;
+    }
   }
 }
 
@@ -922,6 +970,7 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
     L.x = (const _Float16*)lv[i].x; L.wn = (const half8*)lv[i].wn_packed; L.bn = lv[i].bn;
     L.w1 = (const half8*)lv[i].w1_packed; L.w2 = (const half8*)lv[i].w2_packed;
     L.wf = (const half8*)lv[i].wf_packed; L.bf = lv[i].bf; L.scale = lv[i].scale;
+    L.w1f = (const half8*)lv[i].w1_folded; L.w2f = (const half8*)lv[i].w2_folded;
     L.cin = d->level_cin[i]; L.hw = d->level_hw[i]; L.p_off = d->level_point_offset[i];
     L.tile_start = ts[i]; L.tiles_per_img = tp[i];
   }
@@ -978,8 +1027,15 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
 
 int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const float* const* gamma,
                            const float* const* beta, float eps, float* ab, lfd_stream_t stream) {
+  return lfd_groupnorm_finalize_fold(d, partial, gamma, beta, eps, ab, nullptr, 0, stream);
+}
+
+int lfd_groupnorm_finalize_fold(const lfd_head_desc_t* d, const float* partial, const float* const* gamma,
+                                const float* const* beta, float eps, float* ab, const lfd_head_level_ptrs_t* lv,
+                                int32_t which, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d || !partial || !gamma || !beta || !ab) return LFD_ERR_INVALID_ARGUMENT;
+  if (lv && which != 1 && which != 2) return LFD_ERR_INVALID_ARGUMENT;
   FinalizeArgs f{};
   int nt = 0;
   int rc = fill_levels(d, f.tile_start, f.tiles_per_img, &nt);
@@ -989,6 +1045,10 @@ int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const
     if (!gamma[i] || !beta[i]) return LFD_ERR_INVALID_ARGUMENT;
     f.hw[i] = d->level_hw[i]; f.gamma[i] = gamma[i]; f.beta[i] = beta[i];
     f.tile_stride[i] = 1;
+    if (lv) {
+      f.wsrc[i] = (const _Float16*)(which == 1 ? lv[i].w1_packed : lv[i].w2_packed);
+      f.wdst[i] = (half8*)(which == 1 ? lv[i].w1_folded : lv[i].w2_folded);
+    }
   }
   f.part = partial; f.ab = ab; f.N = d->n; f.ngroups = d->num_groups; f.gsize = HC / d->num_groups; f.eps = eps;
   hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels), dim3(256), 0, st, f);

@@ -46,7 +46,11 @@ class HeadDesc(C.Structure):
 class HeadLevelPtrs(C.Structure):
     """lfd_head_level_ptrs_t"""
     _fields_ = [('x', C.c_void_p), ('wn_packed', C.c_void_p), ('bn', C.c_void_p), ('w1_packed', C.c_void_p),
-                ('w2_packed', C.c_void_p), ('wf_packed', C.c_void_p), ('bf', C.c_void_p), ('scale', C.c_void_p)]
+                ('w2_packed', C.c_void_p), ('wf_packed', C.c_void_p), ('bf', C.c_void_p), ('scale', C.c_void_p),
+                ('w1_folded', C.c_void_p), ('w2_folded', C.c_void_p)]
+
+
+HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS
 
 
 class AssignDesc(C.Structure):
@@ -131,6 +135,8 @@ _SIGNATURES = {
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),
     'lfd_head_forward_f16': (C.c_int, [C.POINTER(HeadDesc), _I32, C.POINTER(HeadLevelPtrs), _P, _P, _P, _P, _P, _P, _P]),
     'lfd_groupnorm_finalize': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P, _P]),
+    'lfd_groupnorm_finalize_fold': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P,
+                                              C.POINTER(HeadLevelPtrs), _I32, _P]),
     'lfd_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_fasterblock_fused_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -409,8 +409,8 @@ class EnginePlan(object):
                     for p, ab, gam, bet, eps in ((1, ab1, hs['g1'], hs['b1'], hs['eps1']), (2, ab2, hs['g2'], hs['b2'], hs['eps2'])):
                         check(l.lfd_head_forward_f16(C.byref(d), p, lv, ptr(ab1), None, ptr(part), None, None, ptr(z), sp),
                               'lfd_head_forward_f16(pass %d)' % p)
-                        check(l.lfd_groupnorm_finalize(C.byref(d), ptr(part), gam, bet, eps, ptr(ab), sp),
-                              'lfd_groupnorm_finalize')
+                        check(l.lfd_groupnorm_finalize_fold(C.byref(d), ptr(part), gam, bet, eps, ptr(ab), lv, p, sp),
+                              'lfd_groupnorm_finalize_fold')
                 check(l.lfd_head_forward_f16(C.byref(d), 3, lv, ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg), ptr(z), sp),
                       'lfd_head_forward_f16(pass 3)')
 
@@ -528,6 +528,11 @@ class _ShapeState(object):
                             lvp[k].wf_packed, lvp[k].bf = t.wf.data_ptr(), t.bf.data_ptr()
                             lvp[k].scale = t.scale.data_ptr() if t.scale is not None else None
                         call = dict(desc=d, levels=lvp)
+                        if plan.head_gn and os.environ.get('LFD_HEAD_FOLD', '1') != '0':
+                            # per-(level, image) GroupNorm-folded tower filters, written by the finalize launches
+                            call['folded'] = torch.empty((nl, 2, n, _lib.HEAD_FOLDED_HALFS), dtype=torch.float16, device=dev)
+                            for k in range(nl):
+                                lvp[k].w1_folded, lvp[k].w2_folded = call['folded'][k, 0].data_ptr(), call['folded'][k, 1].data_ptr()
                         if plan.head_gn:
                             call['ab1'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
                             call['ab2'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)

@@ -136,7 +136,7 @@ def test_full_size_properties_1080p():
     assert torch.equal(c1[0], cls[5]) and torch.equal(r1[0], reg[5])
 
 
-def test_head_chunk_length_does_not_change_outputs():
+def test_head_chunk_length_and_fold_site_do_not_change_outputs():
     """k_head2's work-chunk length is a load-balance knob chosen from the batch size (h2_plan_chunks, csrc/head.hip).
     GroupNorm partial sums are kept per 64-pixel statistics tile whatever the chunk, so every even chunk length must
     give bit-identical logits (LFD_H2_CHUNK forces one; it is read once per process -> subprocesses)."""
@@ -151,11 +151,13 @@ def test_head_chunk_length_does_not_change_outputs():
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lfd-a-light-and-fast-detector_amd'))
     hashes = {}
-    for chunk in (0, 2, 6, 12):
-        env = dict(os.environ, LFD_H2_CHUNK=str(chunk))
+    # LFD_HEAD_FOLD=0: every work chunk folds GroupNorm into its filters itself instead of loading the per-(level, image)
+    # copy written by lfd_groupnorm_finalize_fold -- the same arithmetic, so the same bits
+    for chunk, fold in ((0, 1), (2, 1), (6, 0), (12, 1), (0, 0)):
+        env = dict(os.environ, LFD_H2_CHUNK=str(chunk), LFD_HEAD_FOLD=str(fold))
         out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
-        hashes[chunk] = [l for l in out.stdout.splitlines() if l.startswith('HASH')][-1]
+        hashes[(chunk, fold)] = [l for l in out.stdout.splitlines() if l.startswith('HASH')][-1]
     assert len(set(hashes.values())) == 1, hashes
 
 
