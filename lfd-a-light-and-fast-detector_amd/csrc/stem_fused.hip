@@ -420,10 +420,18 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
 
   // ---- filters.  conv1 / conv3 in the standard order; the two 1x1s with permuted K (to consume the previous
   //      accumulator registers directly) and permuted rows (8 consecutive channels per lane).
-  // (the last W3L k-steps of conv3's filter live in LDS: 4 reads per tile buy back 16 registers -- with everything
-  //  resident the aligned-frame kernel was a handful of registers over 512 and spilled a filter fragment to scratch)
-  constexpr int W3L = 2, W3R = 36 - W3L;
-  half8 w1r[2][2], w2r[2][4], w3r[2][W3R];
+  // conv3's filter (72 fragments): the first W3A k-steps of both cout tiles are loaded straight into AccVGPRs by inline
+  // asm ("=a" outputs) and read from there by the MFMAs.  Left to the register allocator, ~47 of the 72 fragments were
+  // "spilled" to AccVGPRs and copied back with v_accvgpr_read in front of every use (190 VALU instructions per tile that
+  // nothing overlaps with one wave per SIMD).  The next W3V k-steps are ordinary registers, the last W3L live in LDS
+  // (W3L * 2 reads per tile): everything resident was a handful of registers over 512.
+#ifndef X2_W3A
+#define X2_W3A 30
+#endif
+  constexpr int W3A = X2_W3A, W3L = 2, W3R = 36 - W3L, W3V = W3R - W3A;
+  static_assert(W3A % 2 == 0 && W3A >= 0 && W3V >= 0 && 8 * W3A <= 256, "AccVGPR budget");
+  half8 w1r[2][2], w2r[2][4], w3r[2][W3V > 0 ? W3V : 1];
+  u32x4 w3a[2][W3A > 0 ? W3A : 1];
   half8* s_w3t = reinterpret_cast<half8*>(smem + X2::OFF_W3T);   // [2][W3L][64]
   half8* s_w4 = reinterpret_cast<half8*>(smem + X2::OFF_W4);   // [2][4][64]; only needed for 8 MFMAs per tile
 #pragma unroll
@@ -431,7 +439,13 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) w1r[c][k] = a.w1[(c * 2 + k) * 64 + lane];
 #pragma unroll
-    for (int k = 0; k < W3R; ++k) w3r[c][k] = a.w3[(c * 36 + k) * 64 + lane];
+    for (int k = 0; k < W3A; k += 2) {
+      const half8* p = a.w3 + (c * 36 + k) * 64 + lane;
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024"
+                   : "=&a"(w3a[c][k]), "=&a"(w3a[c][k + 1]) : "v"(p) : "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < W3V; ++k) w3r[c][k] = a.w3[(c * 36 + W3A + k) * 64 + lane];
     if (wave == 0) {
 #pragma unroll
       for (int k = 0; k < W3L; ++k) s_w3t[(c * W3L + k) * 64 + lane] = a.w3[(c * 36 + W3R + k) * 64 + lane];
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
         if (wave == 0) s_w4[(c * 4 + q) * 64 + lane] = perm(a.w4, c, q);
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the AccVGPR loads above are invisible to the compiler's counters
   if (threadIdx.x < 64) {
     s_b[threadIdx.x] = a.b1[threadIdx.x]; s_b[64 + threadIdx.x] = a.b2[threadIdx.x];
     s_b[128 + threadIdx.x] = a.b3[threadIdx.x]; s_b[192 + threadIdx.x] = a.b4[threadIdx.x];
@@ -958,7 +973,9 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
 #pragma unroll
             for (int kk = 0; kk < W3L; ++kk) w3t[c][kk] = s_w3t[(c * W3L + kk) * 64 + lane];
           }
-          acc3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < W3R ? w3r[c][k < W3R ? k : 0] : w3t[c][k < W3R ? 0 : k - W3R], xq[k % (PD + 1)], acc3[c], 0, 0, 0);
+          const half8 wk = k < W3A ? __builtin_bit_cast(half8, w3a[c][k < W3A ? k : 0])
+                                   : (k < W3R ? w3r[c][(k >= W3A && k < W3R) ? k - W3A : 0] : w3t[c][k < W3R ? 0 : k - W3R]);
+          acc3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk, xq[k % (PD + 1)], acc3[c], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
