@@ -251,8 +251,51 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       }
     }
   };
+  // FAST2 (3x3 stride 2, 64 input channels: the first conv of every stage + its 1x1 downsample branch): the same idea for
+  // the column-de-interleaved stride-2 tile.  A halo row is IWs = 34 slots (even columns 0..32, then odd columns 1..31):
+  // five row-aligned instructions of 8 slots; wave w issues rows w, w+4, ...  The slot -> (column, swizzled chunk) map of
+  // the five parts is computed once per tile (30 VALU), each instruction adds a scalar row base and selects the zero line
+  // for out-of-image pixels.  The generic slot walk cost 4.5 k cycles of issue per tile against 1.5 k of contraction
+  // (integer divisions by 34 and 64-bit multiplies per instruction, tools: scratch/conv_s2_timing.py).
+  constexpr bool FAST2 = (CIN == 64 && KS == 3 && S == 2 && !TAIL);
+  auto issue_dma_s2 = [&](int t, int buf) {
+    int ol = lane;
+    asm volatile("" : "+v"(ol));     // recomputed per tile, not hoisted (registers)
+    const int sl = ol >> 3, cs = ol & 7;
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * C::TH * 2 - 1, gx0 = tx0 * C::TW * 2 - 1;
+    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * f_rowpitch + (long)gx0 * (CIN * 2);
+    char* lbase = smem + buf * C::IN_BYTES;
+    constexpr int NP = (C::IWs + 7) / 8;            // instructions per row (5)
+    int off[NP];                                    // byte offset of this lane's chunk inside the row, or -1: not needed / outside
+    const char* zsrc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int rem = 8 * j + sl;
+      const int ix = rem < C::IWh ? 2 * rem : 2 * rem - (2 * C::IWh - 1);
+      const int c = cs ^ ((rem / C::PPR) % C::CPP);
+      const int gx = gx0 + ix;
+      const bool ok = rem < C::IWs && ix < C::IW && gx >= 0 && gx < a.W;
+      off[j] = ok ? ix * (CIN * 2) + c * 16 : -1;
+      zsrc[j] = reinterpret_cast<const char*>(a.zeros) + c * 16;
+    }
+    for (int iy = wave; iy < C::IH; iy += 4) {
+      const int gy = gy0 + iy;
+      const bool rv = gy >= 0 && gy < a.H;          // scalar
+      const char* rowp = p00 + iy * f_rowpitch;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const char* src = (rv && off[j] >= 0) ? rowp + off[j] : zsrc[j];
+        if (8 * j + 8 <= C::IWs || (8 * j + sl < C::IWs && 2 * (8 * j + sl) - (2 * C::IWh - 1) < C::IW))
+          dma16(src, lbase + (iy * C::IWs + 8 * j) * C::PIXB);
+      }
+    }
+  };
   auto issue_dma = [&](int t, int buf) {
     if constexpr (FAST) { issue_dma_fast(t, buf); return; }
+    if constexpr (FAST2) { issue_dma_s2(t, buf); return; }
     const int n = t / tiles_per_img;
     const int tr = t - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
@@ -309,9 +352,12 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       CV_T(3);
     } else {
       block_barrier();  // everyone is done reading the single buffer / `mid`
+      CV_T(1);
       issue_dma(t, 0);
+      CV_T(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       block_barrier();
+      CV_T(3);
     }
 
     const int n = t / tiles_per_img;
