@@ -129,6 +129,20 @@ LFD_API int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, con
                        int32_t* out_point, int32_t* out_counts, void* workspace,
                        size_t workspace_bytes, lfd_stream_t stream);
 
+/* Second half of lfd_detect_batched for a workspace whose candidate arrays were filled by a producer kernel
+ * (lfd_head_forward_decode_f16: the head's last pass thresholds, decodes and appends by itself): sort + suppression mask
+ * + scan, 3 launches.  Candidates may have arrived in any order -- ties are broken by (point, class), the reference's
+ * nonzero() order -- so out_dets / out_labels / out_point / out_counts equal lfd_detect_batched's; out_cand is the
+ * arrival slot (not reproducible).  With more than max_candidates candidates (overflow flag) the retained subset is
+ * arbitrary where lfd_detect_batched keeps the first K_cap in point order.
+ * The workspace's two counter arrays must be zero before the first producer launch (lfd_detect_workspace_reset, once
+ * per allocation); lfd_detect_from_candidates re-arms them. */
+LFD_API int lfd_detect_workspace_reset(const lfd_detect_desc_t* desc, int32_t batch, void* workspace,
+                                       size_t workspace_bytes, lfd_stream_t stream);
+LFD_API int lfd_detect_from_candidates(const lfd_detect_desc_t* desc, int32_t batch, float* out_dets, int32_t* out_labels,
+                                       int32_t* out_cand, int32_t* out_point, int32_t* out_counts, void* workspace,
+                                       size_t workspace_bytes, lfd_stream_t stream);
+
 /* Decode only (no threshold/NMS): boxes [N,P,4] f32 and scores [N,P,C] f32 for parity tests
  * and for callers that want the reference's intermediate tensors (lfd.py:449-499). */
 LFD_API int lfd_decode_all(const lfd_detect_desc_t* desc, int32_t batch, const void* cls, const void* reg,
@@ -464,6 +478,16 @@ LFD_API int lfd_head_forward_f16(const lfd_head_desc_t* desc, int32_t pass,
                                  const float* ab1 /*[L][n][128][2]*/, const float* ab2,
                                  float* partial, float* out_cls, float* out_reg, const void* zeros,
                                  lfd_stream_t stream);
+/* Pass 3 that also does the front half of lfd_detect_batched (lfd_head.py:164-185 + lfd.py:449-499 in one launch,
+ * SURVEY 8b lfd_head_final_decode): sigma(cls) > score_thr -> decode -> append {box, score, label 0, point} to the
+ * candidate arrays of `det_workspace`; lfd_detect_from_candidates finishes the step.  out_cls / out_reg may be NULL
+ * (the fp32 [N,P,C'+4] logits then never reach HBM).  Supported: one foreground class with sigmoid scores, a merged
+ * tower (final_reg_rows 4 + final_cls_rows 1), GroupNorm group size >= 8, det levels == head levels;
+ * anything else returns LFD_ERR_UNSUPPORTED (use pass 3 + lfd_detect_batched). */
+LFD_API int lfd_head_forward_decode_f16(const lfd_head_desc_t* desc, const lfd_head_level_ptrs_t* levels,
+                                        const float* ab1, const float* ab2, float* out_cls, float* out_reg,
+                                        const void* zeros, const lfd_detect_desc_t* det, const float* img_meta,
+                                        void* det_workspace, size_t det_workspace_bytes, lfd_stream_t stream);
 /* gamma / beta: host arrays of num_levels device pointers ([128] each). ab: [L][n][128][2]. */
 LFD_API int lfd_groupnorm_finalize(const lfd_head_desc_t* desc, const float* partial,
                                    const float* const* gamma, const float* const* beta, float eps,

@@ -22,6 +22,7 @@
 // weights of every stage stay in VGPRs across the persistent tile loop.
 #include <type_traits>
 #include "common.h"
+#include "decode_impl.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -69,6 +70,7 @@ struct HeadArgs {
   int gshift;            // log2(channels per group)  (GroupNorm(16,128) -> 3)
   int ntiles;
   const _Float16* zeros;
+  LfdAppendTarget dec;   // k_head2<3, 1, true>: where the candidates go (lfd_head_forward_decode_f16)
 };
 
 // global -> LDS DMA through inline asm and a fence-free barrier: see conv.hip.  (With the builtin, the compiler
@@ -464,8 +466,9 @@ __device__ unsigned long long g_h2_dbg[3 * 32];
 #define H2_T(i)
 #endif
 
-template <int PASS, int FT>
+template <int PASS, int FT, bool DEC = false>
 __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
+  static_assert(!DEC || (PASS == 3 && FT == 1), "decode rides on the output pass of a merged single-class tower");
   constexpr int NKN = 4, NKNX = 8, NKH = HC / 16;                      // neck k-steps per 64 input channels / maximum (128 channels)
   constexpr int WN_FRAGS = 4 * (NKNX + 1);                             // neck: 4 cout tiles x (up to 8 k-steps + bias step)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -727,7 +730,46 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
             for (int q = 0; q < NKH; ++q)
               fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wf[(f * (NKH + 1) + q) * 64 + lane], bq[q], fa, 0, 0, 0);
-            if (lane_ok) {
+            if constexpr (DEC) {
+              // ---- threshold + decode + append (front half of lfd_detect_batched: lfd.py:449-499, nms.py:202-207).
+              //      Rows 0..3 (regression) sit in the pixel's hh = 0 lane, row 4 (the class logit) in its hh = 1 lane.
+              const float logit = __shfl(fa[0], pix + 32, 64);
+              const float r0 = fa[0] * scale, r1 = fa[1] * scale, r2 = fa[2] * scale, r3 = fa[3] * scale;
+              float sc = 0.f;
+              bool cand = false;
+              if (hh == 0 && lane_ok) { sc = lfd_sigmoidf_ref(logit); cand = sc > a.dec.score_thr; }
+              const unsigned long long cm = __ballot(cand);
+              if (cm) {                                   // wave-uniform: most groups have no candidate
+                int base = 0;
+                const int first = __builtin_ctzll(cm);
+                if (lane == first) base = atomicAdd(&a.dec.total[n], (int)__popcll(cm));
+                base = __builtin_amdgcn_readlane(base, first);
+                uint32_t mo = 0u;
+                if (cand) {
+                  const int slot = base + (int)__popcll(cm & ((1ull << lane) - 1ull));
+                  if (slot < a.dec.cap) {
+                    const int q = p0 + pix, lw = a.dec.w[l];
+                    const int iy = q / lw, ix = q - iy * lw;
+                    const float4 box = lfd_decode_core(a.dec.decode_mode, r0, r1, r2, r3, (float)(ix * a.dec.stride[l]),
+                                                       (float)(iy * a.dec.stride[l]), a.dec.m[l], a.dec.meta[n * 3 + 0],
+                                                       a.dec.meta[n * 3 + 1], a.dec.meta[n * 3 + 2]);
+                    const size_t o = (size_t)n * a.dec.cap + slot;
+                    a.dec.cand_box[o] = box;
+                    a.dec.cand_score[o] = sc;
+                    a.dec.cand_label[o] = 0;
+                    a.dec.cand_point[o] = L.p_off + q;
+                    mo = lfd_float_ord(fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
+                  }
+                }
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) {
+                  const uint32_t ot = __shfl_xor(mo, sft, 64);
+                  mo = ot > mo ? ot : mo;
+                }
+                if (lane == 0 && mo) atomicMax(&a.dec.maxord[n], mo);
+              }
+            }
+            if (lane_ok && (!DEC || a.out_cls)) {
               // final rows: [reg x reg_rows][cls x cls_rows]; lane (pixel, hh) holds rows 8g + 4hh + j
               if (a.reg_rows == 4 && f == 0 && hh == 0)
                 *reinterpret_cast<float4*>(a.out_reg + row * 4) = make_float4(fa[0] * scale, fa[1] * scale, fa[2] * scale, fa[3] * scale);
@@ -778,19 +820,19 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_h2_timing(unsign
 namespace {
 #endif
 
-template <int PASS, int FT>
+template <int PASS, int FT, bool DEC = false>
 int launch_head2(const HeadArgs& a, hipStream_t st) {
   constexpr int LDS = (4 * 9 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT, DEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
   int blocks = a.h2_nitems < 256 ? a.h2_nitems : 256;
   if (blocks < 1) return LFD_OK;
-  hipLaunchKernelGGL((k_head2<PASS, FT>), dim3(blocks), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((k_head2<PASS, FT, DEC>), dim3(blocks), dim3(256), LDS, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -945,10 +987,9 @@ size_t lfd_head_partial_floats(const lfd_head_desc_t* d) {
   return (size_t)nt * d->num_groups * 2;
 }
 
-int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_level_ptrs_t* lv,
-                         const float* ab1, const float* ab2, float* partial, float* out_cls, float* out_reg,
-                         const void* zeros, lfd_stream_t stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_head_level_ptrs_t* lv,
+                             const float* ab1, const float* ab2, float* partial, float* out_cls, float* out_reg,
+                             const void* zeros, const LfdAppendTarget* dec, hipStream_t st) {
   if (!d || !lv || !zeros) return LFD_ERR_INVALID_ARGUMENT;
   if (d->head_channels != HC) return LFD_ERR_UNSUPPORTED;
   const int gsize = d->num_groups > 0 ? HC / d->num_groups : 0;
@@ -984,7 +1025,7 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
       return LFD_ERR_LAUNCH_FAILED;
   }
   if (pass >= 2 && !ab1) return LFD_ERR_INVALID_ARGUMENT;
-  if (pass == 3 && (!ab2 || !out_cls || !out_reg)) return LFD_ERR_INVALID_ARGUMENT;
+  if (pass == 3 && (!ab2 || (!dec && (!out_cls || !out_reg)) || (!out_cls != !out_reg))) return LFD_ERR_INVALID_ARGUMENT;
   if ((d->final_reg_rows != 0 && d->final_reg_rows != 4) || d->final_cls_rows < 0) return LFD_ERR_INVALID_ARGUMENT;
   const int ft = (d->final_reg_rows + d->final_cls_rows + 31) / 32;
   if (pass == 3 && (ft < 1 || ft > 2)) return LFD_ERR_UNSUPPORTED;
@@ -1005,8 +1046,14 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
     }
     if (pass == 1) return launch_head2<1, 1>(a, st);
     if (pass == 2) return launch_head2<2, 1>(a, st);
+    if (dec) {
+      if (ft != 1 || d->final_reg_rows != 4 || d->final_cls_rows != 1) return LFD_ERR_UNSUPPORTED;
+      a.dec = *dec;
+      return launch_head2<3, 1, true>(a, st);
+    }
     return ft == 2 ? launch_head2<3, 2>(a, st) : launch_head2<3, 1>(a, st);
   }
+  if (dec) return LFD_ERR_UNSUPPORTED;
   // one launch per tap-channel class (64 / 128): homogeneous tiles, compile-time ring geometry
   for (int cin = 64; cin <= 128; cin += 64) {
     a.grp_n = 0;
@@ -1023,6 +1070,33 @@ int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_
     if (rc != LFD_OK) return rc;
   }
   return LFD_OK;
+}
+
+int lfd_head_forward_f16(const lfd_head_desc_t* d, int32_t pass, const lfd_head_level_ptrs_t* lv,
+                         const float* ab1, const float* ab2, float* partial, float* out_cls, float* out_reg,
+                         const void* zeros, lfd_stream_t stream) {
+  return head_forward_impl(d, pass, lv, ab1, ab2, partial, out_cls, out_reg, zeros, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_head_forward_decode_f16(const lfd_head_desc_t* d, const lfd_head_level_ptrs_t* lv, const float* ab1,
+                                const float* ab2, float* out_cls, float* out_reg, const void* zeros,
+                                const lfd_detect_desc_t* det, const float* img_meta, void* det_workspace,
+                                size_t det_workspace_bytes, lfd_stream_t stream) {
+  if (!d || !det) return LFD_ERR_INVALID_ARGUMENT;
+  // one foreground class scored with a sigmoid; the detector's levels are the head's levels
+  if (det->num_classes != 1 || det->num_cls_channels != 1 || det->score_mode != 0 || d->cls_channels != 1)
+    return LFD_ERR_UNSUPPORTED;
+  if (det->num_levels != d->num_levels) return LFD_ERR_INVALID_ARGUMENT;
+  int p = 0;
+  for (int i = 0; i < d->num_levels; ++i) {
+    if (det->level_h[i] * det->level_w[i] != d->level_hw[i] || d->level_point_offset[i] != p) return LFD_ERR_INVALID_ARGUMENT;
+    p += d->level_hw[i];
+  }
+  if (p != d->total_points) return LFD_ERR_INVALID_ARGUMENT;
+  LfdAppendTarget dec;
+  const int rc = lfd_detect_bind_append(det, d->n, img_meta, det_workspace, det_workspace_bytes, &dec);
+  if (rc != LFD_OK) return rc;
+  return head_forward_impl(d, 3, lv, ab1, ab2, nullptr, out_cls, out_reg, zeros, &dec, reinterpret_cast<hipStream_t>(stream));
 }
 
 int lfd_groupnorm_finalize(const lfd_head_desc_t* d, const float* partial, const float* const* gamma,

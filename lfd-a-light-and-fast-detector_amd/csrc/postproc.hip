@@ -22,6 +22,7 @@
 // evaluated exactly as written (separate fp32 mul/add/sub, IEEE divide) to be bit-identical
 // with the reference.
 #include "common.h"
+#include "decode_impl.h"
 
 namespace {
 
@@ -32,6 +33,10 @@ struct SegBuffers {
   int words;          // ceil(cap/64): mask row stride in 64-bit words
   const int* counts;  // [nseg,4] device counts (slot 0 = K) or nullptr
   int k_host;         // used when counts == nullptr
+  int* total;         // appended segments (a producer kernel filled cand_* through LfdAppendTarget): [nseg] candidates
+                      // seen, K = min(total, cap); sort key (score, point * nclass + label); reset by k_scan.  Else nullptr
+  int nclass;
+  int* total_ws;      // the workspace's counter array (total == total_ws when the segment is an appended one)
   int class_agnostic; // nms_cfg['class_agnostic']: no coordinate offsets (nms.py:145-146)
   float iou_thr;
   float4* cand_box;   // [nseg,cap]
@@ -49,7 +54,7 @@ struct SegBuffers {
 };
 
 __device__ __forceinline__ int seg_k(const SegBuffers& b, int seg) {
-  int k = b.counts ? b.counts[seg * 4] : b.k_host;
+  int k = b.total ? b.total[seg] : (b.counts ? b.counts[seg * 4] : b.k_host);
   return k < b.cap ? k : b.cap;
 }
 
@@ -103,7 +108,7 @@ struct DecodeParams {
   int lds_stride;     // > 0: softmax rows of a block are staged through LDS with this (odd) float stride
 };
 
-__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_ref(float x) { return lfd_sigmoidf_ref(x); }
 
 // score of (point p, class c); for softmax mode `mx`/`inv` come from softmax_stats().
 __device__ __forceinline__ void softmax_stats(const DecodeParams& d, int64_t row, float* mx, float* sum) {
@@ -136,23 +141,8 @@ __device__ __forceinline__ float4 decode_box(const DecodeParams& d, int n, int p
   float r1 = lfd_load_f(d.reg, row * 4 + 1, d.in_dtype);
   float r2 = lfd_load_f(d.reg, row * 4 + 2, d.in_dtype);
   float r3 = lfd_load_f(d.reg, row * 4 + 3, d.in_dtype);
-  float d0, d1, d2, d3;
-  if (d.decode_mode == 0) {
-    const float m = d.lv.rmax[l];
-    d0 = sigmoidf_ref(r0) * m; d1 = sigmoidf_ref(r1) * m;
-    d2 = sigmoidf_ref(r2) * m; d3 = sigmoidf_ref(r3) * m;
-  } else if (d.decode_mode == 1) {
-    d0 = expf(r0); d1 = expf(r1); d2 = expf(r2); d3 = expf(r3);
-  } else {
-    const float m = d.lv.rhi[l];
-    d0 = r0 * m; d1 = r1 * m; d2 = r2 * m; d3 = r3 * m;
-  }
   const float W = d.meta[n * 3 + 0], H = d.meta[n * 3 + 1], sc = d.meta[n * 3 + 2];
-  float x1 = fminf(fmaxf(px - d0, 0.f), W);
-  float y1 = fminf(fmaxf(py - d1, 0.f), H);
-  float x2 = fminf(fmaxf(px + d2, 0.f), W);
-  float y2 = fminf(fmaxf(py + d3, 0.f), H);
-  return make_float4(x1 / sc, y1 / sc, x2 / sc, y2 / sc);
+  return lfd_decode_core(d.decode_mode, r0, r1, r2, r3, px, py, d.decode_mode == 0 ? d.lv.rmax[l] : d.lv.rhi[l], W, H, sc);
 }
 
 // Softmax models (46 channels for TT100K): a thread-per-point sweep reads its 184-byte row with a 184-byte lane stride --
@@ -344,12 +334,14 @@ __global__ __launch_bounds__(kBlock) void k_rank_sort(SegBuffers b) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < K;
   const float my_score = live ? b.cand_score[so + i] : 0.f;
-  const unsigned long long my = live ? sort_key(my_score, i) : ~0ull;
+  // appended segments arrive in any order: their tie-break is the reference's nonzero() order, point-major class-minor
+  auto tie = [&](int j) { return b.total ? b.cand_point[so + j] * b.nclass + b.cand_label[so + j] : j; };
+  const unsigned long long my = live ? sort_key(my_score, tie(i)) : ~0ull;
   int rank = 0;
   for (int j0 = 0; j0 < K; j0 += kBlock) {
     const int j = j0 + threadIdx.x;
     __syncthreads();
-    keys[threadIdx.x] = j < K ? sort_key(b.cand_score[so + j], j) : ~0ull;
+    keys[threadIdx.x] = j < K ? sort_key(b.cand_score[so + j], tie(j)) : ~0ull;
     __syncthreads();
     const int lim = (K - j0) < kBlock ? (K - j0) : kBlock;
 #pragma unroll 8
@@ -588,6 +580,16 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(SegBuffers b, ScanOut o) 
   if (threadIdx.x == 0) {
     if (o.counts) o.counts[seg * 4 + 1] = s_nkept;
     if (o.num_keep) o.num_keep[0] = s_nkept;
+    if (b.total) {       // appended segment: publish the counts k_scatter would have written, re-arm the counters
+      const int all = b.total[seg];
+      if (o.counts) {
+        o.counts[seg * 4 + 0] = all < b.cap ? all : b.cap;
+        o.counts[seg * 4 + 2] = all > b.cap;
+        o.counts[seg * 4 + 3] = all;
+      }
+      b.total[seg] = 0;
+      b.maxord[seg] = 0u;
+    }
   }
 }
 
@@ -606,6 +608,9 @@ SegBuffers carve_seg(LfdCarver& cv, int nseg, int cap, bool need_point) {
   b.cand_label = cv.take<int>(tot);
   b.cand_point = need_point ? cv.take<int>(tot) : nullptr;
   b.maxord = cv.take<uint32_t>(nseg);
+  b.total_ws = cv.take<int>(nseg);      // (appended segments only; see lfd_detect_bind_append)
+  b.total = nullptr;
+  b.nclass = 1;
   b.s_box = cv.take<float4>(tot);
   b.s_area = cv.take<float>(tot);
   b.s_score = cv.take<float>(tot);
@@ -690,6 +695,30 @@ int desc_points(const lfd_detect_desc_t* desc) {
 }
 
 }  // namespace
+
+// the append target of a producer kernel (head.hip): same carving as lfd_detect_from_candidates
+int lfd_detect_bind_append(const lfd_detect_desc_t* desc, int32_t batch, const float* img_meta, void* workspace,
+                           size_t workspace_bytes, LfdAppendTarget* out) {
+  if (!desc || !out || !workspace || !img_meta || batch < 1 || desc->max_candidates < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (desc->num_levels < 1 || desc->num_levels > LFD_MAX_LEVELS) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_detect_workspace_bytes(desc, batch)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int P = desc_points(desc);
+  const int nblk = (P + kBlock - 1) / kBlock;
+  LfdCarver cv(workspace);
+  cv.take<int>((size_t)batch * (nblk > 0 ? nblk : 1));
+  SegBuffers b = carve_seg(cv, batch, desc->max_candidates, true);
+  out->cand_box = b.cand_box; out->cand_score = b.cand_score; out->cand_label = b.cand_label; out->cand_point = b.cand_point;
+  out->maxord = b.maxord; out->total = b.total_ws; out->cap = b.cap;
+  out->decode_mode = desc->decode_mode; out->score_thr = desc->score_thr; out->meta = img_meta;
+  for (int i = 0; i < LFD_MAX_LEVELS; ++i) {
+    const bool on = i < desc->num_levels;
+    out->w[i] = on && desc->level_w[i] > 0 ? desc->level_w[i] : 1;
+    out->stride[i] = on ? desc->level_stride[i] : 0;
+    const float rmax = on ? (desc->level_range_lo[i] > desc->level_range_hi[i] ? desc->level_range_lo[i] : desc->level_range_hi[i]) : 0.f;
+    out->m[i] = desc->decode_mode == 0 ? rmax : (on ? desc->level_range_hi[i] : 0.f);
+  }
+  return LFD_OK;
+}
 
 // =================================================================== C ABI
 extern "C" {
@@ -791,6 +820,49 @@ int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void*
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_scatter, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b, out_counts);
   LFD_CHECK_LAUNCH();
+  ScanOut o{};
+  o.dets = out_dets;
+  o.labels = out_labels;
+  o.cand = out_cand;
+  o.point = out_point;
+  o.counts = out_counts;
+  return run_sort_mask_scan(b, o, batch, st);
+}
+
+int lfd_detect_workspace_reset(const lfd_detect_desc_t* desc, int32_t batch, void* workspace, size_t workspace_bytes,
+                               lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!desc || !workspace || batch < 1 || desc->max_candidates < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_detect_workspace_bytes(desc, batch)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int P = desc_points(desc);
+  const int nblk = (P + kBlock - 1) / kBlock;
+  LfdCarver cv(workspace);
+  cv.take<int>((size_t)batch * (nblk > 0 ? nblk : 1));
+  SegBuffers b = carve_seg(cv, batch, desc->max_candidates, true);
+  if (hipMemsetAsync(b.maxord, 0, sizeof(uint32_t) * batch, st) != hipSuccess ||
+      hipMemsetAsync(b.total_ws, 0, sizeof(int) * batch, st) != hipSuccess)
+    return LFD_ERR_LAUNCH_FAILED;
+  return LFD_OK;
+}
+
+int lfd_detect_from_candidates(const lfd_detect_desc_t* desc, int32_t batch, float* out_dets, int32_t* out_labels,
+                               int32_t* out_cand, int32_t* out_point, int32_t* out_counts, void* workspace,
+                               size_t workspace_bytes, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!desc || batch < 1 || !out_counts || !workspace || desc->max_candidates < 1 || desc->num_classes < 1)
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_detect_workspace_bytes(desc, batch)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int P = desc_points(desc);
+  const int nblk = (P + kBlock - 1) / kBlock;
+  LfdCarver cv(workspace);
+  cv.take<int>((size_t)batch * (nblk > 0 ? nblk : 1));
+  SegBuffers b = carve_seg(cv, batch, desc->max_candidates, true);
+  b.counts = out_counts;
+  b.k_host = 0;
+  b.total = b.total_ws;
+  b.nclass = desc->num_classes;
+  b.class_agnostic = desc->class_agnostic ? 1 : 0;
+  b.iou_thr = desc->iou_thr;
   ScanOut o{};
   o.dets = out_dets;
   o.labels = out_labels;

@@ -95,6 +95,8 @@ _SIGNATURES = {
     'lfd_batched_nms_f32': (C.c_int, [_P, _P, _P, _I64, _F, _I32, _P, _P, _P, _P, _SZ, _P]),
     'lfd_detect_workspace_bytes': (_SZ, [C.POINTER(DetectDesc), _I32]),
     'lfd_detect_batched': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'lfd_detect_workspace_reset': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _SZ, _P]),
+    'lfd_detect_from_candidates': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'lfd_decode_all': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _I32, _P, _P, _P, _P]),
     'lfd_sigmoid_focal_loss_fwd': (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _I32, _P]),
     'lfd_sigmoid_focal_loss_bwd': (C.c_int, [_P, _P, _P, _I64, _I32, _F, _F, _P, _I32, _P]),
@@ -134,6 +136,8 @@ _SIGNATURES = {
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),
     'lfd_head_forward_f16': (C.c_int, [C.POINTER(HeadDesc), _I32, C.POINTER(HeadLevelPtrs), _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_head_forward_decode_f16': (C.c_int, [C.POINTER(HeadDesc), C.POINTER(HeadLevelPtrs), _P, _P, _P, _P, _P,
+                                              C.POINTER(DetectDesc), _P, _P, _SZ, _P]),
     'lfd_groupnorm_finalize': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P, _P]),
     'lfd_groupnorm_finalize_fold': (C.c_int, [C.POINTER(HeadDesc), _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _F, _P,
                                               C.POINTER(HeadLevelPtrs), _I32, _P]),

@@ -14,6 +14,7 @@ Unsupported module configurations raise RuntimeError: there is no PyTorch fallba
 inference (the reference's own cuDNN path is what this replaces).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -397,8 +398,19 @@ class EnginePlan(object):
         if after and len(self.convs) in after:
             after[len(self.convs)]()
 
-    def run_head(self, st, groups=None):
-        """5 launches per (level group, tower): pass 1, finalize, pass 2, finalize, pass 3."""
+    def decode_supported(self, st, desc):
+        """the head's output pass can threshold + decode + append by itself (lfd_head_forward_decode_f16): one merged
+        tower over all levels in one launch group, one foreground class with sigmoid scores"""
+        if len(st.head_groups) != 1 or len(st.head_groups[0]) != 1 or os.environ.get('LFD_HEAD_DECODE', '1') == '0':
+            return False
+        d = st.head_groups[0][0]['desc']
+        return (desc.num_classes == 1 and desc.num_cls_channels == 1 and desc.score_mode == 0 and d.cls_channels == 1
+                and d.final_reg_rows == 4 and d.final_cls_rows == 1 and self.head_gn and self.head_groups <= 16)
+
+    def run_head(self, st, groups=None, decode=None):
+        """5 launches per (level group, tower): pass 1, finalize, pass 2, finalize, pass 3.
+        decode = (detect desc, meta [N,3], ops.DetectOutputs): pass 3 appends the candidates itself and the logits are
+        not written (decode_supported() must hold)."""
         l = lib()
         z = ops.zero_line(self.device)
         for gi in (range(len(st.head_groups)) if groups is None else groups):
@@ -411,10 +423,15 @@ class EnginePlan(object):
                               'lfd_head_forward_f16(pass %d)' % p)
                         check(l.lfd_groupnorm_finalize_fold(C.byref(d), ptr(part), gam, bet, eps, ptr(ab), lv, p, sp),
                               'lfd_groupnorm_finalize_fold')
+                if decode is not None:
+                    ddesc, meta, out = decode
+                    check(l.lfd_head_forward_decode_f16(C.byref(d), lv, ptr(ab1), ptr(ab2), None, None, ptr(z), C.byref(ddesc),
+                                                        ptr(meta), ptr(out.ws), out.ws.numel(), sp), 'lfd_head_forward_decode_f16')
+                    continue
                 check(l.lfd_head_forward_f16(C.byref(d), 3, lv, ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg), ptr(z), sp),
                       'lfd_head_forward_f16(pass 3)')
 
-    def run_all(self, x, fmt, st):
+    def run_all(self, x, fmt, st, decode=None):
         """Whole forward.  The neck+head of the FIRST pyramid level (the largest, ~75 % of the head's
         pixels) only depends on the first backbone tap: it is forked onto a side stream as soon as that
         tap is written and overlaps with the remaining (small, latency-bound) backbone stages; the other
@@ -434,7 +451,7 @@ class EnginePlan(object):
             return
         if not st.overlap or len(st.head_groups) < 2:
             self.run_backbone(x, fmt, st)
-            return self.run_head(st)
+            return self.run_head(st, decode=decode)
         main = torch.cuda.current_stream()
 
         def fork():
@@ -626,6 +643,24 @@ def lfd_forward(model, x, use_graph=False, slot=0):
         else:
             plan.run_all(x, fmt, st)
     return st.cls, st.reg, st.sizes
+
+
+def lfd_forward_detect(model, x, desc, meta, out, slot=0):
+    """Forward whose last head pass appends the detection candidates to out.ws instead of writing logits, followed by
+    sort + mask + scan (ops.detect_from_candidates).  Returns False -- nothing enqueued -- when this model / descriptor
+    is not covered (EnginePlan.decode_supported); the caller then runs lfd_forward + ops.detect_batched."""
+    _lib.require_cuda(x, 'LFD.forward')
+    if not x.is_contiguous():
+        x = x.contiguous()
+    fmt, n, h, w = _input_format(x)
+    plan = get_plan(model, model._backbone, model._neck, model._head, x.device)
+    st = plan.state_for(n, h, w, slot)
+    if plan.head is None or not plan.decode_supported(st, desc):
+        return False
+    with torch.cuda.device(x.device):
+        plan.run_all(x, fmt, st, decode=(desc, meta, out))
+        ops.detect_from_candidates(desc, n, out)
+    return True
 
 
 def _run_graphed(plan, st, x, fmt):

@@ -163,10 +163,18 @@ class LFD(nn.Module):
                     out = self.detect(self.forward_resident(x, slot), meta, score_thr, iou_thr, agn, max_candidates)   # warm-up, sizes buffers
                     torch.cuda.synchronize()
                     desc, _ = self._detect_desc(score_thr, iou_thr, agn, max_candidates)
+                    # single-class sigmoid models: the head's output pass thresholds, decodes and appends the candidates
+                    # itself (lfd_head_forward_decode_f16), logits never reach HBM, 3 post-processing launches instead of 5
+                    ops.detect_workspace_reset(desc, x.size(0), out)
+                    fused = engine.lfd_forward_detect(self, x, desc, meta, out, slot)      # warm-up of the fused kernels
+                    torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        cls, reg = self.forward_resident(x, slot)
-                        ops.detect_batched(desc, cls, reg, meta, out=out)
+                        if fused:
+                            engine.lfd_forward_detect(self, x, desc, meta, out, slot)
+                        else:
+                            cls, reg = self.forward_resident(x, slot)
+                            ops.detect_batched(desc, cls, reg, meta, out=out)
             finally:
                 self.use_graph = True
             ent = (g, out, x, meta)          # keep the captured buffers alive

@@ -91,6 +91,41 @@ class DetectOutputs(object):
     __slots__ = ('dets', 'labels', 'cand', 'point', 'counts', 'ws')
 
 
+def detect_outputs(desc, n, dev, out=None):
+    """Output tensors + private workspace of a detection step (ops.DetectOutputs); `appendable` marks a workspace whose
+    candidate counters have been zeroed for the fused head pass (lfd_head_forward_decode_f16)."""
+    cap = desc.max_candidates
+    with torch.cuda.device(dev):
+        if out is None:
+            out = DetectOutputs()
+            out.dets = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
+            out.labels = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.cand = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.point = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.counts = torch.empty((n, 4), dtype=torch.int32, device=dev)   # fully written by the kernels
+            out.ws = None
+        wsb = lib().lfd_detect_workspace_bytes(C.byref(desc), n)
+        if getattr(out, 'ws', None) is None or out.ws.numel() < wsb:
+            out.ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+    return out
+
+
+def detect_workspace_reset(desc, n, out):
+    """zero the candidate counters of out.ws (once per workspace, before the first lfd_head_forward_decode_f16)"""
+    with torch.cuda.device(out.ws.device):
+        check(lib().lfd_detect_workspace_reset(C.byref(desc), n, ptr(out.ws), out.ws.numel(), stream_ptr()),
+              'lfd_detect_workspace_reset')
+
+
+def detect_from_candidates(desc, n, out):
+    """sort + suppression mask + scan over the candidates a fused head pass appended to out.ws (3 launches)"""
+    with torch.cuda.device(out.ws.device):
+        check(lib().lfd_detect_from_candidates(C.byref(desc), n, ptr(out.dets), ptr(out.labels), ptr(out.cand), ptr(out.point),
+                                               ptr(out.counts), ptr(out.ws), out.ws.numel(), stream_ptr()),
+              'lfd_detect_from_candidates')
+    return out
+
+
 def detect_batched(desc, cls, reg, meta, out=None):
     """Enqueues the whole post-processing of a batch; returns device-resident outputs (no sync)."""
     require_cuda(cls, 'detect')

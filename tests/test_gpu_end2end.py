@@ -157,3 +157,39 @@ def test_two_batches_in_flight_on_two_streams_match_the_serial_step():
         for n in range(2):
             k = int(ref[sl][0][n, 1])
             assert k > 0 and torch.equal(outs[sl].dets[n, :k], ref[sl][1][n, :k]) and torch.equal(outs[sl].labels[n, :k], ref[sl][2][n, :k])
+
+
+@pytest.mark.parametrize('shape,q', [((2, 270, 480, 3), 0.95), ((1, 1080, 1920, 3), 0.995), ((3, 200, 312, 3), 0.9)])
+def test_head_pass_that_appends_its_own_candidates_equals_the_unfused_step(shape, q):
+    """lfd_head_forward_decode_f16 (the head's output pass thresholds, decodes and appends the candidates; sort + mask + scan
+    follow through lfd_detect_from_candidates) against forward -> fp32 logits -> lfd_detect_batched: identical counts,
+    detections, labels and point indices (the append order is arbitrary, the sort key (score, point) is not), over several
+    replays of the captured graph (the candidate counters re-arm themselves)."""
+    from lfd_amd import engine
+    m = configs.build_model('WIDERFACE_LFD_S')
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    x = (torch.rand(*shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)) * 2 - 1).half()
+    meta = torch.tensor([[float(shape[2]), float(shape[1]), 1.0]] * shape[0]).cuda()
+    with torch.no_grad():
+        cls, _ = m.forward_resident(x)
+        thr = float(torch.quantile(cls.float().sigmoid().reshape(-1)[:4000000], q))
+        m.use_graph = False
+        u = m.detect_resident(x, meta, score_thr=thr, max_candidates=4096)      # eager: forward + lfd_detect_batched
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in (u.counts, u.dets, u.labels, u.point)]
+        assert int(ref[0][:, 2].max()) == 0 and int(ref[0][:, 0].min()) > 10
+        m.use_graph = True
+        plan = engine.get_plan(m, m._backbone, m._neck, m._head, x.device)
+        for _ in range(3):
+            f = m.detect_resident(x, meta, score_thr=thr, max_candidates=4096)
+            torch.cuda.synchronize()
+            assert torch.equal(f.counts, ref[0])
+            for n in range(shape[0]):
+                k = int(ref[0][n, 1])
+                assert k > 0
+                assert torch.equal(f.dets[n, :k], ref[1][n, :k]) and torch.equal(f.labels[n, :k], ref[2][n, :k])
+                assert torch.equal(f.point[n, :k], ref[3][n, :k])
+    # the fused pass really ran: this model / descriptor is covered
+    desc, _ = m._detect_desc(thr, m._nms_cfg.get('iou_thr', 0.5), m._nms_cfg.get('class_agnostic', False), 4096)
+    assert plan.decode_supported(plan.state_for(*([shape[0], shape[1], shape[2]]), 0), desc)
