@@ -39,6 +39,7 @@ struct LfdAppendTarget {
   int cap;
   int decode_mode;
   float score_thr;
+  float logit_lo;      // conservative bound: sigma(x) > score_thr implies x > logit_lo (prefilter only, never decides)
   const float* meta;   // [N,3] clampW, clampH, resize_scale
   int w[LFD_MAX_LEVELS], stride[LFD_MAX_LEVELS];
   float m[LFD_MAX_LEVELS];   // the level's range constant for decode_mode (rmax | rhi)

@@ -27,6 +27,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -478,6 +479,17 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int hh = lane >> 5, pix = lane & 31;
+  // DEC: wave-private candidate staging, 2 x [64] x {box 16 B | score 4 B | point 4 B}: candidates are decoded where they
+  // are found, collected here and appended with ONE atomic per chunk (per-group atomics on the per-image counter serialise
+  // in L2: 1850 of them on 8 addresses cost the 8 x 1080p launch 19 us).  The staging traffic goes through inline-asm
+  // ds_write / ds_read WITHOUT a memory clobber, on purpose: a compiler-visible LDS store in the pixel loop makes every
+  // loop-invariant LDS fragment (final conv, bias steps: 17 of them) be re-read per group behind serialised waits
+  // (+8 us per launch); nothing else touches this array and LDS operations of one wave execute in order.
+  constexpr int DEC_ST = 64;
+  __shared__ __attribute__((aligned(16))) char s_stage[DEC ? 4 * 2 * DEC_ST * 24 : 16];
+  const uint32_t st_base = (uint32_t)(uintptr_t)s_stage + (DEC ? wave * (2 * DEC_ST * 24) : 0);
+  int npend = 0;       // wave-uniform
+  uint32_t st_tok = 0; // orders the staging asm statements (data dependence instead of `volatile`)
 
   half8 w1[4][NKH], w2[PASS >= 2 ? 4 : 1][NKH];
   float scale = 1.f;
@@ -517,6 +529,50 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
     return r.v;
   };
 
+  // Append the staged candidates: ONE atomic per chunk and wave reserves the slots; its result is not awaited -- the
+  // staging buffer is double-buffered and the reserved range is filled when the NEXT chunk ends (or at kernel end), by
+  // which time the counter value has long arrived (a wave waiting ~2-5 us per chunk for a contended L2 atomic cost the
+  // 8 x 1080p launch 9 us).  No max-coordinate atomic: with one class the reference's class offsets are exactly zero
+  // (label 0 * (max + 1), nms.py:148-150) and lfd_detect_from_candidates skips them.
+  int pend_base = 0, pend_cnt = 0, pend_n = 0, sbuf = 0;       // reservation in flight (wave-uniform but for pend_base)
+  auto dec_copy_out = [&]() {
+    if constexpr (DEC) {
+      if (pend_cnt) {
+        const int base = __builtin_amdgcn_readfirstlane(pend_base);
+        const uint32_t sa = st_base + (sbuf ^ 1) * (DEC_ST * 24);
+        f32x4v bv;
+        float scv;
+        int ptv;
+        asm("ds_read_b128 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(bv), "=&v"(scv), "=&v"(ptv), "+v"(st_tok)
+            : "v"(sa + lane * 16), "v"(sa + DEC_ST * 16 + lane * 4), "v"(sa + DEC_ST * 20 + lane * 4));
+        if (lane < pend_cnt && base + lane < a.dec.cap) {
+          // (explicit global address space: a flat store / atomic may alias LDS as far as the compiler knows, and it would
+          //  re-read the loop-invariant LDS fragments it keeps in registers after each of them)
+          const size_t o = (size_t)pend_n * a.dec.cap + base + lane;
+          typedef __attribute__((address_space(1))) f32x4v gfloat4;
+          typedef __attribute__((address_space(1))) float gfloat;
+          typedef __attribute__((address_space(1))) int gint;
+          ((gfloat4*)(uintptr_t)a.dec.cand_box)[o] = bv;
+          ((gfloat*)(uintptr_t)a.dec.cand_score)[o] = scv;
+          ((gint*)(uintptr_t)a.dec.cand_label)[o] = 0;
+          ((gint*)(uintptr_t)a.dec.cand_point)[o] = ptv;
+        }
+        pend_cnt = 0;
+      }
+    }
+  };
+  auto dec_flush = [&](int n) {
+    if constexpr (DEC) {
+      dec_copy_out();                                  // the previous reservation (its staging buffer becomes free)
+      int base = 0;
+      if (lane == 0)
+        base = __hip_atomic_fetch_add((__attribute__((address_space(1))) int*)(uintptr_t)(a.dec.total + n), npend, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+      pend_base = base; pend_cnt = npend; pend_n = n;
+      sbuf ^= 1;
+    }
+  };
   H2_T(0);
   int cur_j = -1;
   for (int item = blockIdx.x; item < a.h2_nitems; item += gridDim.x) {
@@ -731,45 +787,40 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
             for (int q = 0; q < NKH; ++q)
               fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wf[(f * (NKH + 1) + q) * 64 + lane], bq[q], fa, 0, 0, 0);
             if constexpr (DEC) {
-              // ---- threshold + decode + append (front half of lfd_detect_batched: lfd.py:449-499, nms.py:202-207).
+              // ---- threshold + decode (front half of lfd_detect_batched: lfd.py:449-499, nms.py:202-207).
               //      Rows 0..3 (regression) sit in the pixel's hh = 0 lane, row 4 (the class logit) in its hh = 1 lane.
-              const float logit = __shfl(fa[0], pix + 32, 64);
-              const float r0 = fa[0] * scale, r1 = fa[1] * scale, r2 = fa[2] * scale, r3 = fa[3] * scale;
-              float sc = 0.f;
-              bool cand = false;
-              if (hh == 0 && lane_ok) { sc = lfd_sigmoidf_ref(logit); cand = sc > a.dec.score_thr; }
-              const unsigned long long cm = __ballot(cand);
-              if (cm) {                                   // wave-uniform: most groups have no candidate
-                int base = 0;
-                const int first = __builtin_ctzll(cm);
-                if (lane == first) base = atomicAdd(&a.dec.total[n], (int)__popcll(cm));
-                base = __builtin_amdgcn_readlane(base, first);
-                uint32_t mo = 0u;
-                if (cand) {
-                  const int slot = base + (int)__popcll(cm & ((1ull << lane) - 1ull));
-                  if (slot < a.dec.cap) {
+              //      Common case (no candidate in the group): one compare against a conservative logit bound + a ballot;
+              //      the exact test sigma(x) > thr, the partner's regression rows and the decode only behind it.
+              const bool pre = hh == 1 && lane_ok && fa[0] > a.dec.logit_lo;
+              if (__ballot(pre)) {
+                float sc = 0.f;
+                bool cand = false;
+                if (pre) { sc = lfd_sigmoidf_ref(fa[0]); cand = sc > a.dec.score_thr; }
+                const unsigned long long cm = __ballot(cand);
+                if (cm) {
+                  const float r0 = __shfl(fa[0] * scale, pix, 64), r1 = __shfl(fa[1] * scale, pix, 64);
+                  const float r2 = __shfl(fa[2] * scale, pix, 64), r3 = __shfl(fa[3] * scale, pix, 64);
+                  if (cand) {
+                    const int slot = npend + (int)__popcll(cm & ((1ull << lane) - 1ull));
                     const int q = p0 + pix, lw = a.dec.w[l];
                     const int iy = q / lw, ix = q - iy * lw;
-                    const float4 box = lfd_decode_core(a.dec.decode_mode, r0, r1, r2, r3, (float)(ix * a.dec.stride[l]),
-                                                       (float)(iy * a.dec.stride[l]), a.dec.m[l], a.dec.meta[n * 3 + 0],
-                                                       a.dec.meta[n * 3 + 1], a.dec.meta[n * 3 + 2]);
-                    const size_t o = (size_t)n * a.dec.cap + slot;
-                    a.dec.cand_box[o] = box;
-                    a.dec.cand_score[o] = sc;
-                    a.dec.cand_label[o] = 0;
-                    a.dec.cand_point[o] = L.p_off + q;
-                    mo = lfd_float_ord(fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
+                    const float4 bx = lfd_decode_core(a.dec.decode_mode, r0, r1, r2, r3, (float)(ix * a.dec.stride[l]),
+                                                      (float)(iy * a.dec.stride[l]), a.dec.m[l], a.dec.meta[n * 3 + 0],
+                                                      a.dec.meta[n * 3 + 1], a.dec.meta[n * 3 + 2]);
+                    f32x4v bv; bv[0] = bx.x; bv[1] = bx.y; bv[2] = bx.z; bv[3] = bx.w;
+                    const uint32_t sa = st_base + sbuf * (DEC_ST * 24);
+                    // (not volatile, no memory clobber: ordered against the read-back only through the token operand)
+                    asm("ds_write_b128 %1, %2\n\tds_write_b32 %3, %4\n\tds_write_b32 %5, %6"
+                        : "+v"(st_tok)
+                        : "v"(sa + slot * 16), "v"(bv), "v"(sa + DEC_ST * 16 + slot * 4), "v"(sc),
+                          "v"(sa + DEC_ST * 20 + slot * 4), "v"(L.p_off + q));
                   }
+                  npend += (int)__popcll(cm);
+                  if (npend > DEC_ST - 32) { dec_flush(n); npend = 0; }
                 }
-#pragma unroll
-                for (int sft = 32; sft > 0; sft >>= 1) {
-                  const uint32_t ot = __shfl_xor(mo, sft, 64);
-                  mo = ot > mo ? ot : mo;
-                }
-                if (lane == 0 && mo) atomicMax(&a.dec.maxord[n], mo);
               }
             }
-            if (lane_ok && (!DEC || a.out_cls)) {
+            if (!DEC && lane_ok) {
               // final rows: [reg x reg_rows][cls x cls_rows]; lane (pixel, hh) holds rows 8g + 4hh + j
               if (a.reg_rows == 4 && f == 0 && hh == 0)
                 *reinterpret_cast<float4*>(a.out_reg + row * 4) = make_float4(fa[0] * scale, fa[1] * scale, fa[2] * scale, fa[3] * scale);
@@ -807,9 +858,11 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
         }
       }
     }
+    if constexpr (DEC) { if (npend) { dec_flush(n); npend = 0; } }
     H2_T(16);
     H2_T(17);
   }
+  dec_copy_out();
 }
 
 #ifdef LFD_H2_TIMING
@@ -858,6 +911,21 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
   __shared__ double sm[8][64];
   __shared__ float s_ab[HC][2];
   const int n = blockIdx.x, l = blockIdx.y;
+  // fold: this thread's 8 source fragments (cout tile threadIdx.x / 64, k-steps 0..7) are requested up front -- their L2
+  // round trip hides under the statistics reduction below
+  const bool fold = f.wsrc[l] && f.wdst[l];
+  half4 f_lo[8], f_hi[8];
+  {
+    const int lane = threadIdx.x & 63, m = lane & 31, hk = lane >> 5, ct = threadIdx.x >> 6;
+    if (fold) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const _Float16* base = f.wsrc[l] + (size_t)(ct * 8 + k) * 64 * 8;
+        f_lo[k] = *reinterpret_cast<const half4*>(base + m * 8 + 4 * hk);
+        f_hi[k] = *reinterpret_cast<const half4*>(base + (m + 32) * 8 + 4 * hk);
+      }
+    }
+  }
   const int nv = f.ngroups * 2;                  // values per tile row
   const int t0 = f.tile_start[l] + n * f.tiles_per_img[l];
   const int tl = threadIdx.x >> 5, v0 = threadIdx.x & 31;
@@ -909,27 +977,26 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
   // ---- fold: this (level, image)'s copy of the tower conv with the scale in its rows (one fp16 rounding, the same
   //      arithmetic as k_head2's own fold) and the shift as a bias fragment, in k_head2's K-permuted register layout:
   //      element e of lane (m, hk) of fragment (ct, k) = W[32ct + m][16k + 8(e >> 2) + 4hk + (e & 3)]
-  if (f.wsrc[l] && f.wdst[l]) {
-    half8* dst = f.wdst[l] + (size_t)n * (4 * 9 * 64);
-    for (int i = threadIdx.x; i < 4 * 9 * 64; i += 256) {
-      const int ct = i / (9 * 64), k = (i / 64) % 9, lane = i & 63;
-      const int m = lane & 31, hk = lane >> 5;
+  if (fold) {
+    half8* __restrict__ dst = f.wdst[l] + (size_t)n * (4 * 9 * 64);
+    const int lane = threadIdx.x & 63, m = lane & 31, hk = lane >> 5;
+    const int ct = threadIdx.x >> 6;                 // 256 threads = 4 cout tiles x 64 lanes; fragments (ct, k = 0..8)
+    const float rs = s_ab[ct * 32 + m][0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
       half8 r;
-      if (k < 8) {
-        const float rs = s_ab[ct * 32 + m][0];
-        const _Float16* base = f.wsrc[l] + (size_t)(ct * 8 + k) * 64 * 8;
-        const half4 lo = *reinterpret_cast<const half4*>(base + m * 8 + 4 * hk);
-        const half4 hi = *reinterpret_cast<const half4*>(base + (m + 32) * 8 + 4 * hk);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { r[e] = (_Float16)((float)lo[e] * rs); r[4 + e] = (_Float16)((float)hi[e] * rs); }
-      } else {
-        const float v = s_ab[ct * 32 + m][1];
-        const _Float16 bh = (_Float16)v, bl = (_Float16)(v - (float)bh);
+      for (int e = 0; e < 4; ++e) { r[e] = (_Float16)((float)f_lo[k][e] * rs); r[4 + e] = (_Float16)((float)f_hi[k][e] * rs); }
+      dst[(ct * 9 + k) * 64 + lane] = r;
+    }
+    {
+      const float v = s_ab[ct * 32 + m][1];
+      const _Float16 bh = (_Float16)v, bl = (_Float16)(v - (float)bh);
+      half8 r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.f;
-        if (!hk) { r[0] = bh; r[1] = bl; }
-      }
-      dst[i] = r;
+      for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.f;
+      if (!hk) { r[0] = bh; r[1] = bl; }
+      dst[(ct * 9 + 8) * 64 + lane] = r;
     }
   }
 }
@@ -1025,7 +1092,7 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
       return LFD_ERR_LAUNCH_FAILED;
   }
   if (pass >= 2 && !ab1) return LFD_ERR_INVALID_ARGUMENT;
-  if (pass == 3 && (!ab2 || (!dec && (!out_cls || !out_reg)) || (!out_cls != !out_reg))) return LFD_ERR_INVALID_ARGUMENT;
+  if (pass == 3 && (!ab2 || (!dec && (!out_cls || !out_reg)))) return LFD_ERR_INVALID_ARGUMENT;
   if ((d->final_reg_rows != 0 && d->final_reg_rows != 4) || d->final_cls_rows < 0) return LFD_ERR_INVALID_ARGUMENT;
   const int ft = (d->final_reg_rows + d->final_cls_rows + 31) / 32;
   if (pass == 3 && (ft < 1 || ft > 2)) return LFD_ERR_UNSUPPORTED;

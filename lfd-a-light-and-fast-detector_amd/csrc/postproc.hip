@@ -710,6 +710,14 @@ int lfd_detect_bind_append(const lfd_detect_desc_t* desc, int32_t batch, const f
   out->cand_box = b.cand_box; out->cand_score = b.cand_score; out->cand_label = b.cand_label; out->cand_point = b.cand_point;
   out->maxord = b.maxord; out->total = b.total_ws; out->cap = b.cap;
   out->decode_mode = desc->decode_mode; out->score_thr = desc->score_thr; out->meta = img_meta;
+  {
+    // sigma(x) > thr  =>  x > logit(thr) up to the rounding of the device's expf / divide: widen generously
+    const double thr = (double)desc->score_thr;
+    double lo = -INFINITY;
+    if (thr >= 1.0) lo = INFINITY;                       // sigma(x) <= 1: nothing can pass
+    else if (thr > 0.0) { lo = log(thr / (1.0 - thr)); lo -= 1e-3 * (fabs(lo) > 1.0 ? fabs(lo) : 1.0); }
+    out->logit_lo = (float)lo;
+  }
   for (int i = 0; i < LFD_MAX_LEVELS; ++i) {
     const bool on = i < desc->num_levels;
     out->w[i] = on && desc->level_w[i] > 0 ? desc->level_w[i] : 1;
@@ -861,7 +869,9 @@ int lfd_detect_from_candidates(const lfd_detect_desc_t* desc, int32_t batch, flo
   b.k_host = 0;
   b.total = b.total_ws;
   b.nclass = desc->num_classes;
-  b.class_agnostic = desc->class_agnostic ? 1 : 0;
+  // one class: the class offsets are label 0 * (max + 1) = +0.0, adding them changes no bit -- skip them, and with them
+  // the max-coordinate reduction the producer would have to do
+  b.class_agnostic = (desc->class_agnostic || desc->num_classes == 1) ? 1 : 0;
   b.iou_thr = desc->iou_thr;
   ScanOut o{};
   o.dets = out_dets;
