@@ -28,6 +28,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -467,9 +468,14 @@ __device__ unsigned long long g_h2_dbg[3 * 32];
 #define H2_T(i)
 #endif
 
-template <int PASS, int FT, bool DEC = false>
+// FOLD (output pass only, every level has w1_folded / w2_folded): both tower filters are loaded straight into AccVGPRs by
+// inline asm and read from there by the MFMAs.  As ordinary values, 256 registers of filter + the working set exceed the
+// 256 architectural VGPRs and the allocator parks fragments in AccVGPRs, copying them back in front of every use: 144
+// v_accvgpr_read per pixel group in this pass, with nothing to overlap them (one wave per SIMD).
+template <int PASS, int FT, bool DEC = false, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
   static_assert(!DEC || (PASS == 3 && FT == 1), "decode rides on the output pass of a merged single-class tower");
+  static_assert(!FOLD || PASS == 3, "AccVGPR-resident filters: output pass");
   constexpr int NKN = 4, NKNX = 8, NKH = HC / 16;                      // neck k-steps per 64 input channels / maximum (128 channels)
   constexpr int WN_FRAGS = 4 * (NKNX + 1);                             // neck: 4 cout tiles x (up to 8 k-steps + bias step)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -491,7 +497,8 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
   int npend = 0;       // wave-uniform
   uint32_t st_tok = 0; // orders the staging asm statements (data dependence instead of `volatile`)
 
-  half8 w1[4][NKH], w2[PASS >= 2 ? 4 : 1][NKH];
+  half8 w1[FOLD ? 1 : 4][NKH], w2[(PASS >= 2 && !FOLD) ? 4 : 1][NKH];
+  u32x4v w1a[FOLD ? 4 : 1][NKH], w2a[FOLD ? 4 : 1][NKH];
   float scale = 1.f;
   union { half8 v; uint32_t u[4]; } ones_f;
   ones_f.u[0] = hh ? 0u : 0x3c003c00u; ones_f.u[1] = 0u; ones_f.u[2] = 0u; ones_f.u[3] = 0u;
@@ -623,6 +630,26 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       //  ~600 instructions of permute + scale + round -- 9.8 k cycles per chunk, 40 % of a two-group chunk at batch 1)
       const half8* f1 = (PASS >= 2 && L.w1f) ? L.w1f + (size_t)n * (4 * 9 * 64) : nullptr;
       const half8* f2 = (PASS == 3 && L.w2f) ? L.w2f + (size_t)n * (4 * 9 * 64) : nullptr;
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+          for (int k = 0; k < NKH; k += 4) {
+            const half8* p1 = f1 + (ct * 9 + k) * 64 + lane;
+            const half8* p2 = f2 + (ct * 9 + k) * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:1024\n\t"
+                         "global_load_dwordx4 %2, %8, off offset:2048\n\tglobal_load_dwordx4 %3, %8, off offset:3072\n\t"
+                         "global_load_dwordx4 %4, %9, off\n\tglobal_load_dwordx4 %5, %9, off offset:1024\n\t"
+                         "global_load_dwordx4 %6, %9, off offset:2048\n\tglobal_load_dwordx4 %7, %9, off offset:3072"
+                         : "=&a"(w1a[ct][k]), "=&a"(w1a[ct][k + 1]), "=&a"(w1a[ct][k + 2]), "=&a"(w1a[ct][k + 3]),
+                           "=&a"(w2a[ct][k]), "=&a"(w2a[ct][k + 1]), "=&a"(w2a[ct][k + 2]), "=&a"(w2a[ct][k + 3])
+                         : "v"(p1), "v"(p2) : "memory");
+          }
+          s_wb[ct * 64 + lane] = f1[(ct * 9 + 8) * 64 + lane];
+          s_wb[(4 + ct) * 64 + lane] = f2[(ct * 9 + 8) * 64 + lane];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the AccVGPR loads are invisible to the compiler's counters
+      } else
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         if (f1) {
@@ -762,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
         if constexpr (PASS >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[ct * 64 + lane], ones, zero, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < NKH; ++q)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ct][q], bq[q], (PASS >= 2 || q > 0) ? acc : zero, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FOLD ? __builtin_bit_cast(half8, w1a[FOLD ? ct : 0][q]) : w1[FOLD ? 0 : ct][q], bq[q], (PASS >= 2 || q > 0) ? acc : zero, 0, 0, 0);
         if constexpr (PASS == 1) add_stats(acc, ct, lane_ok ? 1.f : 0.f, tail);
         else { bqn[2 * ct] = to_b(acc, 0); bqn[2 * ct + 1] = to_b(acc, 1); }
       }
@@ -774,7 +801,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
           if constexpr (PASS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[(4 + ct) * 64 + lane], ones, zero, 0, 0, 0);
 #pragma unroll
           for (int q = 0; q < NKH; ++q)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ct][q], bqn[q], (PASS == 3 || q > 0) ? acc : zero, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FOLD ? __builtin_bit_cast(half8, w2a[FOLD ? ct : 0][q]) : w2[FOLD ? 0 : ct][q], bqn[q], (PASS == 3 || q > 0) ? acc : zero, 0, 0, 0);
           if constexpr (PASS == 2) add_stats(acc, ct, lane_ok ? 1.f : 0.f, tail);
           else { bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1); }
         }
@@ -873,19 +900,19 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_h2_timing(unsign
 namespace {
 #endif
 
-template <int PASS, int FT, bool DEC = false>
+template <int PASS, int FT, bool DEC = false, bool FOLD = false>
 int launch_head2(const HeadArgs& a, hipStream_t st) {
   constexpr int LDS = (4 * 9 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT, DEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT, DEC, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
   int blocks = a.h2_nitems < 256 ? a.h2_nitems : 256;
   if (blocks < 1) return LFD_OK;
-  hipLaunchKernelGGL((k_head2<PASS, FT, DEC>), dim3(blocks), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((k_head2<PASS, FT, DEC, FOLD>), dim3(blocks), dim3(256), LDS, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1113,12 +1140,16 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
     }
     if (pass == 1) return launch_head2<1, 1>(a, st);
     if (pass == 2) return launch_head2<2, 1>(a, st);
+    bool fold = true;      // every level brings both folded filters -> AccVGPR-resident variant
+    for (int i = 0; i < d->num_levels; ++i) fold = fold && lv[i].w1_folded && lv[i].w2_folded;
+    { static const int use = [] { const char* e = getenv("LFD_H2_AGPR"); return e ? atoi(e) : 1; }(); fold = fold && use; }
     if (dec) {
       if (ft != 1 || d->final_reg_rows != 4 || d->final_cls_rows != 1) return LFD_ERR_UNSUPPORTED;
       a.dec = *dec;
-      return launch_head2<3, 1, true>(a, st);
+      return fold ? launch_head2<3, 1, true, true>(a, st) : launch_head2<3, 1, true>(a, st);
     }
-    return ft == 2 ? launch_head2<3, 2>(a, st) : launch_head2<3, 1>(a, st);
+    if (ft == 2) return fold ? launch_head2<3, 2, false, true>(a, st) : launch_head2<3, 2>(a, st);
+    return fold ? launch_head2<3, 1, false, true>(a, st) : launch_head2<3, 1>(a, st);
   }
   if (dec) return LFD_ERR_UNSUPPORTED;
   // one launch per tap-channel class (64 / 128): homogeneous tiles, compile-time ring geometry
