@@ -190,6 +190,19 @@ def test_head_pass_that_appends_its_own_candidates_equals_the_unfused_step(shape
                 assert k > 0
                 assert torch.equal(f.dets[n, :k], ref[1][n, :k]) and torch.equal(f.labels[n, :k], ref[2][n, :k])
                 assert torch.equal(f.point[n, :k], ref[3][n, :k])
+    # capacity overflow: the counters keep counting, the slots beyond the capacity are dropped, the flag is raised (the
+    # retained subset is arbitrary in the fused path -- documented -- so only the bookkeeping is compared)
+    with torch.no_grad():
+        m.use_graph = False
+        u = m.detect_resident(x, meta, score_thr=thr, max_candidates=8)
+        torch.cuda.synchronize()
+        uc = u.counts.clone()
+        m.use_graph = True
+        for _ in range(2):
+            f = m.detect_resident(x, meta, score_thr=thr, max_candidates=8)
+            torch.cuda.synchronize()
+            assert torch.equal(f.counts[:, [0, 2, 3]], uc[:, [0, 2, 3]]) and int(f.counts[:, 2].min()) == 1
+            assert int(f.counts[:, 1].max()) <= 8 and int(f.counts[:, 1].min()) >= 1
     # the fused pass really ran: this model / descriptor is covered
     desc, _ = m._detect_desc(thr, m._nms_cfg.get('iou_thr', 0.5), m._nms_cfg.get('class_agnostic', False), 4096)
     assert plan.decode_supported(plan.state_for(*([shape[0], shape[1], shape[2]]), 0), desc)
