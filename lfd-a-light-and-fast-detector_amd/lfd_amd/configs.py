@@ -47,8 +47,8 @@ ARCHS = {
     'TT100K_LFD_S': _tt('faster', [4, 2, 1, 1], [64, 64, 64, 128], ((0, 3), (1, 1), (2, 0), (3, 0))),
     'TL_LFD_L': _tl(64, [5, 3, 2, 2, 2], [64, 64, 128, 128, 128], ((0, 4), (1, 2), (2, 1), (3, 1), (4, 1)),
                     ((4, 32), (32, 64), (64, 128), (128, 256), (256, 512))),
-    # 48-channel stem / first stage: module tree, checkpoints, losses and training through PyTorch-ROCm work; the MFMA conv
-    # kernels are instantiated for 32 / 64 / 128 channels, so the inference engine refuses this one loudly
+    # 48-channel stem / first stage: the inference engine runs them zero-padded to 64 channels (engine.pad_channels: the real
+    # channels are bit-identical to an unpadded evaluation); training goes through PyTorch-ROCm autograd for this config
     'TL_LFD_S': _tl(48, [4, 2, 1, 1, 1], [48, 64, 64, 128, 128], ((0, 3), (1, 1), (2, 0), (3, 0), (4, 0)),
                     ((0, 16), (16, 32), (32, 64), (64, 128), (128, 256))),
 }

@@ -31,8 +31,36 @@ def _unsupported(msg):
 
 
 # ---------------------------------------------------------------------------- weight preparation
+def pad_channels(c):
+    """The MFMA kernels are instantiated for 32 / 64 / 128 channels.  Any other width (TL_LFD_S: a 48-channel stem and first
+    stage, TrafficLight_train/TL_LFD_S.py) runs zero-padded to the next one: padded output channels have zero weights and a
+    zero bias, so they stay exactly 0 through ReLU / residual adds and meet zero weights in every consumer -- the real
+    channels are bit-identical to an unpadded evaluation.  3 (the image) is left alone."""
+    if c == 3:
+        return c
+    for a in (32, 64, 128):
+        if c <= a:
+            return a
+    _unsupported('more than 128 channels')
+
+
+def _pad_wb(w, b):
+    co, ci = pad_channels(w.shape[0]), pad_channels(w.shape[1])
+    if (co, ci) == tuple(w.shape[:2]):
+        return w, b
+    wp = torch.zeros((co, ci) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+    wp[:w.shape[0], :w.shape[1]] = w
+    bp = torch.zeros(co, dtype=b.dtype, device=b.device)
+    bp[:b.shape[0]] = b
+    return wp, bp
+
+
 def fold_conv_norm(conv, norm):
-    """(conv, eval-mode BatchNorm2d | None) -> (weight fp32 OIHW, bias fp32)."""
+    """(conv, eval-mode BatchNorm2d | None) -> (weight fp32 OIHW, bias fp32), channels zero-padded (pad_channels)."""
+    return _pad_wb(*_fold_conv_norm(conv, norm))
+
+
+def _fold_conv_norm(conv, norm):
     w = conv.weight.detach().float()
     b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
     if norm is None:
@@ -127,7 +155,7 @@ class EnginePlan(object):
         for i, (k, s, cin, cout) in enumerate(bb.stem_spec()):
             conv = bb._stem[i * step]
             norm = bb._stem[i * step + 1] if has_norm else None
-            stem_convs.append((k, s, cin, cout) + fold_conv_norm(conv, norm))
+            stem_convs.append((k, s, pad_channels(cin), pad_channels(cout)) + fold_conv_norm(conv, norm))
         import os
         self.fuse_blocks = os.environ.get('LFD_FUSED_BLOCK', '1') == '1'
         self.stem_first = None   # (C, w1, b1, w2|None, b2|None)
@@ -192,21 +220,23 @@ class EnginePlan(object):
                     dnorm = blk._downsample[1] if len(blk._downsample) > 1 else None
                     w, b = fold_conv_norm(dconv, dnorm)
                     c1 = blk._conv1
+                    P = pad_channels
                     if (c1.kernel_size[0] == 3 and c1.stride[0] == 2 and c1.out_channels == dconv.out_channels and
                             c1.in_channels == dconv.in_channels and blk.num_convs == 2):
                         # identity branch rides on the block's 3x3 stride-2 conv (one launch, one input read)
                         ident = new_buf()
-                        self.buf_channels[ident] = dconv.out_channels
+                        self.buf_channels[ident] = P(dconv.out_channels)
                         self.buf_scale[ident] = self.buf_scale[x_in] * 2
                         fuse_ds = (ops.pack_conv_weight(w).to(dev), b.to(dev).contiguous(), ident, w)
                     else:
-                        ident = self._add_conv(x_in, new_buf, dconv.in_channels, dconv.out_channels, 1, 2, False, w, b)
+                        ident = self._add_conv(x_in, new_buf, P(dconv.in_channels), P(dconv.out_channels), 1, 2, False, w, b)
                 nconv = blk.num_convs
                 y = x_in
                 ci = 1
                 if (self.fuse_blocks and blk._downsample is None and nconv == 2 and
                         all(getattr(blk, '_conv%d' % q).kernel_size[0] == 3 and getattr(blk, '_conv%d' % q).stride[0] == 1 and
-                            getattr(blk, '_conv%d' % q).in_channels == 64 and getattr(blk, '_conv%d' % q).out_channels == 64
+                            pad_channels(getattr(blk, '_conv%d' % q).in_channels) == 64 and
+                            pad_channels(getattr(blk, '_conv%d' % q).out_channels) == 64
                             for q in (1, 2))):
                     # whole residual block in one launch (csrc/block.hip): the intermediate map never reaches HBM
                     w1, b1 = fold_conv_norm(blk._conv1, getattr(blk, '_norm1', None))
@@ -223,16 +253,18 @@ class EnginePlan(object):
                     if (not last) and ci + 1 < nconv:
                         nxt = getattr(blk, '_conv%d' % (ci + 1))
                         if (nxt.kernel_size[0] == 1 and nxt.out_channels == conv.out_channels and
-                                _tail_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0])):
+                                _tail_supported(pad_channels(conv.in_channels), pad_channels(conv.out_channels), conv.kernel_size[0],
+                                                conv.stride[0])):
                             w2, b2 = fold_conv_norm(nxt, getattr(blk, '_norm%d' % (ci + 1), None))
                             tail = (ops.pack_conv_weight(w2).to(dev), b2.to(dev), True, w2)   # FastBlock 3x3 -> 1x1
-                    y = self._add_conv(y, new_buf, conv.in_channels, conv.out_channels, conv.kernel_size[0],
+                    y = self._add_conv(y, new_buf, pad_channels(conv.in_channels), pad_channels(conv.out_channels), conv.kernel_size[0],
                                        conv.stride[0], True, w, b, tail=tail, res=ident if last else None,
                                        ds=fuse_ds if ci == 1 else None)
                     ci += 2 if tail is not None else 1
                 cur = y
                 if (i, j) in [tuple(t) for t in bb._out_indices]:
                     self.taps.append(cur)
+                    self.tap_channels = getattr(self, 'tap_channels', []) + [getattr(blk, '_conv%d' % blk.num_convs).out_channels]
                     self.tap_ready_after.append(len(self.convs))   # number of conv launches that must precede
         self.num_bufs = nbuf[0]
 
@@ -281,7 +313,7 @@ class EnginePlan(object):
             nseq = getattr(neck, 'neck%d' % i)
             nconv = nseq[0]
             wn, bn = fold_conv_norm(nconv, nseq[1] if neck._norm_cfg is not None else None)
-            lv.cin = nconv.in_channels
+            lv.cin = pad_channels(nconv.in_channels)
             if lv.cin not in (64, 128):
                 _unsupported('backbone tap channels must be 64 or 128')
             lv.wn = ops.pack_conv_weight(wn).to(dev)
@@ -694,4 +726,4 @@ def backbone_only_forward(backbone, x):
     st = plan.state_for(n, h, w)
     with torch.cuda.device(x.device):
         plan.run_backbone(x.contiguous(), fmt, st)
-    return tuple(st.bufs[t].permute(0, 3, 1, 2).float() for t in plan.taps)
+    return tuple(st.bufs[t][..., :c].permute(0, 3, 1, 2).float() for t, c in zip(plan.taps, plan.tap_channels))

@@ -154,7 +154,7 @@ def main():
 
     # ---------------------------------------------------------------- 4. reference model runs
     for name, (N, H, W) in (('WIDERFACE_LFD_XS', (2, 96, 128)), ('WIDERFACE_LFD_S', (1, 72, 104)),
-                            ('TT100K_LFD_L', (1, 64, 96)), ('TL_LFD_L', (1, 64, 128))):
+                            ('TT100K_LFD_L', (1, 64, 96)), ('TL_LFD_L', (1, 64, 128)), ('TL_LFD_S', (1, 72, 120))):
         if only_model is not None and name != only_model:
             continue
         arch = configs.ARCHS[name]

@@ -26,7 +26,7 @@ def _golden(name):
     return g, m, x
 
 
-@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L'])
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L', 'TL_LFD_S'])
 def test_forward_vs_reference_fp32_golden(name):
     g, m, x = _golden(name)
     m.cuda()
@@ -48,7 +48,7 @@ def test_forward_vs_reference_fp32_golden(name):
 
 @pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_XS', (2, 96, 128)), ('WIDERFACE_LFD_S', (2, 135, 241)),
                                         ('WIDERFACE_LFD_L', (1, 100, 156)), ('TT100K_LFD_L', (1, 90, 161)),
-                                        ('TT100K_LFD_S', (1, 64, 64)), ('WIDERFACE_LFD_M', (1, 64, 96)), ('TL_LFD_L', (1, 128, 192))])
+                                        ('TT100K_LFD_S', (1, 64, 64)), ('WIDERFACE_LFD_M', (1, 64, 96)), ('TL_LFD_L', (1, 128, 192)), ('TL_LFD_S', (2, 120, 168))])
 def test_forward_vs_fp16_emulating_oracle(name, shape):
     m = configs.build_model(name)
     configs.perturb_weights(m)

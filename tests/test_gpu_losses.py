@@ -97,7 +97,7 @@ def test_iou_loss_forward_backward():
 
 
 @pytest.mark.parametrize('fused', ['1', '0'])
-@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L'])
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L', 'TL_LFD_S'])
 def test_get_loss_vs_reference_golden(name, fused, monkeypatch):
     """LFD.get_loss on the reference's own predictions + annotations: loss values and gradients
     w.r.t. the predictions match the reference (its focal path ran through the C restatement).
@@ -229,7 +229,7 @@ def test_fused_get_loss_sums_are_deterministic_and_global_normaliser():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L'])
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L', 'TL_LFD_S'])
 def test_device_target_assignment_bit_exact_vs_reference_golden(name):
     """lfd_assign_targets_f32 (csrc/targets.hip) == the reference's annotation_to_target output (golden, generated by
     the real reference on the CPU), bit for bit: cls targets incl. gray (-1) cells, and reg targets of EVERY point

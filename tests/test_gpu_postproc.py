@@ -116,7 +116,7 @@ def _model_with_sizes(name, sizes):
     return m
 
 
-@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L'])
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L', 'TL_LFD_S'])
 def test_decode_all_vs_oracle(name):
     g = load_golden('ref_model_%s.npz' % name)
     arch = configs.ARCHS[name]
@@ -136,7 +136,7 @@ def test_decode_all_vs_oracle(name):
         np.testing.assert_allclose(scores[n].cpu().numpy(), rs, rtol=2e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L'])
+@pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S', 'TT100K_LFD_L', 'TL_LFD_L', 'TL_LFD_S'])
 def test_get_results_index_exact_vs_reference_golden(name):
     """G3: decode+NMS fed the reference's own fp32 cls/reg -> same kept detections as the
     reference's get_results (labels identical, coordinates to fp32 rounding of sigmoid)."""

@@ -81,8 +81,15 @@ def test_bn_fold_matches_eval_batchnorm():
     w, b = engine.fold_conv_norm(conv, bn)
     x = torch.randn(2, 8, 9, 11)
     ref = bn(conv(x))
-    got = torch.nn.functional.conv2d(x, w, b, padding=1)
-    torch.testing.assert_close(got, ref, atol=2e-6, rtol=1e-5)
+    # channel widths the MFMA kernels are not instantiated for come back zero-padded to 32 / 64 / 128 (engine.pad_channels):
+    # the real channels are unchanged, the padded outputs are exactly zero, padded inputs meet zero weights
+    assert tuple(w.shape) == (32, 32, 3, 3) and tuple(b.shape) == (32,)
+    assert float(w[16:].abs().max()) == 0.0 and float(w[:, 8:].abs().max()) == 0.0 and float(b[16:].abs().max()) == 0.0
+    xp = torch.cat([x, torch.randn(2, 24, 9, 11)], 1)
+    got = torch.nn.functional.conv2d(xp, w, b, padding=1)
+    torch.testing.assert_close(got[:, :16], ref, atol=2e-6, rtol=1e-5)
+    assert float(got[:, 16:].abs().max()) == 0.0
+    assert [engine.pad_channels(c) for c in (3, 32, 48, 64, 96, 128)] == [3, 32, 64, 64, 128, 128]
 
 
 def test_pack_conv_weight_fragment_order():
