@@ -256,7 +256,7 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   // five row-aligned instructions of 8 slots; wave w issues rows w, w+4, ...  The slot -> (column, swizzled chunk) map of
   // the five parts is computed once per tile (30 VALU), each instruction adds a scalar row base and selects the zero line
   // for out-of-image pixels.  The generic slot walk cost 4.5 k cycles of issue per tile against 1.5 k of contraction
-  // (integer divisions by 34 and 64-bit multiplies per instruction, tools: scratch/conv_s2_timing.py).
+  // (integer divisions by 34 and 64-bit multiplies per instruction, tools/timing/conv_s2_phases.py).
   constexpr bool FAST2 = (CIN == 64 && KS == 3 && S == 2 && !TAIL);
   auto issue_dma_s2 = [&](int t, int buf) {
     int ol = lane;
