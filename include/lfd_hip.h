@@ -469,8 +469,13 @@ typedef struct lfd_head_level_ptrs {
    * by lfd_groupnorm_finalize_fold(which = 1 / 2), read by passes 2-3 / pass 3.  NULL: every work chunk folds on its own. */
   void* w1_folded;
   void* w2_folded;
+  /* optional scratch, n * ceil(hw / 32) * LFD_HEAD_TOWER1_GROUP_HALFS halfs: ReLU(GN1(conv1)) of every pixel in fp16, as the MFMA
+   * fragments pass 2 feeds its conv2 with.  Pass 2 writes it; when every level has it (and both folded filters) pass 3 /
+   * lfd_head_forward_decode_f16 load it instead of recomputing neck + conv1: same bits, 45 instead of 101 MFMAs per 32 pixels. */
+  void* tower1_out;
 } lfd_head_level_ptrs_t;
 #define LFD_HEAD_FOLDED_HALFS (4 * 9 * 64 * 8)
+#define LFD_HEAD_TOWER1_GROUP_HALFS (8 * 64 * 8)
 
 LFD_API size_t lfd_head_partial_floats(const lfd_head_desc_t* desc);
 LFD_API int lfd_head_forward_f16(const lfd_head_desc_t* desc, int32_t pass,

@@ -46,6 +46,8 @@ struct HeadLevel {
   const float* scale;    // per-level Scale parameter (device scalar) or nullptr
   const half8* w1f;      // [N][4][9][64] tower conv 1 / 2 with GroupNorm folded in (k_gn_finalize), K-permuted fragments,
   const half8* w2f;      //               k-step 8 = the shift as a bias fragment; or nullptr (fold per work chunk)
+  half8* a1;             // [N][groups of 32 pixels][8][64]: ReLU(GN1(conv1)) of every pixel as conv2's B fragments, written by
+                         // pass 2 and read by the output pass instead of recomputing neck + conv1; or nullptr
   int cin, hw, p_off;    // tap channels, pixels per image, first point of the level
   int tile_start;        // first global tile of this level
   int tiles_per_img;
@@ -472,10 +474,14 @@ __device__ unsigned long long g_h2_dbg[3 * 32];
 // inline asm and read from there by the MFMAs.  As ordinary values, 256 registers of filter + the working set exceed the
 // 256 architectural VGPRs and the allocator parks fragments in AccVGPRs, copying them back in front of every use: 144
 // v_accvgpr_read per pixel group in this pass, with nothing to overlap them (one wave per SIMD).
-template <int PASS, int FT, bool DEC = false, bool FOLD = false>
+// A1 (output pass, with FOLD): conv2's B fragments -- ReLU(GN1(conv1(neck(x)))) in fp16, exactly the registers pass 2 fed its own
+// conv2 with -- are loaded from the buffer pass 2 wrote (lfd_head_level_ptrs_t.tower1_out) instead of recomputed: 45 instead of
+// 101 MFMAs per pixel group, no neck / conv1 filters, bit-identical outputs; costs 256 B per pixel of HBM write + read.
+template <int PASS, int FT, bool DEC = false, bool FOLD = false, bool A1 = false>
 __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
   static_assert(!DEC || (PASS == 3 && FT == 1), "decode rides on the output pass of a merged single-class tower");
   static_assert(!FOLD || PASS == 3, "AccVGPR-resident filters: output pass");
+  static_assert(!A1 || FOLD, "stored tower-1 activations: output pass with folded filters");
   constexpr int NKN = 4, NKNX = 8, NKH = HC / 16;                      // neck k-steps per 64 input channels / maximum (128 channels)
   constexpr int WN_FRAGS = 4 * (NKNX + 1);                             // neck: 4 cout tiles x (up to 8 k-steps + bias step)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
   uint32_t st_tok = 0; // orders the staging asm statements (data dependence instead of `volatile`)
 
   half8 w1[FOLD ? 1 : 4][NKH], w2[(PASS >= 2 && !FOLD) ? 4 : 1][NKH];
-  u32x4v w1a[FOLD ? 4 : 1][NKH], w2a[FOLD ? 4 : 1][NKH];
+  u32x4v w1a[(FOLD && !A1) ? 4 : 1][NKH], w2a[FOLD ? 4 : 1][NKH];
   float scale = 1.f;
   union { half8 v; uint32_t u[4]; } ones_f;
   ones_f.u[0] = hh ? 0u : 0x3c003c00u; ones_f.u[1] = 0u; ones_f.u[2] = 0u; ones_f.u[3] = 0u;
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
       for (int k = 0; k < NKNX; ++k) {
         const int i = threadIdx.x + 256 * k;
-        if (i < 4 * nkl * 64) t_wn[k] = L.wn[i];
+        if (!A1 && i < 4 * nkl * 64) t_wn[k] = L.wn[i];
       }
       t_bn = L.bn[wave * 32 + (lane & 31)];
       if constexpr (PASS == 3) {
@@ -630,7 +636,24 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       //  ~600 instructions of permute + scale + round -- 9.8 k cycles per chunk, 40 % of a two-group chunk at batch 1)
       const half8* f1 = (PASS >= 2 && L.w1f) ? L.w1f + (size_t)n * (4 * 9 * 64) : nullptr;
       const half8* f2 = (PASS == 3 && L.w2f) ? L.w2f + (size_t)n * (4 * 9 * 64) : nullptr;
-      if constexpr (FOLD) {
+      if constexpr (FOLD && A1) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+          for (int k = 0; k < NKH; k += 8) {
+            const half8* p2 = f2 + (ct * 9 + k) * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:1024\n\t"
+                         "global_load_dwordx4 %2, %8, off offset:2048\n\tglobal_load_dwordx4 %3, %8, off offset:3072\n\t"
+                         "global_load_dwordx4 %4, %9, off\n\tglobal_load_dwordx4 %5, %9, off offset:1024\n\t"
+                         "global_load_dwordx4 %6, %9, off offset:2048\n\tglobal_load_dwordx4 %7, %9, off offset:3072"
+                         : "=&a"(w2a[ct][k]), "=&a"(w2a[ct][k + 1]), "=&a"(w2a[ct][k + 2]), "=&a"(w2a[ct][k + 3]),
+                           "=&a"(w2a[ct][k + 4]), "=&a"(w2a[ct][k + 5]), "=&a"(w2a[ct][k + 6]), "=&a"(w2a[ct][k + 7])
+                         : "v"(p2), "v"(p2 + 4 * 64) : "memory");
+          }
+          s_wb[(4 + ct) * 64 + lane] = f2[(ct * 9 + 8) * 64 + lane];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if constexpr (FOLD) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
@@ -682,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
       for (int k = 0; k < NKNX; ++k) {
         const int i = threadIdx.x + 256 * k;
-        if (i < 4 * nkl * 64) {
+        if (!A1 && i < 4 * nkl * 64) {
           const int cc = i / (nkl * 64), r = i - cc * (nkl * 64);
           s_wn[cc * (NKNX + 1) * 64 + r] = t_wn[k];
         }
@@ -742,8 +765,17 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
       for (int q = 0; q < NKN; ++q) xq[q] = *reinterpret_cast<const half8*>(ximg + (size_t)p * cin + 64 * half + 16 * q);
     };
+    // tower-1 activations of this image: fragments q = 0..7 of group g at ((n * gpi + g) * 8 + q) * 64 + lane
+    half8* a1img = L.a1 ? L.a1 + ((size_t)n * gpi) * (NKH * 64) + lane : nullptr;
+    half8 a1n[A1 ? NKH : 1];
+    auto load_a1 = [&](int g) {
+      if constexpr (A1) {
+#pragma unroll
+        for (int q = 0; q < NKH; ++q) a1n[q] = a1img[((size_t)g * NKH + q) * 64];
+      }
+    };
     H2_T(2);
-    load_x(g0, 0);
+    if constexpr (A1) load_a1(g0); else load_x(g0, 0);
     for (int g = g0; g < g1; ++g) {
       if (g - g0 < 12) H2_T(3 + (g - g0));
       const int p0 = g * 32;
@@ -753,6 +785,11 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       // (statistics / ReLU + fp16 pack into the next stage's B operands) before the next tile starts -- at most
       // bq (inputs) + bqn (outputs) + one accumulator are live, instead of four accumulators per stage.
       half8 bq[NKH], bqn[NKH];
+      if constexpr (A1) {
+#pragma unroll
+        for (int q = 0; q < NKH; ++q) bqn[q] = a1n[q];
+        if (g + 1 < g1) load_a1(g + 1);
+      } else {
       // ---- neck: relu(Wn x + bn)
       if (cin == 64) {
 #pragma unroll
@@ -792,6 +829,13 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FOLD ? __builtin_bit_cast(half8, w1a[FOLD ? ct : 0][q]) : w1[FOLD ? 0 : ct][q], bq[q], (PASS >= 2 || q > 0) ? acc : zero, 0, 0, 0);
         if constexpr (PASS == 1) add_stats(acc, ct, lane_ok ? 1.f : 0.f, tail);
         else { bqn[2 * ct] = to_b(acc, 0); bqn[2 * ct + 1] = to_b(acc, 1); }
+      }
+      }   // !A1
+      if constexpr (PASS == 2) {
+        if (a1img) {           // wave-uniform: hand conv2's operands to the output pass
+#pragma unroll
+          for (int q = 0; q < NKH; ++q) a1img[((size_t)g * NKH + q) * 64] = bqn[q];
+        }
       }
       if constexpr (PASS >= 2) {
         // ---- conv2 (pass 3: GN2 folded in)
@@ -900,19 +944,19 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_h2_timing(unsign
 namespace {
 #endif
 
-template <int PASS, int FT, bool DEC = false, bool FOLD = false>
+template <int PASS, int FT, bool DEC = false, bool FOLD = false, bool A1 = false>
 int launch_head2(const HeadArgs& a, hipStream_t st) {
   constexpr int LDS = (4 * 9 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT, DEC, FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT, DEC, FOLD, A1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
   int blocks = a.h2_nitems < 256 ? a.h2_nitems : 256;
   if (blocks < 1) return LFD_OK;
-  hipLaunchKernelGGL((k_head2<PASS, FT, DEC, FOLD>), dim3(blocks), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL((k_head2<PASS, FT, DEC, FOLD, A1>), dim3(blocks), dim3(256), LDS, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1106,6 +1150,7 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
     L.w1 = (const half8*)lv[i].w1_packed; L.w2 = (const half8*)lv[i].w2_packed;
     L.wf = (const half8*)lv[i].wf_packed; L.bf = lv[i].bf; L.scale = lv[i].scale;
     L.w1f = (const half8*)lv[i].w1_folded; L.w2f = (const half8*)lv[i].w2_folded;
+    L.a1 = (half8*)lv[i].tower1_out;
     L.cin = d->level_cin[i]; L.hw = d->level_hw[i]; L.p_off = d->level_point_offset[i];
     L.tile_start = ts[i]; L.tiles_per_img = tp[i];
   }
@@ -1143,13 +1188,17 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
     bool fold = true;      // every level brings both folded filters -> AccVGPR-resident variant
     for (int i = 0; i < d->num_levels; ++i) fold = fold && lv[i].w1_folded && lv[i].w2_folded;
     { static const int use = [] { const char* e = getenv("LFD_H2_AGPR"); return e ? atoi(e) : 1; }(); fold = fold && use; }
+    bool a1 = fold;        // ... and pass 2 left conv2's operands behind -> no neck / conv1 recompute
+    for (int i = 0; i < d->num_levels; ++i) a1 = a1 && lv[i].tower1_out;
+    { static const int use = [] { const char* e = getenv("LFD_H2_A1"); return e ? atoi(e) : 1; }(); a1 = a1 && use; }
     if (dec) {
       if (ft != 1 || d->final_reg_rows != 4 || d->final_cls_rows != 1) return LFD_ERR_UNSUPPORTED;
       a.dec = *dec;
+      if (a1) return launch_head2<3, 1, true, true, true>(a, st);
       return fold ? launch_head2<3, 1, true, true>(a, st) : launch_head2<3, 1, true>(a, st);
     }
-    if (ft == 2) return fold ? launch_head2<3, 2, false, true>(a, st) : launch_head2<3, 2>(a, st);
-    return fold ? launch_head2<3, 1, false, true>(a, st) : launch_head2<3, 1>(a, st);
+    if (ft == 2) return a1 ? launch_head2<3, 2, false, true, true>(a, st) : (fold ? launch_head2<3, 2, false, true>(a, st) : launch_head2<3, 2>(a, st));
+    return a1 ? launch_head2<3, 1, false, true, true>(a, st) : (fold ? launch_head2<3, 1, false, true>(a, st) : launch_head2<3, 1>(a, st));
   }
   if (dec) return LFD_ERR_UNSUPPORTED;
   // one launch per tap-channel class (64 / 128): homogeneous tiles, compile-time ring geometry

@@ -582,6 +582,14 @@ class _ShapeState(object):
                             call['folded'] = torch.empty((nl, 2, n, _lib.HEAD_FOLDED_HALFS), dtype=torch.float16, device=dev)
                             for k in range(nl):
                                 lvp[k].w1_folded, lvp[k].w2_folded = call['folded'][k, 0].data_ptr(), call['folded'][k, 1].data_ptr()
+                            if os.environ.get('LFD_HEAD_A1', '1') != '0':
+                                # ... and conv2's operands (tower-1 activations) handed from pass 2 to the output pass
+                                call['tower1'] = []
+                                for k, li in enumerate(lg):
+                                    hh, ww = self.sizes[li]
+                                    t1 = torch.empty((n, (hh * ww + 31) // 32, _lib.HEAD_TOWER1_GROUP_HALFS), dtype=torch.float16, device=dev)
+                                    call['tower1'].append(t1)
+                                    lvp[k].tower1_out = t1.data_ptr()
                         if plan.head_gn:
                             call['ab1'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
                             call['ab2'] = torch.empty((nl, n, 128, 2), dtype=torch.float32, device=dev)
