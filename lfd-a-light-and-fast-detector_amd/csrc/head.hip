@@ -790,40 +790,60 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
         for (int q = 0; q < NKH; ++q) bqn[q] = a1n[q];
         if (g + 1 < g1) load_a1(g + 1);
       } else {
-      // ---- neck: relu(Wn x + bn)
+      // ---- neck: relu(Wn x + bn).  The filter fragments come from LDS through a 4-deep register ring: read right in front
+      //      of their MFMA (what the compiler emits on its own) every one of the 20 / 36 k-steps waited a full LDS round
+      //      trip -- ~1300 cycles per group, a quarter of pass 1.
+      constexpr int WPD = 3;
+      half8 wring[WPD + 1];
       if (cin == 64) {
+        auto fidx = [](int i) { return (i / 5) * (NKNX + 1) + ((i % 5) == 0 ? NKNX : (i % 5) - 1); };   // bias step, then q = 0..3
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + NKNX) * 64 + lane], ones, zero, 0, 0, 0);
+        for (int i = 0; i < WPD; ++i) wring[i] = s_wn[fidx(i) * 64 + lane];
+        f32x16 acc;
 #pragma unroll
-          for (int q = 0; q < NKN; ++q)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + q) * 64 + lane], xq[q], acc, 0, 0, 0);
-          bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1);
+        for (int i = 0; i < 20; ++i) {
+          if (i + WPD < 20) wring[(i + WPD) % (WPD + 1)] = s_wn[fidx(i + WPD) * 64 + lane];
+          const int ct = i / 5, j = i % 5;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wring[i % (WPD + 1)], j == 0 ? ones : xq[j == 0 ? 0 : j - 1], j == 0 ? zero : acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j == 4) { bq[2 * ct] = to_b(acc, 0); bq[2 * ct + 1] = to_b(acc, 1); }
         }
       } else {
         f32x16 acc4[4];
+        auto fidx0 = [](int i) { return (i / 5) * (NKNX + 1) + ((i % 5) == 0 ? NKNX : (i % 5) - 1); };   // first 64 channels
+        auto fidx1 = [](int i) { return (i / 4) * (NKNX + 1) + NKN + (i % 4); };                       // second 64 channels
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + NKNX) * 64 + lane], ones, zero, 0, 0, 0);
+        for (int i = 0; i < WPD; ++i) wring[i] = s_wn[fidx0(i) * 64 + lane];
 #pragma unroll
-          for (int q = 0; q < NKN; ++q)
-            acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + q) * 64 + lane], xq[q], acc4[ct], 0, 0, 0);
+        for (int i = 0; i < 20; ++i) {
+          if (i + WPD < 20) wring[(i + WPD) % (WPD + 1)] = s_wn[fidx0(i + WPD) * 64 + lane];
+          const int ct = i / 5, j = i % 5;
+          acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wring[i % (WPD + 1)], j == 0 ? ones : xq[j == 0 ? 0 : j - 1], j == 0 ? zero : acc4[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
         load_x(g, 1);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int i = 0; i < WPD; ++i) wring[i] = s_wn[fidx1(i) * 64 + lane];
 #pragma unroll
-          for (int q = 0; q < NKN; ++q)
-            acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wn[(ct * (NKNX + 1) + NKN + q) * 64 + lane], xq[q], acc4[ct], 0, 0, 0);
-          bq[2 * ct] = to_b(acc4[ct], 0); bq[2 * ct + 1] = to_b(acc4[ct], 1);
+        for (int i = 0; i < 16; ++i) {
+          if (i + WPD < 16) wring[(i + WPD) % (WPD + 1)] = s_wn[fidx1(i + WPD) * 64 + lane];
+          const int ct = i / 4, q = i % 4;
+          acc4[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wring[i % (WPD + 1)], xq[q], acc4[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 3) { bq[2 * ct] = to_b(acc4[ct], 0); bq[2 * ct + 1] = to_b(acc4[ct], 1); }
         }
       }
       if (g + 1 < g1) load_x(g + 1, 0);    // next group's pixels: requested now, consumed at the top of the next iteration
       // ---- conv1 (no bias: norm follows, lfd_head.py:97; passes 2, 3: GN1 folded in, its shift on the bias step)
+      half8 wbv[PASS >= 2 ? 4 : 1];       // the stage's four bias-step fragments: one LDS round trip, not one per cout tile
+      if constexpr (PASS >= 2) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) wbv[ct] = s_wb[ct * 64 + lane];
+      }
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         f32x16 acc;
-        if constexpr (PASS >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[ct * 64 + lane], ones, zero, 0, 0, 0);
+        if constexpr (PASS >= 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbv[ct], ones, zero, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < NKH; ++q)
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FOLD ? __builtin_bit_cast(half8, w1a[FOLD ? ct : 0][q]) : w1[FOLD ? 0 : ct][q], bq[q], (PASS >= 2 || q > 0) ? acc : zero, 0, 0, 0);
@@ -839,10 +859,15 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       }
       if constexpr (PASS >= 2) {
         // ---- conv2 (pass 3: GN2 folded in)
+        half8 wbv2[PASS == 3 ? 4 : 1];
+        if constexpr (PASS == 3) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) wbv2[ct] = s_wb[(4 + ct) * 64 + lane];
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
           f32x16 acc;
-          if constexpr (PASS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb[(4 + ct) * 64 + lane], ones, zero, 0, 0, 0);
+          if constexpr (PASS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbv2[ct], ones, zero, 0, 0, 0);
 #pragma unroll
           for (int q = 0; q < NKH; ++q)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(FOLD ? __builtin_bit_cast(half8, w2a[FOLD ? ct : 0][q]) : w2[FOLD ? 0 : ct][q], bqn[q], (PASS == 3 || q > 0) ? acc : zero, 0, 0, 0);
