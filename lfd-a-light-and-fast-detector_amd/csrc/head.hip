@@ -1001,98 +1001,100 @@ struct FinalizeArgs {
 };
 
 __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
-  // block = (image n, level l); thread = (tile lane tl = tid / 32, value v = tid % 32) over the
-  // [tiles][ngroups*2] partial rows (ngroups*2 <= 256/8 ... handled by looping v): coalesced row
-  // reads, 8 tile lanes in flight, fp64 accumulation, fixed-order LDS combine -> deterministic.
-  __shared__ double sm[8][64];
-  __shared__ float s_ab[HC][2];
-  const int n = blockIdx.x, l = blockIdx.y;
-  // fold: this thread's 8 source fragments (cout tile threadIdx.x / 64, k-steps 0..7) are requested up front -- their L2
-  // round trip hides under the statistics reduction below
-  const bool fold = f.wsrc[l] && f.wdst[l];
-  half4 f_lo[8], f_hi[8];
-  {
-    const int lane = threadIdx.x & 63, m = lane & 31, hk = lane >> 5, ct = threadIdx.x >> 6;
-    if (fold) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const _Float16* base = f.wsrc[l] + (size_t)(ct * 8 + k) * 64 * 8;
-        f_lo[k] = *reinterpret_cast<const half4*>(base + m * 8 + 4 * hk);
-        f_hi[k] = *reinterpret_cast<const half4*>(base + (m + 32) * 8 + 4 * hk);
-      }
-    }
-  }
+  // block = (image n, level l, cout tile ct): the statistics of the 32 channels [32 ct, 32 ct + 32) -- 32 / gsize groups, two
+  // values (sum, sum of squares) each -- combined over the level's tile partials in fp64 in a fixed order (deterministic), their
+  // per-channel (scale, shift), and this cout tile's share of the folded filter.  thread = (tile lane tl, value v): coalesced
+  // row reads, four independent accumulators per thread.  (One block per (image, level) took 12.6 us once it also folded.)
+  __shared__ double sm[256];
+  __shared__ double s_tot[64];
+  __shared__ float s_ab[32][2];
+  const int n = blockIdx.x, l = blockIdx.y, ct = blockIdx.z;
   const int nv = f.ngroups * 2;                  // values per tile row
-  const int t0 = f.tile_start[l] + n * f.tiles_per_img[l];
-  const int tl = threadIdx.x >> 5, v0 = threadIdx.x & 31;
-  for (int vb = 0; vb < nv; vb += 32) {          // 32 values per sweep
-    const int v = vb + v0;
-    double acc = 0.0;
-    if (v < nv) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      const int st = f.tile_stride[l];
-      const int T = (f.tiles_per_img[l] + st - 1) / st;   // slots that carry data
-      int t = tl;
-      for (; t + 24 < T; t += 32) {     // 4 independent loads in flight per thread
-        a0 += (double)f.part[(size_t)(t0 + t * st) * nv + v];
-        a1 += (double)f.part[(size_t)(t0 + (t + 8) * st) * nv + v];
-        a2 += (double)f.part[(size_t)(t0 + (t + 16) * st) * nv + v];
-        a3 += (double)f.part[(size_t)(t0 + (t + 24) * st) * nv + v];
-      }
-      for (; t < T; t += 8) a0 += (double)f.part[(size_t)(t0 + t * st) * nv + v];
-      acc = (a0 + a1) + (a2 + a3);
-    }
-    sm[tl][v0] = acc;
-    __syncthreads();
-    if (tl == 0 && v < nv) {
-      double s = 0.0;
-      for (int i = 0; i < 8; ++i) s += sm[i][v0];
-      sm[0][32 + v0] = s;                          // totals of this sweep: (sum, sumsq) interleaved
-    }
-    __syncthreads();
-    // threads 0..15 of the sweep: one group each (pair v0 = 2*g', 2*g'+1)
-    if (threadIdx.x < 16 && (vb / 2 + threadIdx.x) < f.ngroups) {
-      const int g = vb / 2 + threadIdx.x;
-      const double s = sm[0][32 + 2 * threadIdx.x], ss = sm[0][32 + 2 * threadIdx.x + 1];
-      const double cnt = (double)f.hw[l] * f.gsize;
-      const double mean = s / cnt;
-      double var = ss / cnt - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const double rstd = 1.0 / sqrt(var + (double)f.eps);
-      for (int j = 0; j < f.gsize; ++j) {
-        const int c = g * f.gsize + j;
-        const double sc = (double)f.gamma[l][c] * rstd;
-        float* o = f.ab + (((size_t)l * f.N + n) * HC + c) * 2;
-        o[0] = (float)sc;
-        o[1] = (float)((double)f.beta[l][c] - mean * sc);
-        s_ab[c][0] = o[0]; s_ab[c][1] = o[1];
+  const int nvc = 64 / f.gsize;                  // values of this cout tile: 2 * (32 / gsize), 2 .. 64
+  int nvp = 2;
+  while (nvp < nvc) nvp <<= 1;                   // (gsize is a power of two: nvp == nvc)
+  const int TLN = 256 / nvp;                     // tile lanes
+  const int tl = threadIdx.x / nvp, v0 = threadIdx.x - tl * nvp;
+  // fold: this thread's source fragments (k-steps of cout tile ct) are requested up front -- their L2 round trip hides under
+  // the statistics reduction below.  Items i = tid + 256 j < 9 * 64: k = i / 64 (8 = the bias fragment), lane = i % 64.
+  const bool fold = f.wsrc[l] && f.wdst[l];
+  half4 f_lo[3], f_hi[3];
+  if (fold) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = threadIdx.x + 256 * j, k = i >> 6, lane = i & 63, m = lane & 31, hk = lane >> 5;
+      if (k < 8) {
+        const _Float16* base = f.wsrc[l] + (size_t)(ct * 8 + k) * 64 * 8;
+        f_lo[j] = *reinterpret_cast<const half4*>(base + m * 8 + 4 * hk);
+        f_hi[j] = *reinterpret_cast<const half4*>(base + (m + 32) * 8 + 4 * hk);
       }
     }
-    __syncthreads();
   }
+  const int t0 = f.tile_start[l] + n * f.tiles_per_img[l];
+  const int st = f.tile_stride[l];
+  const int T = (f.tiles_per_img[l] + st - 1) / st;   // slots that carry data
+  double acc = 0.0;
+  if (v0 < nvc) {
+    const float* col = f.part + (size_t)t0 * nv + ct * nvc + v0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = tl;
+    for (; t + 3 * TLN < T; t += 4 * TLN) {     // 4 independent loads in flight per thread
+      a0 += (double)col[(size_t)(t * st) * nv];
+      a1 += (double)col[(size_t)((t + TLN) * st) * nv];
+      a2 += (double)col[(size_t)((t + 2 * TLN) * st) * nv];
+      a3 += (double)col[(size_t)((t + 3 * TLN) * st) * nv];
+    }
+    for (; t < T; t += TLN) a0 += (double)col[(size_t)(t * st) * nv];
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < nvc) {                       // fixed-order combine over the tile lanes
+    double sum = 0.0;
+    for (int i = 0; i < TLN; ++i) sum += sm[i * nvp + threadIdx.x];
+    s_tot[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < nvc / 2) {                   // one group each
+    const int g = ct * (nvc / 2) + threadIdx.x;
+    const double sum = s_tot[2 * threadIdx.x], ss = s_tot[2 * threadIdx.x + 1];
+    const double cnt = (double)f.hw[l] * f.gsize;
+    const double mean = sum / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)f.eps);
+    for (int j = 0; j < f.gsize; ++j) {
+      const int c = g * f.gsize + j;
+      const double sc = (double)f.gamma[l][c] * rstd;
+      float* o = f.ab + (((size_t)l * f.N + n) * HC + c) * 2;
+      o[0] = (float)sc;
+      o[1] = (float)((double)f.beta[l][c] - mean * sc);
+      s_ab[c - ct * 32][0] = o[0]; s_ab[c - ct * 32][1] = o[1];
+    }
+  }
+  __syncthreads();
   // ---- fold: this (level, image)'s copy of the tower conv with the scale in its rows (one fp16 rounding, the same
   //      arithmetic as k_head2's own fold) and the shift as a bias fragment, in k_head2's K-permuted register layout:
   //      element e of lane (m, hk) of fragment (ct, k) = W[32ct + m][16k + 8(e >> 2) + 4hk + (e & 3)]
   if (fold) {
-    half8* __restrict__ dst = f.wdst[l] + (size_t)n * (4 * 9 * 64);
-    const int lane = threadIdx.x & 63, m = lane & 31, hk = lane >> 5;
-    const int ct = threadIdx.x >> 6;                 // 256 threads = 4 cout tiles x 64 lanes; fragments (ct, k = 0..8)
-    const float rs = s_ab[ct * 32 + m][0];
+    half8* __restrict__ dst = f.wdst[l] + (size_t)n * (4 * 9 * 64) + (size_t)ct * 9 * 64;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int j = 0; j < 3; ++j) {
+      const int i = threadIdx.x + 256 * j, k = i >> 6, lane = i & 63, m = lane & 31, hk = lane >> 5;
+      if (i >= 9 * 64) break;
       half8 r;
+      if (k < 8) {
+        const float rs = s_ab[m][0];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { r[e] = (_Float16)((float)f_lo[k][e] * rs); r[4 + e] = (_Float16)((float)f_hi[k][e] * rs); }
-      dst[(ct * 9 + k) * 64 + lane] = r;
-    }
-    {
-      const float v = s_ab[ct * 32 + m][1];
-      const _Float16 bh = (_Float16)v, bl = (_Float16)(v - (float)bh);
-      half8 r;
+        for (int e = 0; e < 4; ++e) { r[e] = (_Float16)((float)f_lo[j][e] * rs); r[4 + e] = (_Float16)((float)f_hi[j][e] * rs); }
+      } else {
+        const float v = s_ab[m][1];
+        const _Float16 bh = (_Float16)v, bl = (_Float16)(v - (float)bh);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.f;
-      if (!hk) { r[0] = bh; r[1] = bl; }
-      dst[(ct * 9 + 8) * 64 + lane] = r;
+        for (int e = 0; e < 8; ++e) r[e] = (_Float16)0.f;
+        if (!hk) { r[0] = bh; r[1] = bl; }
+      }
+      dst[i] = r;
     }
   }
 }
@@ -1297,7 +1299,8 @@ int lfd_groupnorm_finalize_fold(const lfd_head_desc_t* d, const float* partial, 
     }
   }
   f.part = partial; f.ab = ab; f.N = d->n; f.ngroups = d->num_groups; f.gsize = HC / d->num_groups; f.eps = eps;
-  hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels), dim3(256), 0, st, f);
+  if (f.gsize > 32) return LFD_ERR_UNSUPPORTED;      // a cout tile of 32 channels holds whole groups
+  hipLaunchKernelGGL(k_gn_finalize, dim3(d->n, d->num_levels, 4), dim3(256), 0, st, f);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
