@@ -1046,7 +1046,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   }
   const int blocks = 8 * ((a.ntiles + 7) / 8) < 256 ? 8 * ((a.ntiles + 7) / 8) : 256;   // (XCD-contiguous tile ranges)
   if (blocks < 1) return LFD_OK;
-  { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg; }
+  { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg && a.ntiles >= 16 * blocks; }   // (few tiles per workgroup: a start delay of up to one tile time costs more than the bursts it spreads)
   hipLaunchKernelGGL((k_stem2x<U8, ALN>), dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
