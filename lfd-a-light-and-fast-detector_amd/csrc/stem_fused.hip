@@ -1046,7 +1046,9 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   }
   const int blocks = 8 * ((a.ntiles + 7) / 8) < 256 ? 8 * ((a.ntiles + 7) / 8) : 256;   // (XCD-contiguous tile ranges)
   if (blocks < 1) return LFD_OK;
-  { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 1; }(); a.stagger = stg && a.ntiles >= 16 * blocks; }   // (few tiles per workgroup: a start delay of up to one tile time costs more than the bursts it spreads)
+  // (round 1's kernel gained 3 % from de-phasing the workgroups' memory bursts with a start delay of up to one tile time; with
+  //  the round-2 staging -- one basic block of loads per tile -- the delay only costs: 178 vs 172 us at 8 x 1080p.  Opt-in.)
+  { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stg && a.ntiles >= 16 * blocks; }
   hipLaunchKernelGGL((k_stem2x<U8, ALN>), dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
