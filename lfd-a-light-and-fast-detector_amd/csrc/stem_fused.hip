@@ -981,19 +981,35 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
       }
     }
     X2_T(5);
-    // conv4 (1x1) straight from conv3's accumulators
+    // conv4 (1x1) straight from conv3's accumulators.  Its ten filter fragments (bias step + four k-steps per cout tile) come
+    // from LDS through a 4-deep register ring requested BEFORE the ReLU / pack of conv3's result: read right in front of
+    // their MFMA, each of them waited a full LDS round trip.
+    auto w4frag = [&](int i) {                     // i = 0..9: cout tile i / 5; step 0 = the bias fragment
+      const int c = i / 5, q = i % 5;
+      return q == 0 ? s_wb4[(2 + c) * 64 + lane] : s_w4[(c * 4 + q - 1) * 64 + lane];
+    };
+    constexpr int W4PD = 3;
+    half8 w4ring[W4PD + 1];
+#pragma unroll
+    for (int i = 0; i < W4PD; ++i) w4ring[i] = w4frag(i);
     half8 bq[4];
 #pragma unroll
     for (int c = 0; c < 2; ++c) { bq[2 * c] = relu8(acc3[c], 0); bq[2 * c + 1] = relu8(acc3[c], 1); }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_wb4[(2 + c) * 64 + lane], ones, zero, 0, 0, 0);   // bias k-step
+      f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w4[(c * 4 + q) * 64 + lane], bq[q], acc, 0, 0, 0);
+      for (int i = 0; i < 10; ++i) {
+        if (i + W4PD < 10) w4ring[(i + W4PD) % (W4PD + 1)] = w4frag(i + W4PD);
+        const int c = i / 5, q = i % 5;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4ring[i % (W4PD + 1)], q == 0 ? ones : bq[q == 0 ? 0 : q - 1], q == 0 ? zero : acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == 4) {
 #pragma unroll
-      for (int g2 = 0; g2 < 2; ++g2)
-        *reinterpret_cast<half8*>(wst + pix * 128 + (((4 * c + 2 * g2 + hh) ^ fo) * 16)) = relu8(acc, g2);
+          for (int g2 = 0; g2 < 2; ++g2)
+            *reinterpret_cast<half8*>(wst + pix * 128 + (((4 * c + 2 * g2 + hh) ^ fo) * 16)) = relu8(acc, g2);
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     X2_T(5 + 3);   // slot 8 unused by the reader; keeps numbering simple
