@@ -55,6 +55,24 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_nms_f32(None, -1, 0.5, None, None, None, 0, None) == -1
     assert l.lfd_conv2d_nhwc_f16(None, None, None, None, None, None, None, None, None, None) == -1
     assert l.lfd_sigmoid_focal_loss_fwd(None, None, 4, 0, 2.0, 0.25, None, 0, None) == -1
+    # round-2 entry points: argument checks happen on the host, before anything touches a device
+    import ctypes as C
+    assert l.lfd_detect_from_candidates(None, 1, None, None, None, None, None, None, 0, None) == -1
+    assert l.lfd_detect_workspace_reset(None, 1, None, 0, None) == -1
+    assert l.lfd_head_forward_decode_f16(None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert l.lfd_groupnorm_finalize_fold(None, None, None, None, 1e-5, None, None, 1, None) == -1
+    assert l.lfd_fasterblock_fused_f16(0, 8, 8, None, None, None, None, None, None, None, None) == -1
+    # the fused head-decode pass covers one sigmoid-scored class: anything else is LFD_ERR_UNSUPPORTED (-4), never a wrong answer
+    hd = _lib.HeadDesc()
+    hd.n, hd.num_levels, hd.num_groups, hd.head_channels = 1, 1, 16, 128
+    hd.level_hw[0], hd.level_cin[0], hd.total_points, hd.cls_channels = 16, 64, 16, 46
+    hd.final_reg_rows, hd.final_cls_rows = 0, 46
+    dd = _lib.DetectDesc()
+    dd.num_levels = 1
+    dd.level_h[0], dd.level_w[0], dd.level_stride[0] = 4, 4, 8
+    dd.num_classes, dd.num_cls_channels, dd.score_mode, dd.max_candidates = 45, 46, 1, 16
+    lv = (_lib.HeadLevelPtrs * 1)()
+    assert l.lfd_head_forward_decode_f16(C.byref(hd), lv, None, None, None, None, None, C.byref(dd), None, None, 0, None) == -4
 
 
 def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
