@@ -159,7 +159,7 @@ def test_two_batches_in_flight_on_two_streams_match_the_serial_step():
             assert k > 0 and torch.equal(outs[sl].dets[n, :k], ref[sl][1][n, :k]) and torch.equal(outs[sl].labels[n, :k], ref[sl][2][n, :k])
 
 
-@pytest.mark.parametrize('shape,q', [((2, 270, 480, 3), 0.95), ((1, 1080, 1920, 3), 0.995), ((3, 200, 312, 3), 0.9)])
+@pytest.mark.parametrize('shape,q', [((2, 270, 480, 3), 0.95), ((1, 1080, 1920, 3), 0.995), ((3, 200, 312, 3), 0.9), ((2, 203, 317, 3), 0.9)])
 def test_head_pass_that_appends_its_own_candidates_equals_the_unfused_step(shape, q):
     """lfd_head_forward_decode_f16 (the head's output pass thresholds, decodes and appends the candidates; sort + mask + scan
     follow through lfd_detect_from_candidates) against forward -> fp32 logits -> lfd_detect_batched: identical counts,
