@@ -473,6 +473,12 @@ typedef struct lfd_head_level_ptrs {
    * fragments pass 2 feeds its conv2 with.  Pass 2 writes it; when every level has it (and both folded filters) pass 3 /
    * lfd_head_forward_decode_f16 load it instead of recomputing neck + conv1: same bits, 45 instead of 101 MFMAs per 32 pixels. */
   void* tower1_out;
+  /* optional: tower conv 1 / 2 in the kernel's K-permuted register layout (element e of lane (m, hk) of fragment (ct, k) =
+   * W[32 ct + m][16 k + 8 (e >> 2) + 4 hk + (e & 3)], LFD_HEAD_FOLDED_HALFS - 4 * 64 * 8 halfs: no bias fragments), for the
+   * passes that use the filter unscaled (conv1 in pass 1, conv2 in pass 2): plain 16-byte loads instead of a permute per
+   * work chunk.  NULL: permuted from w1_packed / w2_packed on the fly. */
+  const void* w1_perm;
+  const void* w2_perm;
 } lfd_head_level_ptrs_t;
 #define LFD_HEAD_FOLDED_HALFS (4 * 9 * 64 * 8)
 #define LFD_HEAD_TOWER1_GROUP_HALFS (8 * 64 * 8)

@@ -46,6 +46,8 @@ struct HeadLevel {
   const float* scale;    // per-level Scale parameter (device scalar) or nullptr
   const half8* w1f;      // [N][4][9][64] tower conv 1 / 2 with GroupNorm folded in (k_gn_finalize), K-permuted fragments,
   const half8* w2f;      //               k-step 8 = the shift as a bias fragment; or nullptr (fold per work chunk)
+  const half8* w1p;      // [4][8][64] tower conv 1 / 2 unscaled, K-permuted (host-made copy), or nullptr (permute on the fly)
+  const half8* w2p;
   half8* a1;             // [N][groups of 32 pixels][8][64]: ReLU(GN1(conv1)) of every pixel as conv2's B fragments, written by
                          // pass 2 and read by the output pass instead of recomputing neck + conv1; or nullptr
   int cin, hw, p_off;    // tap channels, pixels per image, first point of the level
@@ -679,6 +681,9 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
           for (int k = 0; k < NKH; ++k) w1[ct][k] = f1[(ct * 9 + k) * 64 + lane];
           s_wb[ct * 64 + lane] = f1[(ct * 9 + 8) * 64 + lane];
+        } else if (PASS == 1 && L.w1p) {
+#pragma unroll
+          for (int k = 0; k < NKH; ++k) w1[ct][k] = L.w1p[(ct * NKH + k) * 64 + lane];
         } else {
           const float sc1 = PASS >= 2 ? t1[(ct * 32 + m) * 2] : 1.f;
 #pragma unroll
@@ -690,6 +695,9 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
 #pragma unroll
             for (int k = 0; k < NKH; ++k) w2[ct][k] = f2[(ct * 9 + k) * 64 + lane];
             s_wb[(4 + ct) * 64 + lane] = f2[(ct * 9 + 8) * 64 + lane];
+          } else if (PASS == 2 && L.w2p) {
+#pragma unroll
+            for (int k = 0; k < NKH; ++k) w2[ct][k] = L.w2p[(ct * NKH + k) * 64 + lane];
           } else {
             const float sc2 = PASS == 3 ? t2[(ct * 32 + m) * 2] : 1.f;
 #pragma unroll
@@ -1178,6 +1186,7 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
     L.wf = (const half8*)lv[i].wf_packed; L.bf = lv[i].bf; L.scale = lv[i].scale;
     L.w1f = (const half8*)lv[i].w1_folded; L.w2f = (const half8*)lv[i].w2_folded;
     L.a1 = (half8*)lv[i].tower1_out;
+    L.w1p = (const half8*)lv[i].w1_perm; L.w2p = (const half8*)lv[i].w2_perm;
     L.cin = d->level_cin[i]; L.hw = d->level_hw[i]; L.p_off = d->level_point_offset[i];
     L.tile_start = ts[i]; L.tiles_per_img = tp[i];
   }

@@ -47,7 +47,8 @@ class HeadLevelPtrs(C.Structure):
     """lfd_head_level_ptrs_t"""
     _fields_ = [('x', C.c_void_p), ('wn_packed', C.c_void_p), ('bn', C.c_void_p), ('w1_packed', C.c_void_p),
                 ('w2_packed', C.c_void_p), ('wf_packed', C.c_void_p), ('bf', C.c_void_p), ('scale', C.c_void_p),
-                ('w1_folded', C.c_void_p), ('w2_folded', C.c_void_p), ('tower1_out', C.c_void_p)]
+                ('w1_folded', C.c_void_p), ('w2_folded', C.c_void_p), ('tower1_out', C.c_void_p),
+                ('w1_perm', C.c_void_p), ('w2_perm', C.c_void_p)]
 
 
 HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS

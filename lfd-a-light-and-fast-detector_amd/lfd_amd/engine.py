@@ -76,6 +76,14 @@ def _fold_conv_norm(conv, norm):
     return w, b
 
 
+def _perm_head_weight(packed):
+    """ops.pack_conv_weight layout [4][8][64 = (h, m)][8 = (jh, jl)] of a 128 -> 128 1x1 conv -> the K order k_head2 consumes the
+    previous stage's accumulator registers in: element e = (eh, el) of lane (hk, m) = standard lane (eh, m), element 4 hk + el
+    (csrc/head.hip `perm`)."""
+    p = packed.view(4, 8, 2, 32, 2, 4).permute(0, 1, 4, 3, 2, 5).contiguous()
+    return p.view(4, 8, 64, 8)
+
+
 def pack_stem_weight(w):
     """[C,3,3,3] -> [C/32][2][64][8] fp16 in the k-slot order of csrc/stem.hip:
     step0: half0 = row0 e0..7, half1 = row1 e0..7; step1: half0 = row2 e0..7,
@@ -121,7 +129,7 @@ class _HeadLevel(object):
 
 
 class _Tower(object):
-    __slots__ = ('w1', 'w2', 'wf', 'bf', 'norm1', 'norm2', 'reg_rows', 'cls_rows', 'scale', 'static_ab')
+    __slots__ = ('w1', 'w2', 'wf', 'bf', 'norm1', 'norm2', 'reg_rows', 'cls_rows', 'scale', 'static_ab', 'w1p', 'w2p')
 
 
 # ---------------------------------------------------------------------------- plan
@@ -330,6 +338,7 @@ class EnginePlan(object):
                 c1, c2 = seq[0], seq[lstep]
                 t.w1 = ops.pack_conv_weight(c1.weight.detach().float()).to(dev)
                 t.w2 = ops.pack_conv_weight(c2.weight.detach().float()).to(dev)
+                t.w1p = t.w2p = None
                 t.norm1 = seq[1] if has_norm else None
                 t.norm2 = seq[lstep + 1] if has_norm else None
                 t.static_ab = None
@@ -574,6 +583,10 @@ class _ShapeState(object):
                             lvp[k].x = self.bufs[lv.src].data_ptr()
                             lvp[k].wn_packed, lvp[k].bn = lv.wn.data_ptr(), lv.bn.data_ptr()
                             lvp[k].w1_packed, lvp[k].w2_packed = t.w1.data_ptr(), t.w2.data_ptr()
+                            if os.environ.get('LFD_HEAD_PERM', '1') != '0':
+                                if getattr(t, 'w1p', None) is None:       # K-permuted copies, once per plan
+                                    t.w1p, t.w2p = _perm_head_weight(t.w1), _perm_head_weight(t.w2)
+                                lvp[k].w1_perm, lvp[k].w2_perm = t.w1p.data_ptr(), t.w2p.data_ptr()
                             lvp[k].wf_packed, lvp[k].bf = t.wf.data_ptr(), t.bf.data_ptr()
                             lvp[k].scale = t.scale.data_ptr() if t.scale is not None else None
                         call = dict(desc=d, levels=lvp)

@@ -156,11 +156,14 @@ def test_head_chunk_length_and_fold_site_do_not_change_outputs():
     # LFD_H2_AGPR=0: the output pass keeps the folded filters as ordinary register values instead of loading them straight
     # into AccVGPRs (k_head2<.., FOLD>) -- same MFMAs, same operands
     # LFD_HEAD_A1=0: the output pass recomputes neck + conv1 instead of loading the tower-1 activations pass 2 left behind
-    for chunk, fold, agpr, a1 in ((0, 1, 1, 1), (2, 1, 0, 1), (6, 0, 1, 1), (12, 1, 1, 0), (0, 0, 0, 0), (0, 1, 0, 1), (2, 1, 1, 1)):
-        env = dict(os.environ, LFD_H2_CHUNK=str(chunk), LFD_HEAD_FOLD=str(fold), LFD_H2_AGPR=str(agpr), LFD_HEAD_A1=str(a1))
+    # LFD_HEAD_PERM=0: the unscaled filters of passes 1 / 2 are K-permuted on the fly instead of loaded from the host-made copies
+    for chunk, fold, agpr, a1, pm in ((0, 1, 1, 1, 1), (2, 1, 0, 1, 1), (6, 0, 1, 1, 0), (12, 1, 1, 0, 1), (0, 0, 0, 0, 0),
+                                      (0, 1, 0, 1, 0), (2, 1, 1, 1, 1)):
+        env = dict(os.environ, LFD_H2_CHUNK=str(chunk), LFD_HEAD_FOLD=str(fold), LFD_H2_AGPR=str(agpr), LFD_HEAD_A1=str(a1),
+                   LFD_HEAD_PERM=str(pm))
         out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
-        hashes[(chunk, fold, agpr, a1)] = [l for l in out.stdout.splitlines() if l.startswith('HASH')][-1]
+        hashes[(chunk, fold, agpr, a1, pm)] = [l for l in out.stdout.splitlines() if l.startswith('HASH')][-1]
     assert len(set(hashes.values())) == 1, hashes
 
 
