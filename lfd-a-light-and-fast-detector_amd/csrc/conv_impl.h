@@ -457,22 +457,39 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       half8 wq[PW];
 #pragma unroll
       for (int i = 0; i < PW; ++i) wq[i] = wsrc[(size_t)i * 64];
+      // the pixel fragments go through a register ring as well (XPD k-steps ahead, restarted per tap row): read right in
+      // front of their MFMA, each of the 72 x PT LDS reads of a 128-channel tile waited its full round trip
+      constexpr int XPD = RK > 3 ? 3 : RK - 1;
+      half8 xq[XPD + 1][C::PT];
 #pragma unroll 1
       for (int r = 0; r < KS; ++r) {
         const char* xr = xb + r * C::IWs * C::PIXB;
         const int knext = r * RK + PW;   // ring refill index; clamped (re-reads the last fragment, branch-free)
+        auto xfrag = [&](int j, int pt) {
+          const int s = j / C::NQ, q = j % C::NQ;
+          const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
+          return *reinterpret_cast<const half8*>(xr + off + (pt * C::RPT * S) * C::IWs * C::PIXB);
+        };
+#pragma unroll
+        for (int j = 0; j < XPD; ++j)
+#pragma unroll
+          for (int pt = 0; pt < C::PT; ++pt) xq[j][pt] = xfrag(j, pt);
 #pragma unroll
         for (int j = 0; j < RK; ++j) {
           const int s = j / C::NQ, q = j % C::NQ;
+          (void)s;
           const half8 wf = wq[j % PW];
           __builtin_amdgcn_sched_barrier(0);
           wq[j % PW] = wsrc[(size_t)((knext + j) < C::NK ? (knext + j) : (C::NK - 1)) * 64];
-          __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: left alone, the compiler sinks every
-                                               // load next to its use PW steps later (load -> vmcnt(0) -> MFMA)
-          const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
+          if (j + XPD < RK) {
+#pragma unroll
+            for (int pt = 0; pt < C::PT; ++pt) xq[(j + XPD) % (XPD + 1)][pt] = xfrag(j + XPD, pt);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the refills HERE: left alone, the compiler sinks every
+                                               // load next to its use (load -> waitcnt(0) -> MFMA)
 #pragma unroll
           for (int pt = 0; pt < C::PT; ++pt) {
-            const half8 xf = *reinterpret_cast<const half8*>(xr + off + (pt * C::RPT * S) * C::IWs * C::PIXB);
+            const half8 xf = xq[j % (XPD + 1)][pt];
             acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[pt], 0, 0, 0);
             if constexpr (DS) {
               if (r == 1 && s == 1) accd[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdsr[q], xf, accd[pt], 0, 0, 0);
