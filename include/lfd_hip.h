@@ -105,7 +105,8 @@ typedef struct lfd_detect_desc {
   int32_t num_cls_channels;              /* C for sigmoid scores, C+1 for softmax (CE loss) */
   int32_t score_mode;                    /* 0: sigmoid (lfd.py:454); 1: softmax, drop last (:450-452) */
   int32_t decode_mode;                   /* 0: sigmoid(reg)*max(range) (:483-486); 1: exp(reg) (:480-482);
-                                            2: reg*range_hi ('independent', :468-478) */
+                                            2: reg*range_hi ('independent', :468-478);
+                                            3: reg is the distance itself (FCOS, fcos.py:392 on fcos_head.py:145-146) */
   int32_t class_agnostic;                /* nms_cfg['class_agnostic'] (nms.py:143) */
   int32_t max_candidates;                /* capacity K_cap per image of candidate / output rows */
   float score_thr;                       /* strict `>` (nms.py:204) */
@@ -128,6 +129,31 @@ LFD_API int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, con
                        float* out_dets, int32_t* out_labels, int32_t* out_cand,
                        int32_t* out_point, int32_t* out_counts, void* workspace,
                        size_t workspace_bytes, lfd_stream_t stream);
+
+/* The same step for the sibling meta-architectures that share the multiclass_nms boundary:
+ *   FCOS._get_results_for_single_image  (lfd/model/fcos.py:356-412)
+ *   LFDv2._get_results_for_single_image (lfd/model/lfdv2.py:593-669)
+ * which use its two arguments LFD leaves at their defaults, plus a per-level pre-selection:
+ *   centerness  [N,P] logits or NULL: every class score is multiplied by sigmoid(centerness) -- multiclass_nms's
+ *               score_factors (nms.py:192-193; fcos.py:376,403-409), applied BEFORE the threshold as there;
+ *   pre_nms_limit  > 0: a level with more points keeps its pre_nms_limit best, ranked by the point's largest final score
+ *               (fcos.py:383-390 ranks after the centerness factor; lfdv2.py:620-627), before decode and threshold.
+ *               torch.topk leaves the choice among EQUAL keys open; this implementation takes the lowest point index;
+ *   post_nms_limit > 0: multiclass_nms max_num (nms.py:217-219) -- out_counts[n][1] = min(kept, post_nms_limit), rows
+ *               beyond it are unspecified.
+ * Candidate order (out_cand) is point-major within the image, not the reference's "top-k order within the level": it
+ * only reaches the results through the order of exactly equal scores, which the reference leaves unspecified.
+ * Everything else -- outputs, img_meta, thresholds -- as lfd_detect_batched; workspace: lfd_detect_ex_workspace_bytes. */
+typedef struct lfd_detect_ext {
+  int32_t pre_nms_limit;
+  int32_t post_nms_limit;
+} lfd_detect_ext_t;
+LFD_API size_t lfd_detect_ex_workspace_bytes(const lfd_detect_desc_t* desc, int32_t batch);
+LFD_API int lfd_detect_batched_ex(const lfd_detect_desc_t* desc, const lfd_detect_ext_t* ext, int32_t batch,
+                                  const void* cls, const void* reg, const void* centerness, int32_t in_dtype,
+                                  const float* img_meta, float* out_dets, int32_t* out_labels, int32_t* out_cand,
+                                  int32_t* out_point, int32_t* out_counts, void* workspace, size_t workspace_bytes,
+                                  lfd_stream_t stream);
 
 /* Second half of lfd_detect_batched for a workspace whose candidate arrays were filled by a producer kernel
  * (lfd_head_forward_decode_f16: the head's last pass thresholds, decodes and appends by itself): sort + suppression mask
@@ -329,6 +355,29 @@ LFD_API int lfd_conv2d_nhwc_f16(const lfd_conv_desc_t* desc, const void* in, voi
 LFD_API int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
                                       const float* b1, const void* w2_packed, const float* b2, const void* zeros,
                                       lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise operators of the sibling necks / heads, NHWC fp16, channels a multiple of 8:
+ *   lfd_upsample_nearest_add_nhwc_f16   dst[n,H,W,c] += nearest(src[n,h,w,c]) -- the merge step of FPN / SimpleFPN
+ *                                       (`lateral[i-1] += nn.Upsample(size, mode='nearest')(lateral[i])`,
+ *                                       lfd/model/neck/fpn.py:133-135, simple_fpn.py:147-157); source index =
+ *                                       min(floorf(dst_index * float(in)/out), in-1) as ATen computes it; fp32 add.
+ *   lfd_relu_inplace_f16                nn.ReLU(inplace=True) in front of an extra level: it rewrites the PREVIOUS
+ *                                       output level as well (fpn.py:66-79, simple_fpn.py:84-99 feed fpn_outputs[-1]).
+ *   lfd_maxpool3x3s2_nhwc_f16           extra_type='pooling': nn.MaxPool2d(3, 2, 1) (fpn.py:74) -> [n, (h+1)/2, (w+1)/2, c].
+ *   lfd_pack_level_outputs_f32          channels c0 .. c0+count of a level's fp32 output-conv map [n, hw, src_channels]
+ *                                       -> rows point_offset .. +hw of the level-concatenated [n, total_points, count]
+ *                                       tensor the meta-architecture returns (fcos.py:426-449, lfdv2.py:683-702),
+ *                                       times `scale` (the head's per-level Scale), op 1: then expf
+ *                                       (fcos_head.py:145-146). */
+LFD_API int lfd_upsample_nearest_add_nhwc_f16(void* dst, const void* src, int32_t n, int32_t H, int32_t W, int32_t h,
+                                              int32_t w, int32_t c, lfd_stream_t stream);
+LFD_API int lfd_relu_inplace_f16(void* x, int64_t count, lfd_stream_t stream);
+LFD_API int lfd_maxpool3x3s2_nhwc_f16(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c,
+                                      lfd_stream_t stream);
+LFD_API int lfd_pack_level_outputs_f32(const float* src, float* dst, int32_t n, int32_t hw, int32_t src_channels, int32_t c0,
+                                       int32_t count, int32_t total_points, int32_t point_offset, float scale, int32_t op,
+                                       lfd_stream_t stream);
 
 /* Parity instrument (not on the product path): the same MFMA conv kernels with the fp32 accumulators (conv + bias, no
  * activation, no fp16 rounding) written to out_f32 [n, oh, ow, cout].  Used by the engine's G1 mode (SURVEY 8d gate G1:

@@ -61,6 +61,7 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     case 64 * 10000 + 3200 + 20: return launch_conv<64, 3, 2, 2, true, false>(a, st);
     case 64 * 10000 + 3200 + 21: return launch_conv<64, 3, 2, 2, true, true>(a, st);
     case 64 * 10000 + 3200 + 40: return launch_conv<64, 3, 2, 4, true, false>(a, st);
+    case 64 * 10000 + 3100 + 40: return launch_conv<64, 3, 1, 4, true, false>(a, st);   // 3x3 head tower on a 64-channel neck (sibling heads)
     case 64 * 10000 + 3100 + 10: return launch_conv<64, 3, 1, 1, true, false>(a, st);   // data gradient of 32->64 s2 (XS)
     case 64 * 10000 + 1100 + 10: return launch_conv<64, 1, 1, 1, true, false>(a, st);   // data gradient of the 32->64 downsample
     case 64 * 10000 + 1100 + 20: return launch_conv<64, 1, 1, 2, true, false>(a, st);
@@ -71,6 +72,7 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     case 128 * 10000 + 3100 + 40: return launch_conv<128, 3, 1, 4, false, false>(a, st);
     case 128 * 10000 + 3200 + 40: return launch_conv<128, 3, 2, 4, false, false>(a, st);
     case 128 * 10000 + 3100 + 20: return launch_conv<128, 3, 1, 2, false, false>(a, st);  // data gradient of 64->128 s2
+    case 128 * 10000 + 3200 + 20: return launch_conv<128, 3, 2, 2, false, false>(a, st);  // FPN extra level on a 128-channel input, 64 outputs
     case 128 * 10000 + 1100 + 20: return launch_conv<128, 1, 1, 2, true, false>(a, st);   // data gradient of the 64->128 downsample
     case 128 * 10000 + 1100 + 40: return launch_conv<128, 1, 1, 4, true, false>(a, st);
     case 128 * 10000 + 1200 + 40: return launch_conv<128, 1, 2, 4, true, false>(a, st);

@@ -3,7 +3,9 @@
 // the network through these on operands split into fp16 hi + lo parts, so that the SAME tiling / addressing / MFMA
 // contraction code is exercised while inter-layer storage stays fp32:
 //     conv(x, w) ~= acc32(x_hi, w_hi) + acc32(x_lo, w_hi) + acc32(x_hi, w_lo)        (x_lo * w_lo ~ 2^-22, dropped)
-// Not on the product path (never called by engine.py); kept in the library so that the test runs the shipped code.
+// Not on the LFD product path (never called by engine.py); kept in the library so that the test runs the shipped code.
+// The generic layer engine of the sibling meta-architectures (lfd_amd/engine_sibling.py) uses it for the heads' output
+// convs, whose logits leave the network as fp32.
 #include "conv_impl.h"
 
 extern "C" int lfd_conv2d_nhwc_f16_acc32(const lfd_conv_desc_t* d, const void* in, float* out_f32, const void* w_packed,
@@ -30,6 +32,8 @@ extern "C" int lfd_conv2d_nhwc_f16_acc32(const lfd_conv_desc_t* d, const void* i
     ACC32_CASE(64, 1, 1, 2, true);  ACC32_CASE(64, 1, 1, 4, true);  ACC32_CASE(64, 1, 2, 2, true);  ACC32_CASE(64, 1, 2, 4, true);
     ACC32_CASE(128, 3, 1, 4, false); ACC32_CASE(128, 3, 2, 4, false);
     ACC32_CASE(128, 1, 1, 2, true); ACC32_CASE(128, 1, 1, 4, true); ACC32_CASE(128, 1, 2, 4, true);
+    // output convs of the sibling heads (FCOSHead's 3x3 cls / centerness / reg, LFDHead on 64 channels): fp32 logits
+    ACC32_CASE(128, 3, 1, 2, false); ACC32_CASE(64, 3, 1, 1, true); ACC32_CASE(64, 1, 1, 1, true);
     default: return LFD_ERR_UNSUPPORTED;
   }
 #undef ACC32_CASE

@@ -8,7 +8,9 @@
 __device__ __forceinline__ float lfd_sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
 
 // regression outputs r0..r3 of the point at (px, py) -> clamped, rescaled box.  m = max(range) of the level for
-// decode_mode 0 ('sigmoid', lfd.py:483-486), range[1] for mode 2 ('independent', :468-478); mode 1 = exp (:480-482).
+// decode_mode 0 ('sigmoid', lfd.py:483-486), range[1] for mode 2 ('independent', :468-478); mode 1 = exp (:480-482);
+// mode 3 = the regression outputs ARE the distances (FCOS: the head already applied Scale + exp, fcos_head.py:145-146,
+// fcos.py:392 distance2bbox on the raw tensor).
 __device__ __forceinline__ float4 lfd_decode_core(int decode_mode, float r0, float r1, float r2, float r3, float px, float py,
                                                   float m, float W, float H, float sc) {
   float d0, d1, d2, d3;
@@ -17,6 +19,8 @@ __device__ __forceinline__ float4 lfd_decode_core(int decode_mode, float r0, flo
     d2 = lfd_sigmoidf_ref(r2) * m; d3 = lfd_sigmoidf_ref(r3) * m;
   } else if (decode_mode == 1) {
     d0 = expf(r0); d1 = expf(r1); d2 = expf(r2); d3 = expf(r3);
+  } else if (decode_mode == 3) {
+    d0 = r0; d1 = r1; d2 = r2; d3 = r3;
   } else {
     d0 = r0 * m; d1 = r1 * m; d2 = r2 * m; d3 = r3 * m;
   }

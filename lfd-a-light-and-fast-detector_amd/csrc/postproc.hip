@@ -106,6 +106,10 @@ struct DecodeParams {
   const void* reg;
   const float* meta;  // [N,3] = clampW, clampH, resize_scale
   int lds_stride;     // > 0: softmax rows of a block are staged through LDS with this (odd) float stride
+  // sibling meta-architectures (FCOS / LFDv2 get_results, lfd_detect_batched_ex); all zero on the LFD path
+  const void* ctr;        // [N,P] centerness logits (in_dtype): scores are multiplied by sigmoid(ctr) (fcos.py:376,403-409)
+  const uint32_t* keys;   // [N,P] top-k key of the point (fp32 bits of a value >= 0) | bit 31 = selected
+  uint32_t sel_levels;    // bit l: level l keeps only its pre_nms_limit best points (fcos.py:383-390, lfdv2.py:620-627)
 };
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return lfd_sigmoidf_ref(x); }
@@ -145,6 +149,23 @@ __device__ __forceinline__ float4 decode_box(const DecodeParams& d, int n, int p
   return lfd_decode_core(d.decode_mode, r0, r1, r2, r3, px, py, d.decode_mode == 0 ? d.lv.rmax[l] : d.lv.rhi[l], W, H, sc);
 }
 
+__device__ __forceinline__ int level_of(const LevelTable& lv, int p) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LFD_MAX_LEVELS; ++i)
+    if (i < lv.n && p >= lv.start[i]) l = i;
+  return l;
+}
+// score factor of a point (1 when the model has no centerness branch: s * 1.f == s bit for bit)
+__device__ __forceinline__ float ex_factor(const DecodeParams& d, int64_t row) {
+  return d.ctr ? sigmoidf_ref(lfd_load_f(d.ctr, row, d.in_dtype)) : 1.f;
+}
+// true when the point's level runs a pre-NMS top-k and the point did not make it
+__device__ __forceinline__ bool ex_dropped(const DecodeParams& d, int64_t row, int p) {
+  if (!d.sel_levels) return false;
+  return ((d.sel_levels >> level_of(d.lv, p)) & 1u) && !(d.keys[row] >> 31);
+}
+
 // Softmax models (46 channels for TT100K): a thread-per-point sweep reads its 184-byte row with a 184-byte lane stride --
 // every load instruction touches 64 cache lines.  The rows of a block's 256 points are one contiguous region: load it
 // coalesced into LDS (odd float stride: conflict-free thread-per-row reads), then evaluate exactly the expressions of
@@ -171,6 +192,8 @@ __device__ __forceinline__ void softmax_stats_row(const DecodeParams& d, const f
 }
 
 // ------------------------------------------------------------------ count / scatter
+// EX: the sibling meta-architectures' extras (centerness factor, per-level top-k survivors only)
+template <bool EX>
 __global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcounts, int nblk,
                                                   uint32_t* maxord, int* counts) {
   extern __shared__ float s_rows[];
@@ -178,18 +201,37 @@ __global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcoun
   const int n = blockIdx.y, blk = blockIdx.x;
   const int p = blk * kBlock + threadIdx.x;
   int cnt = 0;
+  float f = 1.f;
+  bool live = p < d.P;
   if (d.lds_stride > 0) {
     const float* rowp = stage_rows(d, n, blk, s_rows);
-    if (p < d.P) {
+    if (EX && live) {
+      const int64_t row = (int64_t)n * d.P + p;
+      live = !ex_dropped(d, row, p);
+      f = ex_factor(d, row);
+    }
+    if (live) {
       float mx, sum;
       softmax_stats_row(d, rowp, &mx, &sum);
-      for (int c = 0; c < d.C; ++c) cnt += (expf(rowp[c] - mx) / sum) > d.score_thr;
+      for (int c = 0; c < d.C; ++c) {
+        const float s = expf(rowp[c] - mx) / sum;
+        cnt += (EX ? s * f : s) > d.score_thr;
+      }
     }
-  } else if (p < d.P) {
+  } else if (live) {
     const int64_t row = (int64_t)n * d.P + p;
-    float mx = 0.f, sum = 1.f;
-    if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
-    for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
+    if (EX) {
+      live = !ex_dropped(d, row, p);
+      f = ex_factor(d, row);
+    }
+    if (live) {
+      float mx = 0.f, sum = 1.f;
+      if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+      for (int c = 0; c < d.C; ++c) {
+        const float s = score_of(d, row, c, mx, sum);
+        cnt += (EX ? s * f : s) > d.score_thr;
+      }
+    }
   }
   int total;
   block_excl_scan(cnt, &total, smem);
@@ -202,6 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcoun
   }
 }
 
+template <bool EX>
 __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* blockcounts, int nblk,
                                                     SegBuffers b, int* counts) {
   extern __shared__ float s_rows[];
@@ -226,19 +269,22 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
   }
   const int p = blk * kBlock + threadIdx.x;
   int cnt = 0;
-  float mx = 0.f, sum = 1.f;
-  int64_t row = 0;
+  float mx = 0.f, sum = 1.f, f = 1.f;
+  int64_t row = (int64_t)n * d.P + p;
   const float* rowp = nullptr;
-  if (d.lds_stride > 0) {
-    rowp = stage_rows(d, n, blk, s_rows);
-    if (p < d.P) {
-      softmax_stats_row(d, rowp, &mx, &sum);
-      for (int c = 0; c < d.C; ++c) cnt += (expf(rowp[c] - mx) / sum) > d.score_thr;
+  bool live = p < d.P;
+  if (d.lds_stride > 0) rowp = stage_rows(d, n, blk, s_rows);
+  if (EX && live) {
+    live = !ex_dropped(d, row, p);
+    f = ex_factor(d, row);
+  }
+  if (live) {
+    if (rowp) softmax_stats_row(d, rowp, &mx, &sum);
+    else if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+    for (int c = 0; c < d.C; ++c) {
+      const float s = rowp ? expf(rowp[c] - mx) / sum : score_of(d, row, c, mx, sum);
+      cnt += (EX ? s * f : s) > d.score_thr;
     }
-  } else if (p < d.P) {
-    row = (int64_t)n * d.P + p;
-    if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
-    for (int c = 0; c < d.C; ++c) cnt += score_of(d, row, c, mx, sum) > d.score_thr;
   }
   int total;
   int off = base + block_excl_scan(cnt, &total, smem);
@@ -247,7 +293,8 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
     const float4 box = decode_box(d, n, p);
     bool wrote = false;
     for (int c = 0; c < d.C; ++c) {
-      const float s = rowp ? expf(rowp[c] - mx) / sum : score_of(d, row, c, mx, sum);
+      float s = rowp ? expf(rowp[c] - mx) / sum : score_of(d, row, c, mx, sum);
+      if (EX) s = s * f;
       if (s > d.score_thr) {
         if (off < b.cap) {
           const int64_t o = (int64_t)n * b.cap + off;
@@ -274,6 +321,85 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
     uint32_t m = smax[0];
     for (int i = 1; i < kBlock / 64; ++i) m = smax[i] > m ? smax[i] : m;
     if (m) atomicMax(&b.maxord[n], m);
+  }
+}
+
+// ------------------------------------------------------------------ per-level pre-NMS top-k (sibling meta-architectures)
+// key of a point = max over classes of its final score (fcos.py:384 sorts after the centerness factor, lfdv2.py:621 has none)
+__global__ __launch_bounds__(kBlock) void k_ex_keys(DecodeParams d, uint32_t* keys) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= d.P) return;
+  if (!((d.sel_levels >> level_of(d.lv, p)) & 1u)) return;
+  const int64_t row = (int64_t)n * d.P + p;
+  const float f = ex_factor(d, row);
+  float mx = 0.f, sum = 1.f;
+  if (d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+  float best = 0.f;     // scores are >= 0: their fp32 bit patterns order like the values
+  for (int c = 0; c < d.C; ++c) best = fmaxf(best, score_of(d, row, c, mx, sum) * f);
+  keys[row] = __float_as_uint(best) & 0x7fffffffu;
+}
+
+constexpr int kSelThreads = 1024;
+// One workgroup per (level, image): radix-select the k-th largest key (4 x 8 bits, LDS histograms), then mark the k
+// survivors with bit 31 of their key: every key above the k-th value, and -- in index order -- as many of the keys EQUAL to
+// it as are needed to reach k (torch.topk leaves the choice among equal values open; lowest index first here).
+__global__ __launch_bounds__(kSelThreads) void k_ex_select(DecodeParams d, uint32_t* keys, int limit) {
+  __shared__ int hist[256];
+  __shared__ int s_wsum[kSelThreads / 64];
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_remaining, s_running;
+  const int l = blockIdx.x, n = blockIdx.y;
+  if (l >= d.lv.n || !((d.sel_levels >> l) & 1u)) return;
+  const int p0 = d.lv.start[l], np = d.lv.start[l + 1] - p0;
+  uint32_t* kk = keys + (int64_t)n * d.P + p0;
+  uint32_t prefix = 0u, mask = 0u;
+  int remaining = limit;                 // 0 < limit < np (host)
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = threadIdx.x; i < 256; i += kSelThreads) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < np; i += kSelThreads) {
+      const uint32_t k = kk[i];
+      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, bin = 255;
+      for (; bin > 0; --bin) {           // from the top: first bin whose cumulative count reaches `remaining`
+        if (acc + hist[bin] >= remaining) break;
+        acc += hist[bin];
+      }
+      s_prefix = prefix | ((uint32_t)bin << shift);
+      s_remaining = remaining - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    remaining = s_remaining;
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  // prefix = the k-th largest key; `remaining` of the keys equal to it survive
+  if (threadIdx.x == 0) s_running = 0;
+  __syncthreads();
+  const int lane = lfd_lane(), w = threadIdx.x >> 6;
+  for (int base = 0; base < np; base += kSelThreads) {
+    const int i = base + threadIdx.x;
+    const uint32_t k = i < np ? kk[i] : 0u;
+    const int tie = (i < np && k == prefix) ? 1 : 0;
+    const int inc = wave_incl_scan(tie);
+    if (lane == 63) s_wsum[w] = inc;
+    __syncthreads();
+    int before = s_running, tot = 0;
+    for (int j = 0; j < kSelThreads / 64; ++j) {
+      const int v = s_wsum[j];
+      if (j < w) before += v;
+      tot += v;
+    }
+    const bool sel = i < np && (k > prefix || (tie && before + inc - 1 < remaining));
+    if (sel) kk[i] = k | 0x80000000u;
+    __syncthreads();
+    if (threadIdx.x == 0) s_running += tot;
+    __syncthreads();
   }
 }
 
@@ -430,6 +556,7 @@ struct ScanOut {
   int64_t* keep64; // [cap] (API path, single segment) or nullptr
   int* counts;     // [nseg,4]: slot 1 <- number kept      (or nullptr)
   int* num_keep;   // [1] (API path)                       (or nullptr)
+  int max_keep;    // > 0: multiclass_nms max_num -- only the first max_keep kept rows count (nms.py:217-219)
 };
 
 constexpr int kScanThreads = 512;
@@ -578,8 +705,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(SegBuffers b, ScanOut o) 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (o.counts) o.counts[seg * 4 + 1] = s_nkept;
-    if (o.num_keep) o.num_keep[0] = s_nkept;
+    const int nkept = (o.max_keep > 0 && s_nkept > o.max_keep) ? o.max_keep : s_nkept;   // rows are score-descending
+    if (o.counts) o.counts[seg * 4 + 1] = nkept;
+    if (o.num_keep) o.num_keep[0] = nkept;
     if (b.total) {       // appended segment: publish the counts k_scatter would have written, re-arm the counters
       const int all = b.total[seg];
       if (o.counts) {
@@ -800,17 +928,17 @@ size_t lfd_detect_workspace_bytes(const lfd_detect_desc_t* desc, int32_t batch) 
   return cv.used() + 256;
 }
 
-int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void* cls, const void* reg,
-                       int32_t in_dtype, const float* img_meta, float* out_dets, int32_t* out_labels,
-                       int32_t* out_cand, int32_t* out_point, int32_t* out_counts, void* workspace,
-                       size_t workspace_bytes, lfd_stream_t stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+static int detect_batched_impl(const lfd_detect_desc_t* desc, const lfd_detect_ext_t* ext, int32_t batch, const void* cls,
+                               const void* reg, const void* centerness, int32_t in_dtype, const float* img_meta,
+                               float* out_dets, int32_t* out_labels, int32_t* out_cand, int32_t* out_point,
+                               int32_t* out_counts, void* workspace, size_t workspace_bytes, hipStream_t st) {
   DecodeParams d{};
   int rc = fill_decode_params(desc, in_dtype, cls, reg, img_meta, &d);
   if (rc != LFD_OK) return rc;
   if (batch < 1 || !cls || !reg || !img_meta || !out_counts || !workspace || desc->max_candidates < 1)
     return LFD_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < lfd_detect_workspace_bytes(desc, batch)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const size_t need = ext ? lfd_detect_ex_workspace_bytes(desc, batch) : lfd_detect_workspace_bytes(desc, batch);
+  if (workspace_bytes < need) return LFD_ERR_WORKSPACE_TOO_SMALL;
   if (d.P == 0) {
     if (hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 4 * batch, st) != hipSuccess) return LFD_ERR_LAUNCH_FAILED;
     return LFD_OK;
@@ -824,17 +952,61 @@ int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void*
   b.class_agnostic = desc->class_agnostic ? 1 : 0;
   b.iou_thr = desc->iou_thr;
   const size_t rows_lds = d.lds_stride > 0 ? (size_t)d.lds_stride * kBlock * sizeof(float) : 0;
-  hipLaunchKernelGGL(k_count, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b.maxord, out_counts);
-  LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scatter, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b, out_counts);
-  LFD_CHECK_LAUNCH();
   ScanOut o{};
+  if (ext) {
+    // FCOS / LFDv2: centerness factor, per-level top-k before the threshold, post-NMS cap
+    d.ctr = centerness;
+    uint32_t* keys = cv.take<uint32_t>((size_t)batch * d.P);
+    if (ext->pre_nms_limit > 0)
+      for (int i = 0; i < desc->num_levels; ++i)
+        if (ext->pre_nms_limit < desc->level_h[i] * desc->level_w[i]) d.sel_levels |= 1u << i;
+    if (d.sel_levels) {
+      d.keys = keys;
+      hipLaunchKernelGGL(k_ex_keys, dim3(nblk, batch), dim3(kBlock), 0, st, d, keys);
+      LFD_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_ex_select, dim3(desc->num_levels, batch), dim3(kSelThreads), 0, st, d, keys, ext->pre_nms_limit);
+      LFD_CHECK_LAUNCH();
+    }
+    o.max_keep = ext->post_nms_limit > 0 ? ext->post_nms_limit : 0;
+    hipLaunchKernelGGL(k_count<true>, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b.maxord, out_counts);
+    LFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scatter<true>, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b, out_counts);
+    LFD_CHECK_LAUNCH();
+  } else {
+    hipLaunchKernelGGL(k_count<false>, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b.maxord, out_counts);
+    LFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scatter<false>, dim3(nblk, batch), dim3(kBlock), rows_lds, st, d, blockcounts, nblk, b, out_counts);
+    LFD_CHECK_LAUNCH();
+  }
   o.dets = out_dets;
   o.labels = out_labels;
   o.cand = out_cand;
   o.point = out_point;
   o.counts = out_counts;
   return run_sort_mask_scan(b, o, batch, st);
+}
+
+int lfd_detect_batched(const lfd_detect_desc_t* desc, int32_t batch, const void* cls, const void* reg,
+                       int32_t in_dtype, const float* img_meta, float* out_dets, int32_t* out_labels,
+                       int32_t* out_cand, int32_t* out_point, int32_t* out_counts, void* workspace,
+                       size_t workspace_bytes, lfd_stream_t stream) {
+  return detect_batched_impl(desc, nullptr, batch, cls, reg, nullptr, in_dtype, img_meta, out_dets, out_labels, out_cand,
+                             out_point, out_counts, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t lfd_detect_ex_workspace_bytes(const lfd_detect_desc_t* desc, int32_t batch) {
+  const size_t base = lfd_detect_workspace_bytes(desc, batch);
+  if (!base) return 0;
+  return base + (size_t)batch * desc_points(desc) * sizeof(uint32_t) + 256;
+}
+
+int lfd_detect_batched_ex(const lfd_detect_desc_t* desc, const lfd_detect_ext_t* ext, int32_t batch, const void* cls,
+                          const void* reg, const void* centerness, int32_t in_dtype, const float* img_meta,
+                          float* out_dets, int32_t* out_labels, int32_t* out_cand, int32_t* out_point,
+                          int32_t* out_counts, void* workspace, size_t workspace_bytes, lfd_stream_t stream) {
+  if (!ext) return LFD_ERR_INVALID_ARGUMENT;
+  return detect_batched_impl(desc, ext, batch, cls, reg, centerness, in_dtype, img_meta, out_dets, out_labels, out_cand,
+                             out_point, out_counts, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int lfd_detect_workspace_reset(const lfd_detect_desc_t* desc, int32_t batch, void* workspace, size_t workspace_bytes,

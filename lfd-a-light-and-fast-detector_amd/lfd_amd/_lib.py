@@ -28,6 +28,11 @@ class DetectDesc(C.Structure):
                 ('score_thr', C.c_float), ('iou_thr', C.c_float)]
 
 
+class DetectExt(C.Structure):
+    """lfd_detect_ext_t"""
+    _fields_ = [('pre_nms_limit', C.c_int32), ('post_nms_limit', C.c_int32)]
+
+
 class ConvDesc(C.Structure):
     """lfd_conv_desc_t"""
     _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
@@ -97,6 +102,13 @@ _SIGNATURES = {
     'lfd_batched_nms_f32': (C.c_int, [_P, _P, _P, _I64, _F, _I32, _P, _P, _P, _P, _SZ, _P]),
     'lfd_detect_workspace_bytes': (_SZ, [C.POINTER(DetectDesc), _I32]),
     'lfd_detect_batched': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'lfd_detect_ex_workspace_bytes': (_SZ, [C.POINTER(DetectDesc), _I32]),
+    'lfd_detect_batched_ex': (C.c_int, [C.POINTER(DetectDesc), C.POINTER(DetectExt), _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P,
+                                        _P, _P, _SZ, _P]),
+    'lfd_upsample_nearest_add_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    'lfd_relu_inplace_f16': (C.c_int, [_P, _I64, _P]),
+    'lfd_maxpool3x3s2_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    'lfd_pack_level_outputs_f32': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P]),
     'lfd_detect_workspace_reset': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _SZ, _P]),
     'lfd_detect_from_candidates': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'lfd_decode_all': (C.c_int, [C.POINTER(DetectDesc), _I32, _P, _P, _I32, _P, _P, _P, _P]),

@@ -130,3 +130,125 @@ def perturb_weights(model, seed=1):
             elif v.dim() == 4 and k.startswith('_head.'):
                 v.copy_(torch.randn(v.shape, generator=g) * head_std)
     return model
+
+
+def synthetic_weights(model, seed=1):
+    """Deterministic, non-degenerate weights drawn PER state_dict KEY (generator seeded by crc32(key) ^ seed): two
+    implementations of the same architecture -- this package's modules and the reference's -- get identical tensors as
+    long as their key names and shapes agree, whatever their construction order.  Used for the sibling meta-architectures
+    (FCOS / LFDv2 fixtures, tests/golden/make_golden_siblings.py), whose modules are not built by build_modules.
+    conv weights ~ N(0, 1/fan_in) (output convs, < 16 filters: half of that), norm gamma ~ U(.5, 1.5), biases / running
+    means ~ N(0, .1), running_var ~ U(.5, 1.5), Scale ~ U(.8, 1.2)."""
+    import zlib
+    sd = model.state_dict()
+    seen = set()
+    with torch.no_grad():
+        for k in sorted(sd):
+            v = sd[k]
+            if v.data_ptr() in seen or k.endswith('num_batches_tracked'):
+                continue
+            seen.add(v.data_ptr())
+            g = torch.Generator().manual_seed((zlib.crc32(k.encode()) ^ seed) & 0x7fffffff)
+            if k.endswith('running_var'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith('_scale'):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.4 + 0.8)
+            elif v.dim() == 4:
+                fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+                v.copy_(torch.randn(v.shape, generator=g) * ((0.5 if v.shape[0] < 16 else 1.0) / fan_in ** 0.5))
+            elif v.dim() == 1 and k.endswith('.weight'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            else:
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    return model
+
+
+# ------------------------------------------------------------------ sibling meta-architectures (SURVEY 8 f4)
+# No shipped config uses FCOS / LFDv2 / FPN / SimpleFPN; these small compositions exercise them (tests, fixtures, tools).
+SIBLING_BACKBONE = dict(block_mode='faster', stem_mode='fast', stem_channels=64, body_architecture=[2, 1, 1],
+                        body_channels=[64, 64, 128], out_indices=((0, 1), (1, 0), (2, 0)))
+
+SIBLINGS = {
+    # FCOS: FPN with two conv extra levels (ReLU in front), GroupNorm FCOSHead
+    'FCOS_FPN': dict(meta='FCOS', backbone=SIBLING_BACKBONE,
+                     neck=dict(kind='FPN', num_output_channels=128, num_outputs=5, extra_on_input=False, extra_type='conv',
+                               norm_on_lateral=False, relu_on_lateral=False, relu_before_extra=True, norm_cfg=None),
+                     head=dict(kind='FCOSHead', num_classes=3, num_head_channels=128, num_layers=2,
+                               norm_cfg=dict(type='GroupNorm', num_groups=16)),
+                     regress_ranges=((0, 32), (32, 64), (64, 128), (128, 256), (256, 1e8)), pre_nms_bbox_limit=100,
+                     post_nms_bbox_limit=20),
+    # LFDv2 over SimpleFPN (BN + ReLU laterals, pooled extra level) and an LFDHead of 3x3 convs, separate towers, 64 channels
+    'LFDV2_SFPN': dict(meta='LFDv2', backbone=SIBLING_BACKBONE,
+                       neck=dict(kind='SimpleFPN', num_output_channels=64, num_outputs=4, extra_on_input=False,
+                                 extra_type='pooling', norm_on_lateral=True, relu_on_lateral=True, relu_before_extra=True,
+                                 norm_cfg=dict(type='BatchNorm2d'), neighbouring_mode=False),
+                       head=dict(kind='LFDHead', num_classes=4, num_head_channels=64, num_conv_layers=2, conv_kernel_size=3,
+                                 norm_cfg=dict(type='GroupNorm', num_groups=8), share_head_flag=True, merge_path_flag=False),
+                       classification_loss_type='FocalLoss', regression_loss_type='GIoULoss',
+                       regression_ranges=((4, 32), (32, 64), (64, 128), (128, 256)), gray_range_factors=(0.9, 1.1),
+                       range_assign_mode='sqrt', distance_to_bbox_mode='exp', pre_nms_bbox_limit=150, post_nms_bbox_limit=30),
+    # LFDv2 on the modules the fused LFD plan covers (SimpleNeck + 1x1 merged head): softmax scores, 'sigmoid' decode
+    'LFDV2_SIMPLE': dict(meta='LFDv2', backbone=SIBLING_BACKBONE,
+                         neck=dict(kind='SimpleNeck', num_neck_channels=128),
+                         head=dict(kind='LFDHead', num_classes=5, num_head_channels=128, num_conv_layers=2, conv_kernel_size=1,
+                                   norm_cfg=dict(type='GroupNorm', num_groups=16), share_head_flag=True, merge_path_flag=True),
+                         classification_loss_type='CrossEntropyLoss', regression_loss_type='IoULoss',
+                         regression_ranges=((4, 32), (32, 64), (64, 128)), gray_range_factors=(0.9, 1.1),
+                         range_assign_mode='longer', distance_to_bbox_mode='sigmoid', pre_nms_bbox_limit=120,
+                         post_nms_bbox_limit=25),
+}
+
+
+def build_sibling(spec, B, N, H, M, L, seed=1):
+    """Instantiate a SIBLINGS entry from module namespaces B (backbone), N (neck), H (head), M (meta-architectures) and L
+    (losses) -- this package's or the reference's (identical kwargs) -- and give it synthetic_weights(seed)."""
+    spec = SIBLINGS[spec] if isinstance(spec, str) else spec
+    bbk = spec['backbone']
+    bb = B.LFDResNet(block_mode=bbk['block_mode'], stem_mode=bbk['stem_mode'], body_mode=None, input_channels=3,
+                     stem_channels=bbk['stem_channels'], body_architecture=list(bbk['body_architecture']),
+                     body_channels=list(bbk['body_channels']), out_indices=bbk['out_indices'], frozen_stages=-1,
+                     activation_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='BatchNorm2d'),
+                     init_with_weight_file=None, norm_eval=False)
+    nk = dict(spec['neck'])
+    kind = nk.pop('kind')
+    if kind == 'SimpleNeck':
+        neck = N.SimpleNeck(num_neck_channels=nk['num_neck_channels'], num_input_channels_list=bb.num_output_channels_list,
+                            num_input_strides_list=bb.num_output_strides_list, norm_cfg=dict(type='BatchNorm2d'),
+                            activation_cfg=dict(type='ReLU', inplace=True))
+        cn = nk['num_neck_channels']
+    else:
+        neck = getattr(N, kind)(num_input_channels_list=list(bb.num_output_channels_list),
+                                num_input_strides_list=list(bb.num_output_strides_list), **nk)
+        cn = nk['num_output_channels']
+    strides = list(neck.num_output_strides_list)
+    hk = dict(spec['head'])
+    hkind = hk.pop('kind')
+    if spec['meta'] == 'FCOS':
+        head = H.FCOSHead(num_input_channels=cn, num_heads=len(strides), **hk)
+        model = M.FCOS(backbone=bb, neck=neck, head=head, num_classes=hk['num_classes'], regress_ranges=spec['regress_ranges'],
+                       point_strides=strides,
+                       classification_loss_func=L.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                       regression_loss_func=L.GIoULoss(loss_weight=1.0),
+                       centerness_loss_func=L.BCEWithLogitsLoss(reduction='mean', loss_weight=1.0),
+                       classification_threshold=0.05, nms_threshold=0.5, pre_nms_bbox_limit=spec['pre_nms_bbox_limit'],
+                       post_nms_bbox_limit=spec['post_nms_bbox_limit'])
+    else:
+        cls_loss = (L.CrossEntropyLoss(reduction='mean', loss_weight=1.0) if spec['classification_loss_type'] == 'CrossEntropyLoss'
+                    else L.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0))
+        reg_loss = getattr(L, spec['regression_loss_type'])(reduction='mean', loss_weight=1.0)
+        head = H.LFDHead(num_input_channels=cn, num_heads=len(strides), activation_cfg=dict(type='ReLU', inplace=True),
+                         classification_loss_type=type(cls_loss).__name__, regression_loss_type=type(reg_loss).__name__, **hk)
+        model = M.LFDv2(backbone=bb, neck=neck, head=head, num_classes=hk['num_classes'],
+                        regression_ranges=spec['regression_ranges'], gray_range_factors=spec['gray_range_factors'],
+                        range_assign_mode=spec['range_assign_mode'], point_strides=strides, classification_loss_func=cls_loss,
+                        regression_loss_func=reg_loss, distance_to_bbox_mode=spec['distance_to_bbox_mode'],
+                        classification_threshold=0.05, nms_threshold=0.5, pre_nms_bbox_limit=spec['pre_nms_bbox_limit'],
+                        post_nms_bbox_limit=spec['post_nms_bbox_limit'])
+    return synthetic_weights(model, seed)
+
+
+def build_sibling_model(name, seed=1):
+    """This package's model for a SIBLINGS entry."""
+    from .model import backbone as B, head as H, losses as L, neck as N
+    from . import model as M
+    return build_sibling(name, B, N, H, M, L, seed)

@@ -1,1 +1,2 @@
 from .lfd_head import *
+from .fcos_head import *

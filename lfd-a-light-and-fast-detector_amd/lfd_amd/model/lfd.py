@@ -52,6 +52,8 @@ class _FusedLossFunction(torch.autograd.Function):
 
 class LFD(nn.Module):
 
+    _ASSIGN_MODES = ('longer', 'shorter', 'dist')       # lfd.py:35
+
     def __init__(self, backbone=None, neck=None, head=None, num_classes=80,
                  regression_ranges=((0, 64), (64, 128), (128, 256), (256, 512), (512, 1024)),
                  gray_range_factors=(0.9, 1.1), range_assign_mode='dist', point_strides=(8, 16, 32, 64, 128),
@@ -60,13 +62,13 @@ class LFD(nn.Module):
                  classification_threshold=0.05, nms_threshold=0.4):
         super().__init__()
         assert len(regression_ranges) == len(point_strides)
-        assert range_assign_mode in ['longer', 'shorter', 'dist']
+        assert range_assign_mode in self._ASSIGN_MODES
         assert distance_to_bbox_mode in ['exp', 'sigmoid']
         self._backbone, self._neck, self._head = backbone, neck, head
         self._num_classes = num_classes
         self._regression_ranges = regression_ranges
         self._range_assign_mode = range_assign_mode
-        if range_assign_mode == 'shorter':
+        if range_assign_mode in ('shorter', 'sqrt'):
             assert type(regression_loss_func).__name__ in _UNION
             assert distance_to_bbox_mode == 'exp'
         self._gray_range_factors = (min(gray_range_factors), max(gray_range_factors))
@@ -358,11 +360,16 @@ class LFD(nn.Module):
             gt_l.append(torch.as_tensor(labels_numpy).to(dev))
         pts_list = self.generate_point_coordinates(self._head_indexes_to_feature_map_sizes)
         cls_t, reg_t = self.annotation_to_target(pts_list, gt_b, gt_l)
+        if self._fused_loss_supported(pred_cls):
+            return self._get_loss_fused(pred_cls, pred_reg, cls_t, reg_t)
+        return self._loss_from_targets(pred_cls, pred_reg, cls_t, reg_t, pts_list)
+
+    def _loss_from_targets(self, pred_cls, pred_reg, cls_t, reg_t, pts_list):
+        """lfd.py:300-395 from the flattening on: op by op on the HIP loss kernels (any loss module combination)"""
+        dev = pred_cls.device
         N = pred_cls.size(0)
         C = self._num_classes
         ce = self._is_ce()
-        if self._fused_loss_supported(pred_cls):
-            return self._get_loss_fused(pred_cls, pred_reg, cls_t, reg_t)
         fc = pred_cls.reshape(-1, C + 1 if ce else C)
         fr = pred_reg.reshape(-1, 4)
         ct = cls_t.reshape(-1, C).to(dev)

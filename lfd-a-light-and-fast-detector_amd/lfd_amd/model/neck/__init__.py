@@ -1,1 +1,3 @@
 from .simple_neck import *
+from .fpn import *
+from .simple_fpn import *

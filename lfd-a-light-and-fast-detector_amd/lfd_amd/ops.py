@@ -157,6 +157,42 @@ def detect_batched(desc, cls, reg, meta, out=None):
     return out
 
 
+def detect_batched_ex(desc, cls, reg, meta, centerness=None, pre_nms_limit=-1, post_nms_limit=-1, out=None):
+    """detect_batched for the sibling meta-architectures (FCOS / LFDv2 get_results): optional centerness logits [N,P]
+    (score factor sigmoid(centerness)), per-level pre-NMS top-k, post-NMS cap (lfd_detect_batched_ex)."""
+    require_cuda(cls, 'detect')
+    n = cls.size(0)
+    cls = cls.contiguous()
+    reg = reg.contiguous()
+    if cls.dtype != reg.dtype:
+        raise RuntimeError('cls / reg dtype mismatch')
+    if centerness is not None:
+        centerness = centerness.contiguous()
+        if centerness.dtype != cls.dtype or centerness.numel() != n * cls.size(1):
+            raise RuntimeError('centerness must be [N,P] (or [N,P,1]) in the dtype of cls')
+    dev = cls.device
+    cap = desc.max_candidates
+    ext = _lib.DetectExt(int(pre_nms_limit), int(post_nms_limit))
+    with torch.cuda.device(dev):
+        if out is None:
+            out = DetectOutputs()
+            out.dets = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
+            out.labels = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.cand = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.point = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            out.counts = torch.empty((n, 4), dtype=torch.int32, device=dev)
+            out.ws = None
+        wsb = lib().lfd_detect_ex_workspace_bytes(C.byref(desc), n)
+        if getattr(out, 'ws', None) is None or out.ws.numel() < wsb:
+            out.ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+        ws = out.ws
+        check(lib().lfd_detect_batched_ex(C.byref(desc), C.byref(ext), n, ptr(cls), ptr(reg), ptr(centerness),
+                                          _dtype_code(cls), ptr(meta), ptr(out.dets), ptr(out.labels), ptr(out.cand),
+                                          ptr(out.point), ptr(out.counts), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_detect_batched_ex')
+    return out
+
+
 def decode_all(desc, cls, reg, meta):
     require_cuda(cls, 'decode')
     n, p = cls.size(0), cls.size(1)
@@ -504,6 +540,68 @@ def conv2d_nhwc(x, w_packed, bias, cin, cout, ks, stride, relu, residual=None, t
                                         ptr(tail[0]) if tail else None, ptr(tail[1]) if tail else None,
                                         ptr(zero_line(x.device)), stream_ptr()), 'lfd_conv2d_nhwc_f16')
     return out
+
+
+def conv2d_nhwc_f32out(x, w_packed, bias, cin, cout, ks, stride):
+    """x [N,H,W,cin] fp16 -> conv + bias as fp32 [N,OH,OW,cout] (the MFMA accumulators, un-rounded): the output convs of
+    the sibling heads, whose logits leave the network as fp32 (lfd_conv2d_nhwc_f16_acc32)."""
+    require_cuda(x, 'conv2d')
+    if x.dtype != torch.float16 or not x.is_contiguous() or x.shape[3] != cin:
+        raise RuntimeError('conv2d_nhwc_f32out: x must be contiguous fp16 NHWC with %d channels' % cin)
+    n, h, w_, _ = x.shape
+    pad = ks // 2
+    oh = (h + 2 * pad - ks) // stride + 1
+    ow = (w_ + 2 * pad - ks) // stride + 1
+    d = _lib.ConvDesc(n, h, w_, cin, cout, ks, stride, 0, 0, 0)
+    with torch.cuda.device(x.device):
+        out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+        check(lib().lfd_conv2d_nhwc_f16_acc32(C.byref(d), ptr(x), ptr(out), ptr(w_packed), ptr(bias),
+                                              ptr(zero_line(x.device)), stream_ptr()), 'lfd_conv2d_nhwc_f16_acc32')
+    return out
+
+
+def upsample_nearest_add_(dst, src):
+    """dst [N,H,W,C] += nearest-neighbour resize of src [N,h,w,C] (fp16 NHWC, in place): the FPN merge step"""
+    _nhwc16(dst, 'upsample_nearest_add')
+    _nhwc16(src, 'upsample_nearest_add')
+    n, H, W, c = dst.shape
+    if src.shape[0] != n or src.shape[3] != c:
+        raise RuntimeError('upsample_nearest_add: batch / channel mismatch')
+    with torch.cuda.device(dst.device):
+        check(lib().lfd_upsample_nearest_add_nhwc_f16(ptr(dst), ptr(src), n, H, W, src.shape[1], src.shape[2], c, stream_ptr()),
+              'lfd_upsample_nearest_add_nhwc_f16')
+    return dst
+
+
+def relu_(x):
+    _nhwc16(x, 'relu_')
+    with torch.cuda.device(x.device):
+        check(lib().lfd_relu_inplace_f16(ptr(x), x.numel(), stream_ptr()), 'lfd_relu_inplace_f16')
+    return x
+
+
+def maxpool3x3s2(x):
+    _nhwc16(x, 'maxpool3x3s2')
+    n, h, w_, c = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((n, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1, c), dtype=torch.float16, device=x.device)
+        check(lib().lfd_maxpool3x3s2_nhwc_f16(ptr(x), ptr(out), n, h, w_, c, stream_ptr()), 'lfd_maxpool3x3s2_nhwc_f16')
+    return out
+
+
+def pack_level_outputs(src, dst, c0, count, point_offset, scale=1.0, exp=False):
+    """channels c0..c0+count of src [N,h,w,cs] fp32 -> dst[:, point_offset:point_offset+h*w, :count] (dst [N,P,count] fp32),
+    times `scale`, optionally through expf"""
+    require_cuda(src, 'pack_level_outputs')
+    n, h, w_, cs = src.shape
+    if dst.dtype != torch.float32 or src.dtype != torch.float32 or not dst.is_contiguous() or not src.is_contiguous():
+        raise RuntimeError('pack_level_outputs: contiguous fp32 tensors expected')
+    if dst.size(0) != n or dst.size(2) != count:
+        raise RuntimeError('pack_level_outputs: shape mismatch')
+    with torch.cuda.device(src.device):
+        check(lib().lfd_pack_level_outputs_f32(ptr(src), ptr(dst), n, h * w_, cs, c0, count, dst.size(1), point_offset,
+                                               float(scale), int(bool(exp)), stream_ptr()), 'lfd_pack_level_outputs_f32')
+    return dst
 
 
 def fasterblock_fused(x, w1_packed, b1, w2_packed, b2, out=None):

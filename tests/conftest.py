@@ -15,6 +15,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)      # sibling_cases.py: seeded inputs shared with the fixture generator
 warnings.filterwarnings('ignore', message='.*indexing.*')
 
 
