@@ -211,7 +211,7 @@ class SiblingPlan(object):
             self.num_cls_channels = head._num_classes
             for i in range(head._num_heads):
                 self.levels.append(dict(cls_t=cls_t, reg_t=reg_t, cls_o=cls_o, ctr_o=ctr_o, reg_o=reg_o,
-                                        scale=head._scales[i]._scale, exp=True))
+                                        scale=float(head._scales[i]._scale.detach()), exp=True))
             self.has_ctr = True
             return
         if kind != 'LFDHead':
@@ -231,7 +231,8 @@ class SiblingPlan(object):
             merge = getattr(head, 'head%d_merge_path' % i)
             cls_p = getattr(head, 'head%d_classification_path' % i)
             reg_p = getattr(head, 'head%d_regression_path' % i)
-            lv = dict(exp=False, scale=head._scales[i]._scale if union else None, ctr_o=None)
+            # (a parameter update changes the plan signature, so the value read here cannot go stale)
+            lv = dict(exp=False, scale=float(head._scales[i]._scale.detach()) if union else 1.0, ctr_o=None)
             if head._merge_path_flag:
                 lv['merge'] = compiled(merge, cn)
                 c = lv['merge'].cout
@@ -253,7 +254,7 @@ class SiblingPlan(object):
         ctr = torch.empty((n, P, 1), dtype=torch.float32, device=dev) if self.has_ctr else None
         p0 = 0
         for lv, f, (h, w) in zip(self.levels, feats, sizes):
-            scale = float(lv['scale'].detach()) if lv['scale'] is not None else 1.0
+            scale = lv['scale']
             if self.head_kind == 'FCOSHead':
                 tc = lv['cls_t'](f)
                 tr = lv['reg_t'](f)
@@ -289,15 +290,36 @@ def backbone_taps(plan, x):
 
 
 @torch.no_grad()
-def sibling_forward(model, x):
-    """eval-mode forward of FCOS / LFDv2 on the device -> (cls, reg, centerness | None, sizes), fp32, level-concatenated"""
+def sibling_forward(model, x, use_graph=False):
+    """eval-mode forward of FCOS / LFDv2 on the device -> (cls, reg, centerness | None, sizes), fp32, level-concatenated.
+    use_graph: the ~100 launches of a forward are captured into one HIP graph per input buffer and replayed (the
+    returned tensors are then graph-owned and overwritten by the next call with the same input buffer)."""
     _lib.require_cuda(x, '%s.forward' % type(model).__name__)
     if not x.is_contiguous():
         x = x.contiguous()
     plan = get_plan(model, model._backbone, model._neck, model._head, x.device)
+
+    def run():
+        return plan.run_head(plan.run_neck(backbone_taps(plan, x)))
+
     with torch.cuda.device(x.device):
-        feats = plan.run_neck(backbone_taps(plan, x))
-        return plan.run_head(feats)
+        if not use_graph:
+            return run()
+        graphs = plan.__dict__.setdefault('graphs', {})
+        key = (x.data_ptr(), tuple(x.shape), x.dtype)
+        ent = graphs.get(key)
+        if ent is None:
+            if len(graphs) >= 4:
+                graphs.pop(next(iter(graphs)))
+            run()                               # warm-up outside capture: kernel attributes, workspaces
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = run()
+            ent = (g, outs, x)                  # keep the captured input alive
+            graphs[key] = ent
+        ent[0].replay()
+        return ent[1]
 
 
 @torch.no_grad()

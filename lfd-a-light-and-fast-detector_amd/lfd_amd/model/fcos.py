@@ -50,6 +50,7 @@ class FCOS(nn.Module):
         self._param_groups_cfg = param_groups_cfg
         self._head_indexes_to_feature_map_sizes = dict()
         self.max_candidates = 8192
+        self.use_graph = False       # capture the eval-mode forward into a HIP graph per input buffer
 
     @property
     def head_indexes_to_feature_map_sizes(self):
@@ -77,7 +78,7 @@ class FCOS(nn.Module):
         """fcos.py:414-449"""
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
             return self._forward_train(x)
-        cls, reg, ctr, sizes = engine_sibling.sibling_forward(self, x)
+        cls, reg, ctr, sizes = engine_sibling.sibling_forward(self, x, use_graph=self.use_graph)
         for i, hw in enumerate(sizes):
             self._head_indexes_to_feature_map_sizes[i] = hw
         return cls, reg, ctr

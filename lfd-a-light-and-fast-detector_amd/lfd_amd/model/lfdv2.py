@@ -68,7 +68,7 @@ class LFDv2(LFD):
     def forward_resident(self, x, slot=0):
         if x.is_cuda and self._fused_plan_ok(x.device):
             return super().forward_resident(x, slot)
-        cls, reg, _, sizes = engine_sibling.sibling_forward(self, x)
+        cls, reg, _, sizes = engine_sibling.sibling_forward(self, x, use_graph=self.use_graph)
         for i, hw in enumerate(sizes):
             self._head_indexes_to_feature_map_sizes[i] = hw
         return cls, reg

@@ -43,6 +43,7 @@ def test_workspace_queries_are_pure_host_functions():
     d.num_classes = d.num_cls_channels = 1
     d.max_candidates = 16
     assert l.lfd_detect_workspace_bytes(ctypes.byref(d), 2) > 0
+    assert l.lfd_detect_ex_workspace_bytes(ctypes.byref(d), 2) >= l.lfd_detect_workspace_bytes(ctypes.byref(d), 2) + 2 * 16 * 4
     assert l.lfd_conv_packed_weight_halfs(64, 64, 3) == 64 * 64 * 9
     hd = _lib.HeadDesc()
     hd.n, hd.num_levels, hd.num_groups = 2, 2, 16
@@ -62,6 +63,16 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_head_forward_decode_f16(None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert l.lfd_groupnorm_finalize_fold(None, None, None, None, 1e-5, None, None, 1, None) == -1
     assert l.lfd_fasterblock_fused_f16(0, 8, 8, None, None, None, None, None, None, None, None) == -1
+    # sibling meta-architecture entry points
+    assert l.lfd_detect_batched_ex(None, None, 1, None, None, None, 0, None, None, None, None, None, None, None, 0, None) == -1
+    assert l.lfd_upsample_nearest_add_nhwc_f16(None, None, 1, 4, 4, 2, 2, 64, None) == -1
+    assert l.lfd_relu_inplace_f16(None, 64, None) == -1
+    assert l.lfd_maxpool3x3s2_nhwc_f16(None, None, 1, 4, 4, 64, None) == -1
+    assert l.lfd_pack_level_outputs_f32(None, None, 1, 16, 32, 0, 4, 16, 0, 1.0, 0, None) == -1
+    one = C.c_int(0)
+    assert l.lfd_upsample_nearest_add_nhwc_f16(C.byref(one), C.byref(one), 1, 4, 4, 2, 2, 12, None) == -4      # channels % 8
+    assert l.lfd_pack_level_outputs_f32(C.byref(one), C.byref(one), 1, 16, 32, 30, 4, 16, 0, 1.0, 0, None) == -1   # c0 + count > channels
+    assert l.lfd_pack_level_outputs_f32(C.byref(one), C.byref(one), 1, 16, 32, 0, 4, 8, 0, 1.0, 0, None) == -1     # rows beyond total_points
     # the fused head-decode pass covers one sigmoid-scored class: anything else is LFD_ERR_UNSUPPORTED (-4), never a wrong answer
     hd = _lib.HeadDesc()
     hd.n, hd.num_levels, hd.num_groups, hd.head_channels = 1, 1, 16, 128
@@ -84,7 +95,7 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
     from lfd_amd import _lib
     pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc,
              'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
-             'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob}
+             'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob, 'lfd_detect_ext_t': _lib.DetectExt}
     header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lfd_hip.h"', 'int main(void) {']
     for cname, mirror in pairs.items():

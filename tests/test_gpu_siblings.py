@@ -180,6 +180,20 @@ def test_sibling_forward_on_device_vs_reference(name):
 
 
 @pytest.mark.parametrize('name', NAMES)
+def test_sibling_forward_replayed_from_a_hip_graph_equals_eager_launches(name):
+    g = load_golden('ref_sibling_%s.npz' % name)
+    model = configs.build_sibling_model(name, seed=1).eval().to(DEV)
+    x = model_input(g).to(DEV)
+    with torch.no_grad():
+        eager = [o.clone() for o in model(x)]
+        model.use_graph = True
+        for _ in range(2):                       # capture, then a pure replay
+            graphed = model(x)
+        for a, b in zip(eager, graphed):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name', NAMES)
 def test_sibling_get_results_on_device_equals_oracle_on_the_same_logits(name):
     """get_results of the device model vs the oracle's get_results fed the DEVICE's forward outputs: isolates the
     post-processing (bit-exact rows) from the fp16-storage forward"""
