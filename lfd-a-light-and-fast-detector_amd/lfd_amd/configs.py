@@ -196,6 +196,15 @@ SIBLINGS = {
                          regression_ranges=((4, 32), (32, 64), (64, 128)), gray_range_factors=(0.9, 1.1),
                          range_assign_mode='longer', distance_to_bbox_mode='sigmoid', pre_nms_bbox_limit=120,
                          post_nms_bbox_limit=25),
+    # LFDv2 over SimpleNeck + LFDHeadV1 (per-level output convs outside shared BatchNorm towers): 'exp' decode
+    'LFDV2_HEADV1': dict(meta='LFDv2', backbone=SIBLING_BACKBONE,
+                         neck=dict(kind='SimpleNeck', num_neck_channels=64),
+                         head=dict(kind='LFDHeadV1', num_classes=2, num_head_channels=64, num_conv_layers=2,
+                                   norm_cfg=dict(type='BatchNorm2d'), share_head_flag=True, merge_path_flag=True),
+                         classification_loss_type='FocalLoss', regression_loss_type='IoULoss',
+                         regression_ranges=((4, 32), (32, 64), (64, 128)), gray_range_factors=(0.9, 1.1),
+                         range_assign_mode='dist', distance_to_bbox_mode='exp', pre_nms_bbox_limit=200,
+                         post_nms_bbox_limit=40),
 }
 
 
@@ -223,9 +232,9 @@ def build_sibling(spec, B, N, H, M, L, seed=1):
     strides = list(neck.num_output_strides_list)
     hk = dict(spec['head'])
     hkind = hk.pop('kind')
-    if spec['meta'] == 'FCOS':
+    if spec['meta'] in ('FCOS', 'FCOSv1'):
         head = H.FCOSHead(num_input_channels=cn, num_heads=len(strides), **hk)
-        model = M.FCOS(backbone=bb, neck=neck, head=head, num_classes=hk['num_classes'], regress_ranges=spec['regress_ranges'],
+        model = getattr(M, spec['meta'])(backbone=bb, neck=neck, head=head, num_classes=hk['num_classes'], regress_ranges=spec['regress_ranges'],
                        point_strides=strides,
                        classification_loss_func=L.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
                        regression_loss_func=L.GIoULoss(loss_weight=1.0),
@@ -236,8 +245,9 @@ def build_sibling(spec, B, N, H, M, L, seed=1):
         cls_loss = (L.CrossEntropyLoss(reduction='mean', loss_weight=1.0) if spec['classification_loss_type'] == 'CrossEntropyLoss'
                     else L.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0))
         reg_loss = getattr(L, spec['regression_loss_type'])(reduction='mean', loss_weight=1.0)
-        head = H.LFDHead(num_input_channels=cn, num_heads=len(strides), activation_cfg=dict(type='ReLU', inplace=True),
-                         classification_loss_type=type(cls_loss).__name__, regression_loss_type=type(reg_loss).__name__, **hk)
+        head = getattr(H, hkind)(num_input_channels=cn, num_heads=len(strides), activation_cfg=dict(type='ReLU', inplace=True),
+                                 classification_loss_type=type(cls_loss).__name__,
+                                 regression_loss_type=type(reg_loss).__name__, **hk)
         model = M.LFDv2(backbone=bb, neck=neck, head=head, num_classes=hk['num_classes'],
                         regression_ranges=spec['regression_ranges'], gray_range_factors=spec['gray_range_factors'],
                         range_assign_mode=spec['range_assign_mode'], point_strides=strides, classification_loss_func=cls_loss,

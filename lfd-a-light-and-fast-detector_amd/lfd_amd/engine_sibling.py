@@ -214,7 +214,7 @@ class SiblingPlan(object):
                                         scale=float(head._scales[i]._scale.detach()), exp=True))
             self.has_ctr = True
             return
-        if kind != 'LFDHead':
+        if kind not in ('LFDHead', 'LFDHeadV1'):
             _unsupported('head %s' % kind)
         self.has_ctr = False
         self.num_cls_channels = head.num_cls_channels
@@ -239,8 +239,13 @@ class SiblingPlan(object):
             else:
                 lv['merge'] = None
                 c = cn
-            lv['cls_p'] = compiled(cls_p, c, True)
-            lv['reg_p'] = compiled(reg_p, c, True)
+            if kind == 'LFDHeadV1':     # towers end without the output convs: those are per-level members
+                lv['cls_p'], lv['reg_p'] = compiled(cls_p, c), compiled(reg_p, c)
+                lv['cls_o'] = _Conv(head._classifiers[i], None, False, lv['cls_p'].cout, self.dev, f32out=True)
+                lv['reg_o'] = _Conv(head._regressors[i], None, False, lv['reg_p'].cout, self.dev, f32out=True)
+            else:
+                lv['cls_p'] = compiled(cls_p, c, True)
+                lv['reg_p'] = compiled(reg_p, c, True)
             self.levels.append(lv)
 
     def run_head(self, feats):
@@ -263,8 +268,11 @@ class SiblingPlan(object):
                 ops.pack_level_outputs(lv['reg_o'](tr), reg, 0, 4, p0, scale=scale, exp=True)
             else:
                 t = lv['merge'](f) if lv['merge'] is not None else f
-                ops.pack_level_outputs(lv['cls_p'](t), cls, 0, self.num_cls_channels, p0)
-                ops.pack_level_outputs(lv['reg_p'](t), reg, 0, 4, p0, scale=scale)
+                c, r = lv['cls_p'](t), lv['reg_p'](t)
+                if 'cls_o' in lv:
+                    c, r = lv['cls_o'](c), lv['reg_o'](r)
+                ops.pack_level_outputs(c, cls, 0, self.num_cls_channels, p0)
+                ops.pack_level_outputs(r, reg, 0, 4, p0, scale=scale)
             p0 += h * w
         return cls, reg, ctr, sizes
 

@@ -1,5 +1,5 @@
-"""FCOS meta-architecture -- host-side mirror of lfd/model/fcos.py:12-449 (class FCOS; the FCOSv1 variant :452-900 differs
-only in its target bookkeeping and is not mirrored).
+"""FCOS meta-architecture -- host-side mirror of lfd/model/fcos.py:12-449 (class FCOS) and :452-900 (FCOSv1, the
+multi-label experiment: same network and post-processing, per-class binary targets).
 
 Same constructor kwargs, `forward(x) -> (cls [N,P,C], reg [N,P,4] distances, centerness [N,P,1])` fp32,
 `head_indexes_to_feature_map_sizes`, `get_param_groups_for_optimizer`, `annotation_to_target`, `centerness_target`,
@@ -21,7 +21,7 @@ from .. import _lib, engine_sibling, ops, train_engine
 from .lfd import LFD
 from .utils import multiclass_nms  # noqa: F401  (importable like the reference module)
 
-__all__ = ['FCOS']
+__all__ = ['FCOS', 'FCOSv1']
 
 INF = 1e8
 
@@ -125,7 +125,7 @@ class FCOS(nn.Module):
         assert gt.size(0) == gt_labels.size(0)
         P, G = points.size(0), gt_labels.size(0)
         if G == 0:
-            return gt_labels.new_full((P,), self._num_classes), gt.new_zeros((P, 4))
+            return self._empty_labels(gt_labels, P), gt.new_zeros((P, 4))
         areas = (gt[:, 2] * gt[:, 3])[None].repeat(P, 1)
         rng = ranges[:, None, :].expand(P, G, 2)
         gb = gt[None].expand(P, G, 4)
@@ -138,8 +138,19 @@ class FCOS(nn.Module):
         valid = inside & (far >= rng[:, :, 0]) & (far <= rng[:, :, 1])
         areas = areas * valid + INF * (~valid)
         best_area, best = areas.min(dim=1)
-        labels = gt_labels[best] * (best_area != INF) + self._num_classes * (best_area == INF)
-        return labels, dist[range(P), best]
+        return self._labels(gt_labels, valid, best, best_area), dist[range(P), best]
+
+    def _empty_labels(self, gt_labels, P):
+        return gt_labels.new_full((P,), self._num_classes)
+
+    def _labels(self, gt_labels, valid, best, best_area):
+        """fcos.py:178-181: the label of the smallest valid box, C (background) where no box is valid"""
+        return gt_labels[best] * (best_area != INF) + self._num_classes * (best_area == INF)
+
+    def _flatten_classification(self, pred_cls, cls_t, dev):
+        """-> (logits [M, C'], integer targets [M], indices of the positive POINTS)   (fcos.py:264-284)"""
+        ct = cls_t.reshape(-1).to(dev)
+        return pred_cls.reshape(-1, self._num_classes), ct, (ct != self._num_classes).nonzero().reshape(-1)
 
     def centerness_target(self, pos_flatten_regress_targets):
         """fcos.py:211-215"""
@@ -161,13 +172,11 @@ class FCOS(nn.Module):
         pts_list = self.generate_point_coordinates(self._head_indexes_to_feature_map_sizes)
         cls_t, reg_t = self.annotation_to_target(pts_list, gt_b, gt_l)
         N = pred_cls.shape[0]
-        fc = pred_cls.reshape(-1, self._num_classes)
+        fc, ct, pos = self._flatten_classification(pred_cls, cls_t, dev)
         fr = pred_reg.reshape(-1, 4)
         fctr = pred_ctr.reshape(-1)
-        ct = cls_t.reshape(-1).to(dev)
         rt = reg_t.reshape(-1, 4).to(dev)
         allp = torch.cat(pts_list, dim=0).repeat(N, 1).to(dev)
-        pos = (ct != self._num_classes).nonzero().reshape(-1)
         num_pos = pos.nelement()
         cls_loss = self._classification_loss_func(fc, ct, avg_factor=num_pos + N)
         pr, pc = fr[pos], fctr[pos]
@@ -208,6 +217,29 @@ class FCOS(nn.Module):
     def get_results(self, predict_outputs, *args):
         """fcos.py:319-354: per image a list of [label, score, x1, y1, w, h] rows ([] when nothing survives)"""
         return _results_from_detect(self, predict_outputs, args[0])
+
+
+class FCOSv1(FCOS):
+    """lfd/model/fcos.py:452-900 -- "one point may predict several classes": the classification target of a point is a
+    row of C binary labels (0 = this class is present at the point, 1 = background; :611-616) instead of one label, the
+    logits are flattened to [N*P*C, 1] for a one-class focal loss (:711), a point is positive when any of its classes is
+    (:715-716).  The regression / centerness targets, the network and get_results are FCOS's."""
+
+    def _empty_labels(self, gt_labels, P):
+        # (the reference returns FCOS's [P] vector of C here, :570-572, which its own get_loss cannot reshape to [*, C]
+        # unless C == 1; an all-background row per point is what that branch means)
+        return gt_labels.new_ones((P, self._num_classes))
+
+    def _labels(self, gt_labels, valid, best, best_area):
+        t = gt_labels.new_ones((valid.size(0), self._num_classes))
+        rows, cols = torch.where(valid)
+        t[rows, gt_labels[cols]] = 0
+        return t
+
+    def _flatten_classification(self, pred_cls, cls_t, dev):
+        ct = cls_t.reshape(-1, self._num_classes)
+        pos = (ct == 0).sum(dim=1).nonzero().reshape(-1).to(dev)
+        return pred_cls.reshape(-1, 1), ct.reshape(-1).to(dev), pos
 
 
 def _results_from_detect(model, predict_outputs, meta_batch):

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ..backbone.lfd_resnet import build_activation, build_norm
 
-__all__ = ['LFDHead', 'Scale']
+__all__ = ['LFDHead', 'LFDHeadV1', 'Scale']
 
 _UNION_LOSSES = ('IoULoss', 'GIoULoss', 'DIoULoss', 'CIoULoss')
 
@@ -98,3 +98,64 @@ class LFDHead(nn.Module):
 
     def forward(self, inputs):
         raise RuntimeError('LFDHead is executed inside the fused LFD engine plan; call LFD.forward')
+
+
+class LFDHeadV1(LFDHead):
+    """lfd_head.py:188-343: LFDHead whose towers are always 1x1 and end WITHOUT the output convs -- those are per-level
+    members `_classifiers[i]` / `_regressors[i]` even when the towers are shared; kaiming-normal init for every conv
+    (:310-320).  Executed layer by layer on the gfx950 kernels (engine_sibling)."""
+
+    def __init__(self, num_classes, num_input_channels, num_heads, num_head_channels=128, num_conv_layers=2,
+                 activation_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='BatchNorm2d'),
+                 classification_loss_type='SmoothL1Loss', regression_loss_type='SmoothL1Loss', share_head_flag=False,
+                 merge_path_flag=False):
+        assert classification_loss_type in ['BCEWithLogitsLoss', 'FocalLoss', 'CrossEntropyLoss']
+        nn.Module.__init__(self)
+        self._num_classes = num_classes
+        self._num_input_channels = num_input_channels
+        self._num_head_channels = num_head_channels
+        self._num_conv_layers = num_conv_layers
+        self._conv_kernel_size = 1
+        self._activation_cfg, self._norm_cfg = activation_cfg, norm_cfg
+        self._share_head_flag, self._merge_path_flag = share_head_flag, merge_path_flag
+        self._num_heads = num_heads
+        self._classification_loss_type = classification_loss_type
+        self._regression_loss_type = regression_loss_type
+        assert regression_loss_type in ['SmoothL1Loss', 'MSELoss'] + list(_UNION_LOSSES)
+        if regression_loss_type in _UNION_LOSSES:
+            self._scales = nn.ModuleList([Scale(1.0) for _ in range(num_heads)])
+        self._classifiers = nn.ModuleList()
+        self._regressors = nn.ModuleList()
+        for i in range(num_heads):
+            self._classifiers.append(nn.Conv2d(num_head_channels, self.num_cls_channels, kernel_size=1, bias=True))
+            self._regressors.append(nn.Conv2d(num_head_channels, 4, kernel_size=1, bias=True))
+            if i == 0 or not share_head_flag:
+                paths = self._build_head()
+            else:
+                paths = tuple(getattr(self, 'head0_%s_path' % n) for n in ('classification', 'regression', 'merge'))
+            for name, path in zip(('classification', 'regression', 'merge'), paths):
+                setattr(self, 'head%d_%s_path' % (i, name), path)
+        self._init_weights()
+
+    def _build_head(self):
+        cls_path, reg_path, merge_path = [], [], []
+        for l in range(self._num_conv_layers):
+            cin = self._num_input_channels if l == 0 else self._num_head_channels
+            if self._merge_path_flag:
+                merge_path += self._tower_layer(cin)
+            else:
+                cls_path += self._tower_layer(cin)
+                reg_path += self._tower_layer(cin)
+        return nn.Sequential(*cls_path), nn.Sequential(*reg_path), nn.Sequential(*merge_path)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine, ops, parallel, train_engine
+from .. import engine, engine_sibling, ops, parallel, train_engine
 from .utils import multiclass_nms  # noqa: F401  (kept importable like the reference module)
 
 __all__ = ['LFD']
@@ -109,20 +109,37 @@ class LFD(nn.Module):
     def _is_ce(self):
         return type(self._classification_loss_func).__name__ == 'CrossEntropyLoss'
 
+    def _fused_plan_ok(self, device):
+        """the fused plan of engine.py (stem / block / 3-pass head kernels) covers SimpleNeck + an LFDHead of 1x1 convs --
+        every configuration the reference ships; other module combinations its constructors allow (FPN / SimpleFPN necks,
+        3x3 head convs, LFDHeadV1) run layer by layer on the same kernels (engine_sibling)"""
+        ok = self.__dict__.get('_fused_ok')
+        if ok is None:
+            ok = type(self._neck).__name__ == 'SimpleNeck' and type(self._head).__name__ == 'LFDHead' \
+                and self._head._conv_kernel_size == 1
+            if ok:
+                try:
+                    engine.get_plan(self, self._backbone, self._neck, self._head, device)
+                except RuntimeError:
+                    ok = False
+            self.__dict__['_fused_ok'] = ok
+        return ok
+
     def forward(self, x):
         """lfd.py:511-542.  eval mode: HIP engine.  Returns fresh fp32 tensors (clone of the
         engine's resident output buffers) and records (h, w) per level (:532)."""
         if self.training:
             return self._forward_train(x)
-        cls, reg, sizes = engine.lfd_forward(self, x, use_graph=self.use_graph)
-        for i, hw in enumerate(sizes):
-            self._head_indexes_to_feature_map_sizes[i] = hw
+        cls, reg = self.forward_resident(x)
         return cls.clone(), reg.clone()
 
     def forward_resident(self, x, slot=0):
         """Fast path: same as forward() in eval mode but returns the engine-owned output buffers
         (no copy, valid until the next forward of the same input shape and `slot`)."""
-        cls, reg, sizes = engine.lfd_forward(self, x, use_graph=self.use_graph, slot=slot)
+        if x.is_cuda and not self._fused_plan_ok(x.device):
+            cls, reg, _, sizes = engine_sibling.sibling_forward(self, x, use_graph=self.use_graph)
+        else:
+            cls, reg, sizes = engine.lfd_forward(self, x, use_graph=self.use_graph, slot=slot)
         for i, hw in enumerate(sizes):
             self._head_indexes_to_feature_map_sizes[i] = hw
         return cls, reg
@@ -135,7 +152,7 @@ class LFD(nn.Module):
         activation / output / workspace buffers: steps of DIFFERENT slots may be enqueued on different HIP streams and
         overlap on the device (the small-map stages, the post-processing kernels and the launch gaps of one batch leave most
         CUs idle -- a second batch in flight fills them: 0.75 -> 0.61 ms per batch of 8 at depth 2, tools/ab_pipeline.py)."""
-        if not self.use_graph:
+        if not self.use_graph or not self._fused_plan_ok(x.device):
             return self.detect(self.forward_resident(x, slot), meta, score_thr, iou_thr, class_agnostic, max_candidates)
         score_thr = self._classification_threshold if score_thr is None else score_thr
         iou_thr = self._nms_cfg.get('iou_thr', 0.5) if iou_thr is None else iou_thr
@@ -201,12 +218,17 @@ class LFD(nn.Module):
             feats = list(train_engine.backbone_train_forward(self._backbone, x))
         else:
             feats = self._backbone_train_torch(x)
+        if type(neck).__name__ == 'SimpleNeck':
+            feats = [getattr(neck, 'neck%d' % i)(f) for i, f in enumerate(feats)]
+        else:
+            feats = neck(feats)                    # FPN / SimpleFPN: autograd over their PyTorch-ROCm children
         cls_l, reg_l = [], []
-        for i, f in enumerate(feats):
-            t = getattr(neck, 'neck%d' % i)(f)
+        for i, t in enumerate(feats):
             t = getattr(head, 'head%d_merge_path' % i)(t)
             c = getattr(head, 'head%d_classification_path' % i)(t)
             r = getattr(head, 'head%d_regression_path' % i)(t)
+            if hasattr(head, '_classifiers'):      # LFDHeadV1: per-level output convs outside the (shared) towers
+                c, r = head._classifiers[i](c), head._regressors[i](r)
             if head._regression_loss_type in _UNION:
                 r = head._scales[i](r)
             self._head_indexes_to_feature_map_sizes[i] = (c.shape[2], c.shape[3])

@@ -14,7 +14,7 @@ the reference computes them), losses on the HIP loss kernels.
 """
 import torch
 
-from .. import engine, engine_sibling, ops
+from .. import ops
 from .lfd import LFD
 from .fcos import _results_from_detect
 
@@ -44,58 +44,7 @@ class LFDv2(LFD):
         self._pre_nms_bbox_limit = pre_nms_bbox_limit
         self._post_nms_bbox_limit = post_nms_bbox_limit
 
-    # ------------------------------------------------------------------ forward
-    def _fused_plan_ok(self, device):
-        """the fused LFD plan (engine.py) covers SimpleNeck + an LFDHead of 1x1 convs; anything else -> engine_sibling"""
-        ok = self.__dict__.get('_fused_ok')
-        if ok is None:
-            ok = type(self._neck).__name__ == 'SimpleNeck' and type(self._head).__name__ == 'LFDHead' \
-                and self._head._conv_kernel_size == 1
-            if ok:
-                try:
-                    engine.get_plan(self, self._backbone, self._neck, self._head, device)
-                except RuntimeError:
-                    ok = False
-            self.__dict__['_fused_ok'] = ok
-        return ok
-
-    def forward(self, x):
-        if self.training:
-            return self._forward_train(x)
-        cls, reg = self.forward_resident(x)
-        return cls.clone(), reg.clone()
-
-    def forward_resident(self, x, slot=0):
-        if x.is_cuda and self._fused_plan_ok(x.device):
-            return super().forward_resident(x, slot)
-        cls, reg, _, sizes = engine_sibling.sibling_forward(self, x, use_graph=self.use_graph)
-        for i, hw in enumerate(sizes):
-            self._head_indexes_to_feature_map_sizes[i] = hw
-        return cls, reg
-
-    def _forward_train(self, x):
-        if type(self._neck).__name__ == 'SimpleNeck':
-            return super()._forward_train(x)
-        from .. import _lib, train_engine
-        _lib.require_cuda(x, 'LFDv2.forward')
-        if train_engine.supported(self._backbone):
-            feats = list(train_engine.backbone_train_forward(self._backbone, x))
-        else:
-            feats = self._backbone_train_torch(x)
-        feats = self._neck(feats)
-        head = self._head
-        cls_l, reg_l = [], []
-        for i, f in enumerate(feats):
-            t = getattr(head, 'head%d_merge_path' % i)(f)
-            c = getattr(head, 'head%d_classification_path' % i)(t)
-            r = getattr(head, 'head%d_regression_path' % i)(t)
-            if hasattr(head, '_scales'):
-                r = head._scales[i](r)
-            self._head_indexes_to_feature_map_sizes[i] = (c.shape[2], c.shape[3])
-            cls_l.append(c.permute(0, 2, 3, 1).reshape(c.shape[0], -1, c.shape[1]))
-            reg_l.append(r.permute(0, 2, 3, 1).reshape(r.shape[0], -1, 4))
-        return torch.cat(cls_l, 1), torch.cat(reg_l, 1)
-
+    # forward: LFD's (fused plan when neck / head are what it covers, else the layer engine; training through autograd)
     def detect_resident(self, x, meta, score_thr=None, iou_thr=None, class_agnostic=None, max_candidates=None, slot=0):
         # the whole-step graph of LFD fuses LFD's candidate rule into the head; LFDv2's adds a per-level top-k
         return self.detect(self.forward_resident(x, slot), meta, score_thr, iou_thr, class_agnostic, max_candidates)

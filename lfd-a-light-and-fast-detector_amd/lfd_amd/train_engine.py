@@ -58,6 +58,8 @@ def supported(backbone):
 def network_supported(model):
     """+ SimpleNeck with BatchNorm2d, LFDHead with 1x1 convs and GroupNorm groups of 8 channels, <= 60 output channels."""
     bb, neck, head = model._backbone, model._neck, model._head
+    if type(neck).__name__ != 'SimpleNeck' or type(head).__name__ != 'LFDHead':
+        return False          # FPN / SimpleFPN necks, LFDHeadV1, FCOSHead: PyTorch-ROCm autograd behind the HIP backbone
     if not supported(bb):
         return False
     if not all(p.requires_grad for p in list(neck.parameters()) + list(head.parameters())):

@@ -5,6 +5,7 @@ meta-architectures' forward and get_results:
 
   pyramid_neck_forward   FPN.forward (lfd/model/neck/fpn.py:127-152) and SimpleFPN.forward (simple_fpn.py:141-172)
   fcos_head_forward      FCOSHead.forward (lfd/model/head/fcos_head.py:129-154)
+  lfd_head_v1_forward    LFDHeadV1.forward (lfd/model/head/lfd_head.py:322-343)
   fcos_forward           FCOS.forward (lfd/model/fcos.py:414-449)
   lfdv2_forward          LFDv2.forward (lfd/model/lfdv2.py:671-702)
   get_results_single     FCOS._get_results_for_single_image (fcos.py:356-412) and
@@ -107,6 +108,36 @@ def fcos_head_forward(sd, head, feats, pfx='_head.'):
     return cls, reg, ctr
 
 
+def lfd_head_v1_forward(sd, head, feats, pfx='_head.'):
+    """LFDHeadV1.forward (lfd/model/head/lfd_head.py:322-343): 1x1 towers (merged or separate, any norm) that end without
+    the output convs, then the level's own `_classifiers[i]` / `_regressors[i]`, Scale for the IoU-family losses.
+    head: dict(num_conv_layers, norm (None | 'BatchNorm2d' | ('GroupNorm', g)), merge_path_flag, union)"""
+    step = 3 if head.get('norm') else 2
+
+    def tower(name, x):
+        for l in range(head['num_conv_layers']):
+            x = net_oracle._conv(sd, f'{name}.{step * l}', x)
+            if head.get('norm'):
+                x = _norm(sd, f'{name}.{step * l + 1}', x, head['norm'])
+            x = F.relu(x)
+        return x
+
+    cls, reg = [], []
+    for i, f in enumerate(feats):
+        h = f'{pfx}head{i}_'
+        if head['merge_path_flag']:
+            tc = tr = tower(h + 'merge_path', f)
+        else:
+            tc, tr = tower(h + 'classification_path', f), tower(h + 'regression_path', f)
+        c = net_oracle._conv(sd, f'{pfx}_classifiers.{i}', tc)
+        r = net_oracle._conv(sd, f'{pfx}_regressors.{i}', tr)
+        if head['union']:
+            r = r * sd[f'{pfx}_scales.{i}._scale']
+        cls.append(c)
+        reg.append(r)
+    return cls, reg
+
+
 def _concat(maps):
     return torch.cat([m.permute(0, 2, 3, 1).reshape(m.shape[0], -1, m.shape[1]) for m in maps], 1)
 
@@ -118,11 +149,12 @@ def fcos_forward(sd, arch, neck, head, x):
     return _concat(cls), _concat(reg), _concat(ctr), sizes
 
 
-def lfdv2_forward(sd, arch, neck, x):
-    """arch: the LFDHead / backbone kwargs of net_oracle; neck None = SimpleNeck"""
+def lfdv2_forward(sd, arch, neck, x, head_v1=None):
+    """arch: the LFDHead / backbone kwargs of net_oracle; neck None = SimpleNeck; head_v1: lfd_head_v1_forward's dict when
+    the head is an LFDHeadV1"""
     feats = net_oracle.backbone_forward(sd, arch, x)
     feats = net_oracle.neck_forward(sd, arch, feats) if neck is None else pyramid_neck_forward(sd, neck, feats)
-    cls, reg = net_oracle.head_forward(sd, arch, feats)
+    cls, reg = net_oracle.head_forward(sd, arch, feats) if head_v1 is None else lfd_head_v1_forward(sd, head_v1, feats)
     sizes = [(c.shape[2], c.shape[3]) for c in cls]
     return _concat(cls), _concat(reg), sizes
 

@@ -38,7 +38,8 @@ def state_sha(sd):
     return h.hexdigest()
 
 
-from sibling_cases import NECK_CASES, RESULT_CASES, neck_inputs, result_inputs, synth_annotations  # noqa: E402
+from sibling_cases import (NECK_CASES, RESULT_CASES, neck_inputs, result_inputs, synth_annotations,  # noqa: E402
+                           synth_annotations_overlapping)
 
 
 def main():
@@ -91,6 +92,26 @@ def main():
         res['cls_target'], res['reg_target'] = tg[0].numpy(), tg[1].numpy()
         np.savez_compressed(os.path.join(HERE, 'ref_sibling_%s.npz' % name), **res)
         print(name, 'P', outs[0].shape[1], 'results', [len(r) for r in json.loads(res['results'])], lo['loss_values'])
+
+    # ---------------------------------------------------------------- 1b. FCOSv1: FCOS's network, multi-label targets / loss
+    spec = dict(configs.SIBLINGS['FCOS_FPN'], meta='FCOSv1')
+    model = configs.build_sibling(spec, RB, RN, RH, M, RL, seed=1)
+    g = np.load(os.path.join(HERE, 'ref_sibling_FCOS_FPN.npz'))
+    N_, H, W = [int(v) for v in g['shape']]
+    for i, hw in enumerate(g['sizes'].tolist()):
+        model._head_indexes_to_feature_map_sizes[i] = tuple(hw)
+    preds = [torch.from_numpy(g[k]).requires_grad_(True) for k in ('cls', 'reg', 'ctr')]
+    ann = synth_annotations_overlapping(5, N_, H, W, spec['head']['num_classes'])
+    lo = model.get_loss(tuple(preds), ann)
+    lo['loss'].backward()
+    res = dict(loss_values=json.dumps(lo['loss_values']))
+    for nm, p in zip(('dcls', 'dreg', 'dctr'), preds):
+        res[nm] = p.grad.numpy()
+    pts = model.generate_point_coordinates(model.head_indexes_to_feature_map_sizes)
+    tg = model.annotation_to_target(pts, [torch.from_numpy(b) for b, _ in ann], [torch.from_numpy(l) for _, l in ann])
+    res['cls_target'], res['reg_target'] = tg[0].numpy(), tg[1].numpy()
+    np.savez_compressed(os.path.join(HERE, 'ref_sibling_FCOSV1.npz'), **res)
+    print('FCOSv1', lo['loss_values'])
 
     # ---------------------------------------------------------------- 2. necks alone
     out = {}

@@ -16,6 +16,18 @@ def synth_annotations(seed, n, H, W, num_classes):
     return ann
 
 
+def synth_annotations_overlapping(seed, n, H, W, num_classes):
+    """synth_annotations + per image two nested boxes of different classes whose sizes share a regress range, so that some
+    points lie strictly inside both: FCOSv1 marks both classes there, FCOS only the smaller box's"""
+    ann = synth_annotations(seed, n, H, W, num_classes)
+    out = []
+    for i, (b, l) in enumerate(ann):
+        x0, y0 = 20.0 + 10 * i, 16.0 + 6 * i
+        extra = np.array([[x0, y0, 56.0, 48.0], [x0 + 5, y0 + 4, 46.0, 40.0]], np.float32)
+        out.append((np.concatenate([b, extra]), np.concatenate([l, np.array([0, 1 % num_classes], np.int64)])))
+    return out
+
+
 NECK_CASES = [
     # (name, class, kwargs): inputs are 3 maps of 64 / 64 / 128 channels at 12x16, 6x8, 3x4 (seeded)
     ('fpn_pool_on_input', 'FPN', dict(num_output_channels=64, num_outputs=5, extra_on_input=True, extra_type='pooling',

@@ -259,6 +259,41 @@ def test_sibling_get_loss_on_device_vs_reference(name):
         assert np.abs(got - ref_g).max() <= 2e-4 * scale, (nm, np.abs(got - ref_g).max(), scale)
 
 
+def test_fcosv1_get_loss_on_device_vs_reference():
+    """FCOSv1 (fcos.py:687-768): FCOS's network with multi-label targets, flattened one-class focal loss"""
+    from test_sibling_oracle_golden import _fcosv1_model_and_annotations
+    g, model, ann = _fcosv1_model_and_annotations()
+    ref = load_golden('ref_sibling_FCOSV1.npz')
+    model.to(DEV)
+    preds = [torch.from_numpy(g[k]).to(DEV).requires_grad_(True) for k in ('cls', 'reg', 'ctr')]
+    lo = model.get_loss(tuple(preds), ann)
+    want = json.loads(str(ref['loss_values']))
+    for k, v in want.items():
+        assert abs(lo['loss_values'][k] - v) <= 2e-4 * max(1.0, abs(v)), (k, lo['loss_values'][k], v)
+    lo['loss'].backward()
+    for nm, p in zip(('dcls', 'dreg', 'dctr'), preds):
+        scale = max(np.abs(ref[nm]).max(), 1e-12)
+        assert np.abs(p.grad.cpu().numpy() - ref[nm]).max() <= 2e-4 * scale, nm
+
+
+def test_lfd_meta_architecture_accepts_the_sibling_modules():
+    """LFD itself over an FPN neck and a 3x3 LFDHead (its constructor allows both): routed to the layer engine, same
+    outputs as LFDv2 over the same modules (the two classes share forward and decode)"""
+    from lfd_amd.model import LFD
+    g = load_golden('ref_sibling_LFDV2_SFPN.npz')
+    v2 = configs.build_sibling_model('LFDV2_SFPN', seed=1).eval().to(DEV)
+    spec = configs.SIBLINGS['LFDV2_SFPN']
+    v1 = LFD(backbone=v2._backbone, neck=v2._neck, head=v2._head, num_classes=spec['head']['num_classes'],
+             regression_ranges=spec['regression_ranges'], range_assign_mode='dist', point_strides=v2._point_strides,
+             classification_loss_func=v2._classification_loss_func, regression_loss_func=v2._regression_loss_func,
+             distance_to_bbox_mode=spec['distance_to_bbox_mode']).eval()
+    x = model_input(g).to(DEV)
+    with torch.no_grad():
+        a, b = v1(x), v2(x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert [v1.head_indexes_to_feature_map_sizes[i] for i in range(4)] == [tuple(s) for s in g['sizes'].tolist()]
+
+
 def test_sibling_train_mode_step_runs_through_autograd():
     """training route of the siblings (PyTorch-ROCm autograd over the same parameters + HIP loss kernels): one SGD step
     lowers the loss on the same batch.  (LFDV2_SFPN would not do: ReLU laterals + the in-place ReLU in front of its extra

@@ -42,6 +42,9 @@ def oracle_arch(spec):
     """net_oracle-style arch dict of a SIBLINGS entry (backbone + LFDHead kwargs)"""
     a = dict(spec['backbone'])
     hk = spec['head']
+    if hk['kind'] == 'LFDHeadV1':
+        a.update(classification_loss_type=spec['classification_loss_type'], regression_loss_type=spec['regression_loss_type'],
+                 regression_ranges=spec['regression_ranges'], distance_to_bbox_mode=spec['distance_to_bbox_mode'])
     if hk['kind'] == 'LFDHead':
         a.update(num_classes=hk['num_classes'], num_head_channels=hk['num_head_channels'], num_conv_layers=hk['num_conv_layers'],
                  conv_kernel_size=hk['conv_kernel_size'], gn_groups=hk['norm_cfg']['num_groups'] if hk['norm_cfg'] else None,
@@ -59,7 +62,14 @@ def oracle_forward(name, x):
         hk = spec['head']
         head = dict(num_layers=hk['num_layers'], norm=('GroupNorm', hk['norm_cfg']['num_groups']) if hk['norm_cfg'] else None)
         return sibling_oracle.fcos_forward(sd, oracle_arch(spec), oracle_neck(spec), head, x), model
-    cls, reg, sizes = sibling_oracle.lfdv2_forward(sd, oracle_arch(spec), oracle_neck(spec), x)
+    v1 = None
+    if spec['head']['kind'] == 'LFDHeadV1':
+        hk = spec['head']
+        nc = hk['norm_cfg']
+        v1 = dict(num_conv_layers=hk['num_conv_layers'], merge_path_flag=hk['merge_path_flag'],
+                  norm=None if nc is None else ('BatchNorm2d' if nc['type'] == 'BatchNorm2d' else ('GroupNorm', nc['num_groups'])),
+                  union=spec['regression_loss_type'] in ('IoULoss', 'GIoULoss', 'DIoULoss', 'CIoULoss'))
+    cls, reg, sizes = sibling_oracle.lfdv2_forward(sd, oracle_arch(spec), oracle_neck(spec), x, head_v1=v1)
     return (cls, reg, None, sizes), model
 
 
@@ -183,6 +193,31 @@ def test_host_target_assignment_vs_reference(name):
     np.testing.assert_array_equal(ct.numpy(), g['cls_target'])
     np.testing.assert_array_equal(rt.numpy(), g['reg_target'])
     assert (g['cls_target'] != (spec['head']['num_classes'] if spec['meta'] == 'FCOS' else 0)).any()   # some positives
+
+
+def _fcosv1_model_and_annotations():
+    g = load_golden('ref_sibling_FCOS_FPN.npz')
+    spec = dict(configs.SIBLINGS['FCOS_FPN'], meta='FCOSv1')
+    from lfd_amd.model import backbone as B, head as H, losses as L, neck as N
+    from lfd_amd import model as M
+    model = configs.build_sibling(spec, B, N, H, M, L, seed=1)
+    n, H_, W_ = [int(v) for v in g['shape']]
+    for i, hw in enumerate(g['sizes'].tolist()):
+        model._head_indexes_to_feature_map_sizes[i] = tuple(hw)
+    return g, model, SC.synth_annotations_overlapping(5, n, H_, W_, spec['head']['num_classes'])
+
+
+def test_fcosv1_multi_label_targets_vs_reference():
+    """fcos.py:550-656: per-class binary targets (0 = present), several classes per point where boxes nest -- exact"""
+    from lfd_amd.model import FCOS, FCOSv1
+    _, model, ann = _fcosv1_model_and_annotations()
+    assert isinstance(model, FCOSv1) and isinstance(model, FCOS)
+    ref = load_golden('ref_sibling_FCOSV1.npz')
+    pts = model.generate_point_coordinates(model.head_indexes_to_feature_map_sizes)
+    ct, rt = model.annotation_to_target(pts, [torch.from_numpy(b) for b, _ in ann], [torch.from_numpy(l) for _, l in ann])
+    np.testing.assert_array_equal(ct.numpy(), ref['cls_target'])
+    np.testing.assert_array_equal(rt.numpy(), ref['reg_target'])
+    assert ((ref['cls_target'] == 0).sum(-1) > 1).sum() > 10       # the fixture does contain multi-label points
 
 
 def test_fcos_param_groups_follow_the_reference_rule():
