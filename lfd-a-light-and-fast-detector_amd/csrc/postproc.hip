@@ -341,47 +341,82 @@ __global__ __launch_bounds__(kBlock) void k_ex_keys(DecodeParams d, uint32_t* ke
 }
 
 constexpr int kSelThreads = 1024;
-// One workgroup per (level, image): radix-select the k-th largest key (4 x 8 bits, LDS histograms), then mark the k
+constexpr int kSelBins = 4096;
+// One workgroup per (level, image): radix-select the k-th largest key (12 + 10 + 9 bits, LDS histograms), then mark the k
 // survivors with bit 31 of their key: every key above the k-th value, and -- in index order -- as many of the keys EQUAL to
 // it as are needed to reach k (torch.topk leaves the choice among equal values open; lowest index first here).
+// Each pass streams the level's keys (L2-resident, written by k_ex_keys) with four loads in flight per thread; the bin of
+// the k-th key is found by a block-wide suffix scan over the histogram (thread t owns the four bins 4t..4t+3 from the top).
 __global__ __launch_bounds__(kSelThreads) void k_ex_select(DecodeParams d, uint32_t* keys, int limit) {
-  __shared__ int hist[256];
+  __shared__ int hist[kSelBins];
   __shared__ int s_wsum[kSelThreads / 64];
   __shared__ uint32_t s_prefix;
-  __shared__ int s_remaining, s_running;
+  __shared__ int s_remaining, s_running, s_ties;
   const int l = blockIdx.x, n = blockIdx.y;
   if (l >= d.lv.n || !((d.sel_levels >> l) & 1u)) return;
   const int p0 = d.lv.start[l], np = d.lv.start[l + 1] - p0;
   uint32_t* kk = keys + (int64_t)n * d.P + p0;
+  const int lane = lfd_lane(), w = threadIdx.x >> 6;
   uint32_t prefix = 0u, mask = 0u;
   int remaining = limit;                 // 0 < limit < np (host)
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = threadIdx.x; i < 256; i += kSelThreads) hist[i] = 0;
+  constexpr int kShift[3] = {19, 9, 0};
+  constexpr int kBits[3] = {12, 10, 9};
+#pragma unroll
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = kShift[pass], nb = 1 << kBits[pass];
+    const uint32_t bm = (uint32_t)nb - 1u;
+    for (int i = threadIdx.x; i < nb; i += kSelThreads) hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < np; i += kSelThreads) {
-      const uint32_t k = kk[i];
-      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+    for (int i = threadIdx.x; i < np; i += 4 * kSelThreads) {
+      uint32_t k[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[j] = (i + j * kSelThreads < np) ? kk[i + j * kSelThreads] : 0xffffffffu;   // bit 31 set: never matches
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((k[j] & (mask | 0x80000000u)) == prefix) atomicAdd(&hist[(k[j] >> shift) & bm], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, bin = 255;
-      for (; bin > 0; --bin) {           // from the top: first bin whose cumulative count reaches `remaining`
-        if (acc + hist[bin] >= remaining) break;
-        acc += hist[bin];
+    // descending position q = 4 * tid + j  <->  bin nb - 1 - q
+    int c[4], sum4 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 4 * (int)threadIdx.x + j;
+      c[j] = q < nb ? hist[nb - 1 - q] : 0;
+      sum4 += c[j];
+    }
+    const int inc = wave_incl_scan(sum4);
+    if (lane == 63) s_wsum[w] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int j = 0; j < w; ++j) before += s_wsum[j];
+    int acc = before + inc - sum4;          // keys in the bins above this thread's four
+    if (acc < remaining && remaining <= acc + sum4) {      // exactly one thread: the k-th key is in one of its bins
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (acc < remaining && remaining <= acc + c[j]) {
+          s_prefix = prefix | ((uint32_t)(nb - 1 - (4 * (int)threadIdx.x + j)) << shift);
+          s_remaining = remaining - acc;
+          s_ties = c[j];
+        }
+        acc += c[j];
       }
-      s_prefix = prefix | ((uint32_t)bin << shift);
-      s_remaining = remaining - acc;
     }
     __syncthreads();
     prefix = s_prefix;
     remaining = s_remaining;
-    mask |= 255u << shift;
+    mask |= bm << shift;
     __syncthreads();
   }
-  // prefix = the k-th largest key; `remaining` of the keys equal to it survive
+  // prefix = the k-th largest key; `remaining` of the s_ties keys equal to it survive
+  if (s_ties == remaining) {             // (the usual case: distinct keys) every tie survives, order does not matter
+    for (int i = threadIdx.x; i < np; i += kSelThreads) {
+      const uint32_t k = kk[i];
+      if (k >= prefix) kk[i] = k | 0x80000000u;
+    }
+    return;
+  }
   if (threadIdx.x == 0) s_running = 0;
   __syncthreads();
-  const int lane = lfd_lane(), w = threadIdx.x >> 6;
   for (int base = 0; base < np; base += kSelThreads) {
     const int i = base + threadIdx.x;
     const uint32_t k = i < np ? kk[i] : 0u;
