@@ -11,7 +11,6 @@ run as PyTorch-ROCm modules on the device (training-only route); CPU tensors are
 """
 import math
 
-import torch
 import torch.nn as nn
 
 from ... import _lib
