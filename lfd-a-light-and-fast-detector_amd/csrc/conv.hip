@@ -69,6 +69,10 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     case 64 * 10000 + 1200 + 20: return launch_conv<64, 1, 2, 2, true, false>(a, st);
     case 64 * 10000 + 1200 + 40: return launch_conv<64, 1, 2, 4, true, false>(a, st);
     // ---- 128-channel stages (tiny maps): weights streamed from L2 per k-step
+    // (weights streamed from L2 per k-step: right for the tiny maps of every shipped configuration.  On the LARGE maps of the
+    //  sibling heads -- 128-channel 3x3 towers at stride 4-8 -- a 4-row x 64-cout tile, <128,3,1,2>, halves the filter bytes
+    //  streamed per pixel but measured slower, FCOS forward 3.25 vs 2.97 ms: the two waves sharing a filter slab do not hit
+    //  in each other's fetches.  A register-stationary 128-channel variant is what those maps would want.)
     case 128 * 10000 + 3100 + 40: return launch_conv<128, 3, 1, 4, false, false>(a, st);
     case 128 * 10000 + 3200 + 40: return launch_conv<128, 3, 2, 4, false, false>(a, st);
     case 128 * 10000 + 3100 + 20: return launch_conv<128, 3, 1, 2, false, false>(a, st);  // data gradient of 64->128 s2
