@@ -235,6 +235,46 @@ def train_bench(dev, steps=10, warmup=3):
                 frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup, loss=lv['loss'])
 
 
+def siblings_bench(dev, reps=20, n=8, h=720, w=1280):
+    """SURVEY 8(f) rank 4 on record: the sibling meta-architectures (FCOS / LFDv2 over FPN / SimpleFPN necks, 3x3 heads;
+    lfd_amd.configs.SIBLINGS) -- forward as one HIP graph + lfd_detect_batched_ex, HIP events, median."""
+    from lfd_amd import configs
+    out = []
+    for name in sorted(configs.SIBLINGS):
+        spec = configs.SIBLINGS[name]
+        model = configs.build_sibling_model(name, seed=1).eval().to(dev)
+        model.use_graph = True
+        x = (torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(dev)
+        meta = torch.tensor([[float(w), float(h), 1.0]] * n, dtype=torch.float32, device=dev)
+        fwd = (lambda: model.forward_resident(x)) if hasattr(model, 'forward_resident') else (lambda: model(x))
+        with torch.no_grad():
+            outs = fwd()
+            if len(outs) == 3:
+                sc = outs[0].sigmoid() * outs[2].sigmoid()
+            elif spec.get('classification_loss_type') == 'CrossEntropyLoss':
+                sc = outs[0].softmax(-1)[..., :-1]
+            else:
+                sc = outs[0].sigmoid()
+            model._classification_threshold = float(torch.quantile(sc.flatten()[:4_000_000].float(), 0.98))
+            torch.cuda.synchronize()
+            ts = {}
+            for key, fn in (('forward_ms', fwd), ('detect_ms', lambda: model.detect(outs, meta))):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                v = []
+                for _ in range(reps):
+                    s.record()
+                    fn()
+                    e.record()
+                    e.synchronize()
+                    v.append(s.elapsed_time(e))
+                ts[key] = round(float(np.median(v)), 4)
+            counts = model.detect(outs, meta).counts.cpu()
+        out.append(dict(config=name, meta_arch=spec['meta'], batch=n, input=[h, w], points_per_image=int(outs[0].shape[1]),
+                        images_per_s=round(n / ((ts['forward_ms'] + ts['detect_ms']) * 1e-3), 1),
+                        kept_per_image=float(counts[:, 1].float().mean()), **ts))
+    return out
+
+
 def latency_bs1(model, dev, iters=200):
     """p50 latency of ONE 1920x1080 frame (the second half of BASELINE.json's metric), frame resident in HBM, host-side
     wall clock around launch + synchronize per iteration like the reference's timing loop
@@ -282,6 +322,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
     ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--no-siblings', action='store_true')
     ap.add_argument('--max-candidates', type=int, default=8192)
     ap.add_argument('--clock-warmup-s', type=float, default=0.3, help='untimed replays before the W warm-up steps: an idle MI355X needs '
                     'milliseconds to ramp its clocks (DESIGN 3, lesson 11)')
@@ -453,6 +494,11 @@ def main():
             result['train'] = train_bench(dev)
         except Exception as e:       # the inference line must not be lost to the extra key
             result['train'] = {'error': repr(e)}
+    if rank == 0 and world == 1 and not args.no_siblings:
+        try:
+            result['siblings'] = siblings_bench(dev)
+        except Exception as e:       # an extra key, like `train`
+            result['siblings'] = {'error': repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline()

@@ -122,6 +122,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1 and c['sample']
     assert d['latency_bs1']['forward_ms']['p50'] > 0 and d['latency_bs1']['end_to_end_ms']['p50'] > 0
+    # extra keys the driver records with the line: the training iteration and the sibling meta-architectures
+    assert d['train']['ms_per_iter'] > 0
+    sib = d['siblings']
+    assert isinstance(sib, list) and {r['config'] for r in sib} >= {'FCOS_FPN', 'LFDV2_SFPN', 'LFDV2_SIMPLE'}
+    assert all(r['forward_ms'] > 0 and r['detect_ms'] > 0 and r['images_per_s'] > 0 for r in sib)
 
 
 def test_two_batches_in_flight_on_two_streams_match_the_serial_step():
