@@ -801,7 +801,10 @@ __global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
       // ---- neck: relu(Wn x + bn).  The filter fragments come from LDS through a 4-deep register ring: read right in front
       //      of their MFMA (what the compiler emits on its own) every one of the 20 / 36 k-steps waited a full LDS round
       //      trip -- ~1300 cycles per group, a quarter of pass 1.
-      constexpr int WPD = 3;
+#ifndef LFD_H2_WPD
+#define LFD_H2_WPD 3        // (5 measured the same: 15.7-15.85 k images/s either way, same session)
+#endif
+      constexpr int WPD = LFD_H2_WPD;
       half8 wring[WPD + 1];
       if (cin == 64) {
         auto fidx = [](int i) { return (i / 5) * (NKNX + 1) + ((i % 5) == 0 ? NKNX : (i % 5) - 1); };   // bias step, then q = 0..3

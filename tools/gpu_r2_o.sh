@@ -1,5 +1,4 @@
 #!/bin/bash
-# round 2, call o: bench line with the `siblings` key + its contract test
+# round 2, call o: A/B of the neck-filter ring depth in k_head2 (3 vs 5)
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_end2end.py -q -k "bench_prints" 2>&1 | tail -5
+timeout 600 bash tools/gpu_ab_bench.sh scratch/alt/liblfd_hip_w5.so 3
