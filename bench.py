@@ -218,21 +218,36 @@ def train_bench(dev, steps=10, warmup=3):
         xy = rng.uniform(0, 1, (6, 2)) * (np.array([size, size]) - wh).clip(1)
         ann.append((np.concatenate([xy, wh], 1).astype(np.float32), np.zeros(6, np.int64)))
     clip = dict(max_norm=10, norm_type=2)
-    for _ in range(warmup):
-        lv, _ = train.train_step(m, opt, x, ann, clip, True)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        lv, _ = train.train_step(m, opt, x, ann, clip, True)
+
+    def timed(fn):
+        for _ in range(warmup):
+            lv, _ = fn()
         torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            lv, _ = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return ts, lv
+
+    ts_eager, lv = timed(lambda: train.train_step(m, opt, x, ann, clip, True))
+    # the same iteration replayed as one HIP graph (lfd_amd.train.GraphedTrainStep: ~500 launches, one host call)
+    graphed = None
+    try:
+        step = train.GraphedTrainStep(m, opt, clip, max_boxes=1024)
+        ts, lv = timed(lambda: step(x if step.x is None else step.x, ann, True))     # frames written into the step's own buffer
+        graphed = True
+    except Exception as e:       # keep the eager number
+        graphed = repr(e)
+        ts = ts_eager
     dt = float(np.median(ts))
     gf = 3 * 8.606 * bs
     return dict(workload='WIDERFACE_LFD_S train step 640x640 bs 32 (forward + targets + loss + backward + clip + SGD), fp16 '
                          'activations / fp32 accumulate + parameters', ms_per_iter=round(dt * 1e3, 3),
                 images_per_s=round(bs / dt, 1), gflop_per_iter=round(gf, 1), tflops=round(gf / dt / 1e3, 1),
-                frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup, loss=lv['loss'])
+                frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup, loss=lv['loss'],
+                hip_graph=graphed, ms_per_iter_eager=round(float(np.median(ts_eager)) * 1e3, 3))
 
 
 def siblings_bench(dev, reps=20, n=8, h=720, w=1280):

@@ -457,7 +457,9 @@ class LFD(nn.Module):
             return False
         return type(rf).__name__ == 'IoULoss' and cf.reduction == 'mean' and rf.reduction == 'mean'
 
-    def _get_loss_fused(self, pred_cls, pred_reg, cls_t, reg_t):
+    def _fused_loss_tensor(self, pred_cls, pred_reg, cls_t, reg_t):
+        """-> float32[3] device tensor (classification_loss, regression_loss, loss) with the autograd graph of the fused
+        kernels behind it; no host sync (a captured training iteration reads it after the replay)"""
         cf, rf = self._classification_loss_func, self._regression_loss_func
         sizes = [self._head_indexes_to_feature_map_sizes[i] for i in range(self._num_heads)]
         desc = ops.make_loss_desc(pred_cls.size(0), sizes, self._point_strides, self._regression_ranges,
@@ -469,9 +471,12 @@ class LFD(nn.Module):
         # image-parallel training: the reference normalises by the GLOBAL-batch n_pos (loss computed once over the
         # gathered outputs, executor.py:198-200); gradients are averaged over ranks afterwards, hence the scale
         dist_on = parallel.is_dist()
-        vals = _FusedLossFunction.apply(pred_cls, pred_reg, cls_t, reg_t, desc,
+        return _FusedLossFunction.apply(pred_cls, pred_reg, cls_t, reg_t, desc,
                                         parallel.global_count if dist_on else None,
                                         float(parallel.world_size()) if dist_on else 1.0)
+
+    def _get_loss_fused(self, pred_cls, pred_reg, cls_t, reg_t):
+        vals = self._fused_loss_tensor(pred_cls, pred_reg, cls_t, reg_t)
         c, r, t = vals.tolist()      # the one host sync of the step (the reference does three .item())
         return dict(loss=vals[2], loss_values=dict(loss=t, classification_loss=c, regression_loss=r))
 

@@ -367,15 +367,10 @@ def cross_entropy_backward(logits, labels, d_loss):
 ASSIGN_MODES = {'longer': 0, 'shorter': 1, 'sqrt': 2, 'dist': 3}
 
 
-def assign_targets(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent, gt_bboxes_list,
-                   gt_labels_list):
-    """LFD.annotation_to_target (lfd.py:109-259) for a batch: -> cls targets [N,P,C], reg targets [N,P,4] (fp32,
-    device resident).  gt_bboxes_list[i]: [G_i,4] xywh cuda tensor, gt_labels_list[i]: [G_i] int64."""
-    n = len(gt_bboxes_list)
-    dev = gt_bboxes_list[0].device
-    require_cuda(gt_bboxes_list[0], 'assign_targets')
+def make_assign_desc(n, sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent):
+    """-> (lfd_assign_desc_t, total points per image)"""
     d = _lib.AssignDesc()
-    d.n, d.num_levels = n, len(sizes)
+    d.n, d.num_levels = int(n), len(sizes)
     total = 0
     for i, (h, w) in enumerate(sizes):
         d.level_h[i], d.level_w[i], d.stride[i] = int(h), int(w), int(strides[i])
@@ -384,6 +379,25 @@ def assign_targets(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_
         total += int(h) * int(w)
     d.total_points, d.num_classes = total, int(num_classes)
     d.assign_mode, d.independent = ASSIGN_MODES[assign_mode], int(bool(independent))
+    return d, total
+
+
+def assign_targets_device(desc, total, num_classes, boxes, labels, offs):
+    """targets from device-resident annotations: boxes [K,4] fp32 xywh, labels [K] int64, offs [N+1] int32 (image i owns
+    boxes offs[i] .. offs[i+1]; K may exceed offs[N]: capacity of a static buffer) -- what a captured training iteration
+    (lfd_amd.train.GraphedTrainStep) launches"""
+    require_cuda(boxes, 'assign_targets')
+    return _assign_launch(desc, desc.n, total, num_classes, boxes, labels, offs, boxes.device)
+
+
+def assign_targets(sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent, gt_bboxes_list,
+                   gt_labels_list):
+    """LFD.annotation_to_target (lfd.py:109-259) for a batch: -> cls targets [N,P,C], reg targets [N,P,4] (fp32,
+    device resident).  gt_bboxes_list[i]: [G_i,4] xywh cuda tensor, gt_labels_list[i]: [G_i] int64."""
+    n = len(gt_bboxes_list)
+    dev = gt_bboxes_list[0].device
+    require_cuda(gt_bboxes_list[0], 'assign_targets')
+    d, total = make_assign_desc(n, sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent)
     counts = [int(b.size(0)) for b in gt_bboxes_list]
     offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32).to(dev)
     if sum(counts):
@@ -401,16 +415,7 @@ def assign_targets_from_host(sizes, strides, reg_ranges, gray_ranges, num_classe
     numpy [G]) per image, lfd.py:290-297): concatenated on the host and uploaded with three copies instead of two per image."""
     import numpy as np
     n = len(annotation_batch)
-    d = _lib.AssignDesc()
-    d.n, d.num_levels = n, len(sizes)
-    total = 0
-    for i, (h, w) in enumerate(sizes):
-        d.level_h[i], d.level_w[i], d.stride[i] = int(h), int(w), int(strides[i])
-        d.reg_lo[i], d.reg_hi[i] = int(reg_ranges[i][0]), int(reg_ranges[i][1])
-        d.gray_lo[i], d.gray_hi[i] = int(gray_ranges[i][0]), int(gray_ranges[i][1])
-        total += int(h) * int(w)
-    d.total_points, d.num_classes = total, int(num_classes)
-    d.assign_mode, d.independent = ASSIGN_MODES[assign_mode], int(bool(independent))
+    d, total = make_assign_desc(n, sizes, strides, reg_ranges, gray_ranges, num_classes, assign_mode, independent)
     bl = [np.asarray(b, dtype=np.float32).reshape(-1, 4) for b, _ in annotation_batch]
     ll = [np.asarray(l, dtype=np.int64).reshape(-1) for _, l in annotation_batch]
     counts = [b.shape[0] for b in bl]

@@ -3,7 +3,10 @@ OptimizerHook.after_train_iter (lfd/execution/hooks/optimizer_hook.py:26-36), im
 nn.DataParallel (executor.py:39): forward -> get_loss (global-batch normalisers) -> zero_grad -> backward ->
 one all-reduce of the flat gradient buffer -> clip_grad_norm_ (first `duration` epochs) + SGD update.
 """
-from . import optim, parallel
+import numpy as np
+import torch
+
+from . import ops, optim, parallel, train_engine
 
 
 def train_step(model, optimizer, image_batch, annotation_batch, grad_clip_cfg=None, clip_active=True):
@@ -50,3 +53,118 @@ class OptimizerHook(object):
         cd = executor.config_dict
         active = self._grad_clip_cfg is not None and cd['epoch'] < self._grad_clip_duration
         cd['grad_norm'] = backward_and_update(cd['optimizer'], cd['loss'], self._grad_clip_cfg, active)
+
+
+class GraphedTrainStep(object):
+    """train_step as ONE HIP graph per set of optimizer hyper-parameters: forward, device target assignment, fused get_loss,
+    the hand-written backward, clip_grad_norm_ + SGD -- ~500 launches replayed with one host call, then the iteration's one
+    host sync (the three loss values).  Static shapes: every call must bring an image batch of the first call's shape and at
+    most `max_boxes` annotations in total; the annotations are uploaded into fixed device buffers before the replay.
+
+    Covers what the all-HIP training path covers (train_engine.network_supported + the fused loss + lfd_amd.optim.SGD, one
+    process); raises otherwise -- use train_step.  Learning-rate schedules: the update kernel takes lr / momentum / weight decay
+    by value, so a graph belongs to one set of values; a new set runs eagerly once and is captured when it repeats (a
+    per-iteration warm-up schedule therefore stays eager, the constant-lr bulk of an epoch replays).
+
+        step = GraphedTrainStep(model, optimizer, grad_clip_cfg=dict(max_norm=10, norm_type=2))
+        loss_values, grad_norm = step(image_batch, annotation_batch)        # same contract as train_step
+    """
+
+    def __init__(self, model, optimizer, grad_clip_cfg=None, max_boxes=4096, max_graphs=4):
+        if not isinstance(optimizer, optim.SGD):
+            raise RuntimeError('GraphedTrainStep needs lfd_amd.optim.SGD (the flat-buffer optimizer)')
+        if parallel.is_dist():
+            raise RuntimeError('GraphedTrainStep: single process only (the gradient all-reduce is not captured)')
+        if grad_clip_cfg is not None and float(grad_clip_cfg.get('norm_type', 2)) != 2.0:
+            raise RuntimeError('GraphedTrainStep: L2 gradient clipping only')
+        self.model, self.opt = model, optimizer
+        self.max_norm = None if grad_clip_cfg is None else float(grad_clip_cfg['max_norm'])
+        self.max_boxes, self.max_graphs = int(max_boxes), int(max_graphs)
+        self.graphs, self._last_key, self.x = {}, None, None
+
+    # ------------------------------------------------------------------ static inputs
+    def _bind(self, image_batch):
+        m = self.model
+        if not image_batch.is_cuda or not m.training:
+            raise RuntimeError('GraphedTrainStep: a training-mode model and a device-resident image batch')
+        if not train_engine.network_supported(m) or not m._fused_loss_supported(image_batch):
+            raise RuntimeError('GraphedTrainStep: this model does not run on the all-HIP training path; use train_step')
+        dev = image_batch.device
+        self.x = torch.empty_like(image_batch).contiguous()
+        self.boxes = torch.zeros((self.max_boxes, 4), dtype=torch.float32, device=dev)
+        self.labels = torch.zeros((self.max_boxes,), dtype=torch.int64, device=dev)
+        self.offs = torch.zeros((image_batch.size(0) + 1,), dtype=torch.int32, device=dev)
+        self.adesc = None
+
+    def _upload(self, image_batch, annotation_batch):
+        if self.x is None:
+            self._bind(image_batch)
+        if image_batch.shape != self.x.shape or image_batch.dtype != self.x.dtype:
+            raise RuntimeError('GraphedTrainStep: image batch %s, captured for %s' % (tuple(image_batch.shape), tuple(self.x.shape)))
+        if image_batch.data_ptr() != self.x.data_ptr():
+            self.x.copy_(image_batch)             # (fill `step.x` in place to save this copy)
+        bl = [np.asarray(b, dtype=np.float32).reshape(-1, 4) for b, _ in annotation_batch]
+        ll = [np.asarray(l, dtype=np.int64).reshape(-1) for _, l in annotation_batch]
+        if len(bl) != self.x.size(0):
+            raise RuntimeError('GraphedTrainStep: one annotation per image')
+        counts = [b.shape[0] for b in bl]
+        k = int(sum(counts))
+        if k > self.max_boxes:
+            raise RuntimeError('GraphedTrainStep: %d annotations in the batch, capacity max_boxes=%d' % (k, self.max_boxes))
+        self.offs.copy_(torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)))
+        if k:
+            self.boxes[:k].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate(bl, 0))))
+            self.labels[:k].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate(ll, 0))))
+
+    # ------------------------------------------------------------------ one iteration, device side only
+    def _iteration(self, clip):
+        m = self.model
+        cls, reg = m(self.x)
+        if self.adesc is None:
+            sizes = [m._head_indexes_to_feature_map_sizes[i] for i in range(m._num_heads)]
+            self.adesc = ops.make_assign_desc(self.x.size(0), sizes, m._point_strides, m._regression_ranges, m._gray_ranges,
+                                              m._num_classes, m._range_assign_mode, m._regression_loss_type == 'independent')
+        d, total = self.adesc
+        cls_t, reg_t = ops.assign_targets_device(d, total, m._num_classes, self.boxes, self.labels, self.offs)
+        vals = m._fused_loss_tensor(cls, reg, cls_t, reg_t)
+        self.opt.zero_grad()
+        vals[2].backward()
+        if clip:
+            norm = self.opt.clip_and_step(self.max_norm)
+        else:
+            self.opt.step()
+            norm = None
+        return vals.detach(), norm
+
+    def _key(self, clip):
+        return (bool(clip),) + tuple((float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']),
+                                      bool(g['nesterov'])) for g in self.opt.param_groups)
+
+    def __call__(self, image_batch, annotation_batch, clip_active=True):
+        self._upload(image_batch, annotation_batch)
+        clip = self.max_norm is not None and clip_active
+        key = self._key(clip)
+        ent = self.graphs.get(key)
+        if ent is None and self._last_key == key:
+            # second iteration in a row with these hyper-parameters (the first ran eagerly: momentum buffers, kernel
+            # attributes, workspaces and weight-pack tables exist): capture, then replay like every later call
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                vals, norm = self._iteration(clip)
+            ent = (g, vals, norm)
+            self.graphs[key] = ent
+        self._last_key = key
+        if ent is None:
+            vals, norm = self._iteration(clip)
+        else:
+            ent[0].replay()
+            vals, norm = ent[1], ent[2]
+            # the replayed kernels rewrote parameters and norm buffers behind autograd's back: the inference engine keys its
+            # packed-weight plans on the tensors' version counters
+            optim.increment_version([p for grp in self.opt.param_groups for p in grp['params']])
+            optim.increment_version(list(self.model.buffers()))
+        c, r, t = vals.tolist()          # the one host sync of the iteration
+        return dict(loss=t, classification_loss=c, regression_loss=r), (norm if norm is not None else 0)

@@ -148,6 +148,55 @@ def test_train_step_matches_op_by_op_composition(monkeypatch):
             assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-3 * upd + 2.5e-7, (it, k, upd)      # + 2 ulp at 1.0 (norm weights)
 
 
+def test_graphed_train_step_equals_the_eager_iterations():
+    """GraphedTrainStep: the whole iteration (forward, device targets, fused loss, hand-written backward, clip + SGD) replayed
+    as ONE HIP graph -- same losses, gradient norms, parameters, BatchNorm statistics and momentum buffers as train_step,
+    bit for bit (the kernels are deterministic), over changing batches and annotation counts; a changed learning rate runs
+    eagerly once and is captured again; the inference plan sees the replayed updates."""
+    rng = np.random.default_rng(3)
+    torch.manual_seed(5)
+    ma = configs.build_model('WIDERFACE_LFD_XS').cuda().train()
+    mb = configs.build_model('WIDERFACE_LFD_XS').cuda().train()
+    mb.load_state_dict(ma.state_dict())
+    kw = dict(lr=0.02, momentum=0.9, weight_decay=1e-4)
+    oa, ob = optim.SGD(ma.parameters(), **kw), optim.SGD(mb.parameters(), **kw)
+    clip = dict(max_norm=10, norm_type=2)
+    step = train.GraphedTrainStep(mb, ob, clip, max_boxes=64)
+    xe = torch.randn(1, 3, 160, 192, device='cuda')
+    mb.eval()
+    with torch.no_grad():
+        c0, _ = mb(xe)
+    mb.train()
+    replays = 0
+    for it in range(7):
+        if it == 5:                                   # a learning-rate change: new graph key
+            for o in (oa, ob):
+                o.param_groups[0]['lr'] = 0.01
+        x = torch.from_numpy(rng.normal(0, 1, (4, 3, 160, 192)).astype(np.float32)).cuda()
+        ann = _annotations(rng, 4, (160, 192))
+        if it % 2:
+            ann[1] = (ann[1][0][:2], ann[1][1][:2])   # varying annotation counts, incl. an image without boxes
+            ann[2] = (ann[2][0][:0], ann[2][1][:0])
+        lva, na = train.train_step(ma, oa, x, ann, clip, True)
+        lvb, nb = step(x, ann, True)
+        replays += len(step.graphs) > 0
+        assert lva == lvb, (it, lva, lvb)
+        assert float(na) == float(nb), it
+        for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            assert torch.equal(pa, pb), (it, k)
+        for (k, ba), bb in zip(ma.named_buffers(), mb.buffers()):
+            assert torch.equal(ba, bb), (it, k)
+    assert len(step.graphs) == 2 and replays >= 5      # iterations 1-4 and 6 were graph replays
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert torch.equal(oa.state[pa]['momentum_buffer'], ob.state[pb]['momentum_buffer'])
+    mb.eval()
+    with torch.no_grad():
+        c1, _ = mb(xe)
+    assert not torch.equal(c0, c1)                     # the engine re-packed the weights the replays wrote
+    with pytest.raises(RuntimeError):
+        step(torch.randn(2, 3, 160, 192, device='cuda'), _annotations(rng, 2, (160, 192)))     # another batch shape
+
+
 def test_inference_plan_sees_the_updated_parameters():
     """The update kernel writes the parameters behind autograd's back; the version counters are bumped so that the
     folded fp16 inference plan (engine.get_plan) is rebuilt."""

@@ -1,4 +1,9 @@
 #!/bin/bash
-# round 2, call o: A/B of the neck-filter ring depth in k_head2 (3 vs 5)
+# round 2, call o: the training iteration as one HIP graph (GraphedTrainStep): parity with the eager iterations + timing
 cd "$GRAFT_REPO_ROOT" || exit 1
-timeout 600 bash tools/gpu_ab_bench.sh scratch/alt/liblfd_hip_w5.so 3
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_train.py -q -x -k "graphed" 2>&1 | tail -25
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-siblings 2>gpurun_out/o_bench.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['train'])"
+tail -3 gpurun_out/o_bench.err
