@@ -144,7 +144,19 @@ __global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, in
                                                       float* running_var, float* stats) {
   const int ch = blockIdx.x;           // one wave per channel: lanes stride over the block partials
   double s = 0.0, ss = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 64) {
+  // (four partial rows requested before the first add: the loop is a chain of dependent round trips otherwise; adds in row order)
+  int b = threadIdx.x;
+  for (; b + 192 < nblocks; b += 256) {
+    float u[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      u[k] = partials[(size_t)(b + 64 * k) * 2 * c + ch];
+      v[k] = partials[(size_t)(b + 64 * k) * 2 * c + c + ch];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s += (double)u[k]; ss += (double)v[k]; }
+  }
+  for (; b < nblocks; b += 64) {
     s += (double)partials[(size_t)b * 2 * c + ch];
     ss += (double)partials[(size_t)b * 2 * c + c + ch];
   }
@@ -231,7 +243,18 @@ __global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int 
                                                     int accumulate, float* sums, float* dgamma, float* dbeta) {
   const int ch = blockIdx.x;
   double s = 0.0, sx = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 64) {
+  int b = threadIdx.x;
+  for (; b + 192 < nblocks; b += 256) {        // four rows in flight, adds in row order (see k_bn_stats_final)
+    float u[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      u[k] = partials[(size_t)(b + 64 * k) * 2 * c + ch];
+      v[k] = partials[(size_t)(b + 64 * k) * 2 * c + c + ch];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s += (double)u[k]; sx += (double)v[k]; }
+  }
+  for (; b < nblocks; b += 64) {
     s += (double)partials[(size_t)b * 2 * c + ch];
     sx += (double)partials[(size_t)b * 2 * c + c + ch];
   }
@@ -868,23 +891,43 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
     }
 }
 
-// dW (fp32, OIHW [cout][cin][ks][ks]) = inv_scale * sum over workgroups of the partials
+// dW (fp32, OIHW [cout][cin][ks][ks]) = inv_scale * sum over workgroups of the partials.  A block sums 128 consecutive
+// outputs: 32 lanes x one 16-byte load per partial row and slice (512 contiguous bytes per request instead of 128), 8
+// slices of the workgroup loop in parallel, then the slices in fixed order -- the same summation order as ever, so the
+// results did not change when the loads were widened (14.5 -> ~8 us per call on the 37 MB of a 3x3 64 -> 64 layer's partials).
 __global__ __launch_bounds__(kThreads) void k_wgrad_final(const float* partials, int nwg, int nblk, int cin, int cout,
                                                          int taps, float inv_scale, int accumulate, float* dw) {
-  __shared__ double red[8][32];
+  __shared__ double red[8][128];
   const int per_blk = taps * 64 * 64;
-  const int i = blockIdx.x * 32 + (threadIdx.x & 31);   // 32 consecutive outputs per block, 8 slices of the wg loop
-  const int slice = threadIdx.x >> 5;
-  const int blk = i / per_blk, j = i - blk * per_blk;    // per_blk is a multiple of 32: a block never straddles
-  double s = 0.0;
-  for (int g = slice; g < nwg; g += 8) s += (double)partials[((size_t)g * nblk + blk) * per_blk + j];
-  red[slice][threadIdx.x & 31] = s;
+  const int lane32 = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int i = blockIdx.x * 128 + lane32 * 4;           // 128 consecutive outputs per block, 4 per thread
+  const int blk = i / per_blk, j = i - blk * per_blk;    // per_blk is a multiple of 128: a block never straddles
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // eight partial rows requested before the first is added (one dependent HBM round trip per row otherwise: 32 of them for
+  // 256 workgroups); the adds stay in row order
+  const float* src = partials + (size_t)blk * per_blk + j;
+  const size_t row = (size_t)nblk * per_blk;
+  int g = slice;
+  for (; g + 56 < nwg; g += 64) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(g + 8 * u) * row);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+  }
+  for (; g < nwg; g += 8) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)g * row);
+    s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+  }
+  red[slice][lane32 * 4 + 0] = s0; red[slice][lane32 * 4 + 1] = s1;
+  red[slice][lane32 * 4 + 2] = s2; red[slice][lane32 * 4 + 3] = s3;
   __syncthreads();
-  if (slice != 0) return;
-  s = 0.0;
+  if (threadIdx.x >= 128) return;
+  double s = 0.0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-  const int t = j / 4096, co_l = (j >> 6) & 63, ci_l = j & 63;
+  const int jj = j - lane32 * 4 + (int)threadIdx.x;      // this thread's output inside the block's 128
+  const int t = jj / 4096, co_l = (jj >> 6) & 63, ci_l = jj & 63;
   const int nib = (cin + 63) / 64;
   const int co = (blk / nib) * 64 + co_l, ci = (blk % nib) * 64 + ci_l;
   if (co >= cout || ci >= cin) return;
@@ -1116,7 +1159,7 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
   else rc = launch_wgrad<1, 2>(a, nwg, nblk, st);
   if (rc != LFD_OK) return rc;
   const int taps = ks * ks, total = nblk * taps * 64 * 64;
-  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 32), dim3(kThreads), 0, st, a.partials, nwg, nblk,
+  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 128), dim3(kThreads), 0, st, a.partials, nwg, nblk,
                      cin, cout, taps, inv_scale, accumulate, dw);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
