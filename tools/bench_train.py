@@ -1,6 +1,7 @@
 """Training-step timing (BASELINE.json configs[4]: WIDERFACE_LFD_S, synthetic 640x640, bs 32 per GPU): forward, fused
 get_loss, backward, gradient clipping + SGD.  Prints one JSON line per mode:
   hip   : the whole network on the hand-written kernels (train_engine) + fused loss + flat SGD
+  graph : the same iteration replayed as one HIP graph (lfd_amd.train.GraphedTrainStep)
   torch : the same nn.Modules through PyTorch-ROCm autograd (LFD_HIP_TRAIN=0), op-by-op loss, torch.optim.SGD
 Not the headline metric (bench.py is); recorded in DESIGN.md."""
 import argparse
@@ -26,22 +27,28 @@ def annotations(rng, n, hw, k=6):
 
 
 def run(mode, args):
-    os.environ['LFD_HIP_TRAIN'] = '1' if mode == 'hip' else '0'
-    os.environ['LFD_FUSED_LOSS'] = '1' if mode == 'hip' else '0'
+    hip = mode in ('hip', 'graph')
+    os.environ['LFD_HIP_TRAIN'] = '1' if hip else '0'
+    os.environ['LFD_FUSED_LOSS'] = '1' if hip else '0'
     torch.manual_seed(0)
     m = configs.build_model(args.model).cuda().train()
     kw = dict(lr=0.01, momentum=0.9, weight_decay=1e-4)
-    opt = optim.SGD(m.parameters(), **kw) if mode == 'hip' else torch.optim.SGD(m.parameters(), **kw)
+    opt = optim.SGD(m.parameters(), **kw) if hip else torch.optim.SGD(m.parameters(), **kw)
     rng = np.random.default_rng(0)
     x = torch.randn(args.batch, 3, args.size, args.size, device='cuda')
     ann = annotations(rng, args.batch, (args.size, args.size))
     clip = dict(max_norm=10, norm_type=2)
+    if mode == 'graph':
+        gstep = train.GraphedTrainStep(m, opt, clip, max_boxes=args.batch * 8)
+        step = lambda: gstep(x if gstep.x is None else gstep.x, ann, True)      # noqa: E731
+    else:
+        step = lambda: train.train_step(m, opt, x, ann, clip, True)              # noqa: E731
     for _ in range(args.warmup):
-        lv, _ = train.train_step(m, opt, x, ann, clip, True)
+        lv, _ = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lv, _ = train.train_step(m, opt, x, ann, clip, True)
+        lv, _ = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps(dict(mode=mode, model=args.model, batch=args.batch, size=args.size, ms_per_step=round(dt * 1e3, 3),
