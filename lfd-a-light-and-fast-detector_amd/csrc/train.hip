@@ -649,8 +649,10 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
       const int ky = tab.kyx[s] >> 8, kx = tab.kyx[s] & 255;
       const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
       const bool ok = pv && tab.kyx[s] >= 0 && iy >= 0 && iy < h && ix >= 0 && ix < w;
-      const float v = ok ? xb[tab.off[s]] : 0.f;
-      b[s >> 3][s & 7] = (_Float16)v;
+      // unconditional load from a safe address + select: `ok ? xb[off] : 0` compiles to a branch around every load, and the
+      // 16 loads of a pixel then complete one after the other instead of together
+      const float raw = xb[ok ? tab.off[s] : 0];
+      b[s >> 3][s & 7] = (_Float16)(ok ? raw : 0.f);
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -702,9 +704,9 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
     // stage dy[16 px][64 ch] (zero beyond the row / channel range): 128 16-byte chunks, 2 per lane
     for (int i = l; i < 128; i += 64) {
       const int px = i >> 3, c8 = i & 7;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ox0 + px < wo && c8 * 8 < c)
-        v = *reinterpret_cast<const uint4*>(dy + (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8);
+      const bool in = ox0 + px < wo && c8 * 8 < c;
+      uint4 v = *reinterpret_cast<const uint4*>(in ? dy + (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8 : dy);
+      if (!in) v = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(my + px * 144 + c8 * 16) = v;
     }
     // B: patch[ox0 + 8hk + j][t], j = 0..7
@@ -715,7 +717,8 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
     for (int j = 0; j < 8; ++j) {
       const int ox = ox0 + 8 * hk + j, ix = 2 * ox + kx - 1;
       const bool ok = tkyx >= 0 && ox < wo && iy >= 0 && iy < h && ix >= 0 && ix < w;
-      b[j] = (_Float16)(ok ? xr[2 * ox] : 0.f);
+      const float raw = *(ok ? xr + 2 * ox : x);      // unconditional load + select (see k_conv0_fwd_mfma)
+      b[j] = (_Float16)(ok ? raw : 0.f);
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
