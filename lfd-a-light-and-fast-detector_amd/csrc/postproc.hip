@@ -370,7 +370,11 @@ __global__ __launch_bounds__(kSelThreads) void k_ex_select(DecodeParams d, uint3
     for (int i = threadIdx.x; i < np; i += 4 * kSelThreads) {
       uint32_t k[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k[j] = (i + j * kSelThreads < np) ? kk[i + j * kSelThreads] : 0xffffffffu;   // bit 31 set: never matches
+      for (int j = 0; j < 4; ++j) {       // unconditional loads (index clamped) + select: a conditional load is a branch per load
+        const int idx = i + j * kSelThreads;
+        const uint32_t raw = kk[idx < np ? idx : np - 1];
+        k[j] = idx < np ? raw : 0xffffffffu;                    // bit 31 set: never matches
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if ((k[j] & (mask | 0x80000000u)) == prefix) atomicAdd(&hist[(k[j] >> shift) & bm], 1);
