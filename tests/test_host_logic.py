@@ -521,3 +521,17 @@ def test_checkpoint_written_by_the_reference_loads_strictly():
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.5)
     sched.load_state_dict(ck['lr_scheduler_state_dict'])
     assert sorted(sched.milestones) == [60, 90] and sched.gamma == 0.1
+
+
+def test_graphed_train_step_refuses_what_it_cannot_capture():
+    """lfd_amd.train.GraphedTrainStep: the flat-buffer SGD and L2 clipping only; a CPU batch is refused at the first call"""
+    import torch
+    from lfd_amd import configs, optim, train
+    m = configs.build_model('WIDERFACE_LFD_XS').train()
+    with pytest.raises(RuntimeError):
+        train.GraphedTrainStep(m, torch.optim.SGD(m.parameters(), lr=0.1))
+    with pytest.raises(RuntimeError):
+        train.GraphedTrainStep(m, optim.SGD(m.parameters(), lr=0.1), grad_clip_cfg=dict(max_norm=1.0, norm_type=1))
+    step = train.GraphedTrainStep(m, optim.SGD(m.parameters(), lr=0.1), grad_clip_cfg=dict(max_norm=1.0, norm_type=2))
+    with pytest.raises(RuntimeError):
+        step(torch.zeros(1, 3, 64, 64), [(np.zeros((0, 4), np.float32), np.zeros((0,), np.int64))])
