@@ -1,8 +1,10 @@
 #!/bin/bash
-# round 2, call o: k_ex_select with unconditional key loads: parity + detect timing
+# round 2, last call: the default bench line of the final code (inference + latency + train (graph) + siblings + cpu baseline)
 cd "$GRAFT_REPO_ROOT" || exit 1
-timeout 200 python -m pytest tests/test_gpu_siblings.py -q -x -k "detect_ex or topk" 2>&1 | tail -3
-timeout 200 python tools/bench_siblings.py --no-cpu --reps 20 2>&1 | grep -v amdgpu.ids | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print(d['config'], d['forward_graph_ms']['p50'], d['detect_ms']['p50'])"
+mkdir -p gpurun_out
+timeout 75 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/final_bench.json'))
+print(d['value'], d['ms_per_step'], d['ms_per_step_serial'], d['roofline'], d['latency_bs1']['end_to_end_ms'], d['train']['ms_per_iter'], d['train']['ms_per_iter_eager'], [(s['config'], s['forward_ms'], s['detect_ms']) for s in d['siblings']], d['cpu_baseline']['value'])
+PY
