@@ -245,3 +245,33 @@ def test_sibling_modules_refuse_cpu_tensors():
         m2(torch.zeros(1, 3, 64, 64))
     with pytest.raises(RuntimeError):
         m._neck([torch.zeros(1, 64, 8, 8), torch.zeros(1, 64, 4, 4), torch.zeros(1, 128, 2, 2)])
+
+
+def test_sibling_oracle_edge_cases():
+    """empty result, limits that do not bind, the tie rule of the pre-NMS top-k (lowest point index), cap after NMS"""
+    sizes, strides, ranges = [(6, 8), (3, 4)], [8, 16], [(4, 64), (64, 256)]
+    P = 48 + 12
+    g = torch.Generator().manual_seed(2)
+    cls = torch.randn(P, 2, generator=g)
+    reg = torch.randn(P, 4, generator=g)
+    args = dict(sizes=sizes, strides=strides, ranges=ranges, ce_loss=False, decode='exp', iou_thr=0.5, clamp_hw=(48, 64))
+    # nothing above the threshold: the empty-candidate return of multiclass_nms ((0, 4) boxes, nms.py:207-212)
+    d, l, p = sibling_oracle.get_results_single(cls, reg, None, score_thr=0.9999, pre_nms_limit=10, post_nms_limit=5, **args)
+    assert d.shape[0] == 0 and len(l) == 0 and len(p) == 0
+    # a limit >= the level size selects nothing away; post_nms_limit <= 0 caps nothing
+    a = sibling_oracle.get_results_single(cls, reg, None, score_thr=0.3, pre_nms_limit=48, post_nms_limit=-1, **args)
+    b = sibling_oracle.get_results_single(cls, reg, None, score_thr=0.3, pre_nms_limit=-1, post_nms_limit=-1, **args)
+    np.testing.assert_array_equal(a[2], b[2])
+    c = sibling_oracle.get_results_single(cls, reg, None, score_thr=0.3, pre_nms_limit=-1, post_nms_limit=3, **args)
+    assert len(c[1]) == 3 and np.array_equal(c[2], b[2][:3]) and np.array_equal(c[0], b[0][:3])       # score-descending prefix
+    # ties: 20 points share the best key, the limit takes 5 of them -> the five lowest indices (+ the clear winner)
+    cls2 = torch.full((P, 1), -3.0)
+    cls2[10:30, 0] = 1.0
+    cls2[40, 0] = 2.0
+    far = torch.zeros(P, 4) - 5.0          # tiny boxes: NMS keeps everything
+    d, l, p = sibling_oracle.get_results_single(cls2, far, None, score_thr=0.5, pre_nms_limit=6, post_nms_limit=-1, **args)
+    assert sorted(p.tolist()) == [10, 11, 12, 13, 14, 40]
+    # centerness factors scale the scores before the threshold (nms.py:192-193, 204)
+    ctr = torch.full((P, 1), -20.0)        # sigmoid ~ 2e-9: every product falls below any positive threshold
+    d, l, p = sibling_oracle.get_results_single(cls, reg, ctr, score_thr=1e-6, pre_nms_limit=-1, post_nms_limit=-1, **args)
+    assert len(l) == 0
