@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define LFD_HIP_ABI_VERSION 1
+/* 2: lfd_head_level_ptrs_t grew (w{1,2}_folded, tower1_out, w{1,2}_perm), lfd_conv3x3_c64_chain_nhwc_f16 removed,
+ * lfd_p32_* (fp32-storage precision mode) added.  Every loader checks lfd_hip_abi_version() against this number. */
+#define LFD_HIP_ABI_VERSION 2
 #define LFD_MAX_LEVELS 8
 
 typedef void* lfd_stream_t; /* hipStream_t */
@@ -59,6 +61,13 @@ LFD_API int lfd_nms_cpu_f32(const float* dets, int64_t n, float iou_thr, int64_t
 LFD_API int lfd_soft_nms_cpu_f32(const float* dets, int64_t n, float iou_thr, int32_t method, float sigma, float min_score,
                                  float* out, int64_t* num_out);
 LFD_API int lfd_nms_match_cpu_f32(const float* dets, int64_t n, float iou_thr, int32_t* members, int32_t* group_sizes,
+                                  int64_t* num_groups);
+/* the same three on float64 data: the reference dispatches on the tensor's dtype (AT_DISPATCH_FLOATING_TYPES,
+ * nms_cpu.cpp:70,212,287) and evaluates double tensors -- a numpy array's default dtype -- in double */
+LFD_API int lfd_nms_cpu_f64(const double* dets, int64_t n, float iou_thr, int64_t* keep, int64_t* num_keep);
+LFD_API int lfd_soft_nms_cpu_f64(const double* dets, int64_t n, float iou_thr, int32_t method, float sigma, float min_score,
+                                 double* out, int64_t* num_out);
+LFD_API int lfd_nms_match_cpu_f64(const double* dets, int64_t n, float iou_thr, int32_t* members, int32_t* group_sizes,
                                   int64_t* num_groups);
 
 /* ------------------------------------------------------------------------------------------
@@ -300,9 +309,14 @@ LFD_API int lfd_get_loss_bwd_f32(const lfd_loss_desc_t* d, const float* pred_cls
  * lfd_grad_norm_clip_coef_f32: norm_and_coef[0] = ||grads||_2 (fp64 accumulation, deterministic),
  *   norm_and_coef[1] = min(max_norm / (norm + 1e-6), 1).  extra_sumsq (nullable, device) is added to the
  *   sum of squares before the root (several buffers sharing one norm); sumsq_out (nullable) receives the total.
- * lfd_sgd_step_f32: g *= coef (when norm_and_coef != NULL; written back when write_clipped_grads, as
+ * lfd_sgd_step_f32: g *= coef (when apply_clip; written back when write_clipped_grads, as
  *   clip_grad_norm_ mutates .grad); d = g + wd * p; buf = first_step ? d : momentum * buf + (1 - dampening) * d;
  *   d = nesterov ? d + momentum * buf : buf; p -= lr * d   (torch/optim/sgd.py _single_tensor_sgd).
+ *   Overflow guard of the fp16 activation-gradient path (csrc/train.hip stores dz as fp16 x loss scale): when
+ *   norm_and_coef != NULL and norm_and_coef[0] -- the total gradient norm -- is not finite (an inf gradient gives
+ *   norm = inf and coef = 0, and 0 * inf = NaN would be written into the weights; a NaN gradient gives NaN), the whole
+ *   update is skipped: parameters, momentum and gradients untouched; the caller reads the norm and lowers its loss scale
+ *   (lfd_amd.train.DynamicLossScale).  norm_and_coef must be given when apply_clip != 0.
  */
 LFD_API size_t lfd_grad_norm_workspace_bytes(void);
 LFD_API int lfd_grad_norm_clip_coef_f32(const float* grads, int64_t n, float max_norm, const double* extra_sumsq,
@@ -312,7 +326,7 @@ LFD_API int lfd_grad_norm_clip_coef_f32(const float* grads, int64_t n, float max
 LFD_API int lfd_scale_by_clip_coef_f32(float* grads, int64_t n, const float* norm_and_coef, lfd_stream_t stream);
 LFD_API int lfd_sgd_step_f32(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
                      float dampening, float weight_decay, int32_t nesterov, int32_t first_step,
-                     const float* norm_and_coef, int32_t write_clipped_grads, lfd_stream_t stream);
+                     const float* norm_and_coef, int32_t apply_clip, int32_t write_clipped_grads, lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Inference conv stack, NHWC fp16, fp32 accumulate on MFMA.  Replaces the nn.Conv2d +
@@ -385,6 +399,41 @@ LFD_API int lfd_pack_level_outputs_f32(const float* src, float* dst, int32_t n, 
  * (tail_cout must be 0). */
 LFD_API int lfd_conv2d_nhwc_f16_acc32(const lfd_conv_desc_t* desc, const void* in, float* out_f32, const void* w_packed,
                                       const float* bias, const void* zeros, lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 'fp32_storage' precision mode of the eval forward (LFD.precision = 'fp32_storage'): a shipped mode of the product for
+ * callers that need the reference's fp32 outputs to <= 1e-4 on the raw logits (north_star: "cls/bbox tensors within
+ * 1e-3"); replaces the same reference code as the fp16 entry points above -- nn.Conv2d + eval BatchNorm2d (+ residual)
+ * + ReLU of lfd_resnet.py:354-501 / simple_neck.py:67-74, the head convs, GroupNorm + ReLU and Scale of
+ * lfd_head.py:97-117,164-185.  Activations are fp32 NHWC; ONE launch per conv: operands are split exactly into fp16
+ * hi + 2^-11 lo parts inside the kernel (activations by the tile loader, weights once per plan), three MFMAs per k-step,
+ * fp32 accumulation, epilogue out = relu?( scale * (conv + bias (+ residual)) ) in fp32.
+ *   in_format < 0: `in` is fp32 NHWC [n,h,w,cin], cin a multiple of 32; ks 1|3, stride 1|2, pad ks/2.
+ *   in_format 0|1|2 (NCHW fp32 / NHWC fp16 / NHWC uint8 + simple_normalize): the first stem conv, 3x3 stride 2 on the
+ *     3-channel frame (cin = 3); the 27 taps are one 32-wide k chunk gathered from the frame.
+ *   w_packed: lfd_p32_conv_packed_weight_halfs() fp16 values, [cout/32 slabs][cin/32 chunks][ks*ks taps][2 k-steps]
+ *     [hi | 2^11 lo][64 lanes][8]; lane = 32 * khalf + cout_local, element j = channel 32 chunk + 16 kstep + 8 khalf + j
+ *     (first conv: k = (dy*3 + dx)*3 + c, zero above 27); bias [32 * slabs] fp32 (zero padded).
+ *   out: channel c of pixel (oy, ox) of image i at out[i * out_image_stride + (oy*OW + ox) * out_pixel_stride + c]
+ *     (0 = dense: out_pixel_stride = cout, out_image_stride = OH*OW*cout) -- the head's output convs write straight into
+ *     the level-concatenated [N,P,C'] / [N,P,4] tensors (lfd.py:526-542); residual: dense fp32 [n,OH,OW,cout] or NULL;
+ *     scale: device pointer to ONE float (lfd_head.py Scale, applied after the bias) or NULL. */
+typedef struct lfd_p32_conv_desc {
+  int32_t n, h, w, cin, cout, ks, stride, relu;
+  int32_t in_format;
+  int32_t out_pixel_stride;
+  int64_t out_image_stride;
+} lfd_p32_conv_desc_t;
+LFD_API size_t lfd_p32_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t ks);
+LFD_API int lfd_p32_conv2d_nhwc_f32(const lfd_p32_conv_desc_t* desc, const void* in, float* out, const void* w_packed,
+                                    const float* bias, const float* residual, const float* scale, lfd_stream_t stream);
+/* x [n, hw, c] fp32 <- relu?( GroupNorm(groups)(x) * gamma + beta ) in place (nn.GroupNorm semantics: biased variance
+ * over hw x c/groups elements per image and group; statistics summed in fp64 in a fixed order); c % 4 == 0,
+ * 256 % (c/4) == 0, (c/groups) % 4 == 0, groups <= 64. */
+LFD_API size_t lfd_p32_groupnorm_workspace_bytes(int32_t n, int32_t groups);
+LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t c, int32_t groups, const float* gamma,
+                                       const float* beta, float eps, int32_t relu, void* workspace, size_t workspace_bytes,
+                                       lfd_stream_t stream);
 
 /* First stem unit: conv3x3 s2 (3 -> C) + BN + ReLU chained with conv1x1 (C -> C) + BN + ReLU
  * (lfd_resnet.py:356-374 'fast' stem; first half of the 'faster' stem :376-395).

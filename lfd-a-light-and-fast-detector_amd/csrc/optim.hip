@@ -71,8 +71,8 @@ struct SgdArgs {
   float* buf;
   int64_t n;
   float lr, momentum, dampening, weight_decay;
-  int nesterov, first, write_grad;
-  const float* coef;  // nullable: device pointer to the clip coefficient
+  int nesterov, first, write_grad, clip;
+  const float* coef;  // nullable: device pointer to {total norm, clip coefficient}
 };
 
 __device__ __forceinline__ void sgd_elem(const SgdArgs& a, float coef, float& p, float& g, float& b) {
@@ -86,12 +86,16 @@ __device__ __forceinline__ void sgd_elem(const SgdArgs& a, float coef, float& p,
 }
 
 __global__ __launch_bounds__(kThreads) void k_sgd(SgdArgs a) {
-  const float coef = a.coef ? a.coef[1] : 1.0f;
-  const bool clip = a.coef != nullptr;
-  // overflow guard of the fp16 activation-gradient path (train.hip stores dz as fp16 with a loss scale): a non-finite
-  // total norm gives a NaN coefficient, and torch's clip_grad_norm_ + SGD would write it into every weight.  Skip the
-  // whole update instead (parameters and momentum untouched); the caller sees the non-finite norm in norm_and_coef[0].
-  if (clip && !(coef >= 0.0f && coef <= 1.0f)) return;
+  const bool clip = a.clip != 0;
+  const float coef = clip ? a.coef[1] : 1.0f;
+  // overflow guard of the fp16 activation-gradient path (train.hip stores dz as fp16 with a loss scale).  The gate is the
+  // NORM, not the coefficient: an inf gradient gives norm = inf and coef = max_norm / inf = 0 -- a perfectly valid-looking
+  // coefficient -- and g * coef = inf * 0 = NaN would go into the weights and the momentum; a NaN gradient gives NaN.  Skip
+  // the whole update instead (parameters, momentum, gradients untouched); the caller sees the norm in norm_and_coef[0].
+  if (a.coef) {
+    const float norm = a.coef[0];
+    if (!(norm >= 0.0f && norm <= 3.402823466e38f)) return;
+  }
   const int64_t n4 = a.n >> 2;
   float4* p4 = reinterpret_cast<float4*>(a.p);
   float4* g4 = reinterpret_cast<float4*>(a.g);
@@ -171,17 +175,18 @@ int lfd_scale_by_clip_coef_f32(float* grads, int64_t n, const float* norm_and_co
 
 int lfd_sgd_step_f32(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
                      float dampening, float weight_decay, int32_t nesterov, int32_t first_step,
-                     const float* norm_and_coef, int32_t write_clipped_grads, lfd_stream_t stream) {
+                     const float* norm_and_coef, int32_t apply_clip, int32_t write_clipped_grads, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n < 0) return LFD_ERR_INVALID_ARGUMENT;
   if (n == 0) return LFD_OK;
   if (!params || !grads || (momentum != 0.f && !momentum_buf)) return LFD_ERR_INVALID_ARGUMENT;
   if (nesterov && (momentum <= 0.f || dampening != 0.f)) return LFD_ERR_INVALID_ARGUMENT;  // torch.optim.SGD ctor check
+  if (apply_clip && !norm_and_coef) return LFD_ERR_INVALID_ARGUMENT;
   if (((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
         reinterpret_cast<uintptr_t>(momentum_buf)) & 15) != 0)
     return LFD_ERR_INVALID_ARGUMENT;
   SgdArgs a{params, grads, momentum_buf, n, lr, momentum, dampening, weight_decay, nesterov, first_step,
-            write_clipped_grads, norm_and_coef};
+            write_clipped_grads, apply_clip, norm_and_coef};
   hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(kThreads), 0, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;

@@ -56,6 +56,14 @@ class HeadLevelPtrs(C.Structure):
                 ('w1_perm', C.c_void_p), ('w2_perm', C.c_void_p)]
 
 
+class P32ConvDesc(C.Structure):
+    """lfd_p32_conv_desc_t"""
+    _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
+                ('ks', C.c_int32), ('stride', C.c_int32), ('relu', C.c_int32), ('in_format', C.c_int32),
+                ('out_pixel_stride', C.c_int32), ('out_image_stride', C.c_int64)]
+
+
+ABI_VERSION = 2                         # LFD_HIP_ABI_VERSION
 HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS
 HEAD_TOWER1_GROUP_HALFS = 8 * 64 * 8    # LFD_HEAD_TOWER1_GROUP_HALFS
 
@@ -96,6 +104,9 @@ _SIGNATURES = {
     'lfd_nms_cpu_f32': (C.c_int, [_P, _I64, _F, _P, _P]),
     'lfd_soft_nms_cpu_f32': (C.c_int, [_P, _I64, _F, _I32, _F, _F, _P, _P]),
     'lfd_nms_match_cpu_f32': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
+    'lfd_nms_cpu_f64': (C.c_int, [_P, _I64, _F, _P, _P]),
+    'lfd_soft_nms_cpu_f64': (C.c_int, [_P, _I64, _F, _I32, _F, _F, _P, _P]),
+    'lfd_nms_match_cpu_f64': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
     'lfd_nms_workspace_bytes': (_SZ, [_I64]),
     'lfd_nms_f32': (C.c_int, [_P, _I64, _F, _P, _P, _P, _SZ, _P]),
     'lfd_batched_nms_workspace_bytes': (_SZ, [_I64]),
@@ -132,7 +143,7 @@ _SIGNATURES = {
     'lfd_grad_norm_workspace_bytes': (_SZ, []),
     'lfd_grad_norm_clip_coef_f32': (C.c_int, [_P, _I64, _F, _P, _P, _SZ, _P, _P, _P]),
     'lfd_scale_by_clip_coef_f32': (C.c_int, [_P, _I64, _P, _P]),
-    'lfd_sgd_step_f32': (C.c_int, [_P, _P, _P, _I64, _F, _F, _F, _F, _I32, _I32, _P, _I32, _P]),
+    'lfd_sgd_step_f32': (C.c_int, [_P, _P, _P, _I64, _F, _F, _F, _F, _I32, _I32, _P, _I32, _I32, _P]),
     'lfd_train_workspace_bytes': (_SZ, []),
     'lfd_bn_train_stats_f16': (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_bn_train_apply_f16': (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I32, _P, _P]),
@@ -159,6 +170,10 @@ _SIGNATURES = {
     'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_fasterblock_fused_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_conv2d_nhwc_f16_acc32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'lfd_p32_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
+    'lfd_p32_conv2d_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_p32_groupnorm_workspace_bytes': (_SZ, [_I32, _I32]),
+    'lfd_p32_groupnorm_relu_f32': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P]),
     'lfd_conv2d_downsample_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
@@ -181,8 +196,10 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)   # AttributeError -> missing export: loud by design
             fn.restype, fn.argtypes = res, args
-        if l.lfd_hip_abi_version() != 1:
-            raise RuntimeError('liblfd_hip.so ABI version mismatch')
+        if l.lfd_hip_abi_version() != ABI_VERSION:
+            raise RuntimeError('liblfd_hip.so ABI version mismatch: %s reports %d, this package binds version %d '
+                               '(struct layouts differ -- rebuild with `python __graft_entry__.py`)'
+                               % (LIB_PATH, l.lfd_hip_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

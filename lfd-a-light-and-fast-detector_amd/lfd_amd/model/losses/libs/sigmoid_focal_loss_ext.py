@@ -13,6 +13,7 @@ import os
 import torch
 
 _lib = None
+_ABI_VERSION = 2      # LFD_HIP_ABI_VERSION of include/lfd_hip.h
 
 
 def _load():
@@ -26,6 +27,10 @@ def _load():
             raise RuntimeError('sigmoid_focal_loss_ext: liblfd_hip.so not found (set LFD_HIP_LIB or build it with '
                                '`python __graft_entry__.py`)')
         l = C.CDLL(path)
+        l.lfd_hip_abi_version.restype = C.c_int
+        if l.lfd_hip_abi_version() != _ABI_VERSION:
+            raise RuntimeError('sigmoid_focal_loss_ext: %s has ABI version %d, this file binds version %d'
+                               % (path, l.lfd_hip_abi_version(), _ABI_VERSION))
         l.lfd_sigmoid_focal_loss_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p,
                                                  C.c_int32, C.c_void_p]
         l.lfd_sigmoid_focal_loss_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float,

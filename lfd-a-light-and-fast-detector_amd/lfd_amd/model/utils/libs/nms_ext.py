@@ -16,6 +16,7 @@ import os
 import torch
 
 _lib = None
+_ABI_VERSION = 2      # LFD_HIP_ABI_VERSION of include/lfd_hip.h
 
 
 def _load():
@@ -28,12 +29,18 @@ def _load():
         if path is None:
             raise RuntimeError('nms_ext: liblfd_hip.so not found (set LFD_HIP_LIB or build it with `python __graft_entry__.py`)')
         l = C.CDLL(path)
+        l.lfd_hip_abi_version.restype = C.c_int
+        if l.lfd_hip_abi_version() != _ABI_VERSION:
+            raise RuntimeError('nms_ext: %s has ABI version %d, this file binds version %d' % (path, l.lfd_hip_abi_version(), _ABI_VERSION))
         l.lfd_nms_workspace_bytes.restype = C.c_size_t
         l.lfd_nms_workspace_bytes.argtypes = [C.c_int64]
         l.lfd_nms_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.lfd_nms_cpu_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
         l.lfd_soft_nms_cpu_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         l.lfd_nms_match_cpu_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.lfd_nms_cpu_f64.argtypes = l.lfd_nms_cpu_f32.argtypes
+        l.lfd_soft_nms_cpu_f64.argtypes = l.lfd_soft_nms_cpu_f32.argtypes
+        l.lfd_nms_match_cpu_f64.argtypes = l.lfd_nms_match_cpu_f32.argtypes
         _lib = l
     return _lib
 
@@ -44,9 +51,13 @@ def _check(rc, what):
 
 
 def _host_dets(dets, what):
+    """-> (contiguous CPU tensor, 'f32' | 'f64'): the reference evaluates a tensor in its own floating dtype
+    (AT_DISPATCH_FLOATING_TYPES, nms_cpu.cpp:70,212,287); float64 -- numpy's default -- stays float64"""
     if dets.dim() != 2 or dets.size(1) != 5:
         raise RuntimeError('%s: dets must be [n,5]' % what)
-    return dets.detach().contiguous().float()
+    if dets.dtype == torch.float64:
+        return dets.detach().contiguous(), 'f64'
+    return dets.detach().contiguous().float(), 'f32'
 
 
 def nms(dets, threshold):
@@ -59,10 +70,10 @@ def nms(dets, threshold):
     l = _load()
     n = dets.size(0)
     if not dets.is_cuda:
-        d = _host_dets(dets, 'nms')
+        d, sfx = _host_dets(dets, 'nms')
         keep = torch.empty(n, dtype=torch.long)
         num = C.c_int64(0)
-        _check(l.lfd_nms_cpu_f32(d.data_ptr(), n, float(threshold), keep.data_ptr(), C.byref(num)), 'lfd_nms_cpu_f32')
+        _check(getattr(l, 'lfd_nms_cpu_' + sfx)(d.data_ptr(), n, float(threshold), keep.data_ptr(), C.byref(num)), 'lfd_nms_cpu_' + sfx)
         return keep[:num.value]
     d = dets.detach().contiguous().float()
     with torch.cuda.device(d.device):
@@ -80,12 +91,12 @@ def soft_nms(dets, threshold, method, sigma, min_score):
         raise RuntimeError('soft_nms is not implemented on GPU')       # nms_ext.cpp:33
     if dets.numel() == 0:
         return torch.empty(0, dtype=torch.long)                        # nms_cpu.cpp:83-85
-    d = _host_dets(dets, 'soft_nms')
+    d, sfx = _host_dets(dets, 'soft_nms')
     n = d.size(0)
-    out = torch.empty((n, 6), dtype=torch.float32)
+    out = torch.empty((n, 6), dtype=d.dtype)
     num = C.c_int64(0)
-    _check(_load().lfd_soft_nms_cpu_f32(d.data_ptr(), n, float(threshold), int(method), float(sigma), float(min_score),
-                                        out.data_ptr(), C.byref(num)), 'lfd_soft_nms_cpu_f32')
+    _check(getattr(_load(), 'lfd_soft_nms_cpu_' + sfx)(d.data_ptr(), n, float(threshold), int(method), float(sigma), float(min_score),
+                                                       out.data_ptr(), C.byref(num)), 'lfd_soft_nms_cpu_' + sfx)
     return out[:num.value].to(dets.dtype)
 
 
@@ -94,13 +105,13 @@ def nms_match(dets, threshold):
         raise RuntimeError('nms_match is not implemented on GPU')      # nms_ext.cpp:40
     if dets.numel() == 0:
         return []
-    d = _host_dets(dets, 'nms_match')
+    d, sfx = _host_dets(dets, 'nms_match')
     n = d.size(0)
     members = torch.empty(n, dtype=torch.int32)
     sizes = torch.empty(n, dtype=torch.int32)
     num = C.c_int64(0)
-    _check(_load().lfd_nms_match_cpu_f32(d.data_ptr(), n, float(threshold), members.data_ptr(), sizes.data_ptr(), C.byref(num)),
-           'lfd_nms_match_cpu_f32')
+    _check(getattr(_load(), 'lfd_nms_match_cpu_' + sfx)(d.data_ptr(), n, float(threshold), members.data_ptr(), sizes.data_ptr(),
+                                                        C.byref(num)), 'lfd_nms_match_cpu_' + sfx)
     out, o = [], 0
     mem = members.tolist()
     for s in sizes[:num.value].tolist():

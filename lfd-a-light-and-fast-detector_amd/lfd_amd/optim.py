@@ -218,7 +218,9 @@ class SGD(torch.optim.Optimizer):
                 st['momentum_buffer'] = fg.view(fg.m, p, off)
 
     # -- update ------------------------------------------------------------------------------------------------
-    def _step(self, clip):
+    def _step(self, nc, clip):
+        """nc: device {total norm, clip coefficient} (the update is skipped on the device when the norm is not finite --
+        the overflow guard of the fp16 gradient path, csrc/optim.hip); clip: multiply the gradients by the coefficient"""
         for group, fg in zip(self.param_groups, self._flat):
             ok = fg.adopt_grads()
             self._rebind_state(fg)
@@ -234,7 +236,8 @@ class SGD(torch.optim.Optimizer):
             with torch.cuda.device(fg.device):
                 check(lib().lfd_sgd_step_f32(ptr(fg.p), ptr(fg.g), ptr(fg.m), fg.numel, float(group['lr']), mom,
                                              float(group['dampening']), float(group['weight_decay']),
-                                             int(bool(group['nesterov'])), int(first), ptr(clip), 1, stream_ptr()),
+                                             int(bool(group['nesterov'])), int(first), ptr(nc), int(bool(clip)), 1,
+                                             stream_ptr()),
                       'lfd_sgd_step_f32')
             if first:
                 for p, off in zip(fg.params, fg.offsets):
@@ -247,7 +250,11 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self._step(None)
+        # the norm is computed even without clipping: it is the update's overflow guard (max_norm = inf -> coefficient 1)
+        for fg in self._flat:
+            fg.adopt_grads()
+        self.last_norm = _norm(self._flat, float('inf'))
+        self._step(self.last_norm, False)
         return loss
 
     @torch.no_grad()
@@ -258,7 +265,8 @@ class SGD(torch.optim.Optimizer):
         for fg in self._flat:
             fg.adopt_grads()
         nc = _norm(self._flat, max_norm)
-        self._step(nc)
+        self.last_norm = nc
+        self._step(nc, True)
         return nc[0].clone()
 
     # -- checkpoints -------------------------------------------------------------------------------------------

@@ -9,12 +9,51 @@ import torch
 from . import ops, optim, parallel, train_engine
 
 
-def train_step(model, optimizer, image_batch, annotation_batch, grad_clip_cfg=None, clip_active=True):
+class DynamicLossScale(object):
+    """Loss scale of the fp16 activation-gradient path (train_engine / csrc/train.hip), driven by the finiteness of the
+    total gradient norm -- the same signal the update kernel gates on (csrc/optim.hip: a non-finite norm skips the update):
+    overflow -> halve (the skipped iteration costs one step, the weights stay clean); `growth_interval` clean iterations in a
+    row -> double.  Powers of two in [min_scale, max_scale], so scaling and unscaling are exact.  The reference trains in fp32
+    (optimizer_hook.py:26-36) and needs none; with fp32-representable gradients (|dz| < 65504 / scale) the results do not
+    depend on the scale (measured 1 .. 65536)."""
+
+    def __init__(self, init_scale=None, growth_interval=2000, min_scale=1.0, max_scale=65536.0):
+        if init_scale is not None:
+            train_engine.set_loss_scale(init_scale)
+        self.growth_interval, self.min_scale, self.max_scale = int(growth_interval), float(min_scale), float(max_scale)
+        self.good_steps, self.skipped = 0, 0
+
+    @property
+    def scale(self):
+        return train_engine.loss_scale()
+
+    def update(self, grad_norm):
+        """grad_norm: the iteration's total gradient norm (float or 0-dim tensor).  -> True if the update was applied"""
+        finite = bool(np.isfinite(float(grad_norm)))
+        if not finite:
+            self.skipped += 1
+            self.good_steps = 0
+            train_engine.set_loss_scale(max(self.min_scale, self.scale / 2))
+            return False
+        self.good_steps += 1
+        if self.good_steps >= self.growth_interval:
+            self.good_steps = 0
+            train_engine.set_loss_scale(min(self.max_scale, self.scale * 2))
+        return True
+
+
+def train_step(model, optimizer, image_batch, annotation_batch, grad_clip_cfg=None, clip_active=True, loss_scaler=None):
     """-> (loss_values dict of floats, grad_norm).  grad_clip_cfg: dict(max_norm=..., norm_type=2) or None
-    (config_dict['optimizer_grad_clip_cfg'] without 'duration'); clip_active: epoch < duration."""
+    (config_dict['optimizer_grad_clip_cfg'] without 'duration'); clip_active: epoch < duration; loss_scaler: an optional
+    DynamicLossScale (reads the norm: one more host sync)."""
     predict_outputs = model(image_batch)
     loss_dict = model.get_loss(predict_outputs, annotation_batch)
     grad_norm = backward_and_update(optimizer, loss_dict['loss'], grad_clip_cfg, clip_active)
+    if loss_scaler is not None:
+        if isinstance(optimizer, optim.SGD):
+            loss_scaler.update(optimizer.last_norm[0])
+        else:
+            loss_scaler.update(grad_norm)
     return loss_dict['loss_values'], grad_norm
 
 
@@ -70,7 +109,7 @@ class GraphedTrainStep(object):
         loss_values, grad_norm = step(image_batch, annotation_batch)        # same contract as train_step
     """
 
-    def __init__(self, model, optimizer, grad_clip_cfg=None, max_boxes=4096, max_graphs=4):
+    def __init__(self, model, optimizer, grad_clip_cfg=None, max_boxes=4096, max_graphs=4, loss_scaler=None):
         if not isinstance(optimizer, optim.SGD):
             raise RuntimeError('GraphedTrainStep needs lfd_amd.optim.SGD (the flat-buffer optimizer)')
         if parallel.is_dist():
@@ -81,6 +120,7 @@ class GraphedTrainStep(object):
         self.max_norm = None if grad_clip_cfg is None else float(grad_clip_cfg['max_norm'])
         self.max_boxes, self.max_graphs = int(max_boxes), int(max_graphs)
         self.graphs, self._last_key, self.x = {}, None, None
+        self.loss_scaler = loss_scaler      # DynamicLossScale or None; a graph belongs to one loss scale (it is in the key)
 
     # ------------------------------------------------------------------ static inputs
     def _bind(self, image_batch):
@@ -134,10 +174,10 @@ class GraphedTrainStep(object):
         else:
             self.opt.step()
             norm = None
-        return vals.detach(), norm
+        return vals.detach(), norm, self.opt.last_norm
 
     def _key(self, clip):
-        return (bool(clip),) + tuple((float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']),
+        return (bool(clip), train_engine.loss_scale()) + tuple((float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']),
                                       bool(g['nesterov'])) for g in self.opt.param_groups)
 
     def __call__(self, image_batch, annotation_batch, clip_active=True):
@@ -153,18 +193,20 @@ class GraphedTrainStep(object):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                vals, norm = self._iteration(clip)
-            ent = (g, vals, norm)
+                vals, norm, nc = self._iteration(clip)
+            ent = (g, vals, norm, nc)
             self.graphs[key] = ent
         self._last_key = key
         if ent is None:
-            vals, norm = self._iteration(clip)
+            vals, norm, nc = self._iteration(clip)
         else:
             ent[0].replay()
-            vals, norm = ent[1], ent[2]
+            vals, norm, nc = ent[1], ent[2], ent[3]
             # the replayed kernels rewrote parameters and norm buffers behind autograd's back: the inference engine keys its
             # packed-weight plans on the tensors' version counters
             optim.increment_version([p for grp in self.opt.param_groups for p in grp['params']])
             optim.increment_version(list(self.model.buffers()))
         c, r, t = vals.tolist()          # the one host sync of the iteration
+        if self.loss_scaler is not None:
+            self.loss_scaler.update(nc[0])
         return dict(loss=t, classification_loss=c, regression_loss=r), (norm if norm is not None else 0)

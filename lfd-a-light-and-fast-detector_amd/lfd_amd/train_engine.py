@@ -16,7 +16,22 @@ import torch.nn as nn
 
 from . import ops
 
-LOSS_SCALE = 1024.0   # power of two; activation gradients are stored as fp16 * LOSS_SCALE
+LOSS_SCALE = 1024.0   # initial value; power of two; activation gradients are stored as fp16 * loss_scale()
+_scale_state = {'value': LOSS_SCALE}
+
+
+def loss_scale():
+    """the loss scale the next backward pass multiplies the prediction gradients with (fp16 activation gradients carry it,
+    the weight-gradient / norm kernels divide it out again: parameter gradients are unscaled fp32)"""
+    return _scale_state['value']
+
+
+def set_loss_scale(v):
+    """power of two in [1, 65536] (lfd_amd.train.DynamicLossScale drives this from the gradient norm's finiteness)"""
+    v = float(v)
+    if not (1.0 <= v <= 65536.0) or v != 2.0 ** round(__import__('math').log2(v)):
+        raise ValueError('loss scale must be a power of two in [1, 65536]')
+    _scale_state['value'] = v
 
 
 class _Unit(object):
@@ -290,12 +305,13 @@ class _GradStore(object):
         return p.grad if self.in_place else self.g.get(id(p))
 
 
-def backward(units, saved, grads, scale=LOSS_SCALE, store=None, trace=None):
+def backward(units, saved, grads, scale=None, store=None, trace=None):
     """grads: {activation index: dL/dact NHWC fp16 multiplied by `scale`} for the activations consumed outside the units
     (taps for the backbone alone, tower outputs for the whole network).  -> _GradStore of fp32 parameter gradients.
     trace: optional list that receives the per-unit tensors (tests check every unit against PyTorch given the same
     inputs)."""
     acts, tape = saved
+    scale = loss_scale() if scale is None else scale
     inv = 1.0 / scale
     grads = dict(grads)
     store = store if store is not None else _GradStore()
@@ -384,9 +400,10 @@ def outputs_forward(outs, acts, num_levels):
     return torch.cat(cls_l, 1), torch.cat(reg_l, 1), sizes, saved
 
 
-def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=LOSS_SCALE):
+def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=None):
     """-> {activation index: scaled fp16 gradient} for the tower outputs; parameter gradients go to `store`."""
     grads = {}
+    scale = loss_scale() if scale is None else scale
     inv = 1.0 / scale
     starts, p = [], 0
     for h, w_ in sizes:
@@ -438,11 +455,12 @@ class BackboneTrainFunction(torch.autograd.Function):
     def backward(ctx, *tap_grads):
         units, tap_ids = ctx.plan
         grads = {}
+        scale = loss_scale()
         for t, g in zip(tap_ids, tap_grads):
             if g is not None:
-                g16 = (g * LOSS_SCALE).permute(0, 2, 3, 1).contiguous().half()
+                g16 = (g * scale).permute(0, 2, 3, 1).contiguous().half()
                 grads[t] = g16 if t not in grads else grads[t] + g16
-        backward(units, ctx.saved, grads, store=_GradStore(in_place=True))
+        backward(units, ctx.saved, grads, scale=scale, store=_GradStore(in_place=True))
         ctx.saved = None
         return (None, None) + (None,) * len(backbone_params(units))     # gradients were accumulated into .grad directly
 
@@ -470,8 +488,9 @@ class NetworkTrainFunction(torch.autograd.Function):
             dcls = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
         if dreg is None:
             dreg = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
-        grads = outputs_backward(outs, ctx.saved[0], ctx.osaved, ctx.sizes, dcls.contiguous(), dreg.contiguous(), store)
-        backward(units, ctx.saved, grads, store=store)
+        scale = loss_scale()
+        grads = outputs_backward(outs, ctx.saved[0], ctx.osaved, ctx.sizes, dcls.contiguous(), dreg.contiguous(), store, scale=scale)
+        backward(units, ctx.saved, grads, scale=scale, store=store)
         ctx.saved = ctx.osaved = None
         return (None, None) + (None,) * len(network_params(units, outs))   # accumulated into .grad directly
 

@@ -27,7 +27,14 @@ def test_python_binding_covers_the_header():
 
 def test_abi_version_and_strings():
     l = _lib.lib()
-    assert l.lfd_hip_abi_version() == 1
+    src = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
+    header_version = int(re.search(r'#define LFD_HIP_ABI_VERSION (\d+)', src).group(1))
+    assert l.lfd_hip_abi_version() == header_version == _lib.ABI_VERSION == 2
+    # the two self-contained extension files check the same number (a stale build selected through LFD_HIP_LIB would index
+    # grown structs with the wrong stride)
+    for rel in ('model/utils/libs/nms_ext.py', 'model/losses/libs/sigmoid_focal_loss_ext.py'):
+        text = open(os.path.join(os.path.dirname(_lib.__file__), rel)).read()
+        assert '_ABI_VERSION = %d' % header_version in text and 'lfd_hip_abi_version() != _ABI_VERSION' in text, rel
     assert l.lfd_hip_status_string(0) == b'ok'
     assert l.lfd_hip_status_string(-2) == b'workspace too small'
     assert l.lfd_hip_build_info().startswith(b'gfx950;')
@@ -58,11 +65,22 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_sigmoid_focal_loss_fwd(None, None, 4, 0, 2.0, 0.25, None, 0, None) == -1
     # round-2 entry points: argument checks happen on the host, before anything touches a device
     import ctypes as C
+    one0 = C.c_int(0)
     assert l.lfd_detect_from_candidates(None, 1, None, None, None, None, None, None, 0, None) == -1
     assert l.lfd_detect_workspace_reset(None, 1, None, 0, None) == -1
     assert l.lfd_head_forward_decode_f16(None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert l.lfd_groupnorm_finalize_fold(None, None, None, None, 1e-5, None, None, 1, None) == -1
     assert l.lfd_fasterblock_fused_f16(0, 8, 8, None, None, None, None, None, None, None, None) == -1
+    # round-3 entry points: the fp32-storage precision mode and the gated update
+    assert l.lfd_p32_conv2d_nhwc_f32(None, None, None, None, None, None, None, None) == -1
+    assert l.lfd_p32_groupnorm_relu_f32(None, 1, 16, 128, 16, None, None, 1e-5, 1, None, 0, None) == -1
+    pd = _lib.P32ConvDesc(1, 8, 8, 48, 64, 3, 1, 1, -1, 0, 0)
+    assert l.lfd_p32_conv2d_nhwc_f32(C.byref(pd), C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0), None, None, None) == -4   # cin % 32
+    pd = _lib.P32ConvDesc(1, 8, 8, 64, 64, 5, 1, 1, -1, 0, 0)
+    assert l.lfd_p32_conv2d_nhwc_f32(C.byref(pd), C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0), None, None, None) == -4   # 5x5
+    assert l.lfd_p32_conv_packed_weight_halfs(64, 64, 3) == 2 * 2 * 9 * 2 * 2 * 64 * 8
+    assert l.lfd_p32_groupnorm_workspace_bytes(8, 16) == 8 * 64 * 16 * 16
+    assert l.lfd_sgd_step_f32(C.byref(one0), C.byref(one0), C.byref(one0), 4, 0.1, 0.9, 0.0, 0.0, 0, 0, None, 1, 1, None) == -1   # clip without a norm
     # sibling meta-architecture entry points
     assert l.lfd_detect_batched_ex(None, None, 1, None, None, None, 0, None, None, None, None, None, None, None, 0, None) == -1
     assert l.lfd_upsample_nearest_add_nhwc_f16(None, None, 1, 4, 4, 2, 2, 64, None) == -1
@@ -95,7 +113,8 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
     from lfd_amd import _lib
     pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc,
              'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
-             'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob, 'lfd_detect_ext_t': _lib.DetectExt}
+             'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob, 'lfd_detect_ext_t': _lib.DetectExt,
+             'lfd_p32_conv_desc_t': _lib.P32ConvDesc}
     header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lfd_hip.h"', 'int main(void) {']
     for cname, mirror in pairs.items():

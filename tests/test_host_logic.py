@@ -535,3 +535,31 @@ def test_graphed_train_step_refuses_what_it_cannot_capture():
     step = train.GraphedTrainStep(m, optim.SGD(m.parameters(), lr=0.1), grad_clip_cfg=dict(max_norm=1.0, norm_type=2))
     with pytest.raises(RuntimeError):
         step(torch.zeros(1, 3, 64, 64), [(np.zeros((0, 4), np.float32), np.zeros((0,), np.int64))])
+
+
+def test_cpu_nms_surface_evaluates_float64_input_in_double_like_the_reference():
+    """AT_DISPATCH_FLOATING_TYPES (nms_cpu.cpp:70,212,287): a float64 tensor / numpy array -- numpy's default dtype -- is
+    evaluated in double.  tests/golden/ref_nms_cpu_f64.npz holds outputs of the reference's own compiled extension on double
+    tensors (make_golden_nms_f64.py), including a case whose float32 evaluation keeps a box the double evaluation
+    suppresses."""
+    from conftest import GOLDEN
+    from lfd_amd.model.utils import nms as nms_py
+    from lfd_amd.model.utils.libs import nms_ext
+    g = np.load(os.path.join(GOLDEN, 'ref_nms_cpu_f64.npz'))
+    nc = int(g['num_cases'])
+    for ci in range(nc):
+        d = torch.from_numpy(g['dets_%d' % ci])
+        assert d.dtype == torch.float64
+        thr, method, sigma, min_score = [float(v) for v in g['params_%d' % ci]]
+        np.testing.assert_array_equal(nms_ext.nms(d, thr).numpy(), g['keep_%d' % ci])
+        soft = nms_ext.soft_nms(d, thr, int(method), sigma, min_score)
+        assert soft.dtype == torch.float64
+        np.testing.assert_array_equal(soft.numpy(), g['soft_%d' % ci])
+        groups = nms_ext.nms_match(d, thr)
+        assert [len(x) for x in groups] == g['match_sizes_%d' % ci].tolist()
+        assert [i for x in groups for i in x] == g['match_members_%d' % ci].tolist()
+        kept, inds = nms_py(g['dets_%d' % ci], thr)            # numpy float64 in -> numpy out (nms.py:36-47)
+        assert inds.tolist() == g['keep_%d' % ci].tolist() and kept.dtype == np.float64
+    d = torch.from_numpy(g['dets_%d' % (nc - 1)])
+    thr = float(g['params_%d' % (nc - 1)][0])
+    assert nms_ext.nms(d.float(), thr).tolist() == [0, 1, 2] and nms_ext.nms(d, thr).tolist() == [0, 2]
