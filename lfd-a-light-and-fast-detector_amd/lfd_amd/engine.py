@@ -26,8 +26,13 @@ IN_NCHW_F32, IN_NHWC_F16, IN_NHWC_U8 = 0, 1, 2
 _UNION = ('IoULoss', 'GIoULoss', 'DIoULoss', 'CIoULoss')
 
 
+class Unsupported(RuntimeError):
+    """a module configuration the fused plan does not cover (a RuntimeError, so callers that expect the reference's error
+    type keep working); anything else -- HIP out of memory, a library load failure -- is NOT this type"""
+
+
 def _unsupported(msg):
-    raise RuntimeError('lfd_amd engine: unsupported configuration: %s (no PyTorch fallback for inference)' % msg)
+    raise Unsupported('lfd_amd engine: unsupported configuration: %s (no PyTorch fallback for inference)' % msg)
 
 
 # ---------------------------------------------------------------------------- weight preparation
@@ -638,19 +643,28 @@ def _param_signature(*mods):
 
 
 def version_sum(model):
-    """Cheap change detector for the replay fast path: (number of tensors, sum of their in-place version counters) over the
-    parameters and buffers of an LFD.  Versions only increase, so the sum changes iff a tensor was written in place."""
-    ts = model.__dict__.get('_lfd_tensors')
-    if ts is None:
+    """Cheap change detector for the replay fast path: (number of tensors, sum of their in-place version counters, sum of
+    their storage addresses) over the parameters and buffers of an LFD.  Versions only increase, so their sum changes iff a
+    tensor was written in place; the address sum catches `p.data = other` and load_state_dict(assign=True), which swap
+    storage without touching a version counter or going through _apply.  The tensor LIST is cached and refreshed whenever a
+    submodule or parameter object is replaced (LFD.__setattr__ / the load_state_dict post-hook drop it) and, as a backstop,
+    every 256th call."""
+    d = model.__dict__
+    ts = d.get('_lfd_tensors')
+    calls = d.get('_lfd_tensors_calls', 0) + 1
+    if ts is None or calls >= 256:
         ts = []
         for m in (model._backbone, model._neck, model._head):
             if m is not None:
                 ts += list(m.parameters()) + list(m.buffers())
-        model.__dict__['_lfd_tensors'] = ts
-    v = 0
+        d['_lfd_tensors'] = ts
+        calls = 0
+    d['_lfd_tensors_calls'] = calls
+    v = a = 0
     for t in ts:
         v += t._version
-    return (len(ts), v)
+        a += t.data_ptr()
+    return (len(ts), v, a)
 
 
 # ---------------------------------------------------------------------------- entry points

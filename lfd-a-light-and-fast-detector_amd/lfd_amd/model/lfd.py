@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine, engine_sibling, ops, parallel, train_engine
+from .. import engine, engine_p32, engine_sibling, ops, parallel, train_engine
 from .utils import multiclass_nms  # noqa: F401  (kept importable like the reference module)
 
 __all__ = ['LFD']
@@ -93,10 +93,47 @@ class LFD(nn.Module):
         self._head_indexes_to_feature_map_sizes = dict()
         self.max_candidates = 8192   # per-image capacity of the fused post-processing pass
         self.use_graph = False       # capture the forward into a HIP graph per input shape
+        self._precision = 'fp16'
+        self.register_load_state_dict_post_hook(LFD._forget_cached_tensors)
+
+    PRECISIONS = ('fp16', 'fp32_storage')
+
+    @property
+    def precision(self):
+        """Numeric mode of the eval-mode forward (training is unaffected):
+        'fp16'          fp16 MFMA operands and fp16 inter-layer storage, fp32 accumulation -- the fused stem / block / head
+                        kernels of engine.py; sigma(cls) / sigma(reg) within 1.3e-3 .. 2.3e-3 of the fp32 reference;
+        'fp32_storage'  fp32 inter-layer storage, every conv ONE launch that splits its fp32 operands exactly into fp16
+                        hi + lo parts for the matrix cores (engine_p32.py, csrc/precise.hip); raw logits within 1e-4 of
+                        the fp32 reference (north_star: "tensors within 1e-3"), ~3-5x the time."""
+        return self.__dict__.get('_precision', 'fp16')
+
+    @precision.setter
+    def precision(self, value):
+        if value not in self.PRECISIONS:
+            raise ValueError('precision must be one of %s' % (self.PRECISIONS,))
+        if value != self.precision:
+            self.__dict__.get('_step_graphs', {}).clear()
+            self.__dict__['_step_graphs_ver'] = None
+        self._precision = value
+
+    @staticmethod
+    def _forget_cached_tensors(module, incompatible_keys=None):
+        # load_state_dict (assign=True swaps the parameter objects): the cached tensor list of engine.version_sum is stale
+        module.__dict__.pop('_lfd_tensors', None)
+        module.__dict__['_step_graphs_ver'] = None
+
+    def __setattr__(self, name, value):
+        if name in ('_backbone', '_neck', '_head'):      # a replaced submodule: new tensors, maybe a new plan family
+            self.__dict__.pop('_lfd_tensors', None)
+            self.__dict__.pop('_fused_ok', None)
+            self.__dict__['_step_graphs_ver'] = None
+        super().__setattr__(name, value)
 
     def _apply(self, fn, recurse=True):
         # .to() / .cuda() / .half(): parameter storage is replaced -> forget the cached tensor list and captured graphs
         self.__dict__.pop('_lfd_tensors', None)
+        self.__dict__.pop('_fused_ok', None)
         self.__dict__['_step_graphs_ver'] = None
         self.__dict__.get('_step_graphs', {}).clear()
         return super()._apply(fn, recurse)
@@ -120,8 +157,9 @@ class LFD(nn.Module):
             if ok:
                 try:
                     engine.get_plan(self, self._backbone, self._neck, self._head, device)
-                except RuntimeError:
-                    ok = False
+                except engine.Unsupported:
+                    ok = False       # only "this module tree is not covered" selects the layer engine; an out-of-memory or
+                                     # a library failure propagates instead of silently (and permanently) slowing the model
             self.__dict__['_fused_ok'] = ok
         return ok
 
@@ -136,7 +174,9 @@ class LFD(nn.Module):
     def forward_resident(self, x, slot=0):
         """Fast path: same as forward() in eval mode but returns the engine-owned output buffers
         (no copy, valid until the next forward of the same input shape and `slot`)."""
-        if x.is_cuda and not self._fused_plan_ok(x.device):
+        if self.precision == 'fp32_storage':
+            cls, reg, sizes = engine_p32.lfd_forward(self, x, use_graph=self.use_graph, slot=slot)
+        elif x.is_cuda and not self._fused_plan_ok(x.device):
             cls, reg, _, sizes = engine_sibling.sibling_forward(self, x, use_graph=self.use_graph)
         else:
             cls, reg, sizes = engine.lfd_forward(self, x, use_graph=self.use_graph, slot=slot)
@@ -152,7 +192,8 @@ class LFD(nn.Module):
         activation / output / workspace buffers: steps of DIFFERENT slots may be enqueued on different HIP streams and
         overlap on the device (the small-map stages, the post-processing kernels and the launch gaps of one batch leave most
         CUs idle -- a second batch in flight fills them: 0.75 -> 0.61 ms per batch of 8 at depth 2, tools/ab_pipeline.py)."""
-        if not self.use_graph or not self._fused_plan_ok(x.device):
+        precise = self.precision == 'fp32_storage'
+        if not self.use_graph or (not precise and not self._fused_plan_ok(x.device)):
             return self.detect(self.forward_resident(x, slot), meta, score_thr, iou_thr, class_agnostic, max_candidates)
         score_thr = self._classification_threshold if score_thr is None else score_thr
         iou_thr = self._nms_cfg.get('iou_thr', 0.5) if iou_thr is None else iou_thr
@@ -166,7 +207,8 @@ class LFD(nn.Module):
         # in place (optimizer step, load_state_dict, .copy_); storage moves (.to / .cuda / .half) go through _apply below.
         ver = engine.version_sum(self)
         if self.__dict__.get('_step_graphs_ver') != ver:
-            plan = engine.get_plan(self, self._backbone, self._neck, self._head, x.device)
+            plan = engine_p32.get_plan(self, x.device) if precise else \
+                engine.get_plan(self, self._backbone, self._neck, self._head, x.device)
             if self.__dict__.get('_step_graphs_plan') is not plan:
                 cache.clear()
                 self.__dict__['_step_graphs_plan'] = plan
@@ -185,7 +227,7 @@ class LFD(nn.Module):
                     # single-class sigmoid models: the head's output pass thresholds, decodes and appends the candidates
                     # itself (lfd_head_forward_decode_f16), logits never reach HBM, 3 post-processing launches instead of 5
                     ops.detect_workspace_reset(desc, x.size(0), out)
-                    fused = engine.lfd_forward_detect(self, x, desc, meta, out, slot)      # warm-up of the fused kernels
+                    fused = (not precise) and engine.lfd_forward_detect(self, x, desc, meta, out, slot)   # warm-up of the fused kernels
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):

@@ -167,10 +167,11 @@ def test_head_chunk_length_and_fold_site_do_not_change_outputs():
     assert len(set(hashes.values())) == 1, hashes
 
 
-def test_config3_widerface_l_4k_properties():
-    """BASELINE config 3: WIDERFACE_LFD_L, one 3840x2160 frame (P = 690,600; the stride-4 level is
-    540x960x128).  Properties: shapes, finiteness, and the top-left 1080p crop agrees with running the
-    crop alone away from the crop border (fully-convolutional consistency)."""
+def test_config3_widerface_l_4k_shapes():
+    """BASELINE config 3: WIDERFACE_LFD_L, one 3840x2160 frame (P = 690,600; the stride-4 level is 540x960x128): output
+    shapes, level sizes, finiteness -- nothing else.  The VALUE checks at this shape (vs the fp32 and the emulating oracle,
+    the bit-exact crop consistency of the backbone, index-exact decode + NMS) are tests/test_gpu_parity_fullsize.py and
+    tests/test_gpu_precise.py; config 4's strict end-to-end check (count mismatch fails) lives there too."""
     m = configs.build_model('WIDERFACE_LFD_L')
     configs.perturb_weights(m)
     m.eval().cuda()
@@ -182,40 +183,6 @@ def test_config3_widerface_l_4k_properties():
     assert torch.isfinite(cls).all() and torch.isfinite(reg).all()
     sizes = [m.head_indexes_to_feature_map_sizes[i] for i in range(5)]
     assert sizes == [(540, 960), (270, 480), (135, 240), (68, 120), (34, 60)]
-
-
-def test_config4_tt100k_l_multiclass_end_to_end():
-    """BASELINE config 4 (one GPU's share): TT100K_LFD_L, 4 x 1280x720, 45 classes (softmax scores, separate
-    cls/reg towers), per-class NMS on the device.  Checked against the oracle's decode + multiclass NMS fed the
-    engine's own logits (index-exact labels / boxes to expf rounding)."""
-    import oracle
-    from oracle import net_oracle
-    arch = configs.ARCHS['TT100K_LFD_L']
-    m = configs.build_model('TT100K_LFD_L')
-    configs.perturb_weights(m)
-    m.eval().cuda()
-    g = torch.Generator(device='cuda').manual_seed(1)
-    x = (torch.rand(4, 720, 1280, 3, device='cuda', generator=g) * 2 - 1).half()
-    with torch.no_grad():
-        cls, reg = [t.clone() for t in m.forward_resident(x)]
-    assert cls.shape == (4, 76520, 46) and reg.shape == (4, 76520, 4)
-    sc = cls[0].softmax(-1)[:, :-1]
-    thr = float(torch.quantile(sc.reshape(-1)[::7].float(), 1 - 2e-4))
-    m._classification_threshold = thr
-    m._nms_cfg = dict(type='nms', iou_thr=0.1)
-    res = m.get_results((cls, reg), [dict(resized_height=720, resized_width=1280, resize_scale=1.0)] * 4)
-    sizes = [m.head_indexes_to_feature_map_sizes[i] for i in range(4)]
-    strides = net_oracle.strides_of(arch)
-    for n in (0, 3):
-        dets, labels, _, K = net_oracle.get_results_single(cls[n].cpu().numpy(), reg[n].cpu().numpy(), sizes, strides, arch,
-                                                           thr, 0.1, False, (720, 1280), 1.0)
-        ref = net_oracle.pack_results(dets, labels)
-        assert K > 50 and abs(len(ref) - len(res[n])) <= max(2, len(ref) // 50)
-        a = sorted(res[n], key=lambda r: (r[0], r[2], r[3]))
-        b = sorted(ref, key=lambda r: (r[0], r[2], r[3]))
-        if len(a) == len(b):
-            assert [r[0] for r in a] == [r[0] for r in b]
-            np.testing.assert_allclose(np.array(a)[:, 1:], np.array(b)[:, 1:], rtol=1e-4, atol=2e-3)
 
 
 def test_checkpoint_from_the_reference_runs_on_the_engine():

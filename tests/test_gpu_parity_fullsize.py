@@ -99,7 +99,7 @@ def test_g2_fp16_pipeline_vs_fp32_and_emulating_oracles_at_the_baseline_shape(ke
     """fp16 storage / fp32 accumulate at the config's own shape.  Gates (stated, see DESIGN 4: fp16 rounding of weights
     ALONE moves sigma by ~1e-3 on these networks, of activations alone by ~1.5e-3):
       vs fp32 oracle:      sigma(cls) | softmax, sigma(reg) <= 2.5e-3;  raw logits <= 2e-2 (reported)
-      vs emulating oracle: raw logits mean <= 1.5e-3, 99.99th percentile <= 7e-3, max <= 1.5e-2  (same rounding points; the
+      vs emulating oracle: raw logits mean <= 1.5e-3, 99.99th percentile <= 7e-3, max <= 1.2e-2  (same rounding points; the
                            remainder is 1-ulp flips seeded by accumulation order, random-walking through ~25 layers.  The
                            MAX over the ~2e5 logits of an image is the extreme of that walk: 0.8e-2 .. 1.05e-2 across kernel
                            revisions that only reorder fp32 sums -- the percentile and the mean do not move)"""
@@ -127,7 +127,11 @@ def test_g2_fp16_pipeline_vs_fp32_and_emulating_oracles_at_the_baseline_shape(ke
                 raw_vs_emulation_q9999=emu_q)
         assert raw < 2e-2
         assert sg_c < 2.5e-3 and sg_r < 2.5e-3
-        assert emu_max < 1.5e-2 and emu_q < 7e-3 and emu_mean < 1.5e-3
+        # FROZEN at the round-2 measured envelope (no further widening): the gates proper are the 99.99th percentile
+        # and the mean; the max over ~2e5 logits is bounded at the measured extreme (1.05e-2) + 15 %, no longer at 1.5e-2.
+        # The mode that meets north_star's 1e-3 is precision='fp32_storage' (tests/test_gpu_precise.py).
+        assert emu_q < 7e-3 and emu_mean < 1.5e-3
+        assert emu_max < 1.2e-2
 
 
 # ------------------------------------------------------------------------------------------------ (c) per launch
@@ -280,19 +284,28 @@ def test_g3_decode_nms_on_oracle_logits_index_exact_at_the_baseline_grid(key, K)
     np.testing.assert_array_equal(out.cand[0, :k].cpu().numpy(), cand)
     np.testing.assert_array_equal(out.labels[0, :k].cpu().numpy(), labels)
     np.testing.assert_array_equal(out.dets[0, :k].cpu().numpy(), dets)
-    # (3)
-    odets, olabels, _, Ko = net_oracle.get_results_single(cls.numpy(), reg.numpy(), [tuple(s) for s in sizes], strides, arch, thr, 0.4,
-                                                          agn, (h, w), 1.0)
-    assert abs(Ko - Kc) <= 2 and abs(len(olabels) - k) <= 2, (Ko, Kc, len(olabels), k)    # expf vs torch.sigmoid at the threshold
+    # (3) the ALL-ORACLE pipeline (torch.sigmoid scores, torch decode, C NMS) on the same logits, compared by IDENTITY: the kept
+    # set as (flat point index, class) pairs.  Only a candidate whose score sits within an ulp of the threshold (expf vs
+    # torch.sigmoid) can differ: <= 2 such pairs are tolerated and counted; every common pair must carry the same box.
+    odets, olabels, ocand, Ko = net_oracle.get_results_single(cls.numpy(), reg.numpy(), [tuple(s) for s in sizes], strides, arch, thr,
+                                                              0.4, agn, (h, w), 1.0)
+    osc = net_oracle.scores_from_logits(cls.numpy(), arch['classification_loss_type'] == 'CrossEntropyLoss')
+    oflat = np.flatnonzero(osc.reshape(-1) > np.float32(thr))
+    assert len(oflat) == Ko
+    ncls = osc.shape[1]
+    okeys = {(int(oflat[c] // ncls), int(l)): row for c, l, row in zip(ocand, olabels, odets)}
     a = out.dets[0, :k].cpu().numpy()
     la = out.labels[0, :k].cpu().numpy()
+    pa = out.point[0, :k].cpu().numpy()
+    dkeys = {(int(p_), int(l)): row for p_, l, row in zip(pa, la, a)}
+    assert len(dkeys) == k and len(okeys) == len(olabels)
+    only = set(dkeys) ^ set(okeys)
+    assert len(only) <= 2, sorted(only)[:8]
     matched = 0
-    for row, lb in zip(odets, olabels):
-        d = np.abs(a[:, :4] - row[:4]).max(1) + 1e3 * (la != lb)
-        j = int(d.argmin())
-        if d[j] < 5e-4 and abs(a[j, 4] - row[4]) < 1e-6 + 2e-5 * row[4]:
-            matched += 1
-    assert matched >= len(olabels) - 2, (matched, len(olabels))
+    for key_ in set(dkeys) & set(okeys):
+        r1, r2 = dkeys[key_], okeys[key_]
+        assert np.abs(r1[:4] - r2[:4]).max() < 5e-4 and abs(r1[4] - r2[4]) < 1e-6 + 2e-5 * r2[4], (key_, r1, r2)
+        matched += 1
     _record('G3 %s K=%d' % (key, K), candidates=int(Kc), kept=k, all_oracle_kept=len(olabels), matched=matched, points=int(P))
 
 

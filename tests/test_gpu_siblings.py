@@ -171,12 +171,19 @@ def test_sibling_forward_on_device_vs_reference(name):
         ref = g[key]
         assert tuple(o.shape) == ref.shape and o.dtype == torch.float32
         got = o.cpu().numpy()
+        # the LFD gates of tests/test_gpu_parity_fullsize.py (G2, fp16 inter-layer storage vs the reference's fp32 tensors):
+        # raw logits <= 2e-2 max, <= 2e-3 mean; what decode consumes -- sigmoid(cls / centerness) -- <= 2.5e-3.  FCOSHead's
+        # reg output is exp(scale * conv) (fcos_head.py:145-146): the logit error is the RELATIVE error of the distance.
         if key == 'reg' and name.startswith('FCOS'):
-            rel = np.abs(got - ref) / np.abs(ref)
-            assert rel.max() <= 2.5e-2 and rel.mean() <= 4e-3, (rel.max(), rel.mean())
+            err = np.abs(got - ref) / np.abs(ref)
         else:
             err = np.abs(got - ref)
-            assert err.max() <= 2.5e-2 and err.mean() <= 4e-3, (key, err.max(), err.mean())
+        print('sibling %s %s: max %.2e mean %.2e' % (name, key, err.max(), err.mean()))
+        assert err.max() <= 2e-2 and err.mean() <= 2e-3, (key, err.max(), err.mean())
+        if key in ('cls', 'ctr'):
+            sg = np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref.astype(np.float64))))
+            print('sibling %s sigmoid(%s): max %.2e' % (name, key, sg.max()))
+            assert sg.max() <= 2.5e-3, (key, sg.max())
 
 
 @pytest.mark.parametrize('name', NAMES)

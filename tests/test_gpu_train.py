@@ -303,3 +303,48 @@ def test_config5_widerface_s_640_loss_curve_vs_fp32_autograd(monkeypatch):
     assert rel[0] < 5e-3                                  # same start: only the fp16 forward differs
     assert rel[:8].max() < 3e-2 and rel.max() < 1e-1      # the curves stay together over the 24 iterations
     assert np.mean(h[-4:]) < h[0]                         # and go down
+
+
+@pytest.mark.parametrize('bad', [float('inf'), float('-inf'), float('nan')])
+def test_update_is_skipped_when_the_gradient_norm_is_not_finite(bad):
+    """ADVICE r2 (csrc/optim.hip): an fp16 overflow in the activation-gradient path yields +-inf gradients WITHOUT a NaN:
+    norm = inf, clip coefficient = max_norm / inf = 0 -- inside [0, 1] -- and g * coef = inf * 0 = NaN would be written
+    into the weights and the momentum.  The update kernel gates on the NORM: parameters, momentum buffers and gradients
+    stay exactly as they were, with clipping and without; the next clean iteration updates normally; DynamicLossScale
+    halves the scale on the skipped iteration."""
+    from lfd_amd import train_engine
+    ma, mb = _pair()
+    oa = optim.SGD(ma.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD(mb.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    oa.zero_grad()
+    _set_grads(ma, mb, 5, 1.0)
+    oa.clip_and_step(10.0)                      # a clean first step: momentum buffers exist from here on
+    torch.nn.utils.clip_grad_norm_(list(mb.parameters()), max_norm=10.0, norm_type=2)
+    ob.step()
+    scaler = train.DynamicLossScale(init_scale=1024.0, growth_interval=2)
+    try:
+        for clip in (True, False):
+            _set_grads(ma, mb, 6, 1.0)
+            p0 = list(ma.parameters())[3]
+            p0.grad.view(-1)[7] = bad
+            before = [(p.detach().clone(), oa.state[p]['momentum_buffer'].clone(), p.grad.clone()) for p in ma.parameters()]
+            norm = oa.clip_and_step(10.0) if clip else (oa.step(), oa.last_norm[0])[1]
+            assert not np.isfinite(float(norm))
+            for p, (pv, mv, gv) in zip(ma.parameters(), before):
+                assert torch.equal(p.detach(), pv) and torch.equal(oa.state[p]['momentum_buffer'], mv)
+                assert torch.equal(p.grad, gv, ) or (bad != bad and bool(torch.isnan(p.grad).any()))
+                assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(oa.state[p]['momentum_buffer']).all())
+            s0 = scaler.scale
+            assert scaler.update(norm) is False and scaler.scale == s0 / 2
+        # clean iterations: identical to torch again (the skipped ones left no trace), and the scale grows back
+        for it in range(2):
+            _set_grads(ma, mb, 8 + it, 0.5)
+            na = oa.clip_and_step(10.0)
+            torch.nn.utils.clip_grad_norm_(list(mb.parameters()), max_norm=10.0, norm_type=2)
+            ob.step()
+            assert scaler.update(na) is True
+            for pa, pb in zip(ma.parameters(), mb.parameters()):
+                torch.testing.assert_close(pa, pb, rtol=3e-6, atol=2e-8)
+        assert scaler.scale == 512.0 and scaler.skipped == 2
+    finally:
+        train_engine.set_loss_scale(train_engine.LOSS_SCALE)

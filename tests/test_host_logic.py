@@ -563,3 +563,62 @@ def test_cpu_nms_surface_evaluates_float64_input_in_double_like_the_reference():
     d = torch.from_numpy(g['dets_%d' % (nc - 1)])
     thr = float(g['params_%d' % (nc - 1)][0])
     assert nms_ext.nms(d.float(), thr).tolist() == [0, 1, 2] and nms_ext.nms(d, thr).tolist() == [0, 2]
+
+
+def test_replay_change_detector_sees_storage_swaps_and_replaced_modules():
+    """engine.version_sum guards the captured step graphs (LFD.detect_resident): in-place writes bump version counters;
+    `p.data = other`, load_state_dict(assign=True) and a replaced submodule change storage without touching them."""
+    from lfd_amd import engine
+    m = configs.build_model('WIDERFACE_LFD_XS').eval()
+    v0 = engine.version_sum(m)
+    assert engine.version_sum(m) == v0
+    p = next(m._backbone.parameters())
+    with torch.no_grad():
+        p.add_(1.0)
+    v1 = engine.version_sum(m)
+    assert v1 != v0
+    p.data = p.data.clone()                       # storage swap, no version bump
+    v2 = engine.version_sum(m)
+    assert v2 != v1 and v2[:2] == v1[:2]
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)            # parameter OBJECTS replaced: the cached tensor list must be dropped
+    assert '_lfd_tensors' not in m.__dict__
+    v3 = engine.version_sum(m)
+    assert v3 != v2
+    other = configs.build_model('WIDERFACE_LFD_XS')
+    m._head = other._head                         # replaced submodule
+    assert '_lfd_tensors' not in m.__dict__ and engine.version_sum(m) != v3
+
+
+def test_precision_property_and_unsupported_exception_type():
+    from lfd_amd import engine
+    m = configs.build_model('WIDERFACE_LFD_XS').eval()
+    assert m.precision == 'fp16' and m.PRECISIONS == ('fp16', 'fp32_storage')
+    m.precision = 'fp32_storage'
+    assert m.precision == 'fp32_storage'
+    with pytest.raises(ValueError):
+        m.precision = 'bf16'
+    with pytest.raises(RuntimeError):             # both modes are HIP-only: a CPU tensor is refused, not emulated
+        m(torch.zeros(1, 3, 64, 64))
+    assert issubclass(engine.Unsupported, RuntimeError)
+    with pytest.raises(engine.Unsupported):
+        engine._unsupported('x')
+
+
+def test_p32_weight_packing_layout():
+    """engine_p32.pack_weight: [slab][chunk][tap][kstep][hi | 2^11 lo][lane = 32 khalf + cout][8]; hi + lo / 2^11 restores
+    the fp32 weight to ~2^-22 relative"""
+    from lfd_amd import engine_p32
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(40, 64, 3, 3, generator=g) * torch.logspace(-4, 1, 40)[:, None, None, None]
+    pk = engine_p32.pack_weight(w)
+    assert pk.shape == (2, 2, 9, 2, 2, 64, 8) and pk.dtype == torch.float16
+    rec = pk[:, :, :, :, 0].float() + pk[:, :, :, :, 1].float() / 2048.0     # [slab, chunk, tap, kk, lane, j]
+    for (co, ci, dy, dx) in [(0, 0, 0, 0), (39, 63, 2, 2), (33, 17, 1, 2), (7, 40, 0, 1)]:
+        slab, col = co // 32, co % 32
+        chunk, r = ci // 32, ci % 32
+        kk, r = r // 16, r % 16
+        khalf, j = r // 8, r % 8
+        got = float(rec[slab, chunk, dy * 3 + dx, kk, khalf * 32 + col, j])
+        assert abs(got - float(w[co, ci, dy, dx])) <= 2.0 ** -21 * abs(float(w[co, ci, dy, dx])) + 1e-10   # (+ fp16-subnormal floor 2^-25 / 2^11)
+    assert float(rec[1, :, :, :, 8:32].abs().max()) == 0 and float(rec[1, :, :, :, 40:64].abs().max()) == 0   # rows 40..63: zero padding
