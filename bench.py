@@ -7,7 +7,9 @@ synthetic 1920x1080 frames, batch 8 per GPU, fp16 NHWC input already resident in
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One process per GPU; images shard across ranks with NO data-path collective (weak scaling:
-8 frames per GPU per step); rank 0 prints ONE JSON line.  `roofline` = the dominant kernel class
+8 frames per GPU per step); rank 0 prints ONE JSON line.  A plain `python bench.py --gpus N` (no launcher in the
+environment) re-executes itself under torch.distributed.run with N ranks; `ranks_seen` in the line is an RCCL all-reduce
+of ones, i.e. the number of ranks that really took part.  `roofline` = the dominant kernel class
 timed live with HIP events on the launch stream; `cpu_baseline` = the oracle's port of the
 reference CPU path (PyTorch fp32 eager NCHW forward + decode + greedy NMS) on this host's cores.
 """
@@ -28,9 +30,13 @@ import torch.distributed as dist  # noqa: E402
 
 MODEL = 'WIDERFACE_LFD_S'
 BATCH, H, W = 8, 1080, 1920
+NBUF = 4                  # distinct resident frame buffers rotated through the steps: 4 x 99.5 MB > the 256 MiB Infinity Cache,
+                          # so the stem's reads are cold HBM reads (one buffer replayed every step would sit in the cache)
 TARGET_K = 256            # candidates per image (SURVEY 8d "sparse-realistic" load), IoU 0.4
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+PMC_SOURCE = ('profiles/pmc_traffic.json: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, '
+              'tools/collect_profiles.sh) committed with the kernels -- a constant of the code, not re-measured on this box')
 
 
 def conv_flops(n, oh, ow, cin, cout, ks):
@@ -290,6 +296,104 @@ def siblings_bench(dev, reps=20, n=8, h=720, w=1280):
     return out
 
 
+def _event_median_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    v = []
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(reps):
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        v.append(s.elapsed_time(e))
+    return float(np.median(v))
+
+
+def other_configs_bench(dev):
+    """BASELINE.json configs[2] and configs[3] on ONE GPU, extra key `configs` (the headline stays configs[1]):
+      config3  WIDERFACE_LFD_L, one 3840x2160 frame                     (large-activation path)
+      config4  TT100K_LFD_L, 4 x 1280x720 = one GPU's share of bs 32 / 8 GPUs, 45 classes, softmax scores, per-class NMS
+    Each: the whole step (forward + decode + NMS) as one HIP graph, HIP-event median; network-only forward; the dominant
+    kernel class with its roofline fraction (same live per-launch timing as the headline's `kernels`)."""
+    from lfd_amd import configs, engine
+    out = {}
+    for key, name, (n, h, w), reps, k_cand in (('config3', 'WIDERFACE_LFD_L', (1, 2160, 3840), 20, 1024),
+                                               ('config4', 'TT100K_LFD_L', (4, 720, 1280), 30, 256)):
+        m = configs.build_model(name)
+        configs.perturb_weights(m)
+        m.eval().to(dev)
+        m.max_candidates = 8192
+        arch = configs.ARCHS[name]
+        ce = arch['classification_loss_type'] == 'CrossEntropyLoss'
+        gen = torch.Generator(device=dev).manual_seed(3)
+        x = (torch.rand(n, h, w, 3, device=dev, generator=gen) * 2 - 1).half()
+        meta = torch.tensor([[float(w), float(h), 1.0]] * n, dtype=torch.float32, device=dev)
+        cls, reg = m.forward_resident(x)
+        sc = (cls[0].float().softmax(-1)[:, :-1] if ce else cls[0].float().sigmoid()).max(-1).values
+        m._classification_threshold = float(torch.quantile(sc[:4_000_000], 1.0 - k_cand / sc.numel()))
+        m._nms_cfg = dict(type='nms', iou_thr=0.4 if not ce else 0.1)
+        fwd_ms = _event_median_ms(lambda: m.forward_resident(x), 5, warm=1)
+        m.use_graph = True
+        step_ms = _event_median_ms(lambda: m.detect_resident(x, meta), reps)
+        counts = m.detect_resident(x, meta).counts.cpu().numpy()
+        fmt, n_, h_, w_ = engine._input_format(x)
+        plan = engine.get_plan(m, m._backbone, m._neck, m._head, dev)
+        br = kernel_breakdown(m, plan, plan.state_for(n_, h_, w_), x, fmt, reps=5)
+        tot = sum(c['time_us'] for c in br.values())
+        nm, c = max(br.items(), key=lambda kv: kv[1]['time_us'])
+        tf, gb = c['flops'] / c['time_us'] / 1e6, c['bytes'] / c['time_us'] / 1e3
+        gflop = sum(c_['flops'] for c_ in br.values()) / 1e9
+        out[key] = dict(workload='%s %d x %dx%d fp16 NHWC resident, forward + decode + NMS (one HIP graph)' % (name, n, w, h),
+                        ms_per_step=round(step_ms, 4), images_per_s=round(n / step_ms * 1e3, 1),
+                        forward_eager_ms=round(fwd_ms, 4), kernel_sum_us=round(tot, 1), gflop_per_step=round(gflop, 1),
+                        frac_mfma_whole_step=round(gflop / step_ms / MFMA_PEAK_TFLOPS, 4),
+                        points_per_image=int(cls.shape[1]), candidates_per_image=float(counts[:, 0].mean()),
+                        kept_per_image=float(counts[:, 1].mean()), overflow=int(counts[:, 2].max()),
+                        roofline=dict(kernel=nm, bound='mfma' if tf / MFMA_PEAK_TFLOPS >= gb / HBM_PEAK_GBS else 'hbm',
+                                      tflops=round(tf, 1), gbs=round(gb, 0), frac_mfma=round(tf / MFMA_PEAK_TFLOPS, 3),
+                                      frac_hbm=round(gb / HBM_PEAK_GBS, 3), share_of_forward=round(c['time_us'] / tot, 3),
+                                      avg_launch_us=round(c['time_us'] / c['launches'], 2)))
+        del m, x, cls, reg, plan, br
+        torch.cuda.empty_cache()
+    return out
+
+
+def precise_bench(model, x, meta, dev):
+    """The shipped fp32-storage precision mode (LFD.precision = 'fp32_storage': raw logits within 1e-4 of the fp32
+    reference, tests/test_gpu_precise.py) on the headline workload: its cost on record next to the fp16 number."""
+    out = {}
+    keep_g = model.use_graph
+    model.precision = 'fp32_storage'
+    try:
+        model.use_graph = True
+        ms = _event_median_ms(lambda: model.detect_resident(x, meta), 10, warm=2)
+        x1 = x[:1].contiguous()
+        meta1 = meta[:1].contiguous()
+        for _ in range(3):
+            model.detect_resident(x1, meta1)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            model.detect_resident(x1, meta1)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts)) * 1e3
+        out = dict(mode="LFD.precision = 'fp32_storage': fp32 NHWC inter-layer storage, one launch per conv, operands split "
+                        "exactly into fp16 hi + 2^-11 lo inside the kernel (3 MFMAs per k-step), fp32 epilogues, fp64 "
+                        "GroupNorm statistics (csrc/precise.hip)",
+                   ms_per_step_bs8=round(ms, 4), images_per_s_bs8=round(x.size(0) / ms * 1e3, 1),
+                   end_to_end_bs1_ms={'p50': round(float(ts[len(ts) // 2]), 4), 'min': round(float(ts[0]), 4)},
+                   mfma_tflops_issued=round(3 * 348.8 / ms, 1),
+                   parity='raw logits <= 1e-4, sigma <= 1e-3 vs the fp32 oracle at configs 2 / 3 / 4 (tests/test_gpu_precise.py)')
+    finally:
+        model.precision = 'fp16'
+        model.use_graph = keep_g
+    return out
+
+
 def latency_bs1(model, dev, iters=200):
     """p50 latency of ONE 1920x1080 frame (the second half of BASELINE.json's metric), frame resident in HBM, host-side
     wall clock around launch + synchronize per iteration like the reference's timing loop
@@ -338,22 +442,40 @@ def main():
     ap.add_argument('--no-latency', action='store_true')
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--no-siblings', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the extra key with BASELINE configs 3 and 4')
+    ap.add_argument('--no-precise', action='store_true', help="skip the extra key with the fp32-storage precision mode")
     ap.add_argument('--max-candidates', type=int, default=8192)
     ap.add_argument('--clock-warmup-s', type=float, default=0.3, help='untimed replays before the W warm-up steps: an idle MI355X needs '
                     'milliseconds to ramp its clocks (DESIGN 3, lesson 11)')
     ap.add_argument('--pipeline', type=int, default=2, help='batches in flight per GPU (HIP streams with their own buffers)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher in the environment: become one (one process per GPU, RCCL rendezvous on 127.0.0.1) instead of silently
+        # measuring a single rank
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl')        # RCCL on ROCm
-    if args.gpus != world and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)                   # every rank that really takes part adds itself
+        ranks_seen = int(one.item())
 
     from lfd_amd import configs, engine
     model = configs.build_model(MODEL)
@@ -363,7 +485,8 @@ def main():
     # candidate capacity per image (an image with more candidates raises its overflow flag in `counts`, checked below)
     model.max_candidates = args.max_candidates
     gen = torch.Generator(device=dev).manual_seed(rank)
-    x = (torch.rand(BATCH, H, W, 3, device=dev, generator=gen) * 2 - 1).half()      # resident NHWC fp16 frames
+    xs = (torch.rand(NBUF, BATCH, H, W, 3, device=dev, generator=gen) * 2 - 1).half()   # NBUF resident batches of NHWC fp16 frames
+    x = xs[0]
     meta = torch.tensor([[float(W), float(H), 1.0]] * BATCH, dtype=torch.float32, device=dev)
 
     with torch.no_grad():
@@ -380,30 +503,33 @@ def main():
         P = max(1, args.pipeline) if model.use_graph else 1
         streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
 
+        # Step i works on frame buffer i % NBUF (distinct frames, 398 MB in rotation: cold reads) with buffer slot
+        # (i % NBUF) % P -- a frame buffer always meets the same slot, so there is one captured graph per frame buffer.
         def step(i=0, serial=False):
-            sl = 0 if serial else i % P
-            with torch.cuda.stream(streams[sl]):
-                return model.detect_resident(x, meta, slot=sl)      # one HIP graph per step and slot unless --no-graph
+            b = i % NBUF
+            sl = b % P
+            with torch.cuda.stream(streams[0 if serial else sl]):
+                return model.detect_resident(xs[b], meta, slot=sl)      # one HIP graph per step unless --no-graph
 
         torch.cuda.synchronize()
-        dets = [None] * P
-        for sl in range(P):                 # graph capture per slot (setup, not a warm-up step)
-            dets[sl] = step(sl)
+        dets = [None] * NBUF
+        for b in range(NBUF):               # graph capture per frame buffer (setup, not a warm-up step)
+            dets[b] = step(b)
         torch.cuda.synchronize()
         t_w = time.perf_counter()
         while time.perf_counter() - t_w < args.clock_warmup_s:      # setup: bring the clocks up (not counted as warm-up steps)
-            for i in range(2 * P):
+            for i in range(NBUF):
                 step(i)
             torch.cuda.synchronize()
         for i in range(args.warmup):
-            dets[i % P] = step(i)
+            dets[i % NBUF] = step(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            dets[i % P] = step(i)
+            dets[i % NBUF] = step(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -413,15 +539,24 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        for i in range(min(NBUF, args.steps + args.warmup), NBUF):
+            dets[i] = step(i)
+        torch.cuda.synchronize()
         det = dets[0]
-        for d_ in dets[1:]:      # same frames in every slot: the overlapped steps must have produced the same detections
-            assert torch.equal(d_.counts, det.counts) and torch.equal(d_.dets[0, :int(det.counts[0, 1])], det.dets[0, :int(det.counts[0, 1])])
+        snap = [(d_.counts.clone(), d_.dets.clone()) for d_ in dets]      # what the overlapped steps produced, per frame buffer
         # the strictly serial replay (one batch in flight), same number of steps: reported next to the headline
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i, serial=True)
         torch.cuda.synchronize()
         dt_serial = time.perf_counter() - t0
+        for b in range(NBUF):     # every frame buffer alone on one stream == what it produced with two batches in flight
+            o = step(b, serial=True)
+            torch.cuda.synchronize()
+            assert torch.equal(o.counts, snap[b][0]), 'overlapped and serial steps disagree (buffer %d)' % b
+            for j in range(BATCH):
+                k_ = int(o.counts[j, 1])
+                assert torch.equal(o.dets[j, :k_], snap[b][1][j, :k_]), 'overlapped and serial steps disagree (buffer %d)' % b
         counts = det.counts.cpu().numpy()
         assert int(counts[:, 2].max()) == 0, 'candidate capacity overflow: raise --max-candidates'
         # per-step distribution with HIP events on the launch stream (SURVEY 8d protocol: >= 100 iterations, median + p95);
@@ -431,7 +566,7 @@ def main():
         with torch.cuda.stream(streams[0]):
             for e0, e1 in evs:
                 e0.record()
-                model.detect_resident(x, meta, slot=0)
+                model.detect_resident(xs[0], meta, slot=0)
                 e1.record()
         torch.cuda.synchronize()
         ev_ms = np.sort(np.array([e0.elapsed_time(e1) for e0, e1 in evs]))
@@ -441,7 +576,7 @@ def main():
             value = world * BATCH * args.steps / dt
             result = {
                 'metric': 'images/sec WIDERFACE-S 1920x1080 bs=8 end-to-end inference (forward + decode + NMS)',
-                'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+                'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps,
                 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
                 'clock_warmup_s': args.clock_warmup_s, 'pipeline_depth': P, 'ms_per_step_serial': round(dt_serial / args.steps * 1e3, 4),
                 'images_per_s_serial': round(world * BATCH * args.steps / dt_serial, 1),
@@ -453,6 +588,7 @@ def main():
                 'config': {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16 NHWC resident in HBM: '
                                        'backbone+neck+head (HIP MFMA convs) + decode + threshold + NMS, results on device',
                            'global_batch': world * BATCH, 'points_per_image': int(cls.shape[1]),
+                           'input_buffers': '%d distinct resident batches rotated (%.0f MB > 256 MiB Infinity Cache)' % (NBUF, NBUF * x.numel() * 2 / 1e6),
                            'candidates_per_image': float(counts[:, 0].mean()), 'kept_per_image': float(counts[:, 1].mean()),
                            'score_thr': thr, 'iou_thr': 0.4, 'max_candidates': int(model.max_candidates), 'parallelism': 'image-parallel x%d, no collective; %d batches in flight per GPU (HIP streams)' % (world, P),
                            'hip_graph': bool(model.use_graph),
@@ -489,21 +625,33 @@ def main():
             if dom['frac_mfma'] >= dom['frac_hbm']:
                 result['roofline'] = {'kernel': dom['kernel'], 'bound': 'mfma',
                                       'achieved': round(dom['tflops'], 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                      'frac': dom['frac_mfma'], 'traffic': pmc.get(dom['kernel'])}
+                                      'frac': dom['frac_mfma'], 'traffic': pmc.get(dom['kernel']), 'traffic_source': PMC_SOURCE}
             else:
                 result['roofline'] = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,
-                                      'unit': 'GB/s', 'frac': dom['frac_hbm'], 'traffic': pmc.get(dom['kernel'])}
+                                      'unit': 'GB/s', 'frac': dom['frac_hbm'], 'traffic': pmc.get(dom['kernel']), 'traffic_source': PMC_SOURCE}
             result['roofline']['avg_launch_us'] = round(dom['time_us_per_forward'] / dom['launches'], 2)
             if k33:
                 result['roofline_conv3x3_s1_64'] = {'bound': 'mfma', 'achieved': k33[0]['tflops'], 'peak': MFMA_PEAK_TFLOPS,
                                                     'unit': 'TFLOP/s', 'frac': k33[0]['frac_mfma'],
                                                     'avg_launch_us': round(k33[0]['time_us_per_forward'] / k33[0]['launches'], 2),
-                                                    'traffic': pmc.get(k33[0]['kernel'])}
+                                                    'traffic': pmc.get(k33[0]['kernel']), 'traffic_source': PMC_SOURCE}
             result['kernels'] = rows
             result['forward_sum_us'] = round(tot, 1)
     if rank == 0 and world == 1 and not args.no_latency:
         with torch.no_grad():
             result['latency_bs1'] = latency_bs1(model, dev)
+    if rank == 0 and world == 1 and not args.no_precise:
+        try:
+            with torch.no_grad():
+                result['precise'] = precise_bench(model, x, meta, dev)
+        except Exception as e:
+            result['precise'] = {'error': repr(e)}
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            with torch.no_grad():
+                result['configs'] = other_configs_bench(dev)
+        except Exception as e:
+            result['configs'] = {'error': repr(e)}
     if rank == 0 and world == 1 and not args.no_train:
         try:
             result['train'] = train_bench(dev)
