@@ -50,8 +50,10 @@ def _conv(x, w, b, ks, stride, relu, res=None, scale=None, out=None, pix_stride=
     if out is None:
         out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=dev)
     d = _lib.P32ConvDesc(n, h, wd, cin, cout, ks, stride, int(relu), fmt, pix_stride, img_stride)
-    check(lib().lfd_p32_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(out), ptr(wp.to(dev)), ptr(engine_p32._pad_bias(b).to(dev)),
-                                        ptr(res), ptr(scale), stream_ptr()), 'lfd_p32_conv2d_nhwc_f32')
+    wd_, bd_ = wp.to(dev), engine_p32._pad_bias(b).to(dev)     # named: a temporary would be freed (and its block reused) before the launch runs
+    check(lib().lfd_p32_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(out), ptr(wd_), ptr(bd_), ptr(res), ptr(scale), stream_ptr()),
+          'lfd_p32_conv2d_nhwc_f32')
+    torch.cuda.synchronize()
     return out
 
 
@@ -84,7 +86,8 @@ def test_p32_conv_vs_float64(cin, cout, ks, stride, h, w):
     res = torch.randn(ref.shape, generator=g)
     sc = torch.tensor([1.37])
     ref2 = _ref_conv(x, wt, b, ks, stride, False, res, sc)
-    got2 = _conv(x.cuda(), wt, b, ks, stride, False, res=res.cuda(), scale=sc.cuda())
+    xd, resd, scd = x.cuda(), res.cuda(), sc.cuda()
+    got2 = _conv(xd, wt, b, ks, stride, False, res=resd, scale=scd)
     assert float((got2.cpu().double() - ref2).abs().max()) <= 3e-6 * max(1.0, float(ref2.abs().max()))
 
 
@@ -142,10 +145,10 @@ def test_p32_groupnorm_relu_vs_float64(n, hw, relu):
     ref = F.group_norm(x.double().permute(0, 2, 1), 16, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1)
     if relu:
         ref = ref.relu()
-    xd = x.cuda()
+    xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()
     ws = torch.empty(int(lib().lfd_p32_groupnorm_workspace_bytes(n, 16)), dtype=torch.uint8, device='cuda')
-    check(lib().lfd_p32_groupnorm_relu_f32(ptr(xd), n, hw, 128, 16, ptr(gamma.cuda()), ptr(beta.cuda()), 1e-5, relu, ptr(ws),
-                                           ws.numel(), stream_ptr()), 'lfd_p32_groupnorm_relu_f32')
+    check(lib().lfd_p32_groupnorm_relu_f32(ptr(xd), n, hw, 128, 16, ptr(gd), ptr(bd), 1e-5, relu, ptr(ws), ws.numel(), stream_ptr()),
+          'lfd_p32_groupnorm_relu_f32')
     assert float((xd.cpu().double() - ref).abs().max()) <= 5e-6
 
 
@@ -220,12 +223,15 @@ def test_precise_mode_at_the_baseline_configs_own_shapes(key, name, shape, imgs)
         dets, labels, _, _ = net_oracle.get_results_single(rc[0].numpy(), rr[0].numpy(), sizes, net_oracle.strides_of(arch), arch,
                                                            thr, 0.4, False, (h, w), 1.0)
         ref = net_oracle.pack_results(dets, labels)
-        # a candidate whose score is within 1e-5 of the threshold, or an IoU within 1e-5 of 0.4, may legitimately differ
-        assert abs(len(got) - len(ref)) <= 2, (len(got), len(ref))
-        if len(got) == len(ref) and len(ref):
-            a, b = np.array(got, np.float64), np.array(ref, np.float64)
-            same = (np.abs(a[:, 2:] - b[:, 2:]).max(1) < 1e-2) & (a[:, 0] == b[:, 0]) & (np.abs(a[:, 1] - b[:, 1]) < 1e-4)
-            assert same.mean() >= 0.99, same.mean()
+        # a candidate whose score is within 1e-5 of the threshold, or an IoU within 1e-5 of 0.4, may legitimately differ; rows are
+        # matched by content (two scores closer than 1e-5 may swap places in the score-descending order)
+        assert abs(len(got) - len(ref)) <= 2 and len(ref) > 50, (len(got), len(ref))
+        a, b = np.array(got, np.float64), np.array(ref, np.float64)
+        matched = 0
+        for row in b:
+            d = np.abs(a[:, 2:] - row[2:]).max(1) + 1e3 * (a[:, 0] != row[0]) + 1e3 * (np.abs(a[:, 1] - row[1]) > 1e-4)
+            matched += int(d.min() < 1e-2)
+        assert matched >= len(b) - 2, (matched, len(b))
 
 
 def test_precise_mode_api_graph_replay_and_mode_switch():
