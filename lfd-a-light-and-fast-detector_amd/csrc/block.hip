@@ -103,6 +103,46 @@ struct TileWalk {
   }
 };
 
+// ---- input halo DMA: 12 rows x 20 pixels, pixel pitch 144 B in LDS (8 chunks of 16 B + one 16-byte gap), so that the
+// MFMA B-fragment reads are conflict-free WITHOUT a swizzle and every tap / k-step is an immediate offset from one address
+// register per pixel tile.  A DMA instruction writes lane-linear (LDS byte 16 L of its 1 KB window), so the gaps are made on
+// the SOURCE side: lane L carries chunk L % 9 of pixel L / 9 (chunk 8 = the gap: masked off together with lane 63, whose
+// 16 bytes would land in the next window).  A row is three windows of 7 + 7 + 6 pixels; rows rw, rw + 4, rw + 8 belong to
+// wave rw (0..3) of the issuing role.  Out-of-image pixels come from the zero line: a lane whose COLUMN is outside the image
+// points at the zero line with a row pitch of 0, a ROW outside the image is a wave-uniform case -- one 64-bit multiply-add
+// per DMA.
+__device__ __forceinline__ void issue_dma(const BlockArgs& a, char* smem, int rw, const TileWalk& tw, int buf) {
+  const long rowpitch = (long)a.W * 128;
+  int ol = threadIdx.x & 63;
+  asm volatile("" : "+v"(ol));          // recompute the per-lane constants per tile instead of pinning registers
+  const int lpx = (ol * 57) >> 9;       // ol / 9 for ol < 64
+  const int ck = ol - 9 * lpx;
+  const int n = tw.n;
+  const int gy0 = tw.ty * BK::TH - 2, gx0 = tw.tx * BK::TW - 2;
+  const char* img = reinterpret_cast<const char*>(a.in) + (long)n * a.H * rowpitch;
+  const char* zsrc = reinterpret_cast<const char*>(a.zeros) + (ck & 7) * 16;
+  char* lbase = smem + BK::OFF_IN + buf * BK::IN_BYTES;
+  if (ck < 8 && ol < 63) {
+#pragma unroll
+    for (int seg = 0; seg < 3; ++seg) {
+      const int col = 7 * seg + lpx;
+      const int gx = gx0 + col;
+      const bool xv = (gx >= 0) && (gx < a.W);
+      const char* cbase_p = xv ? img + (long)gx * 128 + ck * 16 : zsrc;      // row 0 of the image at this lane's column
+      const unsigned rp = xv ? (unsigned)rowpitch : 0u;
+      if (seg < 2 || col < BK::IW) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int iy = rw + 4 * i;
+          const int gy = gy0 + iy;                                           // wave-uniform
+          const char* src = (gy >= 0 && gy < a.H) ? cbase_p + (unsigned long)rp * (unsigned)gy : zsrc;
+          dma16(src, lbase + iy * BK::IN_ROWB + seg * 1008);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ producer (conv1)
 __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw, int t_first, int t_end, int t_step) {
   const int lane = threadIdx.x & 63;
@@ -139,13 +179,33 @@ __device__ __forceinline__ void producer(const BlockArgs& a, char* smem, int pw,
   int buf = 0;
   TileWalk cur;
   cur.init(a, t_first, t_step);
+#ifndef BK_DMA_CONS
+  TileWalk nxt = cur;
+  nxt.advance();
+#endif
   int dbg_step = 0; (void)dbg_step;
+#ifndef BK_DMA_CONS
+  for (;; t += t_step, buf ^= 1, ++dbg_step, cur = nxt, nxt.advance()) {
+#else
   for (;; t += t_step, buf ^= 1, ++dbg_step, cur.advance()) {
+#endif
     const bool active = t < t_end;
     BT(0, 0);
-    block_barrier();       // in[buf] landed (the consumers issue and await the DMA); they are done with mid[buf] (tile t - 2 t_step)
+#ifndef BK_DMA_CONS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t's input (issued a step ago) has landed
+#endif
+    block_barrier();       // in[buf] landed (every issuing wave awaited its DMA); the consumers are done with mid[buf] (tile t - 2 t_step)
     BT(0, 2);
     if (!active) break;    // (the consumers run one more step and meet nobody: the workgroup's barrier count stays equal, see k_block)
+#ifndef BK_DMA_CONS
+    // The PRODUCERS feed themselves (round 3): in[buf ^ 1] is free from this barrier on (they read it in the previous step), the
+    // tile has a whole step to land, and the consumer wave of this SIMD starts its 72 MFMAs right away while this wave is busy
+    // with addresses -- phase stamps of round 2's arrangement showed the consumer chain (DMA issue 2300 + MFMAs 4550 + epilogue
+    // 1550 cycles) as the critical path of a 9300-cycle step with the producers idle for the last 3600 of it.  Measured:
+    // 8300 cycles per step, but the chip gives most of it back as clock (it runs k_block64 at its 1.4 kW power cap, 2.1 GHz:
+    // profiles/r03_power_trace.json): -1.2 % at 8 x 135 x 240, -3.8 % at 32 x 135 x 240, +0.8 % at 8 x 68 x 120.
+    if (t + t_step < t_end) issue_dma(a, smem, pw, nxt, buf ^ 1);
+#endif
     BT(0, 3);
 
     const int ty0 = cur.ty, tx0 = cur.tx;
@@ -233,168 +293,167 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
   char* stg = smem + BK::OFF_STG + cw * BK::STG_WAVE;
   const long rowpitch = (long)a.W * 128;
 
-  // ---- input halo DMA: 12 rows x 20 pixels, pixel pitch 144 B in LDS (8 chunks of 16 B + one 16-byte gap), so that the
-  // MFMA B-fragment reads are conflict-free WITHOUT a swizzle and every tap / k-step is an immediate offset from one address
-  // register per pixel tile.  A DMA instruction writes lane-linear (LDS byte 16 L of its 1 KB window), so the gaps are made on
-  // the SOURCE side: lane L carries chunk L % 9 of pixel L / 9 (chunk 8 = the gap: masked off together with lane 63, whose
-  // 16 bytes would land in the next window).  A row is three windows of 7 + 7 + 6 pixels; rows cw, cw + 4, cw + 8 belong to
-  // consumer wave cw.  Out-of-image pixels come from the zero line: a lane whose COLUMN is outside the image points at the
-  // zero line with a row pitch of 0, a ROW outside the image is a wave-uniform case -- one 64-bit multiply-add per DMA.
-  auto issue_dma = [&](const TileWalk& tw, int buf) {
-    int ol = lane;
-    asm volatile("" : "+v"(ol));          // recompute the per-lane constants per tile instead of pinning registers
-    const int lpx = (ol * 57) >> 9;       // ol / 9 for ol < 64
-    const int ck = ol - 9 * lpx;
-    const int n = tw.n;
-    const int gy0 = tw.ty * BK::TH - 2, gx0 = tw.tx * BK::TW - 2;
-    const char* img = reinterpret_cast<const char*>(a.in) + (long)n * a.H * rowpitch;
-    const char* zsrc = reinterpret_cast<const char*>(a.zeros) + (ck & 7) * 16;
-    char* lbase = smem + BK::OFF_IN + buf * BK::IN_BYTES;
-    if (ck < 8 && ol < 63) {
+  // ---- the two halves of a consumer step.  contract(): conv2 of one tile from mid[] into the accumulators (+ request of the
+  // identity values); epilogue(): + identity -> ReLU -> fp16 -> stores.  Default order: contract, then epilogue of the SAME
+  // tile.  -DBK_EPI_EARLY runs the epilogue at the START of the next step instead, so that both non-MFMA phases of this wave
+  // fall into the producer's MFMA window -- measured round 3 (phase stamps, tools/probe_block.py): the epilogue takes 5100
+  // instead of 1550 cycles beside a contracting partner (the older wave wins every issue arbitration and the LDS round trips
+  // queue behind its B-fragment reads), the two waves' MFMA phases no longer overlap, and a lone wave only reaches 45-56
+  // cycles per MFMA: 47.0 vs 45.3 us at 8 x 135 x 240.  A negative result, kept for A/B.
+  f32x16 acc[2];
+  half4 resv[2][4];
+  auto contract = [&](const TileWalk& tw, const char* mid) {
+    const int n = tw.n, ty0 = tw.ty, tx0 = tw.tx;
+    {
+      const float* bp = sbias + ct * 32 + 4 * h;
 #pragma unroll
-      for (int seg = 0; seg < 3; ++seg) {
-        const int col = 7 * seg + lpx;
-        const int gx = gx0 + col;
-        const bool xv = (gx >= 0) && (gx < a.W);
-        const char* cbase_p = xv ? img + (long)gx * 128 + ck * 16 : zsrc;      // row 0 of the image at this lane's column
-        const unsigned rp = xv ? (unsigned)rowpitch : 0u;
-        if (seg < 2 || col < BK::IW) {
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int iy = cw + 4 * i;
-            const int gy = gy0 + iy;                                           // wave-uniform
-            const char* src = (gy >= 0 && gy < a.H) ? cbase_p + (unsigned long)rp * (unsigned)gy : zsrc;
-            dma16(src, lbase + iy * BK::IN_ROWB + seg * 1008);
-          }
+        for (int pt = 0; pt < 2; ++pt) {
+          acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y; acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
         }
+      }
+    }
+    auto xfrag = [&](int k, int pt) {
+      const int r = k / 12, s = (k / 4) % 3, q = k % 4;
+      return *reinterpret_cast<const half8*>(mid + cbase + (pt * 2 * BK::MID_ROWB + r * BK::MID_ROWB + s * BK::MID_PIXB + q * 32));
+    };
+    // identity branch: requested two thirds into the contraction (its ~L2 latency hides under the last 12 k-steps)
+    constexpr int RES_K = 22;
+    constexpr int PD = 3;
+    half8 xq[PD + 1][2];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) xq[k][pt] = xfrag(k, pt);
+    }
+#pragma unroll
+    for (int k = 0; k < BK::NK; ++k) {
+      if (k + PD < BK::NK) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
+      }
+      if (k == RES_K) {
+#ifdef BK_NO_RES
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) resv[pt][g] = half4{0, 0, 0, 0};
+#else
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const int oy = ty0 * BK::TH + pgc * 4 + pt * 2 + (pix >> 4);
+          const int ox = tx0 * BK::TW + (pix & 15);
+          const bool ok = oy < a.H && ox < a.W;
+          const _Float16* rp = a.in + (((size_t)n * a.H + (ok ? oy : 0)) * a.W + (ok ? ox : 0)) * 64 + co_base + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) resv[pt][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
+        }
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[k], xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // one MFMA tile (32 pixels = 2 output rows x 16) at a time: + identity -> ReLU -> fp16 -> wave-private staging (32 pixels x
+  // 64 B, chunk XOR (p >> 2) & 3) -> 16-byte stores; four lanes write the 64-byte half line of one pixel (the other cout
+  // tile's wave writes the other half).  LDS operations of one wave execute in order: the second tile may overwrite the
+  // staging area right after the first tile's reads were issued.
+  auto epilogue = [&](const TileWalk& tw) {
+    const int n = tw.n, ty0 = tw.ty, tx0 = tw.tx;
+    char* obase = reinterpret_cast<char*>(a.out) + ((long)n * a.H + ty0 * BK::TH + pgc * 4) * rowpitch + (long)tx0 * BK::TW * 128 + ct * 64;
+    char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (threadIdx.x & 127) * 16;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float x0 = acc[pt][4 * g + 0] + (float)resv[pt][g][0], x1 = acc[pt][4 * g + 1] + (float)resv[pt][g][1];
+        const float x2 = acc[pt][4 * g + 2] + (float)resv[pt][g][2], x3 = acc[pt][4 * g + 3] + (float)resv[pt][g][3];
+        uint2 v;
+        v.x = lfd_cvt_pk_max(x0, x1, LFD_PK_RELU);
+        v.y = lfd_cvt_pk_max(x2, x3, LFD_PK_RELU);
+        *reinterpret_cast<uint2*>(stg + pix * 64 + ((g ^ ((pix >> 2) & 3)) << 4) + 8 * h) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int idx = j * 64 + lane;
+        const int p = idx >> 2, c = idx & 3;                              // p = pixel of this MFMA tile
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + p * 64 + ((c ^ ((p >> 2) & 3)) << 4));
+        const int orow = pt * 2 + (p >> 4), ocol = p & 15;
+        const bool ok = (ty0 * BK::TH + pgc * 4 + orow < a.H) && (tx0 * BK::TW + ocol < a.W);
+        char* dst = ok ? obase + orow * rowpitch + ocol * 128 + c * 16 : trash;
+#ifdef BK_NO_STORE
+        if (a.N < 0)
+#endif
+        *reinterpret_cast<uint4*>(dst) = v;
       }
     }
   };
 
-  int t = t_first;        // the tile the PRODUCERS work on in this step; this wave consumes the previous one
+  int t = t_first;        // the tile the PRODUCERS work on in this step; this wave contracts the previous one
   int buf = 0;
   int tp = -1;
-  bool stored = false;     // the previous step ended with this wave's 4 copy-out stores
-  TileWalk prv, cur, nxt;  // tiles tp (consumed here), t (the producers'), t + t_step (whose input is fetched now)
+  bool pending = false;    // acc / resv hold a contracted tile (coordinates `pnd`) whose epilogue has not run yet
+  TileWalk pnd, prv, cur, nxt;  // tiles: awaiting its epilogue, tp (contracted here), t (the producers'), t + t_step (fetched now)
   cur.init(a, t_first, t_step);
   prv = cur;
+  pnd = cur;
   nxt = cur;
   nxt.advance();
-  if (t < t_end) issue_dma(cur, 0);
+  bool first_step = true; (void)first_step;
+  if (t < t_end) issue_dma(a, smem, cw, cur, 0);     // the FIRST tile's input is always fetched by the consumers: the producers' prologue is the longer one
   int dbg_step = 0; (void)dbg_step;
   for (;; t += t_step, buf ^= 1, ++dbg_step, prv = cur, cur = nxt, nxt.advance()) {
     BT(1, 0);
-    // The DMA of tile t (issued one step ago) must have landed.  VMEM retires in order and the only operations issued after
-    // it are this wave's residual loads (consumed already) and the 4 copy-out stores of the previous tile (every lane issues
-    // exactly 4, masked lanes into the trash line): allow those 4 to stay in flight.
-    if (stored) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stored = false;
+    // -DBK_DMA_CONS (rounds 1-2): this wave issued the DMA of tile t one step ago and awaits it here.  Default (round 3): the
+    // producers fetch and await every tile but the first.
+#ifndef BK_DMA_CONS
+    if (first_step) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the prologue DMA (later tiles: the producers fetch and await them)
+    first_step = false;
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     BT(1, 1);
     block_barrier();       // in[buf] landed for everybody; mid[buf ^ 1] (tile tp) is complete; the producers are done with in[buf ^ 1]
     BT(1, 2);
-#ifndef BK_NO_DMA
-    if (t + t_step < t_end) issue_dma(nxt, buf ^ 1);
+#ifndef BK_EPI_EARLY
+#ifdef BK_DMA_CONS
+    if (t + t_step < t_end) issue_dma(a, smem, cw, nxt, buf ^ 1);
 #endif
     BT(1, 3);
     if (tp >= 0) {
-      const int n = prv.n, ty0 = prv.ty, tx0 = prv.tx;
-      const char* mid = smem + BK::OFF_MID + (buf ^ 1) * BK::MID_BYTES;
-      f32x16 acc[2];
-      {
-        const float* bp = sbias + ct * 32 + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
-            acc[pt][4 * g + 0] = b4.x; acc[pt][4 * g + 1] = b4.y; acc[pt][4 * g + 2] = b4.z; acc[pt][4 * g + 3] = b4.w;
-          }
-        }
-      }
-      auto xfrag = [&](int k, int pt) {
-        const int r = k / 12, s = (k / 4) % 3, q = k % 4;
-        return *reinterpret_cast<const half8*>(mid + cbase + (pt * 2 * BK::MID_ROWB + r * BK::MID_ROWB + s * BK::MID_PIXB + q * 32));
-      };
-      // identity branch: requested two thirds into the contraction (its ~L2 latency hides under the last 12 k-steps
-      // without holding 16 registers across the whole loop)
-      half4 resv[2][4];
-      constexpr int RES_K = 22;
-      constexpr int PD = 3;
-      half8 xq[PD + 1][2];
-#pragma unroll
-      for (int k = 0; k < PD; ++k) {
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) xq[k][pt] = xfrag(k, pt);
-      }
-#pragma unroll
-      for (int k = 0; k < BK::NK; ++k) {
-        if (k + PD < BK::NK) {
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) xq[(k + PD) % (PD + 1)][pt] = xfrag(k + PD, pt);
-        }
-        if (k == RES_K) {
-#ifdef BK_NO_RES
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) resv[pt][g] = half4{0, 0, 0, 0};
-#else
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
-            const int oy = ty0 * BK::TH + pgc * 4 + pt * 2 + (pix >> 4);
-            const int ox = tx0 * BK::TW + (pix & 15);
-            const bool ok = oy < a.H && ox < a.W;
-            const _Float16* rp = a.in + (((size_t)n * a.H + (ok ? oy : 0)) * a.W + (ok ? ox : 0)) * 64 + co_base + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) resv[pt][g] = *reinterpret_cast<const half4*>(rp + 8 * g);
-          }
-#endif
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[k], xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      contract(prv, smem + BK::OFF_MID + (buf ^ 1) * BK::MID_BYTES);
       BT(1, 4);
-      // ---- epilogue, one MFMA tile (32 pixels = 2 output rows x 16) at a time: + identity -> ReLU -> fp16 -> wave-private
-      // staging (32 pixels x 64 B, chunk XOR (p >> 2) & 3) -> 16-byte stores; four lanes write the 64-byte half line of one
-      // pixel (the other cout tile's wave writes the other half).  LDS operations of one wave execute in order: the second
-      // tile may overwrite the staging area right after the first tile's reads were issued.
-      char* obase = reinterpret_cast<char*>(a.out) + ((long)n * a.H + ty0 * BK::TH + pgc * 4) * rowpitch + (long)tx0 * BK::TW * 128 + ct * 64;
-      char* trash = reinterpret_cast<char*>(const_cast<_Float16*>(a.zeros)) + 2048 + (threadIdx.x & 127) * 16;
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float x0 = acc[pt][4 * g + 0] + (float)resv[pt][g][0], x1 = acc[pt][4 * g + 1] + (float)resv[pt][g][1];
-          const float x2 = acc[pt][4 * g + 2] + (float)resv[pt][g][2], x3 = acc[pt][4 * g + 3] + (float)resv[pt][g][3];
-          uint2 v;
-          v.x = lfd_cvt_pk_max(x0, x1, LFD_PK_RELU);
-          v.y = lfd_cvt_pk_max(x2, x3, LFD_PK_RELU);
-          *reinterpret_cast<uint2*>(stg + pix * 64 + ((g ^ ((pix >> 2) & 3)) << 4) + 8 * h) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int idx = j * 64 + lane;
-          const int p = idx >> 2, c = idx & 3;                              // p = pixel of this MFMA tile
-          const uint4 v = *reinterpret_cast<const uint4*>(stg + p * 64 + ((c ^ ((p >> 2) & 3)) << 4));
-          const int orow = pt * 2 + (p >> 4), ocol = p & 15;
-          const bool ok = (ty0 * BK::TH + pgc * 4 + orow < a.H) && (tx0 * BK::TW + ocol < a.W);
-          char* dst = ok ? obase + orow * rowpitch + ocol * 128 + c * 16 : trash;
-#ifdef BK_NO_STORE
-          if (a.N < 0)
-#endif
-          *reinterpret_cast<uint4*>(dst) = v;
-        }
-      }
-      stored = true;
+      epilogue(prv);
       BT(1, 5);
     }
+#else
+    // the epilogue comes FIRST: its identity values are compiler-visible loads, and a compiler-counted vmcnt in front of their
+    // first use would also wait for DMA instructions issued after them (VMEM retires in order, the inline-asm DMA is not counted)
+    if (pending) epilogue(pnd);
+    pending = false;
+    BT(1, 3);
+#if !defined(BK_NO_DMA) && defined(BK_DMA_CONS)
+    if (t + t_step < t_end) issue_dma(a, smem, cw, nxt, buf ^ 1);
+#endif
+    BT(1, 4);
+    if (tp >= 0) {
+      contract(prv, smem + BK::OFF_MID + (buf ^ 1) * BK::MID_BYTES);
+      pnd = prv;
+      pending = true;
+    }
+    BT(1, 5);
+#endif
     if (t >= t_end) break;   // the producers had no tile in this step: tp was the last one
     tp = t;
   }
+#ifdef BK_EPI_EARLY
+  if (pending) epilogue(pnd);
+#endif
 }
 
 __global__ __launch_bounds__(512) void k_block64(BlockArgs a) {

@@ -44,6 +44,7 @@ try:
                         for r in (0, 1)]      # cycle counter vs the 100 MHz real-time counter over 7 steps
     rec['producer_steps'] = [[int(v - t0) if v else None for v in a[0, s, :6]] for s in range(11)]
     rec['consumer_steps'] = [[int(v - t0) if v else None for v in a[1, s, :6]] for s in range(11)]
+    rec['step_wall_ns'] = [[int(a[r, s + 1, 7] - a[r, s, 7]) * 10 if a[r, s + 1, 7] and a[r, s, 7] else None for s in range(10)] for r in (0, 1)]   # 100 MHz real-time counter at each loop top
 except AttributeError:
     pass
 print(json.dumps(rec))
