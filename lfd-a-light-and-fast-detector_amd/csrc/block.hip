@@ -397,7 +397,7 @@ __device__ __forceinline__ void consumer(const BlockArgs& a, char* smem, int cw,
   int t = t_first;        // the tile the PRODUCERS work on in this step; this wave contracts the previous one
   int buf = 0;
   int tp = -1;
-  bool pending = false;    // acc / resv hold a contracted tile (coordinates `pnd`) whose epilogue has not run yet
+  bool pending = false; (void)pending;    // acc / resv hold a contracted tile (coordinates `pnd`) whose epilogue has not run yet
   TileWalk pnd, prv, cur, nxt;  // tiles: awaiting its epilogue, tp (contracted here), t (the producers'), t + t_step (fetched now)
   cur.init(a, t_first, t_step);
   prv = cur;

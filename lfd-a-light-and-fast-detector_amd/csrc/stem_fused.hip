@@ -836,13 +836,27 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
         G.fk = inreg ? (rem >> 1) & 7 : 0;
         G.dst = inreg ? X2::OFF_MID + (my * X2::IWs + rem) * 128 : X2::OFF_DUMMY + pix * 128;
       };
+      // Lane -> column within a 32-column half (round 3): lane p works on column 4 (p & 7) + {0, 2, 1, 3}[p >> 3], not on
+      // column p.  A pixel's 16-byte chunks are XOR-swizzled with the key (slot >> 1) & 7 of its de-interleaved slot -- what
+      // makes conv3's B-fragment reads conflict-free -- and ds_write_b128 is serviced 8 consecutive lanes at a time over 32
+      // banks: with lane = column, 8 consecutive lanes are 4 even + 4 odd columns whose keys coincide in pairs and across
+      // the two parities -> 4-way bank conflicts on every one of the 80 tile writes (32 instead of 8 LDS cycles each;
+      // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.53 in profiles/r02b_pmc_sq_counters.txt).  With this order the 8 lanes of
+      // a group hold columns of ONE parity, 4 apart = slots 2 apart = 8 distinct keys: conflict-free (scratch/stem_lds_sim.py).
+      // The raw-tile reads keep their bank pattern (the same 32 addresses per instruction, assigned to other lanes), and a
+      // lane's pixel is computed by that lane alone from im2col to the store, so the values do not change.
+#ifdef X2_LINEAR_LANES
+      const int pcol = pix;
+#else
+      const int pcol = 4 * (pix & 7) + ((0x3120 >> (4 * (pix >> 3))) & 3);
+#endif
       auto s_addr_k = [&](Grp& G, int k) {
         if (k < 4) {                               // wave-uniform row / half
           const int grp = wave + 4 * k;
-          s_addr_px(G, grp >> 1, ((grp & 1) << 5) + pix, true);
+          s_addr_px(G, grp >> 1, ((grp & 1) << 5) + pcol, true);
         } else {                                   // selects, no branches
           const int my = wave < 2 ? X2::IH - 1 : (wave == 2 ? (pix < X2::IH ? pix : X2::IH - 1) : 0);
-          const int mx = wave < 2 ? (wave << 5) + pix : (wave == 2 ? X2::IW - 1 : pix);
+          const int mx = wave < 2 ? (wave << 5) + pcol : (wave == 2 ? X2::IW - 1 : pix);
           s_addr_px(G, my, mx, wave < 2 || (wave == 2 && pix < X2::IH));
         }
       };
