@@ -252,28 +252,30 @@ def test_training_on_a_fixed_batch_reduces_the_loss_like_the_pytorch_path(monkey
 
 
 def test_config5_widerface_s_640_loss_curve_vs_fp32_autograd(monkeypatch):
-    """BASELINE config 5 protocol on one GPU's share, reduced batch: WIDERFACE_LFD_S from scratch (reference init, seed of
-    the config), synthetic 640x640 frames, G ~ U{1..20} boxes per image with w, h ~ logU[6, 300], a FRESH batch
-    of 8 every iteration, SGD momentum 0.9 / weight decay 1e-4 / lr 0.1 with the config's linear warm-up (ratio 0.1 over 200
-    iterations, WIDERFACE_LFD_S.py:218-241), clip_grad_norm_(10) -- 24 iterations.  The all-HIP iteration (fp16 activations,
-    loss scale 1024, fp32 accumulate / parameters) against the same nn.Modules through PyTorch-ROCm fp32 autograd + the
-    op-by-op loss + torch.optim.SGD from identical initial weights: the loss CURVES must agree (tolerance on the loss, not
-    on bits: two fp32 runs with different reduction orders drift apart at the same rate)."""
+    """BASELINE config 5 protocol on one GPU's share: WIDERFACE_LFD_S from scratch (reference init, seed of the config),
+    synthetic 640x640 frames, G ~ U{1..20} boxes per image with w, h ~ logU[6, 300], a FRESH batch of 32 (the
+    config's per-GPU batch) every iteration, SGD momentum 0.9 / weight decay 1e-4 / lr 0.1 with the config's linear warm-up
+    (ratio 0.1 over 200 iterations, WIDERFACE_LFD_S.py:218-241), clip_grad_norm_(10) -- 40 iterations.  The all-HIP
+    iteration (fp16 activations, dynamic loss scale starting at 1024, fp32 accumulate / parameters) against an INDEPENDENT
+    fp32 path: this package's mirror nn.Modules (same parameters, same semantics as the reference's -- pinned by the
+    reference-generated goldens) through PyTorch-ROCm autograd (MIOpen fp32 convolutions) + the op-by-op loss +
+    torch.optim.SGD, from identical initial weights.  The loss CURVES must agree: 1 % over the first 16 iterations, 2 % at
+    any of the 40 (measured: 0.29 % max) (tolerance on the loss, not on bits: two fp32 runs with different reduction orders drift apart too)."""
     import json
     import os
     from conftest import ROOT
-    steps, bs, size = 24, 8, 640
-    rng = np.random.default_rng(55)
-    batches = []
-    for _ in range(steps):
-        x = torch.from_numpy(rng.normal(0, 1, (bs, 3, size, size)).astype(np.float32))
+    steps, bs, size = 40, 32, 640              # the config's own per-GPU batch (WIDERFACE_LFD_S.py: batch 32 per GPU)
+
+    def batch(it):                              # regenerated per iteration from its own seed: 40 x 157 MB would not fit the host
+        rng = np.random.default_rng(5500 + it)
+        x = torch.randn((bs, 3, size, size), device='cuda', generator=torch.Generator(device='cuda').manual_seed(5500 + it))
         ann = []
         for _ in range(bs):
             g = int(rng.integers(1, 21))
             wh = np.exp(rng.uniform(np.log(6), np.log(300), (g, 2)))
             xy = rng.uniform(0, 1, (g, 2)) * (size - wh).clip(1)
             ann.append((np.concatenate([xy, wh], 1).astype(np.float32), np.zeros(g, np.int64)))
-        batches.append((x, ann))
+        return x, ann
     clip = dict(max_norm=10, norm_type=2)
     curves, norms = {}, {}
     for mode in ('hip', 'torch'):
@@ -283,11 +285,15 @@ def test_config5_widerface_s_640_loss_curve_vs_fp32_autograd(monkeypatch):
         kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-4)
         opt = optim.SGD(m.parameters(), **kw) if mode == 'hip' else torch.optim.SGD(m.parameters(), **kw)
         losses, gns = [], []
-        for it, (x, ann) in enumerate(batches):
+        scaler = train.DynamicLossScale(init_scale=1024.0) if mode == 'hip' else None
+        if scaler is not None:
+            hip_scaler = scaler
+        for it in range(steps):
+            x, ann = batch(it)
             lr = 0.1 * (0.1 + (1 - 0.1) * it / 200.0)          # LrSchedulerHook linear warm-up (lr_scheduler_hook.py:80-99)
             for gr in opt.param_groups:
                 gr['lr'] = lr
-            lv, gn = train.train_step(m, opt, x.cuda(), ann, clip, clip_active=True)
+            lv, gn = train.train_step(m, opt, x.cuda(), ann, clip, clip_active=True, loss_scaler=scaler)
             assert np.isfinite(lv['loss']) and np.isfinite(float(gn)), (mode, it)
             losses.append(float(lv['loss']))
             gns.append(float(gn))
@@ -300,8 +306,9 @@ def test_config5_widerface_s_640_loss_curve_vs_fp32_autograd(monkeypatch):
                    rel=rel.tolist()), open(os.path.join(out, 'train_curve_config5.json'), 'w'), indent=1)
     print('config 5 loss curve: hip %s\n torch %s\n max rel diff %.3e (first step %.3e)' % (np.round(h, 4).tolist(), np.round(t, 4).tolist(),
                                                                                         rel.max(), rel[0]))
+    assert hip_scaler.skipped == 0 and hip_scaler.scale == 1024.0  # no overflow at the default loss scale
     assert rel[0] < 5e-3                                  # same start: only the fp16 forward differs
-    assert rel[:8].max() < 3e-2 and rel.max() < 1e-1      # the curves stay together over the 24 iterations
+    assert rel[:16].max() < 1e-2 and rel.max() < 2e-2     # asked: 2 % / 5 % at bs 32 over 40 iterations; measured 0.29 % max
     assert np.mean(h[-4:]) < h[0]                         # and go down
 
 
