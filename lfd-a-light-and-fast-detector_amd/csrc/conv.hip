@@ -1,5 +1,10 @@
 // csrc/conv.hip -- C ABI entry points of the NHWC fp16 implicit-GEMM convolution (kernel templates: conv_impl.h).
 #include "conv_impl.h"
+#include <cstdlib>
+
+// csrc/conv_small.hip: split-K, one output slab per workgroup -- the 128 -> 128 3x3 convs of the small last-stage maps
+int lfd_conv128_splitk_launch(const _Float16* in, _Float16* out, const void* w_packed, const float* bias, const _Float16* res,
+                              int n, int h, int w, int relu, hipStream_t st);
 
 #ifdef LFD_CONV_TIMING
 extern "C" __attribute__((visibility("default"))) int lfd_debug_conv_timing(unsigned long long* host_out) {
@@ -73,7 +78,14 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     //  sibling heads -- 128-channel 3x3 towers at stride 4-8 -- a 4-row x 64-cout tile, <128,3,1,2>, halves the filter bytes
     //  streamed per pixel but measured slower, FCOS forward 3.25 vs 2.97 ms: the two waves sharing a filter slab do not hit
     //  in each other's fetches.  A register-stationary 128-channel variant is what those maps would want.)
-    case 128 * 10000 + 3100 + 40: return launch_conv<128, 3, 1, 4, false, false>(a, st);
+    case 128 * 10000 + 3100 + 40: {
+      // small maps (the 17 x 30 / 23 x 40 last stages): 4 x the workgroups, a quarter of the filter and of the k-steps each
+      // (conv_small.hip); large maps (sibling heads) keep the streamed-weight kernel.  LFD_CONV128_SPLITK=0: A/B switch.
+      static const bool splitk = [] { const char* e = getenv("LFD_CONV128_SPLITK"); return !e || atoi(e) != 0; }();
+      if (splitk && (long)a.N * a.OH * a.OW <= 16384)
+        return lfd_conv128_splitk_launch(a.in, a.out, w_packed, bias, a.res, a.N, a.H, a.W, a.relu, st);
+      return launch_conv<128, 3, 1, 4, false, false>(a, st);
+    }
     case 128 * 10000 + 3200 + 40: return launch_conv<128, 3, 2, 4, false, false>(a, st);
     case 128 * 10000 + 3100 + 20: return launch_conv<128, 3, 1, 2, false, false>(a, st);  // data gradient of 64->128 s2
     case 128 * 10000 + 3200 + 20: return launch_conv<128, 3, 2, 2, false, false>(a, st);  // FPN extra level on a 128-channel input, 64 outputs

@@ -245,3 +245,41 @@ def test_fused_stem_uint8_frames_equal_normalised_fp16_frames(n, h, w):
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_conv128_small_map_split_k_kernel_and_the_generic_kernel():
+    """cin = cout = 128, 3x3 stride 1: maps of <= 16384 pixels take the split-K / slab-per-workgroup kernel
+    (csrc/conv_small.hip), larger ones the streamed-weight kernel -- both against float64, over partial tiles (17 x 30: one
+    valid row in the last tile row, 14 valid columns in the last tile column), with and without residual / ReLU; on the
+    same input the two kernels agree to one fp16 ulp (different association of the fp32 sum over k)."""
+    import os
+    import subprocess
+    import sys
+    for kw in (dict(res=True), dict(relu=False), dict()):
+        _run(128, 128, 3, 1, 1, 17, 30, **kw)
+        _run(128, 128, 3, 1, 8, 17, 30, **kw)
+    _run(128, 128, 3, 1, 2, 23, 40, res=True)            # TT100K_LFD_L's last stage at 720p
+    _run(128, 128, 3, 1, 3, 80, 80, res=True)            # 19200 pixels: the generic kernel
+    code = '''
+import torch, sys
+sys.path.insert(0, %r)
+from lfd_amd import ops
+g = torch.Generator().manual_seed(4)
+x = (torch.randn(8, 17, 30, 128, generator=g) * 0.5).half().cuda()
+w = ops.pack_conv_weight((torch.randn(128, 128, 3, 3, generator=g) / 34).half().float()).cuda()
+b = (torch.randn(128, generator=g) * 0.1).cuda()
+y = ops.conv2d_nhwc(x, w, b, 128, 128, 3, 1, True, residual=x)
+torch.save(y.cpu(), sys.argv[1])
+''' % os.path.dirname(os.path.dirname(ops.__file__))
+    import tempfile
+    outs = []
+    for flag in ('1', '0'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            r = subprocess.run([sys.executable, '-c', code, f.name], env=dict(os.environ, LFD_CONV128_SPLITK=flag), capture_output=True,
+                               text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(f.name).float())
+    d = (outs[0] - outs[1]).abs()
+    ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(outs[0].abs(), outs[1].abs()).clamp(min=2.0 ** -14))) - 10)
+    # (below 2^-14 the fp16 spacing, 2^-24, is finer than the fp32 accumulation noise of a sum of O(1) terms: + 2^-22)
+    assert bool((d <= ulp + 2.0 ** -22).all()) and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
