@@ -118,6 +118,8 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             by += dst.numel() * 2
         name = 'conv%dx%d_s%d_%dto%d%s (k_conv)' % (c.ks, c.ks, c.stride, c.cin, c.cout,
                                                    '+1x1' if c.tail else ('+downsample1x1s2' if c.ds is not None else ''))
+        if c.cin == 128 and c.cout == 128 and c.ks == 3 and c.stride == 1 and not c.tail and n * dst.shape[1] * dst.shape[2] <= 16384:
+            name = 'conv3x3_s1_128to128 small map, split-K (k_conv128_splitk)'
         if c.blk is not None:
             # whole residual block: two 3x3 convs; algorithmic bytes = the map read once + written once (the identity is
             # the same tensor as the input; the intermediate never reaches HBM)
