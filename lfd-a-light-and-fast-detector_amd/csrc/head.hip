@@ -1041,6 +1041,18 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
       }
     }
   }
+  // affine parameters of this thread's group (threads < nvc / 2 own one group each): requested now, so that their round trip
+  // runs beside the statistics reduction instead of behind it (groups of up to 8 channels; larger ones load in place)
+  float ga_pre[8], be_pre[8];
+  if ((int)threadIdx.x < nvc / 2 && f.gsize <= 8) {
+    const int g = ct * (nvc / 2) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g * f.gsize + (j < f.gsize ? j : 0);
+      ga_pre[j] = f.gamma[l][c];
+      be_pre[j] = f.beta[l][c];
+    }
+  }
   const int t0 = f.tile_start[l] + n * f.tiles_per_img[l];
   const int st = f.tile_stride[l];
   const int T = (f.tiles_per_img[l] + st - 1) / st;   // slots that carry data
@@ -1086,10 +1098,11 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
     const double rstd = 1.0 / sqrt(var + (double)f.eps);
     for (int j = 0; j < f.gsize; ++j) {
       const int c = g * f.gsize + j;
-      const double sc = (double)f.gamma[l][c] * rstd;
+      const float gam = f.gsize <= 8 ? ga_pre[j & 7] : f.gamma[l][c], bet = f.gsize <= 8 ? be_pre[j & 7] : f.beta[l][c];
+      const double sc = (double)gam * rstd;
       float* o = f.ab + (((size_t)l * f.N + n) * HC + c) * 2;
       o[0] = (float)sc;
-      o[1] = (float)((double)f.beta[l][c] - mean * sc);
+      o[1] = (float)((double)bet - mean * sc);
       s_ab[c - ct * 32][0] = o[0]; s_ab[c - ct * 32][1] = o[1];
     }
   }
