@@ -427,6 +427,13 @@ typedef struct lfd_p32_conv_desc {
 LFD_API size_t lfd_p32_conv_packed_weight_halfs(int32_t cin, int32_t cout, int32_t ks);
 LFD_API int lfd_p32_conv2d_nhwc_f32(const lfd_p32_conv_desc_t* desc, const void* in, float* out, const void* w_packed,
                                     const float* bias, const float* residual, const float* scale, lfd_stream_t stream);
+/* the same conv chained with a 1x1 conv 64 -> 64 in ONE launch: out = relu?( conv1x1( relu?(conv(in) + bias) ) + tail_bias )
+ * -- the stem pairs conv3x3 s2 + BN + ReLU -> conv1x1 + BN + ReLU (lfd_resnet.py:356-413); the 64-channel fp32 intermediate
+ * stays in LDS.  desc->cout must be 64, the conv 3x3 stride 2 (in_format < 0) or the first stem conv (in_format 0|1|2);
+ * tail_w_packed = lfd_p32_conv_packed_weight_halfs(64, 64, 1) halfs in the same layout. */
+LFD_API int lfd_p32_conv2d_tail_nhwc_f32(const lfd_p32_conv_desc_t* desc, const void* in, float* out, const void* w_packed,
+                                         const float* bias, const void* tail_w_packed, const float* tail_bias, int32_t tail_relu,
+                                         lfd_stream_t stream);
 /* x [n, hw, c] fp32 <- relu?( GroupNorm(groups)(x) * gamma + beta ) in place (nn.GroupNorm semantics: biased variance
  * over hw x c/groups elements per image and group; statistics summed in fp64 in a fixed order); c % 4 == 0,
  * 256 % (c/4) == 0, (c/groups) % 4 == 0, groups <= 64. */

@@ -38,6 +38,9 @@ struct P32Args {
   const float* bias;     // [32 * nslab]
   const float* res;      // fp32 NHWC [N,OH,OW,cout] or null
   const float* scale;    // one float (lfd_head.py Scale) or null
+  const half8* w2;       // TAIL: chained 1x1 64 -> 64, [2 slabs][2 chunks][1 tap][2 k-steps][hi | lo][64 lanes]
+  const float* bias2;    // TAIL: [64]
+  int relu2;
   int N, H, W, OH, OW, cin, cout, nslab, relu, fmt;
   long out_img_stride;   // floats between images of `out`
   int out_pix_stride;    // floats between pixels of `out`
@@ -64,7 +67,11 @@ __device__ __forceinline__ float frame_value(const void* in, int fmt, int n, int
 
 // One workgroup = 4 waves = TH x 16 output pixels x 64 output channels; wave w: channel slab (w & 1), pixel rows
 // (w >> 1) * 2 NG + [0, 2 NG) as NG MFMA pixel tiles of 2 rows x 16 columns.  Input channels in chunks of 32.
-template <int KS, int S, int NG, bool PATCH>
+// TAIL: the conv is followed by a 1x1 conv 64 -> 64 (+ bias + ReLU) in the SAME launch (the stem pairs, lfd_resnet.py:356-413:
+// conv3x3 + BN + ReLU -> conv1x1 + BN + ReLU): the first conv's fp32 results (bias, ReLU applied) are split into hi / lo planes
+// straight into LDS -- wave (slab s) fills channel chunk s of its 64 pixels -- and contracted again; the 64-channel fp32
+// intermediate (1.06 GB per 8 x 1080p for the first pair) never reaches HBM.  Needs cout == 64 (one workgroup = both slabs).
+template <int KS, int S, int NG, bool PATCH, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_p32_conv(const P32Args a) {
   constexpr int TW = 16, TH = 4 * NG;
   constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
@@ -154,8 +161,60 @@ __global__ __launch_bounds__(256) void k_p32_conv(const P32Args a) {
       }
     }
   }
+  if constexpr (TAIL) {
+    // ---- first conv's epilogue into LDS planes: channel chunk `slab`, pixel (prow0 + 2g + (p >> 4)) * 16 + (p & 15)
+    constexpr int CHB = TH * TW * kPitch;                 // bytes of one plane of one 32-channel chunk
+    __syncthreads();                                      // every wave is done reading the input tile
+    char* const t_hi = smem;                              // [2 chunks][TH*TW px][kPitch]
+    char* const t_lo = smem + 2 * CHB;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int pix = (prow0 + 2 * g + (p >> 4)) * TW + (p & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        union { _Float16 h[4]; uint2 u; } hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = accm[g][4 * q + e] + accc[g][4 * q + e] * kInvLo + a.bias[slab * 32 + 8 * q + 4 * kh + e];
+          if (a.relu) v = fmaxf(v, 0.f);
+          const _Float16 hh = (_Float16)v;
+          hi.h[e] = hh;
+          lo.h[e] = (_Float16)((v - (float)hh) * kLo);
+        }
+        const int off = slab * CHB + pix * kPitch + (8 * q + 4 * kh) * 2;
+        *reinterpret_cast<uint2*>(t_hi + off) = hi.u;
+        *reinterpret_cast<uint2*>(t_lo + off) = lo.u;
+      }
+    }
+    __syncthreads();
+    // ---- chained 1x1: 2 chunks x 2 k-steps, A = w2 fragments of this wave's output slab
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accm[g][r] = accc[g][r] = 0.f;
+    const half8* w2s = a.w2 + (size_t)slab * 2 * 4 * 64 + lane;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const half8 wh = w2s[((c2 * 2 + kk) * 2 + 0) * 64];
+        const half8 wl = w2s[((c2 * 2 + kk) * 2 + 1) * 64];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int pix = (prow0 + 2 * g + (p >> 4)) * TW + (p & 15);
+          const int off = c2 * CHB + pix * kPitch + (kk * 16 + kh * 8) * 2;
+          const half8 xh = *reinterpret_cast<const half8*>(t_hi + off);
+          const half8 xl = *reinterpret_cast<const half8*>(t_lo + off);
+          accm[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, accm[g], 0, 0, 0);
+          accc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accc[g], 0, 0, 0);
+          accc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accc[g], 0, 0, 0);
+        }
+      }
+  }
   if (!active) return;
   // ---- epilogue on the fp32 accumulators: register 4q + e of lane (kh, p) = channel 32 slab + 8q + 4kh + e of pixel p
+  const float* const ebias = TAIL ? a.bias2 : a.bias;
+  const int erelu = TAIL ? a.relu2 : a.relu;
   const float sc = a.scale ? *a.scale : 1.f;
   const bool vec = (a.cout & 3) == 0 && (a.out_pix_stride & 3) == 0 && (a.out_img_stride & 3) == 0;
 #pragma unroll
@@ -170,7 +229,7 @@ __global__ __launch_bounds__(256) void k_p32_conv(const P32Args a) {
       const int c0 = slab * 32 + 8 * q + 4 * kh;
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = accm[g][4 * q + e] + accc[g][4 * q + e] * kInvLo + a.bias[c0 + e];
+      for (int e = 0; e < 4; ++e) v[e] = accm[g][4 * q + e] + accc[g][4 * q + e] * kInvLo + ebias[c0 + e];
       if (vec) {
         if (c0 >= a.cout) continue;
         if (r) {
@@ -180,7 +239,7 @@ __global__ __launch_bounds__(256) void k_p32_conv(const P32Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] *= sc;
-          if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          if (erelu) v[e] = fmaxf(v[e], 0.f);
         }
         *reinterpret_cast<float4*>(o + c0) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -190,7 +249,7 @@ __global__ __launch_bounds__(256) void k_p32_conv(const P32Args a) {
           float x = v[e];
           if (r) x += r[c0 + e];
           x *= sc;
-          if (a.relu) x = fmaxf(x, 0.f);
+          if (erelu) x = fmaxf(x, 0.f);
           o[c0 + e] = x;
         }
       }
@@ -198,16 +257,17 @@ __global__ __launch_bounds__(256) void k_p32_conv(const P32Args a) {
   }
 }
 
-template <int KS, int S, int NG, bool PATCH>
+template <int KS, int S, int NG, bool PATCH, bool TAIL = false>
 int launch_p32(P32Args a, hipStream_t st) {
   constexpr int TH = 4 * NG, TW = 16;
   constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
-  constexpr int lds = 2 * IH * IW * kPitch;
+  constexpr int lds_in = 2 * IH * IW * kPitch, lds_tail = TAIL ? 4 * TH * TW * kPitch : 0;
+  constexpr int lds = lds_in > lds_tail ? lds_in : lds_tail;
   a.tiles_x = (a.OW + TW - 1) / TW;
   a.tiles_y = (a.OH + TH - 1) / TH;
   const long tiles = (long)a.tiles_x * a.tiles_y * a.N;
   if (tiles > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
-  auto kern = k_p32_conv<KS, S, NG, PATCH>;
+  auto kern = k_p32_conv<KS, S, NG, PATCH, TAIL>;
   if (lds > 64 * 1024) {
     static bool set = false;   // (idempotent; races only repeat the same call)
     if (!set) {
@@ -330,6 +390,31 @@ int lfd_p32_conv2d_nhwc_f32(const lfd_p32_conv_desc_t* d, const void* in, float*
     case 12: return launch_p32<1, 2, 1, false>(a, st);
     default: return LFD_ERR_UNSUPPORTED;
   }
+}
+
+int lfd_p32_conv2d_tail_nhwc_f32(const lfd_p32_conv_desc_t* d, const void* in, float* out, const void* w_packed,
+                                 const float* bias, const void* tail_w_packed, const float* tail_bias, int32_t tail_relu,
+                                 lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!d || !in || !out || !w_packed || !bias || !tail_w_packed || !tail_bias) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->n < 1 || d->h < 1 || d->w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->cout != 64) return LFD_ERR_UNSUPPORTED;          // both 32-channel slabs in one workgroup; the chained 1x1 is 64 -> 64
+  const bool patch = d->in_format >= 0;
+  if (patch) {
+    if (d->in_format > 2 || d->cin != 3 || d->ks != 3 || d->stride != 2) return LFD_ERR_UNSUPPORTED;
+  } else if (d->cin < 32 || d->cin % 32 || d->ks != 3 || d->stride != 2) {
+    return LFD_ERR_UNSUPPORTED;                           // the stem pairs: 3x3 stride 2 -> 1x1
+  }
+  P32Args a{};
+  a.in = in; a.out = out; a.w = (const half8*)w_packed; a.bias = bias; a.w2 = (const half8*)tail_w_packed; a.bias2 = tail_bias;
+  a.relu2 = tail_relu;
+  a.N = d->n; a.H = d->h; a.W = d->w; a.cin = d->cin; a.cout = 64; a.nslab = 2; a.relu = d->relu; a.fmt = d->in_format;
+  a.OH = (d->h + 2 - 3) / 2 + 1;
+  a.OW = (d->w + 2 - 3) / 2 + 1;
+  a.out_pix_stride = d->out_pixel_stride > 0 ? d->out_pixel_stride : 64;
+  a.out_img_stride = d->out_image_stride > 0 ? d->out_image_stride : (long)a.OH * a.OW * a.out_pix_stride;
+  if (patch) return launch_p32<1, 1, 2, true, true>(a, st);
+  return launch_p32<3, 2, 1, false, true>(a, st);
 }
 
 size_t lfd_p32_groupnorm_workspace_bytes(int32_t n, int32_t groups) {

@@ -172,6 +172,7 @@ _SIGNATURES = {
     'lfd_conv2d_nhwc_f16_acc32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'lfd_p32_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_p32_conv2d_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_p32_conv2d_tail_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _I32, _P]),
     'lfd_p32_groupnorm_workspace_bytes': (_SZ, [_I32, _I32]),
     'lfd_p32_groupnorm_relu_f32': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P]),
     'lfd_conv2d_downsample_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

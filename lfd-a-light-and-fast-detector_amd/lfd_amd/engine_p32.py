@@ -53,7 +53,7 @@ def _pad_bias(b):
 
 class _Op(object):
     __slots__ = ('kind', 'src', 'dst', 'res', 'cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'scale', 'patch', 'ref_w',
-                 'gamma', 'beta', 'eps', 'groups', 'out', 'level')
+                 'gamma', 'beta', 'eps', 'groups', 'out', 'level', 'tail')
 
 
 class PrecisePlan(object):
@@ -76,10 +76,12 @@ class PrecisePlan(object):
         self.buf_channels[b], self.buf_scale[b] = channels, scale
         return b
 
-    def _conv(self, src, w, b, ks, stride, relu, res=None, patch=False, scale=None, out=None, level=None):
-        """w: folded fp32 OIHW (channel-padded where engine.fold_conv_norm pads), b: fp32 bias"""
+    def _conv(self, src, w, b, ks, stride, relu, res=None, patch=False, scale=None, out=None, level=None, tail=None):
+        """w: folded fp32 OIHW (channel-padded where engine.fold_conv_norm pads), b: fp32 bias;
+        tail = (w2 [64,64,1,1], b2): a chained 1x1 + ReLU in the same launch (lfd_p32_conv2d_tail_nhwc_f32)"""
         dev = self.device
         o = _Op()
+        o.tail = None if tail is None else (pack_weight(tail[0]).to(dev), _pad_bias(tail[1]).to(dev))
         o.kind, o.src, o.res, o.ks, o.stride, o.relu, o.patch, o.scale = 'conv', src, res, ks, stride, int(relu), patch, scale
         o.cout = w.shape[0]
         o.ref_w = w
@@ -119,14 +121,26 @@ class PrecisePlan(object):
         has_norm = bb._norm_cfg is not None
         step = 3 if has_norm else 2
         cur = 'input'
-        for i, (k, s, cin, cout) in enumerate(bb.stem_spec()):
-            w, b = engine.fold_conv_norm(bb._stem[i * step], bb._stem[i * step + 1] if has_norm else None)
+        spec = list(bb.stem_spec())
+        folded = [engine.fold_conv_norm(bb._stem[i * step], bb._stem[i * step + 1] if has_norm else None) for i in range(len(spec))]
+        import os
+        fuse_tail = os.environ.get('LFD_P32_TAIL', '1') != '0'
+        i = 0
+        while i < len(spec):
+            k, s, cin, cout = spec[i]
+            w, b = folded[i]
+            # a stem pair conv3x3 s2 -> conv1x1 (64 -> 64) runs as ONE launch: the fp32 intermediate stays in LDS
+            tail = None
+            if (fuse_tail and i + 1 < len(spec) and (k, s) == (3, 2) and w.shape[0] == 64 and spec[i + 1][0] == 1 and spec[i + 1][1] == 1
+                    and tuple(folded[i + 1][0].shape[:2]) == (64, 64)):
+                tail = folded[i + 1]
             if i == 0:
                 if (k, s, cin) != (3, 2, 3):
                     engine._unsupported('first stem conv must be 3x3 stride 2 on 3 channels')
-                cur = self._conv(cur, w, b, 3, 2, True, patch=True)
+                cur = self._conv(cur, w, b, 3, 2, True, patch=True, tail=tail)
             else:
-                cur = self._conv(cur, w, b, k, s, True)
+                cur = self._conv(cur, w, b, k, s, True, tail=tail)
+            i += 2 if tail is not None else 1
         taps = [tuple(t) for t in bb._out_indices]
         self.taps = []
         for i, nblk in enumerate(bb._body_architecture):
@@ -217,6 +231,10 @@ class PrecisePlan(object):
                 cw = t.shape[2]
                 d.out_pixel_stride, d.out_image_stride = cw, st.P * cw
                 dst = C.c_void_p(t.data_ptr() + st.p_off[o.level] * cw * 4)
+            if o.tail is not None:
+                check(l.lfd_p32_conv2d_tail_nhwc_f32(C.byref(d), ptr(src), dst, ptr(o.w), ptr(o.b), ptr(o.tail[0]), ptr(o.tail[1]), 1, sp),
+                      'lfd_p32_conv2d_tail_nhwc_f32')
+                continue
             check(l.lfd_p32_conv2d_nhwc_f32(C.byref(d), ptr(src), dst, ptr(o.w), ptr(o.b),
                                             ptr(st.bufs[o.res]) if o.res is not None else None,
                                             ptr(o.scale) if o.scale is not None else None, sp), 'lfd_p32_conv2d_nhwc_f32')

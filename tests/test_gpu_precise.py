@@ -266,3 +266,42 @@ def test_precise_mode_api_graph_replay_and_mode_switch():
         assert torch.equal(c16b, c16) and torch.equal(r16b, r16)
     d = float((c16 - c32).abs().max())
     assert 1e-5 < d < 5e-2, d
+
+
+@pytest.mark.parametrize('fmt', [-1, 1])
+def test_p32_conv_with_chained_1x1_keeps_the_intermediate_in_lds(fmt):
+    """lfd_p32_conv2d_tail_nhwc_f32: a stem pair conv3x3 s2 + ReLU -> conv1x1 (64 -> 64) + ReLU in one launch (the first pair
+    reads the frame, the second fp32 NHWC maps) vs the float64 chain; odd sizes (tile overhang in both directions)."""
+    g = torch.Generator().manual_seed(7 + fmt)
+    n, h, w = 2, 37, 51
+    if fmt < 0:
+        cin = 64
+        x = torch.randn(n, h, w, cin, generator=g)
+        xr = x
+        wt = torch.randn(64, cin, 3, 3, generator=g) / 24
+        wp = engine_p32.pack_weight(wt)
+    else:
+        cin = 3
+        x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half()
+        xr = x.float()
+        wt = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+        w27 = wt.permute(0, 2, 3, 1).reshape(64, 27)
+        wp = engine_p32.pack_weight(torch.cat([w27, w27.new_zeros((64, 5))], 1).reshape(64, 32, 1, 1))
+    b = torch.randn(64, generator=g)
+    w2, b2 = torch.randn(64, 64, 1, 1, generator=g) / 8, torch.randn(64, generator=g)
+    ref = _ref_conv(_ref_conv(xr, wt, b, 3, 2, True).float(), w2, b2, 1, 1, True)       # fp32 hand-off like the kernel's LDS planes
+    ref64 = _ref_conv(_ref_conv(xr, wt, b, 3, 2, True), w2, b2, 1, 1, True)
+    oh, ow = ref.shape[1], ref.shape[2]
+    out = torch.empty((n, oh, ow, 64), dtype=torch.float32, device='cuda')
+    xd, wd, bd = x.cuda(), wp.cuda(), engine_p32._pad_bias(b).cuda()
+    w2d, b2d = engine_p32.pack_weight(w2).cuda(), engine_p32._pad_bias(b2).cuda()
+    d = _lib.P32ConvDesc(n, h, w, cin, 64, 3, 2, 1, fmt, 0, 0)
+    check(lib().lfd_p32_conv2d_tail_nhwc_f32(C.byref(d), ptr(xd), ptr(out), ptr(wd), ptr(bd), ptr(w2d), ptr(b2d), 1, stream_ptr()),
+          'lfd_p32_conv2d_tail_nhwc_f32')
+    torch.cuda.synchronize()
+    err = float((out.cpu().double() - ref64).abs().max())
+    assert err <= 4e-6 * max(1.0, float(ref64.abs().max())), err
+    # the chained launch == the two separate launches to fp32 rounding of the hand-off
+    mid = _conv(xd, wt, b, 3, 2, True, fmt=fmt)
+    two = _conv(mid, w2, b2, 1, 1, True)
+    assert float((two - out).abs().max()) <= 2e-6 * max(1.0, float(ref64.abs().max()))
