@@ -134,7 +134,9 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
         px = n * hh * ww
         per_tower = 3 * 2 * px * lv.cin * 128 + (3 + 2) * 2 * px * 128 * 128 + 2 * px * 128 * 32
         hf += per_tower * len(lv.towers)
-        hb += (3 * px * lv.cin * 2) * len(lv.towers) + px * (plan.cls_channels + 4) * 4
+        # bytes a pass structure of this kind has to move: the tap read once per pass, the outputs, AND the deliberate tower-1
+        # hand-off (pass 2 writes conv2's operands, 256 B per pixel, the output pass reads them: DESIGN lesson 19) -- VERDICT r2 #9
+        hb += (3 * px * lv.cin * 2 + 2 * px * 256) * len(lv.towers) + px * (plan.cls_channels + 4) * 4
     add('neck+head 3-pass GN recompute (k_head2 x3 + k_gn_finalize x2)', us, hf, hb)
     return classes
 
