@@ -76,7 +76,14 @@ struct Cfg {
   static constexpr int OUT_STAGE_BYTES = (4 / NCT) * PT * 32 * NCT * 64;   // epilogue staging tile (fp16)
   static constexpr int IN_RAW = NSLOT * PIXB > OUT_STAGE_BYTES ? NSLOT * PIXB : OUT_STAGE_BYTES;
   static constexpr int IN_BYTES = ((IN_RAW + 1023) / 1024) * 1024;
+#ifdef CV_S2_SINGLE
   static constexpr int NBUF = (S == 1) ? 2 : 1;     // S=2 tiles are 4x larger: single buffer, 2 blocks/CU
+#else
+  // S=2 tiles are 4x larger: single buffer, 2 blocks/CU -- except the 64-channel 3x3 (the HBM-bound first conv of a stage,
+  // with or without its downsample branch): its 39 KB tile fits twice and still leaves room for two blocks per CU
+  // (2 x 81.4 KB of 160 KB), so the next tile's DMA overlaps this tile's contraction inside the workgroup as well
+  static constexpr int NBUF = (S == 1 || (CIN == 64 && KS == 3 && NCT == 2 && !TAIL)) ? 2 : 1;
+#endif
   static constexpr int NK = KS * KS * CIN / 16;     // MFMA k-steps of the main conv
   static constexpr int NQ = CIN / 16;
   // tail (1x1 on the main conv's output): CMID = NCT*32 channels
@@ -340,6 +347,9 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       static_assert(NST == 2 || NST == 4, "copy-out stores per thread");
       // (first tile: no stores behind the DMA yet -> everything must have landed)
       // (ACC32: the accumulator stores below are not counted -> drain everything)
+      // (DS: the identity-branch stores that follow the NST copy-out stores are CONDITIONAL -- a wave whose pixels are all
+      //  outside the image issues none -- so they must not be counted: with NST allowed, whatever is still in flight is
+      //  younger than the DMA in either case)
       if (first || ACC32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
