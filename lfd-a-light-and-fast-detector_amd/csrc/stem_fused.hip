@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void k_stem2x(FusedArgs a) {
       // banks: with lane = column, 8 consecutive lanes are 4 even + 4 odd columns whose keys coincide in pairs and across
       // the two parities -> 4-way bank conflicts on every one of the 80 tile writes (32 instead of 8 LDS cycles each;
       // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.53 in profiles/r02b_pmc_sq_counters.txt).  With this order the 8 lanes of
-      // a group hold columns of ONE parity, 4 apart = slots 2 apart = 8 distinct keys: conflict-free (scratch/stem_lds_sim.py).
+      // a group hold columns of ONE parity, 4 apart = slots 2 apart = 8 distinct keys: conflict-free (tools/stem_lds_sim.py).
       // The raw-tile reads keep their bank pattern (the same 32 addresses per instruction, assigned to other lanes), and a
       // lane's pixel is computed by that lane alone from im2col to the store, so the values do not change.
 #ifdef X2_LINEAR_LANES
