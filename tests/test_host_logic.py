@@ -622,3 +622,40 @@ def test_p32_weight_packing_layout():
         got = float(rec[slab, chunk, dy * 3 + dx, kk, khalf * 32 + col, j])
         assert abs(got - float(w[co, ci, dy, dx])) <= 2.0 ** -21 * abs(float(w[co, ci, dy, dx])) + 1e-10   # (+ fp16-subnormal floor 2^-25 / 2^11)
     assert float(rec[1, :, :, :, 8:32].abs().max()) == 0 and float(rec[1, :, :, :, 40:64].abs().max()) == 0   # rows 40..63: zero padding
+
+
+@pytest.mark.parametrize('name', sorted(configs.ARCHS))
+def test_precise_plan_covers_every_named_configuration(name):
+    """engine_p32.PrecisePlan (host side of LFD.precision = 'fp32_storage'): built on CPU tensors for every named configuration
+    -- one conv op per nn.Conv2d of the module tree (a stem pair conv3x3 s2 -> conv1x1 at 64 channels counts as one chained
+    launch), one GroupNorm op per tower norm and level, output convs addressed into the [N,P,C'] / [N,P,4] tensors, packed
+    weights of the documented size, fp32 biases padded to 32-channel slabs."""
+    import torch.nn as nn
+    from lfd_amd import engine_p32
+    m = configs.build_model(name).eval()
+    plan = engine_p32.PrecisePlan(m, torch.device('cpu'))
+    convs = [o for o in plan.ops if o.kind == 'conv']
+    gns = [o for o in plan.ops if o.kind == 'gn']
+    n_conv_modules = sum(isinstance(x, nn.Conv2d) for x in m._backbone.modules())
+    head, neck = m._head, m._neck
+    nl = head._num_heads
+    per_level_head = sum(isinstance(x, nn.Conv2d) for x in
+                         list(getattr(head, 'head0_merge_path').modules()) + list(getattr(head, 'head0_classification_path').modules())
+                         + list(getattr(head, 'head0_regression_path').modules()))
+    expect = n_conv_modules + nl * (1 + per_level_head)
+    chained = sum(o.tail is not None for o in convs)
+    assert len(convs) + chained == expect, (len(convs), chained, expect)
+    stem64 = m._backbone._stem_channels in (48, 64)          # 48 is zero-padded to 64 (TL_LFD_S)
+    assert chained == ({'fast': 1, 'faster': 2, 'fastest': 0}[m._backbone._stem_mode] if stem64 else 0)
+    has_gn = head._norm_cfg is not None and head._norm_cfg['type'] == 'GroupNorm'
+    towers = 1 if head._merge_path_flag else 2
+    assert len(gns) == (nl * towers * head._num_conv_layers if has_gn else 0)
+    outs = [o for o in convs if o.out is not None]
+    assert len(outs) == 2 * nl and {o.out for o in outs} == {'cls', 'reg'} and sorted({o.level for o in outs}) == list(range(nl))
+    for o in convs:
+        ns = -(-o.cout // 32)
+        taps_chunks = 1 if o.patch else (o.cin // 32) * o.ks * o.ks      # the first conv: its 27 taps are ONE 32-wide k chunk
+        assert o.w.dtype == torch.float16 and o.w.numel() == ns * taps_chunks * 2 * 2 * 64 * 8
+        assert o.b.dtype == torch.float32 and o.b.numel() == ns * 32
+        assert o.patch == (o.src == 'input')
+    assert len(plan.taps) == nl
