@@ -441,11 +441,12 @@ constexpr int H2_CH = 12;      // longest chunk (384 pixels): 904 chunks for 8 x
 // 12-group chunks would keep 31 of 256 CUs busy).  Target: about one chunk per wave of the chip (1024), at most
 // H2_CH groups; the small levels get shorter chunks (their few chunks would otherwise be the longest-running
 // work items of the launch).  8 x 1080p: (85 + 22 + 8 + 4 + 2) chunks per image = 968 chunks = 242 work items.
-inline void h2_plan_chunks(int n, int nlev, const int* gpi, int* chg) {
+inline void h2_plan_chunks(int n, int nlev, const int* gpi, int* chg, int waves_per_simd = 1) {
   static const int forced = [] { const char* e = getenv("LFD_H2_CHUNK"); return e ? atoi(e) : 0; }();   // tests: any even value
   long total = 0;
   for (int j = 0; j < nlev; ++j) total += (long)gpi[j] * n;
-  int c = 2 * (int)((total + 2047) / 2048);
+  const long slots = 2048L * waves_per_simd;       // two groups per chunk at least; about one chunk per resident wave
+  int c = 2 * (int)((total + slots - 1) / slots);
   c = c < 2 ? 2 : (c > H2_CH ? H2_CH : c);
   if (forced >= 2) c = forced & ~1;
   for (int j = 0; j < nlev; ++j) {
@@ -479,8 +480,17 @@ __device__ unsigned long long g_h2_dbg[3 * 32];
 // A1 (output pass, with FOLD): conv2's B fragments -- ReLU(GN1(conv1(neck(x)))) in fp16, exactly the registers pass 2 fed its own
 // conv2 with -- are loaded from the buffer pass 2 wrote (lfd_head_level_ptrs_t.tower1_out) instead of recomputed: 45 instead of
 // 101 MFMAs per pixel group, no neck / conv1 filters, bit-identical outputs; costs 256 B per pixel of HBM write + read.
+// Waves per SIMD: one for every pass.  -DH2_P1_TWO gives the statistics pass of conv1 (PASS 1, which keeps only ONE tower
+// filter resident) two workgroups per CU so that the VALU half of a group could overlap the other workgroup's MFMAs --
+// measured round 3: the 256-register budget spills 116 dwords per lane into scratch and the serial step got 31 us SLOWER
+// (0.661 vs 0.629 ms under rocprofv3).  A negative result, kept as a switch.
+#ifdef H2_P1_TWO
+#define H2_WPS(PASS) ((PASS) == 1 ? 2 : 1)
+#else
+#define H2_WPS(PASS) 1
+#endif
 template <int PASS, int FT, bool DEC = false, bool FOLD = false, bool A1 = false>
-__global__ __launch_bounds__(256, 1) void k_head2(HeadArgs a) {
+__global__ __launch_bounds__(256, H2_WPS(PASS)) void k_head2(HeadArgs a) {
   static_assert(!DEC || (PASS == 3 && FT == 1), "decode rides on the output pass of a merged single-class tower");
   static_assert(!FOLD || PASS == 3, "AccVGPR-resident filters: output pass");
   static_assert(!A1 || FOLD, "stored tower-1 activations: output pass with folded filters");
@@ -990,7 +1000,8 @@ int launch_head2(const HeadArgs& a, hipStream_t st) {
       return LFD_ERR_LAUNCH_FAILED;
     done = true;
   }
-  int blocks = a.h2_nitems < 256 ? a.h2_nitems : 256;
+  constexpr int cap = 256 * H2_WPS(PASS);
+  int blocks = a.h2_nitems < cap ? a.h2_nitems : cap;
   if (blocks < 1) return LFD_OK;
   hipLaunchKernelGGL((k_head2<PASS, FT, DEC, FOLD, A1>), dim3(blocks), dim3(256), LDS, st, a);
   LFD_CHECK_LAUNCH();
@@ -1239,7 +1250,7 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
       a.grp_levels[a.grp_n] = i;
       a.grp_gpi[a.grp_n++] = (d->level_hw[i] + 31) / 32;
     }
-    h2_plan_chunks(d->n, a.grp_n, a.grp_gpi, a.h2_chg);
+    h2_plan_chunks(d->n, a.grp_n, a.grp_gpi, a.h2_chg, H2_WPS(pass));
     for (int j = 0; j < a.grp_n; ++j) {
       const int cpi = (a.grp_gpi[j] + a.h2_chg[j] - 1) / a.h2_chg[j];
       a.h2_item_start[j] = a.h2_nitems;
