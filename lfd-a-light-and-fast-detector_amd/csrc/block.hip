@@ -475,8 +475,17 @@ __global__ __launch_bounds__(512) void k_block64(BlockArgs a) {
 #ifdef BK_SETPRIO
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // the second-dispatched half loses every arbitration otherwise
 #endif
+#ifdef BK_SETPRIO3
+  if (wave >= 4) __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef BK_CONS_FIRST
+  // (A/B: the consumers as the OLDER half of the workgroup -- the older wave of a SIMD wins the issue arbitration)
+  if (wave >= 4) producer(a, smem, wave - 4, t_begin + bix, t_end, t_step);
+  else consumer(a, smem, wave, t_begin + bix, t_end, t_step);
+#else
   if (wave < 4) producer(a, smem, wave, t_begin + bix, t_end, t_step);
   else consumer(a, smem, wave - 4, t_begin + bix, t_end, t_step);
+#endif
 }
 
 }  // namespace
