@@ -263,8 +263,12 @@ __global__ __launch_bounds__(kBlock) void k_count(DecodeParams d, int* blockcoun
           cnt += s * f > d.score_thr;
         }
       } else {
+        // every e = expf(x - mx) has x - mx <= 0, i.e. e <= 1 (+ the function's few ulp): when even that is below
+        // softmax_above's sure-reject bound no class of this point can pass -- the usual case (background wins), and the
+        // second sweep of expf (half of this ALU-bound kernel) is skipped.  Written so that a NaN sum takes the loop.
         const float lo_bound = d.score_thr * sum * 0.999999f;
-        for (int c = 0; c < d.C; ++c) cnt += softmax_above(expf(rowp[c] - mx), sum, lo_bound, d.score_thr);
+        if (!(lo_bound > 1.000001f))
+          for (int c = 0; c < d.C; ++c) cnt += softmax_above(expf(rowp[c] - mx), sum, lo_bound, d.score_thr);
       }
     }
   } else if (live) {
@@ -300,13 +304,30 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
   extern __shared__ float s_rows[];
   __shared__ int smem[8];
   __shared__ uint32_t smax[kBlock / 64];
+  __shared__ int s_list[kBlock], s_off[kBlock], s_n;
   const int n = blockIdx.y, blk = blockIdx.x;
+  // softmax rows of at most 64 channels: a WAVE finishes each candidate point (lane = channel), see below
+  const bool by_wave = !EX && pcnt && d.score_mode == 1 && d.Cc <= 64;
+  // a block whose points have no candidate writes nothing (block 0 stays: it publishes the image's totals) -- with a
+  // usable threshold that is nearly every block, and the three scans below were 15 us of nothing for TT100K
+  if (pcnt && blk != 0 && blockcounts[n * nblk + blk] == 0) return;
   // base = sum of the counts of the preceding blocks of this image (fixed order -> deterministic)
   int part = 0, all = 0;
-  for (int i = threadIdx.x; i < nblk; i += kBlock) {
-    int v = blockcounts[n * nblk + i];
-    all += v;
-    if (i < blk) part += v;
+  for (int i0 = threadIdx.x; i0 < nblk; i0 += 8 * kBlock) {       // eight loads in flight, not one round trip per iteration
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * kBlock;
+      v[j] = blockcounts[n * nblk + (i < nblk ? i : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * kBlock;
+      if (i < nblk) {
+        all += v[j];
+        if (i < blk) part += v[j];
+      }
+    }
   }
   // two block reductions via the scan helper's totals
   block_excl_scan(part, &part, smem);
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
     // from global memory (softmax_stats / score_of evaluate the same expressions in the same order as the staged path)
     cnt = live ? (int)pcnt[row] : 0;
     if (EX && cnt > 0) f = ex_factor(d, row);
-    if (cnt > 0 && d.score_mode == 1) softmax_stats(d, row, &mx, &sum);
+    if (cnt > 0 && d.score_mode == 1 && !by_wave) softmax_stats(d, row, &mx, &sum);
     if (cnt == 255) {          // saturated counter (>= 255 classes above the threshold at one point): recount
       cnt = 0;
       for (int c = 0; c < d.C; ++c) {
@@ -354,7 +375,49 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
   int total;
   int off = base + block_excl_scan(cnt, &total, smem);
   uint32_t mo = 0u;
-  if (cnt > 0) {
+  if (by_wave) {
+    // A thread that walks its point's row alone runs ~140 accurate expf / divides as ONE dependent chain (25 us per block
+    // that holds a candidate; a few hundred candidates among 3e5 points, so the other 63 lanes idle).  Instead the block
+    // lists its candidate points (with their output offsets -- the list order is irrelevant) and each wave takes them in
+    // turn with lane = channel: one coalesced load of the row, one expf per lane, the max by butterfly (exact, order-free),
+    // the sum by a lane-ordered chain of adds (the SAME fp32 additions in the SAME order as softmax_stats), one divide per
+    // lane, ballot -> output slots in class order.  Same values as k_count saw, so the counts agree.
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (cnt > 0) {
+      const int i = atomicAdd(&s_n, 1);
+      s_list[i] = threadIdx.x;
+      s_off[i] = off;
+    }
+    __syncthreads();
+    const int nl = s_n, lane = lfd_lane();
+    for (int i = threadIdx.x >> 6; i < nl; i += kBlock / 64) {
+      const int pp = blk * kBlock + s_list[i];
+      const int o0 = s_off[i];
+      const int64_t r = (int64_t)n * d.P + pp;
+      const float x = lfd_load_f(d.cls, r * d.Cc + (lane < d.Cc ? lane : d.Cc - 1), d.in_dtype);
+      const float4 box = decode_box(d, n, pp);     // its loads are requested with the row's, not after the softmax chain
+      float m = lane < d.Cc ? x : -INFINITY;
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+      const float e = lane < d.Cc ? expf(x - m) : 0.f;
+      float sm = 0.f;
+      for (int c = 0; c < d.Cc; ++c) sm += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), c));
+      const float sc = e / sm;
+      const bool pass = lane < d.C && sc > d.score_thr;
+      const unsigned long long bal = __ballot(pass);
+      const int o = o0 + __popcll(bal & ((1ull << lane) - 1ull));
+      if (pass && o < b.cap) {
+        const int64_t oo = (int64_t)n * b.cap + o;
+        b.cand_box[oo] = box;
+        b.cand_score[oo] = sc;
+        b.cand_label[oo] = lane;
+        if (b.cand_point) b.cand_point[oo] = pp;
+        const uint32_t q = lfd_float_ord(fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
+        mo = q > mo ? q : mo;
+      }
+    }
+  } else if (cnt > 0) {
     const float4 box = decode_box(d, n, p);
     bool wrote = false;
     for (int c0 = 0; c0 < d.C; c0 += 8) {
