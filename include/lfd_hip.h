@@ -370,6 +370,18 @@ LFD_API int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const voi
                                       const float* b1, const void* w2_packed, const float* b2, const void* zeros,
                                       lfd_stream_t stream);
 
+/* The FIRST block of a backbone stage -- the FasterBlock with a downsample branch (lfd_resnet.py:96-154, branch :458-468) --
+ * in ONE launch:   y1 = relu(conv3x3_s2(in, w1) + b1);  ident = conv1x1_s2(in, wd) + bd;
+ *                  out = relu(conv3x3_s1(y1, w2) + b2 + ident),      64 -> 64 channels, BN folded, NHWC fp16,
+ * in [n, h, w, 64] -> out [n, (h-1)/2+1, (w-1)/2+1, 64].  y1 and ident live in LDS row rings (csrc/down.hip: a workgroup
+ * streams down a 30-column strip; producer / consumer waves, three register-stationary filters); results are bit-identical
+ * to lfd_conv2d_downsample_nhwc_f16 followed by lfd_conv2d_nhwc_f16 with `residual`.  w1_packed / w2_packed:
+ * lfd_conv_packed_weight_halfs(64, 64, 3) halfs, wd_packed: lfd_conv_packed_weight_halfs(64, 64, 1); `in` must not alias
+ * `out`; zeros: the 4096-byte line of lfd_conv2d_nhwc_f16. */
+LFD_API int lfd_downblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
+                                    const float* b1, const void* wd_packed, const float* bd, const void* w2_packed,
+                                    const float* b2, const void* zeros, lfd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Element-wise operators of the sibling necks / heads, NHWC fp16, channels a multiple of 8:
  *   lfd_upsample_nearest_add_nhwc_f16   dst[n,H,W,c] += nearest(src[n,h,w,c]) -- the merge step of FPN / SimpleFPN

@@ -623,6 +623,39 @@ def fasterblock_fused(x, w1_packed, b1, w2_packed, b2, out=None):
     return out
 
 
+def conv2d_downsample_nhwc(x, w_packed, bias, wd_packed, bd, relu=True):
+    """(relu(conv3x3 stride 2 (x) + bias), conv1x1 stride 2 (x) + bd) for NHWC fp16 [N,H,W,64]: the first launch of a
+    stage's first block with its identity branch riding on the centre tap (lfd_conv2d_downsample_nhwc_f16)."""
+    require_cuda(x, 'conv2d_downsample')
+    if x.dtype != torch.float16 or not x.is_contiguous() or x.dim() != 4:
+        raise RuntimeError('conv2d_downsample_nhwc: x must be contiguous fp16 NHWC')
+    n, h, w_, c = x.shape
+    d = _lib.ConvDesc(n, h, w_, c, c, 3, 2, int(relu), 0, 0)
+    with torch.cuda.device(x.device):
+        out = torch.empty((n, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1, c), dtype=torch.float16, device=x.device)
+        ident = torch.empty_like(out)
+        check(lib().lfd_conv2d_downsample_nhwc_f16(C.byref(d), ptr(x), ptr(out), ptr(w_packed), ptr(bias), ptr(wd_packed), ptr(bd),
+                                                   ptr(ident), ptr(zero_line(x.device)), stream_ptr()),
+              'lfd_conv2d_downsample_nhwc_f16')
+    return out, ident
+
+
+def downblock_fused(x, w1_packed, b1, wd_packed, bd, w2_packed, b2, out=None):
+    """relu(conv3x3(relu(conv3x3_s2(x, w1) + b1), w2) + b2 + conv1x1_s2(x, wd) + bd) for NHWC fp16 [N,H,W,64] in one launch
+    (csrc/down.hip): the first block of a backbone stage."""
+    require_cuda(x, 'downblock_fused')
+    if x.dtype != torch.float16 or not x.is_contiguous() or x.dim() != 4 or x.shape[3] != 64:
+        raise RuntimeError('downblock_fused: x must be contiguous fp16 NHWC with 64 channels')
+    n, h, w_, _ = x.shape
+    with torch.cuda.device(x.device):
+        if out is None:
+            out = torch.empty((n, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1, 64), dtype=torch.float16, device=x.device)
+        check(lib().lfd_downblock_fused_f16(n, h, w_, ptr(x), ptr(out), ptr(w1_packed), ptr(b1), ptr(wd_packed), ptr(bd),
+                                            ptr(w2_packed), ptr(b2), ptr(zero_line(x.device)), stream_ptr()),
+              'lfd_downblock_fused_f16')
+    return out
+
+
 # ------------------------------------------------------------------ training-mode conv stack (csrc/train.hip)
 _train_ws = {}
 
