@@ -47,7 +47,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
     """Times every launch of the plan with HIP events on the launch stream (torch's current
     stream is the stream the C ABI receives).  Returns {class: dict(time_us, launches, flops, bytes)}."""
     import ctypes as C
-    from lfd_amd import _lib, ops
+    from lfd_amd import _lib, engine, ops
     from lfd_amd._lib import check, lib, ptr, stream_ptr
     l = lib()
     z = ops.zero_line(plan.device)
@@ -89,8 +89,23 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
                                                      ptr(so), stream_ptr()), 'stem'))
         add('stem_3x3s2_3toC+1x1 (k_stem)', us, conv_flops(n, so.shape[1], so.shape[2], 3, c0, 3) +
             (conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1) if w2 is not None else 0), x.numel() * x.element_size() + so.numel() * 2)
-    for c in plan.convs:
+    skip = -1
+    for ci, c in enumerate(plan.convs):
+        if ci == skip:
+            continue
         src, dst = st.bufs[c.src], st.bufs[c.dst]
+        if c.down is not None and engine._use_fused_down(n, src.shape[1], src.shape[2]):
+            # the stage's first block in one launch (csrc/down.hip): 3x3 s2 + its 1x1 s2 branch + 3x3 s1 + add; algorithmic
+            # bytes = the input map read once + the output written once (y1 and the branch never reach HBM)
+            c2 = plan.convs[c.down]
+            dst2 = st.bufs[c2.dst]
+            us = timed(lambda: check(l.lfd_downblock_fused_f16(n, src.shape[1], src.shape[2], ptr(src), ptr(dst2), ptr(c.w), ptr(c.b),
+                                                               ptr(c.ds[0]), ptr(c.ds[1]), ptr(c2.w), ptr(c2.b), ptr(z), stream_ptr()),
+                                     'downblock'))
+            fl = (conv_flops(n, dst2.shape[1], dst2.shape[2], 64, 64, 3) * 2 + conv_flops(n, dst2.shape[1], dst2.shape[2], 64, 64, 1))
+            add('downblock_fused_conv3x3_s2+1x1_s2+conv3x3_s1_64to64 (k_down64)', us, fl, (src.numel() + dst2.numel()) * 2)
+            skip = c.down
+            continue
         d = _lib.ConvDesc(n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                           c.cout if c.tail else 0, 1 if c.tail else 0)
         if c.blk is not None:
@@ -613,6 +628,7 @@ def main():
                              'frac_mfma': round(tf / MFMA_PEAK_TFLOPS, 3), 'frac_hbm': round(gb / HBM_PEAK_GBS, 3)})
             dom = rows[0]
             # every 3x3 stride-1 64->64 conv of the backbone: the fused residual blocks + the stand-alone launches
+            # (the 3x3 s1 conv inside the fused downsample block is not separable from its HBM-bound stride-2 conv: listed on its own)
             k33c = [c for nm, c in br.items() if nm.startswith('conv3x3_s1_64to64') or nm.startswith('fasterblock_fused')]
             k33 = []
             if k33c:

@@ -313,14 +313,6 @@ __device__ __forceinline__ void down_consumer(const DownArgs& a, char* smem, int
   const int h = lane >> 5, pix = lane & 31;
   const float* sbias = reinterpret_cast<const float*>(smem + DN::OFF_BIAS) + 128;
 
-  half8 wreg[DN::NK];
-  {
-    const half8* wsrc = a.w2 + (size_t)ct * DN::NK * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < DN::NK; ++k) wreg[k] = wsrc[(size_t)k * 64];
-  }
-#pragma unroll
-  for (int k = 0; k < DN::NK; ++k) asm volatile("" : "+v"(wreg[k]));      // arrived before the first DMA (see down_producer)
   const int cbase = pix * DN::MID_PIXB + h * 16;
   const int ox = sg.ox0 + pix;
   const bool colok = pix < DN::TW && ox < a.OW;
@@ -340,6 +332,19 @@ __device__ __forceinline__ void down_consumer(const DownArgs& a, char* smem, int
   issue_row<DN_SPLIT, DN::NDMA>(a, smem, sg, ro, 1 + cw, 1 + cw);
   issue_row<DN_SPLIT, DN::NDMA>(a, smem, sg, ro, 1 < sg.J ? 5 + cw : -1, 5 + cw);
   int s_dma = wrap(9 + cw, DN::NIN);              // batch j + 2's row for this wave: 4 (j + 2) + 1 + cw
+
+  // the stationary conv2 slab -- requested AFTER the prologue DMA, so that the first input rows travel from HBM while the filter
+  // comes from L2, and forced to have ARRIVED here (which, VMEM retiring in order, drains that DMA too: it is needed in step 0
+  // anyway): left to the compiler, the wait for the filter sits at its first use inside the step loop, with a vmcnt that knows
+  // nothing of the DMA instructions issued in between and drains them every step
+  half8 wreg[DN::NK];
+  {
+    const half8* wsrc = a.w2 + (size_t)ct * DN::NK * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < DN::NK; ++k) wreg[k] = wsrc[(size_t)k * 64];
+  }
+#pragma unroll
+  for (int k = 0; k < DN::NK; ++k) asm volatile("" : "+v"(wreg[k]));
 
   // ring positions: output row ol = 2 (j - 2) + rc reads mid rows ol .. ol + 2 and ident row ol + 1
   int s_mid = rc, s_id = wrap(rc + 1, DN::NID);

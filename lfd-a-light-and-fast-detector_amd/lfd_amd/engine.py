@@ -124,9 +124,23 @@ def _tail_supported(cin, cout, ks, stride):
     return ks == 3 and stride == 2 and cin == cout and cin in (32, 64)
 
 
+def _use_fused_down(n, h, w):
+    """LFD_FUSED_DOWN: '0' never, '1' always, unset: on maps of at least 50,000 input pixels per launch, single images only from
+    4K frames on (a 1080p frame alone gives a workgroup five output rows: the whole forward measured 2 us slower) -- per shape
+    (tools/timing/down_time.py): 8 x 270 x 480: 57.6 vs 76 us for the two launches, 8 x 135 x 240: 20.0 vs 27.4, 8 x 68 x 120: 12.5
+    vs 14.3, 1 x 270 x 480: 14.9 vs 15.9; at 1 x 135 x 240 the workgroups' prologue (three filters, five input rows) is most of
+    the launch: 11.5 vs 11.1"""
+    e = os.environ.get('LFD_FUSED_DOWN', '')
+    if e == '0':
+        return False
+    if e == '1':
+        return True
+    return n * h * w >= 50000 and (n >= 2 or h * w >= 400000)
+
+
 class _Conv(object):
     """one lfd_conv2d_nhwc_f16 launch"""
-    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w', 'blk')
+    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w', 'blk', 'down')
 
 
 class _HeadLevel(object):
@@ -273,6 +287,12 @@ class EnginePlan(object):
                     y = self._add_conv(y, new_buf, pad_channels(conv.in_channels), pad_channels(conv.out_channels), conv.kernel_size[0],
                                        conv.stride[0], True, w, b, tail=tail, res=ident if last else None,
                                        ds=fuse_ds if ci == 1 else None)
+                    if (fuse_ds is not None and ci == 2 and last and tail is None and conv.kernel_size[0] == 3 and conv.stride[0] == 1
+                            and len(self.convs) >= 2 and self.convs[-2].ds is fuse_ds and self.convs[-2].cin == 64
+                            and self.convs[-2].cout == 64 and self.convs[-1].cin == 64 and self.convs[-1].cout == 64):
+                        # the whole downsample block can run as ONE launch (csrc/down.hip): conv 1 + branch + this conv.  Both
+                        # launches stay in the plan; run_backbone picks per shape (the fused kernel wins on the larger maps)
+                        self.convs[-2].down = len(self.convs) - 1
                     ci += 2 if tail is not None else 1
                 cur = y
                 if (i, j) in [tuple(t) for t in bb._out_indices]:
@@ -290,6 +310,7 @@ class EnginePlan(object):
         c.b = b.to(self.device).contiguous()
         c.tail = tail
         c.ds = ds
+        c.down = None        # index of the conv that closes this (downsample) block when the pair can run fused
         c.src = src
         c.dst = new_buf()
         c.res = res
@@ -422,10 +443,19 @@ class EnginePlan(object):
             check(l.lfd_stem_conv_f16(ptr(x), fmt, st.n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2), ptr(b2),
                                       ptr(st.bufs[self.stem_out]), sp), 'lfd_stem_conv_f16')
         z = ops.zero_line(self.device)
+        skip = -1
         for ci, c in enumerate(self.convs):
             if after and ci in after:
                 after[ci]()
+            if ci == skip:
+                continue
             src = st.bufs[c.src]
+            if c.down is not None and _use_fused_down(st.n, src.shape[1], src.shape[2]):
+                c2 = self.convs[c.down]
+                check(l.lfd_downblock_fused_f16(st.n, src.shape[1], src.shape[2], ptr(src), ptr(st.bufs[c2.dst]), ptr(c.w), ptr(c.b),
+                                                ptr(c.ds[0]), ptr(c.ds[1]), ptr(c2.w), ptr(c2.b), ptr(z), sp), 'lfd_downblock_fused_f16')
+                skip = c.down
+                continue
             if c.blk is not None:
                 check(l.lfd_fasterblock_fused_f16(st.n, src.shape[1], src.shape[2], ptr(src), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b),
                                                   ptr(c.blk[0]), ptr(c.blk[1]), ptr(z), sp), 'lfd_fasterblock_fused_f16')

@@ -71,3 +71,26 @@ def test_fused_downblock_rejects_aliasing_and_bad_shapes():
         ops.downblock_fused(x, w, b, wd, b, w, b, out=x)
     with pytest.raises(RuntimeError):
         ops.downblock_fused(torch.zeros(1, 8, 8, 32, dtype=torch.float16).cuda(), w, b, wd, b, w, b)
+
+
+@pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_S', (2, 200, 312)), ('WIDERFACE_LFD_L', (1, 240, 256)), ('TT100K_LFD_L', (1, 192, 320))])
+def test_engine_with_and_without_downblock_fusion_agree(monkeypatch, name, shape):
+    """whole network: LFD_FUSED_DOWN=1 (every qualifying first block of a stage in one launch) and =0 (two launches) give
+    identical logits; the plan marks the blocks it can fuse"""
+    from lfd_amd import configs, engine
+    outs = []
+    n, h, w = shape
+    x = (torch.rand(n, h, w, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).half().cuda()
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LFD_FUSED_DOWN', flag)
+        m = configs.build_model(name)
+        configs.perturb_weights(m)
+        m.eval().cuda()
+        with torch.no_grad():
+            outs.append([t.clone() for t in m.forward_resident(x)])
+        plan = engine.get_plan(m, m._backbone, m._neck, m._head, x.device)
+        marked = [c for c in plan.convs if c.down is not None]
+        assert all(c.ds is not None and c.ks == 3 and c.stride == 2 and c.cin == 64 and c.cout == 64 for c in marked)
+        if name == 'WIDERFACE_LFD_S':
+            assert len(marked) == 3
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
