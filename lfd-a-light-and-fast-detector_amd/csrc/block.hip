@@ -496,12 +496,29 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_block_timing(uns
 }
 #endif
 
+// block_rows.hip: the row-streaming form of the same operator (bit-identical), for large maps
+int lfd_block64_rows_launch(const _Float16* in, _Float16* out, const void* w1, const float* b1, const void* w2, const float* b2,
+                            const _Float16* zeros, int n, int h, int w, hipStream_t st);
+// LFD_BLOCK_ROWS: '0' = always the 8 x 16 tile kernel below, '1' = always the row-streaming kernel, unset = by map size
+static int block_rows_mode() {
+  static const int m = [] { const char* e = getenv("LFD_BLOCK_ROWS"); return e ? atoi(e) : -1; }();
+  return m;
+}
+#ifndef LFD_BLOCK_ROWS_MIN_PIXELS
+#define LFD_BLOCK_ROWS_MIN_PIXELS 100000L
+#endif
+
 extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
                                          const float* b1, const void* w2_packed, const float* b2, const void* zeros,
                                          lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!in || !out || !w1_packed || !b1 || !w2_packed || !b2 || !zeros || in == out) return LFD_ERR_INVALID_ARGUMENT;
   if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  {
+    const int mode = block_rows_mode();
+    if (mode == 1 || (mode < 0 && (long)n * h * w >= LFD_BLOCK_ROWS_MIN_PIXELS))
+      return lfd_block64_rows_launch((const _Float16*)in, (_Float16*)out, w1_packed, b1, w2_packed, b2, (const _Float16*)zeros, n, h, w, st);
+  }
   BlockArgs a{};
   a.in = (const _Float16*)in; a.out = (_Float16*)out;
   a.w1 = (const half8*)w1_packed; a.b1 = b1; a.w2 = (const half8*)w2_packed; a.b2 = b2;
