@@ -504,9 +504,16 @@ static int block_rows_mode() {
   static const int m = [] { const char* e = getenv("LFD_BLOCK_ROWS"); return e ? atoi(e) : -1; }();
   return m;
 }
+// measured per shape (tools/timing/block_rows_sweep.py, same session, rows vs tiles): 8 x 135 x 240 -12 %, 32 x 135 x 240 -17 %,
+// 8 x 68 x 120 -16 %, 1 x 540 x 960 -11 %, 4 x 180 x 320 -7 %, 2 x 135 x 240 -4 %; 8 x 34 x 60 +-0, 1 x 135 x 240 +10 % (a segment of
+// five rows is mostly prologue), 32 x 160 x 160 +5 % (six strips of 30 columns for 160: 12 % of the lanes idle)
 #ifndef LFD_BLOCK_ROWS_MIN_PIXELS
-#define LFD_BLOCK_ROWS_MIN_PIXELS 100000L
+#define LFD_BLOCK_ROWS_MIN_PIXELS 60000L
 #endif
+static bool block_rows_suits(int n, int h, int w) {
+  const int strips = (w + 29) / 30;
+  return (long)n * h * w >= LFD_BLOCK_ROWS_MIN_PIXELS && strips * 30 * 10 <= w * 11;
+}
 
 extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
                                          const float* b1, const void* w2_packed, const float* b2, const void* zeros,
@@ -516,7 +523,7 @@ extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const 
   if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
   {
     const int mode = block_rows_mode();
-    if (mode == 1 || (mode < 0 && (long)n * h * w >= LFD_BLOCK_ROWS_MIN_PIXELS))
+    if (mode == 1 || (mode < 0 && block_rows_suits(n, h, w)))
       return lfd_block64_rows_launch((const _Float16*)in, (_Float16*)out, w1_packed, b1, w2_packed, b2, (const _Float16*)zeros, n, h, w, st);
   }
   BlockArgs a{};

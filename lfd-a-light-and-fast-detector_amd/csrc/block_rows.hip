@@ -179,11 +179,20 @@ __device__ __forceinline__ void rows_producer(const RowsArgs& a, char* smem, int
     RT(0, 1);
     block_barrier();
     RT(0, 2);
+#ifdef RB_DMA_AT_TOP
+    // (A/B) batch j + 3 FIRST: while this wave is blocked on its DMA instructions the consumer of the SIMD has the matrix pipe to
+    // itself, and this wave's longer tail (epilogue into the mid ring) no longer follows a contraction that started late
+    rows_issue_share(a, smem, sg, dm, pw, j + 3 < sg.J ? 2 * (j + 3) + 2 + myrow : -1, s_dma);     // (filler rows keep the count)
+    s_dma = rwrap(s_dma + 2, RB::NIN);
+    RT(0, 3);
+    if (j >= sg.J) continue;
+#else
     if (j >= sg.J) {
-      rows_issue_share(a, smem, sg, dm, pw, -1, s_dma);     // (filler rows keep the count)
+      rows_issue_share(a, smem, sg, dm, pw, -1, s_dma);
       s_dma = rwrap(s_dma + 2, RB::NIN);
       continue;
     }
+#endif
     f32x16 acc;
     {
       const float* bp = sbias + ct * 32 + 4 * h;
@@ -229,8 +238,10 @@ __device__ __forceinline__ void rows_producer(const RowsArgs& a, char* smem, int
     s_in = rwrap(s_in + 2, RB::NIN);
     s_mid = rwrap(s_mid + 2, RB::NMID);
     RT(0, 5);
+#ifndef RB_DMA_AT_TOP
     rows_issue_share(a, smem, sg, dm, pw, j + 3 < sg.J ? 2 * (j + 3) + 2 + myrow : -1, s_dma);
     s_dma = rwrap(s_dma + 2, RB::NIN);
+#endif
   }
 }
 
@@ -258,11 +269,43 @@ __device__ __forceinline__ void rows_consumer(const RowsArgs& a, char* smem, int
   // (Tried: finishing the row of step j BETWEEN the MFMAs of step j + 1 -- a software-pipelined epilogue.  The contraction grew
   //  by exactly the epilogue's length, 3480 -> 3700 cycles per step: the issue slots between dependent MFMAs are not free when
   //  the other wave of the SIMD contracts as well.)
+#ifdef RB_EPI_DEFER
+  // (A/B) DEFERRED EPILOGUE: the row contracted in step j is finished at the START of step j + 1, while the producer of this
+  // SIMD contracts.  Measured with -DRB_DMA_AT_TOP / -DRB_EPI_DEFER and the stamps (tools/probe_rows.py): the step is 3480-3800
+  // CYCLES depending on the arrangement (the deferred epilogue takes 1700 cycles beside a contracting partner instead of 400),
+  // but 1.85-1.95 us of WALL time in every one of them -- the clock moves between 1.98 and 2.15 GHz to the same power.  What
+  // this kernel gains over the 8 x 16 tiles (7-19 %) is the work it does not do: 0.89 instead of 0.80 useful MFMA slots and B
+  // fragments, no second read of x.
+  f32x16 accp;
+  half4 idvp[4];
+  _Float16* op = obase;
+  bool pend = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) idvp[g] = half4{0, 0, 0, 0};
+  auto finish_all = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float x0 = accp[4 * g + 0] + (float)idvp[g][0], x1 = accp[4 * g + 1] + (float)idvp[g][1];
+      const float x2 = accp[4 * g + 2] + (float)idvp[g][2], x3 = accp[4 * g + 3] + (float)idvp[g][3];
+      uint2 v;
+      v.x = lfd_cvt_pk_max(x0, x1, LFD_PK_RELU);
+      v.y = lfd_cvt_pk_max(x2, x3, LFD_PK_RELU);
+      if (colok) *reinterpret_cast<uint2*>(op + 8 * g) = v;
+    }
+  };
+#endif
   __builtin_amdgcn_s_barrier();
   for (int j = 0; j < sg.T; ++j) {
     RT(1, 0);
     block_barrier();       // the producers awaited the DMA of this step's rows (identity: two steps old) before they arrived here
     RT(1, 2);
+#ifdef RB_EPI_DEFER
+    if (pend) finish_all();
+    pend = false;
+    RT(1, 3);
+#endif
     const int ol = 2 * (j - 2) + rc;
     if (j < 2) continue;
     if (ol < sg.rows) {
@@ -302,6 +345,13 @@ __device__ __forceinline__ void rows_consumer(const RowsArgs& a, char* smem, int
         __builtin_amdgcn_sched_barrier(0);
       }
       RT(1, 4);
+#ifdef RB_EPI_DEFER
+      accp = acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) idvp[g] = idv[g];
+      op = obase + (size_t)ol * a.W * 64;
+      pend = true;
+#else
       _Float16* o = obase + (size_t)ol * a.W * 64;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -312,11 +362,15 @@ __device__ __forceinline__ void rows_consumer(const RowsArgs& a, char* smem, int
         v.y = lfd_cvt_pk_max(x2, x3, LFD_PK_RELU);
         if (colok) *reinterpret_cast<uint2*>(o + 8 * g) = v;
       }
+#endif
     }
     s_mid = rwrap(s_mid + 2, RB::NMID);
     s_idr = rwrap(s_idr + 2, RB::NIN);
     RT(1, 5);
   }
+#ifdef RB_EPI_DEFER
+  if (pend) finish_all();
+#endif
 }
 
 __global__ __launch_bounds__(512) void k_block64_rows(RowsArgs a) {

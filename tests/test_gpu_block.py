@@ -40,6 +40,25 @@ def test_fused_block_is_bit_identical_to_two_launches(shape):
     assert not bool(bad.any()), 'mismatches: %d of %d, first at %s' % (int(bad.sum()), bad.numel(), bad.nonzero()[0].tolist())
 
 
+@pytest.mark.parametrize('mode', ['0', '1'])
+def test_both_block_kernels_are_bit_identical_to_two_launches(mode):
+    """lfd_fasterblock_fused_f16 picks the 8 x 16-tile kernel (csrc/block.hip) or the row-streaming kernel (csrc/block_rows.hip)
+    by map size; LFD_BLOCK_ROWS forces one of them -- read once per process, so each mode runs in a fresh interpreter"""
+    import os, subprocess, sys
+    code = '''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_block as t
+for shape in [(1, 1, 1), (1, 2, 3), (3, 5, 7), (1, 8, 16), (1, 9, 17), (2, 16, 32), (1, 7, 15), (2, 37, 45), (1, 31, 61), (2, 29, 90),
+              (1, 17, 30), (8, 34, 60), (8, 68, 120), (8, 135, 240), (1, 270, 480), (40, 20, 33)]:
+    one, two = t._both(*t._operands(*shape, seed=sum(shape)))
+    assert torch.isfinite(one.float()).all() and torch.equal(one, two), shape
+print('ok')
+''' % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lfd-a-light-and-fast-detector_amd'))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, LFD_BLOCK_ROWS=mode), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_fused_block_is_deterministic_and_repeatable():
     ops_ = _operands(4, 68, 120, 3)
     a, _ = _both(*ops_)

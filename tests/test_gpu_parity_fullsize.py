@@ -196,9 +196,27 @@ def test_every_backbone_launch_rederived_from_the_stored_tensors(key):
             y = y.float().half().double()
     compare('stem', st.bufs[first_dst][img:img + 1].cpu(), y, mag, flips=flips, min_exact=0.9)
     # ---- every conv launch
-    for c in plan.convs:
+    skip = -1
+    for ci, c in enumerate(plan.convs):
+        if ci == skip:
+            continue
         xin = _nchw64(st.bufs[c.src][img:img + 1].cpu())
         w64, b64 = c.ref_w.cpu().half().double(), c.b.cpu().double()
+        if c.down is not None and engine._use_fused_down(n, xin.shape[2], xin.shape[3]):
+            # the stage's first block ran as ONE launch (csrc/down.hip): conv3x3 s2 -> ReLU -> fp16, the 1x1 s2 branch -> fp16,
+            # conv3x3 s1 + branch -> ReLU; y1 and the branch exist only in LDS
+            c2 = plan.convs[c.down]
+            y1 = F.conv2d(xin, w64, b64, stride=2, padding=1).relu().float().half().double()
+            wd, bd = c.ds[3].cpu().half().double(), c.ds[1].cpu().double()
+            idn = F.conv2d(xin, wd, bd, stride=2).float().half().double()
+            w2, b2 = c2.ref_w.cpu().half().double(), c2.b.cpu().double()
+            ref = (F.conv2d(y1, w2, b2, padding=1) + idn).relu()
+            mag = conv_mag(y1, w2, b2, padding=1) + idn.abs()
+            flips = 4 * 2.0 ** -11 * float(y1.abs().max()) * float(w2.abs().max()) + 2.0 ** -11 * float(idn.abs().max())
+            compare('downsample block (3x3 s2 + 1x1 s2 + 3x3) %d->%d @%dx%d' % (c.cin, c.cout, ref.shape[2], ref.shape[3]),
+                    st.bufs[c2.dst][img:img + 1].cpu(), ref, mag, flips=flips, min_exact=0.9)
+            skip = c.down
+            continue
         ref = F.conv2d(xin, w64, b64, stride=c.stride, padding=c.ks // 2)
         mag = conv_mag(xin, w64, b64, stride=c.stride, padding=c.ks // 2)
         flips = 0.0
