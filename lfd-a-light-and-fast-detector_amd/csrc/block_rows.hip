@@ -217,7 +217,11 @@ __device__ __forceinline__ void rows_producer(const RowsArgs& a, char* smem, int
     for (int k = 0; k < PD; ++k) xq[k] = xfrag(k);
 #pragma unroll
     for (int k = 0; k < RB::NK; ++k) {
+#ifdef RB_PROBE_HALF_LDS
+      if (k + PD < RB::NK) xq[(k + PD) % (PD + 1)] = ((k + PD) & 1) ? xq[(k + PD - 1) % (PD + 1)] : xfrag(k + PD);
+#else
       if (k + PD < RB::NK) xq[(k + PD) % (PD + 1)] = xfrag(k + PD);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[k], xq[k % (PD + 1)], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -335,7 +339,11 @@ __device__ __forceinline__ void rows_consumer(const RowsArgs& a, char* smem, int
       const char* idb = smem + RB::OFF_IN + s_idr * RB::IN_ROWB + idoff;
 #pragma unroll
       for (int k = 0; k < RB::NK; ++k) {
+#ifdef RB_PROBE_HALF_LDS
+        if (k + PD < RB::NK) xq[(k + PD) % (PD + 1)] = ((k + PD) & 1) ? xq[(k + PD - 1) % (PD + 1)] : xfrag(k + PD);
+#else
         if (k + PD < RB::NK) xq[(k + PD) % (PD + 1)] = xfrag(k + PD);
+#endif
         if (k == 30) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) idv[g] = *reinterpret_cast<const half4*>(idb + 16 * g);
@@ -428,7 +436,8 @@ int lfd_block64_rows_launch(const _Float16* in, _Float16* out, const void* w1, c
   }
   a.strips = (w + RB::TW - 1) / RB::TW;
   const long cols = (long)n * a.strips;
-  int segs = (int)(cus / cols);
+  static const int target = [] { const char* e = getenv("LFD_ROWS_WGS"); return e ? atoi(e) : 0; }();     // (A/B: workgroups per launch)
+  int segs = (int)((target > 0 ? target : cus) / cols);
   if (segs < 1) segs = 1;
   int sh = (h + segs - 1) / segs;
   if (sh < 4) sh = 4;
