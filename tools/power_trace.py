@@ -1,4 +1,4 @@
-"""Shader clock / socket power of the MI355X while (a) a pure MFMA loop, (b) lfd_fasterblock_fused_f16 (k_block64) and
+"""Shader clock / socket power of the MI355X while (a) a pure MFMA loop, (b) lfd_fasterblock_fused_f16 (k_block64: 8 x 16 tiles; k_block64_rows: row streaming), lfd_downblock_fused_f16 (k_down64) and
 (c) the headline bench step run back to back for a few seconds each: rocm-smi polled from a side thread plus the in-kernel
 s_memtime / s_memrealtime ratio where the kernel has stamps.  Evidence for which ceiling the MFMA fractions are quoted
 against ("commit an sclk / power trace next to the kernel stats") -> gpurun_out/power_trace.json."""
@@ -71,10 +71,35 @@ def main():
     b1, b2 = torch.randn(64, generator=g).cuda() * 0.1, torch.randn(64, generator=g).cuda() * 0.1
     x = (torch.randn(32, 135, 240, 64, generator=g) * 0.5).half().cuda()
     y = torch.empty_like(x)
-    phase[0] = 'k_block64'
-    n, dt = run_for(4.0, lambda: ops.fasterblock_fused(x, w1, b1, w2, b2, out=y))
     gf = 2 * 2.0 * 32 * 135 * 240 * 64 * 64 * 9 / 1e9
-    res['k_block64'] = dict(launches=n, us_per_launch=round(dt / n * 1e6, 2), tflops=round(gf * n / dt / 1e3, 1))
+    # the 8 x 16-tile kernel in a child process (LFD_BLOCK_ROWS is read once per process), the row-streaming kernel here
+    phase[0] = 'k_block64'
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), 'child_tiles'], env=dict(os.environ, LFD_BLOCK_ROWS='0'),
+                       capture_output=True, text=True)
+    try:
+        res['k_block64'] = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        res['k_block64'] = {'error': r.stderr[-500:]}
+    phase[0] = 'idle2b'
+    time.sleep(1.0)
+    phase[0] = 'k_block64_rows'
+    n, dt = run_for(4.0, lambda: ops.fasterblock_fused(x, w1, b1, w2, b2, out=y))
+    res['k_block64_rows'] = dict(launches=n, us_per_launch=round(dt / n * 1e6, 2), tflops=round(gf * n / dt / 1e3, 1))
+    phase[0] = 'idle2c'
+    time.sleep(1.0)
+    # the fused downsample block at 8 x 270 x 480 -> 135 x 240 (four rotating inputs: cold reads)
+    pd = ops.pack_conv_weight((torch.randn(64, 64, 1, 1, generator=g) / 8)).cuda()
+    xd = [(torch.randn(8, 270, 480, 64, generator=g) * 0.5).half().cuda() for _ in range(4)]
+    yd = torch.empty(8, 135, 240, 64, dtype=torch.float16, device='cuda')
+    kk = [0]
+    def down():
+        kk[0] += 1
+        ops.downblock_fused(xd[kk[0] & 3], w1, b1, pd, b2, w2, b2, out=yd)
+    phase[0] = 'k_down64'
+    n, dt = run_for(4.0, down)
+    gfd = 2.0 * 8 * 135 * 240 * 64 * 64 * (9 + 1 + 9) / 1e9
+    res['k_down64'] = dict(launches=n, us_per_launch=round(dt / n * 1e6, 2), tflops=round(gfd * n / dt / 1e3, 1),
+                           tb_per_s=round((8 * 270 * 480 + 8 * 135 * 240) * 128 * n / dt / 1e12, 2))
     phase[0] = 'idle3'
     time.sleep(1.0)
     # (c) the headline step (WIDERFACE_LFD_S 8 x 1080p, forward + decode + NMS, one HIP graph, serial replay)
@@ -115,5 +140,21 @@ def main():
     print(json.dumps({k: v for k, v in res.items() if k != 'samples'}, indent=1))
 
 
+def child_tiles():
+    from lfd_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w1 = ops.pack_conv_weight((torch.randn(64, 64, 3, 3, generator=g) / 24)).cuda()
+    w2 = ops.pack_conv_weight((torch.randn(64, 64, 3, 3, generator=g) / 24)).cuda()
+    b1, b2 = torch.randn(64, generator=g).cuda() * 0.1, torch.randn(64, generator=g).cuda() * 0.1
+    x = (torch.randn(32, 135, 240, 64, generator=g) * 0.5).half().cuda()
+    y = torch.empty_like(x)
+    n, dt = run_for(4.0, lambda: ops.fasterblock_fused(x, w1, b1, w2, b2, out=y))
+    gf = 2 * 2.0 * 32 * 135 * 240 * 64 * 64 * 9 / 1e9
+    print(json.dumps(dict(launches=n, us_per_launch=round(dt / n * 1e6, 2), tflops=round(gf * n / dt / 1e3, 1))))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'child_tiles':
+        child_tiles()
+    else:
+        main()
