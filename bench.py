@@ -654,7 +654,11 @@ def main():
                 result['roofline_conv3x3_s1_64'] = {'bound': 'mfma', 'achieved': k33[0]['tflops'], 'peak': MFMA_PEAK_TFLOPS,
                                                     'unit': 'TFLOP/s', 'frac': k33[0]['frac_mfma'],
                                                     'avg_launch_us': round(k33[0]['time_us_per_forward'] / k33[0]['launches'], 2),
-                                                    'traffic': pmc.get(k33[0]['kernel']), 'traffic_source': PMC_SOURCE}
+                                                    'traffic': pmc.get(k33[0]['kernel']), 'traffic_source': PMC_SOURCE,
+                                                    # information beside the contract's peak: what a pure MFMA loop holds on this
+                                                    # part when its operands change (power cap; profiles/r03_mfma_operand_power.txt)
+                                                    'pure_mfma_loop_random_operands_tflops': 1574.0,
+                                                    'frac_of_that': round(k33[0]['tflops'] / 1574.0, 3)}
             result['kernels'] = rows
             result['forward_sum_us'] = round(tot, 1)
     if rank == 0 and world == 1 and not args.no_latency:
