@@ -490,22 +490,39 @@ class EnginePlan(object):
         l = lib()
         z = ops.zero_line(self.device)
         for gi in (range(len(st.head_groups)) if groups is None else groups):
-            sp = stream_ptr()
+            if len(st.head_groups[gi]) == 2 and decode is None and getattr(st, 'tower_overlap', False):
+                # separate classification / regression towers (TT100K_LFD_L): independent launch chains of five that read the same
+                # taps and write different tensors -- the second one runs on a side stream, so that each chain's two short
+                # finalize launches fall beside the other chain's passes
+                main = torch.cuda.current_stream()
+                st.ev_tw0.record(main)
+                with torch.cuda.stream(st.side_tw):
+                    st.side_tw.wait_event(st.ev_tw0)
+                    self._run_tower(st, st.head_groups[gi][1], None, l, z)
+                    st.ev_tw1.record(st.side_tw)
+                self._run_tower(st, st.head_groups[gi][0], None, l, z)
+                main.wait_event(st.ev_tw1)
+                continue
             for hs in st.head_groups[gi]:
-                d, lv, ab1, ab2, part = hs['desc'], hs['levels'], hs['ab1'], hs['ab2'], hs['partial']
-                if self.head_gn:
-                    for p, ab, gam, bet, eps in ((1, ab1, hs['g1'], hs['b1'], hs['eps1']), (2, ab2, hs['g2'], hs['b2'], hs['eps2'])):
-                        check(l.lfd_head_forward_f16(C.byref(d), p, lv, ptr(ab1), None, ptr(part), None, None, ptr(z), sp),
-                              'lfd_head_forward_f16(pass %d)' % p)
-                        check(l.lfd_groupnorm_finalize_fold(C.byref(d), ptr(part), gam, bet, eps, ptr(ab), lv, p, sp),
-                              'lfd_groupnorm_finalize_fold')
-                if decode is not None:
-                    ddesc, meta, out = decode
-                    check(l.lfd_head_forward_decode_f16(C.byref(d), lv, ptr(ab1), ptr(ab2), None, None, ptr(z), C.byref(ddesc),
-                                                        ptr(meta), ptr(out.ws), out.ws.numel(), sp), 'lfd_head_forward_decode_f16')
-                    continue
-                check(l.lfd_head_forward_f16(C.byref(d), 3, lv, ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg), ptr(z), sp),
-                      'lfd_head_forward_f16(pass 3)')
+                self._run_tower(st, hs, decode, l, z)
+
+    def _run_tower(self, st, hs, decode, l, z):
+        """the five launches of one tower on torch's current stream"""
+        sp = stream_ptr()
+        d, lv, ab1, ab2, part = hs['desc'], hs['levels'], hs['ab1'], hs['ab2'], hs['partial']
+        if self.head_gn:
+            for p, ab, gam, bet, eps in ((1, ab1, hs['g1'], hs['b1'], hs['eps1']), (2, ab2, hs['g2'], hs['b2'], hs['eps2'])):
+                check(l.lfd_head_forward_f16(C.byref(d), p, lv, ptr(ab1), None, ptr(part), None, None, ptr(z), sp),
+                      'lfd_head_forward_f16(pass %d)' % p)
+                check(l.lfd_groupnorm_finalize_fold(C.byref(d), ptr(part), gam, bet, eps, ptr(ab), lv, p, sp),
+                      'lfd_groupnorm_finalize_fold')
+        if decode is not None:
+            ddesc, meta, out = decode
+            check(l.lfd_head_forward_decode_f16(C.byref(d), lv, ptr(ab1), ptr(ab2), None, None, ptr(z), C.byref(ddesc),
+                                                ptr(meta), ptr(out.ws), out.ws.numel(), sp), 'lfd_head_forward_decode_f16')
+            return
+        check(l.lfd_head_forward_f16(C.byref(d), 3, lv, ptr(ab1), ptr(ab2), None, ptr(st.cls), ptr(st.reg), ptr(z), sp),
+              'lfd_head_forward_f16(pass 3)')
 
     def run_all(self, x, fmt, st, decode=None):
         """Whole forward.  The neck+head of the FIRST pyramid level (the largest, ~75 % of the head's
@@ -654,6 +671,11 @@ class _ShapeState(object):
                                                       dtype=torch.float32, device=dev)
                         calls.append(call)
                     self.head_groups.append(calls)
+                self.tower_overlap = ntow == 2 and os.environ.get('LFD_TOWER_OVERLAP', '1') == '1'
+                if self.tower_overlap:
+                    self.side_tw = torch.cuda.Stream(device=dev)
+                    self.ev_tw0 = torch.cuda.Event()
+                    self.ev_tw1 = torch.cuda.Event()
                 if self.overlap or self.split_head:
                     self.side = torch.cuda.Stream(device=dev)
                     self.ev_tap = torch.cuda.Event()

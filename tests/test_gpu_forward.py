@@ -206,3 +206,26 @@ def test_checkpoint_from_the_reference_runs_on_the_engine():
     assert cls.shape == rc.shape and reg.shape == rr.shape
     assert float((cls.cpu().sigmoid() - rc.sigmoid()).abs().max()) < 2.5e-3
     assert float((reg.cpu().sigmoid() - rr.sigmoid()).abs().max()) < 2.5e-3
+
+
+def test_separate_towers_on_two_streams_give_identical_outputs(monkeypatch):
+    """TT100K_LFD_L has separate classification / regression towers: by default the second tower's five launches run on a side
+    stream beside the first tower's (LFD_TOWER_OVERLAP=0: one after the other).  Same kernels, same operands: identical tensors,
+    eagerly and as one HIP graph."""
+    import torch
+    from lfd_amd import configs
+    x = (torch.rand(2, 192, 320, 3, generator=torch.Generator().manual_seed(3)) * 2 - 1).half().cuda()
+    outs = []
+    for flag, graph in (('1', False), ('1', True), ('0', False)):
+        monkeypatch.setenv('LFD_TOWER_OVERLAP', flag)
+        m = configs.build_model('TT100K_LFD_L')
+        configs.perturb_weights(m)
+        m.eval().cuda()
+        m.use_graph = graph
+        with torch.no_grad():
+            for _ in range(2):
+                cls, reg = m.forward_resident(x)
+            outs.append((cls.clone(), reg.clone()))
+        torch.cuda.synchronize()
+    for cls, reg in outs[1:]:
+        assert torch.equal(cls, outs[0][0]) and torch.equal(reg, outs[0][1])
