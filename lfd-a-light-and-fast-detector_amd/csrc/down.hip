@@ -23,10 +23,11 @@
 //   * 512 threads = 8 waves, PRODUCER / CONSUMER specialisation as in block.hip: waves 0-3 run conv1 (+ the 1x1 branch on
 //     the centre tap's fragments) for mid rows (2j, 2j+1) x two 32-channel slabs in step j, waves 4-7 run conv2 for
 //     output rows (2j-4, 2j-3) x two slabs; wave w and w+4 share a SIMD.  All three filters are register-stationary.
-//   * ONE s_barrier per step; the producers issue the DMA of the rows two steps ahead right after it and wait for their
-//     own share with a counted vmcnt (instructions retire in order).
+//   * ONE s_barrier per step; the CONSUMERS issue the DMA of the rows two steps ahead right after it (conv2 has fewer MFMAs
+//     per step than conv1 + branch) and wait for their own share with a counted vmcnt (instructions retire in order: every
+//     step issues exactly 9 DMA + 4 store instructions per wave).
 // Results are BIT-IDENTICAL to the two-launch path: same k order (tap-major, 16-channel group minor), bias in the
-// accumulator, the same fp16 rounding of y1 / ident, one rounding of acc + ident (tests/test_gpu_block.py).
+// accumulator, the same fp16 rounding of y1 / ident, one rounding of acc + ident (tests/test_gpu_down.py).
 #include "conv_impl.h"
 
 namespace {
