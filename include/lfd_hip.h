@@ -535,6 +535,14 @@ LFD_API int lfd_gn_train_bwd_f16(const void* dz, const void* y, const void* z, i
 /* out[n, 2i, 2j, :] = in[n, i, j, :], zero elsewhere; ho in {2*hi-1, 2*hi}, wo likewise */
 LFD_API int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t channels, int32_t ho,
                               int32_t wo, void* out, lfd_stream_t stream);
+/* Data gradient of a 3x3 stride-2 pad-1 convolution, 64 -> 64 channels, WITHOUT the zero-inserted tensor:
+ *   dx [n, h, w, 64] = conv3x3_s1(zero_insert2(dy), w)  (+ residual)   computed per output parity (1 / 2 / 2 / 4 taps),
+ * dy [n, (h-1)/2+1, (w-1)/2+1, 64]; w_packed = the data-gradient pack of the conv's weight (lfd_pack_conv_weight_train_f16 with
+ * mode 1: roles swapped, taps flipped -- the fragments lfd_conv2d_nhwc_f16 would consume on the zero-inserted tensor);
+ * residual (nullable): the gradient already collected for the same activation, added before the fp16 rounding.  Bit-identical
+ * to lfd_zero_insert2_nhwc_f16 + lfd_conv2d_nhwc_f16 (csrc/dgrad_s2.hip). */
+LFD_API int lfd_conv3x3s2_dgrad_nhwc_f16(int32_t n, int32_t h, int32_t w, const void* dy, void* dx, const void* w_packed,
+                                         const void* residual, lfd_stream_t stream);
 /* dW [cout, cin, ks, ks] fp32 (OIHW, the nn.Conv2d.weight layout) = inv_scale * sum over pixels of
  * dy (x) x for a conv with pad ks/2; x [n,h,w,cin], dy [n,ho,wo,cout]; cin, cout multiples of 8, <= 128. */
 LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,

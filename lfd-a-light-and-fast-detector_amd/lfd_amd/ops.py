@@ -751,6 +751,20 @@ def gn_train_backward(dz, y, z, groups, stats, gamma, inv_scale, dgamma, dbeta, 
     return dy
 
 
+def conv3x3s2_dgrad(dy, w_packed_dgrad, h, w, residual=None):
+    """data gradient of a 3x3 stride-2 pad-1 conv, 64 -> 64 channels: dx [N,h,w,64] from dy [N,(h-1)//2+1,(w-1)//2+1,64] without
+    the zero-inserted tensor (csrc/dgrad_s2.hip); bit-identical to zero_insert2 + conv2d_nhwc on the same packed filter"""
+    _nhwc16(dy, 'conv3x3s2_dgrad')
+    n, ho, wo, c = dy.shape
+    if c != 64 or ho != (h - 1) // 2 + 1 or wo != (w - 1) // 2 + 1:
+        raise RuntimeError('conv3x3s2_dgrad: dy must be [N, (h-1)//2+1, (w-1)//2+1, 64]')
+    with torch.cuda.device(dy.device):
+        dx = torch.empty((n, h, w, 64), dtype=torch.float16, device=dy.device)
+        check(lib().lfd_conv3x3s2_dgrad_nhwc_f16(n, h, w, ptr(dy), ptr(dx), ptr(w_packed_dgrad), ptr(residual), stream_ptr()),
+              'lfd_conv3x3s2_dgrad_nhwc_f16')
+    return dx
+
+
 def zero_insert2(t, ho, wo):
     _nhwc16(t, 'zero_insert2')
     n, hi, wi, c = t.shape

@@ -11,6 +11,8 @@ scale), fp32 accumulation on MFMA, fp32 statistics, parameters and parameter gra
 The backward is a hand-written schedule over the recorded units (no autograd inside):
     g, dy = bn_bwd(dz)  ->  dW = wgrad(x, dy)  ->  dx = conv(dy, W^T flipped) (+ gradient already collected for x)
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -344,11 +346,15 @@ def backward(units, saved, grads, scale=None, store=None, trace=None):
             ops.stem_conv0_wgrad(xin, dy, inv, out=dw, accumulate=True)
         else:
             ops.conv_wgrad(xin, dy, ks, st, inv, out=dw, accumulate=True)
-            if st == 2:
-                dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
             cin = conv.in_channels
-            grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, ks, 1,
-                                           False, residual=grads.get(u.src))
+            if (st == 2 and ks == 3 and cin == 64 and conv.out_channels == 64 and os.environ.get('LFD_DGRAD_S2', '1') == '1'):
+                # per output parity, 9 tap-products per 2 x 2 pixels instead of 36 and no zero-inserted tensor (csrc/dgrad_s2.hip)
+                grads[u.src] = ops.conv3x3s2_dgrad(dy, packs(conv.weight, True), xin.size(1), xin.size(2), residual=grads.get(u.src))
+            else:
+                if st == 2:
+                    dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
+                grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, ks, 1,
+                                               False, residual=grads.get(u.src))
             if rec is not None:
                 rec['dx'] = grads[u.src]
         if rec is not None:      # this unit's own contribution (the buffers accumulate over shared modules)

@@ -411,3 +411,34 @@ def test_whole_network_train_forward_backward(name, hw, monkeypatch):
         worst = min(worst, (cs, k))
         assert cs > 0.999 and 0.98 < ratio < 1.02, (k, cs, ratio)
     print('mask-replay end-to-end gradients %s: worst cos %.6f (%s)' % (name, worst[0], worst[1]))
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (1, 2, 2), (2, 5, 7), (1, 16, 32), (1, 17, 33), (3, 31, 30), (2, 64, 64), (1, 160, 160), (4, 159, 161)])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_stride2_data_gradient_per_parity_is_bit_identical_to_the_zero_inserted_conv(shape, with_res):
+    """lfd_conv3x3s2_dgrad_nhwc_f16 (csrc/dgrad_s2.hip): dx per output parity (1 / 2 / 2 / 4 taps) == conv3x3 over the
+    zero-inserted dy with the same data-gradient filter pack, bit for bit (the skipped products are exact zeros and the taps that
+    remain are visited in the same order); also against a float64 conv_transpose of the fp16 operands."""
+    import torch.nn.functional as F
+    n, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(with_res))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dy = (torch.randn(n, ho, wo, 64, generator=g) * 0.5).half().cuda()
+    weight = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda()
+    res = (torch.randn(n, h, w, 64, generator=g) * 0.5).half().cuda() if with_res else None
+    wp = ops.pack_conv_weight_train(weight, data_gradient=True)
+    zeros = torch.zeros(64, device='cuda')
+    ref = ops.conv2d_nhwc(ops.zero_insert2(dy, h, w), wp, zeros, 64, 64, 3, 1, False, residual=res)
+    got = ops.conv3x3s2_dgrad(dy, wp, h, w, residual=res)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.isfinite(got.float()).all()
+    bad = got != ref
+    assert not bool(bad.any()), 'mismatches: %d of %d, first at %s' % (int(bad.sum()), bad.numel(), bad.nonzero()[0].tolist())
+    # independent check: autograd's transposed convolution in float64 on the fp16-rounded operands
+    w16 = weight.half().double().cpu()
+    dy64 = dy.double().cpu().permute(0, 3, 1, 2)
+    dx64 = F.conv_transpose2d(dy64, w16, stride=2, padding=1, output_padding=(h - 1 - 2 * (ho - 1), w - 1 - 2 * (wo - 1)))
+    if with_res:
+        dx64 = dx64 + res.double().cpu().permute(0, 3, 1, 2)
+    err = (got.double().cpu().permute(0, 3, 1, 2) - dx64).abs()
+    assert bool((err <= 2e-3 * dx64.abs().clamp(min=1.0)).all()), float(err.max())
