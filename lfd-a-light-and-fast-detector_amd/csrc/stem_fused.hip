@@ -1118,6 +1118,10 @@ int dispatch_fmt(int fmt, const FusedArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// stem_rows.hip: the row-streaming form of the same operator (NHWC fp16 frames, W % 128 == 0, 16-byte aligned base)
+int lfd_stem_rows_launch(const void* in, void* out, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                         const float* b3, const void* w4, const float* b4, int n, int h, int w, hipStream_t st);
+
 extern "C" {
 
 int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
@@ -1142,6 +1146,13 @@ int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int3
   // fp16 frames, a 16-byte aligned base (LFD_X2_ALN=0 forces the general kernel: tests compare the two bit for bit)
   static const int use_aln = [] { const char* e = getenv("LFD_X2_ALN"); return e ? atoi(e) : 1; }();
   const bool aln = use_aln && (w % 8) == 0;
+  // LFD_STEM_ROWS=1: the row-streaming kernel (stem_rows.hip) whenever the frame suits it.  OFF by default: measured equal to
+  // k_stem2x (8 x 1080p: 165-181 us against 168; 1 x 1080p: 31.4 against 32.4) -- see the header of stem_rows.hip for why.
+  static const int use_rows = [] { const char* e = getenv("LFD_STEM_ROWS"); return e ? atoi(e) : 0; }();
+  if (use_rows == 1 && channels == 64 && in_format == IN_NHWC_F16 && (w % 128) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+    const int rc = lfd_stem_rows_launch(in, out, w1_packed, b1, w2_packed, b2, w3_packed, b3, w4_packed, b4, n, h, w, st);
+    if (rc != LFD_ERR_UNSUPPORTED) return rc;
+  }
   if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) {
     if (aln && (reinterpret_cast<uintptr_t>(in) & 15) == 0) return launch_stem2x<false, true>(a, st);
     return launch_stem2x<false, false>(a, st);
