@@ -1146,10 +1146,12 @@ int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int3
   // fp16 frames, a 16-byte aligned base (LFD_X2_ALN=0 forces the general kernel: tests compare the two bit for bit)
   static const int use_aln = [] { const char* e = getenv("LFD_X2_ALN"); return e ? atoi(e) : 1; }();
   const bool aln = use_aln && (w % 8) == 0;
-  // LFD_STEM_ROWS=1: the row-streaming kernel (stem_rows.hip) whenever the frame suits it.  OFF by default: measured equal to
-  // k_stem2x (8 x 1080p: 165-181 us against 168; 1 x 1080p: 31.4 against 32.4) -- see the header of stem_rows.hip for why.
+  // LFD_STEM_ROWS=1: the row-streaming kernel (stem_rows.hip) whenever the frame suits it.  OPT-IN: measured against k_stem2x
+  // (graph-captured chains over rotating inputs) 1 x 1080p 30.0 vs 32.2 us, 2 x 1080p 48.2 vs 54.3, 8 x 640 x 640 45.7 vs 49.3, but
+  // EQUAL at 8 x 1080p and 4 x 720p (165 us: both at the chip's power limit) -- and it differs from k_stem2x in the last fp16 bit
+  // of a few outputs per million, which the uint8-frame path (k_stem2x<U8>) is tested to match bit for bit.
   static const int use_rows = [] { const char* e = getenv("LFD_STEM_ROWS"); return e ? atoi(e) : 0; }();
-  if (use_rows == 1 && channels == 64 && in_format == IN_NHWC_F16 && (w % 128) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+  if (use_rows == 1 && channels == 64 && in_format == IN_NHWC_F16 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
     const int rc = lfd_stem_rows_launch(in, out, w1_packed, b1, w2_packed, b2, w3_packed, b3, w4_packed, b4, n, h, w, st);
     if (rc != LFD_ERR_UNSUPPORTED) return rc;
   }

@@ -6,10 +6,9 @@
 // (VALU-heavy: gathers, packs, LDS writes), then the 3x3 s2 contraction -- alternate inside that one wave and nothing overlaps
 // them: SQ MFMA-pipe busy 0.46, VALU active 0.45, 0.33-0.37 of the MFMA peak.  Here the two phases belong to DIFFERENT waves of
 // the same SIMD (the producer / consumer split of block.hip, down.hip) and rows stream through LDS rings (down.hip):
-//   * a 512-thread workgroup owns a strip of 32 output columns (one MFMA pixel tile per output row) and walks down a segment
-//     of output rows, two per step;
-//   * waves 0-3 PRODUCE four rows of the 64-channel stride-2 intermediate per step (4 x 65 pixels, numbered linearly: 9 MFMA
-//     tiles): conv 1 as two K = 16 MFMAs per 32-channel slab on a K layout of 3 rows x (1 junk + 9 values) -- each lane's
+//   * a 512-thread workgroup owns a strip of 31 output columns (one MFMA pixel tile per output row, lane 31 idle) and walks down
+//     a segment of output rows, two per step;
+//   * waves 0-3 PRODUCE four rows of the 64-channel stride-2 intermediate per step (4 x 64 pixels = 8 MFMA tiles, two per wave): conv 1 as two K = 16 MFMAs per 32-channel slab on a K layout of 3 rows x (1 junk + 9 values) -- each lane's
 //     fragments are EIGHT aligned dword reads from the raw ring, no packing arithmetic --, ReLU -> fp16 in registers, which
 //     ARE the B fragments of the 1x1 under a K permutation of its filter (gathered once per wave from the standard pack),
 //     ReLU -> fp16 -> the intermediate ring in the de-interleaved, XOR-swizzled layout of the stride-2 contraction;
@@ -18,17 +17,14 @@
 //     channels of a row -> ReLU -> fp16 -> stores (the consumers are the longer chain of a step).  The consumers also issue the
 //     LDS-DMA of the raw rows (one 16-byte-per-lane instruction per row, two rows per wave and step, counted vmcnt);
 //   * one s_barrier per step.
-// STATUS (round 3): correct (within one fp16 ulp of k_stem2x and of the two-kernel stem on every tested frame), NOT faster, opt-in
-// (LFD_STEM_ROWS=1).  Phase stamps (tools/probe_stem_rows.py, -DLFD_SROWS_TIMING): a step (two output rows) is ~5600 cycles for
-// 67 MFMAs per SIMD; the producer wave that owns three of the step's nine tiles needs 5100 of them -- ~610 instructions, i.e. 8
-// cycles per instruction: a tile is ONE dependent chain (window reads -> 2 MFMAs -> pack -> 4 MFMAs -> pack -> writes) with two
-// independent accumulator chains at most, beside a consumer that issues an MFMA-dense loop on the same SIMD.  Two tiles in lock
-// step need more registers than the wave has (spills), biases in registers instead of LDS, the bias as the first MFMA's C operand
-// and s_setprio on the producers all measured within noise.  What would change it: 64 intermediate columns per strip (31 output
-// columns: eight tiles, two per producer wave, and 256 instead of 240 workgroups) -- needs an 8-byte-granular left border of the raw
-// rows; not built.
-// Requirements (else lfd_stem_faster_fused_f16 keeps k_stem2x): 64 channels, NHWC fp16 frame, 16-byte aligned base, W % 128 == 0
-// (whole strips; rows are 16-byte aligned).  Rounding points as in k_stem2x (fp16 after every ReLU); summation order differs:
+// STATUS (round 3): within one fp16 ulp of k_stem2x and of the two-kernel stem on every tested frame.  A strip is 31 output columns
+// = 64 intermediate columns = eight producer tiles per step, two per producer wave (a first version with 32 / 65 columns had nine:
+// the wave with three was the critical path of a 5600-cycle step; now ~4500, producers 3700, consumers 4300), 256 workgroups at
+// 8 x 1080p.  Against k_stem2x (tools/timing/stem_rows_time.py): -7 % at 1 x 1080p, -11 % at 2 x 1080p, equal at 8 x 1080p, where
+// both run at the power limit -- opt-in (LFD_STEM_ROWS=1, stem_fused.hip): the gain at batch 1 is 2 us of a 220 us forward.  Tried without effect: two producer
+// tiles in lock step (registers), biases in registers / as the first MFMA's C operand, s_setprio on the producers.
+// Requirements (else lfd_stem_faster_fused_f16 keeps k_stem2x): 64 channels, NHWC fp16 frame, 16-byte aligned base, W % 4 == 0 (raw
+// rows 8-byte aligned).  Rounding points as in k_stem2x (fp16 after every ReLU); summation order differs:
 // the two agree to ~1 fp16 ulp (tests/test_gpu_conv.py).
 #include "conv_impl.h"
 #include <type_traits>
@@ -51,16 +47,16 @@ struct SRArgs {
 };
 
 struct SR {
-  static constexpr int TW = 32;                        // output columns of a strip = one MFMA pixel tile
-  static constexpr int IW = 2 * TW + 1;                // 65 intermediate columns
-  static constexpr int IWh = (IW + 1) / 2, IWs = 2 * IWh;
+  static constexpr int TW = 31;                        // output columns of a strip (one MFMA pixel tile, lane 31 idle)
+  static constexpr int IW = 64;                        // intermediate columns: 2 ox0 - 1 .. 2 ox0 + 62
+  static constexpr int IWh = 33, IWs = 66;             // ring row layout of down.hip (65 columns wide: column 64 unused)
   static constexpr int IN_ROWB = IWs * 128;            // 8448: intermediate ring row (layout of down.hip's input ring)
   static constexpr int NI = 10;                        // intermediate ring rows (9 live)
-  static constexpr int RAW_PX = 4 * TW + 8;            // 136 raw pixels: columns 4 ox0 - 8 .. 4 ox0 + 127
-  static constexpr int RAW_ROWB = RAW_PX * 6;          // 816 bytes = 51 lanes x 16
+  static constexpr int RAW_LANES = 49;                 // raw columns 4 ox0 - 4 .. 4 ox0 + 126 (784 bytes = 49 lanes x 16)
+  static constexpr int RAW_ROWB = 816;
   static constexpr int NRAW = 32;                      // raw ring rows
   static constexpr int PIXB = 144;
-  static constexpr int Y3_ROWB = TW * PIXB;            // 4608
+  static constexpr int Y3_ROWB = 32 * PIXB;            // 4608 (all 32 lanes of an MFMA tile write, the 32nd column is not an output)
   static constexpr int NK = 36;
   static constexpr int OFF_I = 0;
   static constexpr int OFF_RAW = OFF_I + NI * IN_ROWB;                 // 84480
@@ -68,7 +64,7 @@ struct SR {
   static constexpr int OFF_BIAS = OFF_Y3 + 2 * 2 * Y3_ROWB;            // [step parity][row][32 px][144]
   static constexpr int LDS_BYTES = OFF_BIAS + 4 * 64 * 4;
   static constexpr int OFF_DUMMY = OFF_RAW + NRAW * RAW_ROWB;          // 1024 bytes: filler DMA target (first 16: kept zero? no: see OFF_ZERO)
-  static constexpr int M_STEP = 4 * IW;                // 260 intermediate pixels per step
+  static constexpr int M_STEP = 4 * IW;                // 256 intermediate pixels per step = 8 tiles
 };
 static_assert(SR::LDS_BYTES <= 160 * 1024, "LDS capacity");
 
@@ -148,7 +144,7 @@ __device__ __forceinline__ void sr_producer(const SRArgs& a, char* smem, int pw,
     for (int i = 0; i < 8; ++i) { rsel[i] = h ? r1[i] : r0[i]; dcst[i] = 4 * (h ? d1[i] : d0[i]); }
   }
   // this wave's tiles of the step's 260 intermediate pixels: pw, pw + 4 and (wave 0) 8
-  const int ntile = pw == 0 ? 3 : 2;
+  const int ntile = 2;
   int t_irow[3], t_icol[3], t_woff[3];
   bool t_ok[3];
 #pragma unroll
@@ -172,7 +168,7 @@ __device__ __forceinline__ void sr_producer(const SRArgs& a, char* smem, int pw,
 #pragma unroll
   for (int k = 0; k < 4; ++k) w4r[k] = a.w4[((size_t)tct * 4 + k) * 64 + lane];
   const int ox = sg.ox0 + pix;
-  const bool colok = ox < a.W2;
+  const bool colok = pix < SR::TW && ox < a.W2;
   _Float16* obase = a.out + (((size_t)sg.n * a.H2 + sg.oy0) * a.W2 + (colok ? ox : 0)) * 64 + tct * 32 + 4 * h;
   const int y3r = trc * SR::Y3_ROWB + pix * SR::PIXB + h * 16;
 
@@ -202,7 +198,7 @@ __device__ __forceinline__ void sr_producer(const SRArgs& a, char* smem, int pw,
       const int k = k0 + u;
       int radr[4];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) radr[r] = SR::OFF_RAW + swrap(swrap(s_raw + 2 * t_irow[k] + r, SR::NRAW), SR::NRAW) * SR::RAW_ROWB + 28 + 12 * t_icol[k];
+      for (int r = 0; r < 3; ++r) radr[r] = SR::OFF_RAW + swrap(swrap(s_raw + 2 * t_irow[k] + r, SR::NRAW), SR::NRAW) * SR::RAW_ROWB + 4 + 12 * t_icol[k];
       radr[3] = zero_addr;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -315,38 +311,68 @@ __device__ __forceinline__ void sr_producer(const SRArgs& a, char* smem, int pw,
 }
 
 // ------------------------------------------------------------------------------------------------ consumer (conv 3 + 1x1)
+// INTERIOR is a template parameter: with both raw-row paths in ONE loop the compiler waits (vmcnt 0) for the border path's register
+// loads at the join behind the branch -- i.e. for the DMA just issued on the interior path (2800 cycles per step)
+template <bool INTERIOR>
 __device__ __forceinline__ void sr_consumer(const SRArgs& a, char* smem, int cw, const SSeg& sg) {
   const int lane = threadIdx.x & 63;
   const int ct = cw & 1, rc = cw >> 1;
   const int h = lane >> 5, pix = lane & 31;
   const float* sbias = reinterpret_cast<const float*>(smem + SR::OFF_BIAS);
 
-  // ---- raw rows: batch b = raw rows 8 b - 5 .. 8 b + 2 (row 8 b - 6 came with batch b - 1), two rows per consumer wave; one
-  // 16-byte-per-lane DMA per row (51 lanes).  Rows above / below the frame and the three chunks left of column 0 (first strip)
-  // are written as zeros by ds_write; a row that is not fetched still issues its DMA (into a dummy window) so that the counted
-  // vmcnt waits hold.
+  // ---- raw rows: batch b = raw rows 8 b - 5 .. 8 b + 2 (row 8 b - 6 came with batch b - 1), two rows per consumer wave.  A row of
+  // the strip = raw columns 4 ox0 - 4 .. 4 ox0 + 126, 784 bytes = 49 chunks of 16 (8-byte aligned in memory).
+  //   INTERIOR strips (every chunk inside the frame's row): one 16-byte-per-lane LDS-DMA per row, two steps ahead, counted vmcnt;
+  //   a row above / below the frame is written as zeros by ds_write and still issues a DMA (into a dummy window) to keep the count.
+  //   BORDER strips (the first: columns -4 .. -1 are conv 1's zero padding and end in the middle of a chunk; the last ones: the
+  //   row ends inside the strip): the chunks go through registers -- requested in step s, written to LDS in step s + 1 -- with
+  //   chunks that straddle the frame's edge assembled from their valid halves.  No DMA, no counted wait in these workgroups.
   const unsigned rowpitch = (unsigned)a.W * 6u;
   const char* img = reinterpret_cast<const char*>(a.in) + (long)sg.n * a.H * (long)rowpitch;
-  const bool left = sg.ox0 == 0;
-  const char* lane_src = img + ((long)4 * sg.ox0 - 8) * 6 + lane * 16;      // this lane's chunk in raw row 0 of the image
-  const bool lane_in = lane < 51 && !(left && lane < 3);
-  auto issue_raw = [&](int rl, int slot) {
-    const int gy = 4 * sg.oy0 - 3 + rl;
-    const bool rv = rl >= 0 && gy >= 0 && gy < a.H;
-    char* ldst = smem + SR::OFF_RAW + slot * SR::RAW_ROWB;
-    if (rv) {
-      if (lane_in) dma16(lane_src + (unsigned long)rowpitch * (unsigned)gy, ldst);
-      if (left && lane < 3) *reinterpret_cast<uint4*>(ldst + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+  const long b0 = ((long)4 * sg.ox0 - 4) * 6;                        // byte offset of the strip's first column in a raw row
+  const long c0 = b0 + lane * 16;                                    // this lane's chunk
+  const bool lane_in = lane < SR::RAW_LANES;
+  const bool chunk_full = c0 >= 0 && c0 + 16 <= (long)rowpitch;
+  const char* lane_src = img + (chunk_full ? c0 : 0);
+  auto slot_of = [](int rl) { return (rl + 4 * SR::NRAW) & (SR::NRAW - 1); };
+  auto row_valid = [&](int rl) { const int gy = 4 * sg.oy0 - 3 + rl; return rl >= 0 && gy >= 0 && gy < a.H; };
+  auto issue_raw = [&](int rl) {                                     // interior strips
+    char* ldst = smem + SR::OFF_RAW + slot_of(rl) * SR::RAW_ROWB;
+    if (row_valid(rl)) {
+      if (lane_in) dma16(lane_src + (unsigned long)rowpitch * (unsigned)(4 * sg.oy0 - 3 + rl), ldst);
     } else {
-      if (lane < 51) *reinterpret_cast<uint4*>(ldst + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+      if (lane_in) *reinterpret_cast<uint4*>(ldst + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
       if (lane < 16) dma16(img + lane * 16, smem + SR::OFF_DUMMY);     // any valid address: the data goes to the dummy window
     }
   };
-  auto issue_batch = [&](int b) {
-    const int r0 = 8 * b - 5 + 2 * cw;
-    issue_raw(r0, (r0 + 4 * SR::NRAW) & (SR::NRAW - 1));
-    issue_raw(r0 + 1, (r0 + 1 + 4 * SR::NRAW) & (SR::NRAW - 1));
+  // border strips: this lane's chunk as two 8-byte pieces (rows and the strip's first byte are 8-byte aligned: a piece is inside the
+  // frame's row or outside it, never across its edge).  load_chunk only LOADS (from a clamped address); zero-filling happens at
+  // store time, one step later, from the positions alone -- any arithmetic on the loaded values here would put the load's latency
+  // on this step's critical path.
+  const bool v_lo = c0 >= 0 && c0 + 8 <= (long)rowpitch, v_hi = c0 + 8 >= 0 && c0 + 16 <= (long)rowpitch;
+  const char* src_lo = img + (v_lo ? c0 : 0);
+  const char* src_hi = img + (v_hi ? c0 + 8 : 0);
+  auto load_chunk = [&](int rl) {
+    const int gy = 4 * sg.oy0 - 3 + rl;
+    const unsigned long ro = (unsigned long)rowpitch * (unsigned)(row_valid(rl) ? gy : 0);
+    const uint2 lo = *reinterpret_cast<const uint2*>(src_lo + ro), hi = *reinterpret_cast<const uint2*>(src_hi + ro);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
+  auto store_chunk = [&](int rl, uint4 v) {
+    const bool rv = row_valid(rl);
+    if (!(rv && v_lo)) { v.x = 0u; v.y = 0u; }
+    if (!(rv && v_hi)) { v.z = 0u; v.w = 0u; }
+    if (lane_in) *reinterpret_cast<uint4*>(smem + SR::OFF_RAW + slot_of(rl) * SR::RAW_ROWB + lane * 16) = v;
+  };
+  const int myrow0 = -5 + 2 * cw;                                    // this wave's first row of batch 0
+  uint4 pend[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  auto issue_batch = [&](int b) {
+    if constexpr (INTERIOR) { issue_raw(8 * b + myrow0); issue_raw(8 * b + myrow0 + 1); }
+  };
+  if constexpr (!INTERIOR) {       // batches 0 and 1 straight into the ring
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { store_chunk(8 * b + myrow0, load_chunk(8 * b + myrow0)); store_chunk(8 * b + myrow0 + 1, load_chunk(8 * b + myrow0 + 1)); }
+  }
   issue_batch(0);
   issue_batch(1);
 
@@ -375,11 +401,18 @@ __device__ __forceinline__ void sr_consumer(const SRArgs& a, char* smem, int cw,
   __builtin_amdgcn_s_barrier();
   for (int s = 0; s < sg.T; ++s) {
     ST(1, 0);
-    sr_wait_vmcnt<2>();    // batch s landed (batch s + 1, two instructions, may be in flight); no other VMEM in this loop
+    if constexpr (INTERIOR) sr_wait_vmcnt<2>();    // batch s landed (batch s + 1, two instructions, may be in flight); no other VMEM in this loop
     ST(1, 1);
     block_barrier();
     ST(1, 2);
-    issue_batch(s + 2);
+    if constexpr (INTERIOR) {
+      issue_batch(s + 2);
+    } else {
+      // batch s + 1 (requested a step ago) -> ring; batch s + 2 -> registers.  (Step 0 writes nothing: batch 1 is in the ring.)
+      if (s > 0) { store_chunk(8 * (s + 1) + myrow0, pend[0]); store_chunk(8 * (s + 1) + myrow0 + 1, pend[1]); }
+      pend[0] = load_chunk(8 * (s + 2) + myrow0);
+      pend[1] = load_chunk(8 * (s + 2) + myrow0 + 1);
+    }
     ST(1, 3);
     ST(1, 4);
     // ---- conv 3 for output row 2 j + rc, j = s - 2: intermediate rows 4 j + 2 rc + r
@@ -458,7 +491,11 @@ __global__ __launch_bounds__(512) void k_stem_rows(SRArgs a) {
   if (wave < 4) __builtin_amdgcn_s_setprio(2);
 #endif
   if (wave < 4) sr_producer(a, smem, wave, sg);
-  else sr_consumer(a, smem, wave - 4, sg);
+  else {
+    const long b0 = ((long)4 * sg.ox0 - 4) * 6, rowb = (long)a.W * 6;      // the strip's raw columns lie inside the frame's row?
+    if (b0 >= 0 && b0 + SR::RAW_LANES * 16 <= rowb) sr_consumer<true>(a, smem, wave - 4, sg);
+    else sr_consumer<false>(a, smem, wave - 4, sg);
+  }
 }
 
 }  // namespace
@@ -472,7 +509,7 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_srows_timing(uns
 // called by lfd_stem_faster_fused_f16 (stem_fused.hip); LFD_ERR_UNSUPPORTED = the shape does not suit this kernel
 int lfd_stem_rows_launch(const void* in, void* out, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                          const float* b3, const void* w4, const float* b4, int n, int h, int w, hipStream_t st) {
-  if ((w % 128) != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return LFD_ERR_UNSUPPORTED;
+  if ((w % 4) != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return LFD_ERR_UNSUPPORTED;      // raw rows 8-byte aligned
   SRArgs a{};
   a.in = (const _Float16*)in; a.out = (_Float16*)out;
   a.w1 = (const half8*)w1; a.b1 = b1; a.w2 = (const half8*)w2; a.b2 = b2; a.w3 = (const half8*)w3; a.b3 = b3; a.w4 = (const half8*)w4; a.b4 = b4;
@@ -489,7 +526,7 @@ int lfd_stem_rows_launch(const void* in, void* out, const void* w1, const float*
       return LFD_ERR_LAUNCH_FAILED;
     cus = c;
   }
-  a.strips = a.W2 / SR::TW;
+  a.strips = (a.W2 + SR::TW - 1) / SR::TW;
   const long cols = (long)n * a.strips;
   int segs = (int)(cus / cols);
   if (segs < 1) segs = 1;
