@@ -132,6 +132,13 @@ def test_engine_plan_structure_on_cpu():
     assert sum(1 for c in plan.convs if c.blk is not None) == 5 and len(plan.convs) == 22 - 5
     assert all(c.res == c.src and c.cin == c.cout == 64 for c in plan.convs if c.blk is not None)
     assert sum(1 for c in plan.convs if c.ds is not None) == 4
+    # the three 64 -> 64 first blocks of a stage can run as ONE launch (csrc/down.hip): the stride-2 conv points at the conv that
+    # closes its block; the 64 -> 128 one cannot.  run_backbone decides per shape (engine._use_fused_down)
+    marked = [i for i, c in enumerate(plan.convs) if c.down is not None]
+    assert len(marked) == 3 and all(plan.convs[i].down == i + 1 and plan.convs[i].ds is not None and plan.convs[i].cout == 64
+                                     and plan.convs[i + 1].res == plan.convs[i].ds[2] and plan.convs[i + 1].ks == 3 for i in marked)
+    assert engine._use_fused_down(8, 270, 480) and engine._use_fused_down(8, 68, 120) and engine._use_fused_down(1, 540, 960)
+    assert not engine._use_fused_down(1, 270, 480) and not engine._use_fused_down(8, 34, 60)
     assert len(plan.taps) == 5 and len(plan.levels) == 5
     assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
     assert all(len(lv.towers) == 1 and lv.towers[0].reg_rows == 4 and lv.towers[0].cls_rows == 1 for lv in plan.levels)
