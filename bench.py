@@ -140,7 +140,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             # the same tensor as the input; the intermediate never reaches HBM)
             fl *= 2
             by = (src.numel() + dst.numel()) * 2
-            name = 'fasterblock_fused_2x_conv3x3_s1_64to64 (k_block64)'
+            name = 'fasterblock_fused_2x_conv3x3_s1_64to64 (k_block64_rows on large maps, k_block64 on small ones)'
         add(name, us, fl, by)
     us = timed(lambda: plan.run_head(st))
     hf = 0.0
@@ -634,7 +634,7 @@ def main():
             if k33c:
                 t33 = sum(c['time_us'] for c in k33c)
                 f33 = sum(c['flops'] for c in k33c)
-                k33 = [{'kernel': 'all conv3x3 s1 64->64 (k_block64 fused blocks + k_conv)', 'tflops': round(f33 / t33 / 1e6, 1),
+                k33 = [{'kernel': 'all conv3x3 s1 64->64 (fused residual blocks k_block64_rows / k_block64 + stand-alone k_conv)', 'tflops': round(f33 / t33 / 1e6, 1),
                         'frac_mfma': round(f33 / t33 / 1e6 / MFMA_PEAK_TFLOPS, 3), 'time_us_per_forward': round(t33, 1),
                         'launches': sum(c['launches'] for c in k33c)}]
             pmc = {}

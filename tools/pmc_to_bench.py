@@ -18,8 +18,8 @@ fwd = sum(raw[k]['launches_sampled'] for k in stem) or None
 out = {
     'conv3x3_s1_64to64 (k_conv)': wavg(['k_conv<cin=64,k=3,s=1,nct=2>', 'k_conv<cin=64,k=3,s=1,nct=2,res>']),
     'whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem2x)': wavg(stem),
-    'fasterblock_fused_2x_conv3x3_s1_64to64 (k_block64)': wavg(['k_block64', 'k_block64_rows']),      # tiles on small maps, rows on large ones
-    'all conv3x3 s1 64->64 (k_block64 fused blocks + k_conv)': wavg(['k_block64', 'k_block64_rows', 'k_conv<cin=64,k=3,s=1,nct=2>', 'k_conv<cin=64,k=3,s=1,nct=2,res>']),
+    'fasterblock_fused_2x_conv3x3_s1_64to64 (k_block64_rows on large maps, k_block64 on small ones)': wavg(['k_block64', 'k_block64_rows']),      # tiles on small maps, rows on large ones
+    'all conv3x3 s1 64->64 (fused residual blocks k_block64_rows / k_block64 + stand-alone k_conv)': wavg(['k_block64', 'k_block64_rows', 'k_conv<cin=64,k=3,s=1,nct=2>', 'k_conv<cin=64,k=3,s=1,nct=2,res>']),
     'downblock_fused_conv3x3_s2+1x1_s2+conv3x3_s1_64to64 (k_down64)': wavg(['k_down64']),
     'conv3x3_s2_64to64+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=2,ds>']),
     'conv3x3_s2_64to128+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=4,ds>']),
