@@ -710,8 +710,14 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
 __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __restrict__ x,
                                                               const __half* __restrict__ dy, int n, int h, int w,
                                                               int c, float* partials) {
-  __shared__ __attribute__((aligned(16))) char sdy[4][16 * 144];
-  __shared__ float red[4][64 * 32];
+  // FOUR k-steps (16-pixel segments) per wave and loop trip, visited in the order s, s + S, s + 2 S, s + 3 S of the rolled loop (the
+  // same sums, bit for bit): all their loads -- 8 x 16 B of dy and 32 gathered floats per lane -- are requested before the first LDS
+  // write.  One k-step per trip was a chain load -> LDS -> transposing read -> 2 MFMAs with one round trip to HBM each: 265 us for
+  // the 576 MB of a 32 x 640 x 640 batch (2.2 TB/s).
+  constexpr int U = 4;
+  __shared__ __attribute__((aligned(16))) char smem_w[4 * U * 16 * 144 > 4 * 64 * 32 * 4 ? 4 * U * 16 * 144 : 4 * 64 * 32 * 4];
+  char (*sdy)[U][16 * 144] = reinterpret_cast<char (*)[U][16 * 144]>(smem_w);
+  float (*red)[64 * 32] = reinterpret_cast<float (*)[64 * 32]>(smem_w);        // after the loop (behind a barrier)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hk = l >> 5;
   const int ho = (h + 1) / 2, wo = (w + 1) / 2;
   const int segs = (wo + 15) / 16;                       // k-step = 16 consecutive output pixels of one row
@@ -726,38 +732,62 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
   const int i16 = l & 15, grp = (l >> 4) & 1;
   uint32_t a_off[2];
   for (int r = 0; r < 2; ++r) a_off[r] = (8 * hk + 4 * r + (i16 >> 2)) * 144 + (16 * grp + 4 * (i16 & 3)) * 2;
-  char* my = sdy[wave];
-  for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < total; s += (int64_t)gridDim.x * 4) {
-    const int seg = (int)(s % segs);
-    const int64_t q = s / segs;
-    const int oy = (int)(q % ho);
-    const int img = (int)(q / ho);
-    const int ox0 = seg * 16;
-    // stage dy[16 px][64 ch] (zero beyond the row / channel range): 128 16-byte chunks, 2 per lane
-    for (int i = l; i < 128; i += 64) {
-      const int px = i >> 3, c8 = i & 7;
-      const bool in = ox0 + px < wo && c8 * 8 < c;
-      uint4 v = *reinterpret_cast<const uint4*>(in ? dy + (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8 : dy);
-      if (!in) v = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(my + px * 144 + c8 * 16) = v;
-    }
-    // B: patch[ox0 + 8hk + j][t], j = 0..7
-    h8 b;
-    const int iy = 2 * oy + ky - 1;
-    const float* xr = x + ((int64_t)img * 3 * h + 2 * oy) * w + toff;
+  const int64_t S = (int64_t)gridDim.x * 4;
+  for (int64_t s0 = (int64_t)blockIdx.x * 4 + wave; s0 < total; s0 += U * S) {
+    uint4 dv[U][2];
+    float raw[U][8];
+    bool okj[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ox = ox0 + 8 * hk + j, ix = 2 * ox + kx - 1;
-      const bool ok = tkyx >= 0 && ox < wo && iy >= 0 && iy < h && ix >= 0 && ix < w;
-      const float raw = *(ok ? xr + 2 * ox : x);      // unconditional load + select (see k_conv0_fwd_mfma)
-      b[j] = (_Float16)(ok ? raw : 0.f);
+    for (int u = 0; u < U; ++u) {
+      const int64_t s = s0 + u * S;
+      const bool sv = s < total;
+      const int64_t sc = sv ? s : 0;
+      const int seg = (int)(sc % segs);
+      const int64_t q = sc / segs;
+      const int oy = (int)(q % ho);
+      const int img = (int)(q / ho);
+      const int ox0 = seg * 16;
+      // dy[16 px][64 ch] (zero beyond the row / channel range): 128 16-byte chunks, 2 per lane
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = l + 64 * k;
+        const int px = i >> 3, c8 = i & 7;
+        const bool in = sv && ox0 + px < wo && c8 * 8 < c;
+        dv[u][k] = *reinterpret_cast<const uint4*>(in ? dy + (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8 : dy);
+        if (!in) dv[u][k] = make_uint4(0, 0, 0, 0);
+      }
+      // B: patch[ox0 + 8hk + j][t], j = 0..7
+      const int iy = 2 * oy + ky - 1;
+      const float* xr = x + ((int64_t)img * 3 * h + 2 * oy) * w + toff;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ox = ox0 + 8 * hk + j, ix = 2 * ox + kx - 1;
+        okj[u][j] = sv && tkyx >= 0 && ox < wo && iy >= 0 && iy < h && ix >= 0 && ix < w;
+        raw[u][j] = *(okj[u][j] ? xr + 2 * ox : x);      // unconditional load + select (see k_conv0_fwd_mfma)
+      }
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const h8 af = tr_frag(my, a_off[0] + ct * 64, a_off[1] + ct * 64);
-      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b, acc[ct], 0, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      char* my = sdy[wave][u];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = l + 64 * k;
+        *reinterpret_cast<uint4*>(my + (i >> 3) * 144 + (i & 7) * 16) = dv[u][k];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      h8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = (_Float16)(okj[u][j] ? raw[u][j] : 0.f);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const h8 af = tr_frag(sdy[wave][u], a_off[0] + ct * 64, a_off[1] + ct * 64);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b, acc[ct], 0, 0, 0);
+      }
     }
   }
+  __syncthreads();     // red aliases the staging tiles of waves that may still have been contracting
   // combine the 4 waves in fixed order; D layout: lane = column (tap), reg r -> row (co) 8*(r>>2) + 4*hk + (r&3)
   for (int ct = 0; ct < 2; ++ct)
     for (int r = 0; r < 16; ++r) red[wave][(ct * 32 + 8 * (r >> 2) + 4 * hk + (r & 3)) * 32 + t] = acc[ct][r];
