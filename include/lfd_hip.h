@@ -509,6 +509,16 @@ LFD_API int lfd_pack_conv_weights_train_f16(const lfd_pack_job_t* jobs_device, i
 LFD_API int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channels, float eps, float momentum,
                            float* running_mean, float* running_var, void* workspace, size_t workspace_bytes,
                            float* stats, lfd_stream_t stream);
+/* The conv in front of a train-mode BatchNorm and the batch statistics of its output in one pass (replaces
+ * lfd_conv2d_nhwc_f16 -> lfd_bn_train_stats_f16 for a unit nn.Conv2d(bias=False) -> nn.BatchNorm2d, lfd_resnet.py:96-154,
+ * :354-439, :458-468 in train mode): the conv kernel sums the fp16 values it stores and their squares per channel on the
+ * way out, one row of partials per workgroup in `workspace`; the fp64 final pass is lfd_bn_train_stats_f16's.  `d->relu`
+ * and `d->tail_cout` must be 0.  Shapes without such a kernel run the two calls it replaces.  `out`, `stats`,
+ * running_mean / running_var as in the two calls. */
+LFD_API int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                                 const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
+                                 float* running_var, void* workspace, size_t workspace_bytes, float* stats,
+                                 lfd_stream_t stream);
 /* z = relu?( gamma * (y - mean) * rstd + beta (+ residual) ) */
 LFD_API int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, const float* stats, const float* gamma,
                            const float* beta, const void* residual, int32_t relu, void* z, lfd_stream_t stream);

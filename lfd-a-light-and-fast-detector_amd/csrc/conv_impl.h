@@ -49,6 +49,7 @@ struct ConvArgs {
   int cout2;   // tail output channels (TAIL only)
   int relu, relu2;
   int tiles_x, tiles_y, ntiles;
+  float* stat_partials;  // STATS kernels: [gridDim.x][2][cout] per-workgroup sums of the stored outputs and of their squares
 };
 
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
@@ -130,10 +131,33 @@ __device__ unsigned long long g_conv_dbg[8 * 16];
 #endif
 
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false>
+// STATS (training forward, lfd_resnet.py:96-154 in train mode): the per-channel sums BatchNorm's batch statistics need are
+// taken from the fp16 values on their way from the staging tile to memory -- every thread copies the same 16-byte channel
+// chunk of every pixel it stores, so 8 sums + 8 sums of squares per thread last the whole persistent tile walk -- and the
+// workgroup leaves one row of partials; k_bn_stats_final (train.hip) adds the rows in fp64.  The separate read of the
+// whole output (k_bn_stats_partial) is what this replaces.
+__device__ __forceinline__ void stats_add(uint4 v, bool ok, float (&s)[8], float (&q)[8]) {
+  if (!ok) v = make_uint4(0, 0, 0, 0);
+  const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(wd[j] & 0xffffu));
+    const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(wd[j] >> 16));
+    s[2 * j] += lo;  q[2 * j] += lo * lo;
+    s[2 * j + 1] += hi;  q[2 * j + 1] += hi * hi;
+  }
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false>
 __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES), "DS: the residual block's 1x1 s2 downsample rides on its 3x3 s2 conv");
   static_assert(!ACC32 || (!TAIL && !RES && !DS), "ACC32 writes the bare accumulators of ONE conv");
+  static_assert(!STATS || (!TAIL && !RES && !DS && !ACC32), "STATS: the bare conv in front of a train-mode BatchNorm");
+  float st_s[8], st_q[8];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
+  }
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -617,8 +641,10 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint4 v = *reinterpret_cast<const uint4*>(sout + k * 4096 + lofs);
-        char* dst = (colok && ty0 * C::TH + 2 * k + trow < a.OH) ? obase + 2 * k * f_rowpitch + gofs : trash;
+        const bool ok = colok && ty0 * C::TH + 2 * k + trow < a.OH;
+        char* dst = ok ? obase + 2 * k * f_rowpitch + gofs : trash;
         *reinterpret_cast<uint4*>(dst) = v;
+        if constexpr (STATS) stats_add(v, ok, st_s, st_q);
       }
     } else {
       const int cslice = TAIL ? 0 : cog * NCT * 32;
@@ -631,10 +657,11 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
         const uint4 v = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
         // exactly one store per lane and iteration (see the counted wait at the loop top): lanes of
         // out-of-image pixels write into the trash half of the `zeros` line
-        _Float16* dst = (oy < a.OH && ox < a.OW)
-                            ? a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + cslice + c * 8
-                            : const_cast<_Float16*>(a.zeros) + 1024 + (threadIdx.x & 127) * 8;
+        const bool ok = oy < a.OH && ox < a.OW;
+        _Float16* dst = ok ? a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + cslice + c * 8
+                           : const_cast<_Float16*>(a.zeros) + 1024 + (threadIdx.x & 127) * 8;
         *reinterpret_cast<uint4*>(dst) = v;
+        if constexpr (STATS) stats_add(v, ok, st_s, st_q);   // (c == threadIdx.x % OCPP in every iteration)
       }
     }
     CV_T(8);
@@ -668,17 +695,46 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       }
     }
   }
+  if constexpr (STATS) {
+    // lanes l, l + OCPP, ... of a wave hold the same chunk: butterfly over them, then the four waves through LDS in wave order
+    constexpr int OCPP = NCT * 4, CB = NCT * 32;
+    static_assert(256 % OCPP == 0 && 64 % OCPP == 0, "one channel chunk per thread");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int d = 32; d >= OCPP; d >>= 1) {
+        st_s[e] += __shfl_xor(st_s[e], d);
+        st_q[e] += __shfl_xor(st_q[e], d);
+      }
+    }
+    block_barrier();      // the staging tile is dead for every wave
+    float* red = reinterpret_cast<float*>(smem);          // [4 waves][2][CB]
+    static_assert(4 * 2 * CB * 4 <= C::IN_BYTES, "partials fit the input buffer");
+    if (lane < OCPP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * CB + lane * 8 + e] = st_s[e];
+        red[(wave * 2 + 1) * CB + lane * 8 + e] = st_q[e];
+      }
+    }
+    block_barrier();
+    for (int o = threadIdx.x; o < 2 * CB; o += 256) {
+      const int q = o / CB, chl = o - q * CB;
+      const float t = ((red[(0 * 2 + q) * CB + chl] + red[(1 * 2 + q) * CB + chl]) + red[(2 * 2 + q) * CB + chl]) + red[(3 * 2 + q) * CB + chl];
+      a.stat_partials[(size_t)blockIdx.x * 2 * a.cout + (size_t)q * a.cout + cog * CB + chl] = t;
+    }
+  }
   CV_END();
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32>(a, smem);
+  conv_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>(a, smem);
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false>
-int launch_conv_(const ConvArgs& a0, hipStream_t st) {
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false>
+int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) {
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   ConvArgs a = a0;
   a.tiles_x = (a.OW + C::TW - 1) / C::TW;
@@ -691,7 +747,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   static_assert(LDSB <= 160 * 1024, "LDS capacity");
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     attr_done = true;
@@ -701,7 +757,8 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st) {
   int blocks = 512 / cgroups;
   if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
+  if (blocks_out) *blocks_out = blocks;
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

@@ -1,0 +1,66 @@
+// csrc/conv_stats.hip -- train-mode conv + BatchNorm batch statistics in one pass over the output.
+//
+// The reference's unit is nn.Conv2d(bias=False) -> nn.BatchNorm2d in train mode (lfd_resnet.py:96-154 blocks, :354-439
+// stem, :458-468 downsample).  The conv kernels of conv_impl.h, instantiated with STATS, sum every channel of the fp16
+// values they store (and their squares) while copying them out, one row of partials per workgroup; k_bn_stats_final
+// (train.hip) adds the rows in fp64 and updates the running statistics.  Shapes without a STATS instantiation (the tiny
+// last-stage maps, whose split-K kernel has no single owner of an output pixel) run the conv and the two statistics
+// launches of lfd_bn_train_stats_f16 -- the result is the same up to the order of the fp32 partial sums.
+#include "conv_impl.h"
+
+int lfd_bn_stats_final_launch(const float* partials, int nblocks, int channels, double pixels, float eps, float momentum,
+                              float* running_mean, float* running_var, float* stats, hipStream_t st);
+
+namespace {
+
+template <int CIN, int KS, int S, int NCT, bool WREG>
+int launch_stats(const ConvArgs& a, hipStream_t st, int* blocks) {
+  return launch_conv_<CIN, KS, S, NCT, WREG, false, false, false, false, true>(a, st, blocks);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                                 const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
+                                 float* running_var, void* workspace, size_t workspace_bytes, float* stats,
+                                 lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!d || !in || !out || !w_packed || !bias || !zeros || !workspace || !stats) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->n < 1 || d->h < 1 || d->w < 1 || d->tail_cout || d->relu) return LFD_ERR_INVALID_ARGUMENT;
+  if ((d->ks != 1 && d->ks != 3) || (d->stride != 1 && d->stride != 2)) return LFD_ERR_UNSUPPORTED;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  ConvArgs a{};
+  a.in = (const _Float16*)in; a.out = (_Float16*)out; a.w = (const half8*)w_packed; a.bias = bias;
+  a.res_px = d->cout; a.zeros = (const _Float16*)zeros;
+  a.N = d->n; a.H = d->h; a.W = d->w;
+  const int pad = d->ks / 2;
+  a.OH = (d->h + 2 * pad - d->ks) / d->stride + 1;
+  a.OW = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  a.cout = d->cout;
+  a.stat_partials = reinterpret_cast<float*>(workspace);
+  const int64_t pixels = (int64_t)a.N * a.OH * a.OW;
+  int blocks = 0, rc = LFD_ERR_UNSUPPORTED;
+  switch (d->cin * 10000 + d->ks * 1000 + d->stride * 100 + (d->cout / 32) * 10 + (d->cout % 32 ? 1 : 0)) {
+    case 64 * 10000 + 3100 + 20: rc = launch_stats<64, 3, 1, 2, true>(a, st, &blocks); break;
+    case 64 * 10000 + 3200 + 20: rc = launch_stats<64, 3, 2, 2, true>(a, st, &blocks); break;
+    case 64 * 10000 + 3200 + 40: rc = launch_stats<64, 3, 2, 4, true>(a, st, &blocks); break;
+    case 64 * 10000 + 1100 + 20: rc = launch_stats<64, 1, 1, 2, true>(a, st, &blocks); break;
+    case 64 * 10000 + 1200 + 20: rc = launch_stats<64, 1, 2, 2, true>(a, st, &blocks); break;
+    case 64 * 10000 + 1200 + 40: rc = launch_stats<64, 1, 2, 4, true>(a, st, &blocks); break;
+    case 128 * 10000 + 1100 + 40: rc = launch_stats<128, 1, 1, 4, true>(a, st, &blocks); break;
+    default: {
+      rc = lfd_conv2d_nhwc_f16(d, in, out, w_packed, bias, nullptr, nullptr, nullptr, zeros, stream);
+      if (rc != LFD_OK) return rc;
+      return lfd_bn_train_stats_f16(out, pixels, d->cout, eps, momentum, running_mean, running_var, workspace, workspace_bytes,
+                                    stats, stream);
+    }
+  }
+  if (rc != LFD_OK) return rc;
+  return lfd_bn_stats_final_launch(a.stat_partials, blocks, d->cout, (double)pixels, eps, momentum, running_mean, running_var,
+                                   stats, st);
+}
+
+}  // extern "C"

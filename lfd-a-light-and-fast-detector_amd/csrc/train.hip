@@ -1023,6 +1023,16 @@ constexpr int kWgradWgCap = 1024;  // most persistent workgroups per (cout, cin)
 
 }  // namespace
 
+// csrc/conv_stats.hip: the conv kernels that leave BatchNorm's partial sums behind hand their rows to the same final pass
+int lfd_bn_stats_final_launch(const float* partials, int nblocks, int channels, double pixels, float eps, float momentum,
+                              float* running_mean, float* running_var, float* stats, hipStream_t st) {
+  if (nblocks < 1 || nblocks > kMaxBlocks || !channels_ok(channels)) return LFD_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_bn_stats_final, dim3(channels), dim3(64), 0, st, partials, nblocks, channels, pixels, eps, momentum,
+                     running_mean, running_var, stats);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
 extern "C" {
 
 size_t lfd_train_workspace_bytes(void) {

@@ -689,6 +689,28 @@ def bn_train_stats(y, eps, momentum, running_mean=None, running_var=None):
     return stats
 
 
+def conv2d_bn_stats(x, w_packed, bias, cin, cout, ks, stride, eps, momentum, running_mean=None, running_var=None):
+    """The conv of a train-mode Conv2d(bias=False) -> BatchNorm2d unit with the batch statistics of its output taken in the
+    conv's own epilogue: x [N,H,W,cin] fp16 -> (y [N,OH,OW,cout] fp16, float32[2*cout] (mean, rstd)); updates the running
+    statistics in place (lfd_conv2d_bn_stats_nhwc_f16)."""
+    _nhwc16(x, 'conv2d_bn_stats')
+    n, h, w_, c = x.shape
+    if c != cin:
+        raise RuntimeError('conv2d_bn_stats: channel mismatch')
+    pad = ks // 2
+    oh = (h + 2 * pad - ks) // stride + 1
+    ow = (w_ + 2 * pad - ks) // stride + 1
+    d = _lib.ConvDesc(n, h, w_, cin, cout, ks, stride, 0, 0, 0)
+    ws = train_workspace(x.device)
+    with torch.cuda.device(x.device):
+        y = torch.empty((n, oh, ow, cout), dtype=torch.float16, device=x.device)
+        stats = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+        check(lib().lfd_conv2d_bn_stats_nhwc_f16(C.byref(d), ptr(x), ptr(y), ptr(w_packed), ptr(bias), ptr(zero_line(x.device)),
+                                                 float(eps), float(momentum), ptr(running_mean), ptr(running_var), ptr(ws),
+                                                 ws.numel(), ptr(stats), stream_ptr()), 'lfd_conv2d_bn_stats_nhwc_f16')
+    return y, stats
+
+
 def bn_train_apply(y, stats, gamma, beta, residual=None, relu=True):
     _nhwc16(y, 'bn_train_apply')
     c = y.size(3)

@@ -258,12 +258,19 @@ def forward(units, tap_ids, x):
     tape = []
     zeros = _Zeros(x.device)
     packs = _Packs(units, False)
+    fused_stats = os.environ.get('LFD_CONV_BN_STATS', '1') == '1'     # A/B switch: 0 = conv, then a statistics pass over y
     for u in units:
         conv, norm = u.conv, u.norm
         xin = acts[u.src]
         ks, st = conv.kernel_size[0], conv.stride[0]
+        stats = None
         if u.first:
             y = ops.stem_conv0_train_fwd(xin, conv.weight)
+        elif isinstance(norm, nn.BatchNorm2d) and fused_stats:
+            # the batch statistics come out of the conv's epilogue: no separate read of y (csrc/conv_stats.hip)
+            cout = conv.out_channels
+            y, stats = ops.conv2d_bn_stats(xin, packs(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, norm.eps,
+                                           norm.momentum, norm.running_mean, norm.running_var)
         else:
             cout = conv.out_channels
             y = ops.conv2d_nhwc(xin, packs(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, False)
@@ -271,7 +278,8 @@ def forward(units, tap_ids, x):
             stats = ops.gn_train_stats(y, norm.num_groups, norm.eps)
             z = ops.gn_train_apply(y, norm.num_groups, stats, norm.weight.detach(), norm.bias.detach(), u.relu)
         else:
-            stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
+            if stats is None:
+                stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
             z = ops.bn_train_apply(y, stats, norm.weight.detach(), norm.bias.detach(),
                                    acts[u.res] if u.res is not None else None, u.relu)
         acts[u.dst] = z

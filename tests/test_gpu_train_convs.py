@@ -52,6 +52,40 @@ def test_bn_train_stats_and_apply(c):
     torch.testing.assert_close(_nchw(z2), bn(_nchw(y)), rtol=2e-3, atol=2e-3)
 
 
+# (cin, cout, ks, stride): the seven shapes with statistics in the conv epilogue, then two that run conv + statistics pass
+_STATS_SHAPES = [(64, 64, 3, 1), (64, 64, 3, 2), (64, 128, 3, 2), (64, 64, 1, 1), (64, 64, 1, 2), (64, 128, 1, 2),
+                 (128, 128, 1, 1), (128, 128, 3, 1), (32, 64, 3, 2)]
+
+
+@pytest.mark.parametrize('cin,cout,ks,stride', _STATS_SHAPES)
+@pytest.mark.parametrize('nhw', [(2, 37, 53), (1, 8, 8), (3, 130, 70)])
+def test_conv_with_bn_statistics_in_the_epilogue(cin, cout, ks, stride, nhw):
+    """lfd_conv2d_bn_stats_nhwc_f16 (csrc/conv_stats.hip): y bit-identical to lfd_conv2d_nhwc_f16; mean / rstd / running
+    statistics equal to fp64 sums over the STORED fp16 y (what F.batch_norm(training=True) normalises with), i.e. to
+    lfd_bn_train_stats_f16 up to the order of the fp32 partial sums.  Ragged maps: tiles hang over the right / bottom edge."""
+    n, h, w = nhw
+    x = _rand16((n, h, w, cin), 7 * cin + ks + stride, 1.0, 0.2)
+    g = torch.Generator(device='cuda').manual_seed(cout + ks)
+    wt = torch.randn((cout, cin, ks, ks), generator=g, device='cuda') * (2.0 / (cin * ks * ks)) ** 0.5
+    pk = ops.pack_conv_weight_train(wt)
+    zb = torch.zeros(cout, device='cuda')
+    y0 = ops.conv2d_nhwc(x, pk, zb, cin, cout, ks, stride, False)
+    rm = torch.randn(cout, generator=g, device='cuda') * 0.1
+    rv = torch.rand(cout, generator=g, device='cuda') + 0.5
+    rm0, rv0, rm1, rv1 = rm.clone(), rv.clone(), rm.clone(), rv.clone()
+    st0 = ops.bn_train_stats(y0, 1e-5, 0.1, rm0, rv0)
+    y1, st1 = ops.conv2d_bn_stats(x, pk, zb, cin, cout, ks, stride, 1e-5, 0.1, rm1, rv1)
+    assert torch.equal(y0, y1)
+    yd = y0.double().reshape(-1, cout)
+    torch.testing.assert_close(st1[:cout].double(), yd.mean(0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st1[cout:].double(), 1 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), rtol=1e-5, atol=0)
+    torch.testing.assert_close(st1, st0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rm1, rm0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-5, atol=1e-6)
+    y2, st2 = ops.conv2d_bn_stats(x, pk, zb, cin, cout, ks, stride, 1e-5, 0.1)      # no running statistics; same bits again
+    assert torch.equal(y2, y1) and torch.equal(st2, st1)
+
+
 @pytest.mark.parametrize('c,relu,with_res', [(64, True, True), (128, True, False), (32, False, False)])
 def test_bn_train_backward_vs_autograd(c, relu, with_res):
     shape = (2, 29, 41, c)
