@@ -562,6 +562,13 @@ LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, in
  * forward -> y NHWC fp16 (pre-norm), and its weight gradient (OIHW fp32); channels in {32, 64} */
 LFD_API int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
                              const float* weight_oihw, void* y, lfd_stream_t stream);
+/* the same conv with the batch statistics of its train-mode BatchNorm (lfd_resnet.py:358-359) taken from the values on
+ * their way to memory (64 channels; 32 channels: conv, then lfd_bn_train_stats_f16); stats / running_* / workspace as in
+ * lfd_bn_train_stats_f16 */
+LFD_API int lfd_stem_conv0_train_fwd_bn_stats(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
+                                      const float* weight_oihw, void* y, float eps, float momentum, float* running_mean,
+                                      float* running_var, void* workspace, size_t workspace_bytes, float* stats,
+                                      lfd_stream_t stream);
 LFD_API int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t h, int32_t w, int32_t channels,
                          float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream);
 

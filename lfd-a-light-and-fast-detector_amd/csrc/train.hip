@@ -617,8 +617,14 @@ __device__ __forceinline__ void tap_of(int t, int h, int w, int& off, int& kyx) 
 }
 
 __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __restrict__ x, int n, int h, int w, int c,
-                                                            const float* __restrict__ wt, __half* __restrict__ y) {
+                                                            const float* __restrict__ wt, __half* __restrict__ y,
+                                                            float* stat_partials) {
   __shared__ __attribute__((aligned(16))) uint4 s_stage[kThreads / 64][256];     // per wave: 32 pixels x 128 B
+  // stat_partials (c == 64 only): row [blockIdx.x][2][64] of per-channel sums of the stored fp16 outputs and of their squares,
+  // for the train-mode BatchNorm behind this conv (lfd_resnet.py:358-359) -- every lane copies chunk l & 7 of every line it
+  // stores, so 8 + 8 sums per lane last the whole walk (the same scheme as the STATS instantiations of conv_impl.h)
+  float st_s[8], st_q[8];
+  for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
   const int l = threadIdx.x & 63, hk = l >> 5;
   const int ho = (h + 1) / 2, wo = (w + 1) / 2;
   const int64_t total = (int64_t)n * ho * wo;
@@ -682,7 +688,18 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
         const int idx = j * 64 + l;
         const int q = idx >> 3, ck = idx & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(stg + q * 128 + ((ck ^ (q & 7)) << 4));
-        if (p0 + q < total) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + (p0 + q) * 128 + ck * 16) = v;
+        const bool ok = p0 + q < total;
+        if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + (p0 + q) * 128 + ck * 16) = v;
+        if (stat_partials) {
+          const uint32_t wd[4] = {ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(wd[k] & 0xffffu));
+            const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(wd[k] >> 16));
+            st_s[2 * k] += lo;  st_q[2 * k] += lo * lo;
+            st_s[2 * k + 1] += hi;  st_q[2 * k + 1] += hi * hi;
+          }
+        }
       }
       continue;
     }
@@ -702,6 +719,28 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
           *reinterpret_cast<h4*>(y + p * c + ct * 32 + 8 * g + 4 * hk) = o;
         }
       }
+    }
+  }
+  if (stat_partials) {
+    // lanes l, l + 8, ... hold the same chunk: butterfly, then the four waves through LDS in wave order
+    for (int e = 0; e < 8; ++e)
+      for (int d = 32; d >= 8; d >>= 1) {
+        st_s[e] += __shfl_xor(st_s[e], d);
+        st_q[e] += __shfl_xor(st_q[e], d);
+      }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&s_stage[0][0]);        // [4 waves][2][64]
+    const int wv = threadIdx.x >> 6;
+    if (l < 8)
+      for (int e = 0; e < 8; ++e) {
+        red[(wv * 2 + 0) * 64 + l * 8 + e] = st_s[e];
+        red[(wv * 2 + 1) * 64 + l * 8 + e] = st_q[e];
+      }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int q = threadIdx.x >> 6, ch = threadIdx.x & 63;
+      stat_partials[(size_t)blockIdx.x * 128 + threadIdx.x] =
+          ((red[(0 * 2 + q) * 64 + ch] + red[(1 * 2 + q) * 64 + ch]) + red[(2 * 2 + q) * 64 + ch]) + red[(3 * 2 + q) * 64 + ch];
     }
   }
 }
@@ -1240,16 +1279,50 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
   return LFD_OK;
 }
 
+static int conv0_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels, const float* weight_oihw, void* y,
+                     float* stat_partials, unsigned* blocks_out, hipStream_t st);
+
 int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
                              const float* weight_oihw, void* y, lfd_stream_t stream) {
+  return conv0_fwd(x_nchw, n, h, w, channels, weight_oihw, y, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_stem_conv0_train_fwd_bn_stats(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,
+                                      const float* weight_oihw, void* y, float eps, float momentum, float* running_mean,
+                                      float* running_var, void* workspace, size_t workspace_bytes, float* stats,
+                                      lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!workspace || !stats || (running_mean == nullptr) != (running_var == nullptr)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t pixels = (int64_t)n * ((h + 1) / 2) * ((w + 1) / 2);
+  static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
+  if (channels != 64 || use_valu) {      // the 32-channel stem (XS) and the VALU A/B kernel: conv, then the statistics pass
+    const int rc = conv0_fwd(x_nchw, n, h, w, channels, weight_oihw, y, nullptr, nullptr, st);
+    if (rc != LFD_OK) return rc;
+    return lfd_bn_train_stats_f16(y, pixels, channels, eps, momentum, running_mean, running_var, workspace, workspace_bytes, stats,
+                                  stream);
+  }
+  unsigned blocks = 0;
+  float* partials = reinterpret_cast<float*>(workspace);
+  const int rc = conv0_fwd(x_nchw, n, h, w, channels, weight_oihw, y, partials, &blocks, st);
+  if (rc != LFD_OK) return rc;
+  hipLaunchKernelGGL(k_bn_stats_final, dim3(channels), dim3(64), 0, st, partials, (int)blocks, channels, (double)pixels, eps,
+                     momentum, running_mean, running_var, stats);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+static int conv0_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels, const float* weight_oihw, void* y,
+                     float* stat_partials, unsigned* blocks_out, hipStream_t st) {
   if (!x_nchw || !weight_oihw || !y || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
     return LFD_ERR_INVALID_ARGUMENT;
   static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
   if (!use_valu) {
     const int64_t groups = ((int64_t)n * ((h + 1) / 2) * ((w + 1) / 2) + 127) / 128;   // 4 waves x 32 pixels per block pass
-    hipLaunchKernelGGL(k_conv0_fwd_mfma, dim3((unsigned)(groups < 2048 ? groups : 2048)), dim3(kThreads), 0, st, x_nchw, n, h,
-                       w, channels, weight_oihw, (__half*)y);
+    const unsigned blocks = (unsigned)(groups < 2048 ? groups : 2048);   // (2048 rows x 2 x 64 floats = half the partials area)
+    if (blocks_out) *blocks_out = blocks;
+    hipLaunchKernelGGL(k_conv0_fwd_mfma, dim3(blocks), dim3(kThreads), 0, st, x_nchw, n, h, w, channels, weight_oihw, (__half*)y,
+                       stat_partials);
     LFD_CHECK_LAUNCH();
     return LFD_OK;
   }

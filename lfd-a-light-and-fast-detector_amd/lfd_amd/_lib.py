@@ -158,6 +158,7 @@ _SIGNATURES = {
     'lfd_conv3x3s2_dgrad_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P]),
     'lfd_conv_wgrad_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_train_fwd': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'lfd_stem_conv0_train_fwd_bn_stats': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_wgrad': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -885,6 +885,22 @@ def stem_conv0_train_fwd(x_nchw, weight):
     return y
 
 
+def stem_conv0_train_fwd_bn_stats(x_nchw, weight, eps, momentum, running_mean=None, running_var=None):
+    """stem_conv0_train_fwd + the batch statistics of its output from the conv's own stores -> (y, float32[2*C])"""
+    require_cuda(x_nchw, 'stem_conv0_train_fwd_bn_stats')
+    x = x_nchw.contiguous().float()
+    n, _, h, w_ = x.shape
+    c = weight.size(0)
+    ws = train_workspace(x.device)
+    with torch.cuda.device(x.device):
+        y = torch.empty((n, (h + 1) // 2, (w_ + 1) // 2, c), dtype=torch.float16, device=x.device)
+        stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        check(lib().lfd_stem_conv0_train_fwd_bn_stats(ptr(x), n, h, w_, c, ptr(weight.detach().contiguous().float()), ptr(y),
+                                                      float(eps), float(momentum), ptr(running_mean), ptr(running_var), ptr(ws),
+                                                      ws.numel(), ptr(stats), stream_ptr()), 'lfd_stem_conv0_train_fwd_bn_stats')
+    return y, stats
+
+
 def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None, accumulate=False):
     x = x_nchw.contiguous().float()
     n, _, h, w_ = x.shape

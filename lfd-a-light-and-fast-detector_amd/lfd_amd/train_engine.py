@@ -264,7 +264,10 @@ def forward(units, tap_ids, x):
         xin = acts[u.src]
         ks, st = conv.kernel_size[0], conv.stride[0]
         stats = None
-        if u.first:
+        if u.first and isinstance(norm, nn.BatchNorm2d) and fused_stats:
+            y, stats = ops.stem_conv0_train_fwd_bn_stats(xin, conv.weight, norm.eps, norm.momentum, norm.running_mean,
+                                                         norm.running_var)
+        elif u.first:
             y = ops.stem_conv0_train_fwd(xin, conv.weight)
         elif isinstance(norm, nn.BatchNorm2d) and fused_stats:
             # the batch statistics come out of the conv's epilogue: no separate read of y (csrc/conv_stats.hip)

@@ -75,6 +75,7 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_downblock_fused_f16(0, 8, 8, C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0),
                                      C.byref(one0), C.byref(one0), C.byref(one0), None) == -1       # n < 1
     assert l.lfd_conv2d_bn_stats_nhwc_f16(None, None, None, None, None, None, 1e-5, 0.1, None, None, None, 0, None, None) == -1
+    assert l.lfd_stem_conv0_train_fwd_bn_stats(None, 1, 8, 8, 64, None, None, 1e-5, 0.1, None, None, None, 0, None, None) == -1
     # round-3 entry points: the fp32-storage precision mode and the gated update
     assert l.lfd_p32_conv2d_nhwc_f32(None, None, None, None, None, None, None, None) == -1
     assert l.lfd_p32_groupnorm_relu_f32(None, 1, 16, 128, 16, None, None, 1e-5, 1, None, 0, None) == -1

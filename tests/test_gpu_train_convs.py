@@ -214,6 +214,30 @@ def test_first_stem_conv_forward_and_wgrad(c):
     assert float((dw * 2 - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize('c', [32, 64])
+@pytest.mark.parametrize('nhw', [(3, 61, 77), (2, 256, 320), (1, 5, 3)])
+def test_first_stem_conv_with_bn_statistics(c, nhw):
+    """lfd_stem_conv0_train_fwd_bn_stats: y bit-identical to lfd_stem_conv0_train_fwd, statistics = fp64 sums over the stored
+    fp16 y (64 channels: from the conv's own stores; 32: the separate pass)"""
+    n, h, w = nhw
+    g = torch.Generator(device='cuda').manual_seed(c + h)
+    x = torch.randn((n, 3, h, w), generator=g, device='cuda')
+    wt = torch.randn((c, 3, 3, 3), generator=g, device='cuda') * 0.2
+    y0 = ops.stem_conv0_train_fwd(x, wt)
+    rm = torch.randn(c, generator=g, device='cuda') * 0.1
+    rv = torch.rand(c, generator=g, device='cuda') + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    st0 = ops.bn_train_stats(y0, 1e-5, 0.1, rm0, rv0)
+    y1, st1 = ops.stem_conv0_train_fwd_bn_stats(x, wt, 1e-5, 0.1, rm, rv)
+    assert torch.equal(y0, y1)
+    yd = y0.double().reshape(-1, c)
+    torch.testing.assert_close(st1[:c].double(), yd.mean(0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st1[c:].double(), 1 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5), rtol=1e-5, atol=0)
+    torch.testing.assert_close(st1, st0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rm, rm0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv, rv0, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize('ks,stride,cin,cout', [(3, 1, 64, 64), (3, 2, 64, 128), (1, 2, 64, 64), (3, 2, 128, 128),
                                                 (1, 1, 32, 32), (3, 2, 32, 64), (1, 2, 32, 64), (1, 2, 64, 128),
                                                 (1, 2, 128, 128), (3, 1, 128, 128), (3, 2, 32, 32), (1, 1, 64, 64)])
@@ -280,16 +304,29 @@ def _check_units_against_autograd(units, acts, tape, trace, S):
             z = F.batch_norm(y, None, None, gam, bet, True, 0.1, u.norm.eps)
         if res is not None:
             z = z + res
+        k = 'unit %d' % rec['ui']
+        keep = torch.ones_like(z)
         if u.relu:
+            # Knife-edge ReLU inputs: |z| within 1e-3 of the tensor's rms, where the sign is decided by the order of the fp32
+            # operations (PyTorch's batch_norm here, y * a + b in the forward kernel, gamma * xhat + beta in the backward one).
+            # One such element of 98,304 deciding the other way is a 100 % error of its own gradient and was the WHOLE 1.5e-3
+            # of a unit whose other elements agree to 2.1e-4 (tools/timing/unit_dy_probe.py).  They must be rare, every other
+            # element must decide like the stored output, and the gradient comparison leaves the knife-edge elements out --
+            # which makes room for a gate at fp16-storage accuracy instead of one with a flipped sign priced in.
+            zd = z.detach()
+            knife = zd.abs() < 1e-3 * zd.pow(2).mean().sqrt()
+            assert float(knife.float().mean()) < 5e-3, k
+            assert torch.equal((zd > 0) | knife, (_nchw(acts[u.dst]) > 0) | knife), k
+            keep = (~knife).float()
             z = F.relu(z)
         z.backward(_nchw(rec['dz']) / S)
-        k = 'unit %d' % rec['ui']
-        assert _rel(_nchw(rec['dy']) / S, y.grad) < 3e-3, k
+        gate = 3e-3 if isinstance(u.norm, torch.nn.GroupNorm) else 1e-3      # (BatchNorm units measure 2.0-2.2e-4)
+        assert _rel(_nchw(rec['dy']) / S * keep, y.grad * keep) < gate, k
         if not isinstance(u.norm, torch.nn.GroupNorm):          # GroupNorm buffers accumulate over the levels: checked in (c)
             # sums of random-sign fp16-rounded terms: the rounding noise does not cancel like the signal does
             assert _rel(rec['dgamma'], gam.grad) < 1.5e-2 and _rel(rec['dbeta'], bet.grad) < 1.5e-2, k
         if res is not None:
-            assert _rel(_nchw(rec['g']) / S, res.grad) < 1e-3, k
+            assert _rel(_nchw(rec['g']) / S * keep, res.grad * keep) < 1e-3, k
         xin = acts[u.src] if u.first else _nchw(acts[u.src])
         xin = xin.detach().clone().requires_grad_(not u.first)
         wt = u.conv.weight.detach().clone().requires_grad_(True)
