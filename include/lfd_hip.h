@@ -558,6 +558,31 @@ LFD_API int lfd_conv3x3s2_dgrad_nhwc_f16(int32_t n, int32_t h, int32_t w, const 
 LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
                             int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
                             size_t workspace_bytes, float* dw, lfd_stream_t stream);
+/* The glue around the head's per-level OUTPUT convs in a training iteration (csrc/head_out.hip).  The reference's head ends,
+ * per level, in a classification and a regression conv with fp32 outputs, the regression one through a learnable per-level
+ * Scale (lfd_head.py:157-185); LFD.forward concatenates the levels along the point axis (lfd.py:526-542).  The training
+ * engine runs a level's convs as ONE 1x1 conv padded to 64 output rows; `y` [n, hw, 64] fp16 is its output, a segment is
+ * the row range [row0, row0 + channels) of one of the convs.
+ *   lfd_head_out_split_f16: out[img, point0 + p, j] = float(y[img, p, row0 + j]) (* *scale) for every segment -- `out` is the
+ *     level-concatenated [n, points_total, channels] fp32 tensor.
+ *   lfd_head_out_grad_f16: from grad (same layout as out) writes dy [n, hw, 64] fp16 = grad (* *scale) * loss_scale (other rows
+ *     zero) and ACCUMULATES dbias[j] += sum grad (* *scale), *dscale += sum grad * float(y) (both nullable) through per-block
+ *     partials in `workspace` (>= 512 KB) and one fixed-order fp64 final launch: what autograd computes for
+ *     conv bias / Scale, as 2 launches instead of ~20 per level. */
+typedef struct lfd_head_out_seg {
+  float* out;          /* split: destination */
+  const float* grad;   /* grad: source */
+  float* dbias;        /* grad: [channels], += (nullable) */
+  const float* scale;  /* device scalar (nullable: no Scale) */
+  float* dscale;       /* grad: device scalar, += (nullable) */
+  int32_t channels, row0;
+} lfd_head_out_seg_t;
+LFD_API int lfd_head_out_split_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                           const lfd_head_out_seg_t* segs, int32_t nsegs, lfd_stream_t stream);
+LFD_API int lfd_head_out_grad_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                          const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy, void* workspace,
+                          size_t workspace_bytes, lfd_stream_t stream);
+
 /* first stem conv (3 -> channels, 3x3 stride 2 pad 1, lfd_resnet.py:358,:378) on the NCHW fp32 image batch:
  * forward -> y NHWC fp16 (pre-norm), and its weight gradient (OIHW fp32); channels in {32, 64} */
 LFD_API int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,

@@ -40,6 +40,12 @@ class ConvDesc(C.Structure):
                 ('tail_relu', C.c_int32)]
 
 
+class HeadOutSeg(C.Structure):
+    """lfd_head_out_seg_t"""
+    _fields_ = [('out', C.c_void_p), ('grad', C.c_void_p), ('dbias', C.c_void_p), ('scale', C.c_void_p),
+                ('dscale', C.c_void_p), ('channels', C.c_int32), ('row0', C.c_int32)]
+
+
 class HeadDesc(C.Structure):
     """lfd_head_desc_t"""
     _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32), ('level_hw', C.c_int32 * MAX_LEVELS),
@@ -158,6 +164,8 @@ _SIGNATURES = {
     'lfd_conv3x3s2_dgrad_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P]),
     'lfd_conv_wgrad_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_train_fwd': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'lfd_head_out_split_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _P]),
+    'lfd_head_out_grad_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),
     'lfd_stem_conv0_train_fwd_bn_stats': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_wgrad': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),

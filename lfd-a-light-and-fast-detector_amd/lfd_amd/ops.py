@@ -873,6 +873,57 @@ def conv_wgrad(x, dy, ks, stride, inv_scale, out=None, accumulate=False):
     return out
 
 
+def _head_out_segs(segs, field, tensors):
+    arr = (_lib.HeadOutSeg * len(segs))()
+    for i, (sg, t) in enumerate(zip(segs, tensors)):
+        arr[i].channels, arr[i].row0 = int(sg['channels']), int(sg['row0'])
+        arr[i].scale = ptr(sg.get('scale'))
+        setattr(arr[i], field, ptr(t))
+        if field == 'grad':
+            arr[i].dbias, arr[i].dscale = ptr(sg.get('dbias')), ptr(sg.get('dscale'))
+    return arr
+
+
+def head_out_split(y, segs, outs, point0):
+    """y [n,h,w,64] fp16 (a level's padded output conv) -> outs[i][:, point0:point0+h*w, :] = float(y[..., rows of segment i])
+    (* scale); outs[i]: the level-concatenated [n, P, channels] fp32 tensors.  segs: dicts channels, row0, scale (tensor or
+    None).  (lfd_head_out_split_f16)"""
+    _nhwc16(y, 'head_out_split')
+    n, h, w_, rows = y.shape
+    if rows != 64:
+        raise RuntimeError('head_out_split: 64 output rows expected')
+    for sg, o in zip(segs, outs):
+        if o.dtype != torch.float32 or not o.is_contiguous() or o.size(0) != n or o.size(2) != sg['channels']:
+            raise RuntimeError('head_out_split: outs must be contiguous fp32 [n, P, channels]')
+    arr = _head_out_segs(segs, 'out', outs)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_head_out_split_f16(ptr(y), n, h * w_, outs[0].size(1), int(point0), arr, len(segs), stream_ptr()),
+              'lfd_head_out_split_f16')
+
+
+def head_out_grad(y, segs, grads, point0, loss_scale):
+    """-> dy [n,h,w,64] fp16 = grads[i][:, point0:point0+h*w, :] (* scale) * loss_scale in the rows of segment i, zero
+    elsewhere; accumulates segs[i]['dbias'] / ['dscale'] (fp32 tensors or None) in place.  (lfd_head_out_grad_f16)"""
+    _nhwc16(y, 'head_out_grad')
+    n, h, w_, rows = y.shape
+    if rows != 64:
+        raise RuntimeError('head_out_grad: 64 output rows expected')
+    for sg, g in zip(segs, grads):
+        if g.dtype != torch.float32 or not g.is_contiguous() or g.size(0) != n or g.size(2) != sg['channels']:
+            raise RuntimeError('head_out_grad: grads must be contiguous fp32 [n, P, channels]')
+        for k in ('dbias', 'dscale'):
+            t = sg.get(k)
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                raise RuntimeError('head_out_grad: %s must be contiguous fp32' % k)
+    arr = _head_out_segs(segs, 'grad', grads)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        dy = torch.empty_like(y)
+        check(lib().lfd_head_out_grad_f16(ptr(y), n, h * w_, grads[0].size(1), int(point0), arr, len(segs), float(loss_scale),
+                                          ptr(dy), ptr(ws), ws.numel(), stream_ptr()), 'lfd_head_out_grad_f16')
+    return dy
+
+
 def stem_conv0_train_fwd(x_nchw, weight):
     require_cuda(x_nchw, 'stem_conv0_train_fwd')
     x = x_nchw.contiguous().float()

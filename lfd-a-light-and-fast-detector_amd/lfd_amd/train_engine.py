@@ -388,9 +388,90 @@ def _out_weight(o):
     return wp, bp
 
 
+def _fused_outputs():
+    """A/B switch: LFD_OUT_FUSED=0 runs the glue around the output convs as PyTorch ops (~25 launches per level)"""
+    return os.environ.get('LFD_OUT_FUSED', '1') == '1'
+
+
+def _out_segs(o):
+    segs, r0 = [], 0
+    for kind, conv in o.convs:
+        segs.append(dict(kind=kind, conv=conv, channels=conv.out_channels, row0=r0,
+                         scale=o.scale._scale.detach() if (kind == 'reg' and o.scale is not None) else None))
+        r0 += conv.out_channels
+    return segs
+
+
+def _outputs_forward_fused(outs, acts, num_levels):
+    """outputs_forward with one launch per level behind the padded conv (ops.head_out_split) writing straight into the
+    level-concatenated tensors"""
+    sizes = [None] * num_levels
+    for o in outs:
+        sizes[o.level] = tuple(acts[o.src].shape[1:3])
+    starts, p = [], 0
+    for h, w_ in sizes:
+        starts.append(p)
+        p += h * w_
+    x0 = acts[outs[0].src]
+    n = x0.size(0)
+    width = {}
+    for o in outs:
+        for kind, conv in o.convs:
+            width[kind] = conv.out_channels
+    full = {k: torch.empty((n, p, c), dtype=torch.float32, device=x0.device) for k, c in width.items()}
+    cache, saved = {}, []
+    for o in outs:
+        x = acts[o.src]
+        c = x.size(3)
+        key = tuple(id(cv) for _, cv in o.convs)
+        if key not in cache:
+            wp, bp = _out_weight(o)
+            cache[key] = (wp, bp, ops.pack_conv_weight_train(wp))
+        wp, bp, wpk = cache[key]
+        y = ops.conv2d_nhwc(x, wpk, bp, c, wp.size(0), 1, 1, False)
+        segs = _out_segs(o)
+        ops.head_out_split(y, segs, [full[sg['kind']] for sg in segs], starts[o.level])
+        saved.append((wp, y))
+    return full['cls'], full['reg'], sizes, saved
+
+
+def _outputs_backward_fused(outs, acts, saved, sizes, dcls, dreg, store, scale):
+    grads = {}
+    inv = 1.0 / scale
+    starts, p = [], 0
+    for h, w_ in sizes:
+        starts.append(p)
+        p += h * w_
+    zeros = _Zeros(dcls.device)
+    packs = _Packs()
+    full = {'cls': dcls.contiguous(), 'reg': dreg.contiguous()}
+    dws = {}
+    for o, (wp, y) in zip(outs, saved):
+        x = acts[o.src]
+        c = x.size(3)
+        segs = _out_segs(o)
+        for sg in segs:
+            sg['dbias'] = store.target(sg['conv'].bias)
+            sg['dscale'] = store.target(o.scale._scale) if sg['scale'] is not None else None
+        dy = ops.head_out_grad(y, segs, [full[sg['kind']] for sg in segs], starts[o.level], scale)
+        key = tuple(id(cv) for _, cv in o.convs)
+        if key not in dws:         # one padded weight-gradient buffer per set of (possibly shared) output convs
+            dws[key] = (torch.zeros_like(wp), o)
+        ops.conv_wgrad(x, dy, 1, 1, inv, out=dws[key][0], accumulate=True)
+        grads[o.src] = ops.conv2d_nhwc(dy, packs(wp, True), zeros(c), wp.size(0), c, 1, 1, False, residual=grads.get(o.src))
+    for dw, o in dws.values():
+        r0 = 0
+        for _, conv in o.convs:
+            store.add(conv.weight, dw[r0:r0 + conv.out_channels])
+            r0 += conv.out_channels
+    return grads
+
+
 def outputs_forward(outs, acts, num_levels):
     """-> (cls [N,P,C'], reg [N,P,4]) fp32 in the level-concatenated layout of LFD.forward (lfd.py:526-542), sizes per level,
     and what the backward needs."""
+    if _fused_outputs():
+        return _outputs_forward_fused(outs, acts, num_levels)
     cls_l, reg_l, sizes, saved = [None] * num_levels, [None] * num_levels, [None] * num_levels, []
     cache = {}
     for o in outs:
@@ -421,6 +502,8 @@ def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=None):
     """-> {activation index: scaled fp16 gradient} for the tower outputs; parameter gradients go to `store`."""
     grads = {}
     scale = loss_scale() if scale is None else scale
+    if saved and saved[0][1] is not None and saved[0][1].dtype == torch.float16:      # saved by _outputs_forward_fused
+        return _outputs_backward_fused(outs, acts, saved, sizes, dcls, dreg, store, scale)
     inv = 1.0 / scale
     starts, p = [], 0
     for h, w_ in sizes:

@@ -76,6 +76,13 @@ def test_invalid_arguments_are_status_codes_not_crashes():
                                      C.byref(one0), C.byref(one0), C.byref(one0), None) == -1       # n < 1
     assert l.lfd_conv2d_bn_stats_nhwc_f16(None, None, None, None, None, None, 1e-5, 0.1, None, None, None, 0, None, None) == -1
     assert l.lfd_stem_conv0_train_fwd_bn_stats(None, 1, 8, 8, 64, None, None, 1e-5, 0.1, None, None, None, 0, None, None) == -1
+    sg = (_lib.HeadOutSeg * 1)()
+    sg[0].channels, sg[0].row0 = 4, 62                                         # rows 62..65 of 64
+    assert l.lfd_head_out_split_f16(C.byref(one0), 1, 4, 4, 0, sg, 1, None) == -1
+    sg[0].row0 = 0
+    assert l.lfd_head_out_split_f16(C.byref(one0), 1, 4, 3, 0, sg, 1, None) == -1          # the level does not fit the point axis
+    assert l.lfd_head_out_split_f16(C.byref(one0), 1, 4, 4, 0, sg, 1, None) == -1          # no destination
+    assert l.lfd_head_out_grad_f16(C.byref(one0), 1, 4, 4, 0, sg, 1, 1024.0, None, None, 0, None) == -1
     # round-3 entry points: the fp32-storage precision mode and the gated update
     assert l.lfd_p32_conv2d_nhwc_f32(None, None, None, None, None, None, None, None) == -1
     assert l.lfd_p32_groupnorm_relu_f32(None, 1, 16, 128, 16, None, None, 1e-5, 1, None, 0, None) == -1
@@ -119,7 +126,7 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
     pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc,
              'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
              'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob, 'lfd_detect_ext_t': _lib.DetectExt,
-             'lfd_p32_conv_desc_t': _lib.P32ConvDesc}
+             'lfd_p32_conv_desc_t': _lib.P32ConvDesc, 'lfd_head_out_seg_t': _lib.HeadOutSeg}
     header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lfd_hip.h"', 'int main(void) {']
     for cname, mirror in pairs.items():

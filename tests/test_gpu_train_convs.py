@@ -394,6 +394,49 @@ def test_backbone_train_forward_backward_vs_torch_modules(name, hw):
     print('mask-replay end-to-end gradients %s: worst cos %.6f (%s)' % (name, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize('ncls,two_convs,with_scale', [(1, True, True), (45, True, True), (45, False, False), (3, True, False)])
+def test_head_output_glue_kernels_vs_torch_ops(ncls, two_convs, with_scale):
+    """lfd_head_out_split_f16 / lfd_head_out_grad_f16 (csrc/head_out.hip) against the PyTorch ops they replace: slices of the
+    padded conv output -> fp32 (x Scale) into the level-concatenated tensors; gradients -> dy fp16 (bit-identical: the same
+    fp32 products, then one rounding), bias / Scale gradients accumulated (fp64 sums: tighter than torch's fp32 ones)."""
+    n, h, w, P, p0, S = 3, 13, 21, 1000, 317, 1024.0
+    g = torch.Generator(device='cuda').manual_seed(ncls)
+    y = (torch.randn((n, h, w, 64), generator=g, device='cuda') * 2).half()
+    scale = torch.tensor(1.37, device='cuda') if with_scale else None
+    segs = [dict(kind='cls', channels=ncls, row0=0, scale=None)]
+    if two_convs:
+        segs.append(dict(kind='reg', channels=4, row0=ncls, scale=scale))
+    outs = [torch.full((n, P, sg['channels']), -7.0, device='cuda') for sg in segs]
+    ops.head_out_split(y, segs, outs, p0)
+    yv = y.view(n, h * w, 64)
+    for sg, o in zip(segs, outs):
+        ref = yv[..., sg['row0']:sg['row0'] + sg['channels']].float()
+        if sg['scale'] is not None:
+            ref = ref * sg['scale']
+        assert torch.equal(o[:, p0:p0 + h * w], ref)
+        assert bool((o[:, :p0] == -7).all()) and bool((o[:, p0 + h * w:] == -7).all())      # nothing outside the level
+    grads = [torch.randn((n, P, sg['channels']), generator=g, device='cuda') * 1e-3 for sg in segs]
+    ref_dy = torch.zeros((n, h * w, 64), dtype=torch.float16, device='cuda')
+    for sg, gr in zip(segs, grads):
+        sg['dbias'] = torch.full((sg['channels'],), 0.5, device='cuda')
+        sg['dscale'] = torch.full((), 0.25, device='cuda') if sg['scale'] is not None else None
+        d = gr[:, p0:p0 + h * w]
+        raw = yv[..., sg['row0']:sg['row0'] + sg['channels']].float()
+        sg['ref_dscale'] = 0.25 + (d.double() * raw.double()).sum() if sg['scale'] is not None else None
+        if sg['scale'] is not None:
+            d = d * sg['scale']
+        sg['ref_dbias'] = 0.5 + d.double().sum((0, 1))
+        ref_dy[..., sg['row0']:sg['row0'] + sg['channels']] = (d * S).half()
+    dy = ops.head_out_grad(y, segs, grads, p0, S)
+    assert torch.equal(dy.view(n, h * w, 64), ref_dy)
+    for sg in segs:
+        torch.testing.assert_close(sg['dbias'].double(), sg['ref_dbias'], rtol=1e-6, atol=1e-7)
+        if sg['scale'] is not None:
+            torch.testing.assert_close(sg['dscale'].double(), sg['ref_dscale'], rtol=1e-6, atol=1e-7)
+    dy2 = ops.head_out_grad(y, segs, grads, p0, S)           # deterministic; accumulates
+    assert torch.equal(dy2, dy)
+
+
 @pytest.mark.parametrize('name,hw', [('WIDERFACE_LFD_S', (160, 192)), ('TT100K_LFD_L', (128, 160)), ('WIDERFACE_LFD_XS', (96, 128))])
 def test_whole_network_train_forward_backward(name, hw, monkeypatch):
     """LFD.forward in train mode = ONE autograd node on the HIP kernels (backbone, neck, GroupNorm towers shared by the
