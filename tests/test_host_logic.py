@@ -341,6 +341,41 @@ def test_training_schedule_covers_every_parameter_once():
     assert not te.network_supported(m)
 
 
+def test_output_conv_segments_follow_the_padded_weight_rows(monkeypatch):
+    """train_engine._out_segs (what lfd_head_out_split_f16 / lfd_head_out_grad_f16 are told) names exactly the rows
+    train_engine._out_weight concatenates: class rows first, then the 4 regression rows, zero rows up to 64; the per-level
+    Scale (lfd_head.py:157-185) rides on the regression segment only.  Shared heads give one segment table for every level,
+    TT100K's separate towers one single-segment output per kind and level.  LFD_OUT_FUSED=0 is the PyTorch-op A/B path."""
+    from lfd_amd import train_engine as te
+    for name in ('WIDERFACE_LFD_S', 'TT100K_LFD_L', 'WIDERFACE_LFD_XS'):
+        m = configs.build_model(name).train()
+        _, outs = te.build_network(m)
+        for o in outs:
+            wp, bp = te._out_weight(o)
+            assert wp.shape[0] == 64 and bp.shape == (64,)
+            segs = te._out_segs(o)
+            assert [sg['kind'] for sg in segs] == [k for k, _ in o.convs]
+            r = 0
+            for sg, (kind, conv) in zip(segs, o.convs):
+                assert sg['row0'] == r and sg['channels'] == conv.out_channels and sg['conv'] is conv
+                assert torch.equal(wp[r:r + conv.out_channels], conv.weight.detach())
+                assert torch.equal(bp[r:r + conv.out_channels], conv.bias.detach())
+                if kind == 'reg':
+                    assert conv.out_channels == 4
+                    assert (sg['scale'] is None) == (o.scale is None)
+                    if o.scale is not None:
+                        assert sg['scale'].data_ptr() == o.scale._scale.data_ptr()
+                else:
+                    assert sg['scale'] is None and conv.out_channels == m._head.num_cls_channels
+                r += conv.out_channels
+            assert r <= 64 and not wp[r:].any() and not bp[r:].any()
+        kinds = sorted((o.level, k) for o in outs for k, _ in o.convs)
+        assert kinds == sorted((l, k) for l in range(m._num_heads) for k in ('cls', 'reg'))     # every level, each kind once
+    assert te._fused_outputs()
+    monkeypatch.setenv('LFD_OUT_FUSED', '0')
+    assert not te._fused_outputs()
+
+
 def test_every_loss_the_lfd_constructor_accepts_is_provided():
     """lfd.py:52-66: classification loss in {BCEWithLogitsLoss, FocalLoss, CrossEntropyLoss, QualityFocalLoss}, regression
     loss in {SmoothL1Loss, MSELoss} ('independent') or {IoULoss, GIoULoss, DIoULoss, CIoULoss} ('union'): all importable
