@@ -1,0 +1,31 @@
+"""tests/golden/train_step_cases.py -- the seeded inputs of the training-iteration fixtures, shared by the generator
+(make_golden_train_step.py, runs the reference) and the tests (tests/test_train_golden.py, run this repository)."""
+import numpy as np
+import torch
+
+# configuration -> (images, height, width): a focal + IoU loss model with a shared head, and the 45-class cross-entropy one
+# with separate towers (WIDERFACE_LFD_S.py / TT100K_LFD_L.py)
+CASES = {'WIDERFACE_LFD_S': (2, 128, 160), 'TT100K_LFD_L': (2, 96, 128)}
+# WIDERFACE_LFD_S.py:217-241: SGD momentum 0.9, weight decay 1e-4, lr 0.1 x warm-up ratio 0.1 in the first iteration,
+# clip_grad_norm_(max_norm=10, norm_type=2) during the first 5 epochs
+LR, MOMENTUM, WEIGHT_DECAY = 0.01, 0.9, 1e-4
+GRAD_CLIP = dict(max_norm=10, norm_type=2, duration=5)
+ITERATIONS = 3
+
+
+def images(name):
+    n, h, w = CASES[name]
+    return torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(11)) * 2 - 1
+
+
+def annotations(name, num_classes):
+    """per image (boxes xywh float32 [g, 4], labels int64 [g]), 1-5 boxes each"""
+    n, h, w = CASES[name]
+    rs = np.random.default_rng(5)
+    ann = []
+    for _ in range(n):
+        g = int(rs.integers(1, 6))
+        wh = np.exp(rs.uniform(np.log(6), np.log(min(h, w) * 0.9), (g, 2)))
+        xy = rs.uniform(0, [w, h], (g, 2)) - wh / 2
+        ann.append((np.concatenate([xy, wh], 1).astype(np.float32), rs.integers(0, num_classes, g).astype(np.int64)))
+    return ann
