@@ -3,9 +3,10 @@
 import numpy as np
 import torch
 
-# configuration -> (images, height, width): a focal + IoU loss model with a shared head, and the 45-class cross-entropy one
-# with separate towers (WIDERFACE_LFD_S.py / TT100K_LFD_L.py)
-CASES = {'WIDERFACE_LFD_S': (2, 128, 160), 'TT100K_LFD_L': (2, 96, 128)}
+# configuration -> (images, height, width): a focal + IoU loss model with a shared head, the 45-class cross-entropy one with
+# separate towers, the 32-channel-stem model, and a TrafficLight one (quality focal loss, norm-free head: the documented
+# training fallback) (WIDERFACE_LFD_S.py / TT100K_LFD_L.py / WIDERFACE_LFD_XS.py / TL_LFD_L.py)
+CASES = {'WIDERFACE_LFD_S': (2, 128, 160), 'TT100K_LFD_L': (2, 96, 128), 'WIDERFACE_LFD_XS': (2, 96, 128), 'TL_LFD_L': (2, 64, 128)}
 # WIDERFACE_LFD_S.py:217-241: SGD momentum 0.9, weight decay 1e-4, lr 0.1 x warm-up ratio 0.1 in the first iteration,
 # clip_grad_norm_(max_norm=10, norm_type=2) during the first 5 epochs
 LR, MOMENTUM, WEIGHT_DECAY = 0.01, 0.9, 1e-4
