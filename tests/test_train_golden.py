@@ -85,6 +85,19 @@ def test_mirror_modules_and_hook_reproduce_the_reference_training_iteration_on_c
     _close_summaries([_summary(v) for v in sd.values()], g['state_summary_0'], list(sd.keys()), 1e-6, 'state after the update')   # (4e-9)
 
 
+@pytest.mark.parametrize('name', list(cases.CASES))
+def test_loss_oracle_on_the_training_iteration_vectors(name):
+    """oracle/net_oracle.lfd_loss (the checker of the fused loss kernels and of smoke()'s training step) on a second set of
+    reference vectors: the train-mode outputs and annotations of iteration 1 -> the reference's three loss values."""
+    from oracle import net_oracle
+    g = load_golden('ref_train_step_%s.npz' % name)
+    arch = configs.ARCHS[name]
+    ann = cases.annotations(name, arch['num_classes'])
+    out = net_oracle.lfd_loss(arch, torch.from_numpy(g['cls']), torch.from_numpy(g['reg']), [tuple(s) for s in g['sizes'].tolist()],
+                              net_oracle.strides_of(arch), [a[0] for a in ann], [a[1] for a in ann])
+    np.testing.assert_allclose([out['loss'], out['classification_loss'], out['regression_loss']], g['losses'][0], rtol=3e-6)
+
+
 @pytest.mark.gpu
 @pytest.mark.xfail(strict=False, reason='written after round 3\'s GPU minutes were spent: gates are estimates from the other '
                                         'training tests (loss curve within 3 %), first hardware run pending')
