@@ -101,6 +101,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 inline bool channels_ok(int c) { return c >= 8 && c <= kMaxC && (c & (c - 1)) == 0; }
 
+// LFD_BN_LOADS=2: the BatchNorm streaming passes request two vectors per lane before using the first (see k_bn_apply)
+inline int bn_loads() {
+  static const int v = [] { const char* e = getenv("LFD_BN_LOADS"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Per-channel reductions over an NHWC fp16 tensor [m][c]: every thread owns one 8-channel group (the grid stride is
 // a multiple of c/8), accumulates NQ quantities per channel in fp32, the block combines the threads of a group through
@@ -203,6 +209,53 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
   }
 }
 
+// k_bn_*_u<U> (the three BatchNorm streaming passes again): U vectors requested per lane before the first one is used.  With U = 1 a wave has 32-48
+// bytes per lane in flight and the 16 waves of a CU cover ~4.5 TB/s of the ~2 us loaded latency (the 320 x 320 stem units:
+// 5.45 / 4.5 / 5.4 TB/s for apply / backward sums / backward apply); U = 2 doubles that.  Vectors are consumed in the order of
+// the rolled loop, so every sum is the same sum bit for bit.  LFD_BN_LOADS=2 selects them; the default stays the kernels above until U = 2 has been timed on hardware (written after
+// round 3's GPU minutes were spent).
+template <int U>
+__global__ __launch_bounds__(kThreads) void k_bn_apply_u(const __half* __restrict__ y, int64_t vecs, int c,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const __half* __restrict__ res, int relu,
+                                                      __half* __restrict__ z) {
+  const int groups = c >> 3;
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  float a[8], b[8];
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cg * 8 + e;
+    a[e] = gamma[ch] * stats[c + ch];
+    b[e] = beta[ch] - stats[ch] * a[e];
+  }
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < vecs; v0 += U * stride) {
+    h8 h[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < vecs) {
+        h[u] = ld8(y, v);
+        if (res) r[u] = ld8(res, v);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v >= vecs) break;
+      h8 o;
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)h[u][e] * a[e] + b[e];
+        if (res) f += (float)r[u][e];
+        if (relu) f = fmaxf(f, 0.f);
+        o[e] = (_Float16)f;
+      }
+      st8(z, v, o);
+    }
+  }
+}
+
 // sums of g and g * xhat, g = dz * [ReLU passed]: mask from the stored output z when given (units with a residual
 // input), else -- relu_y -- recomputed from y as [gamma * xhat + beta > 0] (saves reading z), else no ReLU
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __restrict__ dz,
@@ -233,6 +286,52 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
       if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
       acc[0][e] += g;
       acc[1][e] += g * xh;
+    }
+  }
+  block_channel_reduce<2>(acc, c, partials);
+}
+
+template <int U>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_partial_u(const __half* __restrict__ dz,
+                                                            const __half* __restrict__ y,
+                                                            const __half* __restrict__ z, int64_t vecs, int c,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu_y,
+                                                            float* partials) {
+  const int groups = c >> 3;
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  float mean[8], rstd[8], acc[2][8], ga[8], be[8];
+  for (int e = 0; e < 8; ++e) {
+    mean[e] = stats[cg * 8 + e];
+    rstd[e] = stats[c + cg * 8 + e];
+    ga[e] = relu_y ? gamma[cg * 8 + e] : 0.f;
+    be[e] = relu_y ? beta[cg * 8 + e] : 0.f;
+    acc[0][e] = acc[1][e] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < vecs; v0 += U * stride) {
+    h8 d[U], yy[U], zz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < vecs) {
+        d[u] = ld8(dz, v);
+        yy[u] = ld8(y, v);
+        if (z) zz[u] = ld8(z, v);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v0 + u * stride >= vecs) break;
+      for (int e = 0; e < 8; ++e) {
+        float g = (float)d[u][e];
+        const float xh = ((float)yy[u][e] - mean[e]) * rstd[e];
+        if (z && !((float)zz[u][e] > 0.f)) g = 0.f;
+        if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
+        acc[0][e] += g;
+        acc[1][e] += g * xh;
+      }
     }
   }
   block_channel_reduce<2>(acc, c, partials);
@@ -302,6 +401,59 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     }
     st8(dy, v, o);
     if (g_out) st8(g_out, v, go);
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply_u(const __half* __restrict__ dz,
+                                                          const __half* __restrict__ y,
+                                                          const __half* __restrict__ z, int64_t vecs, int c,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu_y,
+                                                          const float* __restrict__ sums, float inv_m,
+                                                          __half* __restrict__ dy, __half* __restrict__ g_out) {
+  const int groups = c >> 3;
+  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  float mean[8], rstd[8], a[8], mg[8], mgx[8], ga[8], be[8];
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cg * 8 + e;
+    mean[e] = stats[ch];
+    rstd[e] = stats[c + ch];
+    ga[e] = gamma[ch];
+    be[e] = relu_y ? beta[ch] : 0.f;
+    a[e] = gamma[ch] * rstd[e];
+    mg[e] = sums[ch] * inv_m;
+    mgx[e] = sums[c + ch] * inv_m;
+  }
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < vecs; v0 += U * stride) {
+    h8 d[U], yy[U], zz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < vecs) {
+        d[u] = ld8(dz, v);
+        yy[u] = ld8(y, v);
+        if (z) zz[u] = ld8(z, v);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v >= vecs) break;
+      h8 o, go;
+      for (int e = 0; e < 8; ++e) {
+        float g = (float)d[u][e];
+        const float xh = ((float)yy[u][e] - mean[e]) * rstd[e];
+        if (z && !((float)zz[u][e] > 0.f)) g = 0.f;
+        if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
+        o[e] = (_Float16)(a[e] * (g - mg[e] - xh * mgx[e]));
+        go[e] = (_Float16)g;
+      }
+      st8(dy, v, o);
+      if (g_out) st8(g_out, v, go);
+    }
   }
 }
 
@@ -1129,8 +1281,12 @@ int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, cons
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!y || !stats || !gamma || !beta || !z || pixels < 1 || !channels_ok(channels)) return LFD_ERR_INVALID_ARGUMENT;
   const int64_t vecs = pixels * (channels / 8);
-  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
-                     stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
+  if (bn_loads() == 2)
+    hipLaunchKernelGGL(k_bn_apply_u<2>, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
+                       stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
+  else
+    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
+                       stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1151,15 +1307,25 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t r
   const unsigned g = grid_for_vecs(vecs);
   float* partials = reinterpret_cast<float*>(workspace);
   float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
+  const bool two = bn_loads() == 2;
+  if (two)
+    hipLaunchKernelGGL(k_bn_bwd_partial_u<2>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
                      dgamma, dbeta);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
-                     (__half*)dy, (__half*)g_out);
+  if (two)
+    hipLaunchKernelGGL(k_bn_bwd_apply_u<2>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
+                       (__half*)dy, (__half*)g_out);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
+                       (__half*)dy, (__half*)g_out);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

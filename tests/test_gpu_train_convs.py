@@ -86,6 +86,50 @@ def test_conv_with_bn_statistics_in_the_epilogue(cin, cout, ks, stride, nhw):
     assert torch.equal(y2, y1) and torch.equal(st2, st1)
 
 
+def _bn_pass_outputs(seed=3):
+    """apply + backward of a BatchNorm unit on seeded tensors (ragged sizes, with and without residual / ReLU): every output"""
+    outs = []
+    for c, shape, relu, with_res in [(64, (3, 33, 47), True, True), (128, (2, 17, 30), True, False), (32, (1, 5, 3), False, False),
+                                     (64, (4, 160, 160), True, False)]:
+        y = _rand16(shape + (c,), seed + c, 2.0, 0.7)
+        dz = _rand16(shape + (c,), seed + 1, 0.05)
+        res = _rand16(shape + (c,), seed + 2) if with_res else None
+        g = torch.Generator(device='cuda').manual_seed(seed)
+        gamma = torch.rand(c, generator=g, device='cuda') + 0.5
+        beta = torch.randn(c, generator=g, device='cuda') * 0.3
+        stats = ops.bn_train_stats(y, 1e-5, 0.1)
+        z = ops.bn_train_apply(y, stats, gamma, beta, res, relu)
+        dgamma, dbeta = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+        dy, gg = ops.bn_train_backward(dz, y, z if with_res else None, stats, gamma, 1.0 / 1024, dgamma, dbeta,
+                                       want_g=with_res, accumulate=True, relu=relu, beta=beta)
+        outs += [z, dy, dgamma, dbeta] + ([gg] if gg is not None else [])
+    return outs
+
+
+@pytest.mark.xfail(strict=False, reason='the two-vectors-in-flight BatchNorm passes (LFD_BN_LOADS=2, csrc/train.hip k_bn_*_u<2>) were '
+                                        'written after round 3\'s GPU minutes were spent: first hardware run pending')
+def test_bn_passes_with_two_vectors_in_flight_are_bit_identical():
+    """k_bn_apply_u<2> / k_bn_bwd_partial_u<2> / k_bn_bwd_apply_u<2> consume their vectors in the order of the rolled loops:
+    every output tensor and every sum equals the default kernels' bit for bit.  LFD_BN_LOADS is read once per process."""
+    import os, subprocess, sys, tempfile
+    want = [t.cpu() for t in _bn_pass_outputs()]
+    with tempfile.TemporaryDirectory() as d:
+        code = '''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_train_convs as t
+torch.save([x.cpu() for x in t._bn_pass_outputs()], %r)
+print('ok')
+''' % (os.path.dirname(os.path.abspath(__file__)),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lfd-a-light-and-fast-detector_amd'), os.path.join(d, 'o.pt'))
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, LFD_BN_LOADS='2'), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-2000:]
+        got = torch.load(os.path.join(d, 'o.pt'))
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+
+
 @pytest.mark.parametrize('c,relu,with_res', [(64, True, True), (128, True, False), (32, False, False)])
 def test_bn_train_backward_vs_autograd(c, relu, with_res):
     shape = (2, 29, 41, c)
