@@ -212,8 +212,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
 // k_bn_*_u<U> (the three BatchNorm streaming passes again): U vectors requested per lane before the first one is used.  With U = 1 a wave has 32-48
 // bytes per lane in flight and the 16 waves of a CU cover ~4.5 TB/s of the ~2 us loaded latency (the 320 x 320 stem units:
 // 5.45 / 4.5 / 5.4 TB/s for apply / backward sums / backward apply); U = 2 doubles that.  Vectors are consumed in the order of
-// the rolled loop, so every sum is the same sum bit for bit.  LFD_BN_LOADS=2 selects them; the default stays the kernels above until U = 2 has been timed on hardware (written after
-// round 3's GPU minutes were spent).
+// the rolled loop, so every sum is the same sum bit for bit.  LFD_BN_LOADS=2 selects them; one timing at the end of round 3 showed no gain, the default stays the kernels above.
 template <int U>
 __global__ __launch_bounds__(kThreads) void k_bn_apply_u(const __half* __restrict__ y, int64_t vecs, int c,
                                                       const float* __restrict__ stats,

@@ -106,8 +106,6 @@ def _bn_pass_outputs(seed=3):
     return outs
 
 
-@pytest.mark.xfail(strict=False, reason='the two-vectors-in-flight BatchNorm passes (LFD_BN_LOADS=2, csrc/train.hip k_bn_*_u<2>) were '
-                                        'written after round 3\'s GPU minutes were spent: first hardware run pending')
 def test_bn_passes_with_two_vectors_in_flight_are_bit_identical():
     """k_bn_apply_u<2> / k_bn_bwd_partial_u<2> / k_bn_bwd_apply_u<2> consume their vectors in the order of the rolled loops:
     every output tensor and every sum equals the default kernels' bit for bit.  LFD_BN_LOADS is read once per process."""
