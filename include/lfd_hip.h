@@ -27,6 +27,16 @@ extern "C" {
 #define LFD_HIP_ABI_VERSION 2
 #define LFD_MAX_LEVELS 8
 
+/* Conventions of every entry point below.
+ *  - Plain pointers and sizes; device pointers unless a parameter says "host".  Outputs and workspaces are caller-allocated
+ *    (`*_workspace_bytes()` queries); nothing is allocated, freed or retained by the library between calls.
+ *  - Every launch goes to the `lfd_stream_t` (= hipStream_t, NULL = the default stream) the caller passes; no entry point
+ *    synchronises the device or the stream unless its comment says so.  Calls are re-entrant per stream; two streams must not
+ *    share a workspace.
+ *  - NHWC fp16 tensors are contiguous and 16-byte aligned (the kernels move them as 16-byte vectors and LDS-DMA lines); the
+ *    fused-block, downsample-block, stride-2 data-gradient, conv + statistics and head-output entry points check it.
+ *  - The return value is an `lfd_status`: 0 = launched, negative = refused before anything touched the device (argument
+ *    checks run on the host).  No C++ types or exceptions cross the ABI. */
 typedef void* lfd_stream_t; /* hipStream_t */
 
 #if defined(LFD_BUILDING)

@@ -520,7 +520,7 @@ extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const 
                                          lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!in || !out || !w1_packed || !b1 || !w2_packed || !b2 || !zeros || in == out) return LFD_ERR_INVALID_ARGUMENT;
-  if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || h < 1 || w < 1 || !lfd_aligned16(in) || !lfd_aligned16(out)) return LFD_ERR_INVALID_ARGUMENT;
   {
     const int mode = block_rows_mode();
     if (mode == 1 || (mode < 0 && block_rows_suits(n, h, w)))

@@ -15,6 +15,10 @@
 
 static inline size_t lfd_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// NHWC fp16 tensors cross the ABI 16-byte aligned (include/lfd_hip.h, conventions): the kernels move them as 16-byte vectors
+// and LDS-DMA lines; a misaligned pointer is a status code, not a memory fault
+static inline bool lfd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // Carves sub-buffers out of a caller-owned workspace (256-B aligned).
 struct LfdCarver {
   char* base;

@@ -29,6 +29,7 @@ int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d || !in || !out || !w_packed || !bias || !zeros || !workspace || !stats) return LFD_ERR_INVALID_ARGUMENT;
   if (d->n < 1 || d->h < 1 || d->w < 1 || d->tail_cout || d->relu) return LFD_ERR_INVALID_ARGUMENT;
+  if (!lfd_aligned16(in) || !lfd_aligned16(out)) return LFD_ERR_INVALID_ARGUMENT;
   if ((d->ks != 1 && d->ks != 3) || (d->stride != 1 && d->stride != 2)) return LFD_ERR_UNSUPPORTED;
   if ((running_mean == nullptr) != (running_var == nullptr)) return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;

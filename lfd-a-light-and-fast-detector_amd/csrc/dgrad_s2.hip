@@ -185,7 +185,7 @@ extern "C" int lfd_conv3x3s2_dgrad_nhwc_f16(int32_t n, int32_t h, int32_t w, con
                                             const void* residual, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!dy || !dx || !w_packed || dy == dx) return LFD_ERR_INVALID_ARGUMENT;
-  if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || h < 1 || w < 1 || !lfd_aligned16(dy) || !lfd_aligned16(dx) || !lfd_aligned16(residual)) return LFD_ERR_INVALID_ARGUMENT;
   DgArgs a{};
   a.dy = (const _Float16*)dy; a.dx = (_Float16*)dx; a.w = (const half8*)w_packed; a.res = (const _Float16*)residual;
   a.N = n; a.H = h; a.W = w;

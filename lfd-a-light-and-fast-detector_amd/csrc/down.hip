@@ -475,7 +475,7 @@ extern "C" int lfd_downblock_fused_f16(int32_t n, int32_t h, int32_t w, const vo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!in || !out || !w1_packed || !b1 || !wd_packed || !bd || !w2_packed || !b2 || !zeros || in == out)
     return LFD_ERR_INVALID_ARGUMENT;
-  if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (n < 1 || h < 1 || w < 1 || !lfd_aligned16(in) || !lfd_aligned16(out)) return LFD_ERR_INVALID_ARGUMENT;
   DownArgs a{};
   a.in = (const _Float16*)in; a.out = (_Float16*)out;
   a.w1 = (const half8*)w1_packed; a.b1 = b1; a.wd = (const half8*)wd_packed; a.bd = bd; a.w2 = (const half8*)w2_packed; a.b2 = b2;

@@ -179,7 +179,7 @@ int lfd_head_out_grad_f16(const void* y, int32_t n, int32_t hw, int64_t points_t
                           size_t workspace_bytes, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   Args a{};
-  if (!fill(a, y, n, hw, points_total, point0, segs, nsegs) || !dy || !workspace) return LFD_ERR_INVALID_ARGUMENT;
+  if (!fill(a, y, n, hw, points_total, point0, segs, nsegs) || !dy || !workspace || !lfd_aligned16(dy)) return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < (size_t)kMaxBlocks * 2 * kRows * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
   for (int s = 0; s < nsegs; ++s)
     if (!a.seg[s].grad || (a.seg[s].dscale && !a.seg[s].scale)) return LFD_ERR_INVALID_ARGUMENT;

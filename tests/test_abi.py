@@ -83,6 +83,15 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_head_out_split_f16(C.byref(one0), 1, 4, 3, 0, sg, 1, None) == -1          # the level does not fit the point axis
     assert l.lfd_head_out_split_f16(C.byref(one0), 1, 4, 4, 0, sg, 1, None) == -1          # no destination
     assert l.lfd_head_out_grad_f16(C.byref(one0), 1, 4, 4, 0, sg, 1, 1024.0, None, None, 0, None) == -1
+    # misaligned NHWC fp16 tensors are refused on the host (16-byte alignment is part of the ABI's conventions)
+    buf = (C.c_char * 64)()
+    base = C.addressof(buf)
+    al, mis = C.c_void_p((base + 15) & ~15), C.c_void_p(((base + 15) & ~15) + 2)
+    nn = C.byref(one0)
+    assert l.lfd_fasterblock_fused_f16(1, 8, 8, mis, al, nn, nn, nn, nn, nn, None) == -1
+    assert l.lfd_downblock_fused_f16(1, 8, 8, al, mis, nn, nn, nn, nn, nn, nn, nn, None) == -1
+    assert l.lfd_conv3x3s2_dgrad_nhwc_f16(1, 8, 8, mis, al, nn, None, None) == -1
+    assert l.lfd_conv3x3s2_dgrad_nhwc_f16(1, 8, 8, al, al, nn, None, None) == -1             # dy == dx
     # round-3 entry points: the fp32-storage precision mode and the gated update
     assert l.lfd_p32_conv2d_nhwc_f32(None, None, None, None, None, None, None, None) == -1
     assert l.lfd_p32_groupnorm_relu_f32(None, 1, 16, 128, 16, None, None, 1e-5, 1, None, 0, None) == -1
