@@ -30,6 +30,15 @@ def test_nms_vs_reference_extension_golden():
         np.testing.assert_array_equal(keep.cpu().numpy(), g['keep_%d' % ci], err_msg='case %d' % ci)
 
 
+def test_nms_vs_reference_extension_golden_at_baseline_candidate_counts():
+    """device NMS == the reference's compiled nms_cpu at K = 4096 / 8192 boxes (ref_nms_large.npz; ref_nms.npz stops at 1000)"""
+    import nms_large_cases as cases
+    g = load_golden('ref_nms_large.npz')
+    for ci, (k, thr) in enumerate(cases.CASES):
+        keep = ops.nms_indices(torch.from_numpy(cases.dets(ci)).cuda(), float(thr))
+        np.testing.assert_array_equal(keep.cpu().numpy(), g['keep_%d' % ci], err_msg='case %d' % ci)
+
+
 @pytest.mark.parametrize('k', [1, 2, 63, 64, 65, 127, 128, 129, 1000, 4096, 9000])
 @pytest.mark.parametrize('thr', [0.3, 0.4])
 def test_nms_bit_exact_vs_oracle(k, thr):

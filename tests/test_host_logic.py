@@ -517,6 +517,21 @@ print('ext ok')
     assert out.returncode == 0 and 'ext ok' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_host_nms_at_baseline_candidate_counts():
+    """the product's HOST nms (lfd_nms_cpu_f32 behind lfd_amd.model.utils.nms for CPU tensors, the counterpart of the
+    reference's nms_cpu.cpp:7-66) == the compiled reference at K = 4096 / 8192 boxes (ref_nms_large.npz)"""
+    from conftest import load_golden
+    import nms_large_cases as cases
+    from lfd_amd.model.utils import nms
+    g = load_golden('ref_nms_large.npz')
+    for ci, (k, thr) in enumerate(cases.CASES):
+        d = torch.from_numpy(cases.dets(ci))
+        sup, inds = nms(d, float(thr))
+        assert not inds.is_cuda and inds.dtype == torch.long
+        np.testing.assert_array_equal(inds.numpy(), g['keep_%d' % ci], err_msg='case %d' % ci)
+        assert torch.equal(sup, d[inds])
+
+
 def test_python_nms_api_on_cpu_tensors_and_numpy(known_answers):
     """lfd_amd.model.utils.nms / soft_nms keep the reference's host behaviour (nms.py:7-116): numpy in -> numpy out, CPU
     tensors stay on the CPU, docstring vectors reproduce."""
