@@ -4,7 +4,9 @@ centres uniform over a 1920 x 1080 frame, sizes logU[4, 320], tie-free scores). 
 
     python tests/golden/make_golden_nms_large.py
 
-Output: ref_nms_large.npz -- per case the IoU threshold and the kept indices; the boxes are regenerated from the seed by
+Also soft_nms (linear / gaussian / hard) and nms_match (nms_cpu.cpp:76-283) on 2000 densely overlapping boxes.
+
+Output: ref_nms_large.npz -- per case the kept indices (soft_nms: the output rows; nms_match: group sizes and members); the boxes are regenerated from the seed by
 the tests (make_golden.synth_boxes' recipe, restated in nms_large_cases.py)."""
 import os
 import sys
@@ -29,6 +31,14 @@ def main():
         keep = ext.nms(torch.from_numpy(dets), float(thr)).numpy()
         out['keep_%d' % ci] = keep.astype(np.int32)
         print('K', k, 'thr', thr, 'kept', len(keep))
+    for ci, (k, thr, method, sigma, min_score) in enumerate(cases.SOFT_CASES):
+        dets = torch.from_numpy(cases.soft_dets(ci))
+        soft = ext.soft_nms(dets, float(thr), int(method), float(sigma), float(min_score)).numpy()
+        match = ext.nms_match(dets, float(thr))
+        out['soft_%d' % ci] = soft
+        out['match_sizes_%d' % ci] = np.array([len(m) for m in match], np.int32)
+        out['match_members_%d' % ci] = np.array([i for m in match for i in m], np.int32)
+        print('soft', k, thr, method, 'rows', soft.shape, 'groups', len(match))
     np.savez_compressed(os.path.join(HERE, 'ref_nms_large.npz'), **out)
 
 

@@ -532,6 +532,23 @@ def test_host_nms_at_baseline_candidate_counts():
         assert torch.equal(sup, d[inds])
 
 
+def test_host_soft_nms_and_nms_match_on_2000_dense_boxes():
+    """nms_ext.soft_nms (hard / linear / gaussian) and nms_ext.nms_match -- CPU-only in the reference (nms_cpu.cpp:76-283) --
+    on 2000 densely overlapping boxes == the compiled reference's output rows / groups (ref_nms_large.npz; the fixtures of
+    make_golden.py stop at 300 boxes)"""
+    from conftest import load_golden
+    import nms_large_cases as cases
+    from lfd_amd.model.utils.libs import nms_ext
+    g = load_golden('ref_nms_large.npz')
+    for ci, (k, thr, method, sigma, min_score) in enumerate(cases.SOFT_CASES):
+        d = torch.from_numpy(cases.soft_dets(ci))
+        out = nms_ext.soft_nms(d, float(thr), int(method), float(sigma), float(min_score))
+        np.testing.assert_array_equal(out.numpy(), g['soft_%d' % ci], err_msg='soft case %d' % ci)
+        groups = nms_ext.nms_match(d, float(thr))
+        assert [len(x) for x in groups] == g['match_sizes_%d' % ci].tolist()
+        assert [i for x in groups for i in x] == g['match_members_%d' % ci].tolist()
+
+
 def test_python_nms_api_on_cpu_tensors_and_numpy(known_answers):
     """lfd_amd.model.utils.nms / soft_nms keep the reference's host behaviour (nms.py:7-116): numpy in -> numpy out, CPU
     tensors stay on the CPU, docstring vectors reproduce."""
