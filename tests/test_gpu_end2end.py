@@ -54,6 +54,37 @@ def test_end_to_end_detections_match_reference(name):
     assert unmatched <= max(2, total // 10)
 
 
+@pytest.mark.xfail(strict=False, reason='written after round 3\'s GPU minutes were spent; same matching rule as '
+                                        'test_end_to_end_detections_match_reference, first hardware run pending')
+@pytest.mark.parametrize('tag', ['predict_py', 'q90'])
+def test_baseline_config1_predict_for_single_image_matches_the_reference(tag):
+    """BASELINE config 1: WIDERFACE_LFD_XS.predict_for_single_image on the seeded 640 x 480 uint8 frame against the
+    rows the REAL reference's predict_for_single_image returned on its CPU path (tests/golden/make_golden_config1.py):
+    detections matched by class, IoU >= 0.97 and score within 3e-3 (fp16 storage against fp32); candidates whose score sits
+    within the forward tolerance of the threshold may differ -- counted and bounded."""
+    g = load_golden('ref_config1_predict.npz')
+    img = np.random.default_rng(0).integers(0, 256, (480, 640, 3)).astype(np.uint8)
+
+    def aug(sample):   # simple_normalize (augmentation_pipeline.py:31-36)
+        sample['image'] = ((sample['image'].astype(np.float32) / 255 - 0.5) / 0.5)
+        return sample
+    m = configs.build_model('WIDERFACE_LFD_XS', seed=666)
+    configs.perturb_weights(m, seed=1)
+    res = m.predict_for_single_image(img, aug, classification_threshold=float(g[tag + '/thr']), nms_threshold=float(g[tag + '/iou']))
+    ref = json.loads(str(g[tag + '/results']))
+    used, unmatched = set(), 0
+    for r in ref:
+        best = max(((i, _iou(r[2:], q[2:])) for i, q in enumerate(res) if i not in used and q[0] == r[0]),
+                   key=lambda t: t[1], default=(None, 0.0))
+        if best[0] is not None and best[1] >= 0.97 and abs(res[best[0]][1] - r[1]) <= 3e-3:
+            used.add(best[0])
+        else:
+            unmatched += 1
+    unmatched += len(res) - len(used)
+    print('config 1 %s: %d reference detections, %d unmatched' % (tag, len(ref), unmatched))
+    assert unmatched <= max(2, len(ref) // 10)
+
+
 def test_predict_for_single_image_api():
     m = configs.build_model('WIDERFACE_LFD_XS')
     configs.perturb_weights(m)
