@@ -69,7 +69,7 @@ def main():
         out['sizes'] = np.array([model.head_indexes_to_feature_map_sizes[i] for i in range(len(model._point_strides))])
     finally:
         torch.Tensor.cuda, torch.nn.Module.cuda = tensor_cuda, module_cuda
-    np.savez_compressed(os.path.join(HERE, 'ref_config1_predict.npz'), **out)
+    np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_config1_predict.npz'), **out)
 
 
 if __name__ == '__main__':

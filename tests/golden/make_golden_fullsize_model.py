@@ -78,7 +78,7 @@ def main():
     idx = cases.sample_index(cl.shape[1])
     out['train/grad_cls'], out['train/grad_reg'] = cg.grad[:, idx].numpy(), rgg.grad[:, idx].numpy()
     print('train', out['train/counts'], out['train/loss'], out['train/grad_norms'])
-    np.savez_compressed(os.path.join(HERE, 'ref_fullsize_model.npz'), **out)
+    np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_fullsize_model.npz'), **out)
 
 
 if __name__ == '__main__':

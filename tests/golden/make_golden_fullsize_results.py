@@ -63,7 +63,7 @@ def main():
             out['%s/labels_%d' % (key, si)] = rows[:, 0].astype(np.int16)
             out['%s/rows_%d' % (key, si)] = rows[:, 1:].astype(np.float32)                             # score, x1, y1, w, h
             print(key, name, 'P', cls.shape[1], 'K', K, 'iou', iou, 'agnostic', agn, 'kept', len(res[0]))
-    np.savez_compressed(os.path.join(HERE, 'ref_fullsize_results.npz'), **out)
+    np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_fullsize_results.npz'), **out)
 
 
 if __name__ == '__main__':

@@ -39,7 +39,7 @@ def main():
         out['match_sizes_%d' % ci] = np.array([len(m) for m in match], np.int32)
         out['match_members_%d' % ci] = np.array([i for m in match for i in m], np.int32)
         print('soft', k, thr, method, 'rows', soft.shape, 'groups', len(match))
-    np.savez_compressed(os.path.join(HERE, 'ref_nms_large.npz'), **out)
+    np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_nms_large.npz'), **out)
 
 
 if __name__ == '__main__':

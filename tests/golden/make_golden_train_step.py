@@ -106,7 +106,7 @@ def main():
         res['losses'] = np.array(losses, np.float64)
         res['grad_norms'] = np.array(norms, np.float64)
         res['sizes'] = np.array([model.head_indexes_to_feature_map_sizes[i] for i in range(len(arch['regression_ranges']))])
-        np.savez_compressed(os.path.join(HERE, 'ref_train_step_%s.npz' % name), **res)
+        np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_train_step_%s.npz' % name), **res)
         print(name, 'losses', res['losses'][:, 0], 'grad norms', res['grad_norms'], 'P', res['cls'].shape[1])
 
 
