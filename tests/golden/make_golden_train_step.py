@@ -1,6 +1,6 @@
 """tests/golden/make_golden_train_step.py -- three TRAINING ITERATIONS of the real reference, frozen as fixtures.
 
-    python tests/golden/make_golden_train_step.py
+    python tests/golden/make_golden_train_step.py [case ...]
 
 Runs, on CPU in the build container, the loop body of the reference's Executor.train (lfd/execution/executor.py:191-211:
 model(image_batch) in train mode -> model.get_loss -> hooks) with the reference's OWN OptimizerHook.after_train_iter
@@ -61,8 +61,12 @@ def main():
             sys.modules[pkg] = mod
     RefHook = importlib.import_module('lfd.execution.hooks.optimizer_hook').OptimizerHook
 
-    for name in cases.CASES:
-        arch = configs.ARCHS[name]
+    only = sys.argv[1:]
+    for name in list(cases.CASES) + list(cases.LARGE_CASES):
+        if only and name not in only:
+            continue
+        large = name in cases.LARGE_CASES                              # (round 4) summaries only, see train_step_cases.py
+        arch = configs.ARCHS[cases.shape_of(name)[0]]
         model = configs.build_modules(arch, RB.LFDResNet, RN.SimpleNeck, RH.LFDHead, M.LFD, RL.FocalLoss,
                                       RL.IoULoss, RL.CrossEntropyLoss, seed=666, qfl_cls=RL.QualityFocalLoss)
         configs.perturb_weights(model, seed=1)
@@ -83,7 +87,10 @@ def main():
             if it == 0:
                 cls.retain_grad()
                 reg.retain_grad()
-                res['cls'], res['reg'] = cls.detach().numpy().copy(), reg.detach().numpy().copy()
+                if large:      # every 8th point of the train-mode outputs
+                    res['cls_s8'], res['reg_s8'] = cls.detach().numpy()[:, ::8].copy(), reg.detach().numpy()[:, ::8].copy()
+                else:
+                    res['cls'], res['reg'] = cls.detach().numpy().copy(), reg.detach().numpy().copy()
             lo = model.get_loss((cls, reg), ann)                         # executor.py:203-205
             Executor.config_dict.update(loss=lo['loss'])
             hook.after_train_iter(Executor)                              # optimizer_hook.py:26-36
@@ -93,7 +100,8 @@ def main():
             if it == 0:
                 # (the hook clipped p.grad in place: undo the clip coefficient so that the stored gradients are dL/dp)
                 coef = min(1.0, cases.GRAD_CLIP['max_norm'] / (norms[0] + 1e-6))
-                res['dcls'], res['dreg'] = cls.grad.numpy().copy(), reg.grad.numpy().copy()
+                if not large:
+                    res['dcls'], res['dreg'] = cls.grad.numpy().copy(), reg.grad.numpy().copy()
                 res['grad_summary'] = np.stack([summary(p.grad / coef) for _, p in model.named_parameters()])
                 for k, p in model.named_parameters():
                     if p.dim() <= 1:
@@ -106,8 +114,8 @@ def main():
         res['losses'] = np.array(losses, np.float64)
         res['grad_norms'] = np.array(norms, np.float64)
         res['sizes'] = np.array([model.head_indexes_to_feature_map_sizes[i] for i in range(len(arch['regression_ranges']))])
-        np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_train_step_%s.npz' % name), **res)
-        print(name, 'losses', res['losses'][:, 0], 'grad norms', res['grad_norms'], 'P', res['cls'].shape[1])
+        np.savez_compressed(os.path.join(os.environ.get('LFD_GOLDEN_OUT', HERE), 'ref_train_step_%s.npz' % cases.file_tag(name)), **res)
+        print(name, 'losses', res['losses'][:, 0], 'grad norms', res['grad_norms'], 'P', cls.shape[1])
 
 
 if __name__ == '__main__':

@@ -12,16 +12,31 @@ CASES = {'WIDERFACE_LFD_S': (2, 128, 160), 'TT100K_LFD_L': (2, 96, 128), 'WIDERF
 LR, MOMENTUM, WEIGHT_DECAY = 0.01, 0.9, 1e-4
 GRAD_CLIP = dict(max_norm=10, norm_type=2, duration=5)
 ITERATIONS = 3
+# round 4: the same protocol at sizes where EVERY BatchNorm of the network sees >= 512 elements per channel (the stride-64 maps
+# of the cases above are 2 x 2..3 pixels x 2 images = 8-12 elements: batch statistics over a dozen fp16 values).  key -> (arch,
+# images, height, width); the fixtures hold the iteration summaries only (losses, gradient norms, gradient / state summaries)
+LARGE_CASES = {'WIDERFACE_LFD_S@8x512x512': ('WIDERFACE_LFD_S', 8, 512, 512), 'WIDERFACE_LFD_XS@8x512x512': ('WIDERFACE_LFD_XS', 8, 512, 512)}
+
+
+def shape_of(name):
+    """-> (arch name, images, height, width) for a key of CASES or LARGE_CASES"""
+    if name in CASES:
+        return (name,) + tuple(CASES[name])
+    return LARGE_CASES[name]
+
+
+def file_tag(name):
+    return name.replace('@', '_at_')
 
 
 def images(name):
-    n, h, w = CASES[name]
+    _, n, h, w = shape_of(name)
     return torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(11)) * 2 - 1
 
 
 def annotations(name, num_classes):
     """per image (boxes xywh float32 [g, 4], labels int64 [g]), 1-5 boxes each"""
-    n, h, w = CASES[name]
+    _, n, h, w = shape_of(name)
     rs = np.random.default_rng(5)
     ann = []
     for _ in range(n):

@@ -15,6 +15,28 @@ from lfd_amd import configs
 pytestmark = pytest.mark.gpu
 
 
+# Unmatched detections (reference rows without a partner + rows of ours without one), gated at the count MEASURED on the MI355X
+# + 1 (round 4, gpurun_out/end2end_counts.json; rounds 1-3 allowed 10 % of the reference's rows).  A candidate whose score sits
+# within the fp16 forward's tolerance of the threshold can fall on the other side of it: that is what these counts are.
+_UNMATCHED_GATE = {'end_to_end/WIDERFACE_LFD_XS': 2,      # measured 1 of 43
+                   'end_to_end/WIDERFACE_LFD_S': 1,       # 0 of 21
+                   'config1/predict_py': 6,               # 5 of 1148 (thr 0.5 / IoU 0.3, predict.py:22)
+                   'config1/q90': 1}                      # 0 of 314
+
+
+def _record(key, value):
+    from conftest import ROOT
+    d = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(d, exist_ok=True)
+    f = os.path.join(d, 'end2end_counts.json')
+    try:
+        cur = json.load(open(f))
+    except Exception:
+        cur = {}
+    cur[key] = value
+    json.dump(cur, open(f, 'w'), indent=1)
+
+
 def _iou(a, b):
     ax2, ay2, bx2, by2 = a[0] + a[2] - 1, a[1] + a[3] - 1, b[0] + b[2] - 1, b[1] + b[3] - 1
     w = max(0.0, min(ax2, bx2) - max(a[0], b[0]))
@@ -51,11 +73,10 @@ def test_end_to_end_detections_match_reference(name):
                 unmatched += 1
         unmatched += len(res[n]) - len(used)
     print('%s: %d reference detections, %d unmatched' % (name, total, unmatched))
-    assert unmatched <= max(2, total // 10)
+    _record('end_to_end/' + name, dict(reference_detections=total, unmatched=unmatched))
+    assert unmatched <= _UNMATCHED_GATE['end_to_end/' + name], (unmatched, total)
 
 
-@pytest.mark.xfail(strict=False, reason='written after round 3\'s GPU minutes were spent; same matching rule as '
-                                        'test_end_to_end_detections_match_reference, first hardware run pending')
 @pytest.mark.parametrize('tag', ['predict_py', 'q90'])
 def test_baseline_config1_predict_for_single_image_matches_the_reference(tag):
     """BASELINE config 1: WIDERFACE_LFD_XS.predict_for_single_image on the seeded 640 x 480 uint8 frame against the
@@ -82,7 +103,8 @@ def test_baseline_config1_predict_for_single_image_matches_the_reference(tag):
             unmatched += 1
     unmatched += len(res) - len(used)
     print('config 1 %s: %d reference detections, %d unmatched' % (tag, len(ref), unmatched))
-    assert unmatched <= max(2, len(ref) // 10)
+    _record('config1/' + tag, dict(reference_detections=len(ref), unmatched=unmatched))
+    assert unmatched <= _UNMATCHED_GATE['config1/' + tag], (unmatched, len(ref))
 
 
 def test_predict_for_single_image_api():
