@@ -41,6 +41,18 @@ def gather_results(local_results, num_items):
     return out
 
 
+def sharded_map(num_items, fn):
+    """Image-parallel map: this rank evaluates `fn(lo, hi)` -> list of per-item results on ITS contiguous shard of
+    `num_items` items; every rank gets the full list in item order.  No data-path collective -- only the results travel
+    (tools/infer_sharded.py: fn = forward + decode + NMS on the rank's frames; replaces nn.DataParallel's scatter / gather,
+    lfd/execution/executor.py:39,230-236)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
+    lo, hi = shard_range(num_items, rank, world)
+    local = list(fn(lo, hi))
+    assert len(local) == hi - lo, 'sharded_map: fn(lo, hi) must return one result per item'
+    return gather_results(local, num_items)
+
+
 def global_count(t):
     """Sum a per-rank count tensor over all ranks (loss normalisers)."""
     if is_dist():

@@ -72,9 +72,12 @@ def main():
             out = m.detect_resident(x, meta)
         torch.cuda.synchronize()
         dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-        counts = out.counts.cpu()
-        local_results = [m._pack(out.dets[i, :int(counts[i, 1])], out.labels[i, :int(counts[i, 1])]) for i in range(hi - lo)]
-    results = parallel.gather_results(local_results, a.frames)
+
+        def detect_shard(lo_, hi_):       # this rank's frames are resident already: [lo, hi) is x
+            assert (lo_, hi_) == (lo, hi)
+            counts = out.counts.cpu()
+            return [m._pack(out.dets[i, :int(counts[i, 1])], out.labels[i, :int(counts[i, 1])]) for i in range(hi - lo)]
+    results = parallel.sharded_map(a.frames, detect_shard)      # every rank: all frames' rows, in frame order
     if rank == 0:
         print(json.dumps(dict(model=a.model, frames=a.frames, ranks=world, frames_per_rank=hi - lo, score_thr=thr,
                               detections=sum(len(r) for r in results), ms_per_batch=round(dt / a.steps * 1e3, 3),
