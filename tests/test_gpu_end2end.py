@@ -180,6 +180,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     sib = d['siblings']
     assert isinstance(sib, list) and {r['config'] for r in sib} >= {'FCOS_FPN', 'LFDV2_SFPN', 'LFDV2_SIMPLE'}
     assert all(r['forward_ms'] > 0 and r['detect_ms'] > 0 and r['images_per_s'] > 0 for r in sib)
+    # round 4: SURVEY 8d's remaining points (K = 4096 / IoU 0.3 at the headline shape, 640x480 frames), the all-backbone roofline
+    # entry, and which precision mode meets which gate
+    cf = d['configs']
+    assert cf['stress_k4096_iou03']['ms_per_step'] > 0 and 3000 < cf['stress_k4096_iou03']['candidates_per_image'] < 5000
+    assert cf['stress_k4096_iou03']['overflow'] == 0 and cf['stress_k4096_iou03']['iou_thr'] == 0.3
+    assert cf['frames_640x480']['bs8']['ms_per_step'] > 0 and cf['frames_640x480']['bs1']['points_per_image'] == 6460
+    rb = d['roofline_backbone_3x3']
+    assert rb['bound'] == 'mfma' and 0 < rb['frac'] < 1 and abs(rb['frac'] - rb['achieved'] / rb['peak']) < 2e-3
+    assert "'fp16'" in d['metric'] and 'fp32_storage' in d['metric'] and len(d['parity_gates']) == 2
 
 
 def test_two_batches_in_flight_on_two_streams_match_the_serial_step():
