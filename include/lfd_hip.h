@@ -568,6 +568,39 @@ LFD_API int lfd_conv3x3s2_dgrad_nhwc_f16(int32_t n, int32_t h, int32_t w, const 
 LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
                             int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
                             size_t workspace_bytes, float* dw, lfd_stream_t stream);
+/* The same weight gradient in two stages for a schedule that defers the final sums (round 4): every conv's k_wgrad writes
+ * its per-workgroup partial sums into ITS OWN buffer (`partials`: lfd_conv_wgrad_partial_rows() x blocks x ks*ks x 64 x 64
+ * floats, blocks = ceil(cout/64) * ceil(cin/64)), and ONE lfd_wgrad_final_batched_f32 launch after the last of them turns all
+ * buffers into dW tensors -- the 49 dependent final launches of a WIDERFACE_LFD_S iteration become one, and the partial
+ * launches may run on another stream than the data-gradient chain.  Job table in device memory: head jobs (first_block >= 0,
+ * = running sum of the head jobs' nblk * taps * 32 blocks) own output blocks; `next` chains further partial sets of the same dW
+ * (a conv shared by the pyramid levels, lfd_head.py:67-82; chained jobs have first_block = -1 and the head job's nblk / taps),
+ * summed after the head's rows in chain order, fp64, one rounding.  Rows [co_lo, co_hi) of the conv go to dw rows
+ * [0, co_hi - co_lo): the padded per-level output conv writes its classification and regression rows into two tensors
+ * through two head jobs over the same partials.  dW (+)= inv_scale * sum. */
+typedef struct lfd_wgrad_job {
+  const float* partials;
+  float* dw;
+  int32_t nwg, nblk, cin, cout, taps;
+  int32_t co_lo, co_hi;
+  int32_t first_block, next, accumulate;
+  float inv_scale;
+} lfd_wgrad_job_t;
+LFD_API int32_t lfd_conv_wgrad_partial_rows(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks, int32_t stride);
+LFD_API int lfd_conv_wgrad_partials_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin,
+                                             int32_t cout, int32_t ks, int32_t stride, float* partials, size_t partials_bytes,
+                                             lfd_stream_t stream);
+LFD_API int lfd_wgrad_final_batched_f32(const lfd_wgrad_job_t* jobs_device, int32_t njobs, int32_t total_blocks,
+                                        lfd_stream_t stream);
+/* dst[i] (+)= sum over r < nrows of src[r * row_stride + i], i < count, fp64 in row order; one block per job: the private
+ * per-level copies of small shared parameter gradients (GroupNorm weight / bias of shared towers, output-conv biases)
+ * after the pyramid levels ran on their own streams. */
+typedef struct lfd_rowsum_job {
+  const float* src;
+  float* dst;
+  int32_t nrows, row_stride, count, accumulate;
+} lfd_rowsum_job_t;
+LFD_API int lfd_rows_sum_batched_f32(const lfd_rowsum_job_t* jobs_device, int32_t njobs, lfd_stream_t stream);
 /* The glue around the head's per-level OUTPUT convs in a training iteration (csrc/head_out.hip).  The reference's head ends,
  * per level, in a classification and a regression conv with fp32 outputs, the regression one through a learnable per-level
  * Scale (lfd_head.py:157-185); LFD.forward concatenates the levels along the point axis (lfd.py:526-542).  The training

@@ -1190,6 +1190,75 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_final(const float* partials,
   *dst = (accumulate ? *dst : 0.f) + (float)(s * (double)inv_scale);
 }
 
+// The final stage of MANY weight gradients in one launch (round 4): the training schedule runs every k_wgrad with its own
+// partial buffer and sums all of them after the last one -- 49 dependent ~8 us launches of an iteration become one.  A
+// block of 128 consecutive outputs finds its job in the table (first_block: running sum of the head jobs' blocks); jobs
+// chained through `next` are further partial sets of the SAME dW (a conv shared by the pyramid levels: lfd_head.py:67-82),
+// summed after the head job's rows in chain order -- slices walk the rows as in k_wgrad_final, one rounding at the end.
+__global__ __launch_bounds__(kThreads) void k_wgrad_final_batched(const lfd_wgrad_job_t* __restrict__ jobs, int njobs) {
+  __shared__ double red[8][128];
+  __shared__ int sjob;
+  if (threadIdx.x == 0) {
+    int f = -1;
+    for (int j = 0; j < njobs; ++j) {
+      const int fb = jobs[j].first_block;
+      if (fb >= 0 && (int)blockIdx.x >= fb && (int)blockIdx.x < fb + jobs[j].nblk * jobs[j].taps * 32) f = j;
+    }
+    sjob = f;
+  }
+  __syncthreads();
+  const int hj = sjob;
+  if (hj < 0) return;
+  const lfd_wgrad_job_t J = jobs[hj];
+  const int per_blk = J.taps * 64 * 64;
+  const int lane32 = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int i = ((int)blockIdx.x - J.first_block) * 128 + lane32 * 4;
+  const int blk = i / per_blk, j = i - blk * per_blk;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int k = hj; k >= 0; k = jobs[k].next) {
+    const float* src = jobs[k].partials + (size_t)blk * per_blk + j;
+    const int nwg = jobs[k].nwg;
+    const size_t row = (size_t)J.nblk * per_blk;
+    int g = slice;
+    for (; g + 56 < nwg; g += 64) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(g + 8 * u) * row);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+    }
+    for (; g < nwg; g += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)g * row);
+      s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
+  }
+  red[slice][lane32 * 4 + 0] = s0; red[slice][lane32 * 4 + 1] = s1;
+  red[slice][lane32 * 4 + 2] = s2; red[slice][lane32 * 4 + 3] = s3;
+  __syncthreads();
+  if (threadIdx.x >= 128) return;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+  const int jj = j - lane32 * 4 + (int)threadIdx.x;
+  const int t = jj / 4096, co_l = (jj >> 6) & 63, ci_l = jj & 63;
+  const int nib = (J.cin + 63) / 64;
+  const int co = (blk / nib) * 64 + co_l, ci = (blk % nib) * 64 + ci_l;
+  if (co < J.co_lo || co >= J.co_hi || ci >= J.cin) return;
+  float* dst = J.dw + ((size_t)(co - J.co_lo) * J.cin + ci) * J.taps + t;
+  *dst = (J.accumulate ? *dst : 0.f) + (float)(s * (double)J.inv_scale);
+}
+
+// dst[i] (+)= sum over rows of src[row][i], fp64, rows in order: the per-level private copies of small shared gradients
+// (GroupNorm weight / bias of the shared towers, the output convs' biases) once the levels ran on their own streams
+__global__ __launch_bounds__(kThreads) void k_rows_sum_batched(const lfd_rowsum_job_t* __restrict__ jobs) {
+  const lfd_rowsum_job_t J = jobs[blockIdx.x];
+  for (int i = threadIdx.x; i < J.count; i += kThreads) {
+    double s = 0.0;
+    for (int r = 0; r < J.nrows; ++r) s += (double)J.src[(size_t)r * J.row_stride + i];
+    J.dst[i] = (J.accumulate ? J.dst[i] : 0.f) + (float)s;
+  }
+}
+
 template <int KS, int S>
 int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
   using C = WgradCfg<KS, S>;
@@ -1406,24 +1475,15 @@ int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi,
   return LFD_OK;
 }
 
-int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                            int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
-                            size_t workspace_bytes, float* dw, lfd_stream_t stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!x || !dy || !dw || !workspace || n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+static int wgrad_geometry(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks, int32_t stride, int* nwg_out,
+                          int* nblk_out, int* ho_out, int* wo_out) {
+  if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
   if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return LFD_ERR_INVALID_ARGUMENT;
   if (cin < 8 || cout < 8 || (cin & 7) || (cout & 7) || cin > 128 || cout > 128) return LFD_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
   const int pad = ks / 2;
-  WgradArgs a{};
-  a.x = (const __half*)x;
-  a.dy = (const __half*)dy;
-  a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
-  a.ho = (h + 2 * pad - ks) / stride + 1;
-  a.wo = (w + 2 * pad - ks) / stride + 1;
-  a.partials = reinterpret_cast<float*>(workspace);
+  const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
   const int nblk = ((cout + 63) / 64) * ((cin + 63) / 64);
-  const int tiles = n * ((a.ho + 7) / 8) * ((a.wo + 15) / 16);
+  const int tiles = n * ((ho + 7) / 8) * ((wo + 15) / 16);
   // as many workgroups as the partial buffer holds (1x1: 2048, 3x3 64x64: 1024, 3x3 128x128: 256): several per CU hide
   // the synchronous tile staging behind each other's MFMAs
   int nwg = (kWgradMaxWg * 4 * 9) / (nblk * ks * ks);
@@ -1431,15 +1491,74 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
                                                                                   // stride 1 prefetches the next tile in registers and needs no second workgroup per CU
   if (nwg > kWgradWgCap) nwg = kWgradWgCap;
   if (nwg > tiles) nwg = tiles;
-  int rc;
-  if (ks == 3 && stride == 1) rc = launch_wgrad<3, 1>(a, nwg, nblk, st);
-  else if (ks == 3) rc = launch_wgrad<3, 2>(a, nwg, nblk, st);
-  else if (stride == 1) rc = launch_wgrad<1, 1>(a, nwg, nblk, st);
-  else rc = launch_wgrad<1, 2>(a, nwg, nblk, st);
+  *nwg_out = nwg; *nblk_out = nblk; *ho_out = ho; *wo_out = wo;
+  return LFD_OK;
+}
+
+static int wgrad_launch(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks,
+                        int32_t stride, float* partials, int nwg, int nblk, int ho, int wo, hipStream_t st) {
+  WgradArgs a{};
+  a.x = (const __half*)x;
+  a.dy = (const __half*)dy;
+  a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+  a.ho = ho; a.wo = wo;
+  a.partials = partials;
+  if (ks == 3 && stride == 1) return launch_wgrad<3, 1>(a, nwg, nblk, st);
+  if (ks == 3) return launch_wgrad<3, 2>(a, nwg, nblk, st);
+  if (stride == 1) return launch_wgrad<1, 1>(a, nwg, nblk, st);
+  return launch_wgrad<1, 2>(a, nwg, nblk, st);
+}
+
+int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                            int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
+                            size_t workspace_bytes, float* dw, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!x || !dy || !dw || !workspace) return LFD_ERR_INVALID_ARGUMENT;
+  int nwg, nblk, ho, wo;
+  int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo);
+  if (rc != LFD_OK) return rc;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  float* partials = reinterpret_cast<float*>(workspace);
+  rc = wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, st);
   if (rc != LFD_OK) return rc;
   const int taps = ks * ks, total = nblk * taps * 64 * 64;
-  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 128), dim3(kThreads), 0, st, a.partials, nwg, nblk,
+  hipLaunchKernelGGL(k_wgrad_final, dim3(total / 128), dim3(kThreads), 0, st, partials, nwg, nblk,
                      cin, cout, taps, inv_scale, accumulate, dw);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int32_t lfd_conv_wgrad_partial_rows(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks, int32_t stride) {
+  int nwg, nblk, ho, wo;
+  const int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo);
+  return rc != LFD_OK ? rc : nwg;
+}
+
+int lfd_conv_wgrad_partials_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                     int32_t ks, int32_t stride, float* partials, size_t partials_bytes, lfd_stream_t stream) {
+  if (!x || !dy || !partials) return LFD_ERR_INVALID_ARGUMENT;
+  int nwg, nblk, ho, wo;
+  const int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo);
+  if (rc != LFD_OK) return rc;
+  if (partials_bytes < (size_t)nwg * nblk * ks * ks * 64 * 64 * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  return wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_wgrad_final_batched_f32(const lfd_wgrad_job_t* jobs_device, int32_t njobs, int32_t total_blocks, lfd_stream_t stream) {
+  if (njobs < 0 || total_blocks < 0) return LFD_ERR_INVALID_ARGUMENT;
+  if (njobs == 0 || total_blocks == 0) return LFD_OK;
+  if (!jobs_device || njobs > 4096) return LFD_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_wgrad_final_batched, dim3(total_blocks), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream),
+                     jobs_device, njobs);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_rows_sum_batched_f32(const lfd_rowsum_job_t* jobs_device, int32_t njobs, lfd_stream_t stream) {
+  if (njobs < 0) return LFD_ERR_INVALID_ARGUMENT;
+  if (njobs == 0) return LFD_OK;
+  if (!jobs_device) return LFD_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_rows_sum_batched, dim3(njobs), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), jobs_device);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

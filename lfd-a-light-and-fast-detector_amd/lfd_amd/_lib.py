@@ -102,6 +102,19 @@ class PackJob(C.Structure):
                 ('mode', C.c_int32), ('rows_valid', C.c_int32), ('first_vec', C.c_int32)]
 
 
+class WgradJob(C.Structure):
+    """lfd_wgrad_job_t"""
+    _fields_ = [('partials', C.c_void_p), ('dw', C.c_void_p), ('nwg', C.c_int32), ('nblk', C.c_int32), ('cin', C.c_int32),
+                ('cout', C.c_int32), ('taps', C.c_int32), ('co_lo', C.c_int32), ('co_hi', C.c_int32),
+                ('first_block', C.c_int32), ('next', C.c_int32), ('accumulate', C.c_int32), ('inv_scale', C.c_float)]
+
+
+class RowsumJob(C.Structure):
+    """lfd_rowsum_job_t"""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('nrows', C.c_int32), ('row_stride', C.c_int32),
+                ('count', C.c_int32), ('accumulate', C.c_int32)]
+
+
 _P, _I64, _I32, _F, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
@@ -163,6 +176,10 @@ _SIGNATURES = {
     'lfd_zero_insert2_nhwc_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_conv3x3s2_dgrad_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P]),
     'lfd_conv_wgrad_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
+    'lfd_conv_wgrad_partial_rows': (_I32, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    'lfd_conv_wgrad_partials_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _SZ, _P]),
+    'lfd_wgrad_final_batched_f32': (C.c_int, [_P, _I32, _I32, _P]),
+    'lfd_rows_sum_batched_f32': (C.c_int, [_P, _I32, _P]),
     'lfd_stem_conv0_train_fwd': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'lfd_head_out_split_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _P]),
     'lfd_head_out_grad_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),

@@ -661,7 +661,9 @@ _train_ws = {}
 
 
 def train_workspace(device):
-    key = (device.type, device.index)
+    """scratch of the training kernels (per-block partial sums), one per (device, stream): launch chains on different streams
+    -- the pyramid levels and the weight gradients of lfd_amd.train_engine's schedule -- must not share it"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _train_ws.get(key)
     if ws is None:
         ws = torch.empty(lib().lfd_train_workspace_bytes(), dtype=torch.uint8, device=device)
@@ -871,6 +873,97 @@ def conv_wgrad(x, dy, ks, stride, inv_scale, out=None, accumulate=False):
                                             int(bool(accumulate)), ptr(ws), ws.numel(), ptr(out), stream_ptr()),
               'lfd_conv_wgrad_nhwc_f16')
     return out
+
+
+def conv_wgrad_partial_floats(x, dy, ks, stride):
+    """floats of the partial buffer lfd_conv_wgrad_partials_nhwc_f16 fills for these shapes -> (floats, workgroup rows, blocks)"""
+    n, h, w_, cin = x.shape
+    cout = dy.size(3)
+    nwg = lib().lfd_conv_wgrad_partial_rows(n, h, w_, cin, cout, ks, stride)
+    if nwg < 0:
+        check(nwg, 'lfd_conv_wgrad_partial_rows')
+    nblk = ((cout + 63) // 64) * ((cin + 63) // 64)
+    return nwg * nblk * ks * ks * 4096, nwg, nblk
+
+
+def conv_wgrad_partials(x, dy, ks, stride, partials):
+    """first stage of conv_wgrad only: the per-workgroup partial sums of dW into `partials` (fp32, conv_wgrad_partial_floats);
+    the sums are taken later, for all convs of the iteration at once, by WgradFinals.launch"""
+    _nhwc16(x, 'conv_wgrad_partials')
+    _nhwc16(dy, 'conv_wgrad_partials')
+    n, h, w_, cin = x.shape
+    with torch.cuda.device(x.device):
+        check(lib().lfd_conv_wgrad_partials_nhwc_f16(ptr(x), ptr(dy), n, h, w_, cin, dy.size(3), ks, stride, ptr(partials),
+                                                     partials.numel() * 4, stream_ptr()), 'lfd_conv_wgrad_partials_nhwc_f16')
+
+
+class WgradFinals(object):
+    """The deferred final stage of an iteration's weight gradients and of the small per-level gradient copies: collects jobs
+    during the backward pass, launches lfd_wgrad_final_batched_f32 + lfd_rows_sum_batched_f32 once.  The device tables are
+    cached by content (pointers and shapes repeat from iteration to iteration: flat gradient buffers, persistent partial
+    buffers), so a steady-state backward uploads nothing -- which is also what makes it capturable into a HIP graph."""
+
+    def __init__(self, device):
+        self.device = device
+        self.cache = {}
+        self.reset()
+
+    def reset(self):
+        self.wj, self.rj, self.chains = [], [], {}
+
+    def add_wgrad(self, partials, nwg, nblk, cin, cout, taps, inv_scale, targets):
+        """targets: [(dw tensor, co_lo, co_hi)] -- the rows of this conv that go to each parameter gradient (+=)"""
+        for dw, lo, hi in targets:
+            key = (dw.data_ptr(), lo, hi)
+            idx = len(self.wj)
+            self.wj.append(dict(partials=partials.data_ptr(), dw=dw.data_ptr(), nwg=nwg, nblk=nblk, cin=cin, cout=cout, taps=taps,
+                                co_lo=lo, co_hi=hi, head=key not in self.chains, next=-1, inv_scale=float(inv_scale)))
+            if key in self.chains:
+                self.wj[self.chains[key]]['next'] = idx
+            self.chains[key] = idx
+
+    def add_rowsum(self, src, nrows, row_stride, count, dst, accumulate=True):
+        self.rj.append((src.data_ptr(), dst.data_ptr(), int(nrows), int(row_stride), int(count), int(bool(accumulate))))
+
+    def _table(self, kind, key, build):
+        ent = self.cache.get(kind)
+        if ent is None or ent[0] != key:
+            raw = build()
+            ent = (key, torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(self.device), raw)
+            self.cache[kind] = ent
+        return ent[1]
+
+    def launch(self):
+        with torch.cuda.device(self.device):
+            if self.wj:
+                first = 0
+                for j in self.wj:
+                    j['first_block'] = first if j['head'] else -1
+                    if j['head']:
+                        first += j['nblk'] * j['taps'] * 32
+                key = tuple(tuple(sorted(j.items())) for j in self.wj)
+
+                def build():
+                    arr = (_lib.WgradJob * len(self.wj))()
+                    for a, j in zip(arr, self.wj):
+                        a.partials, a.dw, a.nwg, a.nblk, a.cin, a.cout, a.taps = (j['partials'], j['dw'], j['nwg'], j['nblk'], j['cin'],
+                                                                                  j['cout'], j['taps'])
+                        a.co_lo, a.co_hi, a.first_block, a.next, a.accumulate, a.inv_scale = (j['co_lo'], j['co_hi'], j['first_block'],
+                                                                                              j['next'], 1, j['inv_scale'])
+                    return arr
+                tab = self._table('w', key, build)
+                check(lib().lfd_wgrad_final_batched_f32(ptr(tab), len(self.wj), first, stream_ptr()), 'lfd_wgrad_final_batched_f32')
+            if self.rj:
+                key = tuple(self.rj)
+
+                def build_r():
+                    arr = (_lib.RowsumJob * len(self.rj))()
+                    for a, j in zip(arr, self.rj):
+                        a.src, a.dst, a.nrows, a.row_stride, a.count, a.accumulate = j
+                    return arr
+                tab = self._table('r', key, build_r)
+                check(lib().lfd_rows_sum_batched_f32(ptr(tab), len(self.rj), stream_ptr()), 'lfd_rows_sum_batched_f32')
+        self.reset()
 
 
 def _head_out_segs(segs, field, tensors):

@@ -37,7 +37,7 @@ def set_loss_scale(v):
 
 
 class _Unit(object):
-    __slots__ = ('conv', 'norm', 'relu', 'src', 'res', 'dst', 'first')
+    __slots__ = ('conv', 'norm', 'relu', 'src', 'res', 'dst', 'first', 'level')
 
 
 class _Out(object):
@@ -103,11 +103,12 @@ def network_supported(model):
 
 class _Builder(object):
     def __init__(self):
-        self.units, self.n_act = [], 1
+        self.units, self.n_act, self.level = [], 1, None
 
     def add(self, conv, norm, relu, src, res=None):
         u = _Unit()
         u.conv, u.norm, u.relu, u.src, u.res, u.dst, u.first = conv, norm, relu, src, res, self.n_act, src == 0
+        u.level = self.level            # None: backbone; i: the neck / tower chain of pyramid level i
         self.units.append(u)
         self.n_act += 1
         return u.dst
@@ -158,6 +159,7 @@ def build_network(model):
         return cur
 
     for i, tap in enumerate(taps):
+        b.level = i
         nk = getattr(neck, 'neck%d' % i)
         cur = b.add(nk[0], nk[1], True, tap)
         cur = tower(getattr(head, 'head%d_merge_path' % i), cur)
@@ -541,6 +543,324 @@ def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=None):
     return grads
 
 
+# ---------------------------------------------------------------------------------------------- whole-network schedule
+# Round 4.  The iteration of the shipped configurations is ~500 launches of which ~360 run for less than 12 us (small maps,
+# one-wave finals): as ONE dependent chain they cost 2.3 ms of a 7.4 ms iteration (tools/timing/train_trace.py).  Three things
+# about the reference's graph (lfd_resnet.py:488-501, lfd_head.py:164-185) make most of that chain unnecessary:
+#   * the pyramid levels are independent between their backbone tap and the level-concatenated outputs: neck -> towers ->
+#     output convs of level i run on stream i, forward (from the moment the tap exists, beside the rest of the backbone) and
+#     backward (the backbone's backward waits for a level only where it first touches that tap's gradient);
+#   * a weight gradient is needed by nobody until the optimizer: every k_wgrad runs on a side stream into its OWN partial
+#     buffer, and ONE launch sums all of them at the end (ops.WgradFinals) instead of a final launch per conv;
+#   * parameters shared by the levels (tower convs, GroupNorm weight / bias, output convs and their biases) accumulate
+#     through chained partial sets / private per-level rows summed by the same final launches -- no read-modify-write on a
+#     shared gradient from two streams, and one rounding instead of one per level.
+# PARALLEL = False runs the same launches on the caller's stream (identical results bit for bit: the A/B and the test).
+PARALLEL = True
+
+
+class _Sched(object):
+    """streams and persistent buffers of one training plan on one device"""
+
+    def __init__(self, dev, nlev):
+        self.dev = dev
+        self.lv = [torch.cuda.Stream(device=dev) for _ in range(nlev)]
+        self.w = torch.cuda.Stream(device=dev)
+        self.bufs = {}
+        self.finals = ops.WgradFinals(dev)
+
+    def buf(self, key, numel, dtype=torch.float32):
+        """a buffer that keeps its address from iteration to iteration (partial sums, private gradient rows)"""
+        t = self.bufs.get(key)
+        if t is None or t.numel() != numel or t.dtype != dtype:
+            t = torch.empty(numel, dtype=dtype, device=self.dev)
+            self.bufs[key] = t
+        return t
+
+
+def _sched(plan_owner, dev, nlev):
+    sc = plan_owner.__dict__.get('_lfd_train_sched')
+    if sc is None or sc.dev != dev or len(sc.lv) != nlev:
+        sc = _Sched(dev, nlev)
+        plan_owner.__dict__['_lfd_train_sched'] = sc
+    return sc
+
+
+def _out_pack(o, cache):
+    key = tuple(id(cv) for _, cv in o.convs)           # shared heads: one concatenation + pack for all levels
+    if key not in cache:
+        wp, bp = _out_weight(o)
+        cache[key] = (wp, bp, ops.pack_conv_weight_train(wp), ops.pack_conv_weight_train(wp, data_gradient=True))
+    return cache[key]
+
+
+def network_forward(model, plan, x):
+    """-> (cls [N,P,C'], reg [N,P,4], sizes, saved): LFD.forward in train mode (lfd.py:511-542) over the unit schedule, the
+    pyramid levels on their own streams."""
+    units, outs, nlev = plan
+    dev = x.device
+    sc = _sched(model, dev, nlev)
+    main = torch.cuda.current_stream(dev)
+    par = PARALLEL
+    acts, tape = {0: x}, [None] * len(units)
+    zeros = _Zeros(dev)
+    for c in (32, 64, 128):
+        zeros(c)
+    packs = _Packs(units, False)
+    opk = {}
+    for o in outs:
+        _out_pack(o, opk)
+    taps = set(u.src for u in units if u.level is not None and any(v.dst == u.src and v.level is None for v in units))
+    # the level-concatenated outputs exist before any level starts (allocated on the caller's stream, in its order)
+    hw = {0: (x.size(2), x.size(3))}
+    for u in units:
+        k, st_ = u.conv.kernel_size[0], u.conv.stride[0]
+        h_, w_ = hw[u.src]
+        hw[u.dst] = ((h_ + 2 * (k // 2) - k) // st_ + 1, (w_ + 2 * (k // 2) - k) // st_ + 1)
+    sizes = [None] * nlev
+    for o in outs:
+        sizes[o.level] = hw[o.src]
+    starts, p = [], 0
+    for h_, w_ in sizes:
+        starts.append(p)
+        p += h_ * w_
+    width = {}
+    for o in outs:
+        for kind, conv in o.convs:
+            width[kind] = conv.out_channels
+    full = {k: torch.empty((x.size(0), p, c), dtype=torch.float32, device=dev) for k, c in width.items()}
+    fused_stats = os.environ.get('LFD_CONV_BN_STATS', '1') == '1'
+    ev, started = {}, set()
+
+    def stream_of(level):
+        return sc.lv[level] if (par and level is not None) else main
+
+    for ui, u in enumerate(units):
+        S = stream_of(u.level)
+        if par and u.level is not None and u.level not in started:
+            started.add(u.level)
+            S.wait_event(ev[u.src])                 # the level starts when its backbone tap exists
+        with torch.cuda.stream(S):
+            tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats)
+        if par and u.level is None and u.dst in taps:
+            e = torch.cuda.Event()
+            e.record(main)
+            ev[u.dst] = e
+    torch._foreach_add_([u.norm.num_batches_tracked for u in units if isinstance(u.norm, nn.BatchNorm2d)], 1)
+    # ---- output convs: one padded 1x1 conv per level + the slices into the level-concatenated fp32 tensors
+    osaved = []
+    for o in outs:
+        S = stream_of(o.level)
+        with torch.cuda.stream(S):
+            xo = acts[o.src]
+            assert tuple(xo.shape[1:3]) == sizes[o.level]
+            c = xo.size(3)
+            wp, bp, wpk, _ = _out_pack(o, opk)
+            y = ops.conv2d_nhwc(xo, wpk, bp, c, wp.size(0), 1, 1, False)
+            segs = _out_segs(o)
+            ops.head_out_split(y, segs, [full[sg['kind']] for sg in segs], starts[o.level])
+            osaved.append((wp, y))
+    if par:
+        for S in sc.lv:
+            main.wait_stream(S)
+    return full['cls'], full['reg'], sizes, ((acts, tape), osaved, opk)
+
+
+def _unit_forward(u, acts, packs, zeros, fused_stats):
+    """conv -> norm (batch / group statistics) -> (+ residual) -> ReLU of one unit on the current stream; -> (y, stats)"""
+    conv, norm = u.conv, u.norm
+    xin = acts[u.src]
+    ks, st = conv.kernel_size[0], conv.stride[0]
+    stats = None
+    if u.first and isinstance(norm, nn.BatchNorm2d) and fused_stats:
+        y, stats = ops.stem_conv0_train_fwd_bn_stats(xin, conv.weight, norm.eps, norm.momentum, norm.running_mean,
+                                                     norm.running_var)
+    elif u.first:
+        y = ops.stem_conv0_train_fwd(xin, conv.weight)
+    elif isinstance(norm, nn.BatchNorm2d) and fused_stats:
+        cout = conv.out_channels
+        y, stats = ops.conv2d_bn_stats(xin, packs(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, norm.eps,
+                                       norm.momentum, norm.running_mean, norm.running_var)
+    else:
+        cout = conv.out_channels
+        y = ops.conv2d_nhwc(xin, packs(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, False)
+    if isinstance(norm, nn.GroupNorm):
+        stats = ops.gn_train_stats(y, norm.num_groups, norm.eps)
+        z = ops.gn_train_apply(y, norm.num_groups, stats, norm.weight.detach(), norm.bias.detach(), u.relu)
+    else:
+        if stats is None:
+            stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
+        z = ops.bn_train_apply(y, stats, norm.weight.detach(), norm.bias.detach(),
+                               acts[u.res] if u.res is not None else None, u.relu)
+    acts[u.dst] = z
+    return y, stats
+
+
+def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
+    """the backward of network_forward: parameter gradients accumulate into `.grad` (created zeroed when missing)."""
+    units, outs, nlev = plan
+    (acts, tape), osaved, opk = saved
+    dev = dcls.device
+    sc = _sched(model, dev, nlev)
+    main = torch.cuda.current_stream(dev)
+    par = PARALLEL
+    inv = 1.0 / scale
+    store = _GradStore(in_place=True)
+    fin = sc.finals
+    fin.reset()
+    keep = []               # tensors read on another stream than the one that owns their memory: referenced until the joins
+    zeros = _Zeros(dev)
+    for c in (32, 64, 128):
+        zeros(c)
+    packs = _Packs(units, True)
+    dcls, dreg = dcls.contiguous(), dreg.contiguous()
+    full = {'cls': dcls, 'reg': dreg}
+    # every gradient target exists before the streams fork (a missing .grad is created zeroed on the caller's stream)
+    for u in units:
+        for p_ in (u.conv.weight, u.norm.weight, u.norm.bias):
+            store.target(p_)
+    for o in outs:
+        for _, cv in o.convs:
+            store.target(cv.weight)
+            store.target(cv.bias)
+        if o.scale is not None:
+            store.target(o.scale._scale)
+    # private per-level rows of the small gradients several levels share: GroupNorm weight / bias, output-conv biases
+    small, off = {}, 0
+    for u in units:
+        if isinstance(u.norm, nn.GroupNorm):
+            for p_ in (u.norm.weight, u.norm.bias):
+                if id(p_) not in small:
+                    small[id(p_)] = (p_, off)
+                    off += p_.numel()
+    for o in outs:
+        for _, cv in o.convs:
+            if id(cv.bias) not in small:
+                small[id(cv.bias)] = (cv.bias, off)
+                off += cv.bias.numel()
+    rows = sc.buf(('small', off), max(1, nlev * off)).view(nlev, max(1, off)) if off else None
+    if rows is not None:
+        rows.zero_()
+
+    def row(p_, level):
+        _, o_ = small[id(p_)]
+        return rows[level, o_:o_ + p_.numel()]
+
+    starts, p = [], 0
+    for h, w_ in sizes:
+        starts.append(p)
+        p += h * w_
+
+    def stream_of(level):
+        return sc.lv[level] if (par and level is not None) else main
+    wst = sc.w if par else main
+    if par:
+        for S in sc.lv + [sc.w]:
+            S.wait_stream(main)
+    nj = [0]
+
+    def wgrad(S, xin, dy, ks, st, targets):
+        """the partial sums of dW on the side stream; `targets` as ops.WgradFinals.add_wgrad"""
+        floats, nwg, nblk = ops.conv_wgrad_partial_floats(xin, dy, ks, st)
+        part = sc.buf(('wg', nj[0]), floats)
+        nj[0] += 1
+        if par:
+            wst.wait_stream(S)
+            keep.extend((xin, dy))
+        with torch.cuda.stream(wst):
+            ops.conv_wgrad_partials(xin, dy, ks, st, part)
+        fin.add_wgrad(part, nwg, nblk, xin.size(3), dy.size(3), ks * ks, inv, targets)
+
+    grads, owner = {}, {}
+
+    def visible(S, k):
+        """grads[k] may have been written on another stream"""
+        o_ = owner.get(k)
+        if par and o_ is not None and o_ is not S:
+            S.wait_stream(o_)
+            keep.append(grads[k])
+        owner[k] = S
+
+    # ---- output convs
+    for o, (wp, y) in zip(outs, osaved):
+        S = stream_of(o.level)
+        with torch.cuda.stream(S):
+            xo = acts[o.src]
+            c = xo.size(3)
+            segs = _out_segs(o)
+            for sg in segs:
+                sg['dbias'] = row(sg['conv'].bias, o.level)
+                sg['dscale'] = store.target(o.scale._scale) if sg['scale'] is not None else None
+            dy = ops.head_out_grad(y, segs, [full[sg['kind']] for sg in segs], starts[o.level], scale)
+            r0, targets = 0, []
+            for _, cv in o.convs:
+                targets.append((store.target(cv.weight), r0, r0 + cv.out_channels))
+                r0 += cv.out_channels
+            wgrad(S, xo, dy, 1, 1, targets)
+            visible(S, o.src)
+            grads[o.src] = ops.conv2d_nhwc(dy, _out_pack(o, opk)[3], zeros(c), wp.size(0), c, 1, 1, False, residual=grads.get(o.src))
+    # ---- conv / norm / ReLU units, last to first
+    for ui in range(len(units) - 1, -1, -1):
+        u = units[ui]
+        if u.dst not in grads:
+            continue
+        S = stream_of(u.level)
+        with torch.cuda.stream(S):
+            visible(S, u.dst)
+            dz = grads.pop(u.dst)
+            owner.pop(u.dst, None)
+            conv, norm = u.conv, u.norm
+            y, stats = tape[ui]
+            z = acts[u.dst] if u.relu else None
+            g = None
+            if isinstance(norm, nn.GroupNorm):
+                lvl = u.level if u.level is not None else 0
+                dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, row(norm.weight, lvl),
+                                           row(norm.bias, lvl), False)
+            else:
+                dy, g = ops.bn_train_backward(dz, y, z if u.res is not None else None, stats, norm.weight.detach(), inv,
+                                              store.target(norm.weight), store.target(norm.bias), want_g=u.res is not None,
+                                              accumulate=True, relu=u.relu, beta=norm.bias.detach())
+            if u.res is not None:
+                if u.res in grads:
+                    visible(S, u.res)
+                    grads[u.res] = grads[u.res] + g
+                else:
+                    grads[u.res] = g
+                    owner[u.res] = S
+            xin = acts[u.src]
+            ks, st = conv.kernel_size[0], conv.stride[0]
+            if u.first:
+                if par:
+                    wst.wait_stream(S)
+                    keep.extend((xin, dy))
+                with torch.cuda.stream(wst):
+                    ops.stem_conv0_wgrad(xin, dy, inv, out=store.target(conv.weight), accumulate=True)
+                continue
+            wgrad(S, xin, dy, ks, st, [(store.target(conv.weight), 0, conv.out_channels)])
+            cin = conv.in_channels
+            if u.src in grads:
+                visible(S, u.src)
+            else:
+                owner[u.src] = S
+            if st == 2 and ks == 3 and cin == 64 and conv.out_channels == 64 and os.environ.get('LFD_DGRAD_S2', '1') == '1':
+                grads[u.src] = ops.conv3x3s2_dgrad(dy, packs(conv.weight, True), xin.size(1), xin.size(2), residual=grads.get(u.src))
+            else:
+                if st == 2:
+                    dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
+                grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, ks, 1, False,
+                                               residual=grads.get(u.src))
+    # ---- joins, then the two final launches
+    if par:
+        for S in sc.lv + [sc.w]:
+            main.wait_stream(S)
+    if rows is not None:
+        for p_, o_ in small.values():
+            fin.add_rowsum(rows[0, o_:o_ + p_.numel()], nlev, rows.stride(0), p_.numel(), store.target(p_), True)
+    fin.launch()
+    del keep[:]
+
+
 class BackboneTrainFunction(torch.autograd.Function):
     """taps (NCHW fp32) = backbone(x) as one autograd node (used when neck / head are not covered by network_supported)."""
 
@@ -567,14 +887,12 @@ class BackboneTrainFunction(torch.autograd.Function):
 
 class NetworkTrainFunction(torch.autograd.Function):
     """(cls [N,P,C'], reg [N,P,4]) = LFD.forward(x) in train mode as ONE autograd node: every conv / norm / ReLU of
-    backbone, neck and head runs forward and backward on the hand-written kernels."""
+    backbone, neck and head runs forward and backward on the hand-written kernels (network_forward / network_backward)."""
 
     @staticmethod
-    def forward(ctx, plan, x, *params):
-        units, outs, num_levels = plan
-        _, saved = forward(units, [], x)
-        cls, reg, sizes, osaved = outputs_forward(outs, saved[0], num_levels)
-        ctx.plan, ctx.saved, ctx.osaved, ctx.sizes = plan, saved, osaved, sizes
+    def forward(ctx, model, plan, x, *params):
+        cls, reg, sizes, saved = network_forward(model, plan, x)
+        ctx.model, ctx.plan, ctx.saved, ctx.sizes = model, plan, saved, sizes
         ctx.shapes = (cls.shape, reg.shape)
         NetworkTrainFunction.last_sizes = sizes
         return cls, reg
@@ -582,17 +900,14 @@ class NetworkTrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcls, dreg):
         units, outs, _ = ctx.plan
-        store = _GradStore(in_place=True)
-        dev = ctx.saved[0][0].device
+        dev = ctx.saved[0][0][0].device
         if dcls is None:
             dcls = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
         if dreg is None:
             dreg = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
-        scale = loss_scale()
-        grads = outputs_backward(outs, ctx.saved[0], ctx.osaved, ctx.sizes, dcls.contiguous(), dreg.contiguous(), store, scale=scale)
-        backward(units, ctx.saved, grads, scale=scale, store=store)
-        ctx.saved = ctx.osaved = None
-        return (None, None) + (None,) * len(network_params(units, outs))   # accumulated into .grad directly
+        network_backward(ctx.model, ctx.plan, ctx.saved, ctx.sizes, dcls, dreg, loss_scale())
+        ctx.saved = None
+        return (None, None, None) + (None,) * len(network_params(units, outs))   # accumulated into .grad directly
 
 
 def backbone_train_forward(backbone, x):
@@ -610,5 +925,5 @@ def network_train_forward(model, x):
         units, outs = build_network(model)
         plan = (units, outs, model._num_heads)
         model.__dict__['_lfd_train_plan'] = plan
-    cls, reg = NetworkTrainFunction.apply(plan, x, *network_params(plan[0], plan[1]))
+    cls, reg = NetworkTrainFunction.apply(model, plan, x, *network_params(plan[0], plan[1]))
     return cls, reg, NetworkTrainFunction.last_sizes

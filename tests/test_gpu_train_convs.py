@@ -598,3 +598,66 @@ def test_stride2_data_gradient_per_parity_is_bit_identical_to_the_zero_inserted_
         dx64 = dx64 + res.double().cpu().permute(0, 3, 1, 2)
     err = (got.double().cpu().permute(0, 3, 1, 2) - dx64).abs()
     assert bool((err <= 2e-3 * dx64.abs().clamp(min=1.0)).all()), float(err.max())
+
+
+@pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_S', (2, 128, 160)), ('TT100K_LFD_L', (2, 96, 128)), ('WIDERFACE_LFD_XS', (3, 192, 224))])
+def test_parallel_network_schedule_equals_the_serial_unit_schedule(name, shape):
+    """train_engine.network_forward / network_backward (round 4: pyramid levels on their own streams, weight gradients on a side
+    stream into private partial buffers, ONE batched final launch, private per-level rows for the small shared gradients)
+    against the serial unit API (train_engine.forward / outputs_forward / outputs_backward / backward: the launches in list
+    order on one stream, a final launch per conv): outputs and activation-side results bit for bit; parameter gradients equal
+    up to the ONE rounding the batched final saves per shared parameter (<= 1e-6 of the tensor's largest entry, measured
+    <= 2e-7); PARALLEL on / off: every gradient bit for bit."""
+    import copy
+    from lfd_amd import configs, train_engine
+    torch.manual_seed(3)
+    m0 = configs.build_model(name).cuda().train()
+    configs.perturb_weights(m0, seed=1)
+    n, h, w = shape
+    x = (torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(5)) * 2 - 1).cuda()
+    S = train_engine.LOSS_SCALE
+
+    def serial():
+        m = copy.deepcopy(m0)
+        units, outs = train_engine.build_network(m)
+        _, saved = train_engine.forward(units, [], x)
+        cls, reg, sizes, osaved = train_engine.outputs_forward(outs, saved[0], m._num_heads)
+        g = torch.Generator(device='cuda').manual_seed(9)
+        wc, wr = torch.randn(cls.shape, generator=g, device='cuda') * 1e-2, torch.randn(reg.shape, generator=g, device='cuda') * 1e-2
+        store = train_engine._GradStore()
+        grads = train_engine.outputs_backward(outs, saved[0], osaved, sizes, wc, wr, store)
+        train_engine.backward(units, saved, grads, store=store)
+        return m, cls, reg, wc, wr, {k: store.get(p) for k, p in m.named_parameters()}
+
+    def parallel(flag):
+        m = copy.deepcopy(m0)
+        keep = train_engine.PARALLEL
+        train_engine.PARALLEL = flag
+        try:
+            cls, reg = m(x)
+            cls.backward(wc, retain_graph=True)
+            reg.backward(wr)
+            torch.cuda.synchronize()
+        finally:
+            train_engine.PARALLEL = keep
+        return m, cls.detach(), reg.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    ms, cls_s, reg_s, wc, wr, gs = serial()
+    results = {}
+    for flag in (True, False, True):                       # twice with streams: the persistent buffers are re-used
+        mp, cls_p, reg_p, gp = parallel(flag)
+        assert torch.equal(cls_p, cls_s) and torch.equal(reg_p, reg_s)
+        for (k, a), b in zip(ms.state_dict().items(), mp.state_dict().values()):
+            assert torch.equal(a, b), k                    # BatchNorm running statistics, num_batches_tracked
+        worst = 0.0
+        for k in gs:
+            a, b = gs[k], gp[k]
+            assert a is not None and b is not None, k
+            e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-20))
+            worst = max(worst, e)
+            assert e <= 1e-6, (k, e)
+        results.setdefault(flag, []).append(gp)
+        print('%s PARALLEL=%s: worst relative gradient difference to the serial schedule %.2e' % (name, flag, worst))
+    for k in gs:
+        assert torch.equal(results[True][0][k], results[False][0][k]), k
+        assert torch.equal(results[True][0][k], results[True][1][k]), k
