@@ -548,6 +548,11 @@ LFD_API int lfd_gn_train_stats_f16(const void* y, int32_t n, int64_t hw, int32_t
                            void* workspace, size_t workspace_bytes, float* stats, lfd_stream_t stream);
 LFD_API int lfd_gn_train_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, const float* stats,
                            const float* gamma, const float* beta, int32_t relu, void* z, lfd_stream_t stream);
+/* lfd_gn_train_stats_f16 + lfd_gn_train_apply_f16 in two launches instead of three: the apply pass adds the per-block partial
+ * sums of its image itself (same fp64 arithmetic; `stats` is an OUTPUT here, written for the backward pass). */
+LFD_API int lfd_gn_train_stats_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, float eps,
+                                 const float* gamma, const float* beta, int32_t relu, void* workspace, size_t workspace_bytes,
+                                 float* stats, void* z, lfd_stream_t stream);
 LFD_API int lfd_gn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t n, int64_t hw, int32_t channels,
                          int32_t groups, const float* stats, const float* gamma, float inv_scale, int32_t accumulate,
                          void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy,

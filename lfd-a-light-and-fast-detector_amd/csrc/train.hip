@@ -101,12 +101,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 inline bool channels_ok(int c) { return c >= 8 && c <= kMaxC && (c & (c - 1)) == 0; }
 
-// LFD_BN_LOADS=2: the BatchNorm streaming passes request two vectors per lane before using the first (see k_bn_apply)
-inline int bn_loads() {
-  static const int v = [] { const char* e = getenv("LFD_BN_LOADS"); return e ? atoi(e) : 1; }();
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Per-channel reductions over an NHWC fp16 tensor [m][c]: every thread owns one 8-channel group (the grid stride is
 // a multiple of c/8), accumulates NQ quantities per channel in fp32, the block combines the threads of a group through
@@ -209,52 +203,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
   }
 }
 
-// k_bn_*_u<U> (the three BatchNorm streaming passes again): U vectors requested per lane before the first one is used.  With U = 1 a wave has 32-48
-// bytes per lane in flight and the 16 waves of a CU cover ~4.5 TB/s of the ~2 us loaded latency (the 320 x 320 stem units:
-// 5.45 / 4.5 / 5.4 TB/s for apply / backward sums / backward apply); U = 2 doubles that.  Vectors are consumed in the order of
-// the rolled loop, so every sum is the same sum bit for bit.  LFD_BN_LOADS=2 selects them; one timing at the end of round 3 showed no gain, the default stays the kernels above.
-template <int U>
-__global__ __launch_bounds__(kThreads) void k_bn_apply_u(const __half* __restrict__ y, int64_t vecs, int c,
-                                                      const float* __restrict__ stats,
-                                                      const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta,
-                                                      const __half* __restrict__ res, int relu,
-                                                      __half* __restrict__ z) {
-  const int groups = c >> 3;
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
-  float a[8], b[8];
-  for (int e = 0; e < 8; ++e) {
-    const int ch = cg * 8 + e;
-    a[e] = gamma[ch] * stats[c + ch];
-    b[e] = beta[ch] - stats[ch] * a[e];
-  }
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < vecs; v0 += U * stride) {
-    h8 h[U], r[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v < vecs) {
-        h[u] = ld8(y, v);
-        if (res) r[u] = ld8(res, v);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v >= vecs) break;
-      h8 o;
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)h[u][e] * a[e] + b[e];
-        if (res) f += (float)r[u][e];
-        if (relu) f = fmaxf(f, 0.f);
-        o[e] = (_Float16)f;
-      }
-      st8(z, v, o);
-    }
-  }
-}
-
 // sums of g and g * xhat, g = dz * [ReLU passed]: mask from the stored output z when given (units with a residual
 // input), else -- relu_y -- recomputed from y as [gamma * xhat + beta > 0] (saves reading z), else no ReLU
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __restrict__ dz,
@@ -290,52 +238,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
   block_channel_reduce<2>(acc, c, partials);
 }
 
-template <int U>
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_partial_u(const __half* __restrict__ dz,
-                                                            const __half* __restrict__ y,
-                                                            const __half* __restrict__ z, int64_t vecs, int c,
-                                                            const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int relu_y,
-                                                            float* partials) {
-  const int groups = c >> 3;
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
-  float mean[8], rstd[8], acc[2][8], ga[8], be[8];
-  for (int e = 0; e < 8; ++e) {
-    mean[e] = stats[cg * 8 + e];
-    rstd[e] = stats[c + cg * 8 + e];
-    ga[e] = relu_y ? gamma[cg * 8 + e] : 0.f;
-    be[e] = relu_y ? beta[cg * 8 + e] : 0.f;
-    acc[0][e] = acc[1][e] = 0.f;
-  }
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < vecs; v0 += U * stride) {
-    h8 d[U], yy[U], zz[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v < vecs) {
-        d[u] = ld8(dz, v);
-        yy[u] = ld8(y, v);
-        if (z) zz[u] = ld8(z, v);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (v0 + u * stride >= vecs) break;
-      for (int e = 0; e < 8; ++e) {
-        float g = (float)d[u][e];
-        const float xh = ((float)yy[u][e] - mean[e]) * rstd[e];
-        if (z && !((float)zz[u][e] > 0.f)) g = 0.f;
-        if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
-        acc[0][e] += g;
-        acc[1][e] += g * xh;
-      }
-    }
-  }
-  block_channel_reduce<2>(acc, c, partials);
-}
-
 // sums[0][c] = sum g (= dbeta * scale), sums[1][c] = sum g*xhat (= dgamma * scale); parameter gradients unscaled
 __global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int nblocks, int c, float inv_scale,
                                                     int accumulate, float* sums, float* dgamma, float* dbeta) {
@@ -365,14 +267,34 @@ __global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int 
   if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)(sx * (double)inv_scale);
 }
 
+constexpr int kFoldRows = 64;    // partial rows a FOLD apply pass re-adds per workgroup (64 x 2c floats from L2)
+
+// FOLD: `sums` are the k_bn_bwd_partial rows [nrows][2][c] -- every workgroup adds them itself (fp64, row order; c <= 128),
+// workgroup 0 also writes dgamma / dbeta: the apply pass of a small map does not wait for a k_bn_bwd_final launch
+template <bool FOLD>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restrict__ dz,
                                                           const __half* __restrict__ y,
                                                           const __half* __restrict__ z, int64_t vecs, int c,
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu_y,
-                                                          const float* __restrict__ sums, float inv_m,
+                                                          const float* __restrict__ sums, int nrows, float inv_scale,
+                                                          int accumulate, float* dgamma, float* dbeta, float inv_m,
                                                           __half* __restrict__ dy, __half* __restrict__ g_out) {
+  __shared__ float ssum[FOLD ? 2 * 128 : 1];
+  if constexpr (FOLD) {
+    for (int o = threadIdx.x; o < 2 * c; o += kThreads) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < nrows; ++r) s += (double)sums[(size_t)r * 2 * c + o];
+      ssum[o] = (float)s;
+      if (blockIdx.x == 0) {
+        float* dst = o < c ? dbeta : dgamma;
+        if (dst) dst[o < c ? o : o - c] = (accumulate ? dst[o < c ? o : o - c] : 0.f) + (float)(s * (double)inv_scale);
+      }
+    }
+    __syncthreads();
+  }
   const int groups = c >> 3;
   const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
   float mean[8], rstd[8], a[8], mg[8], mgx[8], ga[8], be[8];
@@ -383,8 +305,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     ga[e] = gamma[ch];
     be[e] = relu_y ? beta[ch] : 0.f;
     a[e] = gamma[ch] * rstd[e];
-    mg[e] = sums[ch] * inv_m;
-    mgx[e] = sums[c + ch] * inv_m;
+    mg[e] = (FOLD ? ssum[ch] : sums[ch]) * inv_m;
+    mgx[e] = (FOLD ? ssum[c + ch] : sums[c + ch]) * inv_m;
   }
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
     const h8 d = ld8(dz, v), yy = ld8(y, v);
@@ -400,59 +322,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     }
     st8(dy, v, o);
     if (g_out) st8(g_out, v, go);
-  }
-}
-
-template <int U>
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply_u(const __half* __restrict__ dz,
-                                                          const __half* __restrict__ y,
-                                                          const __half* __restrict__ z, int64_t vecs, int c,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int relu_y,
-                                                          const float* __restrict__ sums, float inv_m,
-                                                          __half* __restrict__ dy, __half* __restrict__ g_out) {
-  const int groups = c >> 3;
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
-  float mean[8], rstd[8], a[8], mg[8], mgx[8], ga[8], be[8];
-  for (int e = 0; e < 8; ++e) {
-    const int ch = cg * 8 + e;
-    mean[e] = stats[ch];
-    rstd[e] = stats[c + ch];
-    ga[e] = gamma[ch];
-    be[e] = relu_y ? beta[ch] : 0.f;
-    a[e] = gamma[ch] * rstd[e];
-    mg[e] = sums[ch] * inv_m;
-    mgx[e] = sums[c + ch] * inv_m;
-  }
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < vecs; v0 += U * stride) {
-    h8 d[U], yy[U], zz[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v < vecs) {
-        d[u] = ld8(dz, v);
-        yy[u] = ld8(y, v);
-        if (z) zz[u] = ld8(z, v);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v >= vecs) break;
-      h8 o, go;
-      for (int e = 0; e < 8; ++e) {
-        float g = (float)d[u][e];
-        const float xh = ((float)yy[u][e] - mean[e]) * rstd[e];
-        if (z && !((float)zz[u][e] > 0.f)) g = 0.f;
-        if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
-        o[e] = (_Float16)(a[e] * (g - mg[e] - xh * mgx[e]));
-        go[e] = (_Float16)g;
-      }
-      st8(dy, v, o);
-      if (g_out) st8(g_out, v, go);
-    }
   }
 }
 
@@ -529,13 +398,43 @@ __global__ __launch_bounds__(64) void k_gn_stats_final(const float* partials, in
   stats[(size_t)blockIdx.x * 2 * g + g + cg] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// FOLD: `stats` is written HERE -- every workgroup of an image adds that image's k_gn_stats_partial rows itself (<= 64 rows
+// of 2g floats, fp64, row order; the arithmetic of k_gn_stats_final), workgroup x == 0 stores them for the backward pass: the
+// apply pass does not wait for a k_gn_stats_final launch (10 dependent ~4-6 us launches of a WIDERFACE_LFD_S iteration)
+template <bool FOLD>
 __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict__ y, int64_t vecs_per_img, int g,
-                                                      const float* __restrict__ stats,
+                                                      float* __restrict__ stats, const float* __restrict__ partials,
+                                                      int nblocks, double m, float eps,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int relu,
                                                       __half* __restrict__ z) {
+  __shared__ float sst[FOLD ? 64 : 1];
+  if constexpr (FOLD) {
+    if (threadIdx.x < g) {
+      const int cg_ = threadIdx.x;
+      double s = 0.0, ss = 0.0;
+#pragma unroll 4
+      for (int b = 0; b < nblocks; ++b) {
+        const float* p = partials + ((size_t)blockIdx.y * nblocks + b) * 2 * g;
+        s += (double)p[cg_];
+        ss += (double)p[g + cg_];
+      }
+      const double mean = s / m;
+      double var = ss / m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+      sst[cg_] = mf;
+      sst[g + cg_] = rf;
+      if (blockIdx.x == 0) {
+        stats[(size_t)blockIdx.y * 2 * g + cg_] = mf;
+        stats[(size_t)blockIdx.y * 2 * g + g + cg_] = rf;
+      }
+    }
+    __syncthreads();
+  }
   const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
-  const float mean = stats[(size_t)blockIdx.y * 2 * g + cg], rstd = stats[(size_t)blockIdx.y * 2 * g + g + cg];
+  const float mean = FOLD ? sst[cg] : stats[(size_t)blockIdx.y * 2 * g + cg];
+  const float rstd = FOLD ? sst[g + cg] : stats[(size_t)blockIdx.y * 2 * g + g + cg];
   float a[8], b[8];
   for (int e = 0; e < 8; ++e) {
     a[e] = gamma[cg * 8 + e] * rstd;
@@ -1035,6 +934,7 @@ struct WgradArgs {
   int n, h, w, ho, wo, cin, cout;
   int tiles_y, tiles_x;
   float* partials;
+  int vtaps;      // 9: this launch of the 1x1 kernel is ONE TAP (blockIdx.z) of a 3x3 conv -- x is read at the tap's offset
 };
 
 template <int KS, int S>
@@ -1048,6 +948,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
   const int ch = wave >> 1, ih = wave & 1;
   const bool active = (cb * 64 + ch * 32 < a.cout) && (ib * 64 + ih * 32 < a.cin);
+  // tap-split form (small maps, KS == 1 instantiations only): dW[tap] = sum over pixels of dy (x) x shifted by the tap
+  const int vtap = (KS == 1 && a.vtaps == 9) ? (int)blockIdx.z : 0;
+  const int offy = (KS == 1 && a.vtaps == 9) ? vtap / 3 - 1 : 0, offx = (KS == 1 && a.vtaps == 9) ? vtap % 3 - 1 : 0;
   f16v acc[KS * KS];
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t)
@@ -1090,7 +993,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
     for (int j = 0; j < NX; ++j) {
       const int i = tid + j * kThreads;
       const int c8 = i & 7, p = i >> 3;
-      const int iy = ty * C::TH * S - C::PAD + p / C::XW, ix = tx * C::TW * S - C::PAD + p % C::XW;
+      const int iy = ty * C::TH * S - C::PAD + p / C::XW + offy, ix = tx * C::TW * S - C::PAD + p % C::XW + offx;
       const int ci = ib * 64 + c8 * 8;
       const bool ok = i < C::XH * C::XW * 8 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w && ci < a.cin;
       const int64_t off = ok ? ((((int64_t)img * a.h + iy) * a.w + ix) * a.cin + ci) : 0;
@@ -1135,7 +1038,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
     __syncthreads();
   }
   // ---- partial[wg][block][tap][co 64][ci 64]: D layout lane = column (ci), reg r -> row (co) 8*(r>>2) + 4*(l>>5) + (r&3)
-  float* out = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (KS * KS * 64 * 64);
+  float* out = (KS == 1 && a.vtaps == 9)
+                   ? a.partials + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 9 + vtap) * (64 * 64)
+                   : a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (KS * KS * 64 * 64);
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t)
 #pragma unroll
@@ -1272,7 +1177,7 @@ int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
   WgradArgs a = a0;
   a.tiles_y = (a.ho + C::TH - 1) / C::TH;
   a.tiles_x = (a.wo + C::TW - 1) / C::TW;
-  hipLaunchKernelGGL((k_wgrad<KS, S>), dim3(nwg, nblk), dim3(kThreads), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_wgrad<KS, S>), dim3(nwg, nblk, a.vtaps == 9 ? 9 : 1), dim3(kThreads), C::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1349,12 +1254,8 @@ int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, cons
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!y || !stats || !gamma || !beta || !z || pixels < 1 || !channels_ok(channels)) return LFD_ERR_INVALID_ARGUMENT;
   const int64_t vecs = pixels * (channels / 8);
-  if (bn_loads() == 2)
-    hipLaunchKernelGGL(k_bn_apply_u<2>, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
-                       stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
-  else
-    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
-                       stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
+                     stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1375,25 +1276,26 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t r
   const unsigned g = grid_for_vecs(vecs);
   float* partials = reinterpret_cast<float*>(workspace);
   float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
-  const bool two = bn_loads() == 2;
-  if (two)
-    hipLaunchKernelGGL(k_bn_bwd_partial_u<2>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
-  else
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
+  // Small maps (<= 16 MB per tensor; stages 1-3, necks and the like at 640 x 640): the sums pass runs kFoldRows workgroups and
+  // the apply pass re-adds their rows itself (FOLD: fp64, row order, every workgroup the same sum; workgroup 0 writes dgamma /
+  // dbeta) -- one dependent ~5.6 us launch less per unit (25 of the 35 k_bn_bwd_final launches of a WIDERFACE_LFD_S iteration)
+  const bool fold = vecs <= ((int64_t)1 << 20) && channels <= 128;
+  const unsigned gp = fold && g > (unsigned)kFoldRows ? (unsigned)kFoldRows : g;
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(gp), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
-                     dgamma, dbeta);
-  LFD_CHECK_LAUNCH();
-  if (two)
-    hipLaunchKernelGGL(k_bn_bwd_apply_u<2>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
-                       (__half*)dy, (__half*)g_out);
-  else
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
-                       (__half*)dy, (__half*)g_out);
+  if (fold) {
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials, (int)gp, inv_scale, accumulate,
+                       dgamma, dbeta, (float)(1.0 / (double)pixels), (__half*)dy, (__half*)g_out);
+  } else {
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
+                       dgamma, dbeta);
+    LFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, 0, 0.f, 0, nullptr, nullptr,
+                       (float)(1.0 / (double)pixels), (__half*)dy, (__half*)g_out);
+  }
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1431,8 +1333,25 @@ int lfd_gn_train_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channel
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!y || !stats || !gamma || !beta || !z || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
   const int64_t vpi = hw * groups;
-  hipLaunchKernelGGL(k_gn_apply, dim3(gn_blocks(vpi, n), n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, stats,
-                     gamma, beta, relu, (__half*)z);
+  hipLaunchKernelGGL(k_gn_apply<false>, dim3(gn_blocks(vpi, n), n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups,
+                     const_cast<float*>(stats), nullptr, 0, 0.0, 0.f, gamma, beta, relu, (__half*)z);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_gn_train_stats_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, float eps,
+                                 const float* gamma, const float* beta, int32_t relu, void* workspace, size_t workspace_bytes,
+                                 float* stats, void* z, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!y || !stats || !gamma || !beta || !z || !workspace || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t vpi = hw * groups;
+  const unsigned b = gn_blocks(vpi, n);
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_gn_stats_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, partials);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gn_apply<true>, dim3(b, n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, stats, partials, (int)b,
+                     (double)hw * 8.0, eps, gamma, beta, relu, (__half*)z);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1475,8 +1394,18 @@ int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi,
   return LFD_OK;
 }
 
+// Workgroups and partial rows of a weight gradient.  Every workgroup row leaves taps x 64 x 64 floats per (cout, cin) block
+// behind for the final sum, so rows are bytes: round 3 used as many rows as its workspace held (up to 1024) and an iteration
+// of WIDERFACE_LFD_S wrote and re-read 1.29 GB of partials -- 38 MB for a stage-3 conv whose operands are 1.6 MB.  Round 4:
+//  * 1x1: rows x blocks ~ 1024 / 512 / 256 workgroups by operand size (the kernel prefetches: one or two per CU suffice);
+//  * 3x3 on SMALL maps (operands <= 16 MB: stages 1-3 at 640x640): TAP-SPLIT -- the 1x1 kernel runs one tap per
+//    blockIdx.z with x read at the tap's offset (dW[tap] = sum dy (x) x shifted), 288-360 workgroups = splits x blocks x 9,
+//    ~5 MB of partials whatever the layer; the 9 workgroups of a split share an XCD (splits x blocks is a multiple of 8), so
+//    the nine reads of an operand tile meet in one L2;
+//  * 3x3 on large maps: all taps per workgroup as before (operands read once), 256 rows (stride 2: up to 512 on the
+//    largest map, where 75 MB of partials are 14 % of the operands).
 static int wgrad_geometry(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks, int32_t stride, int* nwg_out,
-                          int* nblk_out, int* ho_out, int* wo_out) {
+                          int* nblk_out, int* ho_out, int* wo_out, int* tap_split_out) {
   if (n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
   if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return LFD_ERR_INVALID_ARGUMENT;
   if (cin < 8 || cout < 8 || (cin & 7) || (cout & 7) || cin > 128 || cout > 128) return LFD_ERR_INVALID_ARGUMENT;
@@ -1484,25 +1413,34 @@ static int wgrad_geometry(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t 
   const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
   const int nblk = ((cout + 63) / 64) * ((cin + 63) / 64);
   const int tiles = n * ((ho + 7) / 8) * ((wo + 15) / 16);
-  // as many workgroups as the partial buffer holds (1x1: 2048, 3x3 64x64: 1024, 3x3 128x128: 256): several per CU hide
-  // the synchronous tile staging behind each other's MFMAs
-  int nwg = (kWgradMaxWg * 4 * 9) / (nblk * ks * ks);
-  if (ks == 3 && nwg > (stride == 1 ? 256 : 512)) nwg = stride == 1 ? 256 : 512;   // the fixed-order sum of the partials costs 147 KB of traffic per workgroup;
-                                                                                  // stride 1 prefetches the next tile in registers and needs no second workgroup per CU
+  const int64_t operand_bytes = ((int64_t)n * h * w * cin + (int64_t)n * ho * wo * cout) * 2;
+  int nwg, tap_split = 0;
+  if (ks == 3 && operand_bytes <= (16 << 20)) {
+    tap_split = 1;
+    nwg = nblk == 1 ? 40 : (nblk == 2 ? 16 : 8);
+  } else if (ks == 3) {
+    nwg = 256;
+    if (stride == 2) { nwg = tiles / 6; if (nwg < 256) nwg = 256; if (nwg > 512) nwg = 512; }
+  } else {
+    const int target = operand_bytes >= (128 << 20) ? 1024 : (operand_bytes >= (32 << 20) ? 512 : 256);
+    nwg = target / nblk;
+  }
   if (nwg > kWgradWgCap) nwg = kWgradWgCap;
   if (nwg > tiles) nwg = tiles;
-  *nwg_out = nwg; *nblk_out = nblk; *ho_out = ho; *wo_out = wo;
+  *nwg_out = nwg; *nblk_out = nblk; *ho_out = ho; *wo_out = wo; *tap_split_out = tap_split;
   return LFD_OK;
 }
 
 static int wgrad_launch(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks,
-                        int32_t stride, float* partials, int nwg, int nblk, int ho, int wo, hipStream_t st) {
+                        int32_t stride, float* partials, int nwg, int nblk, int ho, int wo, int tap_split, hipStream_t st) {
   WgradArgs a{};
   a.x = (const __half*)x;
   a.dy = (const __half*)dy;
   a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
   a.ho = ho; a.wo = wo;
   a.partials = partials;
+  a.vtaps = tap_split ? 9 : 0;
+  if (tap_split) return stride == 1 ? launch_wgrad<1, 1>(a, nwg, nblk, st) : launch_wgrad<1, 2>(a, nwg, nblk, st);
   if (ks == 3 && stride == 1) return launch_wgrad<3, 1>(a, nwg, nblk, st);
   if (ks == 3) return launch_wgrad<3, 2>(a, nwg, nblk, st);
   if (stride == 1) return launch_wgrad<1, 1>(a, nwg, nblk, st);
@@ -1514,12 +1452,12 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
                             size_t workspace_bytes, float* dw, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!x || !dy || !dw || !workspace) return LFD_ERR_INVALID_ARGUMENT;
-  int nwg, nblk, ho, wo;
-  int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo);
+  int nwg, nblk, ho, wo, ts;
+  int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo, &ts);
   if (rc != LFD_OK) return rc;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
   float* partials = reinterpret_cast<float*>(workspace);
-  rc = wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, st);
+  rc = wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, ts, st);
   if (rc != LFD_OK) return rc;
   const int taps = ks * ks, total = nblk * taps * 64 * 64;
   hipLaunchKernelGGL(k_wgrad_final, dim3(total / 128), dim3(kThreads), 0, st, partials, nwg, nblk,
@@ -1529,19 +1467,19 @@ int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h,
 }
 
 int32_t lfd_conv_wgrad_partial_rows(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks, int32_t stride) {
-  int nwg, nblk, ho, wo;
-  const int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo);
+  int nwg, nblk, ho, wo, ts;
+  const int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo, &ts);
   return rc != LFD_OK ? rc : nwg;
 }
 
 int lfd_conv_wgrad_partials_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
                                      int32_t ks, int32_t stride, float* partials, size_t partials_bytes, lfd_stream_t stream) {
   if (!x || !dy || !partials) return LFD_ERR_INVALID_ARGUMENT;
-  int nwg, nblk, ho, wo;
-  const int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo);
+  int nwg, nblk, ho, wo, ts;
+  const int rc = wgrad_geometry(n, h, w, cin, cout, ks, stride, &nwg, &nblk, &ho, &wo, &ts);
   if (rc != LFD_OK) return rc;
   if (partials_bytes < (size_t)nwg * nblk * ks * ks * 64 * 64 * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
-  return wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, reinterpret_cast<hipStream_t>(stream));
+  return wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, ts, reinterpret_cast<hipStream_t>(stream));
 }
 
 int lfd_wgrad_final_batched_f32(const lfd_wgrad_job_t* jobs_device, int32_t njobs, int32_t total_blocks, lfd_stream_t stream) {

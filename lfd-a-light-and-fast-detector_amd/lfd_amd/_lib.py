@@ -172,6 +172,7 @@ _SIGNATURES = {
     'lfd_pack_conv_weight_train_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_gn_train_stats_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _F, _P, _SZ, _P, _P]),
     'lfd_gn_train_apply_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
+    'lfd_gn_train_stats_apply_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _F, _P, _P, _I32, _P, _SZ, _P, _P, _P]),
     'lfd_gn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_zero_insert2_nhwc_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_conv3x3s2_dgrad_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P]),

@@ -763,6 +763,19 @@ def gn_train_apply(y, groups, stats, gamma, beta, relu=True):
     return z
 
 
+def gn_train_stats_apply(y, groups, eps, gamma, beta, relu=True):
+    """gn_train_stats + gn_train_apply as two launches (lfd_gn_train_stats_apply_f16) -> (stats, z)"""
+    _nhwc16(y, 'gn_train_stats_apply')
+    n, h, w_, c = y.shape
+    stats = torch.empty(n * 2 * groups, dtype=torch.float32, device=y.device)
+    z = torch.empty_like(y)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_gn_train_stats_apply_f16(ptr(y), n, h * w_, c, groups, float(eps), ptr(gamma), ptr(beta), int(bool(relu)),
+                                                 ptr(ws), ws.numel(), ptr(stats), ptr(z), stream_ptr()), 'lfd_gn_train_stats_apply_f16')
+    return stats, z
+
+
 def gn_train_backward(dz, y, z, groups, stats, gamma, inv_scale, dgamma, dbeta, accumulate=False):
     _nhwc16(dz, 'gn_train_backward')
     n, h, w_, c = y.shape

@@ -131,9 +131,20 @@ class GraphedTrainStep(object):
             raise RuntimeError('GraphedTrainStep: this model does not run on the all-HIP training path; use train_step')
         dev = image_batch.device
         self.x = torch.empty_like(image_batch).contiguous()
-        self.boxes = torch.zeros((self.max_boxes, 4), dtype=torch.float32, device=dev)
-        self.labels = torch.zeros((self.max_boxes,), dtype=torch.int64, device=dev)
-        self.offs = torch.zeros((image_batch.size(0) + 1,), dtype=torch.int32, device=dev)
+        # annotations: ONE device buffer [boxes f32 [max_boxes, 4] | labels i64 [max_boxes] | offsets i32 [n + 1]] filled by
+        # ONE copy from a pinned host buffer of the same layout per iteration (three pageable copies cost ~0.2 ms of
+        # host-side latency in front of every replay, tools/timing/train_trace.py)
+        mb, n = self.max_boxes, image_batch.size(0)
+        nbytes = 16 * mb + 8 * mb + 4 * (n + 1)
+        self.ann = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.ann_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self.boxes = self.ann[:16 * mb].view(torch.float32).view(mb, 4)
+        self.labels = self.ann[16 * mb:24 * mb].view(torch.int64)
+        self.offs = self.ann[24 * mb:].view(torch.int32)
+        hv = self.ann_host.numpy()
+        self._h_boxes = hv[:16 * mb].view(np.float32).reshape(mb, 4)
+        self._h_labels = hv[16 * mb:24 * mb].view(np.int64)
+        self._h_offs = hv[24 * mb:].view(np.int32)
         self.adesc = None
 
     def _upload(self, image_batch, annotation_batch):
@@ -143,18 +154,22 @@ class GraphedTrainStep(object):
             raise RuntimeError('GraphedTrainStep: image batch %s, captured for %s' % (tuple(image_batch.shape), tuple(self.x.shape)))
         if image_batch.data_ptr() != self.x.data_ptr():
             self.x.copy_(image_batch)             # (fill `step.x` in place to save this copy)
-        bl = [np.asarray(b, dtype=np.float32).reshape(-1, 4) for b, _ in annotation_batch]
-        ll = [np.asarray(l, dtype=np.int64).reshape(-1) for _, l in annotation_batch]
-        if len(bl) != self.x.size(0):
+        if len(annotation_batch) != self.x.size(0):
             raise RuntimeError('GraphedTrainStep: one annotation per image')
-        counts = [b.shape[0] for b in bl]
-        k = int(sum(counts))
-        if k > self.max_boxes:
-            raise RuntimeError('GraphedTrainStep: %d annotations in the batch, capacity max_boxes=%d' % (k, self.max_boxes))
-        self.offs.copy_(torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)))
-        if k:
-            self.boxes[:k].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate(bl, 0))))
-            self.labels[:k].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate(ll, 0))))
+        k = 0
+        self._h_offs[0] = 0
+        for i, (b, l) in enumerate(annotation_batch):
+            b = np.asarray(b, dtype=np.float32).reshape(-1, 4)
+            l = np.asarray(l, dtype=np.int64).reshape(-1)
+            g = b.shape[0]
+            if k + g > self.max_boxes:
+                raise RuntimeError('GraphedTrainStep: more than max_boxes=%d annotations in the batch' % self.max_boxes)
+            self._h_boxes[k:k + g] = b
+            self._h_labels[k:k + g] = l
+            k += g
+            self._h_offs[i + 1] = k
+        # (the previous replay has been synchronised by its loss read-back: the pinned buffer is free to rewrite)
+        self.ann.copy_(self.ann_host, non_blocking=True)
 
     # ------------------------------------------------------------------ one iteration, device side only
     def _iteration(self, clip):

@@ -244,14 +244,20 @@ class _Packs(object):
         return self.c[k]
 
 
+_zero_cache = {}
+
+
 class _Zeros(object):
+    """zero bias vectors (the units' convs have none): persistent per device -- nobody writes them"""
+
     def __init__(self, dev):
-        self.dev, self.z = dev, {}
+        self.dev = dev
 
     def __call__(self, n):
-        if n not in self.z:
-            self.z[n] = torch.zeros(n, dtype=torch.float32, device=self.dev)
-        return self.z[n]
+        k = (self.dev.type, self.dev.index, n)
+        if k not in _zero_cache:
+            _zero_cache[k] = torch.zeros(n, dtype=torch.float32, device=self.dev)
+        return _zero_cache[k]
 
 
 def forward(units, tap_ids, x):
@@ -556,7 +562,7 @@ def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=None):
 #     through chained partial sets / private per-level rows summed by the same final launches -- no read-modify-write on a
 #     shared gradient from two streams, and one rounding instead of one per level.
 # PARALLEL = False runs the same launches on the caller's stream (identical results bit for bit: the A/B and the test).
-PARALLEL = True
+PARALLEL = False
 
 
 class _Sched(object):
@@ -568,6 +574,7 @@ class _Sched(object):
         self.w = torch.cuda.Stream(device=dev)
         self.bufs = {}
         self.finals = ops.WgradFinals(dev)
+        self.gather = ops.WgradFinals(dev)      # (its row-sum table with one source row = a batched copy)
 
     def buf(self, key, numel, dtype=torch.float32):
         """a buffer that keeps its address from iteration to iteration (partial sums, private gradient rows)"""
@@ -586,12 +593,42 @@ def _sched(plan_owner, dev, nlev):
     return sc
 
 
+def _out_packs(sc, outs):
+    """{ids of a level's output convs: (padded weight [64, C, 1, 1], padded bias [64], forward pack, data-gradient pack)}: the
+    rows of the convs are gathered into persistent zero-padded buffers by ONE launch (lfd_rows_sum_batched_f32 with one source
+    row = a batched copy), then packed; shared heads: once for all levels"""
+    cache, jobs = {}, []
+    for o in outs:
+        key = tuple(id(cv) for _, cv in o.convs)
+        if key in cache:
+            continue
+        c = o.convs[0][1].in_channels
+        rows = -(-sum(cv.out_channels for _, cv in o.convs) // 64) * 64
+        wp = sc.bufs.get(('outw', key))
+        if wp is None:
+            wp = torch.zeros((rows, c, 1, 1), dtype=torch.float32, device=sc.dev)
+            sc.bufs[('outw', key)] = wp
+            sc.bufs[('outb', key)] = torch.zeros(rows, dtype=torch.float32, device=sc.dev)
+        bp = sc.bufs[('outb', key)]
+        r0 = 0
+        for _, cv in o.convs:
+            n_ = cv.out_channels
+            jobs.append((cv.weight.detach(), wp[r0:r0 + n_]))
+            jobs.append((cv.bias.detach(), bp[r0:r0 + n_]))
+            r0 += n_
+        cache[key] = [wp, bp]
+    fin = sc.gather
+    fin.reset()
+    for src, dst in jobs:
+        fin.add_rowsum(src, 1, src.numel(), src.numel(), dst, False)
+    fin.launch()
+    for v in cache.values():
+        v.extend((ops.pack_conv_weight_train(v[0]), ops.pack_conv_weight_train(v[0], data_gradient=True)))
+    return cache
+
+
 def _out_pack(o, cache):
-    key = tuple(id(cv) for _, cv in o.convs)           # shared heads: one concatenation + pack for all levels
-    if key not in cache:
-        wp, bp = _out_weight(o)
-        cache[key] = (wp, bp, ops.pack_conv_weight_train(wp), ops.pack_conv_weight_train(wp, data_gradient=True))
-    return cache[key]
+    return cache[tuple(id(cv) for _, cv in o.convs)]
 
 
 def network_forward(model, plan, x):
@@ -607,9 +644,7 @@ def network_forward(model, plan, x):
     for c in (32, 64, 128):
         zeros(c)
     packs = _Packs(units, False)
-    opk = {}
-    for o in outs:
-        _out_pack(o, opk)
+    opk = _out_packs(sc, outs)
     taps = set(u.src for u in units if u.level is not None and any(v.dst == u.src and v.level is None for v in units))
     # the level-concatenated outputs exist before any level starts (allocated on the caller's stream, in its order)
     hw = {0: (x.size(2), x.size(3))}
@@ -685,8 +720,7 @@ def _unit_forward(u, acts, packs, zeros, fused_stats):
         cout = conv.out_channels
         y = ops.conv2d_nhwc(xin, packs(conv.weight), zeros(cout), conv.in_channels, cout, ks, st, False)
     if isinstance(norm, nn.GroupNorm):
-        stats = ops.gn_train_stats(y, norm.num_groups, norm.eps)
-        z = ops.gn_train_apply(y, norm.num_groups, stats, norm.weight.detach(), norm.bias.detach(), u.relu)
+        stats, z = ops.gn_train_stats_apply(y, norm.num_groups, norm.eps, norm.weight.detach(), norm.bias.detach(), u.relu)
     else:
         if stats is None:
             stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)

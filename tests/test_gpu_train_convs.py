@@ -106,28 +106,6 @@ def _bn_pass_outputs(seed=3):
     return outs
 
 
-def test_bn_passes_with_two_vectors_in_flight_are_bit_identical():
-    """k_bn_apply_u<2> / k_bn_bwd_partial_u<2> / k_bn_bwd_apply_u<2> consume their vectors in the order of the rolled loops:
-    every output tensor and every sum equals the default kernels' bit for bit.  LFD_BN_LOADS is read once per process."""
-    import os, subprocess, sys, tempfile
-    want = [t.cpu() for t in _bn_pass_outputs()]
-    with tempfile.TemporaryDirectory() as d:
-        code = '''
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import test_gpu_train_convs as t
-torch.save([x.cpu() for x in t._bn_pass_outputs()], %r)
-print('ok')
-''' % (os.path.dirname(os.path.abspath(__file__)),
-       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lfd-a-light-and-fast-detector_amd'), os.path.join(d, 'o.pt'))
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, LFD_BN_LOADS='2'), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-2000:]
-        got = torch.load(os.path.join(d, 'o.pt'))
-    assert len(got) == len(want)
-    for i, (a, b) in enumerate(zip(got, want)):
-        assert torch.equal(a, b), i
-
-
 @pytest.mark.parametrize('c,relu,with_res', [(64, True, True), (128, True, False), (32, False, False)])
 def test_bn_train_backward_vs_autograd(c, relu, with_res):
     shape = (2, 29, 41, c)
@@ -187,6 +165,9 @@ def test_gn_train_forward_backward_vs_autograd(relu):
                                rtol=1e-5, atol=0)
     z = ops.gn_train_apply(y, groups, stats, gamma, beta, relu)
     torch.testing.assert_close(_nchw(z), o.detach(), rtol=2e-3, atol=2e-3)
+    # the two-launch form (round 4: the apply pass adds the partial rows itself): the same statistics and output bit for bit
+    stats2, z2 = ops.gn_train_stats_apply(y, groups, 1e-5, gamma, beta, relu)
+    assert torch.equal(stats2, stats) and torch.equal(z2, z)
     dgamma, dbeta = torch.full((c,), 2.0, device='cuda'), torch.full((c,), -1.0, device='cuda')
     scale = 16.0
     dy = ops.gn_train_backward((dz.float() * scale).half(), y, z if relu else None, groups, stats, gamma, 1 / scale, dgamma,
@@ -535,8 +516,10 @@ def test_whole_network_train_forward_backward(name, hw, monkeypatch):
     train_engine.backward(units, saved, grads, store=store, trace=trace)
     assert len(trace) == len(units)
     _check_units_against_autograd(units, acts, tape, trace, S)
-    for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):      # hand-driven == the autograd node, bit for bit
-        assert torch.equal(pa.grad, store.get(pb)), k
+    # hand-driven serial unit schedule == the autograd node (network_backward: one batched final launch, one rounding per
+    # parameter where the serial schedule rounds once per pyramid level): <= 1e-6 of the tensor's largest entry
+    for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert float((pa.grad - store.get(pb)).abs().max()) <= 1e-6 * float(pa.grad.abs().max()) + 1e-30, k
     # end to end vs fp32 autograd over the same unit graph with the HIP path's own ReLU masks (see _mask_replay_reference):
     # backbone, neck, the GroupNorm towers shared by the pyramid levels, output convs and Scale -- tight
     ref, leaves = _mask_replay_reference(units, acts, x)
@@ -635,8 +618,7 @@ def test_parallel_network_schedule_equals_the_serial_unit_schedule(name, shape):
         train_engine.PARALLEL = flag
         try:
             cls, reg = m(x)
-            cls.backward(wc, retain_graph=True)
-            reg.backward(wr)
+            torch.autograd.backward([cls, reg], [wc, wr])
             torch.cuda.synchronize()
         finally:
             train_engine.PARALLEL = keep
