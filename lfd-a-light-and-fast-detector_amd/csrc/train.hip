@@ -267,34 +267,14 @@ __global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int 
   if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)(sx * (double)inv_scale);
 }
 
-constexpr int kFoldRows = 64;    // partial rows a FOLD apply pass re-adds per workgroup (64 x 2c floats from L2)
-
-// FOLD: `sums` are the k_bn_bwd_partial rows [nrows][2][c] -- every workgroup adds them itself (fp64, row order; c <= 128),
-// workgroup 0 also writes dgamma / dbeta: the apply pass of a small map does not wait for a k_bn_bwd_final launch
-template <bool FOLD>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restrict__ dz,
                                                           const __half* __restrict__ y,
                                                           const __half* __restrict__ z, int64_t vecs, int c,
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu_y,
-                                                          const float* __restrict__ sums, int nrows, float inv_scale,
-                                                          int accumulate, float* dgamma, float* dbeta, float inv_m,
+                                                          const float* __restrict__ sums, float inv_m,
                                                           __half* __restrict__ dy, __half* __restrict__ g_out) {
-  __shared__ float ssum[FOLD ? 2 * 128 : 1];
-  if constexpr (FOLD) {
-    for (int o = threadIdx.x; o < 2 * c; o += kThreads) {
-      double s = 0.0;
-#pragma unroll 8
-      for (int r = 0; r < nrows; ++r) s += (double)sums[(size_t)r * 2 * c + o];
-      ssum[o] = (float)s;
-      if (blockIdx.x == 0) {
-        float* dst = o < c ? dbeta : dgamma;
-        if (dst) dst[o < c ? o : o - c] = (accumulate ? dst[o < c ? o : o - c] : 0.f) + (float)(s * (double)inv_scale);
-      }
-    }
-    __syncthreads();
-  }
   const int groups = c >> 3;
   const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
   float mean[8], rstd[8], a[8], mg[8], mgx[8], ga[8], be[8];
@@ -305,8 +285,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     ga[e] = gamma[ch];
     be[e] = relu_y ? beta[ch] : 0.f;
     a[e] = gamma[ch] * rstd[e];
-    mg[e] = (FOLD ? ssum[ch] : sums[ch]) * inv_m;
-    mgx[e] = (FOLD ? ssum[c + ch] : sums[c + ch]) * inv_m;
+    mg[e] = sums[ch] * inv_m;
+    mgx[e] = sums[c + ch] * inv_m;
   }
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
     const h8 d = ld8(dz, v), yy = ld8(y, v);
@@ -1276,26 +1256,18 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t r
   const unsigned g = grid_for_vecs(vecs);
   float* partials = reinterpret_cast<float*>(workspace);
   float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
-  // Small maps (<= 16 MB per tensor; stages 1-3, necks and the like at 640 x 640): the sums pass runs kFoldRows workgroups and
-  // the apply pass re-adds their rows itself (FOLD: fp64, row order, every workgroup the same sum; workgroup 0 writes dgamma /
-  // dbeta) -- one dependent ~5.6 us launch less per unit (25 of the 35 k_bn_bwd_final launches of a WIDERFACE_LFD_S iteration)
-  const bool fold = vecs <= ((int64_t)1 << 20) && channels <= 128;
-  const unsigned gp = fold && g > (unsigned)kFoldRows ? (unsigned)kFoldRows : g;
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(gp), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+  // (Round 4 tried folding k_bn_bwd_final into the apply pass for small maps -- the sums pass on 64 workgroups, every apply
+  // workgroup re-adding the 64 rows: the 21 saved launches (6.3 us each) were paid back by the slower 64-workgroup sums pass
+  // (+6 us each) and the re-add (+4 us each): 7.06 against 6.98 ms per iteration.  Three launches it stays.)
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
   LFD_CHECK_LAUNCH();
-  if (fold) {
-    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials, (int)gp, inv_scale, accumulate,
-                       dgamma, dbeta, (float)(1.0 / (double)pixels), (__half*)dy, (__half*)g_out);
-  } else {
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
-                       dgamma, dbeta);
-    LFD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, 0, 0.f, 0, nullptr, nullptr,
-                       (float)(1.0 / (double)pixels), (__half*)dy, (__half*)g_out);
-  }
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
+                     dgamma, dbeta);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
+                     (__half*)dy, (__half*)g_out);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

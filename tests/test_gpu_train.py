@@ -193,6 +193,17 @@ def test_graphed_train_step_equals_the_eager_iterations():
     with torch.no_grad():
         c1, _ = mb(xe)
     assert not torch.equal(c0, c1)                     # the engine re-packed the weights the replays wrote
+    mb.train()
+    # sync=False (round 4): five iterations enqueued without reading anything back -- the host runs ahead through the rings
+    # of pinned annotation / loss buffers -- give the same values and parameters as the synchronous calls on the twin
+    batches = [(torch.from_numpy(rng.normal(0, 1, (4, 3, 160, 192)).astype(np.float32)).cuda(), _annotations(rng, 4, (160, 192)))
+               for _ in range(5)]
+    pend = [step(x, ann, True, sync=False)[0] for x, ann in batches]
+    want = [train.train_step(ma, oa, x, ann, clip, True)[0] for x, ann in batches]
+    assert pend[-1].get() == want[-1] and pend[-2].get() == want[-2] and pend[-3].get() == want[-3]
+    torch.cuda.synchronize()
+    for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.equal(pa, pb), k
     with pytest.raises(RuntimeError):
         step(torch.randn(2, 3, 160, 192, device='cuda'), _annotations(rng, 2, (160, 192)))     # another batch shape
 
