@@ -261,21 +261,21 @@ def train_bench(dev, steps=10, warmup=3):
     graphed = None
     try:
         step = train.GraphedTrainStep(m, opt, clip, max_boxes=1024)
-        ts_sync, lv = timed(lambda: step(x if step.x is None else step.x, ann, True))     # frames written into the step's own buffer
-        # the training loop as it runs between two log lines: iterations enqueued back to back (sync=False), the loss of the
-        # last one read at the end -- the device does not wait for the host between replays
+        ts, lv = timed(lambda: step(x if step.x is None else step.x, ann, True))     # frames written into the step's own buffer
+        # the same iterations enqueued back to back (sync=False: no read-back between replays), the last loss read at the end.
+        # Measured round 4: NOT faster (7.23 against 7.08 ms) -- without the ~0.13 ms host gap between replays the chip sits
+        # at its power limit and clocks lower; reported, not used as the headline of this key
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             pend, _ = step(step.x, ann, True, sync=False)
-        lv = pend.get()
+        pend.get()
         torch.cuda.synchronize()
-        ts = [(time.perf_counter() - t0) / steps] * steps
+        ts_b2b = (time.perf_counter() - t0) / steps
         graphed = True
     except Exception as e:       # keep the eager number
         graphed = repr(e)
         ts = ts_eager
-        ts_sync = ts_eager
     dt = float(np.median(ts))
     gf = 3 * 8.606 * bs
     return dict(workload='WIDERFACE_LFD_S train step 640x640 bs 32 (forward + targets + loss + backward + clip + SGD), fp16 '
@@ -283,9 +283,10 @@ def train_bench(dev, steps=10, warmup=3):
                 images_per_s=round(bs / dt, 1), gflop_per_iter=round(gf, 1), tflops=round(gf / dt / 1e3, 1),
                 frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup, loss=lv['loss'],
                 hip_graph=graphed, ms_per_iter_eager=round(float(np.median(ts_eager)) * 1e3, 3),
-                ms_per_iter_sync=(round(float(np.median(ts_sync)) * 1e3, 3) if graphed is True else None),
-                note='ms_per_iter: iterations enqueued back to back (loss read after the last); ms_per_iter_sync: the loss values '
-                     'read back after every iteration; ms_per_iter_eager: ~400 eager launches per iteration')
+                ms_per_iter_back_to_back=(round(ts_b2b * 1e3, 3) if graphed is True else None),
+                note='ms_per_iter: one HIP graph per iteration, the loss values read back after every iteration (median); '
+                     'ms_per_iter_back_to_back: iterations enqueued without read-back (GraphedTrainStep sync=False); '
+                     'ms_per_iter_eager: ~400 eager launches per iteration')
 
 
 def siblings_bench(dev, reps=20, n=8, h=720, w=1280):
