@@ -61,6 +61,28 @@ LFD_API const char* lfd_hip_status_string(int status);
 /* "gfx950;<compiler>;<build date>" */
 LFD_API const char* lfd_hip_build_info(void);
 
+/* Tuning knobs: which kernel variant an entry point dispatches to where several compute the SAME result (bit for bit; the
+ * hash-identity tests flip them) or an A/B timing needs a choice.  Process-global, explicit, thread-safe (relaxed atomics);
+ * the library reads no environment variable.  (Rounds 1-3 read LFD_* variables once per process inside the library; the
+ * Python host layer still translates those names into lfd_tuning_set calls when it loads the library, lfd_amd/_lib.py.)
+ * lfd_tuning_set -> 0 / LFD_ERR_INVALID_ARGUMENT; lfd_tuning_get of an unknown key -> 0. */
+typedef enum lfd_tune_key {
+  LFD_TUNE_HEAD2 = 0,          /* 1: wave-per-32-pixel head passes (k_head2); 0: k_head (4 waves per 64-pixel tile)        default 1 */
+  LFD_TUNE_H2_CHUNK = 1,       /* >= 2 (even): force this many 32-pixel groups per k_head2 work chunk; 0: planned by size   default 0 */
+  LFD_TUNE_H2_AGPR = 2,        /* 1: output pass loads the folded tower filters straight into AccVGPRs                     default 1 */
+  LFD_TUNE_H2_A1 = 3,          /* 1: output pass reads the tower-1 activations pass 2 stored instead of recomputing them   default 1 */
+  LFD_TUNE_STEM2X = 4,         /* 1: fused 'faster' stem with both 32-channel slabs per wave (k_stem2x)                    default 1 */
+  LFD_TUNE_X2_ALN = 5,         /* 1: aligned dword frame loads + funnel shift in k_stem2x                                  default 1 */
+  LFD_TUNE_X2_STAGGER = 6,     /* 1: start-up stagger of k_stem2x workgroups (measured slower since round 2)               default 0 */
+  LFD_TUNE_BLOCK_ROWS = 7,     /* -1: residual block kernel by map size; 0: k_block64 (8 x 16 tiles); 1: k_block64_rows    default -1 */
+  LFD_TUNE_ROWS_WGS = 8,       /* > 0: workgroups per k_block64_rows launch; 0: one per CU                                 default 0 */
+  LFD_TUNE_CONV128_SPLITK = 9, /* 1: split-K kernel for 128 -> 128 3x3 convs on maps of <= 16384 pixels                    default 1 */
+  LFD_TUNE_CONV0_VALU = 10,    /* 1: the first stem conv of the training path on the VALU kernels instead of MFMA         default 0 */
+  LFD_TUNE_COUNT = 11
+} lfd_tune_key_t;
+LFD_API int lfd_tuning_set(int32_t key, int32_t value);
+LFD_API int32_t lfd_tuning_get(int32_t key);
+
 /* HOST-side members of the nms_ext surface, for CPU tensors / numpy arrays (host pointers, no stream): the reference's
  * module dispatches `nms` on the tensor's device (nms_ext.cpp:18-27 -> cpu/nms_cpu.cpp:7-66) and has `soft_nms`
  * (nms_cpu.cpp:76-206) and `nms_match` (:220-283) for CPU tensors only.  Not a fallback of the device path.

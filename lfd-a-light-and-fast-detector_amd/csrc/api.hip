@@ -1,5 +1,12 @@
 // csrc/api.hip -- version / status / build-info entry points of the C ABI.
+#include <atomic>
+
 #include "common.h"
+
+// defaults of the tuning knobs, in lfd_tune_key_t order (include/lfd_hip.h)
+static std::atomic<int> g_tune[LFD_TUNE_COUNT] = {{1}, {0}, {1}, {1}, {1}, {1}, {0}, {-1}, {0}, {1}, {0}};
+
+int lfd_tune(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 
 extern "C" {
 
@@ -18,5 +25,13 @@ const char* lfd_hip_status_string(int status) {
 }
 
 const char* lfd_hip_build_info(void) { return "gfx950;" __VERSION__ ";" __DATE__; }
+
+int lfd_tuning_set(int32_t key, int32_t value) {
+  if (key < 0 || key >= LFD_TUNE_COUNT) return LFD_ERR_INVALID_ARGUMENT;
+  g_tune[key].store(value, std::memory_order_relaxed);
+  return LFD_OK;
+}
+
+int32_t lfd_tuning_get(int32_t key) { return (key < 0 || key >= LFD_TUNE_COUNT) ? 0 : g_tune[key].load(std::memory_order_relaxed); }
 
 }  // extern "C"

@@ -501,7 +501,7 @@ int lfd_block64_rows_launch(const _Float16* in, _Float16* out, const void* w1, c
                             const _Float16* zeros, int n, int h, int w, hipStream_t st);
 // LFD_BLOCK_ROWS: '0' = always the 8 x 16 tile kernel below, '1' = always the row-streaming kernel, unset = by map size
 static int block_rows_mode() {
-  static const int m = [] { const char* e = getenv("LFD_BLOCK_ROWS"); return e ? atoi(e) : -1; }();
+  const int m = lfd_tune(LFD_TUNE_BLOCK_ROWS);
   return m;
 }
 // measured per shape (tools/timing/block_rows_sweep.py, same session, rows vs tiles): 8 x 135 x 240 -12 %, 32 x 135 x 240 -17 %,

@@ -436,7 +436,7 @@ int lfd_block64_rows_launch(const _Float16* in, _Float16* out, const void* w1, c
   }
   a.strips = (w + RB::TW - 1) / RB::TW;
   const long cols = (long)n * a.strips;
-  static const int target = [] { const char* e = getenv("LFD_ROWS_WGS"); return e ? atoi(e) : 0; }();     // (A/B: workgroups per launch)
+  const int target = lfd_tune(LFD_TUNE_ROWS_WGS);     // (A/B: workgroups per launch)
   int segs = (int)((target > 0 ? target : cus) / cols);
   if (segs < 1) segs = 1;
   int sh = (h + segs - 1) / segs;

@@ -67,3 +67,7 @@ __device__ __forceinline__ float lfd_load_f(const void* p, int64_t i, int dtype)
   return dtype == LFD_F16 ? __half2float(reinterpret_cast<const __half*>(p)[i])
                           : reinterpret_cast<const float*>(p)[i];
 }
+
+// Tuning knobs (include/lfd_hip.h: lfd_tuning_set / lfd_tuning_get) -- the library's only mutable global state; every kernel
+// variant a test or an A/B timing selects goes through here instead of a getenv() read once behind the caller's back.
+int lfd_tune(int key);

@@ -81,7 +81,7 @@ static int conv_dispatch(const lfd_conv_desc_t* d, const void* in, void* out, co
     case 128 * 10000 + 3100 + 40: {
       // small maps (the 17 x 30 / 23 x 40 last stages): 4 x the workgroups, a quarter of the filter and of the k-steps each
       // (conv_small.hip); large maps (sibling heads) keep the streamed-weight kernel.  LFD_CONV128_SPLITK=0: A/B switch.
-      static const bool splitk = [] { const char* e = getenv("LFD_CONV128_SPLITK"); return !e || atoi(e) != 0; }();
+      const bool splitk = lfd_tune(LFD_TUNE_CONV128_SPLITK) != 0;
       if (splitk && (long)a.N * a.OH * a.OW <= 16384)
         return lfd_conv128_splitk_launch(a.in, a.out, w_packed, bias, a.res, a.N, a.H, a.W, a.relu, st);
       return launch_conv<128, 3, 1, 4, false, false>(a, st);

@@ -442,7 +442,7 @@ constexpr int H2_CH = 12;      // longest chunk (384 pixels): 904 chunks for 8 x
 // H2_CH groups; the small levels get shorter chunks (their few chunks would otherwise be the longest-running
 // work items of the launch).  8 x 1080p: (85 + 22 + 8 + 4 + 2) chunks per image = 968 chunks = 242 work items.
 inline void h2_plan_chunks(int n, int nlev, const int* gpi, int* chg, int waves_per_simd = 1) {
-  static const int forced = [] { const char* e = getenv("LFD_H2_CHUNK"); return e ? atoi(e) : 0; }();   // tests: any even value
+  const int forced = lfd_tune(LFD_TUNE_H2_CHUNK);   // tests: any even value
   long total = 0;
   for (int j = 0; j < nlev; ++j) total += (long)gpi[j] * n;
   const long slots = 2048L * waves_per_simd;       // two groups per chunk at least; about one chunk per resident wave
@@ -1171,8 +1171,7 @@ int dispatch_head(int pass, int ft, const HeadArgs& a, hipStream_t st) {
 
 // levels whose passes run in k_head2 (and whose statistics therefore occupy one slot per chunk)
 static bool head2_enabled() {
-  static const int use_head2 = [] { const char* e = getenv("LFD_HEAD2"); return e ? atoi(e) : 1; }();
-  return use_head2 != 0;
+  return lfd_tune(LFD_TUNE_HEAD2) != 0;
 }
 int fill_levels(const lfd_head_desc_t* d, int* tile_start, int* tiles_per_img, int* ntiles) {
   if (!d || d->num_levels < 1 || d->num_levels > LFD_MAX_LEVELS || d->n < 1) return LFD_ERR_INVALID_ARGUMENT;
@@ -1260,10 +1259,10 @@ static int head_forward_impl(const lfd_head_desc_t* d, int32_t pass, const lfd_h
     if (pass == 2) return launch_head2<2, 1>(a, st);
     bool fold = true;      // every level brings both folded filters -> AccVGPR-resident variant
     for (int i = 0; i < d->num_levels; ++i) fold = fold && lv[i].w1_folded && lv[i].w2_folded;
-    { static const int use = [] { const char* e = getenv("LFD_H2_AGPR"); return e ? atoi(e) : 1; }(); fold = fold && use; }
+    fold = fold && lfd_tune(LFD_TUNE_H2_AGPR);
     bool a1 = fold;        // ... and pass 2 left conv2's operands behind -> no neck / conv1 recompute
     for (int i = 0; i < d->num_levels; ++i) a1 = a1 && lv[i].tower1_out;
-    { static const int use = [] { const char* e = getenv("LFD_H2_A1"); return e ? atoi(e) : 1; }(); a1 = a1 && use; }
+    a1 = a1 && lfd_tune(LFD_TUNE_H2_A1);
     if (dec) {
       if (ft != 1 || d->final_reg_rows != 4 || d->final_cls_rows != 1) return LFD_ERR_UNSUPPORTED;
       a.dec = *dec;

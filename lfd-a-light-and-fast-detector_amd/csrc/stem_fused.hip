@@ -1078,7 +1078,7 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   if (blocks < 1) return LFD_OK;
   // (round 1's kernel gained 3 % from de-phasing the workgroups' memory bursts with a start delay of up to one tile time; with
   //  the round-2 staging -- one basic block of loads per tile -- the delay only costs: 178 vs 172 us at 8 x 1080p.  Opt-in.)
-  { static const int stg = [] { const char* e = getenv("LFD_X2_STAGGER"); return e ? atoi(e) : 0; }(); a.stagger = stg && a.ntiles >= 16 * blocks; }
+  a.stagger = lfd_tune(LFD_TUNE_X2_STAGGER) && a.ntiles >= 16 * blocks;
   hipLaunchKernelGGL((k_stem2x<U8, ALN>), dim3(blocks), dim3(256), X2::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
@@ -1118,10 +1118,6 @@ int dispatch_fmt(int fmt, const FusedArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// stem_rows.hip: the row-streaming form of the same operator (NHWC fp16 frames, W % 128 == 0, 16-byte aligned base)
-int lfd_stem_rows_launch(const void* in, void* out, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                         const float* b3, const void* w4, const float* b4, int n, int h, int w, hipStream_t st);
-
 extern "C" {
 
 int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
@@ -1141,20 +1137,12 @@ int lfd_stem_faster_fused_f16(const void* in, int32_t in_format, int32_t n, int3
   a.N = n; a.H = h; a.W = w;
   a.H1 = (h - 1) / 2 + 1; a.W1 = (w - 1) / 2 + 1;
   a.H2 = (a.H1 - 1) / 2 + 1; a.W2 = (a.W1 - 1) / 2 + 1;
-  static const int use_x2 = [] { const char* e = getenv("LFD_STEM2X"); return e ? atoi(e) : 1; }();
+  const int use_x2 = lfd_tune(LFD_TUNE_STEM2X);
   // aligned rows: W % 8 == 0 pixels (16-byte row pitch in fp16 / in the virtual fp16 image of a uint8 frame) and, for
   // fp16 frames, a 16-byte aligned base (LFD_X2_ALN=0 forces the general kernel: tests compare the two bit for bit)
-  static const int use_aln = [] { const char* e = getenv("LFD_X2_ALN"); return e ? atoi(e) : 1; }();
+  const int use_aln = lfd_tune(LFD_TUNE_X2_ALN);
   const bool aln = use_aln && (w % 8) == 0;
-  // LFD_STEM_ROWS=1: the row-streaming kernel (stem_rows.hip) whenever the frame suits it.  OPT-IN: measured against k_stem2x
-  // (graph-captured chains over rotating inputs) 1 x 1080p 30.0 vs 32.2 us, 2 x 1080p 48.2 vs 54.3, 8 x 640 x 640 45.7 vs 49.3, but
-  // EQUAL at 8 x 1080p and 4 x 720p (165 us: both at the chip's power limit) -- and it differs from k_stem2x in the last fp16 bit
-  // of a few outputs per million, which the uint8-frame path (k_stem2x<U8>) is tested to match bit for bit.
-  static const int use_rows = [] { const char* e = getenv("LFD_STEM_ROWS"); return e ? atoi(e) : 0; }();
-  if (use_rows == 1 && channels == 64 && in_format == IN_NHWC_F16 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
-    const int rc = lfd_stem_rows_launch(in, out, w1_packed, b1, w2_packed, b2, w3_packed, b3, w4_packed, b4, n, h, w, st);
-    if (rc != LFD_ERR_UNSUPPORTED) return rc;
-  }
+  // (the row-streaming form of this kernel, k_stem_rows, measured equal at 8 x 1080p in round 3: tools/negative_results/stem_rows.hip)
   if (use_x2 && channels == 64 && in_format == IN_NHWC_F16) {
     if (aln && (reinterpret_cast<uintptr_t>(in) & 15) == 0) return launch_stem2x<false, true>(a, st);
     return launch_stem2x<false, false>(a, st);

@@ -1489,7 +1489,7 @@ int lfd_stem_conv0_train_fwd_bn_stats(const float* x_nchw, int32_t n, int32_t h,
   if (!workspace || !stats || (running_mean == nullptr) != (running_var == nullptr)) return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
   const int64_t pixels = (int64_t)n * ((h + 1) / 2) * ((w + 1) / 2);
-  static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
+  const int use_valu = lfd_tune(LFD_TUNE_CONV0_VALU);
   if (channels != 64 || use_valu) {      // the 32-channel stem (XS) and the VALU A/B kernel: conv, then the statistics pass
     const int rc = conv0_fwd(x_nchw, n, h, w, channels, weight_oihw, y, nullptr, nullptr, st);
     if (rc != LFD_OK) return rc;
@@ -1510,7 +1510,7 @@ static int conv0_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32
                      float* stat_partials, unsigned* blocks_out, hipStream_t st) {
   if (!x_nchw || !weight_oihw || !y || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
     return LFD_ERR_INVALID_ARGUMENT;
-  static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
+  const int use_valu = lfd_tune(LFD_TUNE_CONV0_VALU);
   if (!use_valu) {
     const int64_t groups = ((int64_t)n * ((h + 1) / 2) * ((w + 1) / 2) + 127) / 128;   // 4 waves x 32 pixels per block pass
     const unsigned blocks = (unsigned)(groups < 2048 ? groups : 2048);   // (2048 rows x 2 x 64 floats = half the partials area)
@@ -1536,7 +1536,7 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
     return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
   float* partials = reinterpret_cast<float*>(workspace);
-  static const int use_valu = [] { const char* e = getenv("LFD_CONV0_VALU"); return e ? atoi(e) : 0; }();
+  const int use_valu = lfd_tune(LFD_TUNE_CONV0_VALU);
   if (!use_valu) {
     const int64_t ksteps = (int64_t)n * ((h + 1) / 2) * (((w + 1) / 2 + 15) / 16);
     const int nb = (int)(ksteps / 4 < 1 ? 1 : (ksteps / 4 > 1024 ? 1024 : ksteps / 4));

@@ -120,6 +120,8 @@ _SIGNATURES = {
     'lfd_hip_abi_version': (C.c_int, []),
     'lfd_hip_status_string': (C.c_char_p, [C.c_int]),
     'lfd_hip_build_info': (C.c_char_p, []),
+    'lfd_tuning_set': (C.c_int, [_I32, _I32]),
+    'lfd_tuning_get': (_I32, [_I32]),
     'lfd_nms_cpu_f32': (C.c_int, [_P, _I64, _F, _P, _P]),
     'lfd_soft_nms_cpu_f32': (C.c_int, [_P, _I64, _F, _I32, _F, _F, _P, _P]),
     'lfd_nms_match_cpu_f32': (C.c_int, [_P, _I64, _F, _P, _P, _P]),
@@ -209,6 +211,22 @@ _SIGNATURES = {
 }
 
 
+# lfd_tune_key_t (include/lfd_hip.h) and the environment names rounds 1-3 used for the same switches: the LIBRARY reads no
+# environment variable any more; this host layer applies them once, explicitly, when it loads the library (tests and the A/B
+# tools that start a fresh interpreter per variant keep working), and `tune()` sets a knob at run time.
+TUNE_KEYS = {'HEAD2': 0, 'H2_CHUNK': 1, 'H2_AGPR': 2, 'H2_A1': 3, 'STEM2X': 4, 'X2_ALN': 5, 'X2_STAGGER': 6, 'BLOCK_ROWS': 7,
+             'ROWS_WGS': 8, 'CONV128_SPLITK': 9, 'CONV0_VALU': 10}
+
+
+def tune(name, value=None):
+    """tune('BLOCK_ROWS', 0) -> previous value; tune('BLOCK_ROWS') -> current value (lfd_tuning_set / lfd_tuning_get)"""
+    key = TUNE_KEYS[name]
+    prev = lib().lfd_tuning_get(key)
+    if value is not None:
+        check(lib().lfd_tuning_set(key, int(value)), 'lfd_tuning_set')
+    return prev
+
+
 def declared_symbols():
     return sorted(_SIGNATURES)
 
@@ -231,6 +249,10 @@ def lib():
             raise RuntimeError('liblfd_hip.so ABI version mismatch: %s reports %d, this package binds version %d '
                                '(struct layouts differ -- rebuild with `python __graft_entry__.py`)'
                                % (LIB_PATH, l.lfd_hip_abi_version(), ABI_VERSION))
+        for name, key in TUNE_KEYS.items():
+            v = os.environ.get('LFD_' + name)
+            if v is not None and v.strip().lstrip('-').isdigit():
+                l.lfd_tuning_set(key, int(v))
         _lib = l
     return _lib
 

@@ -11,6 +11,5 @@ run() {   # label, env assignments...
 }
 run "default                         " LFD_NOOP=1
 run "LFD_CONV_BN_STATS=0 (stats pass)" LFD_CONV_BN_STATS=0
-run "LFD_OUT_FUSED=0 (torch glue)    " LFD_OUT_FUSED=0
 run "LFD_DGRAD_S2=0 (zero insert)    " LFD_DGRAD_S2=0
 run "default again                   " LFD_NOOP=1
