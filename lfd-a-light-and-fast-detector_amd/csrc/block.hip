@@ -534,7 +534,9 @@ extern "C" int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const 
   a.tiles_x = (w + BK::TW - 1) / BK::TW;
   a.tiles_y = (h + BK::TH - 1) / BK::TH;
   a.ntiles = n * a.tiles_x * a.tiles_y;
-  static int cus = 0;
+  static int cus_of[64] = {};
+  const int dev_ = lfd_device_ordinal();
+  int& cus = cus_of[dev_];
   if (!cus) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block64), hipFuncAttributeMaxDynamicSharedMemorySize,
                             BK::LDS_BYTES) != hipSuccess)

@@ -424,7 +424,9 @@ int lfd_block64_rows_launch(const _Float16* in, _Float16* out, const void* w1, c
   RowsArgs a{};
   a.in = in; a.out = out; a.w1 = (const half8*)w1; a.b1 = b1; a.w2 = (const half8*)w2; a.b2 = b2; a.zeros = zeros;
   a.N = n; a.H = h; a.W = w;
-  static int cus = 0;
+  static int cus_of[64] = {};
+  const int dev_ = lfd_device_ordinal();
+  int& cus = cus_of[dev_];
   if (!cus) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block64_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
                             RB::LDS_BYTES) != hipSuccess)

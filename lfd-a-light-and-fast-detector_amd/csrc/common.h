@@ -68,6 +68,15 @@ __device__ __forceinline__ float lfd_load_f(const void* p, int64_t i, int dtype)
                           : reinterpret_cast<const float*>(p)[i];
 }
 
+// One-time per-DEVICE setup of a launcher (hipFuncSetAttribute and the CU count belong to a device: a process that drives
+// several GPUs must repeat them on each -- ADVICE r3): `mask` is a function-local static, bit = device ordinal.
+static inline int lfd_device_ordinal() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 ? dev : 0;
+}
+#define LFD_ONCE_PER_DEVICE(mask, dev) (!(((mask) >> (dev)) & 1ull))
+#define LFD_DONE_ON_DEVICE(mask, dev) ((mask) |= (1ull << (dev)))
+
 // Tuning knobs (include/lfd_hip.h: lfd_tuning_set / lfd_tuning_get) -- the library's only mutable global state; every kernel
 // variant a test or an A/B timing selects goes through here instead of a getenv() read once behind the caller's back.
 int lfd_tune(int key);

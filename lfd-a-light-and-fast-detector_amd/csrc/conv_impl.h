@@ -745,12 +745,13 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) 
   // the inference shapes all fit two workgroups per CU; a few data-gradient shapes of the training path (few output
   // channels -> tall tiles) only fit one
   static_assert(LDSB <= 160 * 1024, "LDS capacity");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done_mask = 0;
+  const int attr_done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    attr_done = true;
+    LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
   }
   // workgroup b works on XCD b % 8's contiguous tile range [xcd * ceil(ntiles / 8), ...): a small launch needs
   // 8 * ceil(ntiles / 8) workgroups for every tile to have its own (17 tiles on 17 workgroups = two rounds on five XCDs)

@@ -196,12 +196,13 @@ extern "C" int lfd_conv3x3s2_dgrad_nhwc_f16(int32_t n, int32_t h, int32_t w, con
   const long nt = (long)n * a.tiles_x * a.tiles_y;
   if (nt > 0x3fffffffL) return LFD_ERR_UNSUPPORTED;
   a.ntiles = (int)nt;
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done_mask = 0;
+  const int done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(done_mask, done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad_s2_64), hipFuncAttributeMaxDynamicSharedMemorySize,
                             DG::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    done = true;
+    LFD_DONE_ON_DEVICE(done_mask, done_dev);
   }
   int blocks = 512;
   if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);

@@ -483,7 +483,9 @@ extern "C" int lfd_downblock_fused_f16(int32_t n, int32_t h, int32_t w, const vo
   a.N = n; a.H = h; a.W = w;
   a.OH = (h - 1) / 2 + 1;
   a.OW = (w - 1) / 2 + 1;
-  static int cus = 0;
+  static int cus_of[64] = {};
+  const int dev_ = lfd_device_ordinal();
+  int& cus = cus_of[dev_];
   if (!cus) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_down64), hipFuncAttributeMaxDynamicSharedMemorySize,
                             DN::LDS_BYTES) != hipSuccess)

@@ -993,12 +993,13 @@ namespace {
 template <int PASS, int FT, bool DEC = false, bool FOLD = false, bool A1 = false>
 int launch_head2(const HeadArgs& a, hipStream_t st) {
   constexpr int LDS = (4 * 9 + ((PASS == 3) ? FT * 9 : 0) + 4 * 8) * 1024;
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done_mask = 0;
+  const int done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(done_mask, done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head2<PASS, FT, DEC, FOLD, A1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    done = true;
+    LFD_DONE_ON_DEVICE(done_mask, done_dev);
   }
   constexpr int cap = 256 * H2_WPS(PASS);
   int blocks = a.h2_nitems < cap ? a.h2_nitems : cap;
@@ -1147,12 +1148,13 @@ __global__ __launch_bounds__(256) void k_gn_finalize(FinalizeArgs f) {
 template <int CIN, int PASS, int FT>
 int launch_head(const HeadArgs& a, hipStream_t st) {
   constexpr int LDS = 32768 + 2 * TPX * HC * 2 + 512 * 4 + 64 * 4 + 128 * 4 + (PASS == 3 ? FT * 8 * 1024 : 0);
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done_mask = 0;
+  const int done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(done_mask, done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head<CIN, PASS, FT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    done = true;
+    LFD_DONE_ON_DEVICE(done_mask, done_dev);
   }
   int blocks = a.grp_ntiles < 512 ? a.grp_ntiles : 512;
   if (blocks < 1) return LFD_OK;

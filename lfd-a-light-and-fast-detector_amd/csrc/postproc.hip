@@ -350,7 +350,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DecodeParams d, const int* b
     cnt = live ? (int)pcnt[row] : 0;
     if (EX && cnt > 0) f = ex_factor(d, row);
     if (cnt > 0 && d.score_mode == 1 && !by_wave) softmax_stats(d, row, &mx, &sum);
-    if (cnt == 255) {          // saturated counter (>= 255 classes above the threshold at one point): recount
+    // (by_wave implies Cc <= 64 channels -- see its definition -- so a by_wave point can never reach the saturation value 255
+    //  and the recount below, which needs mx / sum, only runs where softmax_stats did: ADVICE r3)
+    if (cnt == 255 && !by_wave) {          // saturated counter (>= 255 classes above the threshold at one point): recount
       cnt = 0;
       for (int c = 0; c < d.C; ++c) {
         const float s = score_of(d, row, c, mx, sum);
@@ -946,12 +948,13 @@ int run_sort_mask_scan(const SegBuffers& b, const ScanOut& o, int nseg, hipStrea
   hipLaunchKernelGGL(k_mask, dim3((unsigned)blocks, nseg), dim3(kBlock), 0, st, b);
   LFD_CHECK_LAUNCH();
   const size_t scan_lds = ((size_t)b.words + 2 + 2 * 64 * kScanPfWords) * sizeof(unsigned long long);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done_mask = 0;
+  const int attr_done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)((kScanMaxWords + 2 + 2 * 64 * kScanPfWords) * sizeof(unsigned long long))) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    attr_done = true;
+    LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
   }
   hipLaunchKernelGGL(k_scan, dim3(nseg), dim3(kScanThreads), scan_lds, st, b, o);
   LFD_CHECK_LAUNCH();

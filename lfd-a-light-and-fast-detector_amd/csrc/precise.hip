@@ -269,11 +269,12 @@ int launch_p32(P32Args a, hipStream_t st) {
   if (tiles > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
   auto kern = k_p32_conv<KS, S, NG, PATCH, TAIL>;
   if (lds > 64 * 1024) {
-    static bool set = false;   // (idempotent; races only repeat the same call)
-    if (!set) {
+    static unsigned long long set_mask = 0;   // (idempotent; races only repeat the same call)
+    const int set_dev = lfd_device_ordinal();
+    if (LFD_ONCE_PER_DEVICE(set_mask, set_dev)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return LFD_ERR_LAUNCH_FAILED;
-      set = true;
+      LFD_DONE_ON_DEVICE(set_mask, set_dev);
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)((a.nslab + 1) / 2)), dim3(256), lds, st, a);

@@ -1067,12 +1067,13 @@ int launch_stem2x(FusedArgs a, hipStream_t st) {
   const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
   if (nt > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
   a.ntiles = (int)nt;
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done_mask = 0;
+  const int done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(done_mask, done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem2x<U8, ALN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             X2::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    done = true;
+    LFD_DONE_ON_DEVICE(done_mask, done_dev);
   }
   const int blocks = 8 * ((a.ntiles + 7) / 8) < 256 ? 8 * ((a.ntiles + 7) / 8) : 256;   // (XCD-contiguous tile ranges)
   if (blocks < 1) return LFD_OK;
@@ -1092,12 +1093,13 @@ int launch_fused(FusedArgs a, hipStream_t st) {
   const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
   if (nt > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
   a.ntiles = (int)nt;
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done_mask = 0;
+  const int done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(done_mask, done_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fused<NCT, FMT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    done = true;
+    LFD_DONE_ON_DEVICE(done_mask, done_dev);
   }
   int blocks = 8 * ((a.ntiles + 7) / 8) < 512 ? 8 * ((a.ntiles + 7) / 8) : 512;
   if (blocks < 1) return LFD_OK;

@@ -1147,12 +1147,13 @@ __global__ __launch_bounds__(kThreads) void k_rows_sum_batched(const lfd_rowsum_
 template <int KS, int S>
 int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
   using C = WgradCfg<KS, S>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set_mask = 0;
+  const int attr_set_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(attr_set_mask, attr_set_dev)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<KS, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
-    attr_set = true;
+    LFD_DONE_ON_DEVICE(attr_set_mask, attr_set_dev);
   }
   WgradArgs a = a0;
   a.tiles_y = (a.ho + C::TH - 1) / C::TH;

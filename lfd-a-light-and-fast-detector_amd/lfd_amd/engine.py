@@ -700,11 +700,13 @@ def version_sum(model):
     tensor was written in place; the address sum catches `p.data = other` and load_state_dict(assign=True), which swap
     storage without touching a version counter or going through _apply.  The tensor LIST is cached and refreshed whenever a
     submodule or parameter object is replaced (LFD.__setattr__ / the load_state_dict post-hook drop it) and, as a backstop,
-    every 256th call."""
+    every 16th call (replacing a NESTED parameter object -- model._backbone.stage0[0]._conv1.weight = nn.Parameter(..)
+    -- goes through neither hook; the new tensor's address differs from the old one's, so the sum over the refreshed list
+    changes within 16 steps; clear model._step_graphs for an immediate effect)."""
     d = model.__dict__
     ts = d.get('_lfd_tensors')
     calls = d.get('_lfd_tensors_calls', 0) + 1
-    if ts is None or calls >= 256:
+    if ts is None or calls >= 16:
         ts = []
         for m in (model._backbone, model._neck, model._head):
             if m is not None:

@@ -246,6 +246,11 @@ class SGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        """torch.optim.SGD.step -- with ONE difference that belongs to the fp16 activation-gradient path this optimizer was
+        written for: the total gradient norm is computed every step (two small launches) and the update is SKIPPED on the
+        device when it is not finite (an overflowed fp16 gradient would otherwise write inf / NaN into the weights); the norm
+        and the clip coefficient stay in `last_norm` (device float32[2]: a non-finite last_norm[0] means "this step was
+        skipped" -- lfd_amd.train.DynamicLossScale reads exactly that).  torch.optim.SGD has no such guard."""
         loss = None
         if closure is not None:
             with torch.enable_grad():

@@ -46,14 +46,16 @@ def train_step(model, optimizer, image_batch, annotation_batch, grad_clip_cfg=No
     """-> (loss_values dict of floats, grad_norm).  grad_clip_cfg: dict(max_norm=..., norm_type=2) or None
     (config_dict['optimizer_grad_clip_cfg'] without 'duration'); clip_active: epoch < duration; loss_scaler: an optional
     DynamicLossScale (reads the norm: one more host sync)."""
+    if loss_scaler is not None and not isinstance(optimizer, optim.SGD):
+        # (ADVICE r3: a torch optimizer has no device-side overflow guard -- a skipped-step signal that is never raised would let
+        #  the scale grow without bound and inf * 0 reach the weights)
+        raise RuntimeError('train_step: a DynamicLossScale needs lfd_amd.optim.SGD (its update is skipped on the device when the '
+                           'gradient norm is not finite)')
     predict_outputs = model(image_batch)
     loss_dict = model.get_loss(predict_outputs, annotation_batch)
     grad_norm = backward_and_update(optimizer, loss_dict['loss'], grad_clip_cfg, clip_active)
     if loss_scaler is not None:
-        if isinstance(optimizer, optim.SGD):
-            loss_scaler.update(optimizer.last_norm[0])
-        else:
-            loss_scaler.update(grad_norm)
+        loss_scaler.update(optimizer.last_norm[0])
     return loss_dict['loss_values'], grad_norm
 
 
