@@ -320,6 +320,12 @@ def test_config5_widerface_s_640_loss_curve_vs_fp32_autograd(monkeypatch):
     assert hip_scaler.skipped == 0 and hip_scaler.scale == 1024.0  # no overflow at the default loss scale
     assert rel[0] < 5e-3                                  # same start: only the fp16 forward differs
     assert rel[:16].max() < 1e-2 and rel.max() < 2e-2     # asked: 2 % / 5 % at bs 32 over 40 iterations; measured 0.29 % max
+    # the total gradient norm the two routes report: within 2 % over the first 15 iterations (measured
+    # <= 1.2 %: 413.779 / 413.779, 151.020 / 151.025, 11.874 / 11.880, ...); later the two TRAJECTORIES have separated enough
+    # that a norm of ~1 is compared between different weights (ratio 0.86 .. 1.23 after iteration 25) -- what kernel error
+    # contributes to that, iteration by iteration from the same state, is gated in tests/test_train_golden.py (<= 0.81 %)
+    gh, gt = np.array(norms['hip']), np.array(norms['torch'])
+    assert (np.abs(gh[:15] - gt[:15]) / gt[:15]).max() < 2e-2, (gh[:15], gt[:15])
     assert np.mean(h[-4:]) < h[0]                         # and go down
 
 
