@@ -175,6 +175,9 @@ __global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, in
   }
 }
 
+// (All streaming passes below request their thread's FIRST vectors before the per-channel parameters: the parameter loads and the
+//  data loads were two dependent round trips -- parameters, s_waitcnt vmcnt(0), then the loop's first load -- and on the small
+//  maps, where a thread owns one or two vectors, that chain is most of the ~5 us a launch takes.)
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict__ y, int64_t vecs, int c,
                                                       const float* __restrict__ stats,
                                                       const float* __restrict__ gamma,
@@ -182,17 +185,21 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
                                                       const __half* __restrict__ res, int relu,
                                                       __half* __restrict__ z) {
   const int groups = c >> 3;
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  h8 h0, r0;
+  if (v0 < vecs) {
+    h0 = ld8(y, v0);
+    if (res) r0 = ld8(res, v0);
+  }
+  const int cg = (int)(v0 & (groups - 1));      // channel counts are powers of two (channels_ok): no 64-bit division
   float a[8], b[8];
   for (int e = 0; e < 8; ++e) {
     const int ch = cg * 8 + e;
     a[e] = gamma[ch] * stats[c + ch];
     b[e] = beta[ch] - stats[ch] * a[e];
   }
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
-    const h8 h = ld8(y, v);
-    h8 r, o;
-    if (res) r = ld8(res, v);
+  auto body = [&](int64_t v, const h8& h, const h8& r) {
+    h8 o;
     for (int e = 0; e < 8; ++e) {
       float f = (float)h[e] * a[e] + b[e];
       if (res) f += (float)r[e];
@@ -200,6 +207,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
       o[e] = (_Float16)f;
     }
     st8(z, v, o);
+  };
+  if (v0 >= vecs) return;
+  body(v0, h0, r0);
+  for (int64_t v = v0 + stride; v < vecs; v += stride) {
+    const h8 h = ld8(y, v);
+    h8 r;
+    if (res) r = ld8(res, v);
+    body(v, h, r);
   }
 }
 
@@ -213,7 +228,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
                                                             const float* __restrict__ beta, int relu_y,
                                                             float* partials) {
   const int groups = c >> 3;
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  h8 d0, y0, z0;
+  if (v0 < vecs) {
+    d0 = ld8(dz, v0);
+    y0 = ld8(y, v0);
+    if (z) z0 = ld8(z, v0);
+  }
+  const int cg = (int)(v0 & (groups - 1));      // channel counts are powers of two (channels_ok): no 64-bit division
   float mean[8], rstd[8], acc[2][8], ga[8], be[8];
   for (int e = 0; e < 8; ++e) {
     mean[e] = stats[cg * 8 + e];
@@ -222,10 +244,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
     be[e] = relu_y ? beta[cg * 8 + e] : 0.f;
     acc[0][e] = acc[1][e] = 0.f;
   }
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
-    const h8 d = ld8(dz, v), yy = ld8(y, v);
-    h8 zz;
-    if (z) zz = ld8(z, v);
+  auto body = [&](const h8& d, const h8& yy, const h8& zz) {
     for (int e = 0; e < 8; ++e) {
       float g = (float)d[e];
       const float xh = ((float)yy[e] - mean[e]) * rstd[e];
@@ -233,6 +252,15 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
       if (relu_y && !(ga[e] * xh + be[e] > 0.f)) g = 0.f;
       acc[0][e] += g;
       acc[1][e] += g * xh;
+    }
+  };
+  if (v0 < vecs) {
+    body(d0, y0, z0);
+    for (int64_t v = v0 + stride; v < vecs; v += stride) {
+      const h8 d = ld8(dz, v), yy = ld8(y, v);
+      h8 zz;
+      if (z) zz = ld8(z, v);
+      body(d, yy, zz);
     }
   }
   block_channel_reduce<2>(acc, c, partials);
@@ -276,7 +304,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
                                                           const float* __restrict__ sums, float inv_m,
                                                           __half* __restrict__ dy, __half* __restrict__ g_out) {
   const int groups = c >> 3;
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % groups);
+  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  h8 d0, y0, z0;
+  if (v0 < vecs) {
+    d0 = ld8(dz, v0);
+    y0 = ld8(y, v0);
+    if (z) z0 = ld8(z, v0);
+  }
+  const int cg = (int)(v0 & (groups - 1));      // channel counts are powers of two (channels_ok): no 64-bit division
   float mean[8], rstd[8], a[8], mg[8], mgx[8], ga[8], be[8];
   for (int e = 0; e < 8; ++e) {
     const int ch = cg * 8 + e;
@@ -288,10 +323,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     mg[e] = sums[ch] * inv_m;
     mgx[e] = sums[c + ch] * inv_m;
   }
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
-    const h8 d = ld8(dz, v), yy = ld8(y, v);
-    h8 zz, o, go;
-    if (z) zz = ld8(z, v);
+  auto body = [&](int64_t v, const h8& d, const h8& yy, const h8& zz) {
+    h8 o, go;
     for (int e = 0; e < 8; ++e) {
       float g = (float)d[e];
       const float xh = ((float)yy[e] - mean[e]) * rstd[e];
@@ -302,6 +335,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     }
     st8(dy, v, o);
     if (g_out) st8(g_out, v, go);
+  };
+  if (v0 >= vecs) return;
+  body(v0, d0, y0, z0);
+  for (int64_t v = v0 + stride; v < vecs; v += stride) {
+    const h8 d = ld8(dz, v), yy = ld8(y, v);
+    h8 zz;
+    if (z) zz = ld8(z, v);
+    body(v, d, yy, zz);
   }
 }
 
@@ -389,6 +430,10 @@ __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict_
                                                       const float* __restrict__ beta, int relu,
                                                       __half* __restrict__ z) {
   __shared__ float sst[FOLD ? 64 : 1];
+  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  h8 h0;
+  if (v0 < vecs_per_img) h0 = ld8(y, base + v0);        // (requested before the statistics: one round trip, not two)
   if constexpr (FOLD) {
     if (threadIdx.x < g) {
       const int cg_ = threadIdx.x;
@@ -412,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict_
     }
     __syncthreads();
   }
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
+  const int cg = (int)((blockIdx.x * kThreads + threadIdx.x) & (g - 1));   // g: a power of two (gn_ok)
   const float mean = FOLD ? sst[cg] : stats[(size_t)blockIdx.y * 2 * g + cg];
   const float rstd = FOLD ? sst[g + cg] : stats[(size_t)blockIdx.y * 2 * g + g + cg];
   float a[8], b[8];
@@ -420,9 +465,7 @@ __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict_
     a[e] = gamma[cg * 8 + e] * rstd;
     b[e] = beta[cg * 8 + e] - mean * a[e];
   }
-  const size_t base = (size_t)blockIdx.y * vecs_per_img;
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
-    const h8 h = ld8(y, base + v);
+  auto body = [&](int64_t v, const h8& h) {
     h8 o;
     for (int e = 0; e < 8; ++e) {
       float f = (float)h[e] * a[e] + b[e];
@@ -430,7 +473,10 @@ __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict_
       o[e] = (_Float16)f;
     }
     st8(z, base + v, o);
-  }
+  };
+  if (v0 >= vecs_per_img) return;
+  body(v0, h0);
+  for (int64_t v = v0 + stride; v < vecs_per_img; v += stride) body(v, ld8(y, base + v));
 }
 
 // per (image, group): sum g*gamma, sum g*gamma*xhat;  per (image, channel): sum g*xhat, sum g
@@ -441,16 +487,20 @@ __global__ __launch_bounds__(kThreads) void k_gn_bwd_partial(const __half* __res
                                                             const float* __restrict__ gamma, float* pgroup,
                                                             float* pchan) {
   __shared__ float red[kThreads][18];
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
+  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  h8 d0, y0, z0;
+  if (v0 < vecs_per_img) {
+    d0 = ld8(dz, base + v0);
+    y0 = ld8(y, base + v0);
+    if (z) z0 = ld8(z, base + v0);
+  }
+  const int cg = (int)((blockIdx.x * kThreads + threadIdx.x) & (g - 1));   // g: a power of two (gn_ok)
   const float mean = stats[(size_t)blockIdx.y * 2 * g + cg], rstd = stats[(size_t)blockIdx.y * 2 * g + g + cg];
   float gam[8], acc[18];
   for (int e = 0; e < 8; ++e) gam[e] = gamma[cg * 8 + e];
   for (int i = 0; i < 18; ++i) acc[i] = 0.f;
-  const size_t base = (size_t)blockIdx.y * vecs_per_img;
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
-    const h8 d = ld8(dz, base + v), yy = ld8(y, base + v);
-    h8 zz;
-    if (z) zz = ld8(z, base + v);
+  auto body = [&](const h8& d, const h8& yy, const h8& zz) {
     for (int e = 0; e < 8; ++e) {
       float gr = (float)d[e];
       if (z && !((float)zz[e] > 0.f)) gr = 0.f;
@@ -459,6 +509,15 @@ __global__ __launch_bounds__(kThreads) void k_gn_bwd_partial(const __half* __res
       acc[1] += gr * gam[e] * xh;
       acc[2 + e] += gr * xh;
       acc[10 + e] += gr;
+    }
+  };
+  if (v0 < vecs_per_img) {
+    body(d0, y0, z0);
+    for (int64_t v = v0 + stride; v < vecs_per_img; v += stride) {
+      const h8 d = ld8(dz, base + v), yy = ld8(y, base + v);
+      h8 zz;
+      if (z) zz = ld8(z, base + v);
+      body(d, yy, zz);
     }
   }
   for (int i = 0; i < 18; ++i) red[threadIdx.x][i] = acc[i];
@@ -513,16 +572,21 @@ __global__ __launch_bounds__(kThreads) void k_gn_bwd_apply(const __half* __restr
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ gsums, float inv_m,
                                                           __half* __restrict__ dy) {
-  const int cg = (int)(((int64_t)blockIdx.x * kThreads + threadIdx.x) % g);
+  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  h8 d0, y0, z0;
+  if (v0 < vecs_per_img) {
+    d0 = ld8(dz, base + v0);
+    y0 = ld8(y, base + v0);
+    if (z) z0 = ld8(z, base + v0);
+  }
+  const int cg = (int)((blockIdx.x * kThreads + threadIdx.x) & (g - 1));   // g: a power of two (gn_ok)
   const float mean = stats[(size_t)blockIdx.y * 2 * g + cg], rstd = stats[(size_t)blockIdx.y * 2 * g + g + cg];
   const float m1 = gsums[(size_t)blockIdx.y * 2 * g + cg] * inv_m, m2 = gsums[(size_t)blockIdx.y * 2 * g + g + cg] * inv_m;
   float gam[8];
   for (int e = 0; e < 8; ++e) gam[e] = gamma[cg * 8 + e];
-  const size_t base = (size_t)blockIdx.y * vecs_per_img;
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
-    const h8 d = ld8(dz, base + v), yy = ld8(y, base + v);
-    h8 zz, o;
-    if (z) zz = ld8(z, base + v);
+  auto body = [&](int64_t v, const h8& d, const h8& yy, const h8& zz) {
+    h8 o;
     for (int e = 0; e < 8; ++e) {
       float gr = (float)d[e];
       if (z && !((float)zz[e] > 0.f)) gr = 0.f;
@@ -530,6 +594,14 @@ __global__ __launch_bounds__(kThreads) void k_gn_bwd_apply(const __half* __restr
       o[e] = (_Float16)(rstd * (gr * gam[e] - m1 - xh * m2));
     }
     st8(dy, base + v, o);
+  };
+  if (v0 >= vecs_per_img) return;
+  body(v0, d0, y0, z0);
+  for (int64_t v = v0 + stride; v < vecs_per_img; v += stride) {
+    const h8 d = ld8(dz, base + v), yy = ld8(y, base + v);
+    h8 zz;
+    if (z) zz = ld8(z, base + v);
+    body(v, d, yy, zz);
   }
 }
 
