@@ -595,6 +595,29 @@ LFD_API int lfd_conv3x3s2_dgrad_nhwc_f16(int32_t n, int32_t h, int32_t w, const 
 LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
                             int32_t ks, int32_t stride, float inv_scale, int32_t accumulate, void* workspace,
                             size_t workspace_bytes, float* dw, lfd_stream_t stream);
+/* The LEVEL-CONCATENATED form of the head's training passes (round 4).  The reference's head applies the SAME towers to every
+ * pyramid level, one tensor per level (lfd_head.py:164-185); the training schedule keeps the levels of an image back to back in
+ * one tensor [n, P, c] (P = points of all levels, the layout LFD.forward returns, lfd.py:526-542), so that a shared 1x1 conv, its
+ * weight gradient and its data gradient are ONE launch over all levels instead of one per level:
+ *   lfd_bn_train_apply_into_f16   a level's neck unit writes its normalised output into rows [point0, point0 + hw) of every image;
+ *   lfd_bn_train_bwd_from_f16     ... and reads its output gradient from there (no residual input; ReLU mask recomputed from y);
+ *   lfd_gn_train_*_seg_f16        GroupNorm with statistics per (image, segment): nseg segments of seg_hw[] pixels per image,
+ *                                 stats [n * nseg][2][groups] (virtual image = img * nseg + segment);
+ *   lfd_head_out_*_concat_f16     the glue kernels below with y / dy = the concatenated conv output [n, P, 64]. */
+LFD_API int lfd_bn_train_apply_into_f16(const void* y, int32_t n, int64_t hw, int32_t channels, const float* stats, const float* gamma,
+                                const float* beta, int32_t relu, void* z_concat, int64_t points_total, int64_t point0,
+                                lfd_stream_t stream);
+LFD_API int lfd_bn_train_bwd_from_f16(const void* dz_concat, int64_t points_total, int64_t point0, const void* y, int32_t relu, int32_t n,
+                              int64_t hw, int32_t channels, const float* stats, const float* gamma, const float* beta,
+                              float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma,
+                              float* dbeta, void* dy, lfd_stream_t stream);
+LFD_API int lfd_gn_train_stats_apply_seg_f16(const void* y, int32_t n, int32_t nseg, const int64_t* seg_hw, int32_t channels,
+                                     int32_t groups, float eps, const float* gamma, const float* beta, int32_t relu,
+                                     void* workspace, size_t workspace_bytes, float* stats, void* z, lfd_stream_t stream);
+LFD_API int lfd_gn_train_bwd_seg_f16(const void* dz, const void* y, const void* z, int32_t n, int32_t nseg, const int64_t* seg_hw,
+                             int32_t channels, int32_t groups, const float* stats, const float* gamma, float inv_scale,
+                             int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy,
+                             lfd_stream_t stream);
 /* The same weight gradient in two stages for a schedule that defers the final sums (round 4): every conv's k_wgrad writes
  * its per-workgroup partial sums into ITS OWN buffer (`partials`: lfd_conv_wgrad_partial_rows() x blocks x ks*ks x 64 x 64
  * floats, blocks = ceil(cout/64) * ceil(cin/64)), and ONE lfd_wgrad_final_batched_f32 launch after the last of them turns all
@@ -652,6 +675,11 @@ LFD_API int lfd_head_out_split_f16(const void* y, int32_t n, int32_t hw, int64_t
 LFD_API int lfd_head_out_grad_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
                           const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy, void* workspace,
                           size_t workspace_bytes, lfd_stream_t stream);
+LFD_API int lfd_head_out_split_concat_f16(const void* y_concat, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                                  const lfd_head_out_seg_t* segs, int32_t nsegs, lfd_stream_t stream);
+LFD_API int lfd_head_out_grad_concat_f16(const void* y_concat, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                                 const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy_concat, void* workspace,
+                                 size_t workspace_bytes, lfd_stream_t stream);
 
 /* first stem conv (3 -> channels, 3x3 stride 2 pad 1, lfd_resnet.py:358,:378) on the NCHW fp32 image batch:
  * forward -> y NHWC fp16 (pre-norm), and its weight gradient (OIHW fp32); channels in {32, 64} */

@@ -32,6 +32,8 @@ struct Args {
   __half* dy;           // [n, hw, 64]
   int n, hw;
   int64_t points_total, point0;
+  int64_t y_total, y_point0;   // y / dy row of (img, p) = img * y_total + y_point0 + p  (a level's own tensor: hw, 0; a level inside
+                               // the level-concatenated conv output of the training schedule: points_total, point0)
   Seg seg[2];
   int nsegs;
   float loss_scale;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(kThreads) void k_out_split(Args a) {
       const int64_t px = i / g.channels;
       const int j = (int)(i - px * g.channels);
       const int64_t img = px / a.hw, p = px - img * a.hw;
-      const float v = __half2float(a.y[px * kRows + g.row0 + j]);
+      const float v = __half2float(a.y[(img * a.y_total + a.y_point0 + p) * kRows + g.row0 + j]);
       g.out[(img * a.points_total + a.point0 + p) * g.channels + j] = g.scale ? v * mul : v;
     }
   }
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_out_grad(Args a) {
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
     const int64_t px = v >> 3;
     const int64_t img = px / a.hw, p = px - img * a.hw;
+    const int64_t yrow = img * a.y_total + a.y_point0 + p;
     union { uint4 u; _Float16 h[8]; } o;
     o.u = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -85,12 +88,12 @@ __global__ __launch_bounds__(kThreads) void k_out_grad(Args a) {
       if (s < 0) continue;
       const Seg& g = a.seg[s];
       float d = g.grad[(img * a.points_total + a.point0 + p) * g.channels + sch[e]];
-      if (g.dscale) acc_r[e] += d * __half2float(a.y[px * kRows + ck * 8 + e]);     // dL/dscale: sum of dreg * raw
+      if (g.dscale) acc_r[e] += d * __half2float(a.y[yrow * kRows + ck * 8 + e]);     // dL/dscale: sum of dreg * raw
       if (g.scale) d = d * mul[s];
       acc_d[e] += d;                                                                // dL/dbias
       o.h[e] = (_Float16)(d * a.loss_scale);
     }
-    reinterpret_cast<uint4*>(a.dy)[v] = o.u;
+    reinterpret_cast<uint4*>(a.dy)[yrow * 8 + ck] = o.u;
   }
   for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = acc_d[e]; red[threadIdx.x][8 + e] = acc_r[e]; }
   __syncthreads();
@@ -145,6 +148,7 @@ bool fill(Args& a, const void* y, int32_t n, int32_t hw, int64_t points_total, i
           int32_t nsegs) {
   if (!y || !segs || n < 1 || hw < 1 || nsegs < 1 || nsegs > 2 || point0 < 0 || point0 + hw > points_total) return false;
   a.y = (const __half*)y; a.n = n; a.hw = hw; a.points_total = points_total; a.point0 = point0; a.nsegs = nsegs;
+  a.y_total = hw; a.y_point0 = 0;
   for (int s = 0; s < nsegs; ++s) {
     const lfd_head_out_seg_t& g = segs[s];
     if (g.channels < 1 || g.row0 < 0 || g.row0 + g.channels > kRows) return false;
@@ -158,10 +162,11 @@ bool fill(Args& a, const void* y, int32_t n, int32_t hw, int64_t points_total, i
 
 extern "C" {
 
-int lfd_head_out_split_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
-                           const lfd_head_out_seg_t* segs, int32_t nsegs, lfd_stream_t stream) {
+static int out_split(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0, const lfd_head_out_seg_t* segs,
+                     int32_t nsegs, bool concat, lfd_stream_t stream) {
   Args a{};
   if (!fill(a, y, n, hw, points_total, point0, segs, nsegs)) return LFD_ERR_INVALID_ARGUMENT;
+  if (concat) { a.y_total = points_total; a.y_point0 = point0; }
   int maxc = 0;
   for (int s = 0; s < nsegs; ++s) {
     if (!a.seg[s].out) return LFD_ERR_INVALID_ARGUMENT;
@@ -174,12 +179,23 @@ int lfd_head_out_split_f16(const void* y, int32_t n, int32_t hw, int64_t points_
   return LFD_OK;
 }
 
-int lfd_head_out_grad_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
-                          const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy, void* workspace,
-                          size_t workspace_bytes, lfd_stream_t stream) {
+int lfd_head_out_split_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                           const lfd_head_out_seg_t* segs, int32_t nsegs, lfd_stream_t stream) {
+  return out_split(y, n, hw, points_total, point0, segs, nsegs, false, stream);
+}
+
+int lfd_head_out_split_concat_f16(const void* y_concat, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                                  const lfd_head_out_seg_t* segs, int32_t nsegs, lfd_stream_t stream) {
+  return out_split(y_concat, n, hw, points_total, point0, segs, nsegs, true, stream);
+}
+
+static int out_grad(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0, const lfd_head_out_seg_t* segs,
+                    int32_t nsegs, float loss_scale, void* dy, void* workspace, size_t workspace_bytes, bool concat,
+                    lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   Args a{};
   if (!fill(a, y, n, hw, points_total, point0, segs, nsegs) || !dy || !workspace || !lfd_aligned16(dy)) return LFD_ERR_INVALID_ARGUMENT;
+  if (concat) { a.y_total = points_total; a.y_point0 = point0; }
   if (workspace_bytes < (size_t)kMaxBlocks * 2 * kRows * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
   for (int s = 0; s < nsegs; ++s)
     if (!a.seg[s].grad || (a.seg[s].dscale && !a.seg[s].scale)) return LFD_ERR_INVALID_ARGUMENT;
@@ -191,6 +207,18 @@ int lfd_head_out_grad_f16(const void* y, int32_t n, int32_t hw, int64_t points_t
   hipLaunchKernelGGL(k_out_grad_final, dim3(kRows), dim3(128), 0, st, a, (int)b);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
+}
+
+int lfd_head_out_grad_f16(const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                          const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy, void* workspace,
+                          size_t workspace_bytes, lfd_stream_t stream) {
+  return out_grad(y, n, hw, points_total, point0, segs, nsegs, loss_scale, dy, workspace, workspace_bytes, false, stream);
+}
+
+int lfd_head_out_grad_concat_f16(const void* y_concat, int32_t n, int32_t hw, int64_t points_total, int64_t point0,
+                                 const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy_concat, void* workspace,
+                                 size_t workspace_bytes, lfd_stream_t stream) {
+  return out_grad(y_concat, n, hw, points_total, point0, segs, nsegs, loss_scale, dy_concat, workspace, workspace_bytes, true, stream);
 }
 
 }  // extern "C"

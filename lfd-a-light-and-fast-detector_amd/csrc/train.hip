@@ -175,6 +175,20 @@ __global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, in
   }
 }
 
+// A per-level tensor [n, hw, c] that lives inside a LEVEL-CONCATENATED one [n, P, c] (the head activations of the training
+// schedule): vector v of the level = pixel v / groups of image (pixel / hw) -> row img * P + p0 + pixel % hw of the concatenated
+// tensor.  32-bit divisions: the tensors this is used on (necks at <= 80 x 80) have far fewer than 2^31 vectors.
+struct RowMap {
+  int hw_vecs;          // vectors per image of the level (hw * groups); 0: identity
+  int64_t img_vecs;     // vectors per image of the concatenated tensor (P * groups)
+  int64_t off_vecs;     // first vector of the level inside an image (p0 * groups)
+};
+__device__ __forceinline__ int64_t mapped(const RowMap& m, int64_t v) {
+  if (!m.hw_vecs) return v;
+  const unsigned img = (unsigned)v / (unsigned)m.hw_vecs, r = (unsigned)v - img * (unsigned)m.hw_vecs;
+  return (int64_t)img * m.img_vecs + m.off_vecs + r;
+}
+
 // (All streaming passes below request their thread's FIRST vectors before the per-channel parameters: the parameter loads and the
 //  data loads were two dependent round trips -- parameters, s_waitcnt vmcnt(0), then the loop's first load -- and on the small
 //  maps, where a thread owns one or two vectors, that chain is most of the ~5 us a launch takes.)
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
                                                       const __half* __restrict__ res, int relu,
-                                                      __half* __restrict__ z) {
+                                                      __half* __restrict__ z, RowMap zmap) {
   const int groups = c >> 3;
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 h0, r0;
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
       if (relu) f = fmaxf(f, 0.f);
       o[e] = (_Float16)f;
     }
-    st8(z, v, o);
+    st8(z, mapped(zmap, v), o);
   };
   if (v0 >= vecs) return;
   body(v0, h0, r0);
@@ -226,12 +240,12 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu_y,
-                                                            float* partials) {
+                                                            float* partials, RowMap dmap) {
   const int groups = c >> 3;
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs) {
-    d0 = ld8(dz, v0);
+    d0 = ld8(dz, mapped(dmap, v0));
     y0 = ld8(y, v0);
     if (z) z0 = ld8(z, v0);
   }
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
   if (v0 < vecs) {
     body(d0, y0, z0);
     for (int64_t v = v0 + stride; v < vecs; v += stride) {
-      const h8 d = ld8(dz, v), yy = ld8(y, v);
+      const h8 d = ld8(dz, mapped(dmap, v)), yy = ld8(y, v);
       h8 zz;
       if (z) zz = ld8(z, v);
       body(d, yy, zz);
@@ -302,12 +316,12 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu_y,
                                                           const float* __restrict__ sums, float inv_m,
-                                                          __half* __restrict__ dy, __half* __restrict__ g_out) {
+                                                          __half* __restrict__ dy, __half* __restrict__ g_out, RowMap dmap) {
   const int groups = c >> 3;
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs) {
-    d0 = ld8(dz, v0);
+    d0 = ld8(dz, mapped(dmap, v0));
     y0 = ld8(y, v0);
     if (z) z0 = ld8(z, v0);
   }
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
   if (v0 >= vecs) return;
   body(v0, d0, y0, z0);
   for (int64_t v = v0 + stride; v < vecs; v += stride) {
-    const h8 d = ld8(dz, v), yy = ld8(y, v);
+    const h8 d = ld8(dz, mapped(dmap, v)), yy = ld8(y, v);
     h8 zz;
     if (z) zz = ld8(z, v);
     body(v, d, yy, zz);
@@ -370,10 +384,29 @@ __global__ __launch_bounds__(kThreads) void k_zero_insert2(const __half* __restr
 // per (image, group) over h*w pixels x 8 channels -- a group is exactly one 16-byte vector of an NHWC pixel.
 // grid = (blocks per image, images); a thread owns one group (the stride is a multiple of the group count).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_gn_stats_partial(const __half* __restrict__ y, int64_t vecs_per_img, int g,
+// A "virtual image" of the GroupNorm kernels = one (image, segment) pair: blockIdx.y = img * nseg + seg.  Plain tensors have one
+// segment per image (the whole image); the LEVEL-CONCATENATED head activations [N, P, C] of the training schedule (round 4: the
+// shared towers run ONCE over all pyramid levels) have one segment per level -- statistics per (image, level) as in the
+// reference, where every level is a tensor of its own (lfd_head.py:164-185).
+struct GnGeom {
+  int nseg;
+  int64_t img_vecs;                    // vectors (8 channels) per image over all segments
+  int64_t off[LFD_MAX_LEVELS];         // first vector of a segment inside its image
+  int64_t vecs[LFD_MAX_LEVELS];        // vectors of a segment
+};
+__device__ __forceinline__ void gn_segment(const GnGeom& G, size_t* base, int64_t* vecs) {
+  const int seg = (int)(blockIdx.y % G.nseg), img = (int)(blockIdx.y / G.nseg);
+  *base = (size_t)img * G.img_vecs + G.off[seg];
+  *vecs = G.vecs[seg];
+}
+
+__global__ __launch_bounds__(kThreads) void k_gn_stats_partial(const __half* __restrict__ y, GnGeom G, int g,
                                                               float* partials) {
   __shared__ float red[kThreads][2];
-  const __half* yi = y + (size_t)blockIdx.y * vecs_per_img * 8;
+  size_t base_;
+  int64_t vecs_per_img;
+  gn_segment(G, &base_, &vecs_per_img);
+  const __half* yi = y + base_ * 8;
   float s = 0.f, ss = 0.f;
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs_per_img; v += (int64_t)gridDim.x * kThreads) {
     const h8 h = ld8(yi, v);
@@ -397,8 +430,9 @@ __global__ __launch_bounds__(kThreads) void k_gn_stats_partial(const __half* __r
 // stats[img][0][g] = mean, stats[img][1][g] = rstd.  One wave per image: lane = part * g + group, the 64 / g parts stride over the
 // block partials (independent loads in flight instead of one dependent chain of `nblocks` L2 round trips: 15 -> ~3 us for the
 // 64 partial blocks of a large map), then a fixed-order butterfly over the parts -- deterministic.
-__global__ __launch_bounds__(64) void k_gn_stats_final(const float* partials, int nblocks, int g, double m, float eps,
+__global__ __launch_bounds__(64) void k_gn_stats_final(const float* partials, int nblocks, int g, GnGeom G, float eps,
                                                       float* stats) {
+  const double m = (double)G.vecs[blockIdx.x % G.nseg] * 8.0;
   const int lane = threadIdx.x, cg = lane % g, part = lane / g, nparts = 64 / g;     // g is a power of two <= 32
   double s = 0.0, ss = 0.0;
 #pragma unroll 4
@@ -423,14 +457,17 @@ __global__ __launch_bounds__(64) void k_gn_stats_final(const float* partials, in
 // of 2g floats, fp64, row order; the arithmetic of k_gn_stats_final), workgroup x == 0 stores them for the backward pass: the
 // apply pass does not wait for a k_gn_stats_final launch (10 dependent ~4-6 us launches of a WIDERFACE_LFD_S iteration)
 template <bool FOLD>
-__global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict__ y, int64_t vecs_per_img, int g,
+__global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict__ y, GnGeom G, int g,
                                                       float* __restrict__ stats, const float* __restrict__ partials,
-                                                      int nblocks, double m, float eps,
+                                                      int nblocks, float eps,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int relu,
                                                       __half* __restrict__ z) {
   __shared__ float sst[FOLD ? 64 : 1];
-  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  size_t base;
+  int64_t vecs_per_img;
+  gn_segment(G, &base, &vecs_per_img);
+  const double m = (double)vecs_per_img * 8.0;
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 h0;
   if (v0 < vecs_per_img) h0 = ld8(y, base + v0);        // (requested before the statistics: one round trip, not two)
@@ -482,12 +519,14 @@ __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict_
 // per (image, group): sum g*gamma, sum g*gamma*xhat;  per (image, channel): sum g*xhat, sum g
 __global__ __launch_bounds__(kThreads) void k_gn_bwd_partial(const __half* __restrict__ dz,
                                                             const __half* __restrict__ y,
-                                                            const __half* __restrict__ z, int64_t vecs_per_img, int g,
+                                                            const __half* __restrict__ z, GnGeom G, int g,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, float* pgroup,
                                                             float* pchan) {
   __shared__ float red[kThreads][18];
-  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  size_t base;
+  int64_t vecs_per_img;
+  gn_segment(G, &base, &vecs_per_img);
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs_per_img) {
@@ -567,12 +606,15 @@ __global__ __launch_bounds__(64) void k_gn_bwd_final(const float* pgroup, const 
 
 __global__ __launch_bounds__(kThreads) void k_gn_bwd_apply(const __half* __restrict__ dz,
                                                           const __half* __restrict__ y,
-                                                          const __half* __restrict__ z, int64_t vecs_per_img, int g,
+                                                          const __half* __restrict__ z, GnGeom G, int g,
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ gamma,
-                                                          const float* __restrict__ gsums, float inv_m,
+                                                          const float* __restrict__ gsums,
                                                           __half* __restrict__ dy) {
-  const size_t base = (size_t)blockIdx.y * vecs_per_img;
+  size_t base;
+  int64_t vecs_per_img;
+  gn_segment(G, &base, &vecs_per_img);
+  const float inv_m = (float)(1.0 / ((double)vecs_per_img * 8.0));
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs_per_img) {
@@ -1302,23 +1344,40 @@ int lfd_bn_train_stats_f16(const void* y, int64_t pixels, int32_t channels, floa
   return LFD_OK;
 }
 
+static bool row_map(RowMap* m, int64_t n, int64_t hw, int64_t points_total, int64_t point0, int groups) {
+  if (n < 1 || hw < 1 || point0 < 0 || point0 + hw > points_total || n * hw * groups >= ((int64_t)1 << 31)) return false;
+  m->hw_vecs = (int)(hw * groups); m->img_vecs = points_total * groups; m->off_vecs = point0 * groups;
+  return true;
+}
+
 int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, const float* stats, const float* gamma,
                            const float* beta, const void* residual, int32_t relu, void* z, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!y || !stats || !gamma || !beta || !z || pixels < 1 || !channels_ok(channels)) return LFD_ERR_INVALID_ARGUMENT;
   const int64_t vecs = pixels * (channels / 8);
   hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
-                     stats, gamma, beta, (const __half*)residual, relu, (__half*)z);
+                     stats, gamma, beta, (const __half*)residual, relu, (__half*)z, RowMap{});
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
 
-int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t relu, int64_t pixels, int32_t channels,
-                         const float* stats, const float* gamma, const float* beta, float inv_scale,
-                         int32_t accumulate, void* workspace,
-                         size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
-                         lfd_stream_t stream) {
+int lfd_bn_train_apply_into_f16(const void* y, int32_t n, int64_t hw, int32_t channels, const float* stats, const float* gamma,
+                                const float* beta, int32_t relu, void* z_concat, int64_t points_total, int64_t point0,
+                                lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  RowMap m{};
+  if (!y || !stats || !gamma || !beta || !z_concat || !channels_ok(channels) || !row_map(&m, n, hw, points_total, point0, channels / 8))
+    return LFD_ERR_INVALID_ARGUMENT;
+  const int64_t vecs = (int64_t)n * hw * (channels / 8);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)y, vecs, channels,
+                     stats, gamma, beta, (const __half*)nullptr, relu, (__half*)z_concat, m);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+static int bn_bwd(const void* dz, const RowMap& dmap, const void* y, const void* z, int32_t relu, int64_t pixels, int32_t channels,
+                  const float* stats, const float* gamma, const float* beta, float inv_scale, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out, hipStream_t st) {
   if (!dz || !y || !stats || !gamma || !dy || !workspace || pixels < 1 || !channels_ok(channels))
     return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
@@ -1333,21 +1392,40 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t r
   // workgroup re-adding the 64 rows: the 21 saved launches (6.3 us each) were paid back by the slower 64-workgroup sums pass
   // (+6 us each) and the re-add (+4 us each): 7.06 against 6.98 ms per iteration.  Three launches it stays.)
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials);
+                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials, dmap);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
                      dgamma, dbeta);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
-                     (__half*)dy, (__half*)g_out);
+                     (__half*)dy, (__half*)g_out, dmap);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
 
-static inline unsigned gn_blocks(int64_t vecs_per_img, int n) {
+int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t relu, int64_t pixels, int32_t channels,
+                         const float* stats, const float* gamma, const float* beta, float inv_scale,
+                         int32_t accumulate, void* workspace,
+                         size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out,
+                         lfd_stream_t stream) {
+  return bn_bwd(dz, RowMap{}, y, z, relu, pixels, channels, stats, gamma, beta, inv_scale, accumulate, workspace, workspace_bytes,
+                dgamma, dbeta, dy, g_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_bn_train_bwd_from_f16(const void* dz_concat, int64_t points_total, int64_t point0, const void* y, int32_t relu, int32_t n,
+                              int64_t hw, int32_t channels, const float* stats, const float* gamma, const float* beta,
+                              float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma,
+                              float* dbeta, void* dy, lfd_stream_t stream) {
+  RowMap m{};
+  if (!channels_ok(channels) || !row_map(&m, n, hw, points_total, point0, channels / 8)) return LFD_ERR_INVALID_ARGUMENT;
+  return bn_bwd(dz_concat, m, y, nullptr, relu, (int64_t)n * hw, channels, stats, gamma, beta, inv_scale, accumulate, workspace,
+                workspace_bytes, dgamma, dbeta, dy, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+static inline unsigned gn_blocks(int64_t vecs_per_img, int nvirt) {
   int64_t b = (vecs_per_img + kThreads - 1) / kThreads;
-  int64_t cap = 1024 / (n < 1 ? 1 : n);
+  int64_t cap = 4096 / (nvirt < 1 ? 1 : nvirt);       // (images x segments) x blocks <= 4096 workgroups
   if (cap < 1) cap = 1;
   if (cap > 64) cap = 64;
   if (b > cap) b = cap;
@@ -1357,29 +1435,61 @@ static inline unsigned gn_blocks(int64_t vecs_per_img, int n) {
 static inline bool gn_ok(int n, int64_t hw, int c, int g) {
   return n >= 1 && n <= 1024 && hw >= 1 && g >= 1 && g <= 32 && (g & (g - 1)) == 0 && c == 8 * g;
 }
+// geometry of n images x nseg segments of seg_hw[] pixels; -> the largest segment's vectors (0: invalid)
+static int64_t gn_geometry(GnGeom* G, int n, int nseg, const int64_t* seg_hw, int channels, int groups) {
+  if (nseg < 1 || nseg > LFD_MAX_LEVELS || !seg_hw || n < 1 || n * nseg > 4096) return 0;
+  int64_t tot = 0, mx = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!gn_ok(n, seg_hw[i], channels, groups)) return 0;
+    G->off[i] = tot * groups;
+    G->vecs[i] = seg_hw[i] * groups;
+    tot += seg_hw[i];
+    if (G->vecs[i] > mx) mx = G->vecs[i];
+  }
+  G->nseg = nseg;
+  G->img_vecs = tot * groups;
+  return mx;
+}
+// workspace layout of the GroupNorm passes: [4096][2g <= 64] group partials | [4096][2c <= 512] channel partials | group sums
+static constexpr size_t kGnGroupFloats = (size_t)4096 * 2 * 32, kGnChanFloats = (size_t)4096 * 2 * 256;
+
+static int gn_stats_apply(const void* y, int n, int nseg, const int64_t* seg_hw, int channels, int groups, float eps,
+                          const float* gamma, const float* beta, int relu, void* workspace, size_t workspace_bytes, float* stats,
+                          void* z, bool fold, hipStream_t st) {
+  GnGeom G{};
+  const int64_t mx = gn_geometry(&G, n, nseg, seg_hw, channels, groups);
+  if (!mx || !y || !stats || !workspace) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int nv = n * nseg;
+  const unsigned b = gn_blocks(mx, nv);
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_gn_stats_partial, dim3(b, nv), dim3(kThreads), 0, st, (const __half*)y, G, groups, partials);
+  LFD_CHECK_LAUNCH();
+  if (fold) {
+    if (!gamma || !beta || !z) return LFD_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_gn_apply<true>, dim3(b, nv), dim3(kThreads), 0, st, (const __half*)y, G, groups, stats, partials, (int)b,
+                       eps, gamma, beta, relu, (__half*)z);
+  } else {
+    hipLaunchKernelGGL(k_gn_stats_final, dim3(nv), dim3(64), 0, st, partials, (int)b, groups, G, eps, stats);
+  }
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
 
 int lfd_gn_train_stats_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, float eps,
                            void* workspace, size_t workspace_bytes, float* stats, lfd_stream_t stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!y || !stats || !workspace || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
-  const int64_t vpi = hw * groups;
-  const unsigned b = gn_blocks(vpi, n);
-  float* partials = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_gn_stats_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, partials);
-  LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_gn_stats_final, dim3(n), dim3(64), 0, st, partials, (int)b, groups, (double)hw * 8.0, eps, stats);
-  LFD_CHECK_LAUNCH();
-  return LFD_OK;
+  return gn_stats_apply(y, n, 1, &hw, channels, groups, eps, nullptr, nullptr, 0, workspace, workspace_bytes, stats, nullptr, false,
+                        reinterpret_cast<hipStream_t>(stream));
 }
 
 int lfd_gn_train_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, const float* stats,
                            const float* gamma, const float* beta, int32_t relu, void* z, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!y || !stats || !gamma || !beta || !z || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
-  const int64_t vpi = hw * groups;
-  hipLaunchKernelGGL(k_gn_apply<false>, dim3(gn_blocks(vpi, n), n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups,
-                     const_cast<float*>(stats), nullptr, 0, 0.0, 0.f, gamma, beta, relu, (__half*)z);
+  GnGeom G{};
+  const int64_t mx = gn_geometry(&G, n, 1, &hw, channels, groups);
+  if (!mx || !y || !stats || !gamma || !beta || !z) return LFD_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_gn_apply<false>, dim3(gn_blocks(mx, n), n), dim3(kThreads), 0, st, (const __half*)y, G, groups,
+                     const_cast<float*>(stats), nullptr, 0, 0.f, gamma, beta, relu, (__half*)z);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1387,16 +1497,37 @@ int lfd_gn_train_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channel
 int lfd_gn_train_stats_apply_f16(const void* y, int32_t n, int64_t hw, int32_t channels, int32_t groups, float eps,
                                  const float* gamma, const float* beta, int32_t relu, void* workspace, size_t workspace_bytes,
                                  float* stats, void* z, lfd_stream_t stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!y || !stats || !gamma || !beta || !z || !workspace || !gn_ok(n, hw, channels, groups)) return LFD_ERR_INVALID_ARGUMENT;
+  return gn_stats_apply(y, n, 1, &hw, channels, groups, eps, gamma, beta, relu, workspace, workspace_bytes, stats, z, true,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_gn_train_stats_apply_seg_f16(const void* y, int32_t n, int32_t nseg, const int64_t* seg_hw, int32_t channels,
+                                     int32_t groups, float eps, const float* gamma, const float* beta, int32_t relu,
+                                     void* workspace, size_t workspace_bytes, float* stats, void* z, lfd_stream_t stream) {
+  return gn_stats_apply(y, n, nseg, seg_hw, channels, groups, eps, gamma, beta, relu, workspace, workspace_bytes, stats, z, true,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+static int gn_bwd(const void* dz, const void* y, const void* z, int n, int nseg, const int64_t* seg_hw, int channels, int groups,
+                  const float* stats, const float* gamma, float inv_scale, int accumulate, void* workspace, size_t workspace_bytes,
+                  float* dgamma, float* dbeta, void* dy, hipStream_t st) {
+  GnGeom G{};
+  const int64_t mx = gn_geometry(&G, n, nseg, seg_hw, channels, groups);
+  if (!mx || !dz || !y || !stats || !gamma || !dgamma || !dbeta || !dy || !workspace) return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
-  const int64_t vpi = hw * groups;
-  const unsigned b = gn_blocks(vpi, n);
-  float* partials = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_gn_stats_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, partials);
+  const int nv = n * nseg;
+  const unsigned b = gn_blocks(mx, nv);
+  float* pgroup = reinterpret_cast<float*>(workspace);
+  float* pchan = pgroup + kGnGroupFloats;
+  float* gsums = pchan + kGnChanFloats;
+  hipLaunchKernelGGL(k_gn_bwd_partial, dim3(b, nv), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, G, groups, stats, gamma, pgroup, pchan);
   LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_gn_apply<true>, dim3(b, n), dim3(kThreads), 0, st, (const __half*)y, vpi, groups, stats, partials, (int)b,
-                     (double)hw * 8.0, eps, gamma, beta, relu, (__half*)z);
+  hipLaunchKernelGGL(k_gn_bwd_final, dim3(nv * 2 * groups + 2 * channels), dim3(64), 0, st, pgroup, pchan, nv, (int)b, groups,
+                     inv_scale, accumulate, gsums, dgamma, dbeta);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(b, nv), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                     (const __half*)z, G, groups, stats, gamma, gsums, (__half*)dy);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1405,25 +1536,16 @@ int lfd_gn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t n
                          int32_t groups, const float* stats, const float* gamma, float inv_scale, int32_t accumulate,
                          void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy,
                          lfd_stream_t stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!dz || !y || !stats || !gamma || !dgamma || !dbeta || !dy || !workspace || !gn_ok(n, hw, channels, groups))
-    return LFD_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
-  const int64_t vpi = hw * groups;
-  const unsigned b = gn_blocks(vpi, n);
-  float* pgroup = reinterpret_cast<float*>(workspace);
-  float* pchan = pgroup + (size_t)1024 * 2 * 32;
-  float* gsums = pchan + (size_t)1024 * 2 * 256;
-  hipLaunchKernelGGL(k_gn_bwd_partial, dim3(b, n), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vpi, groups, stats, gamma, pgroup, pchan);
-  LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_gn_bwd_final, dim3(n * 2 * groups + 2 * channels), dim3(64), 0, st, pgroup, pchan, n, (int)b, groups, inv_scale,
-                     accumulate, gsums, dgamma, dbeta);
-  LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(b, n), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vpi, groups, stats, gamma, gsums, (float)(1.0 / ((double)hw * 8.0)), (__half*)dy);
-  LFD_CHECK_LAUNCH();
-  return LFD_OK;
+  return gn_bwd(dz, y, z, n, 1, &hw, channels, groups, stats, gamma, inv_scale, accumulate, workspace, workspace_bytes, dgamma,
+                dbeta, dy, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_gn_train_bwd_seg_f16(const void* dz, const void* y, const void* z, int32_t n, int32_t nseg, const int64_t* seg_hw,
+                             int32_t channels, int32_t groups, const float* stats, const float* gamma, float inv_scale,
+                             int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy,
+                             lfd_stream_t stream) {
+  return gn_bwd(dz, y, z, n, nseg, seg_hw, channels, groups, stats, gamma, inv_scale, accumulate, workspace, workspace_bytes,
+                dgamma, dbeta, dy, reinterpret_cast<hipStream_t>(stream));
 }
 
 int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi, int32_t channels, int32_t ho,

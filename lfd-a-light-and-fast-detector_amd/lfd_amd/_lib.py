@@ -175,6 +175,12 @@ _SIGNATURES = {
     'lfd_gn_train_stats_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _F, _P, _SZ, _P, _P]),
     'lfd_gn_train_apply_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
     'lfd_gn_train_stats_apply_f16': (C.c_int, [_P, _I32, _I64, _I32, _I32, _F, _P, _P, _I32, _P, _SZ, _P, _P, _P]),
+    'lfd_gn_train_stats_apply_seg_f16': (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _F, _P, _P, _I32, _P, _SZ, _P, _P, _P]),
+    'lfd_gn_train_bwd_seg_f16': (C.c_int, [_P, _P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
+    'lfd_bn_train_apply_into_f16': (C.c_int, [_P, _I32, _I64, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
+    'lfd_bn_train_bwd_from_f16': (C.c_int, [_P, _I64, _I64, _P, _I32, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
+    'lfd_head_out_split_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _P]),
+    'lfd_head_out_grad_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),
     'lfd_gn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_zero_insert2_nhwc_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_conv3x3s2_dgrad_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P]),

@@ -776,6 +776,64 @@ def gn_train_stats_apply(y, groups, eps, gamma, beta, relu=True):
     return stats, z
 
 
+def _seg_array(seg_hw):
+    return (C.c_int64 * len(seg_hw))(*[int(v) for v in seg_hw])
+
+
+def gn_train_stats_apply_seg(y, seg_hw, groups, eps, gamma, beta, relu=True):
+    """GroupNorm + ReLU of a LEVEL-CONCATENATED tensor y [n, P, c] (P = sum(seg_hw)), statistics per (image, segment)
+    -> (stats [n * nseg, 2, groups], z) (lfd_gn_train_stats_apply_seg_f16)"""
+    require_cuda(y, 'gn_train_stats_apply_seg')
+    n, p, c = y.shape
+    if y.dtype != torch.float16 or not y.is_contiguous() or p != sum(seg_hw):
+        raise RuntimeError('gn_train_stats_apply_seg: contiguous fp16 [n, sum(seg_hw), c] expected')
+    stats = torch.empty(n * len(seg_hw) * 2 * groups, dtype=torch.float32, device=y.device)
+    z = torch.empty_like(y)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_gn_train_stats_apply_seg_f16(ptr(y), n, len(seg_hw), _seg_array(seg_hw), c, groups, float(eps), ptr(gamma),
+                                                     ptr(beta), int(bool(relu)), ptr(ws), ws.numel(), ptr(stats), ptr(z),
+                                                     stream_ptr()), 'lfd_gn_train_stats_apply_seg_f16')
+    return stats, z
+
+
+def gn_train_backward_seg(dz, y, z, seg_hw, groups, stats, gamma, inv_scale, dgamma, dbeta, accumulate=False):
+    require_cuda(y, 'gn_train_backward_seg')
+    n, p, c = y.shape
+    dy = torch.empty_like(y)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_gn_train_bwd_seg_f16(ptr(dz), ptr(y), ptr(z), n, len(seg_hw), _seg_array(seg_hw), c, groups, ptr(stats),
+                                             ptr(gamma), float(inv_scale), int(bool(accumulate)), ptr(ws), ws.numel(), ptr(dgamma),
+                                             ptr(dbeta), ptr(dy), stream_ptr()), 'lfd_gn_train_bwd_seg_f16')
+    return dy
+
+
+def bn_train_apply_into(y, stats, gamma, beta, relu, z_concat, point0):
+    """bn_train_apply of a level's tensor y [n, h, w, c] into rows [point0, point0 + h * w) of every image of z_concat [n, P, c]"""
+    _nhwc16(y, 'bn_train_apply_into')
+    n, h, w_, c = y.shape
+    with torch.cuda.device(y.device):
+        check(lib().lfd_bn_train_apply_into_f16(ptr(y), n, h * w_, c, ptr(stats), ptr(gamma), ptr(beta), int(bool(relu)),
+                                                ptr(z_concat), z_concat.size(1), int(point0), stream_ptr()),
+              'lfd_bn_train_apply_into_f16')
+
+
+def bn_train_backward_from(dz_concat, point0, y, stats, gamma, beta, inv_scale, dgamma, dbeta, relu=True, accumulate=True):
+    """bn_train_backward of a level's unit (no residual; ReLU mask recomputed from y) whose output gradient is rows
+    [point0, point0 + h * w) of every image of dz_concat [n, P, c] -> dy [n, h, w, c]"""
+    _nhwc16(y, 'bn_train_backward_from')
+    n, h, w_, c = y.shape
+    dy = torch.empty_like(y)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        check(lib().lfd_bn_train_bwd_from_f16(ptr(dz_concat), dz_concat.size(1), int(point0), ptr(y), int(bool(relu)), n, h * w_, c,
+                                              ptr(stats), ptr(gamma), ptr(beta), float(inv_scale), int(bool(accumulate)), ptr(ws),
+                                              ws.numel(), ptr(dgamma), ptr(dbeta), ptr(dy), stream_ptr()),
+              'lfd_bn_train_bwd_from_f16')
+    return dy
+
+
 def gn_train_backward(dz, y, z, groups, stats, gamma, inv_scale, dgamma, dbeta, accumulate=False):
     _nhwc16(dz, 'gn_train_backward')
     n, h, w_, c = y.shape
@@ -988,6 +1046,28 @@ def _head_out_segs(segs, field, tensors):
         if field == 'grad':
             arr[i].dbias, arr[i].dscale = ptr(sg.get('dbias')), ptr(sg.get('dscale'))
     return arr
+
+
+def head_out_split_concat(y_concat, hw, segs, outs, point0):
+    """head_out_split for a level whose conv output is rows [point0, point0 + hw) of every image of y_concat [n, P, 64]"""
+    require_cuda(y_concat, 'head_out_split_concat')
+    n = y_concat.size(0)
+    arr = _head_out_segs(segs, 'out', outs)
+    with torch.cuda.device(y_concat.device):
+        check(lib().lfd_head_out_split_concat_f16(ptr(y_concat), n, int(hw), outs[0].size(1), int(point0), arr, len(segs),
+                                                  stream_ptr()), 'lfd_head_out_split_concat_f16')
+
+
+def head_out_grad_concat(y_concat, hw, segs, grads, point0, loss_scale, dy_concat):
+    """head_out_grad writing the level's rows of dy_concat [n, P, 64]; accumulates dbias / dscale of the segments"""
+    require_cuda(y_concat, 'head_out_grad_concat')
+    n = y_concat.size(0)
+    arr = _head_out_segs(segs, 'grad', grads)
+    ws = train_workspace(y_concat.device)
+    with torch.cuda.device(y_concat.device):
+        check(lib().lfd_head_out_grad_concat_f16(ptr(y_concat), n, int(hw), grads[0].size(1), int(point0), arr, len(segs),
+                                                 float(loss_scale), ptr(dy_concat), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_head_out_grad_concat_f16')
 
 
 def head_out_split(y, segs, outs, point0):

@@ -631,6 +631,161 @@ def _out_pack(o, cache):
     return cache[tuple(id(cv) for _, cv in o.convs)]
 
 
+# Level-concatenated head (round 4).  The shipped heads apply the SAME tower modules to every pyramid level (lfd_head.py:67-82,
+# :164-185).  Per level that is 11 launches forward and 19 backward, 150 per iteration, most of them ~5 us kernels on the small
+# levels.  With the levels of an image stored back to back -- [N, P, C], the point order LFD.forward returns anyway (lfd.py:526-542)
+# -- a shared 1x1 conv, its weight gradient and its data gradient are ONE launch over all levels (a 1x1 conv does not care which
+# pixel belongs to which level), GroupNorm takes its statistics per (image, level) segment (ops.gn_train_*_seg), and only the
+# per-level modules stay per level: the neck units (own weights / BatchNorm; they write into / read from the concatenated tensor)
+# and the glue of the output convs (per-level Scale).  Used when the head has this structure and no streams are forked.
+CONCAT_HEAD = True
+
+
+def _concat_layout(units, outs, nlev):
+    """-> None, or the structure of a head whose towers and output convs are shared by all levels"""
+    lv_units = [[ui for ui, u in enumerate(units) if u.level == l] for l in range(nlev)]
+    k = len(lv_units[0]) if lv_units else 0
+    if nlev < 2 or k < 2 or any(len(v) != k for v in lv_units):
+        return None
+    pos_of = [dict((units[ui].dst, p_) for p_, ui in enumerate(lv_units[l])) for l in range(nlev)]
+    for p_ in range(k):
+        u0 = units[lv_units[0][p_]]
+        for l in range(nlev):
+            u = units[lv_units[l][p_]]
+            if u.res is not None or u.first or tuple(u.conv.kernel_size) != (1, 1) or tuple(u.conv.stride) != (1, 1) or not u.relu:
+                return None
+            if p_ == 0:      # the level's own neck unit on its backbone tap
+                if not isinstance(u.norm, nn.BatchNorm2d) or u.src in pos_of[l] or u.conv.out_channels != u0.conv.out_channels:
+                    return None
+            else:
+                if u.conv is not u0.conv or u.norm is not u0.norm or not isinstance(u.norm, nn.GroupNorm):
+                    return None
+                if pos_of[l].get(u.src) is None or pos_of[l].get(u.src) != pos_of[0].get(u0.src):
+                    return None
+    lv_outs = [[o for o in outs if o.level == l] for l in range(nlev)]
+    m = len(lv_outs[0])
+    if m < 1 or any(len(v) != m for v in lv_outs):
+        return None
+    for j in range(m):
+        o0 = lv_outs[0][j]
+        for l in range(nlev):
+            o = lv_outs[l][j]
+            if [id(cv) for _, cv in o.convs] != [id(cv) for _, cv in o0.convs]:
+                return None
+            if pos_of[l].get(o.src) is None or pos_of[l].get(o.src) != pos_of[0].get(o0.src):
+                return None
+    return dict(lv_units=lv_units, npos=k, src_pos=[None] + [pos_of[0][units[lv_units[0][p_]].src] for p_ in range(1, k)],
+                out_src=[pos_of[0][lv_outs[0][j].src] for j in range(m)], lv_outs=lv_outs)
+
+
+def _as_image(t):
+    """[N, P, C] -> [1, H, W, C] view with N * P = H * W: how a 1x1 conv kernel sees the concatenated pixels (None: no usable W)"""
+    total = t.size(0) * t.size(1)
+    for w_ in (256, 128, 64, 32, 16):
+        if total % w_ == 0:
+            return t.view(1, total // w_, w_, t.size(2))
+    return None
+
+
+def _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, n, dev):
+    """neck units per level into A[0]; shared tower units over all levels; output convs over all levels + per-level slices"""
+    seg_hw = [h_ * w_ for h_, w_ in sizes]
+    ptot = sum(seg_hw)
+    A, Y = [None] * cl['npos'], [None] * cl['npos']
+    c0 = units[cl['lv_units'][0][0]].conv.out_channels
+    A[0] = torch.empty((n, ptot, c0), dtype=torch.float16, device=dev)
+    if _as_image(A[0]) is None:
+        return None
+    for l in range(len(sizes)):
+        ui = cl['lv_units'][l][0]
+        u = units[ui]
+        conv, norm = u.conv, u.norm
+        xin = acts[u.src]
+        if fused_stats:
+            y, stats = ops.conv2d_bn_stats(xin, packs(conv.weight), zeros(conv.out_channels), conv.in_channels, conv.out_channels, 1, 1,
+                                           norm.eps, norm.momentum, norm.running_mean, norm.running_var)
+        else:
+            y = ops.conv2d_nhwc(xin, packs(conv.weight), zeros(conv.out_channels), conv.in_channels, conv.out_channels, 1, 1, False)
+            stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
+        ops.bn_train_apply_into(y, stats, norm.weight.detach(), norm.bias.detach(), True, A[0], starts[l])
+        tape[ui] = (y, stats)
+    for p_ in range(1, cl['npos']):
+        u = units[cl['lv_units'][0][p_]]
+        conv, norm = u.conv, u.norm
+        xin = _as_image(A[cl['src_pos'][p_]])
+        y = ops.conv2d_nhwc(xin, packs(conv.weight), zeros(conv.out_channels), conv.in_channels, conv.out_channels, 1, 1, False)
+        y = y.view(n, ptot, conv.out_channels)
+        stats, A[p_] = ops.gn_train_stats_apply_seg(y, seg_hw, norm.num_groups, norm.eps, norm.weight.detach(), norm.bias.detach(), True)
+        Y[p_] = (y, stats)
+    yo = []
+    for j, sp in enumerate(cl['out_src']):
+        o0 = cl['lv_outs'][0][j]
+        wp, bp, wpk, _ = _out_pack(o0, opk)
+        xin = _as_image(A[sp])
+        y = ops.conv2d_nhwc(xin, wpk, bp, xin.size(3), wp.size(0), 1, 1, False).view(n, ptot, wp.size(0))
+        for l in range(len(sizes)):
+            segs = _out_segs(cl['lv_outs'][l][j])
+            ops.head_out_split_concat(y, seg_hw[l], segs, [full[sg['kind']] for sg in segs], starts[l])
+        yo.append(y)
+    return dict(A=A, Y=Y, yo=yo, seg_hw=seg_hw, ptot=ptot)
+
+
+def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts, store, wgrad, grads, scale, inv, n, dev):
+    """the backward of _concat_forward; leaves the gradients of the backbone taps in `grads`"""
+    A, Y, seg_hw, ptot = cs['A'], cs['Y'], cs['seg_hw'], cs['ptot']
+    dA = [None] * cl['npos']
+    nlev = len(seg_hw)
+    for j, sp in enumerate(cl['out_src']):
+        o0 = cl['lv_outs'][0][j]
+        wp = _out_pack(o0, opk)[0]
+        y = cs['yo'][j]
+        dyo = torch.empty_like(y)
+        for l in range(nlev):
+            o = cl['lv_outs'][l][j]
+            segs = _out_segs(o)
+            for sg in segs:
+                sg['dbias'] = store.target(sg['conv'].bias)
+                sg['dscale'] = store.target(o.scale._scale) if sg['scale'] is not None else None
+            ops.head_out_grad_concat(y, seg_hw[l], segs, [full[sg['kind']] for sg in segs], starts[l], scale, dyo)
+        r0, targets = 0, []
+        for _, cv in o0.convs:
+            targets.append((store.target(cv.weight), r0, r0 + cv.out_channels))
+            r0 += cv.out_channels
+        xin, dy4 = _as_image(A[sp]), _as_image(dyo)
+        wgrad(None, xin, dy4, 1, 1, targets)
+        c = xin.size(3)
+        res = _as_image(dA[sp]) if dA[sp] is not None else None
+        dA[sp] = ops.conv2d_nhwc(dy4, _out_pack(o0, opk)[3], zeros(c), wp.size(0), c, 1, 1, False, residual=res).view(n, ptot, c)
+    for p_ in range(cl['npos'] - 1, 0, -1):
+        if dA[p_] is None:
+            continue
+        u = units[cl['lv_units'][0][p_]]
+        conv, norm = u.conv, u.norm
+        y, stats = Y[p_]
+        dy = ops.gn_train_backward_seg(dA[p_], y, A[p_], seg_hw, norm.num_groups, stats, norm.weight.detach(), inv,
+                                       store.target(norm.weight), store.target(norm.bias), True)
+        dA[p_] = None
+        sp = cl['src_pos'][p_]
+        xin, dy4 = _as_image(A[sp]), _as_image(dy)
+        wgrad(None, xin, dy4, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
+        cin = conv.in_channels
+        res = _as_image(dA[sp]) if dA[sp] is not None else None
+        dA[sp] = ops.conv2d_nhwc(dy4, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, 1, 1, False,
+                                 residual=res).view(n, ptot, cin)
+    for l in range(nlev - 1, -1, -1):
+        ui = cl['lv_units'][l][0]
+        u = units[ui]
+        conv, norm = u.conv, u.norm
+        y, stats = tape[ui]
+        dy = ops.bn_train_backward_from(dA[0], starts[l], y, stats, norm.weight.detach(), norm.bias.detach(), inv,
+                                        store.target(norm.weight), store.target(norm.bias), relu=True, accumulate=True)
+        xin = acts[u.src]
+        wgrad(None, xin, dy, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
+        cin = conv.in_channels
+        grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, 1, 1, False,
+                                       residual=grads.get(u.src))
+
+
 def network_forward(model, plan, x):
     """-> (cls [N,P,C'], reg [N,P,4], sizes, saved): LFD.forward in train mode (lfd.py:511-542) over the unit schedule, the
     pyramid levels on their own streams."""
@@ -670,7 +825,25 @@ def network_forward(model, plan, x):
     def stream_of(level):
         return sc.lv[level] if (par and level is not None) else main
 
+    cl = None
+    if CONCAT_HEAD and not par:
+        cl = model.__dict__.get('_lfd_concat_layout', 0)
+        if cl == 0:
+            cl = _concat_layout(units, outs, nlev)
+            model.__dict__['_lfd_concat_layout'] = cl
+    if cl is not None:
+        for ui, u in enumerate(units):
+            if u.level is None:
+                tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats)
+        cs = _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, x.size(0), dev)
+        if cs is not None:
+            torch._foreach_add_([u.norm.num_batches_tracked for u in units if isinstance(u.norm, nn.BatchNorm2d)], 1)
+            return full['cls'], full['reg'], sizes, ((acts, tape), cs, opk)
+        cl = None        # (no usable image view of N * P pixels: the per-level schedule below; the backbone units are done)
+
     for ui, u in enumerate(units):
+        if tape[ui] is not None:
+            continue
         S = stream_of(u.level)
         if par and u.level is not None and u.level not in started:
             started.add(u.level)
@@ -760,14 +933,15 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         if o.scale is not None:
             store.target(o.scale._scale)
     # private per-level rows of the small gradients several levels share: GroupNorm weight / bias, output-conv biases
+    # (per-level schedule only: the level-concatenated one touches every shared parameter once)
     small, off = {}, 0
-    for u in units:
+    for u in (() if isinstance(osaved, dict) else units):
         if isinstance(u.norm, nn.GroupNorm):
             for p_ in (u.norm.weight, u.norm.bias):
                 if id(p_) not in small:
                     small[id(p_)] = (p_, off)
                     off += p_.numel()
-    for o in outs:
+    for o in (() if isinstance(osaved, dict) else outs):
         for _, cv in o.convs:
             if id(cv.bias) not in small:
                 small[id(cv.bias)] = (cv.bias, off)
@@ -798,7 +972,7 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         floats, nwg, nblk = ops.conv_wgrad_partial_floats(xin, dy, ks, st)
         part = sc.buf(('wg', nj[0]), floats)
         nj[0] += 1
-        if par:
+        if par and S is not None:
             wst.wait_stream(S)
             keep.extend((xin, dy))
         with torch.cuda.stream(wst):
@@ -806,6 +980,7 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         fin.add_wgrad(part, nwg, nblk, xin.size(3), dy.size(3), ks * ks, inv, targets)
 
     grads, owner = {}, {}
+    concat = isinstance(osaved, dict)
 
     def visible(S, k):
         """grads[k] may have been written on another stream"""
@@ -815,8 +990,11 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
             keep.append(grads[k])
         owner[k] = S
 
+    if concat:
+        _concat_backward(model.__dict__['_lfd_concat_layout'], osaved, units, acts, tape, packs, opk, zeros, full, starts, store,
+                         wgrad, grads, scale, inv, dcls.size(0), dev)
     # ---- output convs
-    for o, (wp, y) in zip(outs, osaved):
+    for o, (wp, y) in (() if concat else zip(outs, osaved)):
         S = stream_of(o.level)
         with torch.cuda.stream(S):
             xo = acts[o.src]
@@ -836,7 +1014,7 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
     # ---- conv / norm / ReLU units, last to first
     for ui in range(len(units) - 1, -1, -1):
         u = units[ui]
-        if u.dst not in grads:
+        if u.dst not in grads or (concat and u.level is not None):
             continue
         S = stream_of(u.level)
         with torch.cuda.stream(S):

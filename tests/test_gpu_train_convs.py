@@ -583,14 +583,21 @@ def test_stride2_data_gradient_per_parity_is_bit_identical_to_the_zero_inserted_
     assert bool((err <= 2e-3 * dx64.abs().clamp(min=1.0)).all()), float(err.max())
 
 
-@pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_S', (2, 128, 160)), ('TT100K_LFD_L', (2, 96, 128)), ('WIDERFACE_LFD_XS', (3, 192, 224))])
-def test_parallel_network_schedule_equals_the_serial_unit_schedule(name, shape):
-    """train_engine.network_forward / network_backward (round 4: pyramid levels on their own streams, weight gradients on a side
-    stream into private partial buffers, ONE batched final launch, private per-level rows for the small shared gradients)
-    against the serial unit API (train_engine.forward / outputs_forward / outputs_backward / backward: the launches in list
-    order on one stream, a final launch per conv): outputs and activation-side results bit for bit; parameter gradients equal
-    up to the ONE rounding the batched final saves per shared parameter (<= 1e-6 of the tensor's largest entry, measured
-    <= 2e-7); PARALLEL on / off: every gradient bit for bit."""
+@pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_S', (2, 128, 160)), ('TT100K_LFD_L', (2, 96, 128)), ('WIDERFACE_LFD_XS', (3, 192, 224)),
+                                        ('WIDERFACE_LFD_S', (3, 100, 132))])
+def test_network_schedules_equal_the_serial_unit_schedule(name, shape):
+    """train_engine.network_forward / network_backward (round 4) against the serial unit API (train_engine.forward /
+    outputs_forward / outputs_backward / backward: the launches in list order on one stream, a final launch per conv), in its
+    three forms:
+      per-level, one stream   weight gradients into private partial buffers + ONE batched final launch, private per-level rows
+                              for the small shared gradients: outputs, BatchNorm statistics bit for bit; parameter gradients
+                              equal up to the ONE rounding the batched final saves per shared parameter (<= 1e-6 of the tensor's
+                              largest entry);
+      per-level, streams      (PARALLEL: levels and weight gradients on their own streams) every gradient bit for bit equal to
+                              the one-stream form, also on a second run (persistent buffers re-used);
+      level-concatenated      (CONCAT_HEAD, the default: shared towers once over all levels) the same network up to the order
+                              of GroupNorm's partial sums (another block partition of a level's pixels): outputs within 2e-3
+                              of the logit scale, gradients cos > 0.9999 and norm within 0.2 % per parameter."""
     import copy
     from lfd_amd import configs, train_engine
     torch.manual_seed(3)
@@ -598,7 +605,6 @@ def test_parallel_network_schedule_equals_the_serial_unit_schedule(name, shape):
     configs.perturb_weights(m0, seed=1)
     n, h, w = shape
     x = (torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(5)) * 2 - 1).cuda()
-    S = train_engine.LOSS_SCALE
 
     def serial():
         m = copy.deepcopy(m0)
@@ -612,34 +618,52 @@ def test_parallel_network_schedule_equals_the_serial_unit_schedule(name, shape):
         train_engine.backward(units, saved, grads, store=store)
         return m, cls, reg, wc, wr, {k: store.get(p) for k, p in m.named_parameters()}
 
-    def parallel(flag):
+    def node(parallel, concat):
         m = copy.deepcopy(m0)
-        keep = train_engine.PARALLEL
-        train_engine.PARALLEL = flag
+        keep = train_engine.PARALLEL, train_engine.CONCAT_HEAD
+        train_engine.PARALLEL, train_engine.CONCAT_HEAD = parallel, concat
         try:
             cls, reg = m(x)
             torch.autograd.backward([cls, reg], [wc, wr])
             torch.cuda.synchronize()
         finally:
-            train_engine.PARALLEL = keep
+            train_engine.PARALLEL, train_engine.CONCAT_HEAD = keep
         return m, cls.detach(), reg.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
 
     ms, cls_s, reg_s, wc, wr, gs = serial()
-    results = {}
-    for flag in (True, False, True):                       # twice with streams: the persistent buffers are re-used
-        mp, cls_p, reg_p, gp = parallel(flag)
+    res = {}
+    for key in ((False, False), (True, False), (True, False)):          # twice with streams: the persistent buffers are re-used
+        mp, cls_p, reg_p, gp = node(*key)
         assert torch.equal(cls_p, cls_s) and torch.equal(reg_p, reg_s)
         for (k, a), b in zip(ms.state_dict().items(), mp.state_dict().values()):
             assert torch.equal(a, b), k                    # BatchNorm running statistics, num_batches_tracked
         worst = 0.0
         for k in gs:
             a, b = gs[k], gp[k]
-            assert a is not None and b is not None, k
             e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-20))
             worst = max(worst, e)
             assert e <= 1e-6, (k, e)
-        results.setdefault(flag, []).append(gp)
-        print('%s PARALLEL=%s: worst relative gradient difference to the serial schedule %.2e' % (name, flag, worst))
+        res.setdefault(key, []).append(gp)
+        print('%s PARALLEL=%s: worst relative gradient difference to the serial schedule %.2e' % (name, key[0], worst))
     for k in gs:
-        assert torch.equal(results[True][0][k], results[False][0][k]), k
-        assert torch.equal(results[True][0][k], results[True][1][k]), k
+        assert torch.equal(res[(True, False)][0][k], res[(False, False)][0][k]), k
+        assert torch.equal(res[(True, False)][0][k], res[(True, False)][1][k]), k
+    # the level-concatenated form
+    mc, cls_c, reg_c, gc = node(False, True)
+    assert mc.__dict__.get('_lfd_concat_layout') is not None
+    lim = 2e-3 * float(cls_s.abs().max().clamp_min(1.0))
+    assert float((cls_c - cls_s).abs().max()) <= lim and float((reg_c - reg_s).abs().max()) <= lim
+    worst_cos, worst_norm = 1.0, 0.0
+    for k in gs:
+        a, b = gs[k].double().reshape(-1), gc[k].double().reshape(-1)
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0, k
+            continue
+        cos = float(a @ b / (a.norm() * b.norm()))
+        nr = abs(float(b.norm() / a.norm()) - 1.0)
+        worst_cos, worst_norm = min(worst_cos, cos), max(worst_norm, nr)
+        assert cos > 0.9999 and nr < 2e-3, (k, cos, nr)
+    for (k, a), b in zip(ms.state_dict().items(), mc.state_dict().values()):
+        if 'running_' in k:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=k)
+    print('%s level-concatenated: worst gradient cosine %.6f, worst norm deviation %.2e' % (name, worst_cos, worst_norm))
