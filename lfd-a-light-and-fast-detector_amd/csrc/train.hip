@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void k_gn_stats_partial(const __half* __r
 // 64 partial blocks of a large map), then a fixed-order butterfly over the parts -- deterministic.
 __global__ __launch_bounds__(64) void k_gn_stats_final(const float* partials, int nblocks, int g, GnGeom G, float eps,
                                                       float* stats) {
-  const double m = (double)G.vecs[blockIdx.x % G.nseg] * 8.0;
+  const double m = (double)(G.vecs[blockIdx.x % G.nseg] / g) * 8.0;       // pixels of the segment x 8 channels per group
   const int lane = threadIdx.x, cg = lane % g, part = lane / g, nparts = 64 / g;     // g is a power of two <= 32
   double s = 0.0, ss = 0.0;
 #pragma unroll 4
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void k_gn_apply(const __half* __restrict_
   size_t base;
   int64_t vecs_per_img;
   gn_segment(G, &base, &vecs_per_img);
-  const double m = (double)vecs_per_img * 8.0;
+  const double m = (double)(vecs_per_img / g) * 8.0;       // pixels of the segment x 8 channels per group
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 h0;
   if (v0 < vecs_per_img) h0 = ld8(y, base + v0);        // (requested before the statistics: one round trip, not two)
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void k_gn_bwd_apply(const __half* __restr
   size_t base;
   int64_t vecs_per_img;
   gn_segment(G, &base, &vecs_per_img);
-  const float inv_m = (float)(1.0 / ((double)vecs_per_img * 8.0));
+  const float inv_m = (float)(1.0 / ((double)(vecs_per_img / g) * 8.0));
   const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs_per_img) {

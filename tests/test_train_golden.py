@@ -116,7 +116,7 @@ _FREE_GATES = {
     'WIDERFACE_LFD_S': ([0.01, 0.015, 0.03], [0.03, 0.03, 0.20], 0.01),           # measured 0.0004 0.0073 0.0188 | 0.005 0.015 0.136 | 0.0055
     'WIDERFACE_LFD_XS': ([0.01, 0.01, 0.05], [0.03, 0.03, 0.20], 0.03),           # 0.0008 0.0040 0.0339 | 0.0002 0.008 0.129 | 0.019
     'TT100K_LFD_L': ([0.01, 0.01, 0.01], [0.03, 0.03, 0.03], 0.01),               # 0.0001 0.0004 0.0031 | 0.0006 0.0004 0.0059 | 0.0038
-    'TL_LFD_L': ([0.01, 0.01, 0.01], [0.03, 0.03, 0.03], 0.01),                   # 0.0000 0.0000 0.0001 | 0.0001 0.0001 0.0001 | 0.0041
+    'TL_LFD_L': ([0.01, 0.01, 0.01], [0.03, 0.03, 0.03], 0.03),                   # 0.0000 0.0000 0.0001 | 0.0001 0.0001 0.0001 | 0.0026-0.0103 (neck4: 2 x 1 x 2 values)
     'WIDERFACE_LFD_S@8x512x512': ([0.01, 0.01, 0.01], [0.03, 0.03, 0.03], 0.003),   # 0.0005 0.0013 0.0040 | 0.0001 0.0002 0.0039 | 0.00016
     'WIDERFACE_LFD_XS@8x512x512': ([0.01, 0.01, 0.01], [0.03, 0.03, 0.06], 0.003),  # 0.0005 0.0003 0.0014 | 0.0003 0.0003 0.0353 | 0.00015
 }
