@@ -594,7 +594,18 @@ __global__ __launch_bounds__(64) void k_gn_bwd_final(const float* pgroup, const 
     if (threadIdx.x == 0) gsums[o] = (float)s;
   } else {
     const int j = o - n * 2 * g;
-    for (int b = threadIdx.x; b < n * nblocks; b += 64) s += (double)pchan[(size_t)b * 2 * c + j];
+    // (eight rows requested before the first add: the level-concatenated head has n * nblocks ~ 4000 rows, a chain of 62
+    //  dependent L2 round trips per lane otherwise -- 27 us per launch; adds in row order within a lane)
+    const int rows = n * nblocks;
+    int b = threadIdx.x;
+    for (; b + 7 * 64 < rows; b += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pchan[(size_t)(b + 64 * u) * 2 * c + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < rows; b += 64) s += (double)pchan[(size_t)b * 2 * c + j];
     s = wave_sum_d(s);
     if (threadIdx.x == 0) {
       float* dst = j < c ? dgamma + j : dbeta + (j - c);
