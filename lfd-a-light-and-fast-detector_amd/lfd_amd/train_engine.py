@@ -550,34 +550,26 @@ def outputs_backward(outs, acts, saved, sizes, dcls, dreg, store, scale=None):
 
 
 # ---------------------------------------------------------------------------------------------- whole-network schedule
-# Round 4.  The iteration of the shipped configurations is ~500 launches of which ~360 run for less than 12 us (small maps,
-# one-wave finals): as ONE dependent chain they cost 2.3 ms of a 7.4 ms iteration (tools/timing/train_trace.py).  Three things
-# about the reference's graph (lfd_resnet.py:488-501, lfd_head.py:164-185) make most of that chain unnecessary:
-#   * the pyramid levels are independent between their backbone tap and the level-concatenated outputs: neck -> towers ->
-#     output convs of level i run on stream i, forward (from the moment the tap exists, beside the rest of the backbone) and
-#     backward (the backbone's backward waits for a level only where it first touches that tap's gradient);
-#   * a weight gradient is needed by nobody until the optimizer: every k_wgrad runs on a side stream into its OWN partial
-#     buffer, and ONE launch sums all of them at the end (ops.WgradFinals) instead of a final launch per conv;
-#   * parameters shared by the levels (tower convs, GroupNorm weight / bias, output convs and their biases) accumulate
-#     through chained partial sets / private per-level rows summed by the same final launches -- no read-modify-write on a
-#     shared gradient from two streams, and one rounding instead of one per level.
-# PARALLEL = False runs the same launches on the caller's stream (identical results bit for bit: the A/B and the test).
-PARALLEL = False
+# Round 4.  An iteration of the shipped configurations was ~500 launches of which ~360 ran for less than 12 us (small maps,
+# one-wave finals): 2.3 ms of a 7.4 ms iteration as ONE dependent chain (tools/timing/train_trace.py).  What this schedule does
+# about it, on ONE stream (side streams inside a HIP graph measured slower: tools/negative_results/train_streams.py.txt):
+#   * a weight gradient is needed by nobody until the optimizer: every k_wgrad writes its per-workgroup partial sums into its
+#     OWN persistent buffer and ONE launch sums all of them at the end (ops.WgradFinals) -- 49 final launches become one; a conv
+#     shared by the pyramid levels is a chain of partial sets summed with one rounding;
+#   * the shared head runs level-concatenated (below): 150 launches per iteration become ~70.
 
 
 class _Sched(object):
-    """streams and persistent buffers of one training plan on one device"""
+    """persistent buffers and job tables of one training plan on one device"""
 
-    def __init__(self, dev, nlev):
+    def __init__(self, dev):
         self.dev = dev
-        self.lv = [torch.cuda.Stream(device=dev) for _ in range(nlev)]
-        self.w = torch.cuda.Stream(device=dev)
         self.bufs = {}
         self.finals = ops.WgradFinals(dev)
         self.gather = ops.WgradFinals(dev)      # (its row-sum table with one source row = a batched copy)
 
     def buf(self, key, numel, dtype=torch.float32):
-        """a buffer that keeps its address from iteration to iteration (partial sums, private gradient rows)"""
+        """a buffer that keeps its address from iteration to iteration (partial sums of the weight gradients)"""
         t = self.bufs.get(key)
         if t is None or t.numel() != numel or t.dtype != dtype:
             t = torch.empty(numel, dtype=dtype, device=self.dev)
@@ -585,10 +577,10 @@ class _Sched(object):
         return t
 
 
-def _sched(plan_owner, dev, nlev):
+def _sched(plan_owner, dev):
     sc = plan_owner.__dict__.get('_lfd_train_sched')
-    if sc is None or sc.dev != dev or len(sc.lv) != nlev:
-        sc = _Sched(dev, nlev)
+    if sc is None or sc.dev != dev:
+        sc = _Sched(dev)
         plan_owner.__dict__['_lfd_train_sched'] = sc
     return sc
 
@@ -637,7 +629,8 @@ def _out_pack(o, cache):
 # -- a shared 1x1 conv, its weight gradient and its data gradient are ONE launch over all levels (a 1x1 conv does not care which
 # pixel belongs to which level), GroupNorm takes its statistics per (image, level) segment (ops.gn_train_*_seg), and only the
 # per-level modules stay per level: the neck units (own weights / BatchNorm; they write into / read from the concatenated tensor)
-# and the glue of the output convs (per-level Scale).  Used when the head has this structure and no streams are forked.
+# and the glue of the output convs (per-level Scale).  Used when the head has this structure (every shipped configuration);
+# CONCAT_HEAD = False, or a head whose levels do not share their towers, runs the same launches level by level.
 CONCAT_HEAD = True
 
 
@@ -752,7 +745,7 @@ def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts,
             targets.append((store.target(cv.weight), r0, r0 + cv.out_channels))
             r0 += cv.out_channels
         xin, dy4 = _as_image(A[sp]), _as_image(dyo)
-        wgrad(None, xin, dy4, 1, 1, targets)
+        wgrad(xin, dy4, 1, 1, targets)
         c = xin.size(3)
         res = _as_image(dA[sp]) if dA[sp] is not None else None
         dA[sp] = ops.conv2d_nhwc(dy4, _out_pack(o0, opk)[3], zeros(c), wp.size(0), c, 1, 1, False, residual=res).view(n, ptot, c)
@@ -767,7 +760,7 @@ def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts,
         dA[p_] = None
         sp = cl['src_pos'][p_]
         xin, dy4 = _as_image(A[sp]), _as_image(dy)
-        wgrad(None, xin, dy4, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
+        wgrad(xin, dy4, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
         cin = conv.in_channels
         res = _as_image(dA[sp]) if dA[sp] is not None else None
         dA[sp] = ops.conv2d_nhwc(dy4, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, 1, 1, False,
@@ -780,28 +773,21 @@ def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts,
         dy = ops.bn_train_backward_from(dA[0], starts[l], y, stats, norm.weight.detach(), norm.bias.detach(), inv,
                                         store.target(norm.weight), store.target(norm.bias), relu=True, accumulate=True)
         xin = acts[u.src]
-        wgrad(None, xin, dy, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
+        wgrad(xin, dy, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
         cin = conv.in_channels
         grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, 1, 1, False,
                                        residual=grads.get(u.src))
 
 
 def network_forward(model, plan, x):
-    """-> (cls [N,P,C'], reg [N,P,4], sizes, saved): LFD.forward in train mode (lfd.py:511-542) over the unit schedule, the
-    pyramid levels on their own streams."""
+    """-> (cls [N,P,C'], reg [N,P,4], sizes, saved): LFD.forward in train mode (lfd.py:511-542) over the unit schedule"""
     units, outs, nlev = plan
     dev = x.device
-    sc = _sched(model, dev, nlev)
-    main = torch.cuda.current_stream(dev)
-    par = PARALLEL
+    sc = _sched(model, dev)
     acts, tape = {0: x}, [None] * len(units)
     zeros = _Zeros(dev)
-    for c in (32, 64, 128):
-        zeros(c)
     packs = _Packs(units, False)
     opk = _out_packs(sc, outs)
-    taps = set(u.src for u in units if u.level is not None and any(v.dst == u.src and v.level is None for v in units))
-    # the level-concatenated outputs exist before any level starts (allocated on the caller's stream, in its order)
     hw = {0: (x.size(2), x.size(3))}
     for u in units:
         k, st_ = u.conv.kernel_size[0], u.conv.stride[0]
@@ -820,57 +806,33 @@ def network_forward(model, plan, x):
             width[kind] = conv.out_channels
     full = {k: torch.empty((x.size(0), p, c), dtype=torch.float32, device=dev) for k, c in width.items()}
     fused_stats = os.environ.get('LFD_CONV_BN_STATS', '1') == '1'
-    ev, started = {}, set()
-
-    def stream_of(level):
-        return sc.lv[level] if (par and level is not None) else main
-
     cl = None
-    if CONCAT_HEAD and not par:
+    if CONCAT_HEAD:
         cl = model.__dict__.get('_lfd_concat_layout', 0)
         if cl == 0:
             cl = _concat_layout(units, outs, nlev)
             model.__dict__['_lfd_concat_layout'] = cl
-    if cl is not None:
-        for ui, u in enumerate(units):
-            if u.level is None:
-                tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats)
-        cs = _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, x.size(0), dev)
-        if cs is not None:
-            torch._foreach_add_([u.norm.num_batches_tracked for u in units if isinstance(u.norm, nn.BatchNorm2d)], 1)
-            return full['cls'], full['reg'], sizes, ((acts, tape), cs, opk)
-        cl = None        # (no usable image view of N * P pixels: the per-level schedule below; the backbone units are done)
-
+    cs = None
     for ui, u in enumerate(units):
-        if tape[ui] is not None:
-            continue
-        S = stream_of(u.level)
-        if par and u.level is not None and u.level not in started:
-            started.add(u.level)
-            S.wait_event(ev[u.src])                 # the level starts when its backbone tap exists
-        with torch.cuda.stream(S):
+        if u.level is None:
             tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats)
-        if par and u.level is None and u.dst in taps:
-            e = torch.cuda.Event()
-            e.record(main)
-            ev[u.dst] = e
-    torch._foreach_add_([u.norm.num_batches_tracked for u in units if isinstance(u.norm, nn.BatchNorm2d)], 1)
-    # ---- output convs: one padded 1x1 conv per level + the slices into the level-concatenated fp32 tensors
-    osaved = []
-    for o in outs:
-        S = stream_of(o.level)
-        with torch.cuda.stream(S):
+    if cl is not None:
+        cs = _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, x.size(0), dev)
+    osaved = cs
+    if cs is None:     # level by level: heads that do not share their towers, or no usable image view of N * P pixels
+        for ui, u in enumerate(units):
+            if u.level is not None:
+                tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats)
+        osaved = []
+        for o in outs:
             xo = acts[o.src]
-            assert tuple(xo.shape[1:3]) == sizes[o.level]
             c = xo.size(3)
             wp, bp, wpk, _ = _out_pack(o, opk)
             y = ops.conv2d_nhwc(xo, wpk, bp, c, wp.size(0), 1, 1, False)
             segs = _out_segs(o)
             ops.head_out_split(y, segs, [full[sg['kind']] for sg in segs], starts[o.level])
             osaved.append((wp, y))
-    if par:
-        for S in sc.lv:
-            main.wait_stream(S)
+    torch._foreach_add_([u.norm.num_batches_tracked for u in units if isinstance(u.norm, nn.BatchNorm2d)], 1)
     return full['cls'], full['reg'], sizes, ((acts, tape), osaved, opk)
 
 
@@ -908,169 +870,85 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
     units, outs, nlev = plan
     (acts, tape), osaved, opk = saved
     dev = dcls.device
-    sc = _sched(model, dev, nlev)
-    main = torch.cuda.current_stream(dev)
-    par = PARALLEL
+    sc = _sched(model, dev)
     inv = 1.0 / scale
     store = _GradStore(in_place=True)
     fin = sc.finals
     fin.reset()
-    keep = []               # tensors read on another stream than the one that owns their memory: referenced until the joins
     zeros = _Zeros(dev)
-    for c in (32, 64, 128):
-        zeros(c)
     packs = _Packs(units, True)
     dcls, dreg = dcls.contiguous(), dreg.contiguous()
     full = {'cls': dcls, 'reg': dreg}
-    # every gradient target exists before the streams fork (a missing .grad is created zeroed on the caller's stream)
-    for u in units:
-        for p_ in (u.conv.weight, u.norm.weight, u.norm.bias):
-            store.target(p_)
-    for o in outs:
-        for _, cv in o.convs:
-            store.target(cv.weight)
-            store.target(cv.bias)
-        if o.scale is not None:
-            store.target(o.scale._scale)
-    # private per-level rows of the small gradients several levels share: GroupNorm weight / bias, output-conv biases
-    # (per-level schedule only: the level-concatenated one touches every shared parameter once)
-    small, off = {}, 0
-    for u in (() if isinstance(osaved, dict) else units):
-        if isinstance(u.norm, nn.GroupNorm):
-            for p_ in (u.norm.weight, u.norm.bias):
-                if id(p_) not in small:
-                    small[id(p_)] = (p_, off)
-                    off += p_.numel()
-    for o in (() if isinstance(osaved, dict) else outs):
-        for _, cv in o.convs:
-            if id(cv.bias) not in small:
-                small[id(cv.bias)] = (cv.bias, off)
-                off += cv.bias.numel()
-    rows = sc.buf(('small', off), max(1, nlev * off)).view(nlev, max(1, off)) if off else None
-    if rows is not None:
-        rows.zero_()
-
-    def row(p_, level):
-        _, o_ = small[id(p_)]
-        return rows[level, o_:o_ + p_.numel()]
-
     starts, p = [], 0
     for h, w_ in sizes:
         starts.append(p)
         p += h * w_
-
-    def stream_of(level):
-        return sc.lv[level] if (par and level is not None) else main
-    wst = sc.w if par else main
-    if par:
-        for S in sc.lv + [sc.w]:
-            S.wait_stream(main)
     nj = [0]
 
-    def wgrad(S, xin, dy, ks, st, targets):
-        """the partial sums of dW on the side stream; `targets` as ops.WgradFinals.add_wgrad"""
+    def wgrad(xin, dy, ks, st, targets):
+        """the partial sums of dW into this conv's own buffer; `targets` as ops.WgradFinals.add_wgrad"""
         floats, nwg, nblk = ops.conv_wgrad_partial_floats(xin, dy, ks, st)
         part = sc.buf(('wg', nj[0]), floats)
         nj[0] += 1
-        if par and S is not None:
-            wst.wait_stream(S)
-            keep.extend((xin, dy))
-        with torch.cuda.stream(wst):
-            ops.conv_wgrad_partials(xin, dy, ks, st, part)
+        ops.conv_wgrad_partials(xin, dy, ks, st, part)
         fin.add_wgrad(part, nwg, nblk, xin.size(3), dy.size(3), ks * ks, inv, targets)
 
-    grads, owner = {}, {}
+    grads = {}
     concat = isinstance(osaved, dict)
-
-    def visible(S, k):
-        """grads[k] may have been written on another stream"""
-        o_ = owner.get(k)
-        if par and o_ is not None and o_ is not S:
-            S.wait_stream(o_)
-            keep.append(grads[k])
-        owner[k] = S
-
     if concat:
         _concat_backward(model.__dict__['_lfd_concat_layout'], osaved, units, acts, tape, packs, opk, zeros, full, starts, store,
                          wgrad, grads, scale, inv, dcls.size(0), dev)
-    # ---- output convs
+    # ---- output convs, level by level
     for o, (wp, y) in (() if concat else zip(outs, osaved)):
-        S = stream_of(o.level)
-        with torch.cuda.stream(S):
-            xo = acts[o.src]
-            c = xo.size(3)
-            segs = _out_segs(o)
-            for sg in segs:
-                sg['dbias'] = row(sg['conv'].bias, o.level)
-                sg['dscale'] = store.target(o.scale._scale) if sg['scale'] is not None else None
-            dy = ops.head_out_grad(y, segs, [full[sg['kind']] for sg in segs], starts[o.level], scale)
-            r0, targets = 0, []
-            for _, cv in o.convs:
-                targets.append((store.target(cv.weight), r0, r0 + cv.out_channels))
-                r0 += cv.out_channels
-            wgrad(S, xo, dy, 1, 1, targets)
-            visible(S, o.src)
-            grads[o.src] = ops.conv2d_nhwc(dy, _out_pack(o, opk)[3], zeros(c), wp.size(0), c, 1, 1, False, residual=grads.get(o.src))
+        xo = acts[o.src]
+        c = xo.size(3)
+        segs = _out_segs(o)
+        for sg in segs:
+            sg['dbias'] = store.target(sg['conv'].bias)
+            sg['dscale'] = store.target(o.scale._scale) if sg['scale'] is not None else None
+        dy = ops.head_out_grad(y, segs, [full[sg['kind']] for sg in segs], starts[o.level], scale)
+        r0, targets = 0, []
+        for _, cv in o.convs:
+            targets.append((store.target(cv.weight), r0, r0 + cv.out_channels))
+            r0 += cv.out_channels
+        wgrad(xo, dy, 1, 1, targets)
+        grads[o.src] = ops.conv2d_nhwc(dy, _out_pack(o, opk)[3], zeros(c), wp.size(0), c, 1, 1, False, residual=grads.get(o.src))
     # ---- conv / norm / ReLU units, last to first
     for ui in range(len(units) - 1, -1, -1):
         u = units[ui]
         if u.dst not in grads or (concat and u.level is not None):
             continue
-        S = stream_of(u.level)
-        with torch.cuda.stream(S):
-            visible(S, u.dst)
-            dz = grads.pop(u.dst)
-            owner.pop(u.dst, None)
-            conv, norm = u.conv, u.norm
-            y, stats = tape[ui]
-            z = acts[u.dst] if u.relu else None
-            g = None
-            if isinstance(norm, nn.GroupNorm):
-                lvl = u.level if u.level is not None else 0
-                dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, row(norm.weight, lvl),
-                                           row(norm.bias, lvl), False)
-            else:
-                dy, g = ops.bn_train_backward(dz, y, z if u.res is not None else None, stats, norm.weight.detach(), inv,
-                                              store.target(norm.weight), store.target(norm.bias), want_g=u.res is not None,
-                                              accumulate=True, relu=u.relu, beta=norm.bias.detach())
-            if u.res is not None:
-                if u.res in grads:
-                    visible(S, u.res)
-                    grads[u.res] = grads[u.res] + g
-                else:
-                    grads[u.res] = g
-                    owner[u.res] = S
-            xin = acts[u.src]
-            ks, st = conv.kernel_size[0], conv.stride[0]
-            if u.first:
-                if par:
-                    wst.wait_stream(S)
-                    keep.extend((xin, dy))
-                with torch.cuda.stream(wst):
-                    ops.stem_conv0_wgrad(xin, dy, inv, out=store.target(conv.weight), accumulate=True)
-                continue
-            wgrad(S, xin, dy, ks, st, [(store.target(conv.weight), 0, conv.out_channels)])
-            cin = conv.in_channels
-            if u.src in grads:
-                visible(S, u.src)
-            else:
-                owner[u.src] = S
-            if st == 2 and ks == 3 and cin == 64 and conv.out_channels == 64 and os.environ.get('LFD_DGRAD_S2', '1') == '1':
-                grads[u.src] = ops.conv3x3s2_dgrad(dy, packs(conv.weight, True), xin.size(1), xin.size(2), residual=grads.get(u.src))
-            else:
-                if st == 2:
-                    dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
-                grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, ks, 1, False,
-                                               residual=grads.get(u.src))
-    # ---- joins, then the two final launches
-    if par:
-        for S in sc.lv + [sc.w]:
-            main.wait_stream(S)
-    if rows is not None:
-        for p_, o_ in small.values():
-            fin.add_rowsum(rows[0, o_:o_ + p_.numel()], nlev, rows.stride(0), p_.numel(), store.target(p_), True)
+        dz = grads.pop(u.dst)
+        conv, norm = u.conv, u.norm
+        y, stats = tape[ui]
+        z = acts[u.dst] if u.relu else None
+        g = None
+        if isinstance(norm, nn.GroupNorm):
+            dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, store.target(norm.weight),
+                                       store.target(norm.bias), True)
+        else:
+            # without a residual input the ReLU mask is recomputed from y (one tensor less to read in both passes)
+            dy, g = ops.bn_train_backward(dz, y, z if u.res is not None else None, stats, norm.weight.detach(), inv,
+                                          store.target(norm.weight), store.target(norm.bias), want_g=u.res is not None,
+                                          accumulate=True, relu=u.relu, beta=norm.bias.detach())
+        if u.res is not None:
+            grads[u.res] = g if u.res not in grads else grads[u.res] + g
+        xin = acts[u.src]
+        ks, st = conv.kernel_size[0], conv.stride[0]
+        if u.first:
+            ops.stem_conv0_wgrad(xin, dy, inv, out=store.target(conv.weight), accumulate=True)
+            continue
+        wgrad(xin, dy, ks, st, [(store.target(conv.weight), 0, conv.out_channels)])
+        cin = conv.in_channels
+        if st == 2 and ks == 3 and cin == 64 and conv.out_channels == 64 and os.environ.get('LFD_DGRAD_S2', '1') == '1':
+            # per output parity, 9 tap-products per 2 x 2 pixels instead of 36 and no zero-inserted tensor (csrc/dgrad_s2.hip)
+            grads[u.src] = ops.conv3x3s2_dgrad(dy, packs(conv.weight, True), xin.size(1), xin.size(2), residual=grads.get(u.src))
+        else:
+            if st == 2:
+                dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))
+            grads[u.src] = ops.conv2d_nhwc(dy, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, ks, 1, False,
+                                           residual=grads.get(u.src))
     fin.launch()
-    del keep[:]
 
 
 class BackboneTrainFunction(torch.autograd.Function):

@@ -587,17 +587,15 @@ def test_stride2_data_gradient_per_parity_is_bit_identical_to_the_zero_inserted_
                                         ('WIDERFACE_LFD_S', (3, 100, 132))])
 def test_network_schedules_equal_the_serial_unit_schedule(name, shape):
     """train_engine.network_forward / network_backward (round 4) against the serial unit API (train_engine.forward /
-    outputs_forward / outputs_backward / backward: the launches in list order on one stream, a final launch per conv), in its
-    three forms:
-      per-level, one stream   weight gradients into private partial buffers + ONE batched final launch, private per-level rows
-                              for the small shared gradients: outputs, BatchNorm statistics bit for bit; parameter gradients
-                              equal up to the ONE rounding the batched final saves per shared parameter (<= 1e-6 of the tensor's
-                              largest entry);
-      per-level, streams      (PARALLEL: levels and weight gradients on their own streams) every gradient bit for bit equal to
-                              the one-stream form, also on a second run (persistent buffers re-used);
+    outputs_forward / outputs_backward / backward: the launches in list order, a final launch per conv), in both forms:
+      level by level          weight gradients into private partial buffers + ONE batched final launch: outputs and BatchNorm
+                              statistics bit for bit; parameter gradients equal up to the ONE rounding the batched final saves
+                              per shared parameter (<= 1e-6 of the tensor's largest entry); a second run (persistent buffers
+                              re-used) bit for bit equal to the first;
       level-concatenated      (CONCAT_HEAD, the default: shared towers once over all levels) the same network up to the order
                               of GroupNorm's partial sums (another block partition of a level's pixels): outputs within 2e-3
-                              of the logit scale, gradients cos > 0.9999 and norm within 0.2 % per parameter."""
+                              of the logit scale, gradients cos > 0.9999 and norm within 0.2 % per parameter (measured: cos
+                              1.000000, norm 7e-8)."""
     import copy
     from lfd_amd import configs, train_engine
     torch.manual_seed(3)
@@ -618,22 +616,22 @@ def test_network_schedules_equal_the_serial_unit_schedule(name, shape):
         train_engine.backward(units, saved, grads, store=store)
         return m, cls, reg, wc, wr, {k: store.get(p) for k, p in m.named_parameters()}
 
-    def node(parallel, concat):
+    def node(concat):
         m = copy.deepcopy(m0)
-        keep = train_engine.PARALLEL, train_engine.CONCAT_HEAD
-        train_engine.PARALLEL, train_engine.CONCAT_HEAD = parallel, concat
+        keep = train_engine.CONCAT_HEAD
+        train_engine.CONCAT_HEAD = concat
         try:
             cls, reg = m(x)
             torch.autograd.backward([cls, reg], [wc, wr])
             torch.cuda.synchronize()
         finally:
-            train_engine.PARALLEL, train_engine.CONCAT_HEAD = keep
+            train_engine.CONCAT_HEAD = keep
         return m, cls.detach(), reg.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
 
     ms, cls_s, reg_s, wc, wr, gs = serial()
-    res = {}
-    for key in ((False, False), (True, False), (True, False)):          # twice with streams: the persistent buffers are re-used
-        mp, cls_p, reg_p, gp = node(*key)
+    res = []
+    for rep in range(2):                                   # twice: the persistent partial buffers are re-used
+        mp, cls_p, reg_p, gp = node(False)
         assert torch.equal(cls_p, cls_s) and torch.equal(reg_p, reg_s)
         for (k, a), b in zip(ms.state_dict().items(), mp.state_dict().values()):
             assert torch.equal(a, b), k                    # BatchNorm running statistics, num_batches_tracked
@@ -643,13 +641,12 @@ def test_network_schedules_equal_the_serial_unit_schedule(name, shape):
             e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-20))
             worst = max(worst, e)
             assert e <= 1e-6, (k, e)
-        res.setdefault(key, []).append(gp)
-        print('%s PARALLEL=%s: worst relative gradient difference to the serial schedule %.2e' % (name, key[0], worst))
+        res.append(gp)
+        print('%s level by level: worst relative gradient difference to the serial schedule %.2e' % (name, worst))
     for k in gs:
-        assert torch.equal(res[(True, False)][0][k], res[(False, False)][0][k]), k
-        assert torch.equal(res[(True, False)][0][k], res[(True, False)][1][k]), k
+        assert torch.equal(res[0][k], res[1][k]), k
     # the level-concatenated form
-    mc, cls_c, reg_c, gc = node(False, True)
+    mc, cls_c, reg_c, gc = node(True)
     assert mc.__dict__.get('_lfd_concat_layout') is not None
     lim = 2e-3 * float(cls_s.abs().max().clamp_min(1.0))
     assert float((cls_c - cls_s).abs().max()) <= lim and float((reg_c - reg_s).abs().max()) <= lim

@@ -64,11 +64,11 @@ if __name__ == '__main__':
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--modes', default='hip,torch')
-    ap.add_argument('--parallel', type=int, default=-1, help='train_engine.PARALLEL: 1 = pyramid levels / weight gradients on their '
-                    'own streams, 0 = every launch on the caller\'s stream (default: the module\'s setting)')
+    ap.add_argument('--concat', type=int, default=-1, help='train_engine.CONCAT_HEAD: 1 = shared head towers once over all pyramid '
+                    'levels, 0 = level by level (default: the module\'s setting)')
     a = ap.parse_args()
-    if a.parallel >= 0:
+    if a.concat >= 0:
         from lfd_amd import train_engine
-        train_engine.PARALLEL = bool(a.parallel)
+        train_engine.CONCAT_HEAD = bool(a.concat)
     for md in a.modes.split(','):
         run(md, a)
