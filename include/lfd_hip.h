@@ -694,6 +694,14 @@ LFD_API int lfd_stem_conv0_train_fwd_bn_stats(const float* x_nchw, int32_t n, in
                                       lfd_stream_t stream);
 LFD_API int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t h, int32_t w, int32_t channels,
                          float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dw, lfd_stream_t stream);
+/* The backward of the FIRST conv unit (Conv2d(3, 64, 3, 2, 1, bias=False) -> train-mode BatchNorm2d -> ReLU, lfd_resnet.py:358-366)
+ * without materialising dL/dy: BatchNorm's sums (dgamma, dbeta +=) and the conv's weight gradient computed straight from dz = dL/dz
+ * of the unit's output and its stored pre-norm output y -- the unit has no data gradient, so its dy has no other consumer.  The
+ * values are those of lfd_bn_train_bwd_f16 (ReLU mask recomputed from y) followed by lfd_stem_conv0_wgrad, bit for bit. */
+LFD_API int lfd_stem_conv0_bn_bwd_wgrad(const float* x_nchw, const void* dz, const void* y, int32_t n, int32_t h, int32_t w,
+                                int32_t channels, const float* stats, const float* gamma, const float* beta, float inv_scale,
+                                int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, float* dw,
+                                lfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neck + head of ALL pyramid levels.  Replaces SimpleNeck.forward (simple_neck.py:67-74),

@@ -901,9 +901,24 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
 }
 
 // partial[block][co 64][t 32]
+// BN (round 4): `dy` is dL/dz of the first unit -- the gradient w.r.t. the OUTPUT of its BatchNorm + ReLU -- and the kernel applies
+// BatchNorm's backward to every 16-byte chunk on its way into LDS (the arithmetic of k_bn_bwd_apply, bit for bit: mask recomputed
+// from y, dy = a (g - mean(g) - xhat mean(g xhat)) rounded to fp16).  The first conv has no data gradient, so its dy has exactly
+// this one consumer: the separate apply pass (read dz + y, write dy: 1.26 GB at 32 x 640 x 640, 245 us) and this kernel's read of
+// dy disappear, for one more tensor read here.
+struct Conv0BnArgs {
+  const __half* y;          // pre-norm output of the first conv
+  const float* stats;       // [2][c] mean, rstd
+  const float* gamma;
+  const float* beta;
+  const float* sums;        // [2][c] sum g, sum g * xhat (k_bn_bwd_final)
+  float inv_m;
+};
+
+template <bool BN>
 __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __restrict__ x,
                                                               const __half* __restrict__ dy, int n, int h, int w,
-                                                              int c, float* partials) {
+                                                              int c, float* partials, Conv0BnArgs bn) {
   // FOUR k-steps (16-pixel segments) per wave and loop trip, visited in the order s, s + S, s + 2 S, s + 3 S of the rolled loop (the
   // same sums, bit for bit): all their loads -- 8 x 16 B of dy and 32 gathered floats per lane -- are requested before the first LDS
   // write.  One k-step per trip was a chain load -> LDS -> transposing read -> 2 MFMAs with one round trip to HBM each: 265 us for
@@ -926,9 +941,27 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
   const int i16 = l & 15, grp = (l >> 4) & 1;
   uint32_t a_off[2];
   for (int r = 0; r < 2; ++r) a_off[r] = (8 * hk + 4 * r + (i16 >> 2)) * 144 + (16 * grp + 4 * (i16 & 3)) * 2;
+  // BN: per-channel constants of this lane's 16-byte chunk (chunk l & 7 in both of its loads: 64 k does not change the low bits)
+  float p_mean[8], p_rstd[8], p_a[8], p_mg[8], p_mgx[8], p_ga[8], p_be[8];
+  if constexpr (BN) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = (l & 7) * 8 + e;
+      const bool cv = ch < c;
+      p_mean[e] = cv ? bn.stats[ch] : 0.f;
+      p_rstd[e] = cv ? bn.stats[c + ch] : 0.f;
+      p_ga[e] = cv ? bn.gamma[ch] : 0.f;
+      p_be[e] = cv ? bn.beta[ch] : 0.f;
+      p_a[e] = p_ga[e] * p_rstd[e];
+      p_mg[e] = cv ? bn.sums[ch] * bn.inv_m : 0.f;
+      p_mgx[e] = cv ? bn.sums[c + ch] * bn.inv_m : 0.f;
+    }
+  }
   const int64_t S = (int64_t)gridDim.x * 4;
   for (int64_t s0 = (int64_t)blockIdx.x * 4 + wave; s0 < total; s0 += U * S) {
     uint4 dv[U][2];
+    uint4 yv[BN ? U : 1][2];
+    bool okd[BN ? U : 1][2];
     float raw[U][8];
     bool okj[U][8];
 #pragma unroll
@@ -947,8 +980,11 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
         const int i = l + 64 * k;
         const int px = i >> 3, c8 = i & 7;
         const bool in = sv && ox0 + px < wo && c8 * 8 < c;
-        dv[u][k] = *reinterpret_cast<const uint4*>(in ? dy + (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8 : dy);
-        if (!in) dv[u][k] = make_uint4(0, 0, 0, 0);
+        const int64_t eo = in ? (((int64_t)img * ho + oy) * wo + ox0 + px) * c + c8 * 8 : 0;
+        dv[u][k] = *reinterpret_cast<const uint4*>(dy + eo);
+        if constexpr (BN) yv[u][k] = *reinterpret_cast<const uint4*>(bn.y + eo);
+        if (!in) dv[u][k] = make_uint4(0, 0, 0, 0);      // (g = 0 and, BN: the chunk is zeroed again after the transform)
+        if constexpr (BN) okd[u][k] = in;
       }
       // B: patch[ox0 + 8hk + j][t], j = 0..7
       const int iy = 2 * oy + ky - 1;
@@ -959,6 +995,23 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
         okj[u][j] = sv && tkyx >= 0 && ox < wo && iy >= 0 && iy < h && ix >= 0 && ix < w;
         raw[u][j] = *(okj[u][j] ? xr + 2 * ox : x);      // unconditional load + select (see k_conv0_fwd_mfma)
       }
+    }
+    if constexpr (BN) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          union { uint4 q; _Float16 hh[8]; } d, yy, o;
+          d.q = dv[u][k]; yy.q = yv[u][k];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float g = (float)d.hh[e];
+            const float xh = ((float)yy.hh[e] - p_mean[e]) * p_rstd[e];
+            if (!(p_ga[e] * xh + p_be[e] > 0.f)) g = 0.f;
+            o.hh[e] = (_Float16)(p_a[e] * (g - p_mg[e] - xh * p_mgx[e]));
+          }
+          dv[u][k] = okd[u][k] ? o.q : make_uint4(0, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1746,8 +1799,8 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
   if (!use_valu) {
     const int64_t ksteps = (int64_t)n * ((h + 1) / 2) * (((w + 1) / 2 + 15) / 16);
     const int nb = (int)(ksteps / 4 < 1 ? 1 : (ksteps / 4 > 1024 ? 1024 : ksteps / 4));
-    hipLaunchKernelGGL(k_conv0_wgrad_mfma, dim3(nb), dim3(kThreads), 0, st, x_nchw, (const __half*)dy, n, h, w, channels,
-                       partials);
+    hipLaunchKernelGGL(k_conv0_wgrad_mfma<false>, dim3(nb), dim3(kThreads), 0, st, x_nchw, (const __half*)dy, n, h, w, channels,
+                       partials, Conv0BnArgs{});
     LFD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sum_partials, dim3(2048), dim3(64), 0, st, partials, nb, 2048, inv_scale, 2, channels, 27,
                        accumulate, dw);
@@ -1765,6 +1818,38 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
   const int count = 27 * channels;
   hipLaunchKernelGGL(k_sum_partials, dim3(count), dim3(64), 0, st, partials, blocks,
                      count, inv_scale, 1, channels, 27, accumulate, dw);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+// BatchNorm backward of the FIRST unit without its apply pass (round 4): the sums (k_bn_bwd_partial + k_bn_bwd_final: dgamma, dbeta,
+// and the two per-channel sums in the workspace) and then the first conv's weight gradient straight from dz and y
+// (k_conv0_wgrad_mfma<true>) -- the unit has no data gradient, so nobody else needs its dy.
+int lfd_stem_conv0_bn_bwd_wgrad(const float* x_nchw, const void* dz, const void* y, int32_t n, int32_t h, int32_t w, int32_t channels,
+                                const float* stats, const float* gamma, const float* beta, float inv_scale, int32_t accumulate,
+                                void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, float* dw, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!x_nchw || !dz || !y || !stats || !gamma || !beta || !dw || !workspace || n < 1 || h < 1 || w < 1 || channels != 64)
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int64_t pixels = (int64_t)n * ho * wo, vecs = pixels * (channels / 8);
+  const unsigned g = grid_for_vecs(vecs);
+  float* partials = reinterpret_cast<float*>(workspace);
+  float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
+  float* wpart = sums + 2 * kMaxC;                      // the weight gradient's own partial rows: [<= 1024][2048]
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y, (const __half*)nullptr,
+                     vecs, channels, stats, gamma, beta, 1, partials, RowMap{});
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
+                     dgamma, dbeta);
+  LFD_CHECK_LAUNCH();
+  const int64_t ksteps = (int64_t)n * ho * ((wo + 15) / 16);
+  const int nb = (int)(ksteps / 4 < 1 ? 1 : (ksteps / 4 > 1024 ? 1024 : ksteps / 4));
+  Conv0BnArgs bn{(const __half*)y, stats, gamma, beta, sums, (float)(1.0 / (double)pixels)};
+  hipLaunchKernelGGL(k_conv0_wgrad_mfma<true>, dim3(nb), dim3(kThreads), 0, st, x_nchw, (const __half*)dz, n, h, w, channels, wpart, bn);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sum_partials, dim3(2048), dim3(64), 0, st, wpart, nb, 2048, inv_scale, 2, channels, 27, accumulate, dw);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

@@ -194,6 +194,7 @@ _SIGNATURES = {
     'lfd_head_out_grad_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),
     'lfd_stem_conv0_train_fwd_bn_stats': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_wgrad': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
+    'lfd_stem_conv0_bn_bwd_wgrad': (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),

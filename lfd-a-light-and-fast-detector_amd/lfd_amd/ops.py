@@ -1138,6 +1138,20 @@ def stem_conv0_train_fwd_bn_stats(x_nchw, weight, eps, momentum, running_mean=No
     return y, stats
 
 
+def stem_conv0_bn_bwd_wgrad(x_nchw, dz, y, stats, gamma, beta, inv_scale, dgamma, dbeta, dw):
+    """backward of the first conv unit (conv 3 -> 64 + train-mode BatchNorm + ReLU) from dz = dL/d(output): dgamma / dbeta / dw += ;
+    no dy tensor (lfd_stem_conv0_bn_bwd_wgrad)"""
+    require_cuda(x_nchw, 'stem_conv0_bn_bwd_wgrad')
+    x = x_nchw.contiguous().float()
+    n, _, h, w_ = x.shape
+    c = y.size(3)
+    ws = train_workspace(x.device)
+    with torch.cuda.device(x.device):
+        check(lib().lfd_stem_conv0_bn_bwd_wgrad(ptr(x), ptr(dz), ptr(y), n, h, w_, c, ptr(stats), ptr(gamma), ptr(beta), float(inv_scale), 1,
+                                                ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta), ptr(dw), stream_ptr()),
+              'lfd_stem_conv0_bn_bwd_wgrad')
+
+
 def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None, accumulate=False):
     x = x_nchw.contiguous().float()
     n, _, h, w_ = x.shape

@@ -923,6 +923,12 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         y, stats = tape[ui]
         z = acts[u.dst] if u.relu else None
         g = None
+        if (u.first and isinstance(norm, nn.BatchNorm2d) and u.relu and u.res is None and conv.out_channels == 64
+                and os.environ.get('LFD_CONV0_BN_WGRAD', '1') == '1'):
+            # the first unit has no data gradient: BatchNorm's sums, then the weight gradient straight from dz and y (no dy tensor)
+            ops.stem_conv0_bn_bwd_wgrad(acts[u.src], dz, y, stats, norm.weight.detach(), norm.bias.detach(), inv,
+                                        store.target(norm.weight), store.target(norm.bias), store.target(conv.weight))
+            continue
         if isinstance(norm, nn.GroupNorm):
             dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, store.target(norm.weight),
                                        store.target(norm.bias), True)

@@ -664,3 +664,27 @@ def test_network_schedules_equal_the_serial_unit_schedule(name, shape):
         if 'running_' in k:
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=k)
     print('%s level-concatenated: worst gradient cosine %.6f, worst norm deviation %.2e' % (name, worst_cos, worst_norm))
+
+
+@pytest.mark.parametrize('nhw', [(2, 70, 94), (3, 128, 160)])
+def test_first_unit_backward_without_a_dy_tensor_is_bit_identical(nhw):
+    """lfd_stem_conv0_bn_bwd_wgrad (round 4): BatchNorm's sums and the first conv's weight gradient straight from dz and y -- the
+    unit has no data gradient, so the apply pass that would write dy is folded into the weight gradient's loader -- against
+    lfd_bn_train_bwd_f16 + lfd_stem_conv0_wgrad: dgamma, dbeta and dW bit for bit (the same arithmetic in the same order)."""
+    n, h, w = nhw
+    c = 64
+    g = torch.Generator(device='cuda').manual_seed(21)
+    x = torch.randn(n, 3, h, w, generator=g, device='cuda')
+    wt = torch.randn(c, 3, 3, 3, generator=g, device='cuda') * 0.2
+    gamma = torch.empty(c, device='cuda').uniform_(0.5, 1.5)
+    beta = torch.empty(c, device='cuda').normal_(0, 0.3)
+    y, stats = ops.stem_conv0_train_fwd_bn_stats(x, wt, 1e-5, 0.1)
+    dz = (torch.randn(y.shape, generator=g, device='cuda') * 0.5).half()
+    inv = 1.0 / 64
+    dga, dba, dwa = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), torch.zeros_like(wt)
+    dy, _ = ops.bn_train_backward(dz, y, None, stats, gamma, inv, dga, dba, want_g=False, accumulate=True, relu=True, beta=beta)
+    ops.stem_conv0_wgrad(x, dy, inv, out=dwa, accumulate=True)
+    dgb, dbb, dwb = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), torch.zeros_like(wt)
+    ops.stem_conv0_bn_bwd_wgrad(x, dz, y, stats, gamma, beta, inv, dgb, dbb, dwb)
+    assert torch.equal(dga, dgb) and torch.equal(dba, dbb)
+    assert float(dwa.abs().max()) > 0 and torch.equal(dwa, dwb)
