@@ -106,6 +106,17 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             add('downblock_fused_conv3x3_s2+1x1_s2+conv3x3_s1_64to64 (k_down64)', us, fl, (src.numel() + dst2.numel()) * 2)
             skip = c.down
             continue
+        if c.blk128 is not None and engine._use_fused_block128(n, src.shape[1], src.shape[2]):
+            # a 128-channel block of the last stage in one launch (csrc/block128.hip); algorithmic bytes = the map read once +
+            # written once + both filters once
+            c2 = plan.convs[c.blk128]
+            dst2 = st.bufs[c2.dst]
+            us = timed(lambda: check(l.lfd_fasterblock128_fused_f16(n, src.shape[1], src.shape[2], ptr(src), ptr(dst2), ptr(c.w), ptr(c.b),
+                                                                    ptr(c2.w), ptr(c2.b), stream_ptr()), 'block128'))
+            add('fasterblock128_fused_2x_conv3x3_s1_128to128 small map (k_block128)', us,
+                2 * conv_flops(n, dst2.shape[1], dst2.shape[2], 128, 128, 3), (src.numel() + dst2.numel()) * 2 + 2 * 128 * 128 * 9 * 2)
+            skip = c.blk128
+            continue
         d = _lib.ConvDesc(n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                           c.cout if c.tail else 0, 1 if c.tail else 0)
         if c.blk is not None:

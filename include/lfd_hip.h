@@ -402,6 +402,16 @@ LFD_API int lfd_fasterblock_fused_f16(int32_t n, int32_t h, int32_t w, const voi
                                       const float* b1, const void* w2_packed, const float* b2, const void* zeros,
                                       lfd_stream_t stream);
 
+/* The same block at 128 channels on the SMALL maps of the last backbone stage (17 x 30 at 1080p; WIDERFACE_LFD_S.py:97-146,
+ * lfd_resnet.py:96-154) in ONE launch:   out = relu( conv3x3(relu(conv3x3(in, w1) + b1), w2) + b2 + in ),  128 -> 128 -> 128,
+ * NHWC fp16 [n, h, w, 128].  A workgroup owns 4 x 8 output pixels and recomputes the 6 x 10 halo of the intermediate map in
+ * LDS; both filters are streamed from L2 per workgroup, so this form is for maps of a few thousand pixels per launch (the
+ * caller decides; csrc/block128.hip).  Results are bit-identical to two lfd_conv2d_nhwc_f16 launches on their split-K path
+ * (n * h * w <= 16384).  w1_packed / w2_packed: lfd_conv_packed_weight_halfs(128, 128, 3) halfs each; `in` must not alias
+ * `out`; all pointers 16-byte aligned. */
+LFD_API int lfd_fasterblock128_fused_f16(int32_t n, int32_t h, int32_t w, const void* in, void* out, const void* w1_packed,
+                                         const float* b1, const void* w2_packed, const float* b2, lfd_stream_t stream);
+
 /* The FIRST block of a backbone stage -- the FasterBlock with a downsample branch (lfd_resnet.py:96-154, branch :458-468) --
  * in ONE launch:   y1 = relu(conv3x3_s2(in, w1) + b1);  ident = conv1x1_s2(in, wd) + bd;
  *                  out = relu(conv3x3_s1(y1, w2) + b2 + ident),      64 -> 64 channels, BN folded, NHWC fp16,

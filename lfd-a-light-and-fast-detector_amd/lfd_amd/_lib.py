@@ -207,6 +207,7 @@ _SIGNATURES = {
     'lfd_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_conv2d_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_fasterblock_fused_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_fasterblock128_fused_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_downblock_fused_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_conv2d_nhwc_f16_acc32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'lfd_p32_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),

@@ -138,9 +138,19 @@ def _use_fused_down(n, h, w):
     return n * h * w >= 50000 and (n >= 2 or h * w >= 400000)
 
 
+def _use_fused_block128(n, h, w):
+    """LFD_FUSED_BLOCK128: '0' never; otherwise wherever the block's two launches would run the split-K kernel (n * h * w <=
+    16384 pixels: the fused launch is bit-identical to that pair).  Per shape (tools/timing/block128_in_graph.py, one block in
+    a graphed chain): 1 x 17 x 30: 9.4 vs 10.8 us, 8 x 17 x 30: 10.4 vs 13.5, 8 x 12 x 20: 9.8 vs 10.5, 1 x 34 x 60: 9.7 vs 11.1,
+    16 x 23 x 40: 22.7 vs 31.1"""
+    if os.environ.get('LFD_FUSED_BLOCK128', '') == '0':
+        return False
+    return n * h * w <= 16384
+
+
 class _Conv(object):
     """one lfd_conv2d_nhwc_f16 launch"""
-    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w', 'blk', 'down')
+    __slots__ = ('cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'src', 'dst', 'res', 'ds', 'ref_w', 'blk', 'down', 'blk128')
 
 
 class _HeadLevel(object):
@@ -294,6 +304,14 @@ class EnginePlan(object):
                         # launches stay in the plan; run_backbone picks per shape (the fused kernel wins on the larger maps)
                         self.convs[-2].down = len(self.convs) - 1
                     ci += 2 if tail is not None else 1
+                if (blk._downsample is None and nconv == 2 and len(self.convs) >= 2 and
+                        all(c_.cin == 128 and c_.cout == 128 and c_.ks == 3 and c_.stride == 1 and c_.tail is None and c_.ds is None
+                            and c_.relu for c_ in self.convs[-2:])
+                        and self.convs[-2].src == x_in and self.convs[-2].res is None and self.convs[-1].src == self.convs[-2].dst
+                        and self.convs[-1].res == x_in and self.convs[-1].dst == y):
+                    # a 128-channel block without branch: ONE launch on small maps (csrc/block128.hip); both launches stay in
+                    # the plan, run_backbone picks per shape
+                    self.convs[-2].blk128 = len(self.convs) - 1
                 cur = y
                 if (i, j) in [tuple(t) for t in bb._out_indices]:
                     self.taps.append(cur)
@@ -311,6 +329,7 @@ class EnginePlan(object):
         c.tail = tail
         c.ds = ds
         c.down = None        # index of the conv that closes this (downsample) block when the pair can run fused
+        c.blk128 = None      # index of the conv that closes this 128-channel block without branch when the pair can run fused
         c.src = src
         c.dst = new_buf()
         c.res = res
@@ -459,6 +478,12 @@ class EnginePlan(object):
             if c.blk is not None:
                 check(l.lfd_fasterblock_fused_f16(st.n, src.shape[1], src.shape[2], ptr(src), ptr(st.bufs[c.dst]), ptr(c.w), ptr(c.b),
                                                   ptr(c.blk[0]), ptr(c.blk[1]), ptr(z), sp), 'lfd_fasterblock_fused_f16')
+                continue
+            if c.blk128 is not None and _use_fused_block128(st.n, src.shape[1], src.shape[2]):
+                c2 = self.convs[c.blk128]
+                check(l.lfd_fasterblock128_fused_f16(st.n, src.shape[1], src.shape[2], ptr(src), ptr(st.bufs[c2.dst]), ptr(c.w), ptr(c.b),
+                                                     ptr(c2.w), ptr(c2.b), sp), 'lfd_fasterblock128_fused_f16')
+                skip = c.blk128
                 continue
             d = _lib.ConvDesc(st.n, src.shape[1], src.shape[2], c.cin, c.cout, c.ks, c.stride, int(c.relu),
                               c.cout if c.tail else 0, 1 if c.tail else 0)

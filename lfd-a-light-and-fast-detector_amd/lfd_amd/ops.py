@@ -623,6 +623,21 @@ def fasterblock_fused(x, w1_packed, b1, w2_packed, b2, out=None):
     return out
 
 
+def fasterblock128_fused(x, w1_packed, b1, w2_packed, b2, out=None):
+    """relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2 + x) for NHWC fp16 [N,H,W,128] on the small maps of the last backbone
+    stage in one launch (csrc/block128.hip); bit-identical to two conv2d_nhwc launches on their split-K path."""
+    require_cuda(x, 'fasterblock128_fused')
+    if x.dtype != torch.float16 or not x.is_contiguous() or x.dim() != 4 or x.shape[3] != 128:
+        raise RuntimeError('fasterblock128_fused: x must be contiguous fp16 NHWC with 128 channels')
+    n, h, w_, _ = x.shape
+    with torch.cuda.device(x.device):
+        if out is None:
+            out = torch.empty_like(x)
+        check(lib().lfd_fasterblock128_fused_f16(n, h, w_, ptr(x), ptr(out), ptr(w1_packed), ptr(b1), ptr(w2_packed), ptr(b2),
+                                                 stream_ptr()), 'lfd_fasterblock128_fused_f16')
+    return out
+
+
 def conv2d_downsample_nhwc(x, w_packed, bias, wd_packed, bd, relu=True):
     """(relu(conv3x3 stride 2 (x) + bias), conv1x1 stride 2 (x) + bd) for NHWC fp16 [N,H,W,64]: the first launch of a
     stage's first block with its identity branch riding on the centre tap (lfd_conv2d_downsample_nhwc_f16)."""

@@ -71,6 +71,7 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert l.lfd_head_forward_decode_f16(None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert l.lfd_groupnorm_finalize_fold(None, None, None, None, 1e-5, None, None, 1, None) == -1
     assert l.lfd_fasterblock_fused_f16(0, 8, 8, None, None, None, None, None, None, None, None) == -1
+    assert l.lfd_fasterblock128_fused_f16(1, 8, 8, None, None, None, None, None, None, None) == -1
     assert l.lfd_downblock_fused_f16(1, 8, 8, None, None, None, None, None, None, None, None, None, None) == -1
     assert l.lfd_downblock_fused_f16(0, 8, 8, C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0), C.byref(one0),
                                      C.byref(one0), C.byref(one0), C.byref(one0), None) == -1       # n < 1

@@ -101,3 +101,74 @@ def test_engine_with_and_without_block_fusion_agree(monkeypatch):
         with torch.no_grad():
             outs.append([t.clone() for t in m.forward_resident(x)])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ---------------------------------------------------------------- 128 channels, small maps (csrc/block128.hip)
+def _operands128(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, h, w, 128, generator=g) * 0.5).half()
+    w1 = (torch.randn(128, 128, 3, 3, generator=g) / 34).half().float()
+    w2 = (torch.randn(128, 128, 3, 3, generator=g) / 34).half().float()
+    b1 = torch.randn(128, generator=g) * 0.1
+    b2 = torch.randn(128, generator=g) * 0.1
+    return x, w1, b1, w2, b2
+
+
+def _both128(x, w1, b1, w2, b2):
+    xc = x.cuda()
+    p1, p2 = ops.pack_conv_weight(w1).cuda(), ops.pack_conv_weight(w2).cuda()
+    mid = ops.conv2d_nhwc(xc, p1, b1.cuda(), 128, 128, 3, 1, True)
+    two = ops.conv2d_nhwc(mid, p2, b2.cuda(), 128, 128, 3, 1, True, residual=xc)
+    one = ops.fasterblock128_fused(xc, p1, b1.cuda(), p2, b2.cuda())
+    torch.cuda.synchronize()
+    return one, two, mid
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (1, 2, 3), (3, 5, 7), (1, 4, 8), (1, 5, 9), (2, 8, 16), (1, 7, 15), (1, 17, 30), (8, 17, 30),
+                                   (8, 12, 20), (1, 34, 60), (16, 23, 40)])
+def test_fused_block128_is_bit_identical_to_two_launches(shape):
+    """the two launches run the split-K kernel (n * h * w <= 16384): same quarters of K, added in the same order"""
+    one, two, _ = _both128(*_operands128(*shape, seed=sum(shape)))
+    assert torch.isfinite(one.float()).all()
+    bad = (one != two)
+    assert not bool(bad.any()), 'mismatches: %d of %d, first at %s' % (int(bad.sum()), bad.numel(), bad.nonzero()[0].tolist())
+
+
+def test_fused_block128_against_float64():
+    x, w1, b1, w2, b2 = _operands128(2, 17, 30, seed=5)
+    one, _, _ = _both128(x, w1, b1, w2, b2)
+    xd = x.double().permute(0, 3, 1, 2)
+    mid = F.relu(F.conv2d(xd, w1.double(), b1.double(), padding=1)).half().double()
+    ref = F.relu(F.conv2d(mid, w2.double(), b2.double(), padding=1) + xd).permute(0, 2, 3, 1)
+    err = (one.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def test_fused_block128_rejects_bad_arguments():
+    w = torch.zeros(4 * 72 * 64 * 8, dtype=torch.float16).cuda()
+    b = torch.zeros(128).cuda()
+    x = torch.zeros(1, 8, 8, 128, dtype=torch.float16).cuda()
+    with pytest.raises(RuntimeError):
+        ops.fasterblock128_fused(x, w, b, w, b, out=x)
+    with pytest.raises(RuntimeError):
+        ops.fasterblock128_fused(torch.zeros(1, 8, 8, 64, dtype=torch.float16).cuda(), w, b, w, b)
+
+
+@pytest.mark.parametrize('shape', [(2, 200, 312), (8, 1080, 1920)])
+def test_engine_with_and_without_block128_fusion_agree(monkeypatch, shape):
+    """whole network: LFD_FUSED_BLOCK128=0 (two split-K launches per 128-channel block) and the default (one launch) give
+    identical logits, at a small shape and at the headline batch"""
+    from lfd_amd import configs, engine
+    outs = []
+    x = (torch.rand(shape[0], shape[1], shape[2], 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).half().cuda()
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LFD_FUSED_BLOCK128', flag)
+        assert engine._use_fused_block128(8, 17, 30) == (flag == '1')
+        m = configs.build_model('WIDERFACE_LFD_S')
+        configs.perturb_weights(m)
+        m.eval().cuda()
+        with torch.no_grad():
+            outs.append([t.clone() for t in m.forward_resident(x)])
+        del m
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -217,6 +217,19 @@ def test_every_backbone_launch_rederived_from_the_stored_tensors(key):
                     st.bufs[c2.dst][img:img + 1].cpu(), ref, mag, flips=flips, min_exact=0.9)
             skip = c.down
             continue
+        if c.blk128 is not None and engine._use_fused_block128(n, xin.shape[2], xin.shape[3]):
+            # a 128-channel block of the last stage ran as ONE launch (csrc/block128.hip): conv3x3 -> ReLU -> fp16 (LDS only),
+            # conv3x3 + input -> ReLU
+            c2 = plan.convs[c.blk128]
+            y1 = F.conv2d(xin, w64, b64, padding=1).relu().float().half().double()
+            w2, b2 = c2.ref_w.cpu().half().double(), c2.b.cpu().double()
+            ref = (F.conv2d(y1, w2, b2, padding=1) + xin).relu()
+            mag = conv_mag(y1, w2, b2, padding=1) + xin.abs()
+            flips = 4 * 2.0 ** -11 * float(y1.abs().max()) * float(w2.abs().max())
+            compare('block 2 x conv3x3 s1 128->128 @%dx%d' % (ref.shape[2], ref.shape[3]),
+                    st.bufs[c2.dst][img:img + 1].cpu(), ref, mag, flips=flips, min_exact=0.9)
+            skip = c.blk128
+            continue
         ref = F.conv2d(xin, w64, b64, stride=c.stride, padding=c.ks // 2)
         mag = conv_mag(xin, w64, b64, stride=c.stride, padding=c.ks // 2)
         flips = 0.0

@@ -139,6 +139,11 @@ def test_engine_plan_structure_on_cpu():
                                      and plan.convs[i + 1].res == plan.convs[i].ds[2] and plan.convs[i + 1].ks == 3 for i in marked)
     assert engine._use_fused_down(8, 270, 480) and engine._use_fused_down(8, 68, 120) and engine._use_fused_down(1, 540, 960)
     assert not engine._use_fused_down(1, 270, 480) and not engine._use_fused_down(8, 34, 60)
+    # the two 128-channel blocks without branch of the last stage can run as ONE launch each on small maps (csrc/block128.hip)
+    m128 = [i for i, c in enumerate(plan.convs) if c.blk128 is not None]
+    assert len(m128) == 2 and all(plan.convs[i].blk128 == i + 1 and plan.convs[i + 1].res == plan.convs[i].src
+                                   and plan.convs[i + 1].src == plan.convs[i].dst and plan.convs[i].cin == 128 for i in m128)
+    assert engine._use_fused_block128(8, 17, 30) and engine._use_fused_block128(1, 34, 60) and not engine._use_fused_block128(64, 17, 30)
     assert len(plan.taps) == 5 and len(plan.levels) == 5
     assert [lv.cin for lv in plan.levels] == [64, 64, 64, 128, 128]
     assert all(len(lv.towers) == 1 and lv.towers[0].reg_rows == 4 and lv.towers[0].cls_rows == 1 for lv in plan.levels)
