@@ -561,6 +561,17 @@ LFD_API int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* i
                                  const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
                                  float* running_var, void* workspace, size_t workspace_bytes, float* stats,
                                  lfd_stream_t stream);
+/* A 1x1 stride-1 conv unit whose INPUT is the activation of a train-mode BatchNorm + ReLU unit WITHOUT a residual
+ * (lfd_resnet.py:376-413: the second conv of each stem pair): `y_in` is that unit's PRE-normalisation conv output and
+ * (in_stats, in_gamma, in_beta) its batch statistics (lfd_bn_train_stats_f16 layout) and affine; the kernel normalises +
+ * ReLUs its activation fragments on their way into the MFMA with lfd_bn_train_apply_f16's arithmetic (bit-identical to
+ * applying first), so the producer's z tensor is never written or read.  Everything else as lfd_conv2d_bn_stats_nhwc_f16;
+ * d->cin must be 64, d->ks = d->stride = 1.  The matching weight gradient: lfd_conv1x1_wgrad_partials_of_bn_relu_f16. */
+LFD_API int lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* y_in, const float* in_stats,
+                                             const float* in_gamma, const float* in_beta, void* out, const void* w_packed,
+                                             const float* bias, const void* zeros, float eps, float momentum,
+                                             float* running_mean, float* running_var, void* workspace,
+                                             size_t workspace_bytes, float* stats, lfd_stream_t stream);
 /* z = relu?( gamma * (y - mean) * rstd + beta (+ residual) ) */
 LFD_API int lfd_bn_train_apply_f16(const void* y, int64_t pixels, int32_t channels, const float* stats, const float* gamma,
                            const float* beta, const void* residual, int32_t relu, void* z, lfd_stream_t stream);
@@ -650,6 +661,12 @@ LFD_API int32_t lfd_conv_wgrad_partial_rows(int32_t n, int32_t h, int32_t w, int
 LFD_API int lfd_conv_wgrad_partials_nhwc_f16(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin,
                                              int32_t cout, int32_t ks, int32_t stride, float* partials, size_t partials_bytes,
                                              lfd_stream_t stream);
+/* lfd_conv_wgrad_partials_nhwc_f16 for a 1x1 stride-1 conv whose operand x = relu(BatchNorm(y_in)) was never stored (see
+ * lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16): the tile loader re-forms it from y_in.  Same partial rows / final pass. */
+LFD_API int lfd_conv1x1_wgrad_partials_of_bn_relu_f16(const void* y_in, const float* in_stats, const float* in_gamma,
+                                              const float* in_beta, const void* dy, int32_t n, int32_t h, int32_t w,
+                                              int32_t cin, int32_t cout, float* partials, size_t partials_bytes,
+                                              lfd_stream_t stream);
 LFD_API int lfd_wgrad_final_batched_f32(const lfd_wgrad_job_t* jobs_device, int32_t njobs, int32_t total_blocks,
                                         lfd_stream_t stream);
 /* dst[i] (+)= sum over r < nrows of src[r * row_stride + i], i < count, fp64 in row order; one block per job: the private

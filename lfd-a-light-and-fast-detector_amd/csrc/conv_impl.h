@@ -50,6 +50,11 @@ struct ConvArgs {
   int relu, relu2;
   int tiles_x, tiles_y, ntiles;
   float* stat_partials;  // STATS kernels: [gridDim.x][2][cout] per-workgroup sums of the stored outputs and of their squares
+  // PRO kernels (1x1 stride 1): `in` is the PRE-normalisation output y of the producing train-mode BatchNorm unit; the
+  // activation fragments are normalised + ReLU'd on their way from LDS into the MFMA (the unit's z tensor never exists)
+  const float* pro_stats;   // [2][CIN]: batch mean | rstd of the producer (lfd_bn_train_stats_f16 layout)
+  const float* pro_gamma;   // [CIN]
+  const float* pro_beta;    // [CIN]
 };
 
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
@@ -148,8 +153,9 @@ __device__ __forceinline__ void stats_add(uint4 v, bool ok, float (&s)[8], float
   }
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false>
 __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
+  static_assert(!PRO || (KS == 1 && S == 1 && WREG && !TAIL && !DS), "PRO: a 1x1 stride-1 conv fed by a train-mode BatchNorm + ReLU unit");
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES), "DS: the residual block's 1x1 s2 downsample rides on its 3x3 s2 conv");
   static_assert(!ACC32 || (!TAIL && !RES && !DS), "ACC32 writes the bare accumulators of ONE conv");
   static_assert(!STATS || (!TAIL && !RES && !DS && !ACC32), "STATS: the bare conv in front of a train-mode BatchNorm");
@@ -171,6 +177,35 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_conv_dbg[120] = __builtin_readcyclecounter(); g_conv_dbg[121] = __builtin_amdgcn_s_memrealtime(); }
 #endif
   const int co_base = (cog * NCT + ct) * 32;
+
+  // ---- PRO: the producer's per-channel affine for the 8 channels (16 q + 8 h .. + 7) of each of this lane's fragments,
+  //      formed exactly as k_bn_apply forms it (train.hip): a = gamma * rstd, b = beta - mean * a
+  constexpr int NQP = PRO ? CIN / 16 : 1;
+  float pro_a[NQP][8], pro_b[NQP][8];
+  if constexpr (PRO) {
+#pragma unroll
+    for (int q = 0; q < NQP; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = 16 * q + 8 * h + e;
+        pro_a[q][e] = a.pro_gamma[ch] * a.pro_stats[CIN + ch];
+        pro_b[q][e] = a.pro_beta[ch] - a.pro_stats[ch] * pro_a[q][e];
+      }
+  }
+  auto pro_apply = [&](half8 v, int q) {
+    if constexpr (PRO) {
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e] * pro_a[q][e] + pro_b[q][e];
+        f = fmaxf(f, 0.f);
+        o[e] = (_Float16)f;
+      }
+      return o;
+    } else {
+      return v;
+    }
+  };
 
   // ---- biases into LDS.  They are re-read for every tile; as global loads the compiler's wait for them
   //      (vmcnt is in-order) would also wait for the just-issued DMA prefetch of the next tile.
@@ -470,6 +505,10 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
         }
         __builtin_amdgcn_sched_barrier(0);
         const half8 wf = (k < NKR) ? wreg[k < NKR ? k : 0] : wq[k % (PD + 1)];
+        if constexpr (PRO) {      // at the USE, not at the fetch: the LDS reads stay PD k-steps ahead
+#pragma unroll
+          for (int pt = 0; pt < C::PT; ++pt) xq[k % (PD + 1)][pt] = pro_apply(xq[k % (PD + 1)][pt], k % C::NQ);
+        }
 #pragma unroll
         for (int pt = 0; pt < C::PT; ++pt)
           acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xq[k % (PD + 1)][pt], acc[pt], 0, 0, 0);
@@ -727,13 +766,13 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   CV_END();
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>(a, smem);
+  conv_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO>(a, smem);
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false>
 int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) {
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   ConvArgs a = a0;
@@ -748,7 +787,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) 
   static unsigned long long attr_done_mask = 0;
   const int attr_done_dev = lfd_device_ordinal();
   if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
@@ -759,7 +798,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) 
   if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
   if (blocks < 1) blocks = 1;
   if (blocks_out) *blocks_out = blocks;
-  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

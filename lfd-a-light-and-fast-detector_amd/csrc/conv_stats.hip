@@ -15,6 +15,10 @@ namespace {
 
 template <int CIN, int KS, int S, int NCT, bool WREG>
 int launch_stats(const ConvArgs& a, hipStream_t st, int* blocks) {
+  if constexpr (KS == 1 && S == 1 && CIN == 64) {
+    if (a.pro_stats) return launch_conv_<CIN, KS, S, NCT, WREG, false, false, false, false, true, true>(a, st, blocks);
+  }
+  if (a.pro_stats) return LFD_ERR_UNSUPPORTED;
   return launch_conv_<CIN, KS, S, NCT, WREG, false, false, false, false, true>(a, st, blocks);
 }
 
@@ -22,10 +26,11 @@ int launch_stats(const ConvArgs& a, hipStream_t st, int* blocks) {
 
 extern "C" {
 
-int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
-                                 const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
-                                 float* running_var, void* workspace, size_t workspace_bytes, float* stats,
-                                 lfd_stream_t stream) {
+static int conv_bn_stats(const lfd_conv_desc_t* d, const void* in, const float* in_stats, const float* in_gamma,
+                         const float* in_beta, void* out, const void* w_packed,
+                         const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
+                         float* running_var, void* workspace, size_t workspace_bytes, float* stats,
+                         lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d || !in || !out || !w_packed || !bias || !zeros || !workspace || !stats) return LFD_ERR_INVALID_ARGUMENT;
   if (d->n < 1 || d->h < 1 || d->w < 1 || d->tail_cout || d->relu) return LFD_ERR_INVALID_ARGUMENT;
@@ -42,6 +47,7 @@ int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void*
   a.OW = (d->w + 2 * pad - d->ks) / d->stride + 1;
   a.cout = d->cout;
   a.stat_partials = reinterpret_cast<float*>(workspace);
+  a.pro_stats = in_stats; a.pro_gamma = in_gamma; a.pro_beta = in_beta;
   const int64_t pixels = (int64_t)a.N * a.OH * a.OW;
   int blocks = 0, rc = LFD_ERR_UNSUPPORTED;
   switch (d->cin * 10000 + d->ks * 1000 + d->stride * 100 + (d->cout / 32) * 10 + (d->cout % 32 ? 1 : 0)) {
@@ -53,6 +59,7 @@ int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void*
     case 64 * 10000 + 1200 + 40: rc = launch_stats<64, 1, 2, 4, true>(a, st, &blocks); break;
     case 128 * 10000 + 1100 + 40: rc = launch_stats<128, 1, 1, 4, true>(a, st, &blocks); break;
     default: {
+      if (in_stats) return LFD_ERR_UNSUPPORTED;
       rc = lfd_conv2d_nhwc_f16(d, in, out, w_packed, bias, nullptr, nullptr, nullptr, zeros, stream);
       if (rc != LFD_OK) return rc;
       return lfd_bn_train_stats_f16(out, pixels, d->cout, eps, momentum, running_mean, running_var, workspace, workspace_bytes,
@@ -62,6 +69,24 @@ int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void*
   if (rc != LFD_OK) return rc;
   return lfd_bn_stats_final_launch(a.stat_partials, blocks, d->cout, (double)pixels, eps, momentum, running_mean, running_var,
                                    stats, st);
+}
+
+int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed,
+                                 const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
+                                 float* running_var, void* workspace, size_t workspace_bytes, float* stats,
+                                 lfd_stream_t stream) {
+  return conv_bn_stats(d, in, nullptr, nullptr, nullptr, out, w_packed, bias, zeros, eps, momentum, running_mean, running_var,
+                       workspace, workspace_bytes, stats, stream);
+}
+
+int lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* y_in, const float* in_stats,
+                                             const float* in_gamma, const float* in_beta, void* out, const void* w_packed,
+                                             const float* bias, const void* zeros, float eps, float momentum,
+                                             float* running_mean, float* running_var, void* workspace,
+                                             size_t workspace_bytes, float* stats, lfd_stream_t stream) {
+  if (!d || !in_stats || !in_gamma || !in_beta || d->ks != 1 || d->stride != 1) return LFD_ERR_INVALID_ARGUMENT;
+  return conv_bn_stats(d, y_in, in_stats, in_gamma, in_beta, out, w_packed, bias, zeros, eps, momentum, running_mean,
+                       running_var, workspace, workspace_bytes, stats, stream);
 }
 
 }  // extern "C"

@@ -1093,10 +1093,17 @@ struct WgradArgs {
   int tiles_y, tiles_x;
   float* partials;
   int vtaps;      // 9: this launch of the 1x1 kernel is ONE TAP (blockIdx.z) of a 3x3 conv -- x is read at the tap's offset
+  // XPRO: `x` is the PRE-normalisation output y of the BatchNorm + ReLU unit whose activation this conv consumed (a unit whose
+  // z tensor is never stored: the forward conv normalised its operand on the way into the MFMA, conv_impl.h PRO); the tile
+  // loader re-forms z = fp16(max(y * a + b, 0)) with k_bn_apply's arithmetic
+  const float* xpro_stats;   // [2][cin] mean | rstd
+  const float* xpro_gamma;
+  const float* xpro_beta;
 };
 
-template <int KS, int S>
+template <int KS, int S, bool XPRO = false>
 __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
+  static_assert(!XPRO || (KS == 1 && S == 1), "XPRO: 1x1 stride-1 convs");
   using C = WgradCfg<KS, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sdy = smem;
@@ -1131,6 +1138,16 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
   constexpr int NX = (C::XH * C::XW * 8 + kThreads - 1) / kThreads;
   constexpr bool PF = (S == 1);
   uint4 rdy[NDY], rx[NX];
+  float xa[XPRO ? 8 : 1], xb[XPRO ? 8 : 1];      // a thread stages the same 8 channels (tid & 7) of every x pixel it loads
+  if constexpr (XPRO) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = ib * 64 + (tid & 7) * 8 + e;
+      const bool okc = c < a.cin;
+      xa[e] = okc ? a.xpro_gamma[c] * a.xpro_stats[a.cin + c] : 0.f;
+      xb[e] = okc ? a.xpro_beta[c] - a.xpro_stats[c] * xa[e] : 0.f;
+    }
+  }
   auto tile_load = [&](int t) {
     const int tx = t % a.tiles_x;
     const int q = t / a.tiles_x;
@@ -1155,7 +1172,18 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
       const int ci = ib * 64 + c8 * 8;
       const bool ok = i < C::XH * C::XW * 8 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w && ci < a.cin;
       const int64_t off = ok ? ((((int64_t)img * a.h + iy) * a.w + ix) * a.cin + ci) : 0;
-      const uint4 v = *reinterpret_cast<const uint4*>(a.x + off);
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + off);
+      if constexpr (XPRO) {
+        const h8 hv = __builtin_bit_cast(h8, v);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)hv[e] * xa[e] + xb[e];
+          f = fmaxf(f, 0.f);
+          o[e] = (_Float16)f;
+        }
+        v = __builtin_bit_cast(uint4, o);
+      }
       rx[j] = ok ? v : make_uint4(0, 0, 0, 0);
     }
   };
@@ -1322,13 +1350,13 @@ __global__ __launch_bounds__(kThreads) void k_rows_sum_batched(const lfd_rowsum_
   }
 }
 
-template <int KS, int S>
+template <int KS, int S, bool XPRO = false>
 int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
   using C = WgradCfg<KS, S>;
   static unsigned long long attr_set_mask = 0;
   const int attr_set_dev = lfd_device_ordinal();
   if (LFD_ONCE_PER_DEVICE(attr_set_mask, attr_set_dev)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<KS, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<KS, S, XPRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     LFD_DONE_ON_DEVICE(attr_set_mask, attr_set_dev);
@@ -1336,7 +1364,7 @@ int launch_wgrad(const WgradArgs& a0, int nwg, int nblk, hipStream_t st) {
   WgradArgs a = a0;
   a.tiles_y = (a.ho + C::TH - 1) / C::TH;
   a.tiles_x = (a.wo + C::TW - 1) / C::TW;
-  hipLaunchKernelGGL((k_wgrad<KS, S>), dim3(nwg, nblk, a.vtaps == 9 ? 9 : 1), dim3(kThreads), C::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_wgrad<KS, S, XPRO>), dim3(nwg, nblk, a.vtaps == 9 ? 9 : 1), dim3(kThreads), C::LDS_BYTES, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -1663,8 +1691,13 @@ static int wgrad_geometry(int32_t n, int32_t h, int32_t w, int32_t cin, int32_t 
 }
 
 static int wgrad_launch(const void* x, const void* dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t ks,
-                        int32_t stride, float* partials, int nwg, int nblk, int ho, int wo, int tap_split, hipStream_t st) {
+                        int32_t stride, float* partials, int nwg, int nblk, int ho, int wo, int tap_split, hipStream_t st,
+                        const float* x_stats = nullptr, const float* x_gamma = nullptr, const float* x_beta = nullptr) {
   WgradArgs a{};
+  a.xpro_stats = x_stats; a.xpro_gamma = x_gamma; a.xpro_beta = x_beta;
+  if (x_stats) {
+    if (ks != 1 || stride != 1 || tap_split) return LFD_ERR_UNSUPPORTED;
+  }
   a.x = (const __half*)x;
   a.dy = (const __half*)dy;
   a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
@@ -1674,7 +1707,7 @@ static int wgrad_launch(const void* x, const void* dy, int32_t n, int32_t h, int
   if (tap_split) return stride == 1 ? launch_wgrad<1, 1>(a, nwg, nblk, st) : launch_wgrad<1, 2>(a, nwg, nblk, st);
   if (ks == 3 && stride == 1) return launch_wgrad<3, 1>(a, nwg, nblk, st);
   if (ks == 3) return launch_wgrad<3, 2>(a, nwg, nblk, st);
-  if (stride == 1) return launch_wgrad<1, 1>(a, nwg, nblk, st);
+  if (stride == 1) return x_stats ? launch_wgrad<1, 1, true>(a, nwg, nblk, st) : launch_wgrad<1, 1>(a, nwg, nblk, st);
   return launch_wgrad<1, 2>(a, nwg, nblk, st);
 }
 
@@ -1711,6 +1744,19 @@ int lfd_conv_wgrad_partials_nhwc_f16(const void* x, const void* dy, int32_t n, i
   if (rc != LFD_OK) return rc;
   if (partials_bytes < (size_t)nwg * nblk * ks * ks * 64 * 64 * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
   return wgrad_launch(x, dy, n, h, w, cin, cout, ks, stride, partials, nwg, nblk, ho, wo, ts, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_conv1x1_wgrad_partials_of_bn_relu_f16(const void* y_in, const float* in_stats, const float* in_gamma,
+                                              const float* in_beta, const void* dy, int32_t n, int32_t h, int32_t w,
+                                              int32_t cin, int32_t cout, float* partials, size_t partials_bytes,
+                                              lfd_stream_t stream) {
+  if (!y_in || !in_stats || !in_gamma || !in_beta || !dy || !partials) return LFD_ERR_INVALID_ARGUMENT;
+  int nwg, nblk, ho, wo, ts;
+  const int rc = wgrad_geometry(n, h, w, cin, cout, 1, 1, &nwg, &nblk, &ho, &wo, &ts);
+  if (rc != LFD_OK) return rc;
+  if (partials_bytes < (size_t)nwg * nblk * 64 * 64 * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  return wgrad_launch(y_in, dy, n, h, w, cin, cout, 1, 1, partials, nwg, nblk, ho, wo, ts, reinterpret_cast<hipStream_t>(stream),
+                      in_stats, in_gamma, in_beta);
 }
 
 int lfd_wgrad_final_batched_f32(const lfd_wgrad_job_t* jobs_device, int32_t njobs, int32_t total_blocks, lfd_stream_t stream) {

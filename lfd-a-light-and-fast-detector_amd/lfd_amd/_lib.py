@@ -168,6 +168,7 @@ _SIGNATURES = {
     'lfd_train_workspace_bytes': (_SZ, []),
     'lfd_bn_train_stats_f16': (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_conv2d_bn_stats_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _P]),
+    'lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_bn_train_apply_f16': (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     'lfd_bn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P, _P]),
     'lfd_pack_conv_weights_train_f16': (C.c_int, [_P, _I32, _I32, _P]),
@@ -187,6 +188,7 @@ _SIGNATURES = {
     'lfd_conv_wgrad_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_conv_wgrad_partial_rows': (_I32, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     'lfd_conv_wgrad_partials_nhwc_f16': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _SZ, _P]),
+    'lfd_conv1x1_wgrad_partials_of_bn_relu_f16': (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _SZ, _P]),
     'lfd_wgrad_final_batched_f32': (C.c_int, [_P, _I32, _I32, _P]),
     'lfd_rows_sum_batched_f32': (C.c_int, [_P, _I32, _P]),
     'lfd_stem_conv0_train_fwd': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),

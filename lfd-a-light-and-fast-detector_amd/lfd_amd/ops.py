@@ -728,6 +728,25 @@ def conv2d_bn_stats(x, w_packed, bias, cin, cout, ks, stride, eps, momentum, run
     return y, stats
 
 
+def conv1x1_of_bn_relu_bn_stats(y_in, in_stats, in_gamma, in_beta, w_packed, bias, cout, eps, momentum, running_mean=None,
+                                running_var=None):
+    """conv2d_bn_stats for a 1x1 stride-1 conv whose input is relu(BatchNorm(y_in)) of a unit WITHOUT a residual: the
+    normalisation + ReLU happens on the activation fragments inside the conv kernel (bit-identical to bn_train_apply first),
+    the producer's z tensor is never stored (lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16); 64 input channels."""
+    _nhwc16(y_in, 'conv1x1_of_bn_relu_bn_stats')
+    n, h, w_, cin = y_in.shape
+    d = _lib.ConvDesc(n, h, w_, cin, cout, 1, 1, 0, 0, 0)
+    ws = train_workspace(y_in.device)
+    with torch.cuda.device(y_in.device):
+        y = torch.empty((n, h, w_, cout), dtype=torch.float16, device=y_in.device)
+        stats = torch.empty(2 * cout, dtype=torch.float32, device=y_in.device)
+        check(lib().lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16(C.byref(d), ptr(y_in), ptr(in_stats), ptr(in_gamma), ptr(in_beta), ptr(y),
+                                                             ptr(w_packed), ptr(bias), ptr(zero_line(y_in.device)), float(eps),
+                                                             float(momentum), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel(),
+                                                             ptr(stats), stream_ptr()), 'lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16')
+    return y, stats
+
+
 def bn_train_apply(y, stats, gamma, beta, residual=None, relu=True):
     _nhwc16(y, 'bn_train_apply')
     c = y.size(3)
@@ -981,6 +1000,18 @@ def conv_wgrad_partials(x, dy, ks, stride, partials):
     with torch.cuda.device(x.device):
         check(lib().lfd_conv_wgrad_partials_nhwc_f16(ptr(x), ptr(dy), n, h, w_, cin, dy.size(3), ks, stride, ptr(partials),
                                                      partials.numel() * 4, stream_ptr()), 'lfd_conv_wgrad_partials_nhwc_f16')
+
+
+def conv1x1_wgrad_partials_of_bn_relu(y_in, in_stats, in_gamma, in_beta, dy, partials):
+    """conv_wgrad_partials(ks 1, stride 1) with x = relu(BatchNorm(y_in)) re-formed in the tile loader (the operand of a
+    conv1x1_of_bn_relu_bn_stats forward was never stored)"""
+    _nhwc16(y_in, 'conv1x1_wgrad_partials_of_bn_relu')
+    _nhwc16(dy, 'conv1x1_wgrad_partials_of_bn_relu')
+    n, h, w_, cin = y_in.shape
+    with torch.cuda.device(y_in.device):
+        check(lib().lfd_conv1x1_wgrad_partials_of_bn_relu_f16(ptr(y_in), ptr(in_stats), ptr(in_gamma), ptr(in_beta), ptr(dy), n, h, w_,
+                                                              cin, dy.size(3), ptr(partials), partials.numel() * 4, stream_ptr()),
+              'lfd_conv1x1_wgrad_partials_of_bn_relu_f16')
 
 
 class WgradFinals(object):

@@ -779,6 +779,35 @@ def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts,
                                        residual=grads.get(u.src))
 
 
+def _deferred_units(units, outs):
+    """-> {index of a unit whose activation is never stored: index of its only consumer}.  A BatchNorm + ReLU unit without a
+    residual whose output feeds exactly one 1x1 stride-1 conv unit (the first conv of each stem pair, lfd_resnet.py:376-413):
+    the consumer normalises its operand inside the conv kernel (ops.conv1x1_of_bn_relu_bn_stats) and its weight gradient
+    re-forms it (ops.conv1x1_wgrad_partials_of_bn_relu) -- one write and one read of the largest tensors of the iteration less.
+    LFD_BN_APPLY_IN_CONV=0: every unit stores its activation."""
+    if os.environ.get('LFD_BN_APPLY_IN_CONV', '1') != '1':
+        return {}
+    uses = {}
+    for vi, v in enumerate(units):
+        uses.setdefault(v.src, []).append(vi)
+        if v.res is not None:
+            uses.setdefault(v.res, []).append(-1)
+    for o in outs:
+        uses.setdefault(o.src, []).append(-1)
+    out = {}
+    for ui, u in enumerate(units):
+        if not (isinstance(u.norm, nn.BatchNorm2d) and u.relu and u.res is None and u.level is None):
+            continue
+        cons = uses.get(u.dst, [])
+        if len(cons) != 1 or cons[0] < 0:
+            continue
+        v = units[cons[0]]
+        if (v.level is None and isinstance(v.norm, nn.BatchNorm2d) and v.conv.kernel_size[0] == 1 and v.conv.stride[0] == 1
+                and v.conv.in_channels == 64 and v.conv.out_channels % 32 == 0 and not v.first):
+            out[ui] = cons[0]
+    return out
+
+
 def network_forward(model, plan, x):
     """-> (cls [N,P,C'], reg [N,P,4], sizes, saved): LFD.forward in train mode (lfd.py:511-542) over the unit schedule"""
     units, outs, nlev = plan
@@ -813,9 +842,12 @@ def network_forward(model, plan, x):
             cl = _concat_layout(units, outs, nlev)
             model.__dict__['_lfd_concat_layout'] = cl
     cs = None
+    defer = _deferred_units(units, outs) if fused_stats else {}
+    fed = {v: u for u, v in defer.items()}
     for ui, u in enumerate(units):
         if u.level is None:
-            tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats)
+            tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats, store=ui not in defer,
+                                     producer=(units[fed[ui]], tape[fed[ui]]) if ui in fed else None)
     if cl is not None:
         cs = _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, x.size(0), dev)
     osaved = cs
@@ -836,13 +868,20 @@ def network_forward(model, plan, x):
     return full['cls'], full['reg'], sizes, ((acts, tape), osaved, opk)
 
 
-def _unit_forward(u, acts, packs, zeros, fused_stats):
-    """conv -> norm (batch / group statistics) -> (+ residual) -> ReLU of one unit on the current stream; -> (y, stats)"""
+def _unit_forward(u, acts, packs, zeros, fused_stats, store=True, producer=None):
+    """conv -> norm (batch / group statistics) -> (+ residual) -> ReLU of one unit on the current stream; -> (y, stats).
+    store=False: the activation is not written (_deferred_units: its consumer forms it from (y, stats)); producer = (unit,
+    (y, stats)) of such an input."""
     conv, norm = u.conv, u.norm
     xin = acts[u.src]
     ks, st = conv.kernel_size[0], conv.stride[0]
     stats = None
-    if u.first and isinstance(norm, nn.BatchNorm2d) and fused_stats:
+    if producer is not None:
+        pu, (py, pstats) = producer
+        cout = conv.out_channels
+        y, stats = ops.conv1x1_of_bn_relu_bn_stats(py, pstats, pu.norm.weight.detach(), pu.norm.bias.detach(), packs(conv.weight),
+                                                   zeros(cout), cout, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
+    elif u.first and isinstance(norm, nn.BatchNorm2d) and fused_stats:
         y, stats = ops.stem_conv0_train_fwd_bn_stats(xin, conv.weight, norm.eps, norm.momentum, norm.running_mean,
                                                      norm.running_var)
     elif u.first:
@@ -860,7 +899,7 @@ def _unit_forward(u, acts, packs, zeros, fused_stats):
         if stats is None:
             stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
         z = ops.bn_train_apply(y, stats, norm.weight.detach(), norm.bias.detach(),
-                               acts[u.res] if u.res is not None else None, u.relu)
+                               acts[u.res] if u.res is not None else None, u.relu) if store else None
     acts[u.dst] = z
     return y, stats
 
@@ -885,12 +924,17 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         p += h * w_
     nj = [0]
 
-    def wgrad(xin, dy, ks, st, targets):
-        """the partial sums of dW into this conv's own buffer; `targets` as ops.WgradFinals.add_wgrad"""
+    def wgrad(xin, dy, ks, st, targets, producer=None):
+        """the partial sums of dW into this conv's own buffer; `targets` as ops.WgradFinals.add_wgrad.  producer = (unit, (y,
+        stats)): xin is that unit's pre-normalisation output, its activation was never stored (_deferred_units)"""
         floats, nwg, nblk = ops.conv_wgrad_partial_floats(xin, dy, ks, st)
         part = sc.buf(('wg', nj[0]), floats)
         nj[0] += 1
-        ops.conv_wgrad_partials(xin, dy, ks, st, part)
+        if producer is not None:
+            pu, (_, pstats) = producer
+            ops.conv1x1_wgrad_partials_of_bn_relu(xin, pstats, pu.norm.weight.detach(), pu.norm.bias.detach(), dy, part)
+        else:
+            ops.conv_wgrad_partials(xin, dy, ks, st, part)
         fin.add_wgrad(part, nwg, nblk, xin.size(3), dy.size(3), ks * ks, inv, targets)
 
     grads = {}
@@ -944,7 +988,12 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         if u.first:
             ops.stem_conv0_wgrad(xin, dy, inv, out=store.target(conv.weight), accumulate=True)
             continue
-        wgrad(xin, dy, ks, st, [(store.target(conv.weight), 0, conv.out_channels)])
+        producer = None
+        if xin is None:         # the input activation was never stored (_deferred_units): re-formed from its producer's y
+            pi = [i for i, p_ in enumerate(units) if p_.dst == u.src][0]
+            producer = (units[pi], tape[pi])
+            xin = tape[pi][0]
+        wgrad(xin, dy, ks, st, [(store.target(conv.weight), 0, conv.out_channels)], producer)
         cin = conv.in_channels
         if st == 2 and ks == 3 and cin == 64 and conv.out_channels == 64 and os.environ.get('LFD_DGRAD_S2', '1') == '1':
             # per output parity, 9 tap-products per 2 x 2 pixels instead of 36 and no zero-inserted tensor (csrc/dgrad_s2.hip)

@@ -688,3 +688,68 @@ def test_first_unit_backward_without_a_dy_tensor_is_bit_identical(nhw):
     ops.stem_conv0_bn_bwd_wgrad(x, dz, y, stats, gamma, beta, inv, dgb, dbb, dwb)
     assert torch.equal(dga, dgb) and torch.equal(dba, dbb)
     assert float(dwa.abs().max()) > 0 and torch.equal(dwa, dwb)
+
+
+@pytest.mark.parametrize('nhw', [(2, 37, 53), (1, 8, 8), (3, 130, 70), (2, 160, 160)])
+@pytest.mark.parametrize('cout', [64])
+def test_conv1x1_of_an_unstored_bn_relu_activation_is_bit_identical(nhw, cout):
+    """lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16 / lfd_conv1x1_wgrad_partials_of_bn_relu_f16 (round 4): the second conv of a stem
+    pair normalises + ReLUs its operand inside the kernels, the producer's activation is never stored -- against
+    lfd_bn_train_apply_f16 followed by the plain kernels: conv output, its batch statistics, the running statistics and the
+    weight-gradient partial sums bit for bit."""
+    n, h, w = nhw
+    cin = 64
+    g = torch.Generator(device='cuda').manual_seed(5 + h)
+    yin = (torch.randn(n, h, w, cin, generator=g, device='cuda') * 1.3 + 0.2).half()
+    pstats = ops.bn_train_stats(yin, 1e-5, 0.1, None, None)
+    pg = torch.empty(cin, device='cuda').uniform_(0.5, 1.5)
+    pb = torch.empty(cin, device='cuda').normal_(0, 0.3)
+    wt = torch.randn(cout, cin, 1, 1, generator=g, device='cuda') * 0.15
+    wp = ops.pack_conv_weight_train(wt)
+    zb = torch.zeros(cout, device='cuda')
+    rm_a, rv_a = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+    rm_b, rv_b = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+    z = ops.bn_train_apply(yin, pstats, pg, pb, None, True)
+    ya, sa = ops.conv2d_bn_stats(z, wp, zb, cin, cout, 1, 1, 1e-5, 0.1, rm_a, rv_a)
+    yb, sb = ops.conv1x1_of_bn_relu_bn_stats(yin, pstats, pg, pb, wp, zb, cout, 1e-5, 0.1, rm_b, rv_b)
+    assert float(ya.float().abs().max()) > 0 and torch.equal(ya, yb)
+    assert torch.equal(sa, sb) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    dy = (torch.randn(n, h, w, cout, generator=g, device='cuda') * 0.5).half()
+    floats, nwg, nblk = ops.conv_wgrad_partial_floats(z, dy, 1, 1)
+    pa, pb_ = torch.zeros(floats, device='cuda'), torch.zeros(floats, device='cuda')
+    ops.conv_wgrad_partials(z, dy, 1, 1, pa)
+    ops.conv1x1_wgrad_partials_of_bn_relu(yin, pstats, pg, pb, dy, pb_)
+    assert float(pa.abs().max()) > 0 and torch.equal(pa, pb_)
+
+
+def test_network_with_and_without_stored_stem_activations_is_bit_identical(monkeypatch):
+    """LFD_BN_APPLY_IN_CONV=0 (every unit stores its activation) against the default (the first conv of each stem pair hands its
+    pre-normalisation output to the 1x1 conv that follows): logits, loss-side gradients and every parameter gradient bit for
+    bit; the two activations are really absent from the saved state."""
+    from lfd_amd import configs, train_engine as TE
+    res = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LFD_BN_APPLY_IN_CONV', flag)
+        torch.manual_seed(0)
+        m = configs.build_model('WIDERFACE_LFD_S')
+        configs.perturb_weights(m)
+        m.train().cuda()
+        units, outs = TE.build_network(m)
+        plan = (units, outs, m._num_heads)
+        d = TE._deferred_units(units, outs)
+        assert (len(d) == 2 and all(units[v].conv.kernel_size[0] == 1 for v in d.values())) if flag == '1' else d == {}
+        x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(1)).cuda()
+        for p in m.parameters():
+            p.grad = None
+        cls, reg, sizes, saved = TE.network_forward(m, plan, x)
+        (acts, tape), _, _ = saved
+        assert [acts[units[u].dst] is None for u in d] == [True] * len(d)
+        gc = torch.randn(cls.shape, generator=torch.Generator().manual_seed(2)).cuda() * 1e-2
+        gr = torch.randn(reg.shape, generator=torch.Generator().manual_seed(3)).cuda() * 1e-2
+        TE.network_backward(m, plan, saved, sizes, gc, gr, 64.0)
+        torch.cuda.synchronize()
+        res.append((cls.clone(), reg.clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+        del m
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert len(res[0][2]) == len(res[1][2]) > 50
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))

@@ -336,6 +336,11 @@ def test_training_schedule_covers_every_parameter_once():
     plain = [u for u in units if u.conv is m._backbone.stage0[1]._conv2][0]
     first = [u for u in units if u.conv is m._backbone.stage0[1]._conv1][0]
     assert plain.res == first.src                                               # identity = the block input
+    # the first conv of each stem pair never stores its activation: the 1x1 conv that follows normalises its operand itself
+    full = te.build_network(m)
+    d = te._deferred_units(*full)
+    assert d == {0: 1, 2: 3} and all(units[v].conv.kernel_size == (1, 1) and units[u].res is None for u, v in d.items())
+    assert te._deferred_units(*te.build_network(configs.build_model('WIDERFACE_LFD_XS').train())) == {}     # 32-channel stem
     m.eval()
     assert not te.network_supported(m)            # BatchNorm in eval mode: running statistics, not this path
     m.train()
