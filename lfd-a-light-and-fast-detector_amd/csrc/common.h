@@ -53,6 +53,24 @@ __device__ __forceinline__ uint32_t lfd_cvt_pk_max(float x, float y, uint32_t lo
   return r.u;
 }
 
+// relu(x * a + b) of 8 fp16 values with per-element fp32 (a, b) -> 8 fp16: the arithmetic of k_bn_apply (train.hip) --
+// fp32 multiply, then add (two roundings, no fma), ReLU, round to nearest even -- written on 2-vectors so that the compiler
+// emits v_pk_mul_f32 / v_pk_add_f32 / v_cvt_pk_f16_f32 / v_pk_max_f16: 24 VALU instructions instead of ~40 scalar ones.
+typedef _Float16 lfd_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ lfd_f16x8 lfd_affine_relu_f16x8(lfd_f16x8 v, const float (&a)[8], const float (&b)[8]) {
+  union { lfd_f16x8 h; uint32_t u[4]; } o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lfd_f32x2 x, aa, bb;
+    x[0] = (float)v[2 * j]; x[1] = (float)v[2 * j + 1];
+    aa[0] = a[2 * j]; aa[1] = a[2 * j + 1];
+    bb[0] = b[2 * j]; bb[1] = b[2 * j + 1];
+    const lfd_f32x2 f = x * aa + bb;
+    o.u[j] = lfd_cvt_pk_max(f[0], f[1], LFD_PK_RELU);
+  }
+  return o.h;
+}
+
 // Monotone float -> uint32 map (a < b  <=>  ord(a) < ord(b) for non-NaN floats).
 __device__ __forceinline__ uint32_t lfd_float_ord(float f) {
   uint32_t u = __float_as_uint(f);

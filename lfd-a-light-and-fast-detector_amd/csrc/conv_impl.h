@@ -194,14 +194,7 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   }
   auto pro_apply = [&](half8 v, int q) {
     if constexpr (PRO) {
-      half8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)v[e] * pro_a[q][e] + pro_b[q][e];
-        f = fmaxf(f, 0.f);
-        o[e] = (_Float16)f;
-      }
-      return o;
+      return (half8)lfd_affine_relu_f16x8(v, pro_a[q], pro_b[q]);
     } else {
       return v;
     }

@@ -1174,15 +1174,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgradArgs a) {
       const int64_t off = ok ? ((((int64_t)img * a.h + iy) * a.w + ix) * a.cin + ci) : 0;
       uint4 v = *reinterpret_cast<const uint4*>(a.x + off);
       if constexpr (XPRO) {
-        const h8 hv = __builtin_bit_cast(h8, v);
-        h8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)hv[e] * xa[e] + xb[e];
-          f = fmaxf(f, 0.f);
-          o[e] = (_Float16)f;
-        }
-        v = __builtin_bit_cast(uint4, o);
+        v = __builtin_bit_cast(uint4, lfd_affine_relu_f16x8(__builtin_bit_cast(h8, v), xa, xb));
       }
       rx[j] = ok ? v : make_uint4(0, 0, 0, 0);
     }
