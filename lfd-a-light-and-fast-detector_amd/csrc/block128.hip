@@ -9,10 +9,9 @@
 // (2 x 72 KB) through a ring of R = 48 fragments in AccVGPRs, R loads in flight per wave from the first instruction on; the
 // L2 -> CU path (64 B / clk: 576 KB per workgroup = 4.4 us) is the floor of a workgroup, the 216 MFMAs per wave hide under it.
 //
-// Measured (round 4): in a graphed chain of blocks with L2-hot filters 9.4 vs 10.8 us per block at 1 x 17 x 30, 10.2 vs 13.4
-// at 8 x 17 x 30, 20.5 vs 30.0 at 16 x 23 x 40 (tools/timing/block128_in_graph.py); inside the network, where every block's
-// filters arrive cold, the forward of one 1080p frame gains 1.6-2 us (0.2213 -> 0.2197 ms) and the batch of eight ~1 us:
-// the last stage is bound by the latency of getting 0.6 MB of filter to every XCD, not by its launches.  (Mapping the split-K
+// Measured (round 4): in a graphed chain of blocks 9.4 vs 10.8 us per block at 1 x 17 x 30, 10.2 vs 13.4 at 8 x 17 x 30, 20.5 vs
+// 30.0 at 16 x 23 x 40 (tools/timing/block128_in_graph.py); inside the network the forward of one 1080p frame gains what
+// the chain predicts (0.2213 -> 0.2197 ms, two blocks), the batch of eight ~1 us instead of 6.  (Mapping the split-K
 // kernel's slabs onto XCDs so that an XCD streams one slab instead of four changed nothing either.)
 //
 // Numerics: bit-identical to two k_conv128_splitk launches.  That kernel splits K into four quarters of 18 k-steps and adds
