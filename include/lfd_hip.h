@@ -730,6 +730,29 @@ LFD_API int lfd_stem_conv0_bn_bwd_wgrad(const float* x_nchw, const void* dz, con
                                 int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, float* dw,
                                 lfd_stream_t stream);
 
+/* BatchNorm's backward sums in the epilogue of the data-gradient conv that produces dz (round 4; the stem pairs,
+ * lfd_resnet.py:376-413): a unit Conv -> train-mode BatchNorm2d -> ReLU (no residual) whose activation feeds exactly one 1x1
+ * stride-1 conv gets its dz = dL/d(activation) from that conv's data gradient -- a 1x1 conv over dy with the transposed
+ * weights.  lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16 runs that conv (desc: cin = cout = 64, ks = stride = 1, relu = 0; bias:
+ * 64 zeros) and, while copying dz out, adds sum g and sum g * xhat per channel (g = dz * [gamma * xhat + beta > 0], the
+ * arithmetic of lfd_bn_train_bwd_f16's first pass on the fp16 values it stores) into one row per workgroup in `workspace`;
+ * *sum_rows (host) receives the row count.  The unit's backward then skips its own pass over (dz, y):
+ *   lfd_bn_train_bwd_rows_f16           the final + apply stages of lfd_bn_train_bwd_f16 (ReLU mask recomputed from y, no g output)
+ *   lfd_stem_conv0_bn_bwd_wgrad_rows    lfd_stem_conv0_bn_bwd_wgrad without its sums pass (sum_rows = 0: with it)
+ * with the SAME workspace and no other workspace user in between.  Values equal the unfused calls up to the order of the
+ * fp32 partial sums. */
+LFD_API int lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16(const lfd_conv_desc_t* d, const void* dy, void* dz, const void* w_packed,
+                                           const float* bias, const void* zeros, const void* y_unit, const float* unit_stats,
+                                           const float* unit_gamma, const float* unit_beta, void* workspace,
+                                           size_t workspace_bytes, int32_t* sum_rows, lfd_stream_t stream);
+LFD_API int lfd_bn_train_bwd_rows_f16(const void* dz, const void* y, int64_t pixels, int32_t channels, const float* stats,
+                              const float* gamma, const float* beta, float inv_scale, int32_t accumulate, int32_t sum_rows,
+                              void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, lfd_stream_t stream);
+LFD_API int lfd_stem_conv0_bn_bwd_wgrad_rows(const float* x_nchw, const void* dz, const void* y, int32_t n, int32_t h, int32_t w,
+                                     int32_t channels, const float* stats, const float* gamma, const float* beta, float inv_scale,
+                                     int32_t accumulate, int32_t sum_rows, void* workspace, size_t workspace_bytes, float* dgamma,
+                                     float* dbeta, float* dw, lfd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Neck + head of ALL pyramid levels.  Replaces SimpleNeck.forward (simple_neck.py:67-74),
  * LFDHead.forward (lfd_head.py:164-185: GroupNorm towers + cls/reg convs + Scale) and the

@@ -55,6 +55,13 @@ struct ConvArgs {
   const float* pro_stats;   // [2][CIN]: batch mean | rstd of the producer (lfd_bn_train_stats_f16 layout)
   const float* pro_gamma;   // [CIN]
   const float* pro_beta;    // [CIN]
+  // BSUM kernels (a data-gradient conv whose output dz is the gradient wrt the activation of a train-mode BatchNorm + ReLU
+  // unit without residual): the backward sums of that unit -- sum g and sum g * xhat per channel, g = dz * [ReLU passed],
+  // k_bn_bwd_partial's arithmetic on the fp16 values stored -- leave through stat_partials like the forward statistics
+  const _Float16* bsum_y;   // the unit's pre-normalisation output, same shape as `out`
+  const float* bsum_stats;  // [2][cout] mean | rstd
+  const float* bsum_gamma;  // [cout]
+  const float* bsum_beta;   // [cout]
 };
 
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL>
@@ -153,14 +160,29 @@ __device__ __forceinline__ void stats_add(uint4 v, bool ok, float (&s)[8], float
   }
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false>
+__device__ __forceinline__ void bsum_add(uint4 v, uint4 yv, bool ok, const float (&m)[8], const float (&r)[8], const float (&ga)[8],
+                                         const float (&be)[8], float (&s)[8], float (&q)[8]) {
+  const lfd_f16x8 d = __builtin_bit_cast(lfd_f16x8, v), yy = __builtin_bit_cast(lfd_f16x8, yv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float g = (float)d[e];
+    const float xh = ((float)yy[e] - m[e]) * r[e];
+    if (!(ga[e] * xh + be[e] > 0.f)) g = 0.f;
+    if (!ok) g = 0.f;
+    s[e] += g;
+    q[e] += g * xh;
+  }
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false, bool BSUM = false>
 __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   static_assert(!PRO || (KS == 1 && S == 1 && WREG && !TAIL && !DS), "PRO: a 1x1 stride-1 conv fed by a train-mode BatchNorm + ReLU unit");
+  static_assert(!BSUM || (KS == 1 && S == 1 && !STATS && !TAIL && !DS && !ACC32), "BSUM: the 1x1 data-gradient conv of a stem pair");
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES), "DS: the residual block's 1x1 s2 downsample rides on its 3x3 s2 conv");
   static_assert(!ACC32 || (!TAIL && !RES && !DS), "ACC32 writes the bare accumulators of ONE conv");
   static_assert(!STATS || (!TAIL && !RES && !DS && !ACC32), "STATS: the bare conv in front of a train-mode BatchNorm");
   float st_s[8], st_q[8];
-  if constexpr (STATS) {
+  if constexpr (STATS || BSUM) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
   }
@@ -199,6 +221,19 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       return v;
     }
   };
+
+  // ---- BSUM: the unit's statistics / affine of the 8 channels this thread copies out (chunk threadIdx.x % (NCT * 4) of every pixel)
+  float bs_m[BSUM ? 8 : 1], bs_r[BSUM ? 8 : 1], bs_g[BSUM ? 8 : 1], bs_b[BSUM ? 8 : 1];
+  if constexpr (BSUM) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = cog * NCT * 32 + ((int)threadIdx.x % (NCT * 4)) * 8 + e;
+      bs_m[e] = a.bsum_stats[ch];
+      bs_r[e] = a.bsum_stats[a.cout + ch];
+      bs_g[e] = a.bsum_gamma[ch];
+      bs_b[e] = a.bsum_beta[ch];
+    }
+  }
 
   // ---- biases into LDS.  They are re-read for every tile; as global loads the compiler's wait for them
   //      (vmcnt is in-order) would also wait for the just-issued DMA prefetch of the next tile.
@@ -444,6 +479,24 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       }
     }
 
+    // BSUM: the unit's y at the pixels / chunk this thread copies out below (same mapping), requested now like the residual
+    constexpr int B_OCPP = NCT * 4, B_OPX = C::PG * C::PT * 32, B_NST = (B_OPX * B_OCPP) / 256;
+    uint4 bs_y[BSUM ? B_NST : 1];
+    if constexpr (BSUM) {
+      static_assert(!BSUM || (B_OPX * B_OCPP) % 256 == 0, "whole copy-out rounds");
+#pragma unroll
+      for (int k = 0; k < B_NST; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int pb = i / B_OCPP, c = i - pb * B_OCPP;
+        const int t32 = pb >> 5, p32 = pb & 31;
+        const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
+        const int ox = tx0 * C::TW + p32 % C::TW;
+        const bool ok = oy < a.OH && ox < a.OW;
+        bs_y[k] = *reinterpret_cast<const uint4*>(a.bsum_y + (((size_t)n * a.OH + (ok ? oy : 0)) * a.OW + (ok ? ox : 0)) * a.cout +
+                                                  cog * NCT * 32 + c * 8);
+      }
+    }
+
     f32x16 accd[DS ? C::PT : 1];
     if constexpr (DS) {
       const float* bp = sbias + 128 + ct * 32 + 4 * h;
@@ -678,6 +731,23 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
         *reinterpret_cast<uint4*>(dst) = v;
         if constexpr (STATS) stats_add(v, ok, st_s, st_q);
       }
+    } else if constexpr (BSUM) {
+      const int cslice = cog * NCT * 32;
+#pragma unroll
+      for (int k = 0; k < B_NST; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int pb = i / OCPP, c = i - pb * OCPP;
+        const int t32 = pb >> 5, p32 = pb & 31;
+        const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
+        const int ox = tx0 * C::TW + p32 % C::TW;
+        const int fo = (pb / OPPR) % OCPP;
+        const uint4 v = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
+        const bool ok = oy < a.OH && ox < a.OW;
+        _Float16* dst = ok ? a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * cout_out + cslice + c * 8
+                           : const_cast<_Float16*>(a.zeros) + 1024 + (threadIdx.x & 127) * 8;
+        *reinterpret_cast<uint4*>(dst) = v;
+        bsum_add(v, bs_y[k], ok, bs_m, bs_r, bs_g, bs_b, st_s, st_q);
+      }
     } else {
       const int cslice = TAIL ? 0 : cog * NCT * 32;
       for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
@@ -727,7 +797,7 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
       }
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS || BSUM) {
     // lanes l, l + OCPP, ... of a wave hold the same chunk: butterfly over them, then the four waves through LDS in wave order
     constexpr int OCPP = NCT * 4, CB = NCT * 32;
     static_assert(256 % OCPP == 0 && 64 % OCPP == 0, "one channel chunk per thread");
@@ -759,13 +829,13 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, char* smem) {
   CV_END();
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false, bool BSUM = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO>(a, smem);
+  conv_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO, BSUM>(a, smem);
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, bool ACC32 = false, bool STATS = false, bool PRO = false, bool BSUM = false>
 int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) {
   using C = Cfg<CIN, KS, S, NCT, WREG, TAIL>;
   ConvArgs a = a0;
@@ -780,7 +850,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) 
   static unsigned long long attr_done_mask = 0;
   const int attr_done_dev = lfd_device_ordinal();
   if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO, BSUM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
       return LFD_ERR_LAUNCH_FAILED;
     LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
@@ -791,7 +861,7 @@ int launch_conv_(const ConvArgs& a0, hipStream_t st, int* blocks_out = nullptr) 
   if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
   if (blocks < 1) blocks = 1;
   if (blocks_out) *blocks_out = blocks;
-  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
+  hipLaunchKernelGGL((k_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, ACC32, STATS, PRO, BSUM>), dim3(blocks, cgroups), dim3(256), LDSB, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }

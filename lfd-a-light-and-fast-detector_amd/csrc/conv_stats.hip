@@ -89,4 +89,32 @@ int lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const voi
                        running_var, workspace, workspace_bytes, stats, stream);
 }
 
+// The 1x1 stride-1 data-gradient conv of a stem pair with the BatchNorm backward sums of the unit it feeds taken in its
+// epilogue (conv_impl.h BSUM): rows of [2][cout] partial sums in `workspace`, *sum_rows of them -- the input of
+// lfd_bn_train_bwd_rows_f16 / lfd_stem_conv0_bn_bwd_wgrad_rows, which skip their own sums pass.
+int lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16(const lfd_conv_desc_t* d, const void* dy, void* dz, const void* w_packed,
+                                           const float* bias, const void* zeros, const void* y_unit, const float* unit_stats,
+                                           const float* unit_gamma, const float* unit_beta, void* workspace,
+                                           size_t workspace_bytes, int32_t* sum_rows, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!d || !dy || !dz || !w_packed || !bias || !zeros || !y_unit || !unit_stats || !unit_gamma || !unit_beta || !workspace || !sum_rows)
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (d->n < 1 || d->h < 1 || d->w < 1 || d->tail_cout || d->relu || d->ks != 1 || d->stride != 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->cin != 64 || d->cout != 64) return LFD_ERR_UNSUPPORTED;
+  if (!lfd_aligned16(dy) || !lfd_aligned16(dz) || !lfd_aligned16(y_unit)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  ConvArgs a{};
+  a.in = (const _Float16*)dy; a.out = (_Float16*)dz; a.w = (const half8*)w_packed; a.bias = bias;
+  a.res_px = d->cout; a.zeros = (const _Float16*)zeros;
+  a.N = d->n; a.H = d->h; a.W = d->w; a.OH = d->h; a.OW = d->w;
+  a.cout = d->cout;
+  a.stat_partials = reinterpret_cast<float*>(workspace);
+  a.bsum_y = (const _Float16*)y_unit; a.bsum_stats = unit_stats; a.bsum_gamma = unit_gamma; a.bsum_beta = unit_beta;
+  int blocks = 0;
+  const int rc = launch_conv_<64, 1, 1, 2, true, false, false, false, false, false, false, true>(a, st, &blocks);
+  if (rc != LFD_OK) return rc;
+  *sum_rows = blocks;
+  return LFD_OK;
+}
+
 }  // extern "C"

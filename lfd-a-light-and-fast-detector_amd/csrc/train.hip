@@ -1461,7 +1461,7 @@ int lfd_bn_train_apply_into_f16(const void* y, int32_t n, int64_t hw, int32_t ch
 
 static int bn_bwd(const void* dz, const RowMap& dmap, const void* y, const void* z, int32_t relu, int64_t pixels, int32_t channels,
                   const float* stats, const float* gamma, const float* beta, float inv_scale, int32_t accumulate, void* workspace,
-                  size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out, hipStream_t st) {
+                  size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, void* g_out, hipStream_t st, int sum_rows = 0) {
   if (!dz || !y || !stats || !gamma || !dy || !workspace || pixels < 1 || !channels_ok(channels))
     return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
@@ -1475,11 +1475,14 @@ static int bn_bwd(const void* dz, const RowMap& dmap, const void* y, const void*
   // (Round 4 tried folding k_bn_bwd_final into the apply pass for small maps -- the sums pass on 64 workgroups, every apply
   // workgroup re-adding the 64 rows: the 21 saved launches (6.3 us each) were paid back by the slower 64-workgroup sums pass
   // (+6 us each) and the re-add (+4 us each): 7.06 against 6.98 ms per iteration.  Three launches it stays.)
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
-                     (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials, dmap);
-  LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
-                     dgamma, dbeta);
+  if (sum_rows < 0 || sum_rows > kMaxBlocks) return LFD_ERR_INVALID_ARGUMENT;
+  if (!sum_rows) {      // (else: the rows are already there -- lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16 left them)
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
+                       (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, partials, dmap);
+    LFD_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, sum_rows ? sum_rows : (int)g, channels, inv_scale,
+                     accumulate, sums, dgamma, dbeta);
   LFD_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y,
                      (const __half*)z, vecs, channels, stats, gamma, beta, relu_y, sums, (float)(1.0 / (double)pixels),
@@ -1495,6 +1498,14 @@ int lfd_bn_train_bwd_f16(const void* dz, const void* y, const void* z, int32_t r
                          lfd_stream_t stream) {
   return bn_bwd(dz, RowMap{}, y, z, relu, pixels, channels, stats, gamma, beta, inv_scale, accumulate, workspace, workspace_bytes,
                 dgamma, dbeta, dy, g_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_bn_train_bwd_rows_f16(const void* dz, const void* y, int64_t pixels, int32_t channels, const float* stats,
+                              const float* gamma, const float* beta, float inv_scale, int32_t accumulate, int32_t sum_rows,
+                              void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, void* dy, lfd_stream_t stream) {
+  if (sum_rows < 1) return LFD_ERR_INVALID_ARGUMENT;
+  return bn_bwd(dz, RowMap{}, y, nullptr, 1, pixels, channels, stats, gamma, beta, inv_scale, accumulate, workspace, workspace_bytes,
+                dgamma, dbeta, dy, nullptr, reinterpret_cast<hipStream_t>(stream), sum_rows);
 }
 
 int lfd_bn_train_bwd_from_f16(const void* dz_concat, int64_t points_total, int64_t point0, const void* y, int32_t relu, int32_t n,
@@ -1863,10 +1874,24 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
 // BatchNorm backward of the FIRST unit without its apply pass (round 4): the sums (k_bn_bwd_partial + k_bn_bwd_final: dgamma, dbeta,
 // and the two per-channel sums in the workspace) and then the first conv's weight gradient straight from dz and y
 // (k_conv0_wgrad_mfma<true>) -- the unit has no data gradient, so nobody else needs its dy.
+int lfd_stem_conv0_bn_bwd_wgrad_rows(const float* x_nchw, const void* dz, const void* y, int32_t n, int32_t h, int32_t w,
+                                     int32_t channels, const float* stats, const float* gamma, const float* beta, float inv_scale,
+                                     int32_t accumulate, int32_t sum_rows, void* workspace, size_t workspace_bytes, float* dgamma,
+                                     float* dbeta, float* dw, lfd_stream_t stream);
+
 int lfd_stem_conv0_bn_bwd_wgrad(const float* x_nchw, const void* dz, const void* y, int32_t n, int32_t h, int32_t w, int32_t channels,
                                 const float* stats, const float* gamma, const float* beta, float inv_scale, int32_t accumulate,
                                 void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta, float* dw, lfd_stream_t stream) {
+  return lfd_stem_conv0_bn_bwd_wgrad_rows(x_nchw, dz, y, n, h, w, channels, stats, gamma, beta, inv_scale, accumulate, 0, workspace,
+                                          workspace_bytes, dgamma, dbeta, dw, stream);
+}
+
+int lfd_stem_conv0_bn_bwd_wgrad_rows(const float* x_nchw, const void* dz, const void* y, int32_t n, int32_t h, int32_t w,
+                                     int32_t channels, const float* stats, const float* gamma, const float* beta, float inv_scale,
+                                     int32_t accumulate, int32_t sum_rows, void* workspace, size_t workspace_bytes, float* dgamma,
+                                     float* dbeta, float* dw, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (sum_rows < 0 || sum_rows > kMaxBlocks) return LFD_ERR_INVALID_ARGUMENT;
   if (!x_nchw || !dz || !y || !stats || !gamma || !beta || !dw || !workspace || n < 1 || h < 1 || w < 1 || channels != 64)
     return LFD_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
@@ -1876,11 +1901,13 @@ int lfd_stem_conv0_bn_bwd_wgrad(const float* x_nchw, const void* dz, const void*
   float* partials = reinterpret_cast<float*>(workspace);
   float* sums = partials + (size_t)kMaxBlocks * 2 * kMaxC;
   float* wpart = sums + 2 * kMaxC;                      // the weight gradient's own partial rows: [<= 1024][2048]
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y, (const __half*)nullptr,
-                     vecs, channels, stats, gamma, beta, 1, partials, RowMap{});
-  LFD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, (int)g, channels, inv_scale, accumulate, sums,
-                     dgamma, dbeta);
+  if (!sum_rows) {
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(g), dim3(kThreads), 0, st, (const __half*)dz, (const __half*)y, (const __half*)nullptr,
+                       vecs, channels, stats, gamma, beta, 1, partials, RowMap{});
+    LFD_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(channels), dim3(64), 0, st, partials, sum_rows ? sum_rows : (int)g, channels, inv_scale,
+                     accumulate, sums, dgamma, dbeta);
   LFD_CHECK_LAUNCH();
   const int64_t ksteps = (int64_t)n * ho * ((wo + 15) / 16);
   const int nb = (int)(ksteps / 4 < 1 ? 1 : (ksteps / 4 > 1024 ? 1024 : ksteps / 4));

@@ -197,6 +197,9 @@ _SIGNATURES = {
     'lfd_stem_conv0_train_fwd_bn_stats': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_wgrad': (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _SZ, _P, _P]),
     'lfd_stem_conv0_bn_bwd_wgrad': (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
+    'lfd_stem_conv0_bn_bwd_wgrad_rows': (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _F, _I32, _I32, _P, _SZ, _P, _P, _P, _P]),
+    'lfd_bn_train_bwd_rows_f16': (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _F, _I32, _I32, _P, _SZ, _P, _P, _P, _P]),
+    'lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, C.POINTER(C.c_int32), _P]),
     'lfd_stem_conv_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'lfd_stem_faster_fused_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_head_partial_floats': (_SZ, [C.POINTER(HeadDesc)]),

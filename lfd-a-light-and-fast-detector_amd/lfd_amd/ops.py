@@ -1184,18 +1184,55 @@ def stem_conv0_train_fwd_bn_stats(x_nchw, weight, eps, momentum, running_mean=No
     return y, stats
 
 
-def stem_conv0_bn_bwd_wgrad(x_nchw, dz, y, stats, gamma, beta, inv_scale, dgamma, dbeta, dw):
+def stem_conv0_bn_bwd_wgrad(x_nchw, dz, y, stats, gamma, beta, inv_scale, dgamma, dbeta, dw, sum_rows=0):
     """backward of the first conv unit (conv 3 -> 64 + train-mode BatchNorm + ReLU) from dz = dL/d(output): dgamma / dbeta / dw += ;
-    no dy tensor (lfd_stem_conv0_bn_bwd_wgrad)"""
+    no dy tensor (lfd_stem_conv0_bn_bwd_wgrad).  sum_rows > 0: BatchNorm's partial sums are already in the training workspace
+    (conv1x1_dgrad_bn_bwd_sums left them): no pass over (dz, y) for them."""
     require_cuda(x_nchw, 'stem_conv0_bn_bwd_wgrad')
     x = x_nchw.contiguous().float()
     n, _, h, w_ = x.shape
     c = y.size(3)
     ws = train_workspace(x.device)
     with torch.cuda.device(x.device):
-        check(lib().lfd_stem_conv0_bn_bwd_wgrad(ptr(x), ptr(dz), ptr(y), n, h, w_, c, ptr(stats), ptr(gamma), ptr(beta), float(inv_scale), 1,
-                                                ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta), ptr(dw), stream_ptr()),
-              'lfd_stem_conv0_bn_bwd_wgrad')
+        check(lib().lfd_stem_conv0_bn_bwd_wgrad_rows(ptr(x), ptr(dz), ptr(y), n, h, w_, c, ptr(stats), ptr(gamma), ptr(beta),
+                                                     float(inv_scale), 1, int(sum_rows), ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta),
+                                                     ptr(dw), stream_ptr()), 'lfd_stem_conv0_bn_bwd_wgrad_rows')
+
+
+def conv1x1_dgrad_bn_bwd_sums(dy, w_packed_dgrad, zero_bias, y_unit, unit_stats, unit_gamma, unit_beta):
+    """The data gradient of a 1x1 stride-1 conv 64 -> 64 whose input was the activation of a BatchNorm + ReLU unit (no residual),
+    with that unit's backward sums taken in the conv's epilogue -> (dz, sum_rows): the rows stay in the training workspace for
+    the NEXT call, which must be bn_train_backward_rows / stem_conv0_bn_bwd_wgrad(sum_rows=...) of that unit
+    (lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16)."""
+    _nhwc16(dy, 'conv1x1_dgrad_bn_bwd_sums')
+    _nhwc16(y_unit, 'conv1x1_dgrad_bn_bwd_sums')
+    n, h, w_, c = dy.shape
+    if c != 64 or y_unit.shape != dy.shape:
+        raise RuntimeError('conv1x1_dgrad_bn_bwd_sums: 64 -> 64 channels, dy and y of one shape')
+    d = _lib.ConvDesc(n, h, w_, 64, 64, 1, 1, 0, 0, 0)
+    ws = train_workspace(dy.device)
+    rows = C.c_int32(0)
+    with torch.cuda.device(dy.device):
+        dz = torch.empty_like(dy)
+        check(lib().lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16(C.byref(d), ptr(dy), ptr(dz), ptr(w_packed_dgrad), ptr(zero_bias),
+                                                           ptr(zero_line(dy.device)), ptr(y_unit), ptr(unit_stats), ptr(unit_gamma),
+                                                           ptr(unit_beta), ptr(ws), ws.numel(), C.byref(rows), stream_ptr()),
+              'lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16')
+    return dz, int(rows.value)
+
+
+def bn_train_backward_rows(dz, y, stats, gamma, beta, inv_scale, dgamma, dbeta, sum_rows, accumulate=True):
+    """bn_train_backward (ReLU mask recomputed from y, no g) whose partial sums conv1x1_dgrad_bn_bwd_sums already left in the
+    training workspace -> dy (lfd_bn_train_bwd_rows_f16)"""
+    _nhwc16(dz, 'bn_train_backward_rows')
+    c = y.size(3)
+    ws = train_workspace(y.device)
+    with torch.cuda.device(y.device):
+        dy = torch.empty_like(y)
+        check(lib().lfd_bn_train_bwd_rows_f16(ptr(dz), ptr(y), y.numel() // c, c, ptr(stats), ptr(gamma), ptr(beta), float(inv_scale),
+                                              int(bool(accumulate)), int(sum_rows), ptr(ws), ws.numel(), ptr(dgamma), ptr(dbeta),
+                                              ptr(dy), stream_ptr()), 'lfd_bn_train_bwd_rows_f16')
+    return dy
 
 
 def stem_conv0_wgrad(x_nchw, dy, inv_scale, out=None, accumulate=False):

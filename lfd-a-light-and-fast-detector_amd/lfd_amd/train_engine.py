@@ -787,6 +787,11 @@ def _deferred_units(units, outs):
     LFD_BN_APPLY_IN_CONV=0: every unit stores its activation."""
     if os.environ.get('LFD_BN_APPLY_IN_CONV', '1') != '1':
         return {}
+    return _stem_pairs(units, outs)
+
+
+def _stem_pairs(units, outs):
+    """the structural part of _deferred_units: {producer unit index: index of its only consumer, a 1x1 stride-1 conv unit}"""
     uses = {}
     for vi, v in enumerate(units):
         uses.setdefault(v.src, []).append(vi)
@@ -938,6 +943,13 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         fin.add_wgrad(part, nwg, nblk, xin.size(3), dy.size(3), ks * ks, inv, targets)
 
     grads = {}
+    # stem pairs (_stem_pairs, adjacent units only: nothing else may touch the training workspace in between): the 1x1 conv's
+    # data gradient leaves the BatchNorm backward sums of the unit in front of it behind (LFD_BN_SUMS_IN_DGRAD=0: separate pass)
+    fed = {}
+    if os.environ.get('LFD_BN_SUMS_IN_DGRAD', '1') == '1' and os.environ.get('LFD_CONV_BN_STATS', '1') == '1':
+        fed = {v: u_ for u_, v in _stem_pairs(units, outs).items()
+               if v == u_ + 1 and units[u_].conv.out_channels == 64 and units[v].conv.out_channels == 64}
+    sum_rows = {}
     concat = isinstance(osaved, dict)
     if concat:
         _concat_backward(model.__dict__['_lfd_concat_layout'], osaved, units, acts, tape, packs, opk, zeros, full, starts, store,
@@ -971,11 +983,15 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
                 and os.environ.get('LFD_CONV0_BN_WGRAD', '1') == '1'):
             # the first unit has no data gradient: BatchNorm's sums, then the weight gradient straight from dz and y (no dy tensor)
             ops.stem_conv0_bn_bwd_wgrad(acts[u.src], dz, y, stats, norm.weight.detach(), norm.bias.detach(), inv,
-                                        store.target(norm.weight), store.target(norm.bias), store.target(conv.weight))
+                                        store.target(norm.weight), store.target(norm.bias), store.target(conv.weight),
+                                        sum_rows=sum_rows.get(ui, 0))
             continue
         if isinstance(norm, nn.GroupNorm):
             dy = ops.gn_train_backward(dz, y, z, norm.num_groups, stats, norm.weight.detach(), inv, store.target(norm.weight),
                                        store.target(norm.bias), True)
+        elif ui in sum_rows:
+            dy = ops.bn_train_backward_rows(dz, y, stats, norm.weight.detach(), norm.bias.detach(), inv, store.target(norm.weight),
+                                            store.target(norm.bias), sum_rows[ui])
         else:
             # without a residual input the ReLU mask is recomputed from y (one tensor less to read in both passes)
             dy, g = ops.bn_train_backward(dz, y, z if u.res is not None else None, stats, norm.weight.detach(), inv,
@@ -998,6 +1014,10 @@ def network_backward(model, plan, saved, sizes, dcls, dreg, scale):
         if st == 2 and ks == 3 and cin == 64 and conv.out_channels == 64 and os.environ.get('LFD_DGRAD_S2', '1') == '1':
             # per output parity, 9 tap-products per 2 x 2 pixels instead of 36 and no zero-inserted tensor (csrc/dgrad_s2.hip)
             grads[u.src] = ops.conv3x3s2_dgrad(dy, packs(conv.weight, True), xin.size(1), xin.size(2), residual=grads.get(u.src))
+        elif ui in fed and u.src not in grads:
+            pu, (py, pstats) = units[fed[ui]], tape[fed[ui]]
+            grads[u.src], sum_rows[fed[ui]] = ops.conv1x1_dgrad_bn_bwd_sums(dy, packs(conv.weight, True), zeros(cin), py, pstats,
+                                                                            pu.norm.weight.detach(), pu.norm.bias.detach())
         else:
             if st == 2:
                 dy = ops.zero_insert2(dy, xin.size(1), xin.size(2))

@@ -517,9 +517,13 @@ def test_whole_network_train_forward_backward(name, hw, monkeypatch):
     assert len(trace) == len(units)
     _check_units_against_autograd(units, acts, tape, trace, S)
     # hand-driven serial unit schedule == the autograd node (network_backward: one batched final launch, one rounding per
-    # parameter where the serial schedule rounds once per pyramid level): <= 1e-6 of the tensor's largest entry
+    # parameter where the serial schedule rounds once per pyramid level): <= 1e-6 of the tensor's largest entry.  The stem's
+    # parameters: <= 1e-4 (measured 4.6e-5, a BatchNorm weight) -- in the node the BatchNorm backward sums of the first unit of each stem pair come out of the 1x1
+    # data-gradient conv's epilogue (another fp32 summation order -> the per-channel means of dy move by ~1e-7 relative -> a few
+    # of its fp16 values by one ulp); everything behind the stem in the backward is untouched by that
     for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
-        assert float((pa.grad - store.get(pb)).abs().max()) <= 1e-6 * float(pa.grad.abs().max()) + 1e-30, k
+        tol = 1e-4 if k.startswith('_backbone._stem') else 1e-6
+        assert float((pa.grad - store.get(pb)).abs().max()) <= tol * float(pa.grad.abs().max()) + 1e-30, k
     # end to end vs fp32 autograd over the same unit graph with the HIP path's own ReLU masks (see _mask_replay_reference):
     # backbone, neck, the GroupNorm towers shared by the pyramid levels, output convs and Scale -- tight
     ref, leaves = _mask_replay_reference(units, acts, x)
@@ -640,7 +644,9 @@ def test_network_schedules_equal_the_serial_unit_schedule(name, shape):
             a, b = gs[k], gp[k]
             e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-20))
             worst = max(worst, e)
-            assert e <= 1e-6, (k, e)
+            # (the stem: the node takes the BatchNorm backward sums of the first unit of each pair in the 1x1 data-gradient conv's
+            #  epilogue -- another fp32 summation order, a few fp16 values of dy one ulp apart -- see the whole-network test)
+            assert e <= (1e-4 if k.startswith('_backbone._stem') else 1e-6), (k, e)
         res.append(gp)
         print('%s level by level: worst relative gradient difference to the serial schedule %.2e' % (name, worst))
     for k in gs:
@@ -753,3 +759,62 @@ def test_network_with_and_without_stored_stem_activations_is_bit_identical(monke
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert len(res[0][2]) == len(res[1][2]) > 50
     assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+
+
+@pytest.mark.parametrize('nhw', [(2, 37, 53), (1, 8, 8), (3, 130, 70), (2, 160, 160)])
+def test_batchnorm_backward_sums_in_the_data_gradient_convs_epilogue(nhw):
+    """lfd_conv1x1_dgrad_bn_bwd_sums_nhwc_f16 + lfd_bn_train_bwd_rows_f16 (round 4): the 1x1 data-gradient conv of a stem pair
+    leaves the BatchNorm backward sums of the unit in front of it behind -- against the plain conv followed by lfd_bn_train_bwd_f16:
+    dz bit for bit (the same conv), dgamma / dbeta to fp32 summation order, dy within an fp16 ulp."""
+    n, h, w = nhw
+    c = 64
+    g = torch.Generator(device='cuda').manual_seed(9 + h)
+    y_u = (torch.randn(n, h, w, c, generator=g, device='cuda') * 1.2 + 0.1).half()
+    stats = ops.bn_train_stats(y_u, 1e-5, 0.1, None, None)
+    gamma = torch.empty(c, device='cuda').uniform_(0.5, 1.5)
+    beta = torch.empty(c, device='cuda').normal_(0, 0.3)
+    dyv = (torch.randn(n, h, w, c, generator=g, device='cuda') * 0.5).half()
+    wt = torch.randn(c, c, 1, 1, generator=g, device='cuda') * 0.15
+    wp = ops.pack_conv_weight_train(wt, data_gradient=True)
+    zb = torch.zeros(c, device='cuda')
+    inv = 1.0 / 64
+    dz_a = ops.conv2d_nhwc(dyv, wp, zb, c, c, 1, 1, False)
+    dga, dba = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    dy_a, _ = ops.bn_train_backward(dz_a, y_u, None, stats, gamma, inv, dga, dba, want_g=False, accumulate=True, relu=True, beta=beta)
+    dz_b, rows = ops.conv1x1_dgrad_bn_bwd_sums(dyv, wp, zb, y_u, stats, gamma, beta)
+    dgb, dbb = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+    dy_b = ops.bn_train_backward_rows(dz_b, y_u, stats, gamma, beta, inv, dgb, dbb, rows)
+    torch.cuda.synchronize()
+    assert rows >= 1 and float(dz_a.float().abs().max()) > 0 and torch.equal(dz_a, dz_b)
+    assert _rel(dgb, dga) < 2e-6 and _rel(dbb, dba) < 2e-6
+    tol = dy_a.float().abs() * 2.0 ** -10 + 2e-6 * float(dy_a.float().abs().max()) + 1e-7
+    assert bool(((dy_a.float() - dy_b.float()).abs() <= tol).all())
+    assert float((dy_a != dy_b).float().mean()) < 2e-3
+
+
+def test_network_with_and_without_epilogue_sums_agree(monkeypatch):
+    """LFD_BN_SUMS_IN_DGRAD=0 (every BatchNorm backward takes its own sums pass) against the default: the same logits, parameter
+    gradients to fp32 summation order"""
+    from lfd_amd import configs, train_engine as TE
+    res = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LFD_BN_SUMS_IN_DGRAD', flag)
+        torch.manual_seed(0)
+        m = configs.build_model('WIDERFACE_LFD_S')
+        configs.perturb_weights(m)
+        m.train().cuda()
+        units, outs = TE.build_network(m)
+        plan = (units, outs, m._num_heads)
+        x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(1)).cuda()
+        for p in m.parameters():
+            p.grad = None
+        cls, reg, sizes, saved = TE.network_forward(m, plan, x)
+        gc = torch.randn(cls.shape, generator=torch.Generator().manual_seed(2)).cuda() * 1e-2
+        gr = torch.randn(reg.shape, generator=torch.Generator().manual_seed(3)).cuda() * 1e-2
+        TE.network_backward(m, plan, saved, sizes, gc, gr, 64.0)
+        torch.cuda.synchronize()
+        res.append((cls.clone(), [(n_, p.grad.clone()) for n_, p in m.named_parameters() if p.grad is not None]))
+        del m
+    assert torch.equal(res[0][0], res[1][0])
+    worst = max((_rel(a, b), n_) for (n_, a), (_, b) in zip(res[0][1], res[1][1]))
+    assert worst[0] < 2e-5, worst
