@@ -792,6 +792,18 @@ def _deferred_units(units, outs):
 
 def _stem_pairs(units, outs):
     """the structural part of _deferred_units: {producer unit index: index of its only consumer, a 1x1 stride-1 conv unit}"""
+    out = {}
+    for ui, vi in _single_consumers(units, outs).items():
+        v = units[vi]
+        if (isinstance(v.norm, nn.BatchNorm2d) and v.conv.kernel_size[0] == 1 and v.conv.stride[0] == 1
+                and v.conv.in_channels == 64 and v.conv.out_channels % 32 == 0):
+            out[ui] = vi
+    return out
+
+
+def _single_consumers(units, outs):
+    """{index of a BatchNorm + ReLU unit without residual: index of the ONE unit that reads its activation} (backbone / neck
+    units only; activations that are also pyramid taps, residual inputs or output-conv inputs do not qualify)"""
     uses = {}
     for vi, v in enumerate(units):
         uses.setdefault(v.src, []).append(vi)
@@ -807,8 +819,7 @@ def _stem_pairs(units, outs):
         if len(cons) != 1 or cons[0] < 0:
             continue
         v = units[cons[0]]
-        if (v.level is None and isinstance(v.norm, nn.BatchNorm2d) and v.conv.kernel_size[0] == 1 and v.conv.stride[0] == 1
-                and v.conv.in_channels == 64 and v.conv.out_channels % 32 == 0 and not v.first):
+        if v.level is None and not v.first:
             out[ui] = cons[0]
     return out
 
