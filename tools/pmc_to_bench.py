@@ -25,6 +25,7 @@ out = {
     'conv3x3_s2_64to128+downsample1x1s2 (k_conv)': wavg(['k_conv<cin=64,k=3,s=2,nct=4,ds>']),
     'conv3x3_s1_128to128 (k_conv)': wavg(['k_conv<cin=128,k=3,s=1,nct=4>', 'k_conv<cin=128,k=3,s=1,nct=4,res>']),
     'conv3x3_s1_128to128 small map, split-K (k_conv128_splitk)': wavg(['k_conv128_splitk']),
+    'fasterblock128_fused_2x_conv3x3_s1_128to128 small map (k_block128)': wavg(['k_block128']),
 }
 if fwd:   # the head is one bench "launch" = all k_head / k_gn_finalize launches of a forward
     out['neck+head 3-pass GN recompute (k_head2 x3 + k_gn_finalize x2)'] = round(sum(
