@@ -48,9 +48,12 @@ __global__ __launch_bounds__(kThreads) void k_out_split(Args a) {
     const float mul = g.scale ? *g.scale : 1.f;
     const int64_t total = pixels * g.channels;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-      const int64_t px = i / g.channels;
-      const int j = (int)(i - px * g.channels);
-      const int64_t img = px / a.hw, p = px - img * a.hw;
+      // 32-bit index arithmetic (fill() refuses n * hw * 64 >= 2^31): as 64-bit divisions these lines were ~400 instructions per element
+      const unsigned iu = (unsigned)i;
+      const unsigned pxu = iu / (unsigned)g.channels;
+      const int j = (int)(iu - pxu * (unsigned)g.channels);
+      const unsigned imgu = pxu / (unsigned)a.hw;
+      const int64_t img = imgu, p = pxu - imgu * (unsigned)a.hw;
       const float v = __half2float(a.y[(img * a.y_total + a.y_point0 + p) * kRows + g.row0 + j]);
       g.out[(img * a.points_total + a.point0 + p) * g.channels + j] = g.scale ? v * mul : v;
     }
@@ -77,8 +80,8 @@ __global__ __launch_bounds__(kThreads) void k_out_grad(Args a) {
   float acc_d[8], acc_r[8];
   for (int e = 0; e < 8; ++e) acc_d[e] = acc_r[e] = 0.f;
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
-    const int64_t px = v >> 3;
-    const int64_t img = px / a.hw, p = px - img * a.hw;
+    const unsigned pxu = (unsigned)(v >> 3), imgu = pxu / (unsigned)a.hw;       // 32-bit, see k_out_split
+    const int64_t img = imgu, p = pxu - imgu * (unsigned)a.hw;
     const int64_t yrow = img * a.y_total + a.y_point0 + p;
     union { uint4 u; _Float16 h[8]; } o;
     o.u = make_uint4(0, 0, 0, 0);
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(128) void k_out_grad_final(Args a, int nblocks) {
 bool fill(Args& a, const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0, const lfd_head_out_seg_t* segs,
           int32_t nsegs) {
   if (!y || !segs || n < 1 || hw < 1 || nsegs < 1 || nsegs > 2 || point0 < 0 || point0 + hw > points_total) return false;
+  if ((int64_t)n * hw * kRows >= ((int64_t)1 << 31)) return false;       // the kernels index pixels and elements in 32 bits
   a.y = (const __half*)y; a.n = n; a.hw = hw; a.points_total = points_total; a.point0 = point0; a.nsegs = nsegs;
   a.y_total = hw; a.y_point0 = 0;
   for (int s = 0; s < nsegs; ++s) {

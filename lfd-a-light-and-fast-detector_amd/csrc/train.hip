@@ -366,12 +366,15 @@ __global__ __launch_bounds__(kThreads) void k_zero_insert2(const __half* __restr
   const int groups = c >> 3;
   const int64_t vecs = (int64_t)n * ho * wo * groups;
   for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
-    const int cg = (int)(v % groups);
-    int64_t p = v / groups;
-    const int x = (int)(p % wo);
-    p /= wo;
-    const int yy = (int)(p % ho);
-    const int img = (int)(p / ho);
+    // 32-bit index arithmetic (the host refuses 2^31 vectors; channel counts are powers of two): lesson 38
+    const unsigned vu = (unsigned)v;
+    const int cg = (int)(vu & (unsigned)(groups - 1));
+    unsigned p = vu / (unsigned)groups;
+    const unsigned pw = p / (unsigned)wo;
+    const int x = (int)(p - pw * (unsigned)wo);
+    const unsigned ph = pw / (unsigned)ho;
+    const int yy = (int)(pw - ph * (unsigned)ho);
+    const int img = (int)ph;
     uint4 val = make_uint4(0, 0, 0, 0);
     if (!(x & 1) && !(yy & 1) && (yy >> 1) < hi && (x >> 1) < wi)
       val = reinterpret_cast<const uint4*>(in)[(((int64_t)img * hi + (yy >> 1)) * wi + (x >> 1)) * groups + cg];
@@ -799,11 +802,13 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
   for (int64_t p0 = wave0; p0 < total; p0 += stride) {
     const int64_t p = p0 + (l & 31);
     const bool pv = p < total;
-    const int64_t pc = pv ? p : 0;
-    const int ox = (int)(pc % wo);
-    const int64_t q = pc / wo;
-    const int oy = (int)(q % ho);
-    const int img = (int)(q / ho);
+    // 32-bit index arithmetic (the host refuses maps of 2^31 elements; lesson 38)
+    const unsigned pc = pv ? (unsigned)p : 0u;
+    const unsigned qq = pc / (unsigned)wo;
+    const int ox = (int)(pc - qq * (unsigned)wo);
+    const unsigned im = qq / (unsigned)ho;
+    const int oy = (int)(qq - im * (unsigned)ho);
+    const int img = (int)im;
     const float* xb = x + ((int64_t)img * 3 * h + 2 * oy) * w + 2 * ox;
     h8 b[2];
 #pragma unroll
@@ -968,11 +973,12 @@ __global__ __launch_bounds__(kThreads) void k_conv0_wgrad_mfma(const float* __re
     for (int u = 0; u < U; ++u) {
       const int64_t s = s0 + u * S;
       const bool sv = s < total;
-      const int64_t sc = sv ? s : 0;
-      const int seg = (int)(sc % segs);
-      const int64_t q = sc / segs;
-      const int oy = (int)(q % ho);
-      const int img = (int)(q / ho);
+      const unsigned sc = sv ? (unsigned)s : 0u;          // 32-bit index arithmetic, see k_conv0_fwd_mfma
+      const unsigned qq = sc / (unsigned)segs;
+      const int seg = (int)(sc - qq * (unsigned)segs);
+      const unsigned im = qq / (unsigned)ho;
+      const int oy = (int)(qq - im * (unsigned)ho);
+      const int img = (int)im;
       const int ox0 = seg * 16;
       // dy[16 px][64 ch] (zero beyond the row / channel range): 128 16-byte chunks, 2 per lane
 #pragma unroll
@@ -1650,6 +1656,7 @@ int lfd_zero_insert2_nhwc_f16(const void* in, int32_t n, int32_t hi, int32_t wi,
       !channels_ok(channels))
     return LFD_ERR_INVALID_ARGUMENT;
   const int64_t vecs = (int64_t)n * ho * wo * (channels / 8);
+  if (vecs >= ((int64_t)1 << 31)) return LFD_ERR_UNSUPPORTED;      // the kernel indexes vectors in 32 bits
   hipLaunchKernelGGL(k_zero_insert2, dim3(grid_for_vecs(vecs)), dim3(kThreads), 0, st, (const __half*)in, n, hi, wi,
                      channels, ho, wo, (__half*)out);
   LFD_CHECK_LAUNCH();
@@ -1819,6 +1826,7 @@ static int conv0_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32
   if (!x_nchw || !weight_oihw || !y || n < 1 || h < 1 || w < 1 || (channels != 32 && channels != 64))
     return LFD_ERR_INVALID_ARGUMENT;
   const int use_valu = lfd_tune(LFD_TUNE_CONV0_VALU);
+  if ((int64_t)n * 3 * h * w >= ((int64_t)1 << 31)) return LFD_ERR_UNSUPPORTED;   // 32-bit pixel / element indices in the kernels
   if (!use_valu) {
     const int64_t groups = ((int64_t)n * ((h + 1) / 2) * ((w + 1) / 2) + 127) / 128;   // 4 waves x 32 pixels per block pass
     const unsigned blocks = (unsigned)(groups < 2048 ? groups : 2048);   // (2048 rows x 2 x 64 floats = half the partials area)
@@ -1847,6 +1855,7 @@ int lfd_stem_conv0_wgrad(const float* x_nchw, const void* dy, int32_t n, int32_t
   const int use_valu = lfd_tune(LFD_TUNE_CONV0_VALU);
   if (!use_valu) {
     const int64_t ksteps = (int64_t)n * ((h + 1) / 2) * (((w + 1) / 2 + 15) / 16);
+    if (ksteps >= ((int64_t)1 << 31) || (int64_t)n * 3 * h * w >= ((int64_t)1 << 31)) return LFD_ERR_UNSUPPORTED;     // 32-bit indices in the kernel
     const int nb = (int)(ksteps / 4 < 1 ? 1 : (ksteps / 4 > 1024 ? 1024 : ksteps / 4));
     hipLaunchKernelGGL(k_conv0_wgrad_mfma<false>, dim3(nb), dim3(kThreads), 0, st, x_nchw, (const __half*)dy, n, h, w, channels,
                        partials, Conv0BnArgs{});
