@@ -762,6 +762,8 @@ __device__ __forceinline__ h8 tr_frag(const char* base, uint32_t off0, uint32_t 
   return u.h;
 }
 
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));      // three consecutive floats at any 4-byte boundary
+
 struct TapTab {
   int off[16];     // ci*h*w + (ky-1)*w + (kx-1), relative to (2*oy, 2*ox)
   int kyx[16];     // (ky << 8) | kx, or -1 for the padding taps >= 27
@@ -774,7 +776,7 @@ __device__ __forceinline__ void tap_of(int t, int h, int w, int& off, int& kyx) 
   kyx = (ky << 8) | kx;
 }
 
-__global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __restrict__ x, int n, int h, int w, int c,
+__global__ __launch_bounds__(kThreads, 3) void k_conv0_fwd_mfma(const float* __restrict__ x, int n, int h, int w, int c,
                                                             const float* __restrict__ wt, __half* __restrict__ y,
                                                             float* stat_partials) {
   __shared__ __attribute__((aligned(16))) uint4 s_stage[kThreads / 64][256];     // per wave: 32 pixels x 128 B
@@ -811,15 +813,46 @@ __global__ __launch_bounds__(kThreads) void k_conv0_fwd_mfma(const float* __rest
     const int img = (int)im;
     const float* xb = x + ((int64_t)img * 3 * h + 2 * oy) * w + 2 * ox;
     h8 b[2];
+    // WIDE path (groups without a lane on the left / right image border: 8 of 10 at 640 columns): the three kx taps of an image
+    // row are 12 consecutive bytes -- six 12-byte loads per lane cover its 16 taps (rows r = ci * 3 + ky: half 0 of the wave
+    // needs rows 0 1 2 5 6 7, half 1 rows 2 3 4 5 8) instead of sixteen 4-byte gathers.  The vector memory path spends ~one clock
+    // per lane ADDRESS on these stride-2 accesses (the kernel sat at ~52 clocks per load instruction and CU whatever its
+    // occupancy or VALU count, lesson 42): with a third of the load instructions a third wave per SIMD pays too
+    // (__launch_bounds__(256, 3)): 197 -> 179 (wide loads) -> 158 us (+ occupancy).  Same values, same tap order.
+    const bool lr_inner = pv && ox > 0 && 2 * ox + 1 < w;
+    if (__builtin_amdgcn_ballot_w64(pv && !lr_inner) == 0) {
+      f3u T[6];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int ky = tab.kyx[s] >> 8, kx = tab.kyx[s] & 255;
-      const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
-      const bool ok = pv && tab.kyx[s] >= 0 && iy >= 0 && iy < h && ix >= 0 && ix < w;
-      // unconditional load from a safe address + select: `ok ? xb[off] : 0` compiles to a branch around every load, and the
-      // 16 loads of a pixel then complete one after the other instead of together
-      const float raw = xb[ok ? tab.off[s] : 0];
-      b[s >> 3][s & 7] = (_Float16)(ok ? raw : 0.f);
+      for (int sl = 0; sl < 6; ++sl) {
+        constexpr int R0[6] = {0, 1, 2, 5, 6, 7}, R1[6] = {2, 3, 4, 5, 8, 8};
+        const int r = hk ? R1[sl] : R0[sl];
+        const int ci = r / 3, ky = r - ci * 3;
+        const int iy = 2 * oy + ky - 1;
+        const bool rv = pv && iy >= 0 && iy < h;
+        const float* src = rv ? xb + (ci * h + ky - 1) * w - 1 : x;      // (unconditional load from a safe address + select)
+        const f3u v = *reinterpret_cast<const f3u*>(src);
+        T[sl] = rv ? v : f3u{0.f, 0.f, 0.f};
+      }
+      // tap s of half 0 / half 1 = T[slot][kx]; taps 27..31 (half 1, s >= 11) are padding
+      constexpr int S0[16] = {0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 5, 5}, K0[16] = {0, 1, 2, 0, 1, 2, 0, 1, 1, 2, 0, 1, 2, 0, 1, 2};
+      constexpr int S1[16] = {0, 1, 1, 1, 2, 2, 2, 3, 4, 4, 4, 4, 4, 4, 4, 4}, K1[16] = {2, 0, 1, 2, 0, 1, 2, 0, 0, 1, 2, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float v0 = T[S0[s]][K0[s]];
+        const float v1 = s < 11 ? T[S1[s]][K1[s]] : 0.f;
+        b[s >> 3][s & 7] = (_Float16)(hk ? v1 : v0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int ky = tab.kyx[s] >> 8, kx = tab.kyx[s] & 255;
+        const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+        const bool ok = pv && tab.kyx[s] >= 0 && iy >= 0 && iy < h && ix >= 0 && ix < w;
+        // unconditional load from a safe address + select: `ok ? xb[off] : 0` compiles to a branch around every load, and the
+        // 16 loads of a pixel then complete one after the other instead of together
+        const float raw = xb[ok ? tab.off[s] : 0];
+        b[s >> 3][s & 7] = (_Float16)(ok ? raw : 0.f);
+      }
     }
     if (c == 64) {
       // 64 output channels: the wave holds the whole 128-byte line of each of its 32 pixels.  Straight from the accumulator
