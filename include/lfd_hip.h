@@ -708,6 +708,21 @@ LFD_API int lfd_head_out_grad_concat_f16(const void* y_concat, int32_t n, int32_
                                  const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy_concat, void* workspace,
                                  size_t workspace_bytes, lfd_stream_t stream);
 
+/* ... and ALL pyramid levels of one (shared) output conv in one launch each (round 4): the per-level calls of the two `_concat`
+ * entry points above, with the levels as blockIdx.y -- every level keeps its own block count and the final stage adds the levels
+ * in level order, so outputs, dy, dbias and dscale are those of the per-level call sequence, bit for bit.  `levels`: host array. */
+typedef struct {
+  int32_t hw;                      /* pixels per image of the level */
+  int32_t nsegs;
+  int64_t point0;                  /* first point of the level inside an image of the concatenated tensors */
+  lfd_head_out_seg_t segs[2];
+} lfd_head_out_level_t;
+LFD_API int lfd_head_out_split_levels_f16(const void* y_concat, int32_t n, int64_t points_total, const lfd_head_out_level_t* levels,
+                                  int32_t nlevels, lfd_stream_t stream);
+LFD_API int lfd_head_out_grad_levels_f16(const void* y_concat, int32_t n, int64_t points_total, const lfd_head_out_level_t* levels,
+                                 int32_t nlevels, float loss_scale, void* dy_concat, void* workspace, size_t workspace_bytes,
+                                 lfd_stream_t stream);
+
 /* first stem conv (3 -> channels, 3x3 stride 2 pad 1, lfd_resnet.py:358,:378) on the NCHW fp32 image batch:
  * forward -> y NHWC fp16 (pre-norm), and its weight gradient (OIHW fp32); channels in {32, 64} */
 LFD_API int lfd_stem_conv0_train_fwd(const float* x_nchw, int32_t n, int32_t h, int32_t w, int32_t channels,

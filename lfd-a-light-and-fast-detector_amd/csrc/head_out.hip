@@ -40,14 +40,14 @@ struct Args {
   float* partials;      // [blocks][2][64]
 };
 
-__global__ __launch_bounds__(kThreads) void k_out_split(Args a) {
+__device__ __forceinline__ void out_split_body(const Args& a, int bx, int nbx) {
   // one thread per (pixel, segment channel): tiny tensors, 2-byte gathers from the 128-byte line of the pixel
   const int64_t pixels = (int64_t)a.n * a.hw;
   for (int s = 0; s < a.nsegs; ++s) {
     const Seg g = a.seg[s];
     const float mul = g.scale ? *g.scale : 1.f;
     const int64_t total = pixels * g.channels;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    for (int64_t i = (int64_t)bx * kThreads + threadIdx.x; i < total; i += (int64_t)nbx * kThreads) {
       // 32-bit index arithmetic (fill() refuses n * hw * 64 >= 2^31): as 64-bit divisions these lines were ~400 instructions per element
       const unsigned iu = (unsigned)i;
       const unsigned pxu = iu / (unsigned)g.channels;
@@ -60,9 +60,23 @@ __global__ __launch_bounds__(kThreads) void k_out_split(Args a) {
   }
 }
 
+__global__ __launch_bounds__(kThreads) void k_out_split(Args a) { out_split_body(a, blockIdx.x, gridDim.x); }
+
+// all pyramid levels of one output conv in ONE launch (blockIdx.y = level; a level uses its own block count, so the values --
+// and for the gradient the partial rows and their sums -- are those of the per-level launches, bit for bit)
+struct LevelsArgs {
+  Args lv[LFD_MAX_LEVELS];
+  int nblocks[LFD_MAX_LEVELS];
+  int nlev;
+};
+__global__ __launch_bounds__(kThreads) void k_out_split_levels(LevelsArgs L) {
+  const int l = blockIdx.y;
+  if ((int)blockIdx.x < L.nblocks[l]) out_split_body(L.lv[l], blockIdx.x, L.nblocks[l]);
+}
+
 // thread = (pixel, 16-byte chunk of its dy line); the chunk index is the same in every trip of the grid-stride loop, so
 // 8 + 8 sums per thread last the walk
-__global__ __launch_bounds__(kThreads) void k_out_grad(Args a) {
+__device__ __forceinline__ void out_grad_body(const Args& a, int bx, int nbx) {
   __shared__ float red[kThreads][17];
   const int64_t vecs = (int64_t)a.n * a.hw * (kRows / 8);
   const int ck = threadIdx.x & 7;
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void k_out_grad(Args a) {
     if (a.seg[s].scale) mul[s] = *a.seg[s].scale;
   float acc_d[8], acc_r[8];
   for (int e = 0; e < 8; ++e) acc_d[e] = acc_r[e] = 0.f;
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < vecs; v += (int64_t)gridDim.x * kThreads) {
+  for (int64_t v = (int64_t)bx * kThreads + threadIdx.x; v < vecs; v += (int64_t)nbx * kThreads) {
     const unsigned pxu = (unsigned)(v >> 3), imgu = pxu / (unsigned)a.hw;       // 32-bit, see k_out_split
     const int64_t img = imgu, p = pxu - imgu * (unsigned)a.hw;
     const int64_t yrow = img * a.y_total + a.y_point0 + p;
@@ -104,8 +118,13 @@ __global__ __launch_bounds__(kThreads) void k_out_grad(Args a) {
     const int q = threadIdx.x >> 6, r = threadIdx.x & 63;
     float s = 0.f;
     for (int t = r >> 3; t < kThreads; t += 8) s += red[t][q * 8 + (r & 7)];
-    a.partials[((size_t)blockIdx.x * 2 + q) * kRows + r] = s;
+    a.partials[((size_t)bx * 2 + q) * kRows + r] = s;
   }
+}
+__global__ __launch_bounds__(kThreads) void k_out_grad(Args a) { out_grad_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(kThreads) void k_out_grad_levels(LevelsArgs L) {
+  const int l = blockIdx.y;
+  if ((int)blockIdx.x < L.nblocks[l]) out_grad_body(L.lv[l], blockIdx.x, L.nblocks[l]);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -130,7 +149,7 @@ __device__ __forceinline__ double column_sum(const float* partials, int nblocks,
 }
 
 // block = output row r; wave 0: dbias of the row; wave 1 of a Scale segment's first row: dscale over the segment's rows
-__global__ __launch_bounds__(128) void k_out_grad_final(Args a, int nblocks) {
+__device__ __forceinline__ void out_grad_final_body(const Args& a, int nblocks) {
   const int q = threadIdx.x >> 6, r = blockIdx.x;
   for (int k = 0; k < a.nsegs; ++k) {
     const Seg& g = a.seg[k];
@@ -145,6 +164,12 @@ __global__ __launch_bounds__(128) void k_out_grad_final(Args a, int nblocks) {
       if ((threadIdx.x & 63) == 0) *g.dscale += (float)t;
     }
   }
+}
+
+__global__ __launch_bounds__(128) void k_out_grad_final(Args a, int nblocks) { out_grad_final_body(a, nblocks); }
+// the levels one after the other in level order: the += into the shared biases happens in the order of the per-level launches
+__global__ __launch_bounds__(128) void k_out_grad_final_levels(LevelsArgs L) {
+  for (int l = 0; l < L.nlev; ++l) out_grad_final_body(L.lv[l], L.nblocks[l]);
 }
 
 bool fill(Args& a, const void* y, int32_t n, int32_t hw, int64_t points_total, int64_t point0, const lfd_head_out_seg_t* segs,
@@ -223,6 +248,68 @@ int lfd_head_out_grad_concat_f16(const void* y_concat, int32_t n, int32_t hw, in
                                  const lfd_head_out_seg_t* segs, int32_t nsegs, float loss_scale, void* dy_concat, void* workspace,
                                  size_t workspace_bytes, lfd_stream_t stream) {
   return out_grad(y_concat, n, hw, points_total, point0, segs, nsegs, loss_scale, dy_concat, workspace, workspace_bytes, true, stream);
+}
+
+static int fill_levels(LevelsArgs& L, const void* y_concat, int32_t n, int64_t points_total, const lfd_head_out_level_t* levels,
+                       int32_t nlevels) {
+  if (!levels || nlevels < 1 || nlevels > LFD_MAX_LEVELS) return LFD_ERR_INVALID_ARGUMENT;
+  L.nlev = nlevels;
+  for (int l = 0; l < nlevels; ++l) {
+    if (!fill(L.lv[l], y_concat, n, levels[l].hw, points_total, levels[l].point0, levels[l].segs, levels[l].nsegs))
+      return LFD_ERR_INVALID_ARGUMENT;
+    L.lv[l].y_total = points_total; L.lv[l].y_point0 = levels[l].point0;
+  }
+  return LFD_OK;
+}
+
+int lfd_head_out_split_levels_f16(const void* y_concat, int32_t n, int64_t points_total, const lfd_head_out_level_t* levels,
+                                  int32_t nlevels, lfd_stream_t stream) {
+  LevelsArgs L{};
+  const int rc = fill_levels(L, y_concat, n, points_total, levels, nlevels);
+  if (rc != LFD_OK) return rc;
+  int mx = 1;
+  for (int l = 0; l < nlevels; ++l) {
+    int maxc = 0;
+    for (int s = 0; s < L.lv[l].nsegs; ++s) {
+      if (!L.lv[l].seg[s].out) return LFD_ERR_INVALID_ARGUMENT;
+      if (L.lv[l].seg[s].channels > maxc) maxc = L.lv[l].seg[s].channels;
+    }
+    int64_t b = ((int64_t)n * L.lv[l].hw * maxc + kThreads - 1) / kThreads;       // the block count of lfd_head_out_split_f16
+    if (b > 1024) b = 1024;
+    L.nblocks[l] = (int)b;
+    if (b > mx) mx = (int)b;
+  }
+  hipLaunchKernelGGL(k_out_split_levels, dim3((unsigned)mx, (unsigned)nlevels), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), L);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+int lfd_head_out_grad_levels_f16(const void* y_concat, int32_t n, int64_t points_total, const lfd_head_out_level_t* levels,
+                                 int32_t nlevels, float loss_scale, void* dy_concat, void* workspace, size_t workspace_bytes,
+                                 lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  LevelsArgs L{};
+  const int rc = fill_levels(L, y_concat, n, points_total, levels, nlevels);
+  if (rc != LFD_OK) return rc;
+  if (!dy_concat || !workspace || !lfd_aligned16(dy_concat)) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < (size_t)nlevels * kMaxBlocks * 2 * kRows * sizeof(float)) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  int mx = 1;
+  for (int l = 0; l < nlevels; ++l) {
+    Args& a = L.lv[l];
+    for (int s = 0; s < a.nsegs; ++s)
+      if (!a.seg[s].grad || (a.seg[s].dscale && !a.seg[s].scale)) return LFD_ERR_INVALID_ARGUMENT;
+    a.dy = (__half*)dy_concat; a.loss_scale = loss_scale;
+    a.partials = reinterpret_cast<float*>(workspace) + (size_t)l * kMaxBlocks * 2 * kRows;
+    int64_t b = ((int64_t)n * a.hw * (kRows / 8) + kThreads - 1) / kThreads;       // the block count of lfd_head_out_grad_f16
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    L.nblocks[l] = (int)b;
+    if (b > mx) mx = (int)b;
+  }
+  hipLaunchKernelGGL(k_out_grad_levels, dim3((unsigned)mx, (unsigned)nlevels), dim3(kThreads), 0, st, L);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_out_grad_final_levels, dim3(kRows), dim3(128), 0, st, L);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
 }
 
 }  // extern "C"

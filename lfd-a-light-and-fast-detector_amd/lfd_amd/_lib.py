@@ -46,6 +46,11 @@ class HeadOutSeg(C.Structure):
                 ('dscale', C.c_void_p), ('channels', C.c_int32), ('row0', C.c_int32)]
 
 
+class HeadOutLevel(C.Structure):
+    """lfd_head_out_level_t"""
+    _fields_ = [('hw', C.c_int32), ('nsegs', C.c_int32), ('point0', C.c_int64), ('segs', HeadOutSeg * 2)]
+
+
 class HeadDesc(C.Structure):
     """lfd_head_desc_t"""
     _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32), ('level_hw', C.c_int32 * MAX_LEVELS),
@@ -182,6 +187,8 @@ _SIGNATURES = {
     'lfd_bn_train_bwd_from_f16': (C.c_int, [_P, _I64, _I64, _P, _I32, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_head_out_split_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _P]),
     'lfd_head_out_grad_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),
+    'lfd_head_out_split_levels_f16': (C.c_int, [_P, _I32, _I64, C.POINTER(HeadOutLevel), _I32, _P]),
+    'lfd_head_out_grad_levels_f16': (C.c_int, [_P, _I32, _I64, C.POINTER(HeadOutLevel), _I32, _F, _P, _P, _SZ, _P]),
     'lfd_gn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_zero_insert2_nhwc_f16': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     'lfd_conv3x3s2_dgrad_nhwc_f16': (C.c_int, [_I32, _I32, _I32, _P, _P, _P, _P, _P]),

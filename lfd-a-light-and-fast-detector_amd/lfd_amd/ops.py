@@ -1116,6 +1116,39 @@ def head_out_grad_concat(y_concat, hw, segs, grads, point0, loss_scale, dy_conca
               'lfd_head_out_grad_concat_f16')
 
 
+def _head_out_levels(levels, field):
+    """levels: [(hw, point0, segs, tensors)] -> (lfd_head_out_level_t array, keep-alive list)"""
+    arr = (_lib.HeadOutLevel * len(levels))()
+    for l, (hw, point0, segs, tensors) in enumerate(levels):
+        arr[l].hw, arr[l].nsegs, arr[l].point0 = int(hw), len(segs), int(point0)
+        sa = _head_out_segs(segs, field, tensors)
+        for i in range(len(segs)):
+            arr[l].segs[i] = sa[i]
+    return arr
+
+
+def head_out_split_levels(y_concat, levels):
+    """head_out_split_concat for ALL pyramid levels of one output conv in one launch; levels: [(hw, point0, segs, outs)]
+    (lfd_head_out_split_levels_f16; bit-identical to the per-level calls)"""
+    require_cuda(y_concat, 'head_out_split_levels')
+    arr = _head_out_levels(levels, 'out')
+    with torch.cuda.device(y_concat.device):
+        check(lib().lfd_head_out_split_levels_f16(ptr(y_concat), y_concat.size(0), levels[0][3][0].size(1), arr, len(levels),
+                                                  stream_ptr()), 'lfd_head_out_split_levels_f16')
+
+
+def head_out_grad_levels(y_concat, levels, loss_scale, dy_concat):
+    """head_out_grad_concat for ALL pyramid levels in one launch (+ one final launch): levels: [(hw, point0, segs, grads)], segs
+    with their dbias / dscale targets (lfd_head_out_grad_levels_f16; bit-identical to the per-level calls)"""
+    require_cuda(y_concat, 'head_out_grad_levels')
+    arr = _head_out_levels(levels, 'grad')
+    ws = train_workspace(y_concat.device)
+    with torch.cuda.device(y_concat.device):
+        check(lib().lfd_head_out_grad_levels_f16(ptr(y_concat), y_concat.size(0), levels[0][3][0].size(1), arr, len(levels),
+                                                 float(loss_scale), ptr(dy_concat), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_head_out_grad_levels_f16')
+
+
 def head_out_split(y, segs, outs, point0):
     """y [n,h,w,64] fp16 (a level's padded output conv) -> outs[i][:, point0:point0+h*w, :] = float(y[..., rows of segment i])
     (* scale); outs[i]: the level-concatenated [n, P, channels] fp32 tensors.  segs: dicts channels, row0, scale (tensor or

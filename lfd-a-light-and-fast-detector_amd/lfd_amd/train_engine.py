@@ -716,9 +716,15 @@ def _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats,
         wp, bp, wpk, _ = _out_pack(o0, opk)
         xin = _as_image(A[sp])
         y = ops.conv2d_nhwc(xin, wpk, bp, xin.size(3), wp.size(0), 1, 1, False).view(n, ptot, wp.size(0))
+        lv = []
         for l in range(len(sizes)):
             segs = _out_segs(cl['lv_outs'][l][j])
-            ops.head_out_split_concat(y, seg_hw[l], segs, [full[sg['kind']] for sg in segs], starts[l])
+            lv.append((seg_hw[l], starts[l], segs, [full[sg['kind']] for sg in segs]))
+        if os.environ.get('LFD_HEAD_OUT_LEVELS', '1') == '1':
+            ops.head_out_split_levels(y, lv)          # all levels (their own Scale each) in one launch
+        else:
+            for hw_, p0_, segs, outs_ in lv:
+                ops.head_out_split_concat(y, hw_, segs, outs_, p0_)
         yo.append(y)
     return dict(A=A, Y=Y, yo=yo, seg_hw=seg_hw, ptot=ptot)
 
@@ -733,13 +739,19 @@ def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts,
         wp = _out_pack(o0, opk)[0]
         y = cs['yo'][j]
         dyo = torch.empty_like(y)
+        lv = []
         for l in range(nlev):
             o = cl['lv_outs'][l][j]
             segs = _out_segs(o)
             for sg in segs:
                 sg['dbias'] = store.target(sg['conv'].bias)
                 sg['dscale'] = store.target(o.scale._scale) if sg['scale'] is not None else None
-            ops.head_out_grad_concat(y, seg_hw[l], segs, [full[sg['kind']] for sg in segs], starts[l], scale, dyo)
+            lv.append((seg_hw[l], starts[l], segs, [full[sg['kind']] for sg in segs]))
+        if os.environ.get('LFD_HEAD_OUT_LEVELS', '1') == '1':
+            ops.head_out_grad_levels(y, lv, scale, dyo)        # all levels in one launch + one final
+        else:
+            for hw_, p0_, segs, grads_ in lv:
+                ops.head_out_grad_concat(y, hw_, segs, grads_, p0_, scale, dyo)
         r0, targets = 0, []
         for _, cv in o0.convs:
             targets.append((store.target(cv.weight), r0, r0 + cv.out_channels))

@@ -818,3 +818,46 @@ def test_network_with_and_without_epilogue_sums_agree(monkeypatch):
     assert torch.equal(res[0][0], res[1][0])
     worst = max((_rel(a, b), n_) for (n_, a), (_, b) in zip(res[0][1], res[1][1]))
     assert worst[0] < 2e-5, worst
+
+
+@pytest.mark.parametrize('ncls', [1, 45])
+def test_head_output_glue_of_all_levels_in_one_launch_is_bit_identical(ncls):
+    """lfd_head_out_split_levels_f16 / lfd_head_out_grad_levels_f16 (round 4): the per-level calls of the `_concat` entry points for
+    all pyramid levels of one output conv as ONE launch each (levels = blockIdx.y, per-level Scale) -- outputs, dy, the shared
+    bias gradients and the per-level Scale gradients bit for bit those of the call sequence."""
+    n, S = 3, 1024.0
+    hws = [80 * 80, 40 * 40, 20 * 20, 10 * 10, 5 * 5]
+    starts = [0]
+    for hw in hws:
+        starts.append(starts[-1] + hw)
+    P = starts[-1]
+    g = torch.Generator(device='cuda').manual_seed(7 + ncls)
+    y = (torch.randn((n, P, 64), generator=g, device='cuda') * 2).half()
+    scales = [torch.tensor(0.7 + 0.2 * l, device='cuda') for l in range(len(hws))]
+    grads = [torch.randn((n, P, c), generator=g, device='cuda') * 1e-3 for c in (ncls, 4)]
+
+    def run(batched):
+        outs = [torch.full((n, P, c), -7.0, device='cuda') for c in (ncls, 4)]
+        dbias = [torch.full((c,), 0.5, device='cuda') for c in (ncls, 4)]
+        dscale = [torch.full((), 0.25, device='cuda') for _ in hws]
+        dy = torch.full((n, P, 64), 3.0, dtype=torch.float16, device='cuda')
+        lv_f, lv_b = [], []
+        for l, hw in enumerate(hws):
+            segs = [dict(kind='cls', channels=ncls, row0=0, scale=None, dbias=dbias[0], dscale=None),
+                    dict(kind='reg', channels=4, row0=ncls, scale=scales[l], dbias=dbias[1], dscale=dscale[l])]
+            lv_f.append((hw, starts[l], segs, outs))
+            lv_b.append((hw, starts[l], segs, grads))
+        if batched:
+            ops.head_out_split_levels(y, lv_f)
+            ops.head_out_grad_levels(y, lv_b, S, dy)
+        else:
+            for hw, p0, segs, o in lv_f:
+                ops.head_out_split_concat(y, hw, segs, o, p0)
+            for hw, p0, segs, gr in lv_b:
+                ops.head_out_grad_concat(y, hw, segs, gr, p0, S, dy)
+        torch.cuda.synchronize()
+        return outs + [dy] + dbias + dscale
+
+    a, b = run(True), run(False)
+    assert float(a[0].abs().max()) > 0 and all(torch.equal(x, z) for x, z in zip(a, b))
+    assert not bool((a[2] == 3.0).all())
