@@ -55,6 +55,7 @@ static int conv_bn_stats(const lfd_conv_desc_t* d, const void* in, const float* 
     case 64 * 10000 + 3200 + 20: rc = launch_stats<64, 3, 2, 2, true>(a, st, &blocks); break;
     case 64 * 10000 + 3200 + 40: rc = launch_stats<64, 3, 2, 4, true>(a, st, &blocks); break;
     case 64 * 10000 + 1100 + 20: rc = launch_stats<64, 1, 1, 2, true>(a, st, &blocks); break;
+    case 64 * 10000 + 1100 + 40: rc = launch_stats<64, 1, 1, 4, true>(a, st, &blocks); break;      // the neck on 64-channel taps
     case 64 * 10000 + 1200 + 20: rc = launch_stats<64, 1, 2, 2, true>(a, st, &blocks); break;
     case 64 * 10000 + 1200 + 40: rc = launch_stats<64, 1, 2, 4, true>(a, st, &blocks); break;
     case 128 * 10000 + 1100 + 40: rc = launch_stats<128, 1, 1, 4, true>(a, st, &blocks); break;

@@ -53,7 +53,7 @@ def test_bn_train_stats_and_apply(c):
 
 
 # (cin, cout, ks, stride): the seven shapes with statistics in the conv epilogue, then two that run conv + statistics pass
-_STATS_SHAPES = [(64, 64, 3, 1), (64, 64, 3, 2), (64, 128, 3, 2), (64, 64, 1, 1), (64, 64, 1, 2), (64, 128, 1, 2),
+_STATS_SHAPES = [(64, 64, 3, 1), (64, 64, 3, 2), (64, 128, 3, 2), (64, 64, 1, 1), (64, 128, 1, 1), (64, 64, 1, 2), (64, 128, 1, 2),
                  (128, 128, 1, 1), (128, 128, 3, 1), (32, 64, 3, 2)]
 
 
