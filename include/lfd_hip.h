@@ -628,6 +628,23 @@ LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, in
 LFD_API int lfd_bn_train_apply_into_f16(const void* y, int32_t n, int64_t hw, int32_t channels, const float* stats, const float* gamma,
                                 const float* beta, int32_t relu, void* z_concat, int64_t points_total, int64_t point0,
                                 lfd_stream_t stream);
+/* lfd_bn_train_bwd_from_f16 for SEVERAL levels (units of the same batch, independent of each other: the neck units of the pyramid
+ * levels) in three launches instead of three per level; values bit-identical to the per-level calls.  `levels`: host array. */
+typedef struct {
+  const void* y;          /* the level's pre-normalisation output [n, hw, channels] fp16 */
+  void* dy;               /* out: [n, hw, channels] fp16 */
+  const float* stats;     /* [2][channels] */
+  const float* gamma;
+  const float* beta;
+  float* dgamma;          /* [channels], (+)= */
+  float* dbeta;
+  int64_t hw, point0;     /* pixels per image; first point of the level inside an image of dz_concat */
+  int32_t channels;
+  int32_t reserved_;
+} lfd_bn_bwd_level_t;
+LFD_API int lfd_bn_train_bwd_from_levels_f16(const void* dz_concat, int64_t points_total, const lfd_bn_bwd_level_t* levels,
+                                     int32_t nlevels, int32_t relu, int32_t n, float inv_scale, int32_t accumulate,
+                                     void* workspace, size_t workspace_bytes, lfd_stream_t stream);
 LFD_API int lfd_bn_train_bwd_from_f16(const void* dz_concat, int64_t points_total, int64_t point0, const void* y, int32_t relu, int32_t n,
                               int64_t hw, int32_t channels, const float* stats, const float* gamma, const float* beta,
                               float inv_scale, int32_t accumulate, void* workspace, size_t workspace_bytes, float* dgamma,

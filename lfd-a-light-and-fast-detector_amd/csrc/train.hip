@@ -107,7 +107,8 @@ inline bool channels_ok(int c) { return c >= 8 && c <= kMaxC && (c & (c - 1)) ==
 // LDS and writes partial[block][NQ][c]; `k_channel_final` sums the partials in fp64 in block order.
 // ---------------------------------------------------------------------------------------------------------
 template <int NQ>
-__device__ __forceinline__ void block_channel_reduce(float (&acc)[NQ][8], int c, float* partial_out) {
+__device__ __forceinline__ void block_channel_reduce(float (&acc)[NQ][8], int c, float* partial_out, int bx = -1) {
+  if (bx < 0) bx = blockIdx.x;
   __shared__ float red[kThreads][NQ * 8 + 1];
   for (int q = 0; q < NQ; ++q)
     for (int e = 0; e < 8; ++e) red[threadIdx.x][q * 8 + e] = acc[q][e];
@@ -118,7 +119,7 @@ __device__ __forceinline__ void block_channel_reduce(float (&acc)[NQ][8], int c,
     const int cg = ch >> 3, e = ch & 7;
     float s = 0.f;
     for (int t = cg; t < kThreads; t += groups) s += red[t][q * 8 + e];
-    partial_out[(size_t)blockIdx.x * NQ * c + o] = s;
+    partial_out[(size_t)bx * NQ * c + o] = s;
   }
 }
 
@@ -234,15 +235,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
 
 // sums of g and g * xhat, g = dz * [ReLU passed]: mask from the stored output z when given (units with a residual
 // input), else -- relu_y -- recomputed from y as [gamma * xhat + beta > 0] (saves reading z), else no ReLU
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __restrict__ dz,
-                                                            const __half* __restrict__ y,
-                                                            const __half* __restrict__ z, int64_t vecs, int c,
-                                                            const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int relu_y,
-                                                            float* partials, RowMap dmap) {
+__device__ __forceinline__ void bn_bwd_partial_body(const __half* __restrict__ dz, const __half* __restrict__ y,
+                                                    const __half* __restrict__ z, int64_t vecs, int c,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int relu_y, float* partials, RowMap dmap,
+                                                    int bx, int nbx) {
   const int groups = c >> 3;
-  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  const int64_t v0 = (int64_t)bx * kThreads + threadIdx.x, stride = (int64_t)nbx * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs) {
     d0 = ld8(dz, mapped(dmap, v0));
@@ -277,13 +276,19 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __res
       body(d, yy, zz);
     }
   }
-  block_channel_reduce<2>(acc, c, partials);
+  block_channel_reduce<2>(acc, c, partials, bx);
+}
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_partial(const __half* __restrict__ dz, const __half* __restrict__ y,
+                                                            const __half* __restrict__ z, int64_t vecs, int c,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu_y, float* partials,
+                                                            RowMap dmap) {
+  bn_bwd_partial_body(dz, y, z, vecs, c, stats, gamma, beta, relu_y, partials, dmap, blockIdx.x, gridDim.x);
 }
 
 // sums[0][c] = sum g (= dbeta * scale), sums[1][c] = sum g*xhat (= dgamma * scale); parameter gradients unscaled
-__global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int nblocks, int c, float inv_scale,
-                                                    int accumulate, float* sums, float* dgamma, float* dbeta) {
-  const int ch = blockIdx.x;
+__device__ __forceinline__ void bn_bwd_final_body(const float* partials, int nblocks, int c, float inv_scale, int accumulate,
+                                                  float* sums, float* dgamma, float* dbeta, int ch) {
   double s = 0.0, sx = 0.0;
   int b = threadIdx.x;
   for (; b + 192 < nblocks; b += 256) {        // four rows in flight, adds in row order (see k_bn_stats_final)
@@ -308,17 +313,19 @@ __global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int 
   if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)(s * (double)inv_scale);
   if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)(sx * (double)inv_scale);
 }
+__global__ __launch_bounds__(64) void k_bn_bwd_final(const float* partials, int nblocks, int c, float inv_scale,
+                                                    int accumulate, float* sums, float* dgamma, float* dbeta) {
+  bn_bwd_final_body(partials, nblocks, c, inv_scale, accumulate, sums, dgamma, dbeta, blockIdx.x);
+}
 
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restrict__ dz,
-                                                          const __half* __restrict__ y,
-                                                          const __half* __restrict__ z, int64_t vecs, int c,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int relu_y,
-                                                          const float* __restrict__ sums, float inv_m,
-                                                          __half* __restrict__ dy, __half* __restrict__ g_out, RowMap dmap) {
+__device__ __forceinline__ void bn_bwd_apply_body(const __half* __restrict__ dz, const __half* __restrict__ y,
+                                                  const __half* __restrict__ z, int64_t vecs, int c,
+                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int relu_y, const float* __restrict__ sums,
+                                                  float inv_m, __half* __restrict__ dy, __half* __restrict__ g_out, RowMap dmap,
+                                                  int bx, int nbx) {
   const int groups = c >> 3;
-  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  const int64_t v0 = (int64_t)bx * kThreads + threadIdx.x, stride = (int64_t)nbx * kThreads;
   h8 d0, y0, z0;
   if (v0 < vecs) {
     d0 = ld8(dz, mapped(dmap, v0));
@@ -358,6 +365,54 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restr
     if (z) zz = ld8(z, v);
     body(v, d, yy, zz);
   }
+}
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const __half* __restrict__ dz, const __half* __restrict__ y,
+                                                          const __half* __restrict__ z, int64_t vecs, int c,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu_y,
+                                                          const float* __restrict__ sums, float inv_m,
+                                                          __half* __restrict__ dy, __half* __restrict__ g_out, RowMap dmap) {
+  bn_bwd_apply_body(dz, y, z, vecs, c, stats, gamma, beta, relu_y, sums, inv_m, dy, g_out, dmap, blockIdx.x, gridDim.x);
+}
+
+// The backward of SEVERAL BatchNorm units in three launches (round 4: the neck units of the pyramid levels, mutually independent,
+// each three ~5 us launches on its own): jobs = blockIdx.y, every job with the block count its own call would use -- the values
+// are those of the per-unit call sequence, bit for bit.
+struct BnBwdJob {
+  const __half* dz;
+  const __half* y;
+  int64_t vecs;
+  int c, blocks;
+  const float* stats;
+  const float* gamma;
+  const float* beta;
+  float* rows;
+  float* sums;
+  float* dgamma;
+  float* dbeta;
+  __half* dy;
+  float inv_m;
+  RowMap dmap;
+};
+struct BnBwdJobs {
+  BnBwdJob j[LFD_MAX_LEVELS];
+  int n, relu_y, accumulate;
+  float inv_scale;
+};
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_partial_jobs(BnBwdJobs J) {
+  const BnBwdJob& b = J.j[blockIdx.y];
+  if ((int)blockIdx.x < b.blocks)
+    bn_bwd_partial_body(b.dz, b.y, nullptr, b.vecs, b.c, b.stats, b.gamma, b.beta, J.relu_y, b.rows, b.dmap, blockIdx.x, b.blocks);
+}
+__global__ __launch_bounds__(64) void k_bn_bwd_final_jobs(BnBwdJobs J) {
+  const BnBwdJob& b = J.j[blockIdx.y];
+  if ((int)blockIdx.x < b.c) bn_bwd_final_body(b.rows, b.blocks, b.c, J.inv_scale, J.accumulate, b.sums, b.dgamma, b.dbeta, blockIdx.x);
+}
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply_jobs(BnBwdJobs J) {
+  const BnBwdJob& b = J.j[blockIdx.y];
+  if ((int)blockIdx.x < b.blocks)
+    bn_bwd_apply_body(b.dz, b.y, nullptr, b.vecs, b.c, b.stats, b.gamma, b.beta, J.relu_y, b.sums, b.inv_m, b.dy, nullptr, b.dmap,
+                      blockIdx.x, b.blocks);
 }
 
 // out[n, 2i, 2j, :] = in[n, i, j, :], zero elsewhere (the gradient of a stride-2 subsampling)
@@ -1555,6 +1610,41 @@ int lfd_bn_train_bwd_from_f16(const void* dz_concat, int64_t points_total, int64
   if (!channels_ok(channels) || !row_map(&m, n, hw, points_total, point0, channels / 8)) return LFD_ERR_INVALID_ARGUMENT;
   return bn_bwd(dz_concat, m, y, nullptr, relu, (int64_t)n * hw, channels, stats, gamma, beta, inv_scale, accumulate, workspace,
                 workspace_bytes, dgamma, dbeta, dy, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_bn_train_bwd_from_levels_f16(const void* dz_concat, int64_t points_total, const lfd_bn_bwd_level_t* levels, int32_t nlevels,
+                                     int32_t relu, int32_t n, float inv_scale, int32_t accumulate, void* workspace,
+                                     size_t workspace_bytes, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!dz_concat || !levels || nlevels < 1 || nlevels > LFD_MAX_LEVELS || !workspace) return LFD_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  BnBwdJobs J{};
+  J.n = nlevels; J.relu_y = relu ? 1 : 0; J.accumulate = accumulate; J.inv_scale = inv_scale;
+  float* ws = reinterpret_cast<float*>(workspace);
+  const size_t per_job = (size_t)kMaxBlocks * 2 * kMaxC + 2 * kMaxC;      // rows | sums, as one lfd_bn_train_bwd_f16 call lays them out
+  int max_blocks = 1, max_c = 8;
+  for (int l = 0; l < nlevels; ++l) {
+    const lfd_bn_bwd_level_t& L = levels[l];
+    BnBwdJob& b = J.j[l];
+    if (!L.y || !L.stats || !L.gamma || !L.dy || L.hw < 1 || !channels_ok(L.channels) || (relu && !L.beta)) return LFD_ERR_INVALID_ARGUMENT;
+    if (!row_map(&b.dmap, n, L.hw, points_total, L.point0, L.channels / 8)) return LFD_ERR_INVALID_ARGUMENT;
+    const int64_t pixels = (int64_t)n * L.hw;
+    b.dz = (const __half*)dz_concat; b.y = (const __half*)L.y; b.vecs = pixels * (L.channels / 8); b.c = L.channels;
+    b.blocks = (int)grid_for_vecs(b.vecs);
+    b.stats = L.stats; b.gamma = L.gamma; b.beta = L.beta; b.dgamma = L.dgamma; b.dbeta = L.dbeta; b.dy = (__half*)L.dy;
+    b.rows = ws + (size_t)l * per_job; b.sums = b.rows + (size_t)kMaxBlocks * 2 * kMaxC;
+    b.inv_m = (float)(1.0 / (double)pixels);
+    if (b.blocks > max_blocks) max_blocks = b.blocks;
+    if (b.c > max_c) max_c = b.c;
+  }
+  if ((size_t)nlevels * per_job * sizeof(float) > workspace_bytes) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  hipLaunchKernelGGL(k_bn_bwd_partial_jobs, dim3(max_blocks, nlevels), dim3(kThreads), 0, st, J);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_final_jobs, dim3(max_c, nlevels), dim3(64), 0, st, J);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_apply_jobs, dim3(max_blocks, nlevels), dim3(kThreads), 0, st, J);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
 }
 
 static inline unsigned gn_blocks(int64_t vecs_per_img, int nvirt) {

@@ -51,6 +51,13 @@ class HeadOutLevel(C.Structure):
     _fields_ = [('hw', C.c_int32), ('nsegs', C.c_int32), ('point0', C.c_int64), ('segs', HeadOutSeg * 2)]
 
 
+class BnBwdLevel(C.Structure):
+    """lfd_bn_bwd_level_t"""
+    _fields_ = [('y', C.c_void_p), ('dy', C.c_void_p), ('stats', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('hw', C.c_int64), ('point0', C.c_int64), ('channels', C.c_int32),
+                ('reserved_', C.c_int32)]
+
+
 class HeadDesc(C.Structure):
     """lfd_head_desc_t"""
     _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32), ('level_hw', C.c_int32 * MAX_LEVELS),
@@ -187,6 +194,7 @@ _SIGNATURES = {
     'lfd_bn_train_bwd_from_f16': (C.c_int, [_P, _I64, _I64, _P, _I32, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_head_out_split_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _P]),
     'lfd_head_out_grad_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),
+    'lfd_bn_train_bwd_from_levels_f16': (C.c_int, [_P, _I64, C.POINTER(BnBwdLevel), _I32, _I32, _I32, _F, _I32, _P, _SZ, _P]),
     'lfd_head_out_split_levels_f16': (C.c_int, [_P, _I32, _I64, C.POINTER(HeadOutLevel), _I32, _P]),
     'lfd_head_out_grad_levels_f16': (C.c_int, [_P, _I32, _I64, C.POINTER(HeadOutLevel), _I32, _F, _P, _P, _SZ, _P]),
     'lfd_gn_train_bwd_f16': (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),

@@ -868,6 +868,28 @@ def bn_train_backward_from(dz_concat, point0, y, stats, gamma, beta, inv_scale, 
     return dy
 
 
+def bn_train_backward_from_levels(dz_concat, levels, inv_scale, relu=True, accumulate=True):
+    """bn_train_backward_from for several levels in three launches; levels: [(point0, y, stats, gamma, beta, dgamma, dbeta)]
+    -> [dy per level] (lfd_bn_train_bwd_from_levels_f16; bit-identical to the per-level calls)"""
+    require_cuda(dz_concat, 'bn_train_backward_from_levels')
+    arr = (_lib.BnBwdLevel * len(levels))()
+    dys = []
+    n = dz_concat.size(0)
+    for l, (point0, y, stats, gamma, beta, dgamma, dbeta) in enumerate(levels):
+        _nhwc16(y, 'bn_train_backward_from_levels')
+        dy = torch.empty_like(y)
+        dys.append(dy)
+        a = arr[l]
+        a.y, a.dy, a.stats, a.gamma, a.beta, a.dgamma, a.dbeta = ptr(y), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta)
+        a.hw, a.point0, a.channels = y.size(1) * y.size(2), int(point0), y.size(3)
+    ws = train_workspace(dz_concat.device)
+    with torch.cuda.device(dz_concat.device):
+        check(lib().lfd_bn_train_bwd_from_levels_f16(ptr(dz_concat), dz_concat.size(1), arr, len(levels), int(bool(relu)), n,
+                                                     float(inv_scale), int(bool(accumulate)), ptr(ws), ws.numel(), stream_ptr()),
+              'lfd_bn_train_bwd_from_levels_f16')
+    return dys
+
+
 def gn_train_backward(dz, y, z, groups, stats, gamma, inv_scale, dgamma, dbeta, accumulate=False):
     _nhwc16(dz, 'gn_train_backward')
     n, h, w_, c = y.shape

@@ -777,13 +777,26 @@ def _concat_backward(cl, cs, units, acts, tape, packs, opk, zeros, full, starts,
         res = _as_image(dA[sp]) if dA[sp] is not None else None
         dA[sp] = ops.conv2d_nhwc(dy4, packs(conv.weight, True), zeros(cin), conv.out_channels, cin, 1, 1, False,
                                  residual=res).view(n, ptot, cin)
+    # the neck units' BatchNorm backward: the levels are independent of each other -- three launches for all of them
+    # (LFD_BN_LEVELS=0: three per level; the same values)
+    dys = None
+    if os.environ.get('LFD_BN_LEVELS', '1') == '1':
+        lv = []
+        for l in range(nlev):
+            u = units[cl['lv_units'][l][0]]
+            y, stats = tape[cl['lv_units'][l][0]]
+            lv.append((starts[l], y, stats, u.norm.weight.detach(), u.norm.bias.detach(), store.target(u.norm.weight),
+                       store.target(u.norm.bias)))
+        if len({t[5].data_ptr() for t in lv}) == len(lv):       # (levels sharing one norm module would race on its gradient)
+            dys = ops.bn_train_backward_from_levels(dA[0], lv, inv, relu=True, accumulate=True)
     for l in range(nlev - 1, -1, -1):
         ui = cl['lv_units'][l][0]
         u = units[ui]
         conv, norm = u.conv, u.norm
         y, stats = tape[ui]
-        dy = ops.bn_train_backward_from(dA[0], starts[l], y, stats, norm.weight.detach(), norm.bias.detach(), inv,
-                                        store.target(norm.weight), store.target(norm.bias), relu=True, accumulate=True)
+        dy = dys[l] if dys is not None else ops.bn_train_backward_from(
+            dA[0], starts[l], y, stats, norm.weight.detach(), norm.bias.detach(), inv, store.target(norm.weight),
+            store.target(norm.bias), relu=True, accumulate=True)
         xin = acts[u.src]
         wgrad(xin, dy, 1, 1, [(store.target(conv.weight), 0, conv.out_channels)])
         cin = conv.in_channels

@@ -861,3 +861,34 @@ def test_head_output_glue_of_all_levels_in_one_launch_is_bit_identical(ncls):
     a, b = run(True), run(False)
     assert float(a[0].abs().max()) > 0 and all(torch.equal(x, z) for x, z in zip(a, b))
     assert not bool((a[2] == 3.0).all())
+
+
+def test_batchnorm_backward_of_all_neck_levels_in_three_launches_is_bit_identical():
+    """lfd_bn_train_bwd_from_levels_f16 (round 4) against lfd_bn_train_bwd_from_f16 level by level: dy, dgamma, dbeta bit for bit"""
+    n, c = 3, 128
+    shapes = [(40, 48), (20, 24), (10, 12), (5, 6), (3, 3)]
+    starts = [0]
+    for h, w in shapes:
+        starts.append(starts[-1] + h * w)
+    P = starts[-1]
+    g = torch.Generator(device='cuda').manual_seed(23)
+    dz = (torch.randn(n, P, c, generator=g, device='cuda') * 0.5).half()
+    ys = [(torch.randn(n, h, w, c, generator=g, device='cuda') * 1.3 + 0.2).half() for h, w in shapes]
+    stats = [ops.bn_train_stats(y, 1e-5, 0.1, None, None) for y in ys]
+    gam = [torch.empty(c, device='cuda').uniform_(0.5, 1.5) for _ in shapes]
+    bet = [torch.empty(c, device='cuda').normal_(0, 0.3) for _ in shapes]
+    inv = 1.0 / 64
+
+    def run(batched):
+        dg = [torch.full((c,), 0.5, device='cuda') for _ in shapes]
+        db = [torch.full((c,), -0.25, device='cuda') for _ in shapes]
+        if batched:
+            dys = ops.bn_train_backward_from_levels(dz, [(starts[l], ys[l], stats[l], gam[l], bet[l], dg[l], db[l])
+                                                         for l in range(len(shapes))], inv)
+        else:
+            dys = [ops.bn_train_backward_from(dz, starts[l], ys[l], stats[l], gam[l], bet[l], inv, dg[l], db[l]) for l in range(len(shapes))]
+        torch.cuda.synchronize()
+        return dys + dg + db
+
+    a, b = run(True), run(False)
+    assert float(a[0].float().abs().max()) > 0 and all(torch.equal(x, z) for x, z in zip(a, b))
