@@ -628,6 +628,27 @@ LFD_API int lfd_conv_wgrad_nhwc_f16(const void* x, const void* dy, int32_t n, in
 LFD_API int lfd_bn_train_apply_into_f16(const void* y, int32_t n, int64_t hw, int32_t channels, const float* stats, const float* gamma,
                                 const float* beta, int32_t relu, void* z_concat, int64_t points_total, int64_t point0,
                                 lfd_stream_t stream);
+/* The forward counterpart: the convs of several independent units leave their statistics rows behind
+ * (lfd_conv2d_bn_partials_nhwc_f16: lfd_conv2d_bn_stats_nhwc_f16 without its final pass, rows in the caller's buffer of at
+ * least 512 x 2 x cout floats, *nrows = how many), then ONE call finishes all of them: the per-channel finals (mean, rstd,
+ * running statistics) of every level in one launch, the apply passes into the level-concatenated tensor in another.  Values
+ * bit-identical to lfd_conv2d_bn_stats_nhwc_f16 + lfd_bn_train_apply_into_f16 per level. */
+LFD_API int lfd_conv2d_bn_partials_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed, const float* bias,
+                                    const void* zeros, float* rows, size_t rows_bytes, int32_t* nrows, lfd_stream_t stream);
+typedef struct {
+  const void* y;           /* [n, hw, channels] fp16 */
+  const float* rows;       /* statistics rows of the conv that produced y */
+  float* running_mean;     /* nullable (both or none) */
+  float* running_var;
+  float* stats;            /* out: [2][channels] */
+  const float* gamma;
+  const float* beta;
+  int64_t hw, point0;
+  int32_t channels, nrows;
+  float eps, momentum;
+} lfd_bn_fwd_level_t;
+LFD_API int lfd_bn_train_finish_into_levels_f16(const lfd_bn_fwd_level_t* levels, int32_t nlevels, int32_t n, int32_t relu,
+                                        void* z_concat, int64_t points_total, lfd_stream_t stream);
 /* lfd_bn_train_bwd_from_f16 for SEVERAL levels (units of the same batch, independent of each other: the neck units of the pyramid
  * levels) in three launches instead of three per level; values bit-identical to the per-level calls.  `levels`: host array. */
 typedef struct {

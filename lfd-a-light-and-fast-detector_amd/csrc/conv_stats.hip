@@ -30,14 +30,15 @@ static int conv_bn_stats(const lfd_conv_desc_t* d, const void* in, const float* 
                          const float* in_beta, void* out, const void* w_packed,
                          const float* bias, const void* zeros, float eps, float momentum, float* running_mean,
                          float* running_var, void* workspace, size_t workspace_bytes, float* stats,
-                         lfd_stream_t stream) {
+                         lfd_stream_t stream, int32_t* rows_only = nullptr) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!d || !in || !out || !w_packed || !bias || !zeros || !workspace || !stats) return LFD_ERR_INVALID_ARGUMENT;
+  if (!d || !in || !out || !w_packed || !bias || !zeros || !workspace || (!stats && !rows_only)) return LFD_ERR_INVALID_ARGUMENT;
   if (d->n < 1 || d->h < 1 || d->w < 1 || d->tail_cout || d->relu) return LFD_ERR_INVALID_ARGUMENT;
   if (!lfd_aligned16(in) || !lfd_aligned16(out)) return LFD_ERR_INVALID_ARGUMENT;
   if ((d->ks != 1 && d->ks != 3) || (d->stride != 1 && d->stride != 2)) return LFD_ERR_UNSUPPORTED;
   if ((running_mean == nullptr) != (running_var == nullptr)) return LFD_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < lfd_train_workspace_bytes()) return LFD_ERR_WORKSPACE_TOO_SMALL;
+  // rows_only: `workspace` is the caller's own row buffer (512 rows x 2 x cout floats suffice)
+  if (workspace_bytes < (rows_only ? (size_t)512 * 2 * d->cout * sizeof(float) : lfd_train_workspace_bytes())) return LFD_ERR_WORKSPACE_TOO_SMALL;
   ConvArgs a{};
   a.in = (const _Float16*)in; a.out = (_Float16*)out; a.w = (const half8*)w_packed; a.bias = bias;
   a.res_px = d->cout; a.zeros = (const _Float16*)zeros;
@@ -60,7 +61,7 @@ static int conv_bn_stats(const lfd_conv_desc_t* d, const void* in, const float* 
     case 64 * 10000 + 1200 + 40: rc = launch_stats<64, 1, 2, 4, true>(a, st, &blocks); break;
     case 128 * 10000 + 1100 + 40: rc = launch_stats<128, 1, 1, 4, true>(a, st, &blocks); break;
     default: {
-      if (in_stats) return LFD_ERR_UNSUPPORTED;
+      if (in_stats || rows_only) return LFD_ERR_UNSUPPORTED;
       rc = lfd_conv2d_nhwc_f16(d, in, out, w_packed, bias, nullptr, nullptr, nullptr, zeros, stream);
       if (rc != LFD_OK) return rc;
       return lfd_bn_train_stats_f16(out, pixels, d->cout, eps, momentum, running_mean, running_var, workspace, workspace_bytes,
@@ -68,6 +69,7 @@ static int conv_bn_stats(const lfd_conv_desc_t* d, const void* in, const float* 
     }
   }
   if (rc != LFD_OK) return rc;
+  if (rows_only) { *rows_only = blocks; return LFD_OK; }
   return lfd_bn_stats_final_launch(a.stat_partials, blocks, d->cout, (double)pixels, eps, momentum, running_mean, running_var,
                                    stats, st);
 }
@@ -78,6 +80,15 @@ int lfd_conv2d_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void*
                                  lfd_stream_t stream) {
   return conv_bn_stats(d, in, nullptr, nullptr, nullptr, out, w_packed, bias, zeros, eps, momentum, running_mean, running_var,
                        workspace, workspace_bytes, stats, stream);
+}
+
+// the conv alone, its per-workgroup statistics rows left in the CALLER's buffer (the final pass comes later, for several convs
+// at once: lfd_bn_train_finish_into_levels_f16); LFD_ERR_UNSUPPORTED for shapes without a STATS kernel
+int lfd_conv2d_bn_partials_nhwc_f16(const lfd_conv_desc_t* d, const void* in, void* out, const void* w_packed, const float* bias,
+                                    const void* zeros, float* rows, size_t rows_bytes, int32_t* nrows, lfd_stream_t stream) {
+  if (!nrows || !rows) return LFD_ERR_INVALID_ARGUMENT;
+  return conv_bn_stats(d, in, nullptr, nullptr, nullptr, out, w_packed, bias, zeros, 0.f, 0.f, nullptr, nullptr, rows, rows_bytes,
+                       nullptr, stream, nrows);
 }
 
 int lfd_conv1x1_of_bn_relu_bn_stats_nhwc_f16(const lfd_conv_desc_t* d, const void* y_in, const float* in_stats,

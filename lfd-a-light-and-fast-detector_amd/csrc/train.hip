@@ -140,10 +140,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats_partial(const __half* __r
 
 // stats[0][c] = mean, stats[1][c] = 1/sqrt(var + eps) (biased variance, as F.batch_norm normalises in training);
 // running_mean / running_var updated with `momentum` and the unbiased variance (torch BatchNorm semantics)
-__global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, int nblocks, int c, double m,
-                                                      float eps, float momentum, float* running_mean,
-                                                      float* running_var, float* stats) {
-  const int ch = blockIdx.x;           // one wave per channel: lanes stride over the block partials
+__device__ __forceinline__ void bn_stats_final_body(const float* partials, int nblocks, int c, double m, float eps, float momentum,
+                                                    float* running_mean, float* running_var, float* stats, int ch) {
+  // one wave per channel: lanes stride over the block partials
   double s = 0.0, ss = 0.0;
   // (four partial rows requested before the first add: the loop is a chain of dependent round trips otherwise; adds in row order)
   int b = threadIdx.x;
@@ -175,6 +174,11 @@ __global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, in
     running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
   }
 }
+__global__ __launch_bounds__(64) void k_bn_stats_final(const float* partials, int nblocks, int c, double m,
+                                                      float eps, float momentum, float* running_mean,
+                                                      float* running_var, float* stats) {
+  bn_stats_final_body(partials, nblocks, c, m, eps, momentum, running_mean, running_var, stats, blockIdx.x);
+}
 
 // A per-level tensor [n, hw, c] that lives inside a LEVEL-CONCATENATED one [n, P, c] (the head activations of the training
 // schedule): vector v of the level = pixel v / groups of image (pixel / hw) -> row img * P + p0 + pixel % hw of the concatenated
@@ -193,14 +197,12 @@ __device__ __forceinline__ int64_t mapped(const RowMap& m, int64_t v) {
 // (All streaming passes below request their thread's FIRST vectors before the per-channel parameters: the parameter loads and the
 //  data loads were two dependent round trips -- parameters, s_waitcnt vmcnt(0), then the loop's first load -- and on the small
 //  maps, where a thread owns one or two vectors, that chain is most of the ~5 us a launch takes.)
-__global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict__ y, int64_t vecs, int c,
-                                                      const float* __restrict__ stats,
-                                                      const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta,
-                                                      const __half* __restrict__ res, int relu,
-                                                      __half* __restrict__ z, RowMap zmap) {
+__device__ __forceinline__ void bn_apply_body(const __half* __restrict__ y, int64_t vecs, int c, const float* __restrict__ stats,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              const __half* __restrict__ res, int relu, __half* __restrict__ z, RowMap zmap,
+                                              int bx, int nbx) {
   const int groups = c >> 3;
-  const int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  const int64_t v0 = (int64_t)bx * kThreads + threadIdx.x, stride = (int64_t)nbx * kThreads;
   h8 h0, r0;
   if (v0 < vecs) {
     h0 = ld8(y, v0);
@@ -231,6 +233,44 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict_
     if (res) r = ld8(res, v);
     body(v, h, r);
   }
+}
+__global__ __launch_bounds__(kThreads) void k_bn_apply(const __half* __restrict__ y, int64_t vecs, int c,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const __half* __restrict__ res, int relu,
+                                                      __half* __restrict__ z, RowMap zmap) {
+  bn_apply_body(y, vecs, c, stats, gamma, beta, res, relu, z, zmap, blockIdx.x, gridDim.x);
+}
+
+// The forward tail of SEVERAL BatchNorm units in two launches (the neck units of the pyramid levels, see BnBwdJobs below): the
+// one-wave-per-channel final of every level, then the apply pass of every level into the level-concatenated tensor.
+struct BnFwdJob {
+  const __half* y;
+  int64_t vecs;
+  int c, blocks, nrows;
+  const float* rows;
+  double m;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  float* stats;
+  const float* gamma;
+  const float* beta;
+  RowMap zmap;
+};
+struct BnFwdJobs {
+  BnFwdJob j[LFD_MAX_LEVELS];
+  int n, relu;
+  __half* z;
+};
+__global__ __launch_bounds__(64) void k_bn_stats_final_jobs(BnFwdJobs J) {
+  const BnFwdJob& b = J.j[blockIdx.y];
+  if ((int)blockIdx.x < b.c)
+    bn_stats_final_body(b.rows, b.nrows, b.c, b.m, b.eps, b.momentum, b.running_mean, b.running_var, b.stats, blockIdx.x);
+}
+__global__ __launch_bounds__(kThreads) void k_bn_apply_jobs(BnFwdJobs J) {
+  const BnFwdJob& b = J.j[blockIdx.y];
+  if ((int)blockIdx.x < b.blocks)
+    bn_apply_body(b.y, b.vecs, b.c, b.stats, b.gamma, b.beta, nullptr, J.relu, J.z, b.zmap, blockIdx.x, b.blocks);
 }
 
 // sums of g and g * xhat, g = dz * [ReLU passed]: mask from the stored output z when given (units with a residual
@@ -1610,6 +1650,34 @@ int lfd_bn_train_bwd_from_f16(const void* dz_concat, int64_t points_total, int64
   if (!channels_ok(channels) || !row_map(&m, n, hw, points_total, point0, channels / 8)) return LFD_ERR_INVALID_ARGUMENT;
   return bn_bwd(dz_concat, m, y, nullptr, relu, (int64_t)n * hw, channels, stats, gamma, beta, inv_scale, accumulate, workspace,
                 workspace_bytes, dgamma, dbeta, dy, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lfd_bn_train_finish_into_levels_f16(const lfd_bn_fwd_level_t* levels, int32_t nlevels, int32_t n, int32_t relu, void* z_concat,
+                                        int64_t points_total, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!levels || nlevels < 1 || nlevels > LFD_MAX_LEVELS || !z_concat || n < 1) return LFD_ERR_INVALID_ARGUMENT;
+  BnFwdJobs J{};
+  J.n = nlevels; J.relu = relu ? 1 : 0; J.z = (__half*)z_concat;
+  int max_blocks = 1, max_c = 8;
+  for (int l = 0; l < nlevels; ++l) {
+    const lfd_bn_fwd_level_t& L = levels[l];
+    BnFwdJob& b = J.j[l];
+    if (!L.y || !L.rows || !L.stats || !L.gamma || !L.beta || L.hw < 1 || L.nrows < 1 || L.nrows > kMaxBlocks * 2 ||
+        !channels_ok(L.channels) || (L.running_mean == nullptr) != (L.running_var == nullptr))
+      return LFD_ERR_INVALID_ARGUMENT;
+    if (!row_map(&b.zmap, n, L.hw, points_total, L.point0, L.channels / 8)) return LFD_ERR_INVALID_ARGUMENT;
+    const int64_t pixels = (int64_t)n * L.hw;
+    b.y = (const __half*)L.y; b.vecs = pixels * (L.channels / 8); b.c = L.channels; b.blocks = (int)grid_for_vecs(b.vecs);
+    b.rows = L.rows; b.nrows = L.nrows; b.m = (double)pixels; b.eps = L.eps; b.momentum = L.momentum;
+    b.running_mean = L.running_mean; b.running_var = L.running_var; b.stats = L.stats; b.gamma = L.gamma; b.beta = L.beta;
+    if (b.blocks > max_blocks) max_blocks = b.blocks;
+    if (b.c > max_c) max_c = b.c;
+  }
+  hipLaunchKernelGGL(k_bn_stats_final_jobs, dim3(max_c, nlevels), dim3(64), 0, st, J);
+  LFD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_apply_jobs, dim3(max_blocks, nlevels), dim3(kThreads), 0, st, J);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
 }
 
 int lfd_bn_train_bwd_from_levels_f16(const void* dz_concat, int64_t points_total, const lfd_bn_bwd_level_t* levels, int32_t nlevels,

@@ -58,6 +58,13 @@ class BnBwdLevel(C.Structure):
                 ('reserved_', C.c_int32)]
 
 
+class BnFwdLevel(C.Structure):
+    """lfd_bn_fwd_level_t"""
+    _fields_ = [('y', C.c_void_p), ('rows', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('stats', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('hw', C.c_int64), ('point0', C.c_int64),
+                ('channels', C.c_int32), ('nrows', C.c_int32), ('eps', C.c_float), ('momentum', C.c_float)]
+
+
 class HeadDesc(C.Structure):
     """lfd_head_desc_t"""
     _fields_ = [('n', C.c_int32), ('num_levels', C.c_int32), ('level_hw', C.c_int32 * MAX_LEVELS),
@@ -194,6 +201,8 @@ _SIGNATURES = {
     'lfd_bn_train_bwd_from_f16': (C.c_int, [_P, _I64, _I64, _P, _I32, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P, _SZ, _P, _P, _P, _P]),
     'lfd_head_out_split_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _P]),
     'lfd_head_out_grad_concat_f16': (C.c_int, [_P, _I32, _I32, _I64, _I64, C.POINTER(HeadOutSeg), _I32, _F, _P, _P, _SZ, _P]),
+    'lfd_conv2d_bn_partials_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _SZ, C.POINTER(C.c_int32), _P]),
+    'lfd_bn_train_finish_into_levels_f16': (C.c_int, [C.POINTER(BnFwdLevel), _I32, _I32, _I32, _P, _I64, _P]),
     'lfd_bn_train_bwd_from_levels_f16': (C.c_int, [_P, _I64, C.POINTER(BnBwdLevel), _I32, _I32, _I32, _F, _I32, _P, _SZ, _P]),
     'lfd_head_out_split_levels_f16': (C.c_int, [_P, _I32, _I64, C.POINTER(HeadOutLevel), _I32, _P]),
     'lfd_head_out_grad_levels_f16': (C.c_int, [_P, _I32, _I64, C.POINTER(HeadOutLevel), _I32, _F, _P, _P, _SZ, _P]),

@@ -868,6 +868,43 @@ def bn_train_backward_from(dz_concat, point0, y, stats, gamma, beta, inv_scale, 
     return dy
 
 
+def conv2d_bn_partials(x, w_packed, bias, cin, cout, ks, stride, rows):
+    """conv2d_bn_stats without its final pass: -> (y, nrows), the per-workgroup statistics rows in `rows` (fp32, >= 512 * 2 * cout);
+    None when the shape has no statistics kernel (lfd_conv2d_bn_partials_nhwc_f16)"""
+    _nhwc16(x, 'conv2d_bn_partials')
+    n, h, w_, c = x.shape
+    pad = ks // 2
+    oh, ow = (h + 2 * pad - ks) // stride + 1, (w_ + 2 * pad - ks) // stride + 1
+    d = _lib.ConvDesc(n, h, w_, cin, cout, ks, stride, 0, 0, 0)
+    nrows = C.c_int32(0)
+    with torch.cuda.device(x.device):
+        y = torch.empty((n, oh, ow, cout), dtype=torch.float16, device=x.device)
+        rc = lib().lfd_conv2d_bn_partials_nhwc_f16(C.byref(d), ptr(x), ptr(y), ptr(w_packed), ptr(bias), ptr(zero_line(x.device)),
+                                                   ptr(rows), rows.numel() * 4, C.byref(nrows), stream_ptr())
+    if rc == -4:          # LFD_ERR_UNSUPPORTED: no STATS kernel for this shape
+        return None
+    check(rc, 'lfd_conv2d_bn_partials_nhwc_f16')
+    return y, int(nrows.value)
+
+
+def bn_train_finish_into_levels(levels, n, relu, z_concat):
+    """the per-channel finals and the apply passes of several units whose convs left statistics rows (conv2d_bn_partials), two
+    launches for all of them; levels: [(point0, y, rows, nrows, eps, momentum, running_mean, running_var, gamma, beta)] -> [stats]
+    (lfd_bn_train_finish_into_levels_f16)"""
+    arr = (_lib.BnFwdLevel * len(levels))()
+    out = []
+    for l, (point0, y, rows, nrows, eps, momentum, rm, rv, gamma, beta) in enumerate(levels):
+        st = torch.empty(2 * y.size(3), dtype=torch.float32, device=y.device)
+        out.append(st)
+        a = arr[l]
+        a.y, a.rows, a.running_mean, a.running_var, a.stats, a.gamma, a.beta = ptr(y), ptr(rows), ptr(rm), ptr(rv), ptr(st), ptr(gamma), ptr(beta)
+        a.hw, a.point0, a.channels, a.nrows, a.eps, a.momentum = y.size(1) * y.size(2), int(point0), y.size(3), int(nrows), float(eps), float(momentum)
+    with torch.cuda.device(z_concat.device):
+        check(lib().lfd_bn_train_finish_into_levels_f16(arr, len(levels), int(n), int(bool(relu)), ptr(z_concat), z_concat.size(1),
+                                                        stream_ptr()), 'lfd_bn_train_finish_into_levels_f16')
+    return out
+
+
 def bn_train_backward_from_levels(dz_concat, levels, inv_scale, relu=True, accumulate=True):
     """bn_train_backward_from for several levels in three launches; levels: [(point0, y, stats, gamma, beta, dgamma, dbeta)]
     -> [dy per level] (lfd_bn_train_bwd_from_levels_f16; bit-identical to the per-level calls)"""

@@ -680,7 +680,7 @@ def _as_image(t):
     return None
 
 
-def _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, n, dev):
+def _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, n, dev, sc=None):
     """neck units per level into A[0]; shared tower units over all levels; output convs over all levels + per-level slices"""
     seg_hw = [h_ * w_ for h_, w_ in sizes]
     ptot = sum(seg_hw)
@@ -689,11 +689,22 @@ def _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats,
     A[0] = torch.empty((n, ptot, c0), dtype=torch.float16, device=dev)
     if _as_image(A[0]) is None:
         return None
+    # the neck units: independent of each other -- every conv leaves its statistics rows in a buffer of its own, then TWO launches
+    # finish all levels (per-channel finals; apply passes into A[0]) instead of two per level (LFD_BN_LEVELS=0; the same values)
+    pending = []
+    batched = fused_stats and sc is not None and os.environ.get('LFD_BN_LEVELS', '1') == '1'
     for l in range(len(sizes)):
         ui = cl['lv_units'][l][0]
         u = units[ui]
         conv, norm = u.conv, u.norm
         xin = acts[u.src]
+        if batched and all(id(norm) != id(units[q[1]].norm) for q in pending):      # (a norm shared by two levels: one after the other)
+            rows = sc.buf(('bnrows', l), 512 * 2 * conv.out_channels)
+            r = ops.conv2d_bn_partials(xin, packs(conv.weight), zeros(conv.out_channels), conv.in_channels, conv.out_channels, 1, 1, rows)
+            if r is not None:
+                pending.append((l, ui, (starts[l], r[0], rows, r[1], norm.eps, norm.momentum, norm.running_mean, norm.running_var,
+                                        norm.weight.detach(), norm.bias.detach())))
+                continue
         if fused_stats:
             y, stats = ops.conv2d_bn_stats(xin, packs(conv.weight), zeros(conv.out_channels), conv.in_channels, conv.out_channels, 1, 1,
                                            norm.eps, norm.momentum, norm.running_mean, norm.running_var)
@@ -702,6 +713,10 @@ def _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats,
             stats = ops.bn_train_stats(y, norm.eps, norm.momentum, norm.running_mean, norm.running_var)
         ops.bn_train_apply_into(y, stats, norm.weight.detach(), norm.bias.detach(), True, A[0], starts[l])
         tape[ui] = (y, stats)
+    if pending:
+        sts = ops.bn_train_finish_into_levels([t[2] for t in pending], n, True, A[0])
+        for (l, ui, lvl), st_ in zip(pending, sts):
+            tape[ui] = (lvl[1], st_)
     for p_ in range(1, cl['npos']):
         u = units[cl['lv_units'][0][p_]]
         conv, norm = u.conv, u.norm
@@ -890,7 +905,7 @@ def network_forward(model, plan, x):
             tape[ui] = _unit_forward(u, acts, packs, zeros, fused_stats, store=ui not in defer,
                                      producer=(units[fed[ui]], tape[fed[ui]]) if ui in fed else None)
     if cl is not None:
-        cs = _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, x.size(0), dev)
+        cs = _concat_forward(cl, units, outs, acts, tape, packs, opk, zeros, fused_stats, full, sizes, starts, x.size(0), dev, sc)
     osaved = cs
     if cs is None:     # level by level: heads that do not share their towers, or no usable image view of N * P pixels
         for ui, u in enumerate(units):

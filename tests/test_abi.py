@@ -136,7 +136,7 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
     pairs = {'lfd_detect_desc_t': _lib.DetectDesc, 'lfd_conv_desc_t': _lib.ConvDesc,
              'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
              'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob, 'lfd_detect_ext_t': _lib.DetectExt,
-             'lfd_p32_conv_desc_t': _lib.P32ConvDesc, 'lfd_head_out_seg_t': _lib.HeadOutSeg, 'lfd_head_out_level_t': _lib.HeadOutLevel, 'lfd_bn_bwd_level_t': _lib.BnBwdLevel,
+             'lfd_p32_conv_desc_t': _lib.P32ConvDesc, 'lfd_head_out_seg_t': _lib.HeadOutSeg, 'lfd_head_out_level_t': _lib.HeadOutLevel, 'lfd_bn_bwd_level_t': _lib.BnBwdLevel, 'lfd_bn_fwd_level_t': _lib.BnFwdLevel,
              'lfd_wgrad_job_t': _lib.WgradJob, 'lfd_rowsum_job_t': _lib.RowsumJob}
     header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lfd_hip.h"', 'int main(void) {']

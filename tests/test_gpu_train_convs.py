@@ -892,3 +892,34 @@ def test_batchnorm_backward_of_all_neck_levels_in_three_launches_is_bit_identica
 
     a, b = run(True), run(False)
     assert float(a[0].float().abs().max()) > 0 and all(torch.equal(x, z) for x, z in zip(a, b))
+
+
+def test_network_with_levels_batched_and_level_by_level_is_bit_identical(monkeypatch):
+    """LFD_BN_LEVELS / LFD_HEAD_OUT_LEVELS = 0 (the neck units' BatchNorm passes and the output convs' glue one pyramid level after
+    the other) against the default (all levels per launch): logits, running statistics and every parameter gradient bit for bit"""
+    from lfd_amd import configs, train_engine as TE
+    res = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LFD_BN_LEVELS', flag)
+        monkeypatch.setenv('LFD_HEAD_OUT_LEVELS', flag)
+        torch.manual_seed(0)
+        m = configs.build_model('WIDERFACE_LFD_S')
+        configs.perturb_weights(m)
+        m.train().cuda()
+        units, outs = TE.build_network(m)
+        plan = (units, outs, m._num_heads)
+        x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(1)).cuda()
+        for p in m.parameters():
+            p.grad = None
+        cls, reg, sizes, saved = TE.network_forward(m, plan, x)
+        assert isinstance(saved[1], dict)                  # the level-concatenated schedule ran
+        gc = torch.randn(cls.shape, generator=torch.Generator().manual_seed(2)).cuda() * 1e-2
+        gr = torch.randn(reg.shape, generator=torch.Generator().manual_seed(3)).cuda() * 1e-2
+        TE.network_backward(m, plan, saved, sizes, gc, gr, 64.0)
+        torch.cuda.synchronize()
+        res.append((cls.clone(), reg.clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None],
+                    [b.clone() for b in m.buffers()]))
+        del m
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2])) and len(res[0][2]) > 50
+    assert all(torch.equal(a, b) for a, b in zip(res[0][3], res[1][3]))
