@@ -23,8 +23,10 @@ extern "C" {
 #endif
 
 /* 2: lfd_head_level_ptrs_t grew (w{1,2}_folded, tower1_out, w{1,2}_perm), lfd_conv3x3_c64_chain_nhwc_f16 removed,
- * lfd_p32_* (fp32-storage precision mode) added.  Every loader checks lfd_hip_abi_version() against this number. */
-#define LFD_HIP_ABI_VERSION 2
+ * lfd_p32_* (fp32-storage precision mode) added.
+ * 3: lfd_pl_* added (the same precision mode on hi/lo fp16 planes, csrc/planes.hip).
+ * Every loader checks lfd_hip_abi_version() against this number. */
+#define LFD_HIP_ABI_VERSION 3
 #define LFD_MAX_LEVELS 8
 
 /* Conventions of every entry point below.
@@ -495,6 +497,54 @@ LFD_API size_t lfd_p32_groupnorm_workspace_bytes(int32_t n, int32_t groups);
 LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t c, int32_t groups, const float* gamma,
                                        const float* beta, float eps, int32_t relu, void* workspace, size_t workspace_bytes,
                                        lfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The same precision mode on "hi/lo planes" (csrc/planes.hip, csrc/planes_impl.h; lfd_amd/engine_p2.py) -- the fast form of
+ * the mode inside north_star's 1e-3 (lfd/model/lfd.py:511-542 to <= 1e-4 on the raw logits).
+ * A plane tensor stores an fp32-valued NHWC activation x as two contiguous NHWC fp16 tensors: hi = fp16(x) at the base pointer,
+ * lo = fp16(2^11 (x - hi)) `*_plane_halfs` halfs behind it (x = hi + 2^-11 lo to ~22 bits; the bytes of fp32).  Both planes are
+ * 16-byte aligned, plane strides multiples of 8 halfs.  Convolutions are weights-stationary LDS-DMA kernels issuing three
+ * fp16 MFMAs per k-step (w_hi x_hi | w_hi x_lo + w_lo x_hi), fp32 accumulation, fp32 epilogue, split on the way out.
+ * Packed weights of every entry point: [2 = hi | 2^11 lo][fragments of lfd_conv_packed_weight_halfs order], rows zero-padded
+ * to a multiple of 32 (engine_p2.pack_planes_weight); biases fp32 padded likewise.
+ *
+ * lfd_pl_stem_pair: frame (in_format as lfd_stem_conv_f16) -> conv3x3 s2 (3 -> C) + BN + ReLU -> conv1x1 (C -> C) + BN + ReLU
+ *   -> planes [n, (h+1)/2, (w+1)/2, C], C = 32 | 64 (lfd_resnet.py:356-374, :376-395).  w1: [2][C/32][2][64][8] in
+ *   engine.pack_stem_weight order per plane.  uint8 / fp32 frames keep their low parts (simple_normalize in fp32).
+ * lfd_pl_conv2d: planes [n,h,w,cin] -> conv ks x ks / stride (+ bias, ReLU) with ONE of
+ *     tail_cout > 0   : a chained 1x1 cout -> cout (+ tail_bias, tail_relu) in the same launch (the intermediate stays in LDS):
+ *                       the second stem pair (3x3 s2 -> 1x1, lfd_resnet.py:396-413), the neck conv -> first tower conv;
+ *     ds_w_packed     : second output ds_out = conv1x1 stride 2 (in) + ds_bias, no ReLU -- the identity branch of a stage's
+ *                       first block (lfd_resnet.py:458-468) from the centre tap of a 3x3 stride-2 conv;
+ *     residual        : y += residual (planes, same shape as out) before the ReLU (lfd_resnet.py:151-152);
+ *   out_mode 0: planes out.  1: planes out + GroupNorm sums: gn_sums[(image * cout/8 + group) * 2 + {0,1}] += {sum, sum of
+ *   squares} of the stored values of that 8-channel group as 64-bit two's-complement fixed point (2^-24 units) --
+ *   order-independent atomics, so the statistics are bit-reproducible; the caller zeroes gn_sums per forward.  2: fp32
+ *   outputs without planes: channel c < f_c0 -> f_out0[image * f_image_stride0 + pixel * f_c0 + c], f_c0 <= c < f_c0 + f_c1
+ *   -> f_out1[image * f_image_stride1 + pixel * f_c1 + c - f_c0] * (*scale1) (lfd_head.py:176-183: cls / reg convs + Scale
+ *   straight into the level-concatenated [N,P,C'] / [N,P,4] tensors, lfd.py:526-542).
+ *   Supported shapes: the layers of every named configuration (see the dispatch in csrc/planes.hip); LFD_ERR_UNSUPPORTED
+ *   otherwise -- the host falls back to lfd_p32_*.  zeros: the 4 KB line of lfd_conv2d_nhwc_f16.
+ * lfd_pl_groupnorm_relu: x (planes [n, hw, c]) <- relu?(GroupNorm(c/8 groups)(x) * gamma + beta) in place, mean / rstd in
+ *   fp64 from gn_sums (lfd_head.py:97-117 conv -> GroupNorm -> ReLU). */
+typedef struct lfd_pl_conv_desc {
+  int32_t n, h, w, cin, cout, ks, stride, relu;
+  int32_t tail_cout, tail_relu;
+  int32_t out_mode;
+  int32_t f_c0, f_c1;
+  int32_t reserved;
+  int64_t in_plane_halfs, out_plane_halfs, res_plane_halfs, ds_plane_halfs;
+  int64_t f_image_stride0, f_image_stride1;
+} lfd_pl_conv_desc_t;
+LFD_API int lfd_pl_stem_pair(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
+                             const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                             int64_t out_plane_halfs, lfd_stream_t stream);
+LFD_API int lfd_pl_conv2d(const lfd_pl_conv_desc_t* desc, const void* in, void* out, const void* w_packed, const float* bias,
+                          const void* residual, const void* tail_w_packed, const float* tail_bias, const void* ds_w_packed,
+                          const float* ds_bias, void* ds_out, void* gn_sums, float* f_out0, float* f_out1, const float* scale1,
+                          const void* zeros, lfd_stream_t stream);
+LFD_API int lfd_pl_groupnorm_relu(void* x, int64_t plane_halfs, int32_t n, int64_t hw, int32_t c, const void* gn_sums,
+                                  const float* gamma, const float* beta, float eps, int32_t relu, lfd_stream_t stream);
 
 /* First stem unit: conv3x3 s2 (3 -> C) + BN + ReLU chained with conv1x1 (C -> C) + BN + ReLU
  * (lfd_resnet.py:356-374 'fast' stem; first half of the 'faster' stem :376-395).

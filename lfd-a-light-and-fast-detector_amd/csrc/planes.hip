@@ -1,0 +1,438 @@
+// csrc/planes.hip -- C ABI of the hi/lo-plane kernels: the 'fp32_storage' precision mode of the LFD eval forward
+// (lfd/model/lfd.py:511-542 and what it calls: lfd_resnet.py:354-501, simple_neck.py:67-74, lfd_head.py:164-185) rebuilt on
+// weights-stationary LDS-DMA kernels (planes_impl.h).  lfd_amd/engine_p2.py drives it; csrc/precise.hip (fp32 tensors, the
+// round-3 form of the same arithmetic) stays as the fallback for layer shapes this file has no instance for.
+//
+//   lfd_pl_stem_pair       frame (NCHW fp32 | NHWC fp16 | NHWC uint8) -> conv3x3 s2 + BN + ReLU -> conv1x1 + BN + ReLU -> planes
+//   lfd_pl_conv2d          planes -> conv (+ chained 1x1 | + 1x1 stride-2 identity branch | + residual) -> planes
+//                          (+ GroupNorm sums) or fp32 cls / reg outputs
+//   lfd_pl_groupnorm_relu  planes -> GroupNorm(groups of 8 channels) + ReLU in place, statistics from the producer's sums
+#include "planes_impl.h"
+
+namespace {
+
+using namespace pl;
+
+enum { IN_NCHW_F32 = 0, IN_NHWC_F16 = 1, IN_NHWC_U8 = 2 };
+
+struct PlStemArgs {
+  const void* in;
+  _Float16* out;       // planes [N,OH,OW,C]
+  long out_plane;
+  const half8* w1;     // [2][C/32][2][64]: engine.pack_stem_weight order per plane
+  long w1_plane;
+  const float* b1;
+  const half8* w2;     // [2][C/32][C/16][64]
+  long w2_plane;
+  const float* b2;
+  int N, H, W, OH, OW;
+  int tiles_x, tiles_y;
+};
+
+template <int FMT>
+__device__ __forceinline__ float load_px(const void* in, int n, int H, int W, int gy, int gx, int c) {
+  if (FMT == IN_NCHW_F32) {
+    return reinterpret_cast<const float*>(in)[(((size_t)n * 3 + c) * H + gy) * W + gx];
+  } else if (FMT == IN_NHWC_F16) {
+    return (float)reinterpret_cast<const _Float16*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+  } else {
+    const float v = (float)reinterpret_cast<const uint8_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+    return (v / 255.f - 0.5f) / 0.5f;     // simple_normalize (augmentation_pipeline.py:31-36) in fp32, like the reference
+  }
+}
+
+// First stem pair (lfd_resnet.py:356-374 'fast' / :376-395 first half of 'faster'): csrc/stem.hip's structure on planes.
+// The frame tile is split into hi / lo raw LDS tiles (fp16 frames: lo = 0, its MFMA is skipped), im2col from LDS, K = 27 -> 32;
+// the C-channel intermediate goes through LDS planes into the 1x1; HBM-write-bound (the pair's output is the largest tensor).
+template <int NCT, int FMT>
+__global__ __launch_bounds__(256, 2) void k_pl_stem(PlStemArgs a) {
+  constexpr bool HASLO = FMT != IN_NHWC_F16;
+  constexpr int C = NCT * 32;
+  constexpr int PG = 4 / NCT, PT = 2, TW = 32, TH = PG * PT;
+  constexpr int IH = 2 * TH + 1, IW = 2 * TW + 1;
+  constexpr int RS = ((IW * 3 + 1) / 2) * 2;
+  constexpr int IN_HALFS = IH * RS + 8;
+  constexpr int MCPP = C / 8, MPIXB = C * 2, MPPR = 16 / MCPP;
+  constexpr int MID_PLANE = TH * TW * MPIXB;
+  __shared__ __attribute__((aligned(16))) _Float16 s_in[2][IN_HALFS];
+  __shared__ __attribute__((aligned(16))) char s_mid[2 * MID_PLANE];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ct = wave % NCT, pg = wave / NCT;
+  const int h = lane >> 5, pix = lane & 31;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = a.N * tiles_per_img;
+  constexpr int NE = IH * IW * 3;
+  constexpr int NIT = (NE + 255) / 256;
+
+  const half8 w1ah = a.w1[(ct * 2 + 0) * 64 + lane], w1bh = a.w1[(ct * 2 + 1) * 64 + lane];
+  const half8 w1al = a.w1[a.w1_plane + (ct * 2 + 0) * 64 + lane], w1bl = a.w1[a.w1_plane + (ct * 2 + 1) * 64 + lane];
+  half8 w2h[C / 16], w2l[C / 16];
+#pragma unroll
+  for (int q = 0; q < C / 16; ++q) {
+    w2h[q] = a.w2[(ct * (C / 16) + q) * 64 + lane];
+    w2l[q] = a.w2[a.w2_plane + (ct * (C / 16) + q) * 64 + lane];
+  }
+
+  float rv[NIT];
+  auto fetch = [&](int t) {
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * TH * 2 - 1, gx0 = tx0 * TW * 2 - 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = it * 256 + threadIdx.x;
+      const int iy = i / (IW * 3), e = i - iy * (IW * 3);
+      const int ix = e / 3, c = e - ix * 3;
+      const int gy = gy0 + iy, gx = gx0 + ix;
+      const bool ok = i < NE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      const float v = load_px<FMT>(a.in, n, a.H, a.W, cy, cx, c);
+      rv[it] = ok ? v : 0.f;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    __syncthreads();   // the previous tile's readers of s_in / s_mid are done
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = it * 256 + threadIdx.x;
+      const int iy = i / (IW * 3), e = i - iy * (IW * 3);
+      if (i < NE) {
+        const _Float16 hh = (_Float16)rv[it];
+        s_in[0][iy * RS + e] = hh;
+        if constexpr (HASLO) s_in[1][iy * RS + e] = (_Float16)((rv[it] - (float)hh) * kLo);
+      }
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+
+    f32x16 accm[PT], accc[PT];
+    {
+      const float* bp = a.b1 + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          accm[pt][4 * g + 0] = b4.x; accm[pt][4 * g + 1] = b4.y; accm[pt][4 * g + 2] = b4.z; accm[pt][4 * g + 3] = b4.w;
+          accc[pt][4 * g + 0] = 0.f; accc[pt][4 * g + 1] = 0.f; accc[pt][4 * g + 2] = 0.f; accc[pt][4 * g + 3] = 0.f;
+        }
+      }
+    }
+    // im2col fragments, k-slots as in csrc/stem.hip: step0 {h=0: row0 e0..7, h=1: row1 e0..7},
+    // step1 {h=0: row2 e0..7, h=1: (row0 e8, row1 e8, row2 e8, 0 x5)},  e = 3 s + c
+    auto gather = [&](const _Float16* plane, int oy, half8& g0, half8& g1) {
+      const _Float16* base = plane + (2 * oy) * RS + 6 * pix;
+      union { half8 v; uint32_t u[4]; } f0, f1;
+      {
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(base + h * RS);
+        f0.u[0] = p0[0]; f0.u[1] = p0[1]; f0.u[2] = p0[2]; f0.u[3] = p0[3];
+      }
+      if (h == 0) {
+        const uint32_t* p2 = reinterpret_cast<const uint32_t*>(base + 2 * RS);
+        f1.u[0] = p2[0]; f1.u[1] = p2[1]; f1.u[2] = p2[2]; f1.u[3] = p2[3];
+      } else {
+        const uint32_t e0 = reinterpret_cast<const uint32_t*>(base + 8)[0] & 0xffffu;
+        const uint32_t e1 = reinterpret_cast<const uint32_t*>(base + RS + 8)[0] & 0xffffu;
+        const uint32_t e2 = reinterpret_cast<const uint32_t*>(base + 2 * RS + 8)[0] & 0xffffu;
+        f1.u[0] = e0 | (e1 << 16); f1.u[1] = e2; f1.u[2] = 0u; f1.u[3] = 0u;
+      }
+      g0 = f0.v; g1 = f1.v;
+    };
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int oy = pg * PT + pt;
+      half8 x0h, x1h;
+      gather(s_in[0], oy, x0h, x1h);
+      accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1ah, x0h, accm[pt], 0, 0, 0);
+      accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bh, x1h, accm[pt], 0, 0, 0);
+      accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1al, x0h, accc[pt], 0, 0, 0);
+      accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bl, x1h, accc[pt], 0, 0, 0);
+      if constexpr (HASLO) {
+        half8 x0l, x1l;
+        gather(s_in[1], oy, x0l, x1l);
+        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1ah, x0l, accc[pt], 0, 0, 0);
+        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bh, x1l, accc[pt], 0, 0, 0);
+      }
+    }
+    // conv1 epilogue (bias in accm, ReLU) -> operand planes of the 1x1
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int pb = (pg * PT + pt) * 32 + pix;
+      const int fm = (pb / MPPR) % MCPP;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo, 0.f);
+        uint2 vh, vl;
+        split2(y[0], y[1], vh.x, vl.x);
+        split2(y[2], y[3], vh.y, vl.y);
+        const int o = pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h;
+        *reinterpret_cast<uint2*>(s_mid + o) = vh;
+        *reinterpret_cast<uint2*>(s_mid + MID_PLANE + o) = vl;
+      }
+    }
+    __syncthreads();
+    {
+      const float* bp = a.b2 + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          accm[pt][4 * g + 0] = b4.x; accm[pt][4 * g + 1] = b4.y; accm[pt][4 * g + 2] = b4.z; accm[pt][4 * g + 3] = b4.w;
+          accc[pt][4 * g + 0] = 0.f; accc[pt][4 * g + 1] = 0.f; accc[pt][4 * g + 2] = 0.f; accc[pt][4 * g + 3] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < C / 16; ++q) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int pb = (pg * PT + pt) * 32 + pix;
+        const int fm = (pb / MPPR) % MCPP;
+        const int o = pb * MPIXB + (((2 * q + h) ^ fm) * 16);
+        const half8 xh = *reinterpret_cast<const half8*>(s_mid + o);
+        const half8 xl = *reinterpret_cast<const half8*>(s_mid + MID_PLANE + o);
+        accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xh, accm[pt], 0, 0, 0);
+        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xl, accc[pt], 0, 0, 0);
+        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[q], xh, accc[pt], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // every wave finished reading s_mid: it becomes the staging tile
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int pb = (pg * PT + pt) * 32 + pix;
+      const int fm = (pb / MPPR) % MCPP;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo, 0.f);
+        uint2 vh, vl;
+        split2(y[0], y[1], vh.x, vl.x);
+        split2(y[2], y[3], vh.y, vl.y);
+        const int o = pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h;
+        *reinterpret_cast<uint2*>(s_mid + o) = vh;
+        *reinterpret_cast<uint2*>(s_mid + MID_PLANE + o) = vl;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW * MCPP; i += 256) {
+      const int pb = i / MCPP, c = i - pb * MCPP;
+      const int oy = ty0 * TH + pb / TW, ox = tx0 * TW + (pb % TW);
+      if (oy < a.OH && ox < a.OW) {
+        const int fm = (pb / MPPR) % MCPP;
+        const uint4 vh = *reinterpret_cast<const uint4*>(s_mid + pb * MPIXB + ((c ^ fm) * 16));
+        const uint4 vl = *reinterpret_cast<const uint4*>(s_mid + MID_PLANE + pb * MPIXB + ((c ^ fm) * 16));
+        _Float16* dst = a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * C + c * 8;
+        *reinterpret_cast<uint4*>(dst) = vh;
+        *reinterpret_cast<uint4*>(dst + a.out_plane) = vl;
+      }
+    }
+  }
+}
+
+template <int NCT, int FMT>
+int launch_pl_stem(PlStemArgs a, hipStream_t st) {
+  constexpr int PG = 4 / NCT, TH = PG * 2, TW = 32;
+  a.tiles_x = (a.OW + TW - 1) / TW;
+  a.tiles_y = (a.OH + TH - 1) / TH;
+  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+  if (ntiles > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
+  const unsigned blocks = ntiles < 1024 ? (unsigned)ntiles : 1024u;   // 4 resident workgroups per CU (LDS)
+  hipLaunchKernelGGL((k_pl_stem<NCT, FMT>), dim3(blocks), dim3(256), 0, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+template <int NCT>
+int dispatch_pl_stem(int fmt, const PlStemArgs& a, hipStream_t st) {
+  switch (fmt) {
+    case IN_NCHW_F32: return launch_pl_stem<NCT, IN_NCHW_F32>(a, st);
+    case IN_NHWC_F16: return launch_pl_stem<NCT, IN_NHWC_F16>(a, st);
+    case IN_NHWC_U8: return launch_pl_stem<NCT, IN_NHWC_U8>(a, st);
+    default: return LFD_ERR_INVALID_ARGUMENT;
+  }
+}
+
+// GroupNorm(groups of 8 channels) + ReLU in place on planes (lfd_head.py:97-117: conv -> GroupNorm -> ReLU); mean / rstd from
+// the producer's fixed-point sums in fp64; y = (x - mean) * rstd * gamma + beta as csrc/precise.hip evaluates it
+__global__ __launch_bounds__(256) void k_pl_gn_apply(_Float16* x, long plane, long hw, int c, const unsigned long long* acc,
+                                                      const float* gamma, const float* beta, float eps, int relu) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int ngrp = c >> 3;
+  if (tid < ngrp) {
+    const long long s = (long long)acc[((size_t)n * ngrp + tid) * 2], q = (long long)acc[((size_t)n * ngrp + tid) * 2 + 1];
+    const double cnt = (double)hw * 8.0;
+    const double m = (double)s / kGnFix / cnt;
+    double var = (double)q / kGnFix / cnt - m * m;
+    var = var > 0. ? var : 0.;
+    s_mean[tid] = (float)m;
+    s_rstd[tid] = (float)(1. / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const long total = hw * ngrp;
+  _Float16* xi = x + (size_t)n * hw * c;
+  for (long i = (long)blockIdx.x * 256 + tid; i < total; i += (long)gridDim.x * 256) {
+    const int g = (int)(i % ngrp);
+    const uint4 vh = *reinterpret_cast<const uint4*>(xi + i * 8);
+    const uint4 vl = *reinterpret_cast<const uint4*>(xi + plane + i * 8);
+    const lfd_f16x8 hh = __builtin_bit_cast(lfd_f16x8, vh), ll = __builtin_bit_cast(lfd_f16x8, vl);
+    const float mean = s_mean[g], rstd = s_rstd[g];
+    union { uint32_t u[4]; uint4 v; } oh, ol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float y[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ch = g * 8 + 2 * j + e;
+        const float v = join1(hh[2 * j + e], ll[2 * j + e]);
+        const float r = (v - mean) * rstd * gamma[ch] + beta[ch];
+        y[e] = relu ? fmaxf(r, 0.f) : r;
+      }
+      split2(y[0], y[1], oh.u[j], ol.u[j]);
+    }
+    *reinterpret_cast<uint4*>(xi + i * 8) = oh.v;
+    *reinterpret_cast<uint4*>(xi + plane + i * 8) = ol.v;
+  }
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, int PTO = 0>
+int launch_pl(const PlArgs& a, int outm, hipStream_t st) {
+  const bool tail = a.w2 != nullptr, res = a.res != nullptr, ds = a.wds != nullptr;
+  if (outm == 2) {
+    if (tail || res || ds) return LFD_ERR_UNSUPPORTED;
+    if constexpr (KS == 1 && S == 1) return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 2, PTO>(a, st);
+    return LFD_ERR_UNSUPPORTED;
+  }
+  if (outm == 1) {
+    if (res || ds) return LFD_ERR_UNSUPPORTED;
+    if constexpr (KS == 1 && S == 1 && NCT == 4) {
+      if (tail) return launch_pl_<CIN, KS, S, NCT, WREG, true, false, false, 1, PTO>(a, st);
+      return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 1, PTO>(a, st);
+    }
+    return LFD_ERR_UNSUPPORTED;
+  }
+  if (tail) {
+    if (res || ds) return LFD_ERR_UNSUPPORTED;
+    if constexpr ((KS == 3 && S == 2 && WREG) || (KS == 1 && S == 1 && NCT == 4))
+      return launch_pl_<CIN, KS, S, NCT, WREG, true, false, false, 0, PTO>(a, st);
+    return LFD_ERR_UNSUPPORTED;
+  }
+  if (ds) {
+    if (res) return LFD_ERR_UNSUPPORTED;
+    if constexpr (KS == 3 && S == 2) return launch_pl_<CIN, KS, S, NCT, WREG, false, false, true, 0, PTO>(a, st);
+    return LFD_ERR_UNSUPPORTED;
+  }
+  if (res) {
+    if constexpr (S == 1 && KS == 3) return launch_pl_<CIN, KS, S, NCT, WREG, false, true, false, 0, PTO>(a, st);
+    return LFD_ERR_UNSUPPORTED;
+  }
+  return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 0, PTO>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfd_pl_stem_pair(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
+                     const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                     int64_t out_plane_halfs, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!in || !w1_packed || !b1 || !w2_packed || !b2 || !out || n < 1 || h < 1 || w < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (channels != 32 && channels != 64) return LFD_ERR_UNSUPPORTED;
+  if (!lfd_aligned16(out) || (out_plane_halfs & 7)) return LFD_ERR_INVALID_ARGUMENT;
+  PlStemArgs a{};
+  a.in = in; a.out = (_Float16*)out; a.out_plane = out_plane_halfs;
+  a.w1 = (const half8*)w1_packed; a.w1_plane = (long)(channels / 32) * 2 * 64; a.b1 = b1;
+  a.w2 = (const half8*)w2_packed; a.w2_plane = (long)(channels / 32) * (channels / 16) * 64; a.b2 = b2;
+  a.N = n; a.H = h; a.W = w; a.OH = (h + 2 - 3) / 2 + 1; a.OW = (w + 2 - 3) / 2 + 1;
+  return channels == 64 ? dispatch_pl_stem<2>(in_format, a, st) : dispatch_pl_stem<1>(in_format, a, st);
+}
+
+int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const void* w_packed, const float* bias,
+                  const void* residual, const void* tail_w_packed, const float* tail_bias, const void* ds_w_packed,
+                  const float* ds_bias, void* ds_out, void* gn_sums, float* f_out0, float* f_out1, const float* scale1,
+                  const void* zeros, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!d || !in || !w_packed || !bias || !zeros) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->n < 1 || d->h < 1 || d->w < 1 || d->cout < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if ((d->ks != 1 && d->ks != 3) || (d->stride != 1 && d->stride != 2)) return LFD_ERR_UNSUPPORTED;
+  const int outm = d->out_mode;
+  if (outm < 0 || outm > 2) return LFD_ERR_INVALID_ARGUMENT;
+  if (outm == 2 ? (d->f_c0 < 0 || d->f_c1 < 0 || d->f_c0 + d->f_c1 < 1 || (d->f_c0 > 0 && !f_out0) || (d->f_c1 > 0 && !f_out1) ||
+                   d->f_c0 + d->f_c1 > d->cout)
+                : !out)
+    return LFD_ERR_INVALID_ARGUMENT;
+  if (outm == 1 && !gn_sums) return LFD_ERR_INVALID_ARGUMENT;
+  if (outm != 2 && (d->cout % 32)) return LFD_ERR_UNSUPPORTED;
+  if (!lfd_aligned16(in) || !lfd_aligned16(out) || !lfd_aligned16(residual) || !lfd_aligned16(ds_out)) return LFD_ERR_INVALID_ARGUMENT;
+  if ((d->in_plane_halfs & 7) || (d->out_plane_halfs & 7) || (d->res_plane_halfs & 7) || (d->ds_plane_halfs & 7)) return LFD_ERR_INVALID_ARGUMENT;
+  const bool tail = d->tail_cout > 0;
+  if (tail && (!tail_w_packed || !tail_bias)) return LFD_ERR_INVALID_ARGUMENT;
+  if (ds_w_packed && (!ds_bias || !ds_out)) return LFD_ERR_INVALID_ARGUMENT;
+  PlArgs a{};
+  const int nslab = (d->cout + 31) / 32, nk = d->ks * d->ks * d->cin / 16;
+  a.in = (const _Float16*)in; a.in_plane = d->in_plane_halfs;
+  a.out = (_Float16*)out; a.out_plane = d->out_plane_halfs;
+  a.w = (const half8*)w_packed; a.w_plane = (long)nslab * nk * 64; a.bias = bias;
+  a.res = (const _Float16*)residual; a.res_plane = d->res_plane_halfs;
+  a.w2 = tail ? (const half8*)tail_w_packed : nullptr; a.w2_plane = tail ? (long)(d->tail_cout / 32) * (d->cout / 16) * 64 : 0;
+  a.bias2 = tail_bias;
+  a.wds = (const half8*)ds_w_packed; a.wds_plane = (long)nslab * (d->cin / 16) * 64; a.bds = ds_bias;
+  a.out_ds = (_Float16*)ds_out; a.ds_plane = d->ds_plane_halfs;
+  a.zeros = (const _Float16*)zeros;
+  a.N = d->n; a.H = d->h; a.W = d->w;
+  const int pad = d->ks / 2;
+  a.OH = (d->h + 2 * pad - d->ks) / d->stride + 1;
+  a.OW = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  a.cout = d->cout; a.cout2 = d->tail_cout; a.relu = d->relu; a.relu2 = d->tail_relu;
+  a.gn_acc = (unsigned long long*)gn_sums;
+  a.f_out0 = f_out0; a.f_out1 = f_out1; a.f_c0 = d->f_c0; a.f_c1 = d->f_c1;
+  a.f_img0 = d->f_image_stride0; a.f_img1 = d->f_image_stride1; a.scale1 = scale1;
+  if (tail && d->tail_cout != d->cout) return LFD_ERR_UNSUPPORTED;     // the chained 1x1 is square (CMID -> CMID)
+  const int key = d->cin * 10000 + d->ks * 1000 + d->stride * 100 + nslab;
+  switch (key) {
+    // ---- 64-channel body
+    case 64 * 10000 + 3100 + 2: return launch_pl<64, 3, 1, 2, true>(a, outm, st);
+    case 64 * 10000 + 3200 + 2: return launch_pl<64, 3, 2, 2, true>(a, outm, st);
+    case 64 * 10000 + 3200 + 4: return launch_pl<64, 3, 2, 2, true>(a, outm, st);        // two cout groups (grid.y)
+    case 64 * 10000 + 1100 + 4: return launch_pl<64, 1, 1, 4, true>(a, outm, st);        // neck 64 -> 128 (+ chained tower conv)
+    // ---- 128-channel stages and the head
+    case 128 * 10000 + 3100 + 4: return launch_pl<128, 3, 1, 4, false, 1>(a, outm, st);   // (one 32-pixel MFMA tile per wave: small maps)
+    case 128 * 10000 + 3200 + 4: return launch_pl<128, 3, 2, 4, false>(a, outm, st);
+    case 128 * 10000 + 1100 + 4: return launch_pl<128, 1, 1, 4, true>(a, outm, st);
+    case 128 * 10000 + 1100 + 1: return launch_pl<128, 1, 1, 1, true, 1>(a, outm, st);   // cls / reg outputs (<= 32 channels)
+    case 128 * 10000 + 1100 + 2: return launch_pl<128, 1, 1, 2, true>(a, outm, st);      // <= 64 output channels (TT100K: 46 classes)
+    // ---- 32-channel stem of the XS model
+    case 32 * 10000 + 3200 + 1: return launch_pl<32, 3, 2, 1, true>(a, outm, st);
+    case 32 * 10000 + 3200 + 2: return launch_pl<32, 3, 2, 2, true>(a, outm, st);
+    default: return LFD_ERR_UNSUPPORTED;
+  }
+}
+
+int lfd_pl_groupnorm_relu(void* x, int64_t plane_halfs, int32_t n, int64_t hw, int32_t c, const void* gn_sums,
+                          const float* gamma, const float* beta, float eps, int32_t relu, lfd_stream_t stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!x || !gn_sums || !gamma || !beta || n < 1 || hw < 1) return LFD_ERR_INVALID_ARGUMENT;
+  if (c < 8 || c % 8 || c > 512 || !lfd_aligned16(x) || (plane_halfs & 7)) return LFD_ERR_UNSUPPORTED;
+  long blocks = (hw * (c / 8) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(k_pl_gn_apply, dim3((unsigned)blocks, n), dim3(256), 0, st, (_Float16*)x, (long)plane_halfs, (long)hw, c,
+                     (const unsigned long long*)gn_sums, gamma, beta, eps, relu);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,782 @@
+// csrc/planes_impl.h -- (device templates of planes.hip)
+// Implicit-GEMM convolution (1x1 / 3x3, stride 1 / 2) on "hi/lo plane" tensors: the tolerance-compliant precision mode of the
+// LFD eval forward (lfd/model/lfd.py:511-542; backbone lfd_resnet.py:96-154,354-439,458-468, neck simple_neck.py:67-74, head
+// lfd_head.py:164-185) at the speed of the fused fp16 structures.
+//
+// Storage: an activation tensor x (fp32 in the reference) lives in HBM as TWO NHWC fp16 planes
+//     hi = fp16(x),   lo = fp16(2^11 (x - hi))            x = hi + 2^-11 lo  to ~22 significant bits
+// -- the bytes of an fp32 tensor, but already in the form the matrix cores consume: the tile loader is a plain global -> LDS
+// DMA per plane (no conversion, no VALU), exactly the loader of the fp16 kernels (conv_impl.h) issued twice.  Weights
+// (BatchNorm folded in fp64 on the host) are split the same way once per plan.  A k-step issues three
+// v_mfma_f32_32x32x16_f16 into two fp32 accumulator sets
+//     main += w_hi x_hi,      corr += w_hi x_lo + w_lo x_hi,      y = main + 2^-11 corr         (w_lo x_lo ~ 2^-22: dropped)
+// and the epilogue (bias, residual, ReLU in fp32) splits y into planes again.  csrc/precise.hip computes the same three
+// products from fp32 storage with the split in its loader (round 3); this file is what makes the mode fast:
+//   * weights-stationary, one wave per SIMD: a wave keeps the hi AND lo [32 cout x K] slabs of its cout tile in registers
+//     (3x3, 64 channels: 72 fragments = 288 of the 512 registers) for the lifetime of a persistent workgroup;
+//   * both planes of the halo tile arrive by direct global -> LDS DMA, double-buffered behind the contraction;
+//   * per pair of LDS fragment reads the matrix pipe gets 3 MFMAs (the fp16 kernels: 1 per read), so the LDS / DMA side that
+//     bounds the fp16 kernels has 1.5x the slack here and the contraction runs at the MFMA issue rate;
+//   * optional chained 1x1 (stem pair 3x3 s2 -> 1x1; neck 1x1 -> first tower 1x1), optional second output (a stage's 1x1
+//     stride-2 identity branch from the centre tap), GroupNorm sums of the stored values as order-independent 64-bit
+//     fixed-point atomics, fp32 outputs for the cls / reg convs (+ Scale, lfd_head.py:180-183).
+#pragma once
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace pl {
+
+constexpr float kLo = 2048.f, kInvLo = 1.f / 2048.f;
+constexpr double kGnFix = 16777216.0;   // 2^24: fixed-point scale of the GroupNorm sums
+
+struct PlArgs {
+  const _Float16* in;      // hi plane [N,H,W,CIN]; the lo plane `in_plane` halfs behind it
+  long in_plane;
+  _Float16* out;           // [N,OH,OW,cout_out] hi plane, lo plane `out_plane` halfs behind it
+  long out_plane;
+  const half8* w;          // packed [2 = hi | lo][cout/32][NK][64 lanes] x 8 halfs (ops.pack_conv_weight order per plane)
+  long w_plane;            // half8 units between the planes
+  const float* bias;       // [cout]
+  const _Float16* res;     // residual planes [N,OH,OW,cout] or null
+  long res_plane;
+  const half8* w2;         // TAIL: chained 1x1 CMID -> cout2, [2][cout2/32][CMID/16][64]
+  long w2_plane;
+  const float* bias2;
+  const half8* wds;        // DS: 1x1 stride-2 identity branch [2][cout/32][CIN/16][64]
+  long wds_plane;
+  const float* bds;
+  _Float16* out_ds;        // DS: [N,OH,OW,cout] planes (no ReLU)
+  long ds_plane;
+  const _Float16* zeros;   // 4 KB line: [0,2048) zero (source of out-of-image pixels), [2048,4096) write-only trash
+  int N, H, W, OH, OW;
+  int cout, cout2, relu, relu2;
+  int tiles_x, tiles_y, ntiles;
+  unsigned long long* gn_acc;   // OUTM 1: [N][cout_out / 8][2] fixed-point sums (sum | sum of squares) of the stored values
+  float* f_out0;           // OUTM 2: channels [0, f_c0) -> f_out0[n * f_img0 + pixel * f_c0 + c]
+  float* f_out1;           //         channels [f_c0, f_c0 + f_c1) -> f_out1[n * f_img1 + pixel * f_c1 + c - f_c0] * scale1
+  int f_c0, f_c1;
+  long f_img0, f_img1;
+  const float* scale1;     // one float or null
+};
+
+// PTO: 32-pixel MFMA tiles per wave (0: 2 for stride 1, 1 for stride 2)
+template <int CIN, int KS, int S, int NCT, bool TAIL, bool RES, int PTO>
+struct PCfg {
+  static constexpr int PT = PTO ? PTO : ((S == 1) ? 2 : 1);
+  static constexpr int TW = (S == 1 && !(CIN == 64 && KS == 3)) ? 32 : 16;
+  static constexpr int RPT = 32 / TW;
+  static constexpr int PG = 4 / NCT;
+  static constexpr int TH = PG * PT * RPT;
+  static constexpr int PAD = KS / 2;
+  static constexpr int IH = (TH - 1) * S + KS;
+  static constexpr int IW = (TW - 1) * S + KS;
+  static constexpr int IWh = (IW + 1) / 2;
+  static constexpr int IWs = (S == 2) ? 2 * IWh : ((IW + 1) & ~1);
+  static constexpr int CPP = CIN / 8;
+  static constexpr int PIXB = CIN * 2;
+  static constexpr int PPR = (CPP >= 16) ? 1 : 16 / CPP;
+  static constexpr int NSLOT = IH * IWs;
+  static constexpr int IN_BYTES = ((NSLOT * PIXB + 1023) / 1024) * 1024;    // one plane of one buffer
+  static constexpr int NK = KS * KS * CIN / 16;
+  static constexpr int NQ = CIN / 16;
+  static constexpr int CMID = NCT * 32;                 // channels of the main conv's output this workgroup holds
+  static constexpr int MCPP = CMID / 8, MPIXB = CMID * 2;
+  static constexpr int MPPR = (MCPP >= 16) ? 1 : 16 / MCPP;
+  static constexpr int NK2 = CMID / 16;
+  static constexpr int OPX = PG * PT * 32;              // pixels of the output tile
+  static constexpr int MID_PLANE = TAIL ? OPX * MPIXB : 0;
+  static constexpr int OUT_PLANE = OPX * NCT * 64;      // staging tile, one plane
+  // scratch: the chained 1x1's operand planes, then (same bytes, one barrier later) the output staging planes; it lives in
+  // the consumed input buffer when it fits there
+  static constexpr int SCR_BYTES = 2 * (MID_PLANE > OUT_PLANE ? MID_PLANE : OUT_PLANE);
+  static constexpr bool ALIAS = SCR_BYTES <= 2 * IN_BYTES;
+  static constexpr int NBUF = (S == 1 || (CIN == 64 && KS == 3 && NCT == 2)) ? 2 : 1;
+  static constexpr int SCR_OFF = NBUF * 2 * IN_BYTES;
+  static constexpr int BIAS_OFF = SCR_OFF + (ALIAS ? 0 : SCR_BYTES);
+  // RES: the residual tile (this workgroup's channel slice, both planes) arrives by DMA in copy-out order
+  static constexpr int RES_OFF = BIAS_OFF + 3 * 128 * 4;
+  static constexpr int RES_PLANE = RES ? OUT_PLANE : 0;
+  static constexpr int LDS_BYTES = RES_OFF + 2 * RES_PLANE;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
+};
+
+__device__ __forceinline__ void dma16(const void* g, const void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory");
+}
+
+__device__ __forceinline__ void block_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// y (fp32) -> packed fp16 pair of the hi plane and of the lo plane.  hi = RNE(y) (v_cvt_pk_f16_f32), y - hi is exact in fp32,
+// so is the scaling by 2^11; the second rounding (lo) leaves |y - hi - 2^-11 lo| <= 2^-23 |y|.
+__device__ __forceinline__ void split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
+  lfd_f32x2 f; f[0] = y0; f[1] = y1;
+  union { lfd_f16x2 v; uint32_t u; } h, l;
+  h.v = __builtin_convertvector(f, lfd_f16x2);
+  lfd_f32x2 r;
+  r[0] = (y0 - (float)h.v[0]) * kLo;
+  r[1] = (y1 - (float)h.v[1]) * kLo;
+  l.v = __builtin_convertvector(r, lfd_f16x2);
+  hi = h.u; lo = l.u;
+}
+
+__device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * kInvLo; }
+
+// OUTM: 0 = planes, 1 = planes + GroupNorm sums (groups of 8 channels), 2 = fp32 outputs (cls / reg)
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+__device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
+  static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES && OUTM == 0), "DS rides on a 3x3 stride-2 conv");
+  static_assert(!TAIL || (!RES && !DS), "TAIL: conv -> 1x1 in one launch");
+  static_assert(OUTM != 2 || (!TAIL && !RES && !DS), "fp32 outputs: the bare cls / reg conv");
+  using C = PCfg<CIN, KS, S, NCT, TAIL, RES, PTO>;
+  constexpr int PT = C::PT;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ct = wave % NCT;
+  const int pg = wave / NCT;
+  const int h = lane >> 5;
+  const int pix = lane & 31;
+  const int oyl = pix / C::TW, oxl = pix % C::TW;
+  const int cog = blockIdx.y;
+  const int co_base = (cog * NCT + ct) * 32;
+
+  float* sbias = reinterpret_cast<float*>(smem + C::BIAS_OFF);
+  if (threadIdx.x < NCT * 32) {
+    sbias[threadIdx.x] = a.bias[cog * NCT * 32 + threadIdx.x];
+    if constexpr (DS) sbias[128 + threadIdx.x] = a.bds[cog * NCT * 32 + threadIdx.x];
+    if constexpr (TAIL) sbias[256 + threadIdx.x] = a.bias2[threadIdx.x];
+  }
+
+  // ---- stationary weights: hi and lo slabs of this wave's cout tile
+  constexpr int NKR = WREG ? C::NK : 1;
+  half8 wh[NKR], wl[NKR];
+  const half8* wsrc = a.w + ((size_t)(cog * NCT + ct) * C::NK) * 64 + lane;
+  if constexpr (WREG) {
+#pragma unroll
+    for (int k = 0; k < NKR; ++k) {
+      wh[k] = wsrc[(size_t)k * 64];
+      wl[k] = wsrc[a.w_plane + (size_t)k * 64];
+    }
+  }
+  half8 w2h[TAIL ? C::NK2 : 1], w2l[TAIL ? C::NK2 : 1];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int k = 0; k < C::NK2; ++k) {
+      w2h[k] = a.w2[((size_t)ct * C::NK2 + k) * 64 + lane];
+      w2l[k] = a.w2[a.w2_plane + ((size_t)ct * C::NK2 + k) * 64 + lane];
+    }
+  }
+  half8 wdh[DS ? C::NQ : 1], wdl[DS ? C::NQ : 1];
+  if constexpr (DS) {
+#pragma unroll
+    for (int q = 0; q < C::NQ; ++q) {
+      wdh[q] = a.wds[((size_t)(cog * NCT + ct) * C::NQ + q) * 64 + lane];
+      wdl[q] = a.wds[a.wds_plane + ((size_t)(cog * NCT + ct) * C::NQ + q) * 64 + lane];
+    }
+  }
+
+  // ---- per-lane LDS read offsets (conv_impl.h: one per column tap and 16-channel group; XOR term formed at the read for 128 ch)
+  constexpr bool XTAB = C::NQ <= 4;
+  int xoff[KS][XTAB ? C::NQ : 1];
+  int xbase[KS], xkey[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int ix = oxl * S + s;
+    const int rem = (S == 2) ? ((ix & 1) * C::IWh + (ix >> 1)) : ix;
+    const int f = (rem / C::PPR) % C::CPP;
+    const int rowbase = ((pg * PT * C::RPT + oyl) * S) * C::IWs + rem;
+    xbase[s] = rowbase * C::PIXB;
+    xkey[s] = f ^ h;
+#pragma unroll
+    for (int q = 0; q < (XTAB ? C::NQ : 1); ++q) xoff[s][q] = rowbase * C::PIXB + (((2 * q + h) ^ f) * 16);
+  }
+
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int t_begin = xcd * per_xcd;
+  const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
+  const int t_step = (nblk + 7 - xcd) / 8;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const long in_plane_b = a.in_plane * 2;    // bytes
+
+  // ---- tile loaders: every DMA of the fp16 kernels (conv_impl.h) issued for both planes; the LDS image of a plane is the
+  //      fp16 kernels' (lane-linear lines, XOR chunk swizzle on the source side), the lo plane IN_BYTES behind the hi plane
+  constexpr bool FAST = (CIN == 64 && KS == 3 && S == 1 && NCT == 2 && !TAIL && !DS && PT == 2);
+  const long f_rowpitch = (long)a.W * (CIN * 2);
+  auto dma2 = [&](const char* src, bool valid, const char* zsrc, char* ldst) {
+    dma16(valid ? src : zsrc, ldst);
+    dma16(valid ? src + in_plane_b : zsrc, ldst + C::IN_BYTES);
+  };
+  auto issue_dma_fast = [&](int t, int buf) {
+    const int ol = lane;
+    const int f_lpx = ol >> 3;
+    const int f_c0 = ((ol & 7) ^ (f_lpx >> 1)) * 16;
+    const int f_off0 = f_lpx * 128 + f_c0, f_off1 = 1024 + f_lpx * 128 + (f_c0 ^ 64);
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * C::TH - 1, gx0 = tx0 * C::TW - 1;
+    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * f_rowpitch + (long)gx0 * (CIN * 2);
+    const char* zsrc0 = reinterpret_cast<const char*>(a.zeros) + f_c0;
+    const char* zsrc1 = reinterpret_cast<const char*>(a.zeros) + (f_c0 ^ 64);
+    const bool xv0 = (gx0 + f_lpx >= 0) && (gx0 + f_lpx < a.W);
+    const bool xv1 = (gx0 + 8 + f_lpx < a.W);
+    char* lbase = smem + buf * 2 * C::IN_BYTES;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int m = wave + 4 * j;
+      const int iy = m >> 1, hf = m & 1;
+      const int gy = gy0 + iy;
+      const bool rv = gy >= 0 && gy < a.H;
+      const char* rowp = p00 + iy * f_rowpitch;
+      if (hf) dma2(rowp + f_off1, rv && xv1, zsrc1, lbase + (iy * C::IWs + 8) * C::PIXB);
+      else dma2(rowp + f_off0, rv && xv0, zsrc0, lbase + (iy * C::IWs) * C::PIXB);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int iy = wave + 4 * j;
+      if (iy < C::IH && ol < 16) {
+        const int gy = gy0 + iy, gx = gx0 + 16 + (ol >> 3);
+        const bool ok = gy >= 0 && gy < a.H && gx < a.W;
+        dma2(p00 + iy * f_rowpitch + 2048 + ol * 16, ok, reinterpret_cast<const char*>(a.zeros) + (ol & 7) * 16,
+             lbase + (iy * C::IWs + 16) * C::PIXB);
+      }
+    }
+  };
+  constexpr bool FAST2 = (CIN == 64 && KS == 3 && S == 2);
+  auto issue_dma_s2 = [&](int t, int buf) {
+    const int ol = lane;
+    const int sl = ol >> 3, cs = ol & 7;
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * C::TH * 2 - 1, gx0 = tx0 * C::TW * 2 - 1;
+    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * f_rowpitch + (long)gx0 * (CIN * 2);
+    char* lbase = smem + buf * 2 * C::IN_BYTES;
+    constexpr int NP = (C::IWs + 7) / 8;
+    int off[NP];
+    const char* zsrc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int rem = 8 * j + sl;
+      const int ix = rem < C::IWh ? 2 * rem : 2 * rem - (2 * C::IWh - 1);
+      const int c = cs ^ ((rem / C::PPR) % C::CPP);
+      const int gx = gx0 + ix;
+      const bool ok = rem < C::IWs && ix < C::IW && gx >= 0 && gx < a.W;
+      off[j] = ok ? ix * (CIN * 2) + c * 16 : -1;
+      zsrc[j] = reinterpret_cast<const char*>(a.zeros) + c * 16;
+    }
+    for (int iy = wave; iy < C::IH; iy += 4) {
+      const int gy = gy0 + iy;
+      const bool rv = gy >= 0 && gy < a.H;
+      const char* rowp = p00 + iy * f_rowpitch;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        if (8 * j + 8 <= C::IWs || (8 * j + sl < C::IWs && 2 * (8 * j + sl) - (2 * C::IWh - 1) < C::IW))
+          dma2(rowp + off[j], rv && off[j] >= 0, zsrc[j], lbase + (iy * C::IWs + 8 * j) * C::PIXB);
+      }
+    }
+  };
+  auto issue_dma = [&](int t, int buf) {
+    if constexpr (FAST) { issue_dma_fast(t, buf); return; }
+    if constexpr (FAST2) { issue_dma_s2(t, buf); return; }
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const int gy0 = ty0 * C::TH * S - C::PAD, gx0 = tx0 * C::TW * S - C::PAD;
+    constexpr int SPW = 64 / C::CPP;
+    char* lbase = smem + buf * 2 * C::IN_BYTES;
+    for (int slot0 = wave * SPW; slot0 < C::NSLOT; slot0 += 4 * SPW) {
+      const int pslot = slot0 + lane / C::CPP;
+      const int cs = lane % C::CPP;
+      if (pslot < C::NSLOT) {
+        const int iy = pslot / C::IWs;
+        const int rem = pslot - iy * C::IWs;
+        const int ix = (S == 2) ? ((rem < C::IWh) ? 2 * rem : 2 * (rem - C::IWh) + 1) : rem;
+        const int c = cs ^ ((rem / C::PPR) % C::CPP);
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        bool needed = ix < C::IW;
+        if (KS == 1 && S == 2) needed = needed && !(ix & 1) && !(iy & 1);
+        if (needed) {
+          const bool valid = (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
+          const char* src = reinterpret_cast<const char*>(a.in + (((size_t)n * a.H + (valid ? gy : 0)) * a.W + (valid ? gx : 0)) * CIN + c * 8);
+          dma2(src, valid, reinterpret_cast<const char*>(a.zeros + c * 8), lbase + slot0 * C::PIXB);
+        }
+      }
+    }
+  };
+
+  // RES: the identity branch's tile -> LDS in copy-out order (pixel-major lines of this workgroup's channel slice), added
+  // where the output lines are formed: no registers held across the contraction, no exposed load latency
+  auto issue_res = [&](int n, int ty0, int tx0) {
+    if constexpr (RES) {
+      constexpr int OCPP_ = NCT * 4, PPI = 64 / OCPP_, NI = C::OPX / PPI;
+      const int c = lane % OCPP_;
+      for (int j = wave; j < NI; j += 4) {
+        const int pl_ = j * PPI + lane / OCPP_;
+        const int oy = ty0 * C::TH + pl_ / C::TW, ox = tx0 * C::TW + pl_ % C::TW;
+        const bool ok = oy < a.OH && ox < a.OW;
+        const _Float16* src = a.res + (((size_t)n * a.OH + (ok ? oy : 0)) * a.OW + (ok ? ox : 0)) * a.cout + cog * NCT * 32 + c * 8;
+        const _Float16* z = a.zeros + c * 8;
+        dma16(ok ? src : z, smem + C::RES_OFF + j * 1024);
+        dma16(ok ? src + a.res_plane : z, smem + C::RES_OFF + C::RES_PLANE + j * 1024);
+      }
+    }
+  };
+
+  // OUTM 1: running GroupNorm sums of the values this thread copies out (always chunk threadIdx.x % OCPP = one group of 8
+  // channels), in fp64 across tiles; flushed as fixed-point atomics when the walk leaves an image
+  double gn_s = 0., gn_q = 0.;
+  int gn_n = -1;
+  auto gn_flush = [&]() {
+    if constexpr (OUTM == 1) {
+      constexpr int OCPP = NCT * 4;
+      double s = gn_s, q = gn_q;
+#pragma unroll
+      for (int d = 32; d >= OCPP; d >>= 1) {
+        s += __shfl_xor(s, d);
+        q += __shfl_xor(q, d);
+      }
+      if (lane < OCPP && gn_n >= 0) {
+        const int grp = cog * OCPP + lane;
+        const int ngrp = (TAIL ? a.cout2 : a.cout) / 8;
+        unsigned long long* dst = a.gn_acc + ((size_t)gn_n * ngrp + grp) * 2;
+        atomicAdd(dst, (unsigned long long)__double2ll_rn(s * kGnFix));
+        atomicAdd(dst + 1, (unsigned long long)__double2ll_rn(q * kGnFix));
+      }
+      gn_s = gn_q = 0.;
+    }
+  };
+
+  int t = t_begin + bix;
+  int buf = 0;
+  bool first = true;
+  if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
+  for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1)) {
+    if (C::NBUF == 2) {
+      // the VMEM operations issued after tile t's DMA that may still be in flight are the previous tile's copy-out stores:
+      // every lane issues exactly NST of them (out-of-image lanes into the trash line), vmcnt retires in order
+      constexpr int NST = (OUTM == 2) ? 0 : 2 * ((C::OPX * NCT * 4) / 256);
+      static_assert(NST == 0 || NST == 4 || NST == 8, "copy-out stores per thread");
+      if (first || NST == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      first = false;
+      block_barrier();
+      if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
+    } else {
+      block_barrier();
+      issue_dma(t, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      block_barrier();
+    }
+
+    const int n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    const char* xb = smem + buf * 2 * C::IN_BYTES;
+    if constexpr (OUTM == 1) {
+      if (n != gn_n) {
+        gn_flush();
+        gn_n = n;
+      }
+    }
+
+    issue_res(n, ty0, tx0);
+
+    f32x16 accm[PT], accc[PT];
+    f32x16 adm[DS ? PT : 1], adc[DS ? PT : 1];
+    {
+      const float* bp = sbias + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          accm[pt][4 * g + 0] = b4.x; accm[pt][4 * g + 1] = b4.y; accm[pt][4 * g + 2] = b4.z; accm[pt][4 * g + 3] = b4.w;
+          accc[pt][4 * g + 0] = 0.f; accc[pt][4 * g + 1] = 0.f; accc[pt][4 * g + 2] = 0.f; accc[pt][4 * g + 3] = 0.f;
+        }
+      }
+      if constexpr (DS) {
+        const float* bd = sbias + 128 + ct * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bd + 8 * g);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            adm[pt][4 * g + 0] = b4.x; adm[pt][4 * g + 1] = b4.y; adm[pt][4 * g + 2] = b4.z; adm[pt][4 * g + 3] = b4.w;
+            adc[pt][4 * g + 0] = 0.f; adc[pt][4 * g + 1] = 0.f; adc[pt][4 * g + 2] = 0.f; adc[pt][4 * g + 3] = 0.f;
+          }
+        }
+      }
+    }
+
+    // ---- contraction: 3 MFMAs per (k-step, pixel tile); activation fragments PD k-steps ahead in a register ring
+    if constexpr (WREG) {
+      auto xaddr = [&](int k, int pt) {
+        const int r = k / (KS * C::NQ), s = (k / C::NQ) % KS, q = k % C::NQ;
+        const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
+        return xb + off + (r + pt * C::RPT * S) * C::IWs * C::PIXB;
+      };
+      constexpr int PD = (RES && C::NK > 20) ? 2 : 3;    // (the residual prefetch takes 32 registers of the 3x3 64-channel kernel's 512)
+      half8 xqh[PD + 1][PT], xql[PD + 1][PT];
+#pragma unroll
+      for (int k = 0; k < PD && k < C::NK; ++k) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const char* p = xaddr(k, pt);
+          xqh[k][pt] = *reinterpret_cast<const half8*>(p);
+          xql[k][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < C::NK; ++k) {
+        if (k + PD < C::NK) {
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            const char* p = xaddr(k + PD, pt);
+            xqh[(k + PD) % (PD + 1)][pt] = *reinterpret_cast<const half8*>(p);
+            xql[(k + PD) % (PD + 1)][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xqh[k % (PD + 1)][pt], accm[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xql[k % (PD + 1)][pt], accc[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xqh[k % (PD + 1)][pt], accc[pt], 0, 0, 0);
+        if constexpr (DS) {
+          if (k / C::NQ == 4) {     // centre tap = the 1x1 stride-2 branch's input pixel (lfd_resnet.py:458-468)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+              adm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdh[k % C::NQ], xqh[k % (PD + 1)][pt], adm[pt], 0, 0, 0);
+              adc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdh[k % C::NQ], xql[k % (PD + 1)][pt], adc[pt], 0, 0, 0);
+              adc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdl[k % C::NQ], xqh[k % (PD + 1)][pt], adc[pt], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // weights streamed from L2 (128-channel 3x3 layers on the small last-stage maps): a ring of PW (hi, lo) fragment pairs
+      constexpr int RK = KS * C::NQ;
+      constexpr int PW = (RK % 12 == 0) ? 12 : 8;
+      static_assert(RK % PW == 0, "weight ring must wrap on a tap-row boundary");
+      half8 wqh[PW], wql[PW];
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        wqh[i] = wsrc[(size_t)i * 64];
+        wql[i] = wsrc[a.w_plane + (size_t)i * 64];
+      }
+      constexpr int XPD = RK > 3 ? 3 : RK - 1;
+      half8 xqh[XPD + 1][PT], xql[XPD + 1][PT];
+#pragma unroll 1
+      for (int r = 0; r < KS; ++r) {
+        const char* xr = xb + r * C::IWs * C::PIXB;
+        const int knext = r * RK + PW;
+        auto xaddr = [&](int j, int pt) {
+          const int s = j / C::NQ, q = j % C::NQ;
+          const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
+          return xr + off + (pt * C::RPT * S) * C::IWs * C::PIXB;
+        };
+#pragma unroll
+        for (int j = 0; j < XPD; ++j)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            const char* p = xaddr(j, pt);
+            xqh[j][pt] = *reinterpret_cast<const half8*>(p);
+            xql[j][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
+          }
+#pragma unroll
+        for (int j = 0; j < RK; ++j) {
+          const int s = j / C::NQ, q = j % C::NQ;
+          (void)s; (void)q;
+          const half8 wfh = wqh[j % PW], wfl = wql[j % PW];
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const size_t kn = (size_t)((knext + j) < C::NK ? (knext + j) : (C::NK - 1)) * 64;
+            wqh[j % PW] = wsrc[kn];
+            wql[j % PW] = wsrc[a.w_plane + kn];
+          }
+          if (j + XPD < RK) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+              const char* p = xaddr(j + XPD, pt);
+              xqh[(j + XPD) % (XPD + 1)][pt] = *reinterpret_cast<const half8*>(p);
+              xql[(j + XPD) % (XPD + 1)][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            const half8 xh = xqh[j % (XPD + 1)][pt], xl = xql[j % (XPD + 1)][pt];
+            accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh, xh, accm[pt], 0, 0, 0);
+            accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh, xl, accc[pt], 0, 0, 0);
+            accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfl, xh, accc[pt], 0, 0, 0);
+            if constexpr (DS) {
+              if (r == 1 && s == 1) {
+                adm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdh[q], xh, adm[pt], 0, 0, 0);
+                adc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdh[q], xl, adc[pt], 0, 0, 0);
+                adc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdl[q], xh, adc[pt], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+
+    char* scr = C::ALIAS ? (smem + buf * 2 * C::IN_BYTES) : (smem + C::SCR_OFF);
+    if constexpr (TAIL) {
+      // main conv's epilogue (bias in accm, ReLU) -> hi / lo operand planes of the chained 1x1 in LDS
+      char* mid = scr;
+      if constexpr (C::ALIAS) block_barrier();      // every wave is done reading the input tile the scratch overlays
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int pb = (pg * PT + pt) * 32 + pix;
+        const int fm = (pb / C::MPPR) % C::MCPP;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y[e] = accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo;
+            if (a.relu) y[e] = fmaxf(y[e], 0.f);
+          }
+          uint2 vh, vl;
+          split2(y[0], y[1], vh.x, vl.x);
+          split2(y[2], y[3], vh.y, vl.y);
+          const int o = pb * C::MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h;
+          *reinterpret_cast<uint2*>(mid + o) = vh;
+          *reinterpret_cast<uint2*>(mid + C::MID_PLANE + o) = vl;
+        }
+      }
+      block_barrier();
+      {
+        const float* bp = sbias + 256 + ct * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            accm[pt][4 * g + 0] = b4.x; accm[pt][4 * g + 1] = b4.y; accm[pt][4 * g + 2] = b4.z; accm[pt][4 * g + 3] = b4.w;
+            accc[pt][4 * g + 0] = 0.f; accc[pt][4 * g + 1] = 0.f; accc[pt][4 * g + 2] = 0.f; accc[pt][4 * g + 3] = 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < C::NK2; ++q) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const int pb = (pg * PT + pt) * 32 + pix;
+          const int fm = (pb / C::MPPR) % C::MCPP;
+          const int o = pb * C::MPIXB + (((2 * q + h) ^ fm) * 16);
+          const half8 xh = *reinterpret_cast<const half8*>(mid + o);
+          const half8 xl = *reinterpret_cast<const half8*>(mid + C::MID_PLANE + o);
+          accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xh, accm[pt], 0, 0, 0);
+          accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xl, accc[pt], 0, 0, 0);
+          accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[q], xh, accc[pt], 0, 0, 0);
+        }
+      }
+    }
+
+    if constexpr (OUTM == 2) {
+      // fp32 outputs straight from the accumulator layout (lane = pixel, registers = channels 8g + 4h + e of the slab)
+      const float sc1 = a.scale1 ? *a.scale1 : 1.f;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int oy = ty0 * C::TH + (pg * PT + pt) * C::RPT + oyl;
+        const int ox = tx0 * C::TW + oxl;
+        if (oy < a.OH && ox < a.OW) {
+          const size_t pixi = (size_t)oy * a.OW + ox;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int co = co_base + 8 * g + 4 * h + e;
+              const float y = accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo;
+              if (co < a.f_c0) a.f_out0[(size_t)n * a.f_img0 + pixi * a.f_c0 + co] = y;
+              else if (co < a.f_c0 + a.f_c1) a.f_out1[(size_t)n * a.f_img1 + pixi * a.f_c1 + (co - a.f_c0)] = y * sc1;
+            }
+        }
+      }
+      continue;
+    }
+
+    // ---- epilogue: y = main + 2^-11 corr (+ residual) -> ReLU -> (hi, lo) -> LDS staging planes -> full-line 16-byte stores
+    const int cout_out = TAIL ? a.cout2 : a.cout;
+    const bool relu_out = TAIL ? a.relu2 : a.relu;
+    constexpr int OCPP = NCT * 4;
+    constexpr int OPIXB = NCT * 64;
+    constexpr int OPPR = (OCPP >= 16) ? 1 : 16 / OCPP;
+    constexpr int OPX = C::OPX;
+    char* sout = scr;
+    // staging overlays the consumed input tile (ALIAS) or the chained 1x1's operand planes (TAIL): every wave must be done
+    // reading them (separate scratch without TAIL: the loop-top barrier did that)
+    if constexpr (C::ALIAS || TAIL) block_barrier();
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int pb = (pg * PT + pt) * 32 + pix;
+      const int fo = (pb / OPPR) % OCPP;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo;
+          if (relu_out && !RES) y[e] = fmaxf(y[e], 0.f);       // RES: the staged value is the pre-activation conv + bias
+        }
+        uint2 vh, vl;
+        split2(y[0], y[1], vh.x, vl.x);
+        split2(y[2], y[3], vh.y, vl.y);
+        const int o = pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h;
+        *reinterpret_cast<uint2*>(sout + o) = vh;
+        *reinterpret_cast<uint2*>(sout + C::OUT_PLANE + o) = vl;
+      }
+    }
+    if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's residual DMAs landed
+    block_barrier();
+    {
+      const int cslice = TAIL ? 0 : cog * NCT * 32;
+      static_assert((OPX * OCPP) % 256 == 0, "whole copy-out rounds");
+#pragma unroll
+      for (int k = 0; k < (OPX * OCPP) / 256; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int pb = i / OCPP, c = i - pb * OCPP;
+        const int t32 = pb >> 5, p32 = pb & 31;
+        const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
+        const int ox = tx0 * C::TW + p32 % C::TW;
+        const int fo = (pb / OPPR) % OCPP;
+        uint4 vh = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
+        uint4 vl = *reinterpret_cast<const uint4*>(sout + C::OUT_PLANE + pb * OPIXB + ((c ^ fo) * 16));
+        if constexpr (RES) {
+          // y = (conv + bias) + identity -> ReLU -> planes (lfd_resnet.py:151-152), on the 8 channels of this line chunk
+          const uint4 rh = *reinterpret_cast<const uint4*>(smem + C::RES_OFF + i * 16);
+          const uint4 rl = *reinterpret_cast<const uint4*>(smem + C::RES_OFF + C::RES_PLANE + i * 16);
+          const lfd_f16x8 sh = __builtin_bit_cast(lfd_f16x8, vh), sl = __builtin_bit_cast(lfd_f16x8, vl);
+          const lfd_f16x8 qh = __builtin_bit_cast(lfd_f16x8, rh), ql = __builtin_bit_cast(lfd_f16x8, rl);
+          union { uint32_t u[4]; uint4 v; } oh, ol;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float y0 = join1(sh[2 * j], sl[2 * j]) + join1(qh[2 * j], ql[2 * j]);
+            float y1 = join1(sh[2 * j + 1], sl[2 * j + 1]) + join1(qh[2 * j + 1], ql[2 * j + 1]);
+            if (relu_out) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+            split2(y0, y1, oh.u[j], ol.u[j]);
+          }
+          vh = oh.v; vl = ol.v;
+        }
+        const bool ok = oy < a.OH && ox < a.OW;
+        // exactly two stores per lane and iteration (the counted wait at the loop top): out-of-image lanes write the trash line
+        _Float16* dst = a.out + (((size_t)n * a.OH + (ok ? oy : 0)) * a.OW + (ok ? ox : 0)) * cout_out + cslice + c * 8;
+        _Float16* trash = const_cast<_Float16*>(a.zeros) + 1024 + (threadIdx.x & 127) * 8;
+        *reinterpret_cast<uint4*>(ok ? dst : trash) = vh;
+        *reinterpret_cast<uint4*>(ok ? dst + a.out_plane : trash) = vl;
+        if constexpr (OUTM == 1) {
+          if (ok) {
+            const lfd_f16x8 hh = __builtin_bit_cast(lfd_f16x8, vh), ll = __builtin_bit_cast(lfd_f16x8, vl);
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = join1(hh[e], ll[e]);
+              s += v;
+              q += v * v;
+            }
+            gn_s += (double)s;
+            gn_q += (double)q;
+          }
+        }
+      }
+    }
+    if constexpr (DS) {
+      // second output: the identity branch (bias in adm, no ReLU) through the same staging planes
+      block_barrier();
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int pb = (pg * PT + pt) * 32 + pix;
+        const int fo = (pb / OPPR) % OCPP;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = adm[pt][4 * g + e] + adc[pt][4 * g + e] * kInvLo;
+          uint2 vh, vl;
+          split2(y[0], y[1], vh.x, vl.x);
+          split2(y[2], y[3], vh.y, vl.y);
+          const int o = pb * OPIXB + (((ct * 4 + g) ^ fo) * 16) + 8 * h;
+          *reinterpret_cast<uint2*>(sout + o) = vh;
+          *reinterpret_cast<uint2*>(sout + C::OUT_PLANE + o) = vl;
+        }
+      }
+      block_barrier();
+      const int cslice = cog * NCT * 32;
+      for (int i = threadIdx.x; i < OPX * OCPP; i += 256) {
+        const int pb = i / OCPP, c = i - pb * OCPP;
+        const int t32 = pb >> 5, p32 = pb & 31;
+        const int oy = ty0 * C::TH + t32 * C::RPT + p32 / C::TW;
+        const int ox = tx0 * C::TW + p32 % C::TW;
+        if (oy < a.OH && ox < a.OW) {
+          const int fo = (pb / OPPR) % OCPP;
+          const uint4 vh = *reinterpret_cast<const uint4*>(sout + pb * OPIXB + ((c ^ fo) * 16));
+          const uint4 vl = *reinterpret_cast<const uint4*>(sout + C::OUT_PLANE + pb * OPIXB + ((c ^ fo) * 16));
+          _Float16* dst = a.out_ds + (((size_t)n * a.OH + oy) * a.OW + ox) * a.cout + cslice + c * 8;
+          *reinterpret_cast<uint4*>(dst) = vh;
+          *reinterpret_cast<uint4*>(dst + a.ds_plane) = vl;
+        }
+      }
+    }
+  }
+  gn_flush();
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+struct PlHeavy {
+  // registers of the stationary hi + lo fragments (main slab, chained 1x1, identity branch); beyond what two waves per SIMD
+  // can hold next to 64 accumulator and 64 ring registers: one workgroup per CU, up to 512 registers per wave
+  static constexpr int wregs = (WREG ? (KS * KS * CIN / 16) * 8 : 96) + (TAIL ? NCT * 2 * 8 : 0) + (DS ? (CIN / 16) * 8 : 0);
+  static constexpr bool value = !WREG || wregs > 96;
+};
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+__global__ __launch_bounds__(256, (PlHeavy<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>::value ? 1 : 2)) void k_pl_conv(PlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>(a, smem);
+}
+
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+int launch_pl_(const PlArgs& a0, hipStream_t st) {
+  using C = PCfg<CIN, KS, S, NCT, TAIL, RES, PTO>;
+  PlArgs a = a0;
+  a.tiles_x = (a.OW + C::TW - 1) / C::TW;
+  a.tiles_y = (a.OH + C::TH - 1) / C::TH;
+  const long nt = (long)a.N * a.tiles_x * a.tiles_y;
+  if (nt > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
+  a.ntiles = (int)nt;
+  const int cgroups = TAIL ? 1 : (a.cout + NCT * 32 - 1) / (NCT * 32);
+  constexpr int LDSB = C::LDS_BYTES;
+  auto kern = k_pl_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>;
+  static unsigned long long attr_done_mask = 0;
+  const int attr_done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
+  }
+  constexpr bool heavy = PlHeavy<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>::value;
+  constexpr int per_cu = (heavy || LDSB > 80 * 1024) ? 1 : 2;
+  int blocks = (256 * per_cu) / cgroups;
+  if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kern, dim3(blocks, cgroups), dim3(256), LDSB, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
+}  // namespace pl

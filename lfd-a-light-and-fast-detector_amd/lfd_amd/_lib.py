@@ -88,7 +88,17 @@ class P32ConvDesc(C.Structure):
                 ('out_pixel_stride', C.c_int32), ('out_image_stride', C.c_int64)]
 
 
-ABI_VERSION = 2                         # LFD_HIP_ABI_VERSION
+class PlConvDesc(C.Structure):
+    """lfd_pl_conv_desc_t"""
+    _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
+                ('ks', C.c_int32), ('stride', C.c_int32), ('relu', C.c_int32), ('tail_cout', C.c_int32),
+                ('tail_relu', C.c_int32), ('out_mode', C.c_int32), ('f_c0', C.c_int32), ('f_c1', C.c_int32),
+                ('reserved', C.c_int32), ('in_plane_halfs', C.c_int64), ('out_plane_halfs', C.c_int64),
+                ('res_plane_halfs', C.c_int64), ('ds_plane_halfs', C.c_int64), ('f_image_stride0', C.c_int64),
+                ('f_image_stride1', C.c_int64)]
+
+
+ABI_VERSION = 3                         # LFD_HIP_ABI_VERSION
 HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS
 HEAD_TOWER1_GROUP_HALFS = 8 * 64 * 8    # LFD_HEAD_TOWER1_GROUP_HALFS
 
@@ -242,6 +252,9 @@ _SIGNATURES = {
     'lfd_p32_conv_packed_weight_halfs': (_SZ, [_I32, _I32, _I32]),
     'lfd_p32_conv2d_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     'lfd_p32_conv2d_tail_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _I32, _P]),
+    'lfd_pl_stem_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    'lfd_pl_conv2d': (C.c_int, [C.POINTER(PlConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_pl_groupnorm_relu': (C.c_int, [_P, _I64, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P]),
     'lfd_p32_groupnorm_workspace_bytes': (_SZ, [_I32, _I32]),
     'lfd_p32_groupnorm_relu_f32': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P]),
     'lfd_conv2d_downsample_nhwc_f16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

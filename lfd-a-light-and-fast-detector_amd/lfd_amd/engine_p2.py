@@ -1,0 +1,359 @@
+"""The 'fp32_storage' precision mode on hi/lo planes (csrc/planes.hip, csrc/planes_impl.h) -- the fast form of the mode inside
+north_star's tolerance (lfd/model/lfd.py:511-542 to <= 1e-4 on the raw logits; tests/test_gpu_precise.py).
+
+Every inter-layer tensor is a pair of NHWC fp16 planes, hi = fp16(x) and lo = fp16(2^11 (x - hi)) -- the bytes of the fp32
+tensor csrc/precise.hip stores, in the form the matrix cores consume -- and the launches are the fused structures of the fp16
+engine rebuilt on three MFMAs per k-step:
+
+  stem        lfd_pl_stem_pair (frame -> conv3x3 s2 -> conv1x1) ; lfd_pl_conv2d 3x3 s2 + chained 1x1     lfd_resnet.py:376-413
+  stage entry lfd_pl_conv2d 3x3 s2 with the 1x1 s2 identity branch as second output                       lfd_resnet.py:458-468
+  block convs lfd_pl_conv2d 3x3 s1 (+ residual + ReLU)                                                    lfd_resnet.py:96-154
+  head        neck 1x1 chained into the first tower 1x1 (GroupNorm sums from the epilogue), GroupNorm + ReLU in place,
+              second tower 1x1 (+ sums), GroupNorm + ReLU, cls + reg 1x1 as ONE conv writing fp32 [N,P,C'] / [N,P,4] (+ Scale)
+                                                                                        simple_neck.py:67-74, lfd_head.py:164-185
+
+`PlanesPlan` has the interface of engine_p32.PrecisePlan (state_for / run); engine_p32.get_plan builds it first and falls
+back to the fp32-tensor plan when a layer has no plane kernel (`Unsupported`).  The host side only folds BatchNorm (fp64),
+splits and packs weights once per parameter version, and walks the launch list.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, engine, ops
+from ._lib import check, lib, ptr, stream_ptr
+
+_UNION = engine._UNION
+_LO = 2048.0
+
+
+class Unsupported(Exception):
+    pass
+
+
+def _split(w):
+    w = w.detach().float()
+    hi = w.half()
+    lo = ((w - hi.float()) * _LO).half()
+    return hi, lo
+
+
+def pack_planes_weight(w):
+    """[cout, cin, k, k] fp32 -> fp16 [2 = hi | 2^11 lo][ceil(cout/32)][k*k*cin/16][64][8] (ops.pack_conv_weight order per
+    plane, include/lfd_hip.h lfd_pl_conv2d); rows zero-padded to a multiple of 32."""
+    w = w.detach().float()
+    cout = w.shape[0]
+    ns = -(-cout // 32)
+    if ns * 32 != cout:
+        w = torch.cat([w, w.new_zeros((ns * 32 - cout,) + tuple(w.shape[1:]))], 0)
+    hi, lo = _split(w)
+    return torch.stack([ops.pack_conv_weight(hi), ops.pack_conv_weight(lo)], 0).contiguous()
+
+
+def pack_planes_stem_weight(w):
+    """[C, 3, 3, 3] fp32 -> [2][C/32][2][64][8] (engine.pack_stem_weight order per plane)"""
+    hi, lo = _split(w)
+    return torch.stack([engine.pack_stem_weight(hi), engine.pack_stem_weight(lo)], 0).contiguous()
+
+
+def _pad_bias(b, mult=32):
+    n = -(-b.numel() // mult) * mult
+    out = b.new_zeros(n, dtype=torch.float32)
+    out[:b.numel()] = b.float()
+    return out
+
+
+def to_planes(x):
+    """fp32 NHWC tensor -> planes [2, N, H, W, C] fp16 (tests, tools)"""
+    hi = x.half()
+    return torch.stack([hi, ((x - hi.float()) * _LO).half()], 0).contiguous()
+
+
+def from_planes(p):
+    return p[0].float() + p[1].float() / _LO
+
+
+# (cin, ks, stride, ceil(cout / 32)) -> options csrc/planes.hip has an instance for (lfd_pl_conv2d's dispatch)
+_DISPATCH = {
+    (64, 3, 1, 2): {'res'}, (64, 3, 2, 2): {'tail', 'ds'}, (64, 3, 2, 4): {'ds'}, (64, 1, 1, 4): {'tail', 'gn', 'out32'},
+    (128, 3, 1, 4): {'res'}, (128, 3, 2, 4): {'ds'}, (128, 1, 1, 4): {'tail', 'gn', 'out32'}, (128, 1, 1, 1): {'out32'},
+    (128, 1, 1, 2): {'out32'}, (32, 3, 2, 1): {'tail', 'ds'}, (32, 3, 2, 2): {'tail', 'ds'},
+}
+
+
+def _check_dispatch(cin, cout, ks, stride, tail, ds, res, gn, out32):
+    opts = _DISPATCH.get((cin, ks, stride, -(-cout // 32)))
+    used = {k for k, v in (('tail', tail), ('ds', ds), ('res', res), ('gn', gn), ('out32', out32)) if v}
+    if opts is None or not (used - {'gn'} <= opts and (not gn or 'gn' in opts)) or len(used - {'gn'}) > 1:
+        raise Unsupported('no plane kernel for conv %d -> %d k%d s%d %s' % (cin, cout, ks, stride, sorted(used)))
+    if gn and (res or ds or out32):
+        raise Unsupported('GroupNorm sums ride on a plain or chained 1x1')
+
+
+class _Op(object):
+    __slots__ = ('kind', 'src', 'dst', 'res', 'ds_dst', 'cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'ds',
+                 'out_mode', 'gn', 'gamma', 'beta', 'eps', 'level', 'f_c0', 'f_c1', 'scale', 'w1', 'b1', 'w2', 'b2', 'channels')
+
+    def __init__(self, kind):
+        self.kind = kind
+        for k in self.__slots__[1:]:
+            setattr(self, k, None)
+
+
+class PlanesPlan(object):
+    """launch plan of the planes forward for one (module tree, parameter version)"""
+
+    def __init__(self, model, device):
+        self.device = device
+        self.param_sig = engine._param_signature(model._backbone, model._neck, model._head)
+        self._shape_cache = {}
+        self.ops = []
+        self.buf_channels = {}
+        self.buf_scale = {}
+        self._nbuf = 0
+        self.num_gn = 0
+        with torch.no_grad():
+            self._build(model)
+
+    # ------------------------------------------------------------------ plan construction
+    def _new_buf(self, channels, scale):
+        b = self._nbuf
+        self._nbuf += 1
+        self.buf_channels[b], self.buf_scale[b] = channels, scale
+        return b
+
+    def _conv(self, src, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=False, out32=None):
+        """w: folded fp32 OIHW, b: fp32 bias.  tail = (w2 [c,c,1,1], b2, relu2); ds = (w [cout,cin,1,1], b): identity branch
+        as second output; gn: GroupNorm sums of the stored values; out32 = (level, c0, c1, scale): fp32 cls / reg outputs"""
+        dev = self.device
+        cout, cin = w.shape[0], w.shape[1]
+        if cin not in (32, 64, 128) or (out32 is None and cout % 32):
+            raise Unsupported('conv %d -> %d' % (cin, cout))
+        _check_dispatch(cin, cout, ks, stride, tail is not None, ds is not None, res is not None, gn, out32 is not None)
+        o = _Op('conv')
+        o.src, o.res, o.ks, o.stride, o.relu, o.cin, o.cout = src, res, ks, stride, int(relu), cin, cout
+        o.w = pack_planes_weight(w).to(dev)
+        o.b = _pad_bias(b, 128).to(dev)
+        sc = self.buf_scale[src] * stride
+        if tail is not None:
+            if tuple(tail[0].shape) != (cout, cout, 1, 1):
+                raise Unsupported('chained 1x1 must be square')
+            o.tail = (pack_planes_weight(tail[0]).to(dev), _pad_bias(tail[1], 128).to(dev), int(tail[2]))
+        if ds is not None:
+            if tuple(ds[0].shape) != (cout, cin, 1, 1) or ks != 3 or stride != 2:
+                raise Unsupported('identity branch must be the 1x1 stride-2 twin of a 3x3 stride-2 conv')
+            o.ds = (pack_planes_weight(ds[0]).to(dev), _pad_bias(ds[1], 128).to(dev))
+            o.ds_dst = self._new_buf(cout, sc)
+        if out32 is not None:
+            o.out_mode = 2
+            o.level, o.f_c0, o.f_c1, o.scale = out32
+        else:
+            o.out_mode = 1 if gn else 0
+            o.dst = self._new_buf(cout, sc)
+            if gn:
+                if cout != 128:
+                    raise Unsupported('GroupNorm sums: 128 channels in groups of 8')
+                o.gn = self.num_gn
+                self.num_gn += 1
+        self.ops.append(o)
+        return o
+
+    def _gn(self, conv_op, norm):
+        if not (isinstance(norm, nn.GroupNorm) and norm.num_channels == 128 and norm.num_groups == 16):
+            raise Unsupported('head norm must be GroupNorm(16, 128)')
+        o = _Op('gn')
+        o.src, o.gn = conv_op.dst, conv_op.gn
+        o.gamma = norm.weight.detach().float().contiguous().to(self.device)
+        o.beta = norm.bias.detach().float().contiguous().to(self.device)
+        o.eps = float(norm.eps)
+        self.ops.append(o)
+
+    def _build(self, model):
+        bb, neck, head = model._backbone, model._neck, model._head
+        if type(neck).__name__ != 'SimpleNeck' or type(head).__name__ != 'LFDHead':
+            raise Unsupported('SimpleNeck + LFDHead')
+        if bb._input_channels != 3 or (bb._norm_cfg is not None and bb._norm_cfg['type'] != 'BatchNorm2d'):
+            raise Unsupported('backbone')
+        has_norm = bb._norm_cfg is not None
+        step = 3 if has_norm else 2
+        spec = list(bb.stem_spec())
+        folded = [engine.fold_conv_norm(bb._stem[i * step], bb._stem[i * step + 1] if has_norm else None) for i in range(len(spec))]
+        # ---- stem: pairs conv3x3 s2 -> conv1x1 (lfd_resnet.py:356-413)
+        if len(spec) not in (2, 4) or [(k, s) for k, s, _, _ in spec] != [(3, 2), (1, 1)] * (len(spec) // 2):
+            raise Unsupported('stem mode')
+        c = folded[0][0].shape[0]
+        if c not in (32, 64) or tuple(folded[1][0].shape[:2]) != (c, c):
+            raise Unsupported('stem channels')
+        o = _Op('stem')
+        o.channels = c
+        o.w1, o.b1 = pack_planes_stem_weight(folded[0][0]).to(self.device), _pad_bias(folded[0][1]).to(self.device)
+        o.w2, o.b2 = pack_planes_weight(folded[1][0]).to(self.device), _pad_bias(folded[1][1]).to(self.device)
+        o.dst = self._new_buf(c, 2)
+        self.ops.append(o)
+        cur = o.dst
+        if len(spec) == 4:
+            if tuple(folded[3][0].shape[:2]) != (c, c):
+                raise Unsupported('stem channels')
+            cur = self._conv(cur, folded[2][0], folded[2][1], 3, 2, True, tail=(folded[3][0], folded[3][1], True)).dst
+        # ---- residual stages (lfd_resnet.py:96-154, :458-468, :488-501)
+        taps = [tuple(t) for t in bb._out_indices]
+        self.taps = []
+        for i, nblk in enumerate(bb._body_architecture):
+            for j in range(nblk):
+                blk = getattr(bb, 'stage%d' % i)[j]
+                ident, y = cur, cur
+                for ci in range(1, blk.num_convs + 1):
+                    conv = getattr(blk, '_conv%d' % ci)
+                    w, b = engine.fold_conv_norm(conv, getattr(blk, '_norm%d' % ci, None))
+                    ks, st = conv.kernel_size[0], conv.stride[0]
+                    last = ci == blk.num_convs
+                    ds = None
+                    if ci == 1 and blk._downsample is not None:
+                        dconv = blk._downsample[0]
+                        if dconv.kernel_size[0] != 1 or dconv.stride[0] != 2 or (ks, st) != (3, 2) or last:
+                            raise Unsupported('downsample branch')
+                        ds = engine.fold_conv_norm(dconv, blk._downsample[1] if len(blk._downsample) > 1 else None)
+                    elif ci > 1 and st != 1:
+                        raise Unsupported('stride inside a block')
+                    if ci == 1 and blk._downsample is None and st != 1:
+                        raise Unsupported('strided block without a downsample branch')
+                    op = self._conv(y, w, b, ks, st, True, res=ident if last else None, ds=ds)
+                    y = op.dst
+                    if ds is not None:
+                        ident = op.ds_dst
+                cur = y
+                if (i, j) in taps:
+                    self.taps.append(cur)
+        # ---- neck + head (simple_neck.py:67-74, lfd_head.py:164-185)
+        if head._norm_cfg is None or head._conv_kernel_size != 1:
+            raise Unsupported('head towers must be 1x1 conv + GroupNorm')
+        nl = head._num_conv_layers
+        union = head._regression_loss_type in _UNION
+        self.cls_channels = head.num_cls_channels
+        self.num_levels = head._num_heads
+        ccls = self.cls_channels
+
+        def tower(seq, t, first_tail_of=None):
+            """conv -> GroupNorm -> ReLU layers; with `first_tail_of` = (neck w, b, src) the neck conv and the first tower conv
+            are one launch"""
+            for l in range(nl):
+                conv, norm = seq[l * 3], seq[l * 3 + 1]
+                bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=conv.weight.device)
+                w = conv.weight.detach().float()
+                if l == 0 and first_tail_of is not None:
+                    nw, nb, src = first_tail_of
+                    op = self._conv(src, nw, nb, 1, 1, True, tail=(w, bias, False), gn=True)
+                else:
+                    op = self._conv(t, w, bias, 1, 1, False, gn=True)
+                self._gn(op, norm)
+                t = op.dst
+            return t
+
+        for i, f in enumerate(self.taps):
+            nseq = getattr(neck, 'neck%d' % i)
+            nw, nb = engine.fold_conv_norm(nseq[0], nseq[1] if neck._norm_cfg is not None else None)
+            if nw.shape[0] != 128 or nw.shape[2] != 1:
+                raise Unsupported('neck must be 1x1 -> 128')
+            cls_path = getattr(head, 'head%d_classification_path' % i)
+            reg_path = getattr(head, 'head%d_regression_path' % i)
+            scale = head._scales[i]._scale.detach().float().reshape(1).to(self.device) if union else None
+            if head._merge_path_flag:
+                if nl < 1:
+                    raise Unsupported('merge path without tower convs')
+                tt = tower(getattr(head, 'head%d_merge_path' % i), None, first_tail_of=(nw, nb, f))
+                cconv, rconv = cls_path[0], reg_path[0]
+                if cconv.kernel_size[0] != 1 or rconv.kernel_size[0] != 1 or ccls + 4 > 64:
+                    raise Unsupported('output convs')
+                w = torch.cat([cconv.weight.detach().float(), rconv.weight.detach().float()], 0)
+                b = torch.cat([cconv.bias.detach().float(), rconv.bias.detach().float()], 0)
+                self._conv(tt, w, b, 1, 1, False, out32=(i, ccls, 4, scale))
+            else:
+                t = self._conv(f, nw, nb, 1, 1, True).dst
+                cconv, rconv = cls_path[nl * 3], reg_path[nl * 3]
+                if cconv.kernel_size[0] != 1 or rconv.kernel_size[0] != 1 or ccls > 64:
+                    raise Unsupported('output convs')
+                tc, tr = tower(cls_path, t), tower(reg_path, t)
+                self._conv(tc, cconv.weight.detach().float(), cconv.bias.detach().float(), 1, 1, False, out32=(i, ccls, 0, None))
+                self._conv(tr, rconv.weight.detach().float(), rconv.bias.detach().float(), 1, 1, False, out32=(i, 0, 4, scale))
+
+    # ------------------------------------------------------------------ execution
+    def state_for(self, n, h, w, slot=0):
+        key = (n, h, w, slot)
+        st = self._shape_cache.get(key)
+        if st is None:
+            st = _State(self, n, h, w)
+            self._shape_cache[key] = st
+        return st
+
+    def run(self, x, fmt, st):
+        l, sp = lib(), stream_ptr()
+        zeros = ptr(ops.zero_line(self.device))
+        if self.num_gn:
+            st.gn_sums.zero_()
+        for o in self.ops:
+            if o.kind == 'stem':
+                dst = st.bufs[o.dst]
+                check(l.lfd_pl_stem_pair(ptr(x), fmt, st.n, st.h, st.w, o.channels, ptr(o.w1), ptr(o.b1), ptr(o.w2), ptr(o.b2),
+                                         ptr(dst), dst[0].numel(), sp), 'lfd_pl_stem_pair')
+                continue
+            if o.kind == 'gn':
+                t = st.bufs[o.src]
+                check(l.lfd_pl_groupnorm_relu(ptr(t), t[0].numel(), st.n, t.shape[2] * t.shape[3], t.shape[4], ptr(st.gn_sums[o.gn]),
+                                              ptr(o.gamma), ptr(o.beta), o.eps, 1, sp), 'lfd_pl_groupnorm_relu')
+                continue
+            src = st.bufs[o.src]
+            d = _lib.PlConvDesc()
+            d.n, d.h, d.w, d.cin, d.cout, d.ks, d.stride, d.relu = st.n, src.shape[2], src.shape[3], o.cin, o.cout, o.ks, o.stride, o.relu
+            d.out_mode = o.out_mode
+            d.in_plane_halfs = src[0].numel()
+            dst = res = dsd = None
+            f0 = f1 = None
+            if o.out_mode == 2:
+                d.f_c0, d.f_c1 = o.f_c0, o.f_c1
+                d.f_image_stride0, d.f_image_stride1 = st.P * o.f_c0, st.P * 4
+                f0 = C.c_void_p(st.cls.data_ptr() + st.p_off[o.level] * o.f_c0 * 4) if o.f_c0 else None
+                f1 = C.c_void_p(st.reg.data_ptr() + st.p_off[o.level] * 4 * 4) if o.f_c1 else None
+            else:
+                dst = st.bufs[o.dst]
+                d.out_plane_halfs = dst[0].numel()
+            if o.res is not None:
+                res = st.bufs[o.res]
+                d.res_plane_halfs = res[0].numel()
+            if o.ds is not None:
+                dsd = st.bufs[o.ds_dst]
+                d.ds_plane_halfs = dsd[0].numel()
+            if o.tail is not None:
+                d.tail_cout, d.tail_relu = o.cout, o.tail[2]
+            check(l.lfd_pl_conv2d(C.byref(d), ptr(src), ptr(dst), ptr(o.w), ptr(o.b), ptr(res),
+                                  ptr(o.tail[0]) if o.tail else None, ptr(o.tail[1]) if o.tail else None,
+                                  ptr(o.ds[0]) if o.ds else None, ptr(o.ds[1]) if o.ds else None, ptr(dsd),
+                                  ptr(st.gn_sums[o.gn]) if o.gn is not None else None, f0, f1,
+                                  ptr(o.scale) if o.scale is not None else None, zeros, sp), 'lfd_pl_conv2d')
+
+
+class _State(object):
+    """plane buffers [2, N, H, W, C] fp16, the fp32 [N,P,C'] / [N,P,4] outputs and the GroupNorm sums for one input shape"""
+
+    def __init__(self, plan, n, h, w):
+        dev = plan.device
+        self.n, self.h, self.w = n, h, w
+        self.bufs, self.dims = {}, {}
+        with torch.cuda.device(dev):
+            for b, sc in plan.buf_scale.items():
+                hh, ww, s = h, w, sc
+                while s > 1:
+                    hh, ww = (hh + 1) // 2, (ww + 1) // 2
+                    s //= 2
+                self.dims[b] = (hh, ww)
+                self.bufs[b] = torch.empty((2, n, hh, ww, plan.buf_channels[b]), dtype=torch.float16, device=dev)
+            self.sizes = [self.dims[t] for t in plan.taps]
+            self.p_off, p = [], 0
+            for hh, ww in self.sizes:
+                self.p_off.append(p)
+                p += hh * ww
+            self.P = p
+            self.cls = torch.empty((n, p, plan.cls_channels), dtype=torch.float32, device=dev)
+            self.reg = torch.empty((n, p, 4), dtype=torch.float32, device=dev)
+            self.gn_sums = torch.zeros((max(plan.num_gn, 1), n, 16, 2), dtype=torch.int64, device=dev)
+        self.graph = {}

@@ -267,13 +267,29 @@ class _State(object):
         self.graph = {}
 
 
+def planes_enabled():
+    """host-side A/B switch (tests, tools): LFD_P32_PLANES=0 keeps the fp32-tensor plan of this file"""
+    import os
+    return os.environ.get('LFD_P32_PLANES', '1') != '0'
+
+
 def get_plan(model, device):
+    """The hi/lo-plane plan (engine_p2.PlanesPlan, csrc/planes.hip) when every layer has a plane kernel -- all named
+    configurations -- else the fp32-tensor plan of this file; same interface, same tolerance."""
     cache = model.__dict__.setdefault('_lfd_p32_cache', {})
-    key = (device.type, device.index)
+    key = (device.type, device.index, planes_enabled())
     plan = cache.get(key)
     sig = engine._param_signature(model._backbone, model._neck, model._head)
     if plan is None or plan.param_sig != sig:
-        plan = PrecisePlan(model, device)
+        plan = None
+        if planes_enabled():
+            from . import engine_p2
+            try:
+                plan = engine_p2.PlanesPlan(model, device)
+            except engine_p2.Unsupported:
+                plan = None
+        if plan is None:
+            plan = PrecisePlan(model, device)
         cache[key] = plan
     return plan
 

@@ -13,7 +13,7 @@ import os
 import torch
 
 _lib = None
-_ABI_VERSION = 2      # LFD_HIP_ABI_VERSION of include/lfd_hip.h
+_ABI_VERSION = 3      # LFD_HIP_ABI_VERSION of include/lfd_hip.h
 
 
 def _load():

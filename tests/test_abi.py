@@ -29,7 +29,7 @@ def test_abi_version_and_strings():
     l = _lib.lib()
     src = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
     header_version = int(re.search(r'#define LFD_HIP_ABI_VERSION (\d+)', src).group(1))
-    assert l.lfd_hip_abi_version() == header_version == _lib.ABI_VERSION == 2
+    assert l.lfd_hip_abi_version() == header_version == _lib.ABI_VERSION == 3
     # the two self-contained extension files check the same number (a stale build selected through LFD_HIP_LIB would index
     # grown structs with the wrong stride)
     for rel in ('model/utils/libs/nms_ext.py', 'model/losses/libs/sigmoid_focal_loss_ext.py'):

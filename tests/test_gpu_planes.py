@@ -1,0 +1,277 @@
+"""The hi/lo-plane kernels of the 'fp32_storage' precision mode (csrc/planes.hip, csrc/planes_impl.h; lfd_amd/engine_p2.py)
+against float64 PyTorch of the same op on the values the planes hold:
+
+  * lfd_pl_conv2d: every dispatched (cin, ks, stride, cout) class with each of its options -- chained 1x1 (stem pair,
+    neck -> tower conv), second output (a stage's 1x1 stride-2 identity branch, lfd_resnet.py:458-468), residual + ReLU
+    (lfd_resnet.py:151-152), GroupNorm sums, fp32 cls / reg outputs at a point offset with Scale (lfd_head.py:176-183,
+    lfd.py:526-542) -- on shapes with partial tiles and several tiles per image;
+  * lfd_pl_stem_pair: the three frame formats (lfd_resnet.py:356-374; simple_normalize augmentation_pipeline.py:31-36);
+  * lfd_pl_groupnorm_relu + the fixed-point sums vs F.group_norm in float64 (lfd_head.py:97-117); sums bit-reproducible;
+  * the planes plan == the fp32-tensor plan of round 3 (engine_p32.PrecisePlan) on whole networks to 2e-5.
+The whole-network gates against the fp32 oracle (raw <= 1e-4, sigma <= 1e-3) are tests/test_gpu_precise.py: LFD.precision =
+'fp32_storage' runs this plan for every configuration it covers.
+"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lfd_amd import _lib, configs, engine_p2, engine_p32, ops
+from lfd_amd._lib import check, lib, ptr, stream_ptr
+
+pytestmark = pytest.mark.gpu
+TOL = 4e-6     # relative to max(1, max |y|): ~22-bit products, fp32 accumulation, one hi/lo split on the way out
+
+
+def _ref_conv(x, w, b, ks, stride, relu, res=None):
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=ks // 2).permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + res.double()
+    return y.relu() if relu else y
+
+
+def _pl_conv(xp, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=None, out32=None):
+    """xp: planes [2,N,H,W,cin] cuda.  Returns planes out (and ds planes) or None for out32."""
+    dev = xp.device
+    n, h, wd, cin = xp.shape[1:]
+    cout = w.shape[0]
+    oh, ow = (h + 2 * (ks // 2) - ks) // stride + 1, (wd + 2 * (ks // 2) - ks) // stride + 1
+    d = _lib.PlConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ks, d.stride, d.relu = n, h, wd, cin, cout, ks, stride, int(relu)
+    d.in_plane_halfs = xp[0].numel()
+    keep = [engine_p2.pack_planes_weight(w).to(dev), engine_p2._pad_bias(b, 128).to(dev)]
+    out = dsd = None
+    tw = tb = dw = db = None
+    f0 = f1 = sc = None
+    if out32 is not None:
+        d.out_mode = 2
+        t0, t1, c0, c1, off, P, scale = out32
+        d.f_c0, d.f_c1, d.f_image_stride0, d.f_image_stride1 = c0, c1, P * c0, P * c1
+        f0 = C.c_void_p(t0.data_ptr() + off * c0 * 4) if c0 else None
+        f1 = C.c_void_p(t1.data_ptr() + off * c1 * 4) if c1 else None
+        sc = scale
+    else:
+        d.out_mode = 1 if gn is not None else 0
+        out = torch.full((2, n, oh, ow, cout), float('nan'), dtype=torch.float16, device=dev)
+        d.out_plane_halfs = out[0].numel()
+    if res is not None:
+        d.res_plane_halfs = res[0].numel()
+    if tail is not None:
+        d.tail_cout, d.tail_relu = cout, int(tail[2])
+        tw, tb = engine_p2.pack_planes_weight(tail[0]).to(dev), engine_p2._pad_bias(tail[1], 128).to(dev)
+    if ds is not None:
+        dw, db = engine_p2.pack_planes_weight(ds[0]).to(dev), engine_p2._pad_bias(ds[1], 128).to(dev)
+        dsd = torch.full((2, n, oh, ow, cout), float('nan'), dtype=torch.float16, device=dev)
+        d.ds_plane_halfs = dsd[0].numel()
+    check(lib().lfd_pl_conv2d(C.byref(d), ptr(xp), ptr(out), ptr(keep[0]), ptr(keep[1]), ptr(res), ptr(tw), ptr(tb), ptr(dw), ptr(db),
+                              ptr(dsd), ptr(gn), f0, f1, ptr(sc), ptr(ops.zero_line(dev)), stream_ptr()), 'lfd_pl_conv2d')
+    torch.cuda.synchronize()
+    return out, dsd
+
+
+def _close(got_planes, ref, what):
+    got = engine_p2.from_planes(got_planes.cpu()).double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert not torch.isnan(got).any(), what + ': unwritten output'
+    err, mag = float((got - ref).abs().max()), float(ref.abs().max())
+    print('%s: err %.2e (max |y| %.2f)' % (what, err, mag))
+    assert err <= TOL * max(1.0, mag), what
+
+
+def _inputs(seed, n, h, w, cin, cout, ks):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, h, w, cin, generator=g) * 2
+    xp = engine_p2.to_planes(x)
+    xv = engine_p2.from_planes(xp)                       # the value the planes hold (|x - xv| <= 2^-22 |x|)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    return g, xp.cuda(), xv, wt, b
+
+
+@pytest.mark.parametrize('cin,cout,ks,stride,n,h,w', [
+    (64, 64, 3, 1, 2, 19, 37), (64, 64, 3, 1, 3, 8, 16), (64, 64, 3, 1, 1, 70, 130), (128, 128, 3, 1, 2, 17, 30), (128, 128, 3, 1, 1, 5, 70),
+    (64, 64, 3, 2, 2, 33, 50), (64, 128, 3, 2, 2, 34, 60), (128, 128, 3, 2, 2, 21, 39), (32, 32, 3, 2, 2, 20, 28), (32, 64, 3, 2, 1, 41, 77),
+    (64, 128, 1, 1, 2, 9, 45), (128, 128, 1, 1, 2, 17, 30), (128, 128, 1, 1, 1, 68, 120)])
+def test_pl_conv_plain_and_residual_vs_float64(cin, cout, ks, stride, n, h, w):
+    g, xp, xv, wt, b = _inputs(cin * 1000 + cout * 10 + ks + stride + h, n, h, w, cin, cout, ks)
+    ref = _ref_conv(xv, wt, b, ks, stride, True)
+    got, _ = _pl_conv(xp, wt, b, ks, stride, True)
+    _close(got, ref, 'plain %d->%d k%d s%d' % (cin, cout, ks, stride))
+    if ks == 3 and stride == 1:
+        res = torch.randn(ref.shape, generator=g)
+        rp = engine_p2.to_planes(res)
+        for relu in (True, False):
+            ref2 = _ref_conv(xv, wt, b, ks, stride, relu, engine_p2.from_planes(rp))
+            got2, _ = _pl_conv(xp, wt, b, ks, stride, relu, res=rp.cuda())
+            _close(got2, ref2, 'residual relu=%d %d->%d' % (relu, cin, cout))
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(64, 64, 2, 33, 50), (64, 64, 1, 135, 240), (64, 128, 2, 34, 60), (128, 128, 2, 21, 39), (32, 64, 2, 20, 28),
+                                            (32, 32, 1, 31, 45)])
+def test_pl_conv_stride2_with_identity_branch_vs_float64(cin, cout, n, h, w):
+    """first block of a stage (lfd_resnet.py:458-468): conv3x3 s2 + BN + ReLU and the 1x1 s2 + BN identity branch in one launch"""
+    g, xp, xv, wt, b = _inputs(7 + cin + cout + h, n, h, w, cin, cout, 3)
+    wd_, bd_ = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5), torch.randn(cout, generator=g)
+    got, dsd = _pl_conv(xp, wt, b, 3, 2, True, ds=(wd_, bd_))
+    _close(got, _ref_conv(xv, wt, b, 3, 2, True), 'entry main %d->%d' % (cin, cout))
+    _close(dsd, _ref_conv(xv, wd_, bd_, 1, 2, False), 'entry identity %d->%d' % (cin, cout))
+
+
+@pytest.mark.parametrize('cin,c,ks,stride,n,h,w', [(64, 64, 3, 2, 2, 33, 50), (64, 64, 3, 2, 1, 100, 180), (32, 32, 3, 2, 2, 20, 28),
+                                                   (64, 128, 1, 1, 2, 9, 45), (128, 128, 1, 1, 2, 17, 30), (64, 128, 1, 1, 1, 68, 120)])
+def test_pl_conv_chained_1x1_vs_float64(cin, c, ks, stride, n, h, w):
+    """stem pair conv3x3 s2 + ReLU -> conv1x1 + ReLU (lfd_resnet.py:396-413); neck conv + ReLU -> first tower conv (no ReLU:
+    GroupNorm follows) with the GroupNorm sums of the stored values"""
+    g, xp, xv, wt, b = _inputs(11 + cin + c + h, n, h, w, cin, c, ks)
+    w2, b2 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
+    relu2 = ks == 3
+    mid = _ref_conv(xv, wt, b, ks, stride, True)
+    # the intermediate is split into planes on its way to the second contraction: reference on the same values
+    midv = engine_p2.from_planes(engine_p2.to_planes(mid.float())).double()
+    ref = _ref_conv(midv, w2, b2, 1, 1, relu2)
+    gn = torch.zeros((n, c // 8, 2), dtype=torch.int64, device='cuda') if ks == 1 else None
+    got, _ = _pl_conv(xp, wt, b, ks, stride, True, tail=(w2, b2, relu2), gn=gn)
+    err_mid = float((mid - midv).abs().max())
+    _close(got, ref, 'chained %d->%d->%d k%d (split of the intermediate %.1e)' % (cin, c, c, ks, err_mid))
+    if gn is not None:
+        _check_sums(gn, got)
+
+
+def _check_sums(gn, planes):
+    v = engine_p2.from_planes(planes.cpu()).double()            # [n, h, w, c]
+    n, c = v.shape[0], v.shape[3]
+    vg = v.reshape(n, -1, c // 8, 8)
+    s, q = vg.sum((1, 3)), (vg * vg).sum((1, 3))
+    sabs = float(vg.abs().sum((1, 3)).max())
+    got = gn.cpu().double() / 2.0 ** 24
+    assert float((got[..., 0] - s).abs().max()) <= 2e-6 * sabs + 1e-5
+    assert float((got[..., 1] - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 17, 30), (1, 135, 240), (3, 1, 5)])
+def test_pl_tower_conv_sums_and_groupnorm_vs_float64(n, h, w):
+    """conv1x1 128 -> 128 with GroupNorm sums, then GroupNorm(16, 128) + ReLU in place (lfd_head.py:97-117)"""
+    g, xp, xv, wt, b = _inputs(3 + h, n, h, w, 128, 128, 1)
+    gamma, beta = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    sums = torch.zeros((n, 16, 2), dtype=torch.int64, device='cuda')
+    got, _ = _pl_conv(xp, wt, b, 1, 1, False, gn=sums)
+    _close(got, _ref_conv(xv, wt, b, 1, 1, False), 'tower conv')
+    _check_sums(sums, got)
+    # bit-reproducible statistics: order-independent fixed-point atomics
+    sums2 = torch.zeros_like(sums)
+    got2, _ = _pl_conv(xp, wt, b, 1, 1, False, gn=sums2)
+    assert torch.equal(sums, sums2) and torch.equal(got, got2)
+    yv = engine_p2.from_planes(got.cpu()).double()
+    ref = F.group_norm(yv.reshape(n, h * w, 128).permute(0, 2, 1), 16, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1).relu()
+    gd, bd = gamma.cuda(), beta.cuda()
+    check(lib().lfd_pl_groupnorm_relu(ptr(got), got[0].numel(), n, h * w, 128, ptr(sums), ptr(gd), ptr(bd), 1e-5, 1, stream_ptr()),
+          'lfd_pl_groupnorm_relu')
+    torch.cuda.synchronize()
+    out = engine_p2.from_planes(got.cpu()).double().reshape(n, h * w, 128)
+    assert float((out - ref).abs().max()) <= 6e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('ccls,merged', [(1, True), (46, False), (3, True)])
+def test_pl_output_convs_write_fp32_into_the_level_concatenated_tensors(ccls, merged):
+    """cls + reg convs (+ Scale on reg) straight into [N,P,C'] / [N,P,4] at a point offset (lfd.py:526-542); everything outside
+    the level's rows stays untouched"""
+    g, xp, xv, _, _ = _inputs(ccls, 3, 5, 37, 128, 32, 1)
+    P, off, hw = 300, 41, 5 * 37
+    wc, bc = torch.randn(ccls, 128, 1, 1, generator=g) * 0.1, torch.randn(ccls, generator=g)
+    wr, br = torch.randn(4, 128, 1, 1, generator=g) * 0.1, torch.randn(4, generator=g)
+    sc = torch.tensor([1.37])
+    cls = torch.full((3, P, ccls), -7.0, device='cuda')
+    reg = torch.full((3, P, 4), -7.0, device='cuda')
+    scd = sc.cuda()
+    if merged:
+        _pl_conv(xp, torch.cat([wc, wr]), torch.cat([bc, br]), 1, 1, False, out32=(cls, reg, ccls, 4, off, P, scd))
+    else:
+        _pl_conv(xp, wc, bc, 1, 1, False, out32=(cls, None, ccls, 0, off, P, None))
+        _pl_conv(xp, wr, br, 1, 1, False, out32=(None, reg, 0, 4, off, P, scd))
+    rc = _ref_conv(xv, wc, bc, 1, 1, False).reshape(3, hw, ccls)
+    rr = (_ref_conv(xv, wr, br, 1, 1, False) * 1.37).reshape(3, hw, 4)
+    c, r = cls.cpu(), reg.cpu()
+    assert float((c[:, off:off + hw].double() - rc).abs().max()) < 1e-5
+    assert float((r[:, off:off + hw].double() - rr).abs().max()) < 1e-5
+    for t in (c, r):
+        assert bool((t[:, :off] == -7).all()) and bool((t[:, off + hw:] == -7).all())
+
+
+@pytest.mark.parametrize('fmt', [0, 1, 2])
+@pytest.mark.parametrize('c', [64, 32])
+def test_pl_stem_pair_vs_float64(fmt, c):
+    g = torch.Generator().manual_seed(fmt * 7 + c)
+    n, h, w = 2, 37, 131
+    w1, b1 = torch.randn(c, 3, 3, 3, generator=g) * 0.3, torch.randn(c, generator=g)
+    w2, b2 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
+    if fmt == 0:
+        x = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+        xr = x.permute(0, 2, 3, 1)
+    elif fmt == 1:
+        x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half()
+        xr = x.float()
+    else:
+        x = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+        xr = (x.float() / 255 - 0.5) / 0.5
+    xr = engine_p2.from_planes(engine_p2.to_planes(xr))
+    mid = _ref_conv(xr, w1, b1, 3, 2, True)
+    ref = _ref_conv(engine_p2.from_planes(engine_p2.to_planes(mid.float())).double(), w2, b2, 1, 1, True)
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    out = torch.full((2, n, oh, ow, c), float('nan'), dtype=torch.float16, device='cuda')
+    xd = x.cuda()
+    keep = [engine_p2.pack_planes_stem_weight(w1).cuda(), engine_p2._pad_bias(b1).cuda(), engine_p2.pack_planes_weight(w2).cuda(),
+            engine_p2._pad_bias(b2).cuda()]
+    check(lib().lfd_pl_stem_pair(ptr(xd), fmt, n, h, w, c, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(out), out[0].numel(),
+                                 stream_ptr()), 'lfd_pl_stem_pair')
+    torch.cuda.synchronize()
+    _close(out, ref, 'stem pair fmt %d c %d' % (fmt, c))
+
+
+def test_pl_conv_refuses_what_it_has_no_instance_for():
+    xp = torch.zeros((2, 1, 8, 8, 64), dtype=torch.float16, device='cuda')
+    d = _lib.PlConvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.ks, d.stride, d.relu = 1, 8, 8, 64, 96, 3, 1, 1
+    d.in_plane_halfs = d.out_plane_halfs = xp[0].numel()
+    w, b = torch.zeros(1 << 16, dtype=torch.float16, device='cuda'), torch.zeros(128, device='cuda')
+    out = torch.zeros((2, 1, 8, 8, 96), dtype=torch.float16, device='cuda')
+    z = ops.zero_line(xp.device)
+    rc = lib().lfd_pl_conv2d(C.byref(d), ptr(xp), ptr(out), ptr(w), ptr(b), None, None, None, None, None, None, None, None, None, None,
+                             ptr(z), stream_ptr())
+    assert rc == -4       # LFD_ERR_UNSUPPORTED
+    d.cout = 64
+    rc = lib().lfd_pl_conv2d(C.byref(d), ptr(xp), None, ptr(w), ptr(b), None, None, None, None, None, None, None, None, None, None,
+                             ptr(z), stream_ptr())
+    assert rc == -1       # out == NULL
+
+
+@pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_S', (2, 135, 241)), ('WIDERFACE_LFD_XS', (1, 96, 128)), ('TT100K_LFD_L', (2, 90, 161)),
+                                        ('WIDERFACE_LFD_L', (1, 100, 156))])
+def test_planes_plan_equals_the_fp32_tensor_plan(name, shape):
+    """the two forms of the mode (hi/lo planes, csrc/planes.hip; fp32 tensors, csrc/precise.hip) agree to 2e-5 on the raw logits"""
+    m = configs.build_model(name)
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    m.precision = 'fp32_storage'
+    x = (torch.rand(shape[0], 3, shape[1], shape[2], generator=torch.Generator().manual_seed(5)) * 2 - 1).cuda()
+    from lfd_amd import engine_p32 as e32
+    with torch.no_grad():
+        plan = e32.get_plan(m, x.device)
+        assert isinstance(plan, engine_p2.PlanesPlan)
+        c, r = m(x)
+        c2, r2 = m(x)
+        assert torch.equal(c, c2) and torch.equal(r, r2)          # deterministic (fixed-point GroupNorm sums)
+        old = os.environ.get('LFD_P32_PLANES')
+        os.environ['LFD_P32_PLANES'] = '0'
+        try:
+            assert isinstance(e32.get_plan(m, x.device), e32.PrecisePlan)
+            c0, r0 = m(x)
+        finally:
+            if old is None:
+                del os.environ['LFD_P32_PLANES']
+            else:
+                os.environ['LFD_P32_PLANES'] = old
+    err = max(float((c - c0).abs().max()), float((r - r0).abs().max()))
+    print('%s: planes vs fp32 tensors %.2e' % (name, err))
+    assert err <= 2e-5
