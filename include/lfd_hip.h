@@ -523,6 +523,10 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  *   outputs without planes: channel c < f_c0 -> f_out0[image * f_image_stride0 + pixel * f_c0 + c], f_c0 <= c < f_c0 + f_c1
  *   -> f_out1[image * f_image_stride1 + pixel * f_c1 + c - f_c0] * (*scale1) (lfd_head.py:176-183: cls / reg convs + Scale
  *   straight into the level-concatenated [N,P,C'] / [N,P,4] tensors, lfd.py:526-542).
+ *   gn_in_sums != NULL (1x1 convs on 128 channels): the input planes are the PRE-normalisation output of the conv that
+ *   accumulated gn_in_sums; the landed tile is normalised (GroupNorm(16, 128), gn_in_gamma / gn_in_beta / desc->gn_in_eps,
+ *   mean / rstd in fp64 from the sums) + ReLU'd in LDS before the contraction -- the tower's conv -> GroupNorm -> ReLU
+ *   (lfd_head.py:97-117) without a pass over the tensor.
  *   Supported shapes: the layers of every named configuration (see the dispatch in csrc/planes.hip); LFD_ERR_UNSUPPORTED
  *   otherwise -- the host falls back to lfd_p32_*.  zeros: the 4 KB line of lfd_conv2d_nhwc_f16.
  * lfd_pl_groupnorm_relu: x (planes [n, hw, c]) <- relu?(GroupNorm(c/8 groups)(x) * gamma + beta) in place, mean / rstd in
@@ -532,7 +536,7 @@ typedef struct lfd_pl_conv_desc {
   int32_t tail_cout, tail_relu;
   int32_t out_mode;
   int32_t f_c0, f_c1;
-  int32_t reserved;
+  float gn_in_eps;
   int64_t in_plane_halfs, out_plane_halfs, res_plane_halfs, ds_plane_halfs;
   int64_t f_image_stride0, f_image_stride1;
 } lfd_pl_conv_desc_t;
@@ -542,7 +546,8 @@ LFD_API int lfd_pl_stem_pair(const void* in, int32_t in_format, int32_t n, int32
 LFD_API int lfd_pl_conv2d(const lfd_pl_conv_desc_t* desc, const void* in, void* out, const void* w_packed, const float* bias,
                           const void* residual, const void* tail_w_packed, const float* tail_bias, const void* ds_w_packed,
                           const float* ds_bias, void* ds_out, void* gn_sums, float* f_out0, float* f_out1, const float* scale1,
-                          const void* zeros, lfd_stream_t stream);
+                          const void* gn_in_sums, const float* gn_in_gamma, const float* gn_in_beta, const void* zeros,
+                          lfd_stream_t stream);
 LFD_API int lfd_pl_groupnorm_relu(void* x, int64_t plane_halfs, int32_t n, int64_t hw, int32_t c, const void* gn_sums,
                                   const float* gamma, const float* beta, float eps, int32_t relu, lfd_stream_t stream);
 

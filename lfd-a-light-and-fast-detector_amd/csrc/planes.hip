@@ -29,26 +29,39 @@ struct PlStemArgs {
   int tiles_x, tiles_y;
 };
 
+// the element as loaded (bit pattern) -- nothing is computed from it at the load site: any use would make the compiler wait for
+// the load right there, i.e. (vmcnt retires in order) for the previous tile's output stores in front of it, a full HBM write
+// round trip per tile (measured: 9-11 k of a tile's 16 k cycles)
 template <int FMT>
-__device__ __forceinline__ float load_px(const void* in, int n, int H, int W, int gy, int gx, int c) {
+__device__ __forceinline__ uint32_t load_px_raw(const void* in, int n, int H, int W, int gy, int gx, int c) {
   if (FMT == IN_NCHW_F32) {
-    return reinterpret_cast<const float*>(in)[(((size_t)n * 3 + c) * H + gy) * W + gx];
+    return reinterpret_cast<const uint32_t*>(in)[(((size_t)n * 3 + c) * H + gy) * W + gx];
   } else if (FMT == IN_NHWC_F16) {
-    return (float)reinterpret_cast<const _Float16*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+    return reinterpret_cast<const uint16_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
   } else {
-    const float v = (float)reinterpret_cast<const uint8_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
-    return (v / 255.f - 0.5f) / 0.5f;     // simple_normalize (augmentation_pipeline.py:31-36) in fp32, like the reference
+    return reinterpret_cast<const uint8_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
   }
+}
+template <int FMT>
+__device__ __forceinline__ float px_value(uint32_t raw) {
+  if (FMT == IN_NCHW_F32) return __uint_as_float(raw);
+  if (FMT == IN_NHWC_F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)raw);
+  return ((float)raw / 255.f - 0.5f) / 0.5f;   // simple_normalize (augmentation_pipeline.py:31-36) in fp32, like the reference
 }
 
 // First stem pair (lfd_resnet.py:356-374 'fast' / :376-395 first half of 'faster'): csrc/stem.hip's structure on planes.
 // The frame tile is split into hi / lo raw LDS tiles (fp16 frames: lo = 0, its MFMA is skipped), im2col from LDS, K = 27 -> 32;
 // the C-channel intermediate goes through LDS planes into the 1x1; HBM-write-bound (the pair's output is the largest tensor).
+// 8 waves per workgroup, one 32-pixel MFMA tile each (wave = cout slab x pixel group): ~110 registers per wave, so two
+// workgroups = 4 waves per SIMD overlap each other's barrier-separated phases (4 waves with two tiles each needed 216
+// registers -> 2 waves per SIMD, and the pair ran latency-bound at 340 us against 210 us of output writes)
+constexpr int kStemThreads = 512;
 template <int NCT, int FMT>
-__global__ __launch_bounds__(256, 2) void k_pl_stem(PlStemArgs a) {
+__global__ __launch_bounds__(kStemThreads, 4) void k_pl_stem(PlStemArgs a) {
   constexpr bool HASLO = FMT != IN_NHWC_F16;
   constexpr int C = NCT * 32;
-  constexpr int PG = 4 / NCT, PT = 2, TW = 32, TH = PG * PT;
+  constexpr int NTH = kStemThreads;
+  constexpr int PG = (NTH / 64) / NCT, PT = 1, TW = 32, TH = PG * PT;
   constexpr int IH = 2 * TH + 1, IW = 2 * TW + 1;
   constexpr int RS = ((IW * 3 + 1) / 2) * 2;
   constexpr int IN_HALFS = IH * RS + 8;
@@ -64,10 +77,8 @@ __global__ __launch_bounds__(256, 2) void k_pl_stem(PlStemArgs a) {
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = a.N * tiles_per_img;
   constexpr int NE = IH * IW * 3;
-  constexpr int NIT = (NE + 255) / 256;
+  constexpr int NIT = (NE + NTH - 1) / NTH;
 
-  const half8 w1ah = a.w1[(ct * 2 + 0) * 64 + lane], w1bh = a.w1[(ct * 2 + 1) * 64 + lane];
-  const half8 w1al = a.w1[a.w1_plane + (ct * 2 + 0) * 64 + lane], w1bl = a.w1[a.w1_plane + (ct * 2 + 1) * 64 + lane];
   half8 w2h[C / 16], w2l[C / 16];
 #pragma unroll
   for (int q = 0; q < C / 16; ++q) {
@@ -75,58 +86,86 @@ __global__ __launch_bounds__(256, 2) void k_pl_stem(PlStemArgs a) {
     w2l[q] = a.w2[a.w2_plane + (ct * (C / 16) + q) * 64 + lane];
   }
 
-  float rv[NIT];
+  uint32_t rv[NIT];
+  uint32_t rok = 0;       // bit `it`: element `it` of this thread lies inside the image
+  // per-thread constants of the raw-tile walk: element i = it * NTH + tid -> (row iy, position e = 3 ix + c in the row)
+  int goff[NIT], loff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * NTH + (int)threadIdx.x;
+    const int iy = i / (IW * 3), e = i - iy * (IW * 3);
+    const int ix = e / 3, c = e - ix * 3;
+    loff[it] = i < NE ? iy * RS + e : -1;
+    if (FMT == IN_NCHW_F32) goff[it] = i < NE ? (c * a.H + iy) * a.W + ix : 0;     // elements
+    else goff[it] = i < NE ? iy * a.W * 3 + e : 0;
+  }
   auto fetch = [&](int t) {
     const int n = t / tiles_per_img;
     const int tr = t - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
     const int gy0 = ty0 * TH * 2 - 1, gx0 = tx0 * TW * 2 - 1;
+    if (gy0 >= 0 && gx0 >= 0 && gy0 + IH <= a.H && gx0 + IW <= a.W) {
+      // interior tile (all but the frame's border tiles): tile base + the per-thread constant offsets
+      rok = 0xffffffffu;
+      if (FMT == IN_NCHW_F32) {
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(a.in) + ((size_t)n * 3 * a.H + gy0) * a.W + gx0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rv[it] = base[goff[it]];
+      } else if (FMT == IN_NHWC_F16) {
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(a.in) + (((size_t)n * a.H + gy0) * a.W + gx0) * 3;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rv[it] = base[goff[it]];
+      } else {
+        const uint8_t* base = reinterpret_cast<const uint8_t*>(a.in) + (((size_t)n * a.H + gy0) * a.W + gx0) * 3;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rv[it] = base[goff[it]];
+      }
+      return;
+    }
+    rok = 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = it * 256 + threadIdx.x;
+      const int i = it * NTH + threadIdx.x;
       const int iy = i / (IW * 3), e = i - iy * (IW * 3);
       const int ix = e / 3, c = e - ix * 3;
       const int gy = gy0 + iy, gx = gx0 + ix;
       const bool ok = i < NE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-      const float v = load_px<FMT>(a.in, n, a.H, a.W, cy, cx, c);
-      rv[it] = ok ? v : 0.f;
+      rv[it] = load_px_raw<FMT>(a.in, n, a.H, a.W, cy, cx, c);
+      rok |= ok ? (1u << it) : 0u;
     }
   };
 
   int t = blockIdx.x;
   if (t < ntiles) fetch(t);
-  for (; t < ntiles; t += gridDim.x) {
+  int dbg_it = 0; (void)dbg_it;
+  for (; t < ntiles; t += gridDim.x, ++dbg_it) {
+    PL_T(0);
+    // the first conv's four filter fragments are re-read per tile (L1 / L2 hits, requested here, used after the next barrier):
+    // 16 registers that are not held across the tile keep the kernel at 128
+    const half8 w1ah = a.w1[(ct * 2 + 0) * 64 + lane], w1bh = a.w1[(ct * 2 + 1) * 64 + lane];
+    const half8 w1al = a.w1[a.w1_plane + (ct * 2 + 0) * 64 + lane], w1bl = a.w1[a.w1_plane + (ct * 2 + 1) * 64 + lane];
     const int n = t / tiles_per_img;
     const int tr = t - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
-    __syncthreads();   // the previous tile's readers of s_in / s_mid are done
+    block_barrier();   // the previous tile's readers of s_in / s_mid are done
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = it * 256 + threadIdx.x;
-      const int iy = i / (IW * 3), e = i - iy * (IW * 3);
-      if (i < NE) {
-        const _Float16 hh = (_Float16)rv[it];
-        s_in[0][iy * RS + e] = hh;
-        if constexpr (HASLO) s_in[1][iy * RS + e] = (_Float16)((rv[it] - (float)hh) * kLo);
+      if (loff[it] >= 0) {
+        const float v = ((rok >> it) & 1u) ? px_value<FMT>(rv[it]) : 0.f;
+        const _Float16 hh = (_Float16)v;
+        s_in[0][loff[it]] = hh;
+        if constexpr (HASLO) s_in[1][loff[it]] = (_Float16)((v - (float)hh) * kLo);
       }
     }
-    __syncthreads();
+    PL_T(1);
+    block_barrier();
+    PL_T(2);
+#ifndef PL_STEM_NOFETCH
     if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+#endif
+    PL_T(3);
 
-    f32x16 accm[PT], accc[PT];
-    {
-      const float* bp = a.b1 + ct * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          accm[pt][4 * g + 0] = b4.x; accm[pt][4 * g + 1] = b4.y; accm[pt][4 * g + 2] = b4.z; accm[pt][4 * g + 3] = b4.w;
-          accc[pt][4 * g + 0] = 0.f; accc[pt][4 * g + 1] = 0.f; accc[pt][4 * g + 2] = 0.f; accc[pt][4 * g + 3] = 0.f;
-        }
-      }
-    }
     // im2col fragments, k-slots as in csrc/stem.hip: step0 {h=0: row0 e0..7, h=1: row1 e0..7},
     // step1 {h=0: row2 e0..7, h=1: (row0 e8, row1 e8, row2 e8, 0 x5)},  e = 3 s + c
     auto gather = [&](const _Float16* plane, int oy, half8& g0, half8& g1) {
@@ -147,77 +186,24 @@ __global__ __launch_bounds__(256, 2) void k_pl_stem(PlStemArgs a) {
       }
       g0 = f0.v; g1 = f1.v;
     };
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int oy = pg * PT + pt;
-      half8 x0h, x1h;
-      gather(s_in[0], oy, x0h, x1h);
-      accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1ah, x0h, accm[pt], 0, 0, 0);
-      accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bh, x1h, accm[pt], 0, 0, 0);
-      accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1al, x0h, accc[pt], 0, 0, 0);
-      accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bl, x1h, accc[pt], 0, 0, 0);
-      if constexpr (HASLO) {
-        half8 x0l, x1l;
-        gather(s_in[1], oy, x0l, x1l);
-        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1ah, x0l, accc[pt], 0, 0, 0);
-        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bh, x1l, accc[pt], 0, 0, 0);
-      }
-    }
-    // conv1 epilogue (bias in accm, ReLU) -> operand planes of the 1x1
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int pb = (pg * PT + pt) * 32 + pix;
-      const int fm = (pb / MPPR) % MCPP;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo, 0.f);
-        uint2 vh, vl;
-        split2(y[0], y[1], vh.x, vl.x);
-        split2(y[2], y[3], vh.y, vl.y);
-        const int o = pb * MPIXB + (((ct * 4 + g) ^ fm) * 16) + 8 * h;
-        *reinterpret_cast<uint2*>(s_mid + o) = vh;
-        *reinterpret_cast<uint2*>(s_mid + MID_PLANE + o) = vl;
-      }
-    }
-    __syncthreads();
-    {
-      const float* bp = a.b2 + ct * 32 + 4 * h;
+    auto acc_init = [&](f32x16& m, f32x16& c, const float* bias) {
+      const float* bp = bias + ct * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          accm[pt][4 * g + 0] = b4.x; accm[pt][4 * g + 1] = b4.y; accm[pt][4 * g + 2] = b4.z; accm[pt][4 * g + 3] = b4.w;
-          accc[pt][4 * g + 0] = 0.f; accc[pt][4 * g + 1] = 0.f; accc[pt][4 * g + 2] = 0.f; accc[pt][4 * g + 3] = 0.f;
-        }
+        m[4 * g + 0] = b4.x; m[4 * g + 1] = b4.y; m[4 * g + 2] = b4.z; m[4 * g + 3] = b4.w;
+        c[4 * g + 0] = 0.f; c[4 * g + 1] = 0.f; c[4 * g + 2] = 0.f; c[4 * g + 3] = 0.f;
       }
-    }
-#pragma unroll
-    for (int q = 0; q < C / 16; ++q) {
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        const int pb = (pg * PT + pt) * 32 + pix;
-        const int fm = (pb / MPPR) % MCPP;
-        const int o = pb * MPIXB + (((2 * q + h) ^ fm) * 16);
-        const half8 xh = *reinterpret_cast<const half8*>(s_mid + o);
-        const half8 xl = *reinterpret_cast<const half8*>(s_mid + MID_PLANE + o);
-        accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xh, accm[pt], 0, 0, 0);
-        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xl, accc[pt], 0, 0, 0);
-        accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[q], xh, accc[pt], 0, 0, 0);
-      }
-    }
-    __syncthreads();   // every wave finished reading s_mid: it becomes the staging tile
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
+    };
+    // (bias in m) -> ReLU -> hi / lo planes of the [pixel][C] tile in s_mid (operand of the 1x1, then the staging tile)
+    auto to_mid = [&](const f32x16& m, const f32x16& c, int pt) {
       const int pb = (pg * PT + pt) * 32 + pix;
       const int fm = (pb / MPPR) % MCPP;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo, 0.f);
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(comb(m[4 * g + e], c[4 * g + e]), 0.f);
         uint2 vh, vl;
         split2(y[0], y[1], vh.x, vl.x);
         split2(y[2], y[3], vh.y, vl.y);
@@ -225,32 +211,93 @@ __global__ __launch_bounds__(256, 2) void k_pl_stem(PlStemArgs a) {
         *reinterpret_cast<uint2*>(s_mid + o) = vh;
         *reinterpret_cast<uint2*>(s_mid + MID_PLANE + o) = vl;
       }
+    };
+    // one pixel tile at a time through each stage: 32 accumulator registers live instead of 64 (four workgroups per CU)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      f32x16 accm, accc;
+      acc_init(accm, accc, a.b1);
+      const int oy = pg * PT + pt;
+      half8 x0h, x1h;
+      gather(s_in[0], oy, x0h, x1h);
+      accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1ah, x0h, accm, 0, 0, 0);
+      accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bh, x1h, accm, 0, 0, 0);
+      accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1al, x0h, accc, 0, 0, 0);
+      accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bl, x1h, accc, 0, 0, 0);
+      if constexpr (HASLO) {
+        half8 x0l, x1l;
+        gather(s_in[1], oy, x0l, x1l);
+        accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1ah, x0l, accc, 0, 0, 0);
+        accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1bh, x1l, accc, 0, 0, 0);
+      }
+      to_mid(accm, accc, pt);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < TH * TW * MCPP; i += 256) {
-      const int pb = i / MCPP, c = i - pb * MCPP;
-      const int oy = ty0 * TH + pb / TW, ox = tx0 * TW + (pb % TW);
-      if (oy < a.OH && ox < a.OW) {
+    PL_T(4);
+    block_barrier();
+    PL_T(5);
+    f32x16 tm[PT], tc[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      acc_init(tm[pt], tc[pt], a.b2);
+      const int pb = (pg * PT + pt) * 32 + pix;
+      const int fm = (pb / MPPR) % MCPP;
+#pragma unroll
+      for (int q = 0; q < C / 16; ++q) {
+        const int o = pb * MPIXB + (((2 * q + h) ^ fm) * 16);
+        const half8 xh = *reinterpret_cast<const half8*>(s_mid + o);
+        const half8 xl = *reinterpret_cast<const half8*>(s_mid + MID_PLANE + o);
+        tm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xh, tm[pt], 0, 0, 0);
+        tc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xl, tc[pt], 0, 0, 0);
+        tc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[q], xh, tc[pt], 0, 0, 0);
+      }
+    }
+    PL_T(6);
+    block_barrier();   // every wave finished reading s_mid: it becomes the staging tile
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) to_mid(tm[pt], tc[pt], pt);
+    PL_T(7);
+    block_barrier();
+    PL_T(8);
+    {
+      // thread tid, round k: staging pixel (tid / MCPP) + (NTH / MCPP) k, chunk tid % MCPP -> tile row k RPC + co_row, column
+      // co_col: a scalar tile base + per-thread constants
+      constexpr int PPRD = NTH / MCPP, RPC = PPRD / TW, NRD = (TH * TW * MCPP) / NTH;
+      static_assert(PPRD % TW == 0 && (TH * TW * MCPP) % NTH == 0, "whole rows per copy-out round");
+      const int pb0 = (int)threadIdx.x / MCPP, c = (int)threadIdx.x % MCPP;
+      const int co_row = pb0 / TW, co_col = pb0 % TW;
+      _Float16* obase = a.out + (((size_t)n * a.OH + ty0 * TH) * a.OW + tx0 * TW) * C;
+      const long gofs = ((long)co_row * a.OW + co_col) * C + c * 8;
+      const bool colok = tx0 * TW + co_col < a.OW;
+#pragma unroll
+      for (int k = 0; k < NRD; ++k) {
+        const int pb = pb0 + PPRD * k;
         const int fm = (pb / MPPR) % MCPP;
         const uint4 vh = *reinterpret_cast<const uint4*>(s_mid + pb * MPIXB + ((c ^ fm) * 16));
         const uint4 vl = *reinterpret_cast<const uint4*>(s_mid + MID_PLANE + pb * MPIXB + ((c ^ fm) * 16));
-        _Float16* dst = a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * C + c * 8;
-        *reinterpret_cast<uint4*>(dst) = vh;
-        *reinterpret_cast<uint4*>(dst + a.out_plane) = vl;
+#ifdef PL_STEM_NOSTORE
+        if (colok && ty0 * TH + k * RPC + co_row < a.OH && vh.x == 0x12345678u) {
+#else
+        if (colok && ty0 * TH + k * RPC + co_row < a.OH) {
+#endif
+          _Float16* dst = obase + gofs + (long)k * RPC * a.OW * C;
+          *reinterpret_cast<uint4*>(dst) = vh;
+          *reinterpret_cast<uint4*>(dst + a.out_plane) = vl;
+        }
       }
     }
+    PL_T(9);
   }
 }
 
 template <int NCT, int FMT>
 int launch_pl_stem(PlStemArgs a, hipStream_t st) {
-  constexpr int PG = 4 / NCT, TH = PG * 2, TW = 32;
+  constexpr int PG = (kStemThreads / 64) / NCT, TH = PG, TW = 32;
   a.tiles_x = (a.OW + TW - 1) / TW;
   a.tiles_y = (a.OH + TH - 1) / TH;
   const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
   if (ntiles > 0x7fffffffLL) return LFD_ERR_UNSUPPORTED;
-  const unsigned blocks = ntiles < 1024 ? (unsigned)ntiles : 1024u;   // 4 resident workgroups per CU (LDS)
-  hipLaunchKernelGGL((k_pl_stem<NCT, FMT>), dim3(blocks), dim3(256), 0, st, a);
+  const unsigned blocks = ntiles < 512 ? (unsigned)ntiles : 512u;   // 2 resident workgroups of 8 waves per CU
+  hipLaunchKernelGGL((k_pl_stem<NCT, FMT>), dim3(blocks), dim3(kStemThreads), 0, st, a);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
@@ -310,7 +357,19 @@ __global__ __launch_bounds__(256) void k_pl_gn_apply(_Float16* x, long plane, lo
 
 template <int CIN, int KS, int S, int NCT, bool WREG, int PTO = 0>
 int launch_pl(const PlArgs& a, int outm, hipStream_t st) {
-  const bool tail = a.w2 != nullptr, res = a.res != nullptr, ds = a.wds != nullptr;
+  const bool tail = a.w2 != nullptr, res = a.res != nullptr, ds = a.wds != nullptr, gnin = a.gnin_acc != nullptr;
+  if (gnin) {
+    // normalise + ReLU the landed tile (the producer's GroupNorm): the tower's second conv and the output convs
+    if (tail || res || ds) return LFD_ERR_UNSUPPORTED;
+    if constexpr (CIN == 128 && KS == 1 && S == 1) {
+      if (outm == 2) return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 2, PTO, true>(a, st);
+      if constexpr (NCT == 4) {
+        if (outm == 1) return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 1, PTO, true>(a, st);
+        return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 0, PTO, true>(a, st);
+      }
+    }
+    return LFD_ERR_UNSUPPORTED;
+  }
   if (outm == 2) {
     if (tail || res || ds) return LFD_ERR_UNSUPPORTED;
     if constexpr (KS == 1 && S == 1) return launch_pl_<CIN, KS, S, NCT, WREG, false, false, false, 2, PTO>(a, st);
@@ -344,6 +403,12 @@ int launch_pl(const PlArgs& a, int outm, hipStream_t st) {
 
 }  // namespace
 
+#ifdef LFD_PL_TIMING
+extern "C" __attribute__((visibility("default"))) int lfd_debug_pl_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pl::g_pl_dbg), sizeof(unsigned long long) * 128);
+}
+#endif
+
 extern "C" {
 
 int lfd_pl_stem_pair(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
@@ -364,7 +429,7 @@ int lfd_pl_stem_pair(const void* in, int32_t in_format, int32_t n, int32_t h, in
 int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const void* w_packed, const float* bias,
                   const void* residual, const void* tail_w_packed, const float* tail_bias, const void* ds_w_packed,
                   const float* ds_bias, void* ds_out, void* gn_sums, float* f_out0, float* f_out1, const float* scale1,
-                  const void* zeros, lfd_stream_t stream) {
+                  const void* gn_in_sums, const float* gn_in_gamma, const float* gn_in_beta, const void* zeros, lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d || !in || !w_packed || !bias || !zeros) return LFD_ERR_INVALID_ARGUMENT;
   if (d->n < 1 || d->h < 1 || d->w < 1 || d->cout < 1) return LFD_ERR_INVALID_ARGUMENT;
@@ -376,6 +441,7 @@ int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const 
                 : !out)
     return LFD_ERR_INVALID_ARGUMENT;
   if (outm == 1 && !gn_sums) return LFD_ERR_INVALID_ARGUMENT;
+  if (gn_in_sums && (!gn_in_gamma || !gn_in_beta || d->cin != 128)) return LFD_ERR_INVALID_ARGUMENT;
   if (outm != 2 && (d->cout % 32)) return LFD_ERR_UNSUPPORTED;
   if (!lfd_aligned16(in) || !lfd_aligned16(out) || !lfd_aligned16(residual) || !lfd_aligned16(ds_out)) return LFD_ERR_INVALID_ARGUMENT;
   if ((d->in_plane_halfs & 7) || (d->out_plane_halfs & 7) || (d->res_plane_halfs & 7) || (d->ds_plane_halfs & 7)) return LFD_ERR_INVALID_ARGUMENT;
@@ -401,6 +467,7 @@ int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const 
   a.gn_acc = (unsigned long long*)gn_sums;
   a.f_out0 = f_out0; a.f_out1 = f_out1; a.f_c0 = d->f_c0; a.f_c1 = d->f_c1;
   a.f_img0 = d->f_image_stride0; a.f_img1 = d->f_image_stride1; a.scale1 = scale1;
+  a.gnin_acc = (const unsigned long long*)gn_in_sums; a.gnin_gamma = gn_in_gamma; a.gnin_beta = gn_in_beta; a.gnin_eps = d->gn_in_eps;
   if (tail && d->tail_cout != d->cout) return LFD_ERR_UNSUPPORTED;     // the chained 1x1 is square (CMID -> CMID)
   const int key = d->cin * 10000 + d->ks * 1000 + d->stride * 100 + nslab;
   switch (key) {

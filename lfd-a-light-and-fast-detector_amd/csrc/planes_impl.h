@@ -60,6 +60,12 @@ struct PlArgs {
   int f_c0, f_c1;
   long f_img0, f_img1;
   const float* scale1;     // one float or null
+  // GNIN: the input planes hold the PRE-normalisation output of a conv whose GroupNorm sums are gnin_acc (same layout as
+  // gn_acc); the landed tile is normalised + ReLU'd in LDS before the contraction (lfd_head.py:97-117 conv -> GroupNorm -> ReLU)
+  const unsigned long long* gnin_acc;
+  const float* gnin_gamma;
+  const float* gnin_beta;
+  float gnin_eps;
 };
 
 // PTO: 32-pixel MFMA tiles per wave (0: 2 for stride 1, 1 for stride 2)
@@ -103,6 +109,13 @@ struct PCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 };
 
+#ifdef LFD_PL_TIMING
+__device__ unsigned long long g_pl_dbg[8 * 16 + 8];
+#define PL_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && dbg_it < 8) g_pl_dbg[dbg_it * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PL_T(i)
+#endif
+
 __device__ __forceinline__ void dma16(const void* g, const void* lds_wave_base) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory");
@@ -116,22 +129,26 @@ __device__ __forceinline__ void block_barrier() {
 
 // y (fp32) -> packed fp16 pair of the hi plane and of the lo plane.  hi = RNE(y) (v_cvt_pk_f16_f32), y - hi is exact in fp32,
 // so is the scaling by 2^11; the second rounding (lo) leaves |y - hi - 2^-11 lo| <= 2^-23 |y|.
+// (2048 y - 2048 hi is exact in fp32, so the fused form rounds once, to fp16, exactly like (y - hi) * 2048 -> fp16; it compiles
+//  to v_mul + v_fma_mix{lo,hi}_f16 per element instead of cvt-back + sub + mul + cvt)
 __device__ __forceinline__ void split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
   lfd_f32x2 f; f[0] = y0; f[1] = y1;
   union { lfd_f16x2 v; uint32_t u; } h, l;
   h.v = __builtin_convertvector(f, lfd_f16x2);
-  lfd_f32x2 r;
-  r[0] = (y0 - (float)h.v[0]) * kLo;
-  r[1] = (y1 - (float)h.v[1]) * kLo;
-  l.v = __builtin_convertvector(r, lfd_f16x2);
+  l.v[0] = (_Float16)fmaf((float)h.v[0], -kLo, y0 * kLo);
+  l.v[1] = (_Float16)fmaf((float)h.v[1], -kLo, y1 * kLo);
   hi = h.u; lo = l.u;
 }
 
-__device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * kInvLo; }
+// hi + 2^-11 lo: one v_fma_mix_f32 on the fp16 operands (2^-11 lo is exact, the sum rounds once)
+__device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return fmaf((float)lo, kInvLo, (float)hi); }
+// main + 2^-11 corr of the two accumulator sets
+__device__ __forceinline__ float comb(float m, float c) { return fmaf(c, kInvLo, m); }
 
 // OUTM: 0 = planes, 1 = planes + GroupNorm sums (groups of 8 channels), 2 = fp32 outputs (cls / reg)
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN>
 __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
+  static_assert(!GNIN || (KS == 1 && S == 1 && CIN == 128 && !TAIL && !RES && !DS), "GNIN: a 1x1 conv on a 128-channel GroupNorm(16) input");
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES && OUTM == 0), "DS rides on a 3x3 stride-2 conv");
   static_assert(!TAIL || (!RES && !DS), "TAIL: conv -> 1x1 in one launch");
   static_assert(OUTM != 2 || (!TAIL && !RES && !DS), "fp32 outputs: the bare cls / reg conv");
@@ -209,92 +226,72 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
 
   // ---- tile loaders: every DMA of the fp16 kernels (conv_impl.h) issued for both planes; the LDS image of a plane is the
   //      fp16 kernels' (lane-linear lines, XOR chunk swizzle on the source side), the lo plane IN_BYTES behind the hi plane
+  // Issued in PIECES (one or two row-aligned DMA pairs each): with two input buffers the pieces of tile t+1 are spread over
+  // the k-steps of tile t's contraction, where their address arithmetic and issue slots hide under the MFMAs (one wave per
+  // SIMD: whatever is issued between two tiles is exposed; the ~16 DMA instructions per wave and tile of the 3x3 kernels were
+  // ~1.6 k cycles of a ~12 k-cycle tile).
   constexpr bool FAST = (CIN == 64 && KS == 3 && S == 1 && NCT == 2 && !TAIL && !DS && PT == 2);
+  constexpr bool FAST2 = (CIN == 64 && KS == 3 && S == 2);
+  constexpr int SPW = 64 / C::CPP;                      // (generic walk) pixel slots per wave instruction
+  constexpr int NP2 = (C::IWs + 7) / 8;                 // (FAST2) instructions per halo row
+  constexpr int NPIECE = FAST ? 8 : (FAST2 ? NP2 * ((C::IH + 3) / 4) : (C::NSLOT + 4 * SPW - 1) / (4 * SPW));
   const long f_rowpitch = (long)a.W * (CIN * 2);
   auto dma2 = [&](const char* src, bool valid, const char* zsrc, char* ldst) {
     dma16(valid ? src : zsrc, ldst);
     dma16(valid ? src + in_plane_b : zsrc, ldst + C::IN_BYTES);
   };
-  auto issue_dma_fast = [&](int t, int buf) {
-    const int ol = lane;
-    const int f_lpx = ol >> 3;
-    const int f_c0 = ((ol & 7) ^ (f_lpx >> 1)) * 16;
-    const int f_off0 = f_lpx * 128 + f_c0, f_off1 = 1024 + f_lpx * 128 + (f_c0 ^ 64);
-    const int n = t / tiles_per_img;
-    const int tr = t - n * tiles_per_img;
+  // tile-level scalars of the tile being fetched
+  int d_n = 0, d_gy0 = 0, d_gx0 = 0;
+  char* d_lbase = smem;
+  auto dma_setup = [&](int t, int buf) {
+    d_n = t / tiles_per_img;
+    const int tr = t - d_n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
-    const int gy0 = ty0 * C::TH - 1, gx0 = tx0 * C::TW - 1;
-    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * f_rowpitch + (long)gx0 * (CIN * 2);
-    const char* zsrc0 = reinterpret_cast<const char*>(a.zeros) + f_c0;
-    const char* zsrc1 = reinterpret_cast<const char*>(a.zeros) + (f_c0 ^ 64);
-    const bool xv0 = (gx0 + f_lpx >= 0) && (gx0 + f_lpx < a.W);
-    const bool xv1 = (gx0 + 8 + f_lpx < a.W);
-    char* lbase = smem + buf * 2 * C::IN_BYTES;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int m = wave + 4 * j;
-      const int iy = m >> 1, hf = m & 1;
-      const int gy = gy0 + iy;
-      const bool rv = gy >= 0 && gy < a.H;
-      const char* rowp = p00 + iy * f_rowpitch;
-      if (hf) dma2(rowp + f_off1, rv && xv1, zsrc1, lbase + (iy * C::IWs + 8) * C::PIXB);
-      else dma2(rowp + f_off0, rv && xv0, zsrc0, lbase + (iy * C::IWs) * C::PIXB);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int iy = wave + 4 * j;
-      if (iy < C::IH && ol < 16) {
-        const int gy = gy0 + iy, gx = gx0 + 16 + (ol >> 3);
-        const bool ok = gy >= 0 && gy < a.H && gx < a.W;
-        dma2(p00 + iy * f_rowpitch + 2048 + ol * 16, ok, reinterpret_cast<const char*>(a.zeros) + (ol & 7) * 16,
-             lbase + (iy * C::IWs + 16) * C::PIXB);
-      }
-    }
+    d_gy0 = ty0 * C::TH * S - C::PAD;
+    d_gx0 = tx0 * C::TW * S - C::PAD;
+    d_lbase = smem + buf * 2 * C::IN_BYTES;
   };
-  constexpr bool FAST2 = (CIN == 64 && KS == 3 && S == 2);
-  auto issue_dma_s2 = [&](int t, int buf) {
-    const int ol = lane;
-    const int sl = ol >> 3, cs = ol & 7;
-    const int n = t / tiles_per_img;
-    const int tr = t - n * tiles_per_img;
-    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
-    const int gy0 = ty0 * C::TH * 2 - 1, gx0 = tx0 * C::TW * 2 - 1;
-    const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)n * a.H + gy0) * f_rowpitch + (long)gx0 * (CIN * 2);
-    char* lbase = smem + buf * 2 * C::IN_BYTES;
-    constexpr int NP = (C::IWs + 7) / 8;
-    int off[NP];
-    const char* zsrc[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int rem = 8 * j + sl;
-      const int ix = rem < C::IWh ? 2 * rem : 2 * rem - (2 * C::IWh - 1);
-      const int c = cs ^ ((rem / C::PPR) % C::CPP);
-      const int gx = gx0 + ix;
-      const bool ok = rem < C::IWs && ix < C::IW && gx >= 0 && gx < a.W;
-      off[j] = ok ? ix * (CIN * 2) + c * 16 : -1;
-      zsrc[j] = reinterpret_cast<const char*>(a.zeros) + c * 16;
-    }
-    for (int iy = wave; iy < C::IH; iy += 4) {
-      const int gy = gy0 + iy;
-      const bool rv = gy >= 0 && gy < a.H;
-      const char* rowp = p00 + iy * f_rowpitch;
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        if (8 * j + 8 <= C::IWs || (8 * j + sl < C::IWs && 2 * (8 * j + sl) - (2 * C::IWh - 1) < C::IW))
-          dma2(rowp + off[j], rv && off[j] >= 0, zsrc[j], lbase + (iy * C::IWs + 8 * j) * C::PIXB);
+  auto dma_piece = [&](int p) {
+    if constexpr (FAST) {
+      // halo rows of 18 pixels: columns 0..15 are two 64-lane instructions (8 pixels x 8 chunks), columns 16..17 one 16-lane
+      // instruction; source chunk swizzled (key = column >> 1), LDS lane-linear
+      const char* p00 = reinterpret_cast<const char*>(a.in) + ((long)d_n * a.H + d_gy0) * f_rowpitch + (long)d_gx0 * (CIN * 2);
+      if (p < 5) {
+        const int f_lpx = lane >> 3;
+        const int m = wave + 4 * p;
+        const int iy = m >> 1, hf = m & 1;
+        const int cc = (((lane & 7) ^ (f_lpx >> 1)) * 16) ^ (hf ? 64 : 0);
+        const int gy = d_gy0 + iy, gx = d_gx0 + 8 * hf + f_lpx;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        dma2(p00 + iy * f_rowpitch + hf * 1024 + f_lpx * 128 + cc, ok, reinterpret_cast<const char*>(a.zeros) + cc,
+             d_lbase + (iy * C::IWs + 8 * hf) * C::PIXB);
+      } else {
+        const int iy = wave + 4 * (p - 5);
+        if (iy < C::IH && lane < 16) {
+          const int gy = d_gy0 + iy, gx = d_gx0 + 16 + (lane >> 3);
+          const bool ok = gy >= 0 && gy < a.H && gx < a.W;
+          dma2(p00 + iy * f_rowpitch + 2048 + lane * 16, ok, reinterpret_cast<const char*>(a.zeros) + (lane & 7) * 16,
+               d_lbase + (iy * C::IWs + 16) * C::PIXB);
+        }
       }
-    }
-  };
-  auto issue_dma = [&](int t, int buf) {
-    if constexpr (FAST) { issue_dma_fast(t, buf); return; }
-    if constexpr (FAST2) { issue_dma_s2(t, buf); return; }
-    const int n = t / tiles_per_img;
-    const int tr = t - n * tiles_per_img;
-    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
-    const int gy0 = ty0 * C::TH * S - C::PAD, gx0 = tx0 * C::TW * S - C::PAD;
-    constexpr int SPW = 64 / C::CPP;
-    char* lbase = smem + buf * 2 * C::IN_BYTES;
-    for (int slot0 = wave * SPW; slot0 < C::NSLOT; slot0 += 4 * SPW) {
+    } else if constexpr (FAST2) {
+      // column-de-interleaved stride-2 tile: a halo row is IWs slots (even columns, then odd columns), NP2 row-aligned
+      // instructions of 8 slots; wave w owns rows w, w + 4, ...
+      const int iy = wave + 4 * (p / NP2), j = p % NP2;
+      if (iy < C::IH) {
+        const int sl = lane >> 3, cs = lane & 7;
+        const int rem = 8 * j + sl;
+        const int ix = rem < C::IWh ? 2 * rem : 2 * rem - (2 * C::IWh - 1);
+        const int c = cs ^ ((rem / C::PPR) % C::CPP);
+        const int gy = d_gy0 + iy, gx = d_gx0 + ix;
+        const bool needed = rem < C::IWs && ix < C::IW;
+        const bool ok = needed && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const char* src = reinterpret_cast<const char*>(a.in) + ((long)d_n * a.H + (ok ? gy : 0)) * f_rowpitch + (long)(ok ? gx : 0) * (CIN * 2) + c * 16;
+        if (8 * j + 8 <= C::IWs || needed)
+          dma2(src, ok, reinterpret_cast<const char*>(a.zeros) + c * 16, d_lbase + (iy * C::IWs + 8 * j) * C::PIXB);
+      }
+    } else {
+      const int slot0 = (wave + 4 * p) * SPW;
       const int pslot = slot0 + lane / C::CPP;
       const int cs = lane % C::CPP;
       if (pslot < C::NSLOT) {
@@ -302,17 +299,25 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         const int rem = pslot - iy * C::IWs;
         const int ix = (S == 2) ? ((rem < C::IWh) ? 2 * rem : 2 * (rem - C::IWh) + 1) : rem;
         const int c = cs ^ ((rem / C::PPR) % C::CPP);
-        const int gy = gy0 + iy, gx = gx0 + ix;
+        const int gy = d_gy0 + iy, gx = d_gx0 + ix;
         bool needed = ix < C::IW;
         if (KS == 1 && S == 2) needed = needed && !(ix & 1) && !(iy & 1);
         if (needed) {
           const bool valid = (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
-          const char* src = reinterpret_cast<const char*>(a.in + (((size_t)n * a.H + (valid ? gy : 0)) * a.W + (valid ? gx : 0)) * CIN + c * 8);
-          dma2(src, valid, reinterpret_cast<const char*>(a.zeros + c * 8), lbase + slot0 * C::PIXB);
+          const char* src = reinterpret_cast<const char*>(a.in + (((size_t)d_n * a.H + (valid ? gy : 0)) * a.W + (valid ? gx : 0)) * CIN + c * 8);
+          dma2(src, valid, reinterpret_cast<const char*>(a.zeros + c * 8), d_lbase + slot0 * C::PIXB);
         }
       }
     }
   };
+  auto issue_dma = [&](int t, int buf) {
+    dma_setup(t, buf);
+    for (int p = 0; p < NPIECE; ++p) dma_piece(p);
+  };
+  // pieces of the next tile issued from inside the contraction (WREG kernels with two buffers): piece i goes in front of
+  // k-step (i * SPREAD) / NPIECE, i.e. they are done after ~70 % of the k-steps and have the rest of the tile to land
+  constexpr bool DMA_IN_LOOP = WREG && C::NBUF == 2;
+  constexpr int SPREAD = (C::NK * 7 + 9) / 10;
 
   // RES: the identity branch's tile -> LDS in copy-out order (pixel-major lines of this workgroup's channel slice), added
   // where the output lines are formed: no registers held across the contraction, no exposed load latency
@@ -356,11 +361,17 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
     }
   };
 
+  float gn_a[GNIN ? 8 : 1], gn_b[GNIN ? 8 : 1];
+  int gnin_n = -1;
+  (void)gn_a; (void)gn_b; (void)gnin_n;
   int t = t_begin + bix;
   int buf = 0;
   bool first = true;
   if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
-  for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1)) {
+  int dbg_it = 0; (void)dbg_it;
+  for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1), ++dbg_it) {
+    bool has_next = false;
+    PL_T(0);
     if (C::NBUF == 2) {
       // the VMEM operations issued after tile t's DMA that may still be in flight are the previous tile's copy-out stores:
       // every lane issues exactly NST of them (out-of-image lanes into the trash line), vmcnt retires in order
@@ -370,8 +381,14 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
       else if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       first = false;
+      PL_T(1);
       block_barrier();
-      if (t + t_step < t_end) issue_dma(t + t_step, buf ^ 1);
+      PL_T(2);
+      has_next = t + t_step < t_end;
+      if (has_next) {
+        if constexpr (DMA_IN_LOOP) dma_setup(t + t_step, buf ^ 1);
+        else issue_dma(t + t_step, buf ^ 1);
+      }
     } else {
       block_barrier();
       issue_dma(t, 0);
@@ -383,6 +400,42 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
     const int tr = t - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
     const char* xb = smem + buf * 2 * C::IN_BYTES;
+    if constexpr (GNIN) {
+      // every thread owns one 16-byte chunk position = one GroupNorm group (8 channels) of the pixels it visits
+      const int gc = (int)threadIdx.x & 15;
+      if (n != gnin_n) {
+        gnin_n = n;
+        const long long s = (long long)a.gnin_acc[((size_t)n * 16 + gc) * 2], q = (long long)a.gnin_acc[((size_t)n * 16 + gc) * 2 + 1];
+        const double cnt = (double)a.H * (double)a.W * 8.0;
+        const double m = (double)s / kGnFix / cnt;
+        double var = (double)q / kGnFix / cnt - m * m;
+        var = var > 0. ? var : 0.;
+        const float rstd = (float)(1. / sqrt(var + (double)a.gnin_eps)), mean = (float)m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          gn_a[e] = rstd * a.gnin_gamma[gc * 8 + e];
+          gn_b[e] = a.gnin_beta[gc * 8 + e] - mean * gn_a[e];
+        }
+      }
+      char* xw = smem + buf * 2 * C::IN_BYTES;
+      static_assert(!GNIN || (C::NSLOT * 16) % 256 == 0, "whole transform rounds");
+#pragma unroll
+      for (int r = 0; r < (C::NSLOT * 16) / 256; ++r) {
+        const int slot = ((int)threadIdx.x >> 4) + 16 * r;
+        const int o = slot * 256 + ((gc ^ (slot & 15)) * 16);
+        const lfd_f16x8 hh = *reinterpret_cast<const lfd_f16x8*>(xw + o), ll = *reinterpret_cast<const lfd_f16x8*>(xw + C::IN_BYTES + o);
+        union { uint32_t u[4]; uint4 v; } oh, ol;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y0 = fmaxf(fmaf(join1(hh[2 * j], ll[2 * j]), gn_a[2 * j], gn_b[2 * j]), 0.f);
+          const float y1 = fmaxf(fmaf(join1(hh[2 * j + 1], ll[2 * j + 1]), gn_a[2 * j + 1], gn_b[2 * j + 1]), 0.f);
+          split2(y0, y1, oh.u[j], ol.u[j]);
+        }
+        *reinterpret_cast<uint4*>(xw + o) = oh.v;
+        *reinterpret_cast<uint4*>(xw + C::IN_BYTES + o) = ol.v;
+      }
+      block_barrier();
+    }
     if constexpr (OUTM == 1) {
       if (n != gn_n) {
         gn_flush();
@@ -391,6 +444,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
     }
 
     issue_res(n, ty0, tx0);
+    PL_T(3);
 
     f32x16 accm[PT], accc[PT];
     f32x16 adm[DS ? PT : 1], adc[DS ? PT : 1];
@@ -426,7 +480,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         const int off = XTAB ? xoff[s][XTAB ? q : 0] : (xbase[s] + (((2 * q) ^ xkey[s]) << 4));
         return xb + off + (r + pt * C::RPT * S) * C::IWs * C::PIXB;
       };
-      constexpr int PD = (RES && C::NK > 20) ? 2 : 3;    // (the residual prefetch takes 32 registers of the 3x3 64-channel kernel's 512)
+      constexpr int PD = ((RES && C::NK > 20) || KS == 1) ? 2 : 3;    // (the residual prefetch takes 32 registers of the 3x3 64-channel kernel's 512)
       half8 xqh[PD + 1][PT], xql[PD + 1][PT];
 #pragma unroll
       for (int k = 0; k < PD && k < C::NK; ++k) {
@@ -439,6 +493,13 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
       }
 #pragma unroll
       for (int k = 0; k < C::NK; ++k) {
+        if constexpr (DMA_IN_LOOP) {
+          if (has_next) {
+#pragma unroll
+            for (int p = 0; p < NPIECE; ++p)
+              if ((p * SPREAD) / NPIECE == k) dma_piece(p);
+          }
+        }
         if (k + PD < C::NK) {
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) {
@@ -534,6 +595,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
       }
     }
 
+    PL_T(4);
     char* scr = C::ALIAS ? (smem + buf * 2 * C::IN_BYTES) : (smem + C::SCR_OFF);
     if constexpr (TAIL) {
       // main conv's epilogue (bias in accm, ReLU) -> hi / lo operand planes of the chained 1x1 in LDS
@@ -548,7 +610,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            y[e] = accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo;
+            y[e] = comb(accm[pt][4 * g + e], accc[pt][4 * g + e]);
             if (a.relu) y[e] = fmaxf(y[e], 0.f);
           }
           uint2 vh, vl;
@@ -602,7 +664,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int co = co_base + 8 * g + 4 * h + e;
-              const float y = accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo;
+              const float y = comb(accm[pt][4 * g + e], accc[pt][4 * g + e]);
               if (co < a.f_c0) a.f_out0[(size_t)n * a.f_img0 + pixi * a.f_c0 + co] = y;
               else if (co < a.f_c0 + a.f_c1) a.f_out1[(size_t)n * a.f_img1 + pixi * a.f_c1 + (co - a.f_c0)] = y * sc1;
             }
@@ -621,7 +683,9 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
     char* sout = scr;
     // staging overlays the consumed input tile (ALIAS) or the chained 1x1's operand planes (TAIL): every wave must be done
     // reading them (separate scratch without TAIL: the loop-top barrier did that)
+    PL_T(5);
     if constexpr (C::ALIAS || TAIL) block_barrier();
+    PL_T(6);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int pb = (pg * PT + pt) * 32 + pix;
@@ -631,7 +695,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          y[e] = accm[pt][4 * g + e] + accc[pt][4 * g + e] * kInvLo;
+          y[e] = comb(accm[pt][4 * g + e], accc[pt][4 * g + e]);
           if (relu_out && !RES) y[e] = fmaxf(y[e], 0.f);       // RES: the staged value is the pre-activation conv + bias
         }
         uint2 vh, vl;
@@ -642,8 +706,10 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         *reinterpret_cast<uint2*>(sout + C::OUT_PLANE + o) = vl;
       }
     }
+    PL_T(7);
     if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's residual DMAs landed
     block_barrier();
+    PL_T(8);
     {
       const int cslice = TAIL ? 0 : cog * NCT * 32;
       static_assert((OPX * OCPP) % 256 == 0, "whole copy-out rounds");
@@ -695,6 +761,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         }
       }
     }
+    PL_T(9);
     if constexpr (DS) {
       // second output: the identity branch (bias in adm, no ReLU) through the same staging planes
       block_barrier();
@@ -706,7 +773,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         for (int g = 0; g < 4; ++g) {
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = adm[pt][4 * g + e] + adc[pt][4 * g + e] * kInvLo;
+          for (int e = 0; e < 4; ++e) y[e] = comb(adm[pt][4 * g + e], adc[pt][4 * g + e]);
           uint2 vh, vl;
           split2(y[0], y[1], vh.x, vl.x);
           split2(y[2], y[3], vh.y, vl.y);
@@ -736,7 +803,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
   gn_flush();
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN = false>
 struct PlHeavy {
   // registers of the stationary hi + lo fragments (main slab, chained 1x1, identity branch); beyond what two waves per SIMD
   // can hold next to 64 accumulator and 64 ring registers: one workgroup per CU, up to 512 registers per wave
@@ -744,13 +811,13 @@ struct PlHeavy {
   static constexpr bool value = !WREG || wregs > 96;
 };
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN = false>
 __global__ __launch_bounds__(256, (PlHeavy<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>::value ? 1 : 2)) void k_pl_conv(PlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>(a, smem);
+  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO, GNIN>(a, smem);
 }
 
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO>
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN = false>
 int launch_pl_(const PlArgs& a0, hipStream_t st) {
   using C = PCfg<CIN, KS, S, NCT, TAIL, RES, PTO>;
   PlArgs a = a0;
@@ -761,7 +828,7 @@ int launch_pl_(const PlArgs& a0, hipStream_t st) {
   a.ntiles = (int)nt;
   const int cgroups = TAIL ? 1 : (a.cout + NCT * 32 - 1) / (NCT * 32);
   constexpr int LDSB = C::LDS_BYTES;
-  auto kern = k_pl_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>;
+  auto kern = k_pl_conv<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO, GNIN>;
   static unsigned long long attr_done_mask = 0;
   const int attr_done_dev = lfd_device_ordinal();
   if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {

@@ -93,7 +93,7 @@ class PlConvDesc(C.Structure):
     _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
                 ('ks', C.c_int32), ('stride', C.c_int32), ('relu', C.c_int32), ('tail_cout', C.c_int32),
                 ('tail_relu', C.c_int32), ('out_mode', C.c_int32), ('f_c0', C.c_int32), ('f_c1', C.c_int32),
-                ('reserved', C.c_int32), ('in_plane_halfs', C.c_int64), ('out_plane_halfs', C.c_int64),
+                ('gn_in_eps', C.c_float), ('in_plane_halfs', C.c_int64), ('out_plane_halfs', C.c_int64),
                 ('res_plane_halfs', C.c_int64), ('ds_plane_halfs', C.c_int64), ('f_image_stride0', C.c_int64),
                 ('f_image_stride1', C.c_int64)]
 
@@ -253,7 +253,7 @@ _SIGNATURES = {
     'lfd_p32_conv2d_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     'lfd_p32_conv2d_tail_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _I32, _P]),
     'lfd_pl_stem_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
-    'lfd_pl_conv2d': (C.c_int, [C.POINTER(PlConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_pl_conv2d': (C.c_int, [C.POINTER(PlConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_pl_groupnorm_relu': (C.c_int, [_P, _I64, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P]),
     'lfd_p32_groupnorm_workspace_bytes': (_SZ, [_I32, _I32]),
     'lfd_p32_groupnorm_relu_f32': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P]),

@@ -8,8 +8,9 @@ engine rebuilt on three MFMAs per k-step:
   stem        lfd_pl_stem_pair (frame -> conv3x3 s2 -> conv1x1) ; lfd_pl_conv2d 3x3 s2 + chained 1x1     lfd_resnet.py:376-413
   stage entry lfd_pl_conv2d 3x3 s2 with the 1x1 s2 identity branch as second output                       lfd_resnet.py:458-468
   block convs lfd_pl_conv2d 3x3 s1 (+ residual + ReLU)                                                    lfd_resnet.py:96-154
-  head        neck 1x1 chained into the first tower 1x1 (GroupNorm sums from the epilogue), GroupNorm + ReLU in place,
-              second tower 1x1 (+ sums), GroupNorm + ReLU, cls + reg 1x1 as ONE conv writing fp32 [N,P,C'] / [N,P,4] (+ Scale)
+  head        neck 1x1 chained into the first tower 1x1 (GroupNorm sums from the epilogue); second tower 1x1 normalises +
+              ReLUs the tile it fetched (+ its own sums); cls + reg 1x1 as ONE conv, again on the normalised tile, writing fp32
+              [N,P,C'] / [N,P,4] (+ Scale): three launches per level, every tower tensor written once and read once
                                                                                         simple_neck.py:67-74, lfd_head.py:164-185
 
 `PlanesPlan` has the interface of engine_p32.PrecisePlan (state_for / run); engine_p32.get_plan builds it first and falls
@@ -93,7 +94,7 @@ def _check_dispatch(cin, cout, ks, stride, tail, ds, res, gn, out32):
 
 class _Op(object):
     __slots__ = ('kind', 'src', 'dst', 'res', 'ds_dst', 'cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'ds',
-                 'out_mode', 'gn', 'gamma', 'beta', 'eps', 'level', 'f_c0', 'f_c1', 'scale', 'w1', 'b1', 'w2', 'b2', 'channels')
+                 'out_mode', 'gn', 'gnin', 'level', 'f_c0', 'f_c1', 'scale', 'w1', 'b1', 'w2', 'b2', 'channels')
 
     def __init__(self, kind):
         self.kind = kind
@@ -123,15 +124,24 @@ class PlanesPlan(object):
         self.buf_channels[b], self.buf_scale[b] = channels, scale
         return b
 
-    def _conv(self, src, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=False, out32=None):
+    def _conv(self, src, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=False, out32=None, gnin=None):
         """w: folded fp32 OIHW, b: fp32 bias.  tail = (w2 [c,c,1,1], b2, relu2); ds = (w [cout,cin,1,1], b): identity branch
-        as second output; gn: GroupNorm sums of the stored values; out32 = (level, c0, c1, scale): fp32 cls / reg outputs"""
+        as second output; gn: GroupNorm sums of the stored values; out32 = (level, c0, c1, scale): fp32 cls / reg outputs;
+        gnin = (sums index, GroupNorm module): `src` holds the pre-normalisation output of the conv with that sums index --
+        GroupNorm + ReLU are applied to the landed tile inside this launch"""
         dev = self.device
         cout, cin = w.shape[0], w.shape[1]
         if cin not in (32, 64, 128) or (out32 is None and cout % 32):
             raise Unsupported('conv %d -> %d' % (cin, cout))
         _check_dispatch(cin, cout, ks, stride, tail is not None, ds is not None, res is not None, gn, out32 is not None)
         o = _Op('conv')
+        if gnin is not None:
+            norm = gnin[1]
+            if not (isinstance(norm, nn.GroupNorm) and norm.num_channels == 128 and norm.num_groups == 16 and cin == 128 and ks == 1
+                    and stride == 1 and tail is None and res is None and ds is None):
+                raise Unsupported('head norm must be GroupNorm(16, 128) in front of a 1x1 conv')
+            o.gnin = (gnin[0], norm.weight.detach().float().contiguous().to(dev), norm.bias.detach().float().contiguous().to(dev),
+                      float(norm.eps))
         o.src, o.res, o.ks, o.stride, o.relu, o.cin, o.cout = src, res, ks, stride, int(relu), cin, cout
         o.w = pack_planes_weight(w).to(dev)
         o.b = _pad_bias(b, 128).to(dev)
@@ -158,16 +168,6 @@ class PlanesPlan(object):
                 self.num_gn += 1
         self.ops.append(o)
         return o
-
-    def _gn(self, conv_op, norm):
-        if not (isinstance(norm, nn.GroupNorm) and norm.num_channels == 128 and norm.num_groups == 16):
-            raise Unsupported('head norm must be GroupNorm(16, 128)')
-        o = _Op('gn')
-        o.src, o.gn = conv_op.dst, conv_op.gn
-        o.gamma = norm.weight.detach().float().contiguous().to(self.device)
-        o.beta = norm.bias.detach().float().contiguous().to(self.device)
-        o.eps = float(norm.eps)
-        self.ops.append(o)
 
     def _build(self, model):
         bb, neck, head = model._backbone, model._neck, model._head
@@ -235,20 +235,24 @@ class PlanesPlan(object):
         ccls = self.cls_channels
 
         def tower(seq, t, first_tail_of=None):
-            """conv -> GroupNorm -> ReLU layers; with `first_tail_of` = (neck w, b, src) the neck conv and the first tower conv
-            are one launch"""
+            """conv -> GroupNorm -> ReLU layers: every conv stores its pre-normalisation output + the GroupNorm sums, its
+            consumer normalises the tile it has just fetched.  Returns (buffer, pending (sums index, norm)).  With
+            `first_tail_of` = (neck w, b, src) the neck conv and the first tower conv are one launch."""
+            pend = None
             for l in range(nl):
                 conv, norm = seq[l * 3], seq[l * 3 + 1]
+                if not isinstance(norm, nn.GroupNorm):
+                    raise Unsupported('head norm must be GroupNorm')
                 bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=conv.weight.device)
                 w = conv.weight.detach().float()
                 if l == 0 and first_tail_of is not None:
                     nw, nb, src = first_tail_of
                     op = self._conv(src, nw, nb, 1, 1, True, tail=(w, bias, False), gn=True)
                 else:
-                    op = self._conv(t, w, bias, 1, 1, False, gn=True)
-                self._gn(op, norm)
+                    op = self._conv(t, w, bias, 1, 1, False, gn=True, gnin=pend)
+                pend = (op.gn, norm)
                 t = op.dst
-            return t
+            return t, pend
 
         for i, f in enumerate(self.taps):
             nseq = getattr(neck, 'neck%d' % i)
@@ -261,21 +265,23 @@ class PlanesPlan(object):
             if head._merge_path_flag:
                 if nl < 1:
                     raise Unsupported('merge path without tower convs')
-                tt = tower(getattr(head, 'head%d_merge_path' % i), None, first_tail_of=(nw, nb, f))
+                tt, pend = tower(getattr(head, 'head%d_merge_path' % i), None, first_tail_of=(nw, nb, f))
                 cconv, rconv = cls_path[0], reg_path[0]
                 if cconv.kernel_size[0] != 1 or rconv.kernel_size[0] != 1 or ccls + 4 > 64:
                     raise Unsupported('output convs')
                 w = torch.cat([cconv.weight.detach().float(), rconv.weight.detach().float()], 0)
                 b = torch.cat([cconv.bias.detach().float(), rconv.bias.detach().float()], 0)
-                self._conv(tt, w, b, 1, 1, False, out32=(i, ccls, 4, scale))
+                self._conv(tt, w, b, 1, 1, False, out32=(i, ccls, 4, scale), gnin=pend)
             else:
                 t = self._conv(f, nw, nb, 1, 1, True).dst
                 cconv, rconv = cls_path[nl * 3], reg_path[nl * 3]
                 if cconv.kernel_size[0] != 1 or rconv.kernel_size[0] != 1 or ccls > 64:
                     raise Unsupported('output convs')
-                tc, tr = tower(cls_path, t), tower(reg_path, t)
-                self._conv(tc, cconv.weight.detach().float(), cconv.bias.detach().float(), 1, 1, False, out32=(i, ccls, 0, None))
-                self._conv(tr, rconv.weight.detach().float(), rconv.bias.detach().float(), 1, 1, False, out32=(i, 0, 4, scale))
+                if nl < 1:
+                    raise Unsupported('towers without convs')
+                (tc, pc), (tr, pr) = tower(cls_path, t), tower(reg_path, t)
+                self._conv(tc, cconv.weight.detach().float(), cconv.bias.detach().float(), 1, 1, False, out32=(i, ccls, 0, None), gnin=pc)
+                self._conv(tr, rconv.weight.detach().float(), rconv.bias.detach().float(), 1, 1, False, out32=(i, 0, 4, scale), gnin=pr)
 
     # ------------------------------------------------------------------ execution
     def state_for(self, n, h, w, slot=0):
@@ -296,11 +302,6 @@ class PlanesPlan(object):
                 dst = st.bufs[o.dst]
                 check(l.lfd_pl_stem_pair(ptr(x), fmt, st.n, st.h, st.w, o.channels, ptr(o.w1), ptr(o.b1), ptr(o.w2), ptr(o.b2),
                                          ptr(dst), dst[0].numel(), sp), 'lfd_pl_stem_pair')
-                continue
-            if o.kind == 'gn':
-                t = st.bufs[o.src]
-                check(l.lfd_pl_groupnorm_relu(ptr(t), t[0].numel(), st.n, t.shape[2] * t.shape[3], t.shape[4], ptr(st.gn_sums[o.gn]),
-                                              ptr(o.gamma), ptr(o.beta), o.eps, 1, sp), 'lfd_pl_groupnorm_relu')
                 continue
             src = st.bufs[o.src]
             d = _lib.PlConvDesc()
@@ -325,11 +326,16 @@ class PlanesPlan(object):
                 d.ds_plane_halfs = dsd[0].numel()
             if o.tail is not None:
                 d.tail_cout, d.tail_relu = o.cout, o.tail[2]
+            gi = o.gnin
+            if gi is not None:
+                d.gn_in_eps = gi[3]
             check(l.lfd_pl_conv2d(C.byref(d), ptr(src), ptr(dst), ptr(o.w), ptr(o.b), ptr(res),
                                   ptr(o.tail[0]) if o.tail else None, ptr(o.tail[1]) if o.tail else None,
                                   ptr(o.ds[0]) if o.ds else None, ptr(o.ds[1]) if o.ds else None, ptr(dsd),
                                   ptr(st.gn_sums[o.gn]) if o.gn is not None else None, f0, f1,
-                                  ptr(o.scale) if o.scale is not None else None, zeros, sp), 'lfd_pl_conv2d')
+                                  ptr(o.scale) if o.scale is not None else None,
+                                  ptr(st.gn_sums[gi[0]]) if gi else None, ptr(gi[1]) if gi else None, ptr(gi[2]) if gi else None,
+                                  zeros, sp), 'lfd_pl_conv2d')
 
 
 class _State(object):

@@ -32,7 +32,7 @@ def _ref_conv(x, w, b, ks, stride, relu, res=None):
     return y.relu() if relu else y
 
 
-def _pl_conv(xp, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=None, out32=None):
+def _pl_conv(xp, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=None, out32=None, gnin=None):
     """xp: planes [2,N,H,W,cin] cuda.  Returns planes out (and ds planes) or None for out32."""
     dev = xp.device
     n, h, wd, cin = xp.shape[1:]
@@ -65,8 +65,12 @@ def _pl_conv(xp, w, b, ks, stride, relu, res=None, tail=None, ds=None, gn=None, 
         dw, db = engine_p2.pack_planes_weight(ds[0]).to(dev), engine_p2._pad_bias(ds[1], 128).to(dev)
         dsd = torch.full((2, n, oh, ow, cout), float('nan'), dtype=torch.float16, device=dev)
         d.ds_plane_halfs = dsd[0].numel()
+    gs = gg = gb = None
+    if gnin is not None:
+        gs, gg, gb, d.gn_in_eps = gnin
     check(lib().lfd_pl_conv2d(C.byref(d), ptr(xp), ptr(out), ptr(keep[0]), ptr(keep[1]), ptr(res), ptr(tw), ptr(tb), ptr(dw), ptr(db),
-                              ptr(dsd), ptr(gn), f0, f1, ptr(sc), ptr(ops.zero_line(dev)), stream_ptr()), 'lfd_pl_conv2d')
+                              ptr(dsd), ptr(gn), f0, f1, ptr(sc), ptr(gs), ptr(gg), ptr(gb), ptr(ops.zero_line(dev)), stream_ptr()),
+          'lfd_pl_conv2d')
     torch.cuda.synchronize()
     return out, dsd
 
@@ -166,11 +170,25 @@ def test_pl_tower_conv_sums_and_groupnorm_vs_float64(n, h, w):
     yv = engine_p2.from_planes(got.cpu()).double()
     ref = F.group_norm(yv.reshape(n, h * w, 128).permute(0, 2, 1), 16, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1).relu()
     gd, bd = gamma.cuda(), beta.cuda()
+    pre = got.clone()
     check(lib().lfd_pl_groupnorm_relu(ptr(got), got[0].numel(), n, h * w, 128, ptr(sums), ptr(gd), ptr(bd), 1e-5, 1, stream_ptr()),
           'lfd_pl_groupnorm_relu')
     torch.cuda.synchronize()
     out = engine_p2.from_planes(got.cpu()).double().reshape(n, h * w, 128)
     assert float((out - ref).abs().max()) <= 6e-6 * max(1.0, float(ref.abs().max()))
+    # the same normalisation applied by the CONSUMER to the tile it fetched: tower conv (with its own sums) and output convs
+    refv = engine_p2.from_planes(engine_p2.to_planes(ref.float().reshape(n, h, w, 128))).double()   # (what the kernel's LDS tile holds)
+    w2, b2 = torch.randn(128, 128, 1, 1, generator=g) * 0.09, torch.randn(128, generator=g)
+    sums2 = torch.zeros_like(sums)
+    got2, _ = _pl_conv(pre, w2, b2, 1, 1, False, gn=sums2, gnin=(sums, gd, bd, 1e-5))
+    _close(got2, _ref_conv(refv, w2, b2, 1, 1, False), 'tower conv on the normalised tile')
+    _check_sums(sums2, got2)
+    wo, bo = torch.randn(5, 128, 1, 1, generator=g) * 0.1, torch.randn(5, generator=g)
+    cls, reg = torch.zeros((n, h * w, 1), device='cuda'), torch.zeros((n, h * w, 4), device='cuda')
+    _pl_conv(pre, wo, bo, 1, 1, False, out32=(cls, reg, 1, 4, 0, h * w, None), gnin=(sums, gd, bd, 1e-5))
+    ro = _ref_conv(refv, wo, bo, 1, 1, False).reshape(n, h * w, 5)
+    err = max(float((cls.cpu().double() - ro[..., :1]).abs().max()), float((reg.cpu().double() - ro[..., 1:]).abs().max()))
+    assert err <= 8e-6 * max(1.0, float(ro.abs().max())), err
 
 
 @pytest.mark.parametrize('ccls,merged', [(1, True), (46, False), (3, True)])
@@ -238,11 +256,11 @@ def test_pl_conv_refuses_what_it_has_no_instance_for():
     out = torch.zeros((2, 1, 8, 8, 96), dtype=torch.float16, device='cuda')
     z = ops.zero_line(xp.device)
     rc = lib().lfd_pl_conv2d(C.byref(d), ptr(xp), ptr(out), ptr(w), ptr(b), None, None, None, None, None, None, None, None, None, None,
-                             ptr(z), stream_ptr())
+                             None, None, None, ptr(z), stream_ptr())
     assert rc == -4       # LFD_ERR_UNSUPPORTED
     d.cout = 64
     rc = lib().lfd_pl_conv2d(C.byref(d), ptr(xp), None, ptr(w), ptr(b), None, None, None, None, None, None, None, None, None, None,
-                             ptr(z), stream_ptr())
+                             None, None, None, ptr(z), stream_ptr())
     assert rc == -1       # out == NULL
 
 
