@@ -443,15 +443,40 @@ def stress_and_small_frame_bench(model, x, meta, dev, cls):
     return out
 
 
-def precise_bench(model, x, meta, dev):
-    """The shipped fp32-storage precision mode (LFD.precision = 'fp32_storage': raw logits within 1e-4 of the fp32
-    reference, tests/test_gpu_precise.py) on the headline workload: its cost on record next to the fp16 number."""
+def precise_bench(model, x, meta, dev, steps=40):
+    """The shipped tolerance-compliant precision mode (LFD.precision = 'fp32_storage': raw logits within 1e-4 of the fp32
+    reference, tests/test_gpu_precise.py) on the headline workload, measured like the headline: the whole step one HIP graph,
+    two batches in flight on two HIP streams with their own buffers (wall clock over `steps` steps), next to the strictly
+    serial HIP-event median and the bs-1 end-to-end latency."""
     out = {}
     keep_g = model.use_graph
     model.precision = 'fp32_storage'
     try:
         model.use_graph = True
         ms = _event_median_ms(lambda: model.detect_resident(x, meta), 10, warm=2)
+        # two batches in flight (distinct frame buffers, buffer slots 0 / 1), as the fp16 headline runs
+        xs = [x, x.clone()]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+        def step(i):
+            with torch.cuda.stream(streams[i % 2]):
+                return model.detect_resident(xs[i % 2], meta, slot=i % 2)
+        torch.cuda.synchronize()
+        ref = [step(0), step(1)]
+        torch.cuda.synchronize()
+        snap = [(o.counts.clone(), o.dets.clone()) for o in ref]
+        for i in range(6):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        ms_pipe = (time.perf_counter() - t0) / steps * 1e3
+        for b in range(2):      # overlapped steps == the same step alone
+            o = step(b)
+            torch.cuda.synchronize()
+            assert torch.equal(o.counts, snap[b][0]) and torch.equal(o.dets, snap[b][1]), 'overlapped precise steps disagree'
         x1 = x[:1].contiguous()
         meta1 = meta[:1].contiguous()
         for _ in range(3):
@@ -464,12 +489,16 @@ def precise_bench(model, x, meta, dev):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         ts = np.sort(np.array(ts)) * 1e3
-        out = dict(mode="LFD.precision = 'fp32_storage': fp32 NHWC inter-layer storage, one launch per conv, operands split "
-                        "exactly into fp16 hi + 2^-11 lo inside the kernel (3 MFMAs per k-step), fp32 epilogues, fp64 "
-                        "GroupNorm statistics (csrc/precise.hip)",
-                   ms_per_step_bs8=round(ms, 4), images_per_s_bs8=round(x.size(0) / ms * 1e3, 1),
+        from lfd_amd import engine_p2, engine_p32
+        planes = isinstance(engine_p32.get_plan(model, x.device), engine_p2.PlanesPlan)
+        out = dict(mode="LFD.precision = 'fp32_storage': inter-layer tensors as fp16 hi + 2^-11 lo planes (the bytes of fp32), "
+                        "weights split the same way, 3 MFMAs per k-step on weights-stationary LDS-DMA kernels, fp32 epilogues, "
+                        "GroupNorm from order-independent fixed-point sums (csrc/planes.hip, planes_c3.hip)" if planes else
+                        "LFD.precision = 'fp32_storage': fp32 NHWC tensors, one launch per conv (csrc/precise.hip)",
+                   ms_per_step_bs8=round(ms_pipe, 4), images_per_s_bs8=round(x.size(0) / ms_pipe * 1e3, 1),
+                   pipeline_depth=2, ms_per_step_bs8_serial=round(ms, 4), images_per_s_bs8_serial=round(x.size(0) / ms * 1e3, 1),
                    end_to_end_bs1_ms={'p50': round(float(ts[len(ts) // 2]), 4), 'min': round(float(ts[0]), 4)},
-                   mfma_tflops_issued=round(3 * 348.8 / ms, 1),
+                   mfma_tflops_issued=round(3 * 348.8 / ms_pipe, 1),
                    parity='raw logits <= 1e-4, sigma <= 1e-3 vs the fp32 oracle at configs 2 / 3 / 4 (tests/test_gpu_precise.py)')
     finally:
         model.precision = 'fp16'

@@ -9,6 +9,9 @@
 //   lfd_pl_groupnorm_relu  planes -> GroupNorm(groups of 8 channels) + ReLU in place, statistics from the producer's sums
 #include "planes_impl.h"
 
+// csrc/planes_c3.hip
+int lfd_pl_c3_launch(const pl::PlArgs& a, bool residual, hipStream_t st);
+
 namespace {
 
 using namespace pl;
@@ -472,7 +475,12 @@ int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const 
   const int key = d->cin * 10000 + d->ks * 1000 + d->stride * 100 + nslab;
   switch (key) {
     // ---- 64-channel body
-    case 64 * 10000 + 3100 + 2: return launch_pl<64, 3, 1, 2, true>(a, outm, st);
+    case 64 * 10000 + 3100 + 2:
+      // the workhorse of the residual blocks: epilogue pipelined under the next tile's contraction (k_pl_c3); tuning knob
+      // LFD_TUNE_PL_C3 = 0 keeps the generic kernel (A/B timing, tests)
+      if (outm == 0 && !tail && !ds_w_packed && lfd_tune(LFD_TUNE_PL_C3) != 0)
+        return lfd_pl_c3_launch(a, residual != nullptr, st);
+      return launch_pl<64, 3, 1, 2, true>(a, outm, st);
     case 64 * 10000 + 3200 + 2: return launch_pl<64, 3, 2, 2, true>(a, outm, st);
     case 64 * 10000 + 3200 + 4: return launch_pl<64, 3, 2, 2, true>(a, outm, st);        // two cout groups (grid.y)
     case 64 * 10000 + 1100 + 4: return launch_pl<64, 1, 1, 4, true>(a, outm, st);        // neck 64 -> 128 (+ chained tower conv)

@@ -109,9 +109,19 @@ struct PCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 };
 
+// scheduling fence around the MFMAs of a k-step (pins the operand ring's prefetch distance)
+#ifdef PL_NO_SB
+#define PL_SB()
+#else
+#define PL_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 #ifdef LFD_PL_TIMING
-__device__ unsigned long long g_pl_dbg[8 * 16 + 8];
-#define PL_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && dbg_it < 8) g_pl_dbg[dbg_it * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#ifndef PL_DBG_BLOCK
+#define PL_DBG_BLOCK 0
+#endif
+__device__ unsigned long long g_pl_dbg[8 * 16 + 8 + 8];
+#define PL_T(i) do { if (blockIdx.x == PL_DBG_BLOCK && blockIdx.y == 0 && threadIdx.x == 0 && dbg_it < 8) g_pl_dbg[dbg_it * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PL_T(i)
 #endif
@@ -119,6 +129,13 @@ __device__ unsigned long long g_pl_dbg[8 * 16 + 8];
 __device__ __forceinline__ void dma16(const void* g, const void* lds_wave_base) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory");
+}
+
+// the same DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset (global_load_lds saddr form): no
+// per-lane 64-bit address arithmetic at the issue site -- the offsets are per-kernel constants of the lane
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, const void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
 }
 
 __device__ __forceinline__ void block_barrier() {
@@ -508,7 +525,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
             xql[(k + PD) % (PD + 1)][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        PL_SB();
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xqh[k % (PD + 1)][pt], accm[pt], 0, 0, 0);
 #pragma unroll
@@ -525,7 +542,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        PL_SB();
       }
     } else {
       // weights streamed from L2 (128-channel 3x3 layers on the small last-stage maps): a ring of PW (hi, lo) fragment pairs
@@ -562,7 +579,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
           const int s = j / C::NQ, q = j % C::NQ;
           (void)s; (void)q;
           const half8 wfh = wqh[j % PW], wfl = wql[j % PW];
-          __builtin_amdgcn_sched_barrier(0);
+          PL_SB();
           {
             const size_t kn = (size_t)((knext + j) < C::NK ? (knext + j) : (C::NK - 1)) * 64;
             wqh[j % PW] = wsrc[kn];
@@ -576,7 +593,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
               xql[(j + XPD) % (XPD + 1)][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
+          PL_SB();
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) {
             const half8 xh = xqh[j % (XPD + 1)][pt], xl = xql[j % (XPD + 1)][pt];
@@ -845,5 +862,6 @@ int launch_pl_(const PlArgs& a0, hipStream_t st) {
   LFD_CHECK_LAUNCH();
   return LFD_OK;
 }
+
 
 }  // namespace pl

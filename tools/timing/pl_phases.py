@@ -42,6 +42,14 @@ def case(tag, n, h, w, cin, cout, ks, stride, res=False, tail=False, ds=False, g
         for it in range(1, 5):
             v = [buf[it * 16 + i] for i in range(10)]
             print('   tile %d: ' % it + '  '.join('%s %d' % (NAMES[i], v[i + 1] - v[i]) for i in range(9)) + '  | total %d  next-gap %d' % (v[9] - v[0], buf[(it + 1) * 16] - v[9]))
+    if hasattr(L, 'lfd_debug_pl_c3_timing') and ks == 3 and stride == 1 and cin == 64 and not (tail or ds or gn):
+        L.lfd_debug_pl_c3_timing.argtypes = [C.c_void_p]
+        buf = (C.c_ulonglong * 136)(); L.lfd_debug_pl_c3_timing(buf)
+        cyc, rt = buf[130] - buf[128], buf[131] - buf[129]
+        print('   k_pl_c3 workgroup 0: %d shader cycles in %.2f us -> %.2f GHz' % (cyc, rt / 100.0, cyc / (rt * 10.0)))
+        for it in range(1, 4):
+            v = [buf[it * 16 + i] for i in range(5)]
+            print('   tile %d: top-wait %d barrier %d setup+bias %d kloop %d  next-top %d' % (it, v[1] - v[0], v[2] - v[1], v[3] - v[2], v[4] - v[3], buf[(it + 1) * 16] - v[4]))
 case('3x3 s1 64 plain 8x135x240', 8, 135, 240, 64, 64, 3, 1)
 case('3x3 s1 64 res   8x135x240', 8, 135, 240, 64, 64, 3, 1, res=True)
 case('3x3 s2 64 tail  8x540x960', 8, 540, 960, 64, 64, 3, 2, tail=True)
