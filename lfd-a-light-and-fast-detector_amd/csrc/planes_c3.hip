@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
 
   // ---- epilogue pieces of the PREVIOUS tile (its accumulator set pm / pc, its coordinates e_n / e_ty0 / e_tx0)
   int e_n = 0, e_ty0 = 1 << 24, e_tx0 = 0;      // (no previous tile yet: rows far outside the image)
-  auto epi_stage = [&](const f32x16& pm, const f32x16& pc, const f32x16& pd, int g) {
+  auto epi_stage = [&](const f32x16& pm, const f32x16& pc, int g) {
     float y[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      y[e] = comb(pm[4 * g + e], pc[4 * g + e] + pd[4 * g + e]);
+      y[e] = comb(pm[4 * g + e], pc[4 * g + e]);
       if (a.relu) y[e] = fmaxf(y[e], 0.f);
     }
     uint2 vh, vl;
@@ -241,10 +241,9 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
   int dbg_it = 0; (void)dbg_it;
 
   // one tile: contraction into (am, ac); the previous tile's set (pm, pc) leaves through the pieces
-  // THREE accumulators per set (w_hi x_hi | w_hi x_lo | w_lo x_hi): with two, the correction set takes two MFMAs per k-step
-  // and one of them always issues right behind a MFMA on the same registers -- a dependent back-to-back pair costs a full
-  // extra pass (~+32 cycles: the k loop of this one-tile-per-wave kernel ran at 51 cycles per MFMA instead of 32)
-  auto tile = [&](f32x16& am, f32x16& ac, f32x16& ad, const f32x16& pm, const f32x16& pc, const f32x16& pd) {
+  // (two accumulator sets per tile: a third one for the second correction product -- so that no MFMA follows another on the
+  //  same registers -- measured the same k loop, 5.6 k cycles per 108 MFMAs, and spilled in the residual variant)
+  auto tile = [&](f32x16& am, f32x16& ac, const f32x16& pm, const f32x16& pc) {
     PL_T(0);
     // the VMEM operations younger than this tile's DMA pieces are the four output stores issued later in the previous
     // contraction: vmcnt retires in order, four may stay in flight
@@ -267,7 +266,6 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
         const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
         am[4 * g + 0] = b4.x; am[4 * g + 1] = b4.y; am[4 * g + 2] = b4.z; am[4 * g + 3] = b4.w;
         ac[4 * g + 0] = 0.f; ac[4 * g + 1] = 0.f; ac[4 * g + 2] = 0.f; ac[4 * g + 3] = 0.f;
-        ad[4 * g + 0] = 0.f; ad[4 * g + 1] = 0.f; ad[4 * g + 2] = 0.f; ad[4 * g + 3] = 0.f;
       }
     }
     PL_T(3);
@@ -288,16 +286,18 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
       constexpr int k = decltype(kc)::value;
       // pieces: DMA of the next tile at k = 1, 3, .. ; staging of the previous tile at k = 2, 4, 6, 8; its LDS -> register
       // reads at k = 16 / 24, its stores at k = 20 / 28 (behind every DMA piece: the counted wait above)
+#ifndef PL_C3_NOPIECES
       if constexpr (k % 2 == 1 && (k - 1) / 2 < NPIECE) {
         if (has_next) dma_piece((k - 1) / 2);
       }
       // (unconditional: in front of the first tile the "previous tile" is a zero set at coordinates outside the image, its
       //  four stores go to the trash line -- no branch around the pieces, one store count for the wait at the tile top)
-      if constexpr (k == 2 || k == 4 || k == 6 || k == 8) epi_stage(pm, pc, pd, k / 2 - 1);
+      if constexpr (k == 2 || k == 4 || k == 6 || k == 8) epi_stage(pm, pc, k / 2 - 1);
       if constexpr (k == 16) epi_read(0, cvh, cvl);
       if constexpr (k == 20) epi_store(0, cvh, cvl);
       if constexpr (k == 24) epi_read(1, cvh, cvl);
       if constexpr (k == 28) epi_store(1, cvh, cvl);
+#endif
       if constexpr (k + PD < C::NK) {
         const char* p = xaddr(k + PD);
         xqh[(k + PD) % (PD + 1)] = *reinterpret_cast<const half8*>(p);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
       PL_SB();
       am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xqh[k % (PD + 1)], am, 0, 0, 0);
       ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xql[k % (PD + 1)], ac, 0, 0, 0);
-      ad = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xqh[k % (PD + 1)], ad, 0, 0, 0);
+      ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xqh[k % (PD + 1)], ac, 0, 0, 0);
       PL_SB();
     }, std::make_integer_sequence<int, C::NK>{});
     if constexpr (RES) {
@@ -323,16 +323,16 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
     e_n = n; e_ty0 = ty0; e_tx0 = tx0;
   };
 
-  f32x16 am0, ac0, ad0, am1, ac1, ad1;
+  f32x16 am0, ac0, am1, ac1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) am0[r] = ac0[r] = ad0[r] = am1[r] = ac1[r] = ad1[r] = 0.f;
+  for (int r = 0; r < 16; ++r) am0[r] = ac0[r] = am1[r] = ac1[r] = 0.f;
   int last = -1;
   while (t < t_end) {
-    tile(am0, ac0, ad0, am1, ac1, ad1);
+    tile(am0, ac0, am1, ac1);
     last = 0;
     t += t_step; buf ^= 1; ++dbg_it;
     if (t >= t_end) break;
-    tile(am1, ac1, ad1, am0, ac0, ad0);
+    tile(am1, ac1, am0, ac0);
     last = 1;
     t += t_step; buf ^= 1; ++dbg_it;
   }
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256, 1) void k_pl_c3(PlArgs a) {
     // the last tile's epilogue has no contraction to hide under
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (last == 0) epi_stage(am0, ac0, ad0, g);
-      else epi_stage(am1, ac1, ad1, g);
+      if (last == 0) epi_stage(am0, ac0, g);
+      else epi_stage(am1, ac1, g);
     }
     uint4 cvh, cvl;
 #pragma unroll

@@ -729,6 +729,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
     PL_T(8);
     {
       const int cslice = TAIL ? 0 : cog * NCT * 32;
+      float tile_s = 0.f, tile_q = 0.f;      // OUTM 1: this thread's sums over the tile (<= 64 values), fp64 across tiles
       static_assert((OPX * OCPP) % 256 == 0, "whole copy-out rounds");
 #pragma unroll
       for (int k = 0; k < (OPX * OCPP) / 256; ++k) {
@@ -772,10 +773,14 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
               s += v;
               q += v * v;
             }
-            gn_s += (double)s;
-            gn_q += (double)q;
+            tile_s += s;
+            tile_q += q;
           }
         }
+      }
+      if constexpr (OUTM == 1) {
+        gn_s += (double)tile_s;
+        gn_q += (double)tile_q;
       }
     }
     PL_T(9);

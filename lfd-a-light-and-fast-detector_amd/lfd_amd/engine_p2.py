@@ -92,6 +92,11 @@ def _check_dispatch(cin, cout, ks, stride, tail, ds, res, gn, out32):
         raise Unsupported('GroupNorm sums ride on a plain or chained 1x1')
 
 
+def _fork_enabled():
+    import os
+    return os.environ.get('LFD_P2_FORK', '0') != '0'
+
+
 class _Op(object):
     __slots__ = ('kind', 'src', 'dst', 'res', 'ds_dst', 'cin', 'cout', 'ks', 'stride', 'relu', 'w', 'b', 'tail', 'ds',
                  'out_mode', 'gn', 'gnin', 'level', 'f_c0', 'f_c1', 'scale', 'w1', 'b1', 'w2', 'b2', 'channels')
@@ -114,6 +119,9 @@ class PlanesPlan(object):
         self.buf_scale = {}
         self._nbuf = 0
         self.num_gn = 0
+        self.head_start = None      # index into self.ops of the first neck / head launch
+        self.level_ops = []         # [(first, last + 1)] launch ranges of the pyramid levels' neck + head
+        self.tap_ready = []         # index of the backbone launch that produces level i's input
         with torch.no_grad():
             self._build(model)
 
@@ -225,6 +233,7 @@ class PlanesPlan(object):
                 cur = y
                 if (i, j) in taps:
                     self.taps.append(cur)
+                    self.tap_ready.append(len(self.ops) - 1)
         # ---- neck + head (simple_neck.py:67-74, lfd_head.py:164-185)
         if head._norm_cfg is None or head._conv_kernel_size != 1:
             raise Unsupported('head towers must be 1x1 conv + GroupNorm')
@@ -254,7 +263,9 @@ class PlanesPlan(object):
                 t = op.dst
             return t, pend
 
+        self.head_start = len(self.ops)
         for i, f in enumerate(self.taps):
+            first_op = len(self.ops)
             nseq = getattr(neck, 'neck%d' % i)
             nw, nb = engine.fold_conv_norm(nseq[0], nseq[1] if neck._norm_cfg is not None else None)
             if nw.shape[0] != 128 or nw.shape[2] != 1:
@@ -282,6 +293,7 @@ class PlanesPlan(object):
                 (tc, pc), (tr, pr) = tower(cls_path, t), tower(reg_path, t)
                 self._conv(tc, cconv.weight.detach().float(), cconv.bias.detach().float(), 1, 1, False, out32=(i, ccls, 0, None), gnin=pc)
                 self._conv(tr, rconv.weight.detach().float(), rconv.bias.detach().float(), 1, 1, False, out32=(i, 0, 4, scale), gnin=pr)
+            self.level_ops.append((first_op, len(self.ops)))
 
     # ------------------------------------------------------------------ execution
     def state_for(self, n, h, w, slot=0):
@@ -293,11 +305,31 @@ class PlanesPlan(object):
         return st
 
     def run(self, x, fmt, st):
-        l, sp = lib(), stream_ptr()
-        zeros = ptr(ops.zero_line(self.device))
+        """Launch order: backbone on the current stream; the neck + head of the FIRST pyramid level (the large map: a third
+        of the head's work in three chip-filling launches) forks onto a side stream as soon as its input exists and runs
+        beside the later backbone stages and the other levels' heads -- 30 short launches that each occupy a fraction of the
+        CUs (small maps) -- and joins before the outputs are used.  Opt-in (LFD_P2_FORK=1): measured 1.905 vs 1.920 ms serial and 1.70 vs 1.675 ms
+        with two batches in flight -- the fork of a captured graph starts late (DESIGN lesson 34) -- so one stream is the default."""
         if self.num_gn:
             st.gn_sums.zero_()
-        for o in self.ops:
+        fork = _fork_enabled() and len(self.level_ops) > 1 and self.tap_ready[0] + 1 < self.head_start
+        if not fork:
+            self._launch(x, fmt, st, range(len(self.ops)))
+            return
+        main = torch.cuda.current_stream()
+        a, b = self.level_ops[0]
+        self._launch(x, fmt, st, range(0, self.tap_ready[0] + 1))
+        st.side.wait_stream(main)
+        with torch.cuda.stream(st.side):
+            self._launch(x, fmt, st, range(a, b))
+        self._launch(x, fmt, st, list(range(self.tap_ready[0] + 1, self.head_start)) + list(range(b, len(self.ops))))
+        main.wait_stream(st.side)
+
+    def _launch(self, x, fmt, st, indices):
+        l, sp = lib(), stream_ptr()
+        zeros = ptr(ops.zero_line(self.device))
+        for i in indices:
+            o = self.ops[i]
             if o.kind == 'stem':
                 dst = st.bufs[o.dst]
                 check(l.lfd_pl_stem_pair(ptr(x), fmt, st.n, st.h, st.w, o.channels, ptr(o.w1), ptr(o.b1), ptr(o.w2), ptr(o.b2),
@@ -362,4 +394,5 @@ class _State(object):
             self.cls = torch.empty((n, p, plan.cls_channels), dtype=torch.float32, device=dev)
             self.reg = torch.empty((n, p, 4), dtype=torch.float32, device=dev)
             self.gn_sums = torch.zeros((max(plan.num_gn, 1), n, 16, 2), dtype=torch.int64, device=dev)
+            self.side = torch.cuda.Stream(device=dev)
         self.graph = {}
