@@ -236,11 +236,14 @@ def cpu_baseline(reps=5):
                        'host\'s %d hardware threads' % (reps, TARGET_K, torch.__version__, cores, host))
 
 
-def train_bench(dev, steps=10, warmup=3):
-    """BASELINE.json configs[4] on one GPU: WIDERFACE_LFD_S train-from-scratch iteration, synthetic 640x640, bs 32 --
+def train_bench(dev, steps=10, warmup=3, world=1, rank=0):
+    """BASELINE.json configs[4]: WIDERFACE_LFD_S train-from-scratch iteration, synthetic 640x640, bs 32 PER GPU --
     forward + device targets + fused get_loss + hand-written backward + clip_grad_norm_ + SGD (lfd_amd.train.train_step).
-    826 GFLOP per iteration = 3 x the 8.606 GFLOP/img forward x 32.  Extra key of the bench line so that the
-    driver records it; the headline `value` is the inference metric."""
+    826 GFLOP per GPU and iteration = 3 x the 8.606 GFLOP/img forward x 32.  At world > 1 (bench.py --gpus N,
+    one process per GPU) every rank runs it: image-parallel DDP -- the all-reduced loss normalisers and ONE all-reduce of
+    the flat gradient buffer per iteration over RCCL -- eagerly (train_step) and as three HIP graphs with the two collectives
+    between them (GraphedTrainStep under torch.distributed); per-iteration time = MAX over ranks of the rank medians.
+    Extra key of the bench line so that the driver records it; the headline `value` is the inference metric."""
     from lfd_amd import configs, optim, train
     torch.manual_seed(0)
     m = configs.build_model(MODEL).to(dev).train()
@@ -268,8 +271,10 @@ def train_bench(dev, steps=10, warmup=3):
         return ts, lv
 
     ts_eager, lv = timed(lambda: train.train_step(m, opt, x, ann, clip, True))
-    # the same iteration replayed as one HIP graph (lfd_amd.train.GraphedTrainStep: ~500 launches, one host call)
+    # the same iteration replayed as one HIP graph (lfd_amd.train.GraphedTrainStep: ~300 launches, one host call; three graphs
+    # with the two RCCL all-reduces between them when a process group is live)
     graphed = None
+    ts_b2b = 0.0
     try:
         step = train.GraphedTrainStep(m, opt, clip, max_boxes=1024)
         ts, lv = timed(lambda: step(x if step.x is None else step.x, ann, True))     # frames written into the step's own buffer
@@ -287,17 +292,27 @@ def train_bench(dev, steps=10, warmup=3):
     except Exception as e:       # keep the eager number
         graphed = repr(e)
         ts = ts_eager
-    dt = float(np.median(ts))
+    dt, dt_eager = float(np.median(ts)), float(np.median(ts_eager))
+    per_rank = [round(dt * 1e3, 3)]
+    if world > 1:
+        t = torch.tensor([dt, dt_eager, ts_b2b], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [round(float(a[0]) * 1e3, 3) for a in allt]
+        dt, dt_eager, ts_b2b = (max(float(a[i]) for a in allt) for i in range(3))
     gf = 3 * 8.606 * bs
-    return dict(workload='WIDERFACE_LFD_S train step 640x640 bs 32 (forward + targets + loss + backward + clip + SGD), fp16 '
-                         'activations / fp32 accumulate + parameters', ms_per_iter=round(dt * 1e3, 3),
-                images_per_s=round(bs / dt, 1), gflop_per_iter=round(gf, 1), tflops=round(gf / dt / 1e3, 1),
-                frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup, loss=lv['loss'],
-                hip_graph=graphed, ms_per_iter_eager=round(float(np.median(ts_eager)) * 1e3, 3),
+    return dict(workload='WIDERFACE_LFD_S train step 640x640 bs 32 per GPU (forward + targets + loss + backward + clip + SGD), fp16 '
+                         'activations / fp32 accumulate + parameters' + ('; image-parallel DDP over %d ranks: all-reduced loss '
+                         'normalisers + one all-reduce of the flat gradient buffer per iteration (RCCL)' % world if world > 1 else ''),
+                n_gpus=world, ranks_seen=len(per_rank), ms_per_iter_per_rank=per_rank,
+                ms_per_iter=round(dt * 1e3, 3), images_per_s=round(world * bs / dt, 1), gflop_per_iter_per_gpu=round(gf, 1),
+                tflops_per_gpu=round(gf / dt / 1e3, 1), frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup,
+                loss=lv['loss'], hip_graph=graphed, graphs_per_iter=(3 if world > 1 or dist.is_initialized() else 1),
+                ms_per_iter_eager=round(dt_eager * 1e3, 3),
                 ms_per_iter_back_to_back=(round(ts_b2b * 1e3, 3) if graphed is True else None),
-                note='ms_per_iter: one HIP graph per iteration, the loss values read back after every iteration (median); '
-                     'ms_per_iter_back_to_back: iterations enqueued without read-back (GraphedTrainStep sync=False); '
-                     'ms_per_iter_eager: ~400 eager launches per iteration')
+                note='ms_per_iter: the iteration as HIP graph(s), the loss values read back after every iteration (median; MAX '
+                     'over ranks); ms_per_iter_back_to_back: iterations enqueued without read-back (GraphedTrainStep sync=False); '
+                     'ms_per_iter_eager: ~300 eager launches per iteration')
 
 
 def siblings_bench(dev, reps=20, n=8, h=720, w=1280):
@@ -504,6 +519,36 @@ def precise_bench(model, x, meta, dev, steps=40):
         model.precision = 'fp16'
         model.use_graph = keep_g
     return out
+
+
+def compact_line(r):
+    """the contract keys + roofline + cpu_baseline + serial figures, <= ~1.8 KB"""
+    keys = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'ms_per_step_serial', 'images_per_s_serial', 'pipeline_depth', 'ranks_seen')
+    c = {k: r[k] for k in keys if k in r}
+    cfg = r.get('config', {})
+    c['config'] = {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16', 'global_batch': cfg.get('global_batch'),
+                   'parallelism': cfg.get('parallelism'), 'hip_graph': cfg.get('hip_graph')}
+    ev = r.get('step_ms_hip_events') or {}
+    c['step_ms_hip_events'] = {k: ev.get(k) for k in ('median', 'p95')}
+    rf = r.get('roofline') or {}
+    c['roofline'] = {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us')}
+    for k in ('roofline_conv3x3_s1_64', 'roofline_backbone_3x3'):
+        if k in r:
+            c[k] = {'frac': r[k].get('frac'), 'achieved': r[k].get('achieved')}
+    cb = r.get('cpu_baseline')
+    c['cpu_baseline'] = None if not cb else {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+    p = r.get('precise') or {}
+    c['precise'] = {k: p.get(k) for k in ('images_per_s_bs8', 'ms_per_step_bs8', 'pipeline_depth', 'images_per_s_bs8_serial',
+                                          'ms_per_step_bs8_serial', 'end_to_end_bs1_ms', 'error') if k in p}
+    t = r.get('train') or {}
+    c['train'] = {k: t.get(k) for k in ('ms_per_iter', 'n_gpus', 'ranks_seen', 'images_per_s', 'graphs_per_iter', 'hip_graph',
+                                        'ms_per_iter_eager', 'error') if k in t}
+    lb = r.get('latency_bs1') or {}
+    if lb:
+        c['latency_bs1'] = {k: (v.get('p50') if isinstance(v, dict) else v) for k, v in lb.items() if k in ('forward_ms', 'end_to_end_ms')}
+    c['full_line'] = 'the line above / gpurun_out/bench_full.json'
+    return c
 
 
 def latency_bs1(model, dev, iters=200):
@@ -784,11 +829,14 @@ def main():
                 result['configs'].update(stress_and_small_frame_bench(model, x, meta, dev, cls))
         except Exception as e:
             result['configs'] = {'error': repr(e)}
-    if rank == 0 and world == 1 and not args.no_train:
+    if not args.no_train:
+        # every rank runs the training leg (the DDP iteration has collectives); rank 0 reports
         try:
-            result['train'] = train_bench(dev)
+            tr = train_bench(dev, world=world, rank=rank)
         except Exception as e:       # the inference line must not be lost to the extra key
-            result['train'] = {'error': repr(e)}
+            tr = {'error': repr(e)}
+        if rank == 0:
+            result['train'] = tr
     if rank == 0 and world == 1 and not args.no_siblings:
         try:
             result['siblings'] = siblings_bench(dev)
@@ -800,6 +848,15 @@ def main():
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result))
+        # the driver keeps a 2 KB tail of stdout: the contract line once more, compact, LAST -- headline keys, `roofline`,
+        # `cpu_baseline`, the serial / HIP-event figures and one-line summaries of the extra keys (everything is in the long
+        # line above and in gpurun_out/bench_full.json)
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            json.dump(result, open(os.path.join(ROOT, 'gpurun_out', 'bench_full.json'), 'w'))
+        except Exception:
+            pass
+        print(json.dumps(compact_line(result)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

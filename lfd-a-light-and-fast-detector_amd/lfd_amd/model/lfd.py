@@ -499,17 +499,21 @@ class LFD(nn.Module):
             return False
         return type(rf).__name__ == 'IoULoss' and cf.reduction == 'mean' and rf.reduction == 'mean'
 
-    def _fused_loss_tensor(self, pred_cls, pred_reg, cls_t, reg_t):
-        """-> float32[3] device tensor (classification_loss, regression_loss, loss) with the autograd graph of the fused
-        kernels behind it; no host sync (a captured training iteration reads it after the replay)"""
+    def _loss_desc(self, n):
+        """lfd_loss_desc_t of the fused get_loss kernels for a batch of n images at the recorded feature-map sizes"""
         cf, rf = self._classification_loss_func, self._regression_loss_func
         sizes = [self._head_indexes_to_feature_map_sizes[i] for i in range(self._num_heads)]
-        desc = ops.make_loss_desc(pred_cls.size(0), sizes, self._point_strides, self._regression_ranges,
+        return ops.make_loss_desc(n, sizes, self._point_strides, self._regression_ranges,
                                   self._num_classes, self._is_ce(), self._distance_to_bbox_mode,
                                   gamma=getattr(cf, 'gamma', 2.0), alpha=getattr(cf, 'alpha', 0.25), iou_eps=rf.eps,
                                   cls_loss_weight=cf.loss_weight, reg_loss_weight=rf.loss_weight,
                                   cls_weighted=self._enable_classification_weight,
                                   reg_weighted=self._enable_regression_weight)
+
+    def _fused_loss_tensor(self, pred_cls, pred_reg, cls_t, reg_t):
+        """-> float32[3] device tensor (classification_loss, regression_loss, loss) with the autograd graph of the fused
+        kernels behind it; no host sync (a captured training iteration reads it after the replay)"""
+        desc = self._loss_desc(pred_cls.size(0))
         # image-parallel training: the reference normalises by the GLOBAL-batch n_pos (loss computed once over the
         # gathered outputs, executor.py:198-200); gradients are averaged over ranks afterwards, hence the scale
         dist_on = parallel.is_dist()

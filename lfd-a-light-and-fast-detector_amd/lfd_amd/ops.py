@@ -469,24 +469,38 @@ def _loss_inputs(desc, pred_cls, pred_reg, cls_t, reg_t):
     return ts
 
 
-def get_loss_forward(desc, pred_cls, pred_reg, cls_t, reg_t, reduce_sums=None, rank_scale=1.0):
-    """Fused LFD.get_loss forward (lfd.py:284-395) -> float32[8] device tensor
-    {classification_loss, regression_loss, loss, n_pos, avg_cls, avg_reg, n_green, rank_scale}.
-    reduce_sums: optional callable mapping the local float64[8] sums tensor to the global one (the
-    all-reduce over image-parallel ranks, lfd_amd.parallel.global_count)."""
+def get_loss_sums(desc, pred_cls, pred_reg, cls_t, reg_t):
+    """First half of the fused get_loss forward: this rank's float64[8] sums (lfd_get_loss_sums_f32).  Under image-parallel
+    training they are all-reduced before `get_loss_finalize` (lfd.py:340,383: `n_pos + 1` / `n_pos` are global-batch counts)."""
     pc, pr, ct, rt = _loss_inputs(desc, pred_cls, pred_reg, cls_t, reg_t)
     dev = pc.device
     nbytes = lib().lfd_get_loss_workspace_bytes()
     ws = _workspace(nbytes, dev)
     sums = torch.empty(8, dtype=torch.float64, device=dev)
-    out = torch.empty(8, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(lib().lfd_get_loss_sums_f32(C.byref(desc), ptr(pc), ptr(pr), ptr(ct), ptr(rt), ptr(ws), nbytes, ptr(sums),
                                           stream_ptr()), 'lfd_get_loss_sums_f32')
-        gsums = reduce_sums(sums) if reduce_sums is not None else sums
+    return sums
+
+
+def get_loss_finalize(desc, sums, gsums, rank_scale=1.0):
+    """Second half: local + global sums -> float32[8] {classification_loss, regression_loss, loss, n_pos, avg_cls, avg_reg,
+    n_green, rank_scale} (lfd_get_loss_finalize_f32)"""
+    out = torch.empty(8, dtype=torch.float32, device=sums.device)
+    with torch.cuda.device(sums.device):
         check(lib().lfd_get_loss_finalize_f32(C.byref(desc), ptr(sums), ptr(gsums), float(rank_scale), ptr(out),
                                               stream_ptr()), 'lfd_get_loss_finalize_f32')
     return out
+
+
+def get_loss_forward(desc, pred_cls, pred_reg, cls_t, reg_t, reduce_sums=None, rank_scale=1.0):
+    """Fused LFD.get_loss forward (lfd.py:284-395) -> float32[8] device tensor
+    {classification_loss, regression_loss, loss, n_pos, avg_cls, avg_reg, n_green, rank_scale}.
+    reduce_sums: optional callable mapping the local float64[8] sums tensor to the global one (the
+    all-reduce over image-parallel ranks, lfd_amd.parallel.global_count)."""
+    sums = get_loss_sums(desc, pred_cls, pred_reg, cls_t, reg_t)
+    gsums = reduce_sums(sums) if reduce_sums is not None else sums
+    return get_loss_finalize(desc, sums, gsums, rank_scale)
 
 
 def get_loss_backward(desc, pred_cls, pred_reg, cls_t, reg_t, finalized, grad_out):
@@ -1102,12 +1116,17 @@ class WgradFinals(object):
         self.rj.append((src.data_ptr(), dst.data_ptr(), int(nrows), int(row_stride), int(count), int(bool(accumulate))))
 
     def _table(self, kind, key, build):
-        ent = self.cache.get(kind)
-        if ent is None or ent[0] != key:
+        """One device table per CONTENT, kept for the life of the plan: a captured training graph holds the raw address of
+        the table that was live at capture, and the content key contains the loss scale (inv_scale) -- with a DynamicLossScale
+        an overflow halves the scale, an eager iteration builds a second table, and `growth_interval` iterations later the
+        first graph replays again.  Replacing (= freeing) the old table handed that replay a dangling job table.
+        A table is ~64 B per job; the keys of a run are a handful (loss scales x batch shapes)."""
+        ent = self.cache.get((kind, key))
+        if ent is None:
             raw = build()
-            ent = (key, torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(self.device), raw)
-            self.cache[kind] = ent
-        return ent[1]
+            ent = (torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(self.device), raw)
+            self.cache[(kind, key)] = ent
+        return ent[0]
 
     def launch(self):
         with torch.cuda.device(self.device):

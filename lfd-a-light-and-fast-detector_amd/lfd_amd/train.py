@@ -109,14 +109,49 @@ class PendingLossValues(object):
         return dict(loss=t, classification_loss=c, regression_loss=r)
 
 
+class SegmentedIteration(object):
+    """The image-parallel training iteration as THREE device segments with the iteration's two collectives between them
+    (lfd/execution/executor.py:39,198-202: the reference's nn.DataParallel gathers the outputs, computes the loss once over
+    the global batch -- lfd.py:340,383 `n_pos + 1` / `n_pos` -- and sums the replicas' gradients):
+
+        A  forward -> targets -> this rank's loss sums           | all-reduce(sums)            (8 doubles)
+        B  finalize (global normalisers) -> backward -> flat g   | all-reduce(flat gradients)  (one bucket per group)
+        C  g /= world -> clip_grad_norm_ -> SGD update
+
+    `a`, `b`, `c` are callables (eager segments, or `CUDAGraph.replay` of the captured ones: RCCL calls are not captured --
+    the collectives run eagerly between the replays, on the stream the graphs replay on); `sums` / `gsums` the local and the
+    reduced loss sums, `grad_buffers` the flat gradient buffers.  Device-agnostic: tests/test_dist_cpu.py drives it with
+    gloo at world size 2."""
+
+    def __init__(self, a, b, c, sums, gsums, grad_buffers):
+        self.a, self.b, self.c = a, b, c
+        self.sums, self.gsums, self.grad_buffers = sums, gsums, list(grad_buffers)
+
+    def run(self):
+        import torch.distributed as dist
+        self.a()
+        self.gsums.copy_(self.sums)
+        if parallel.is_dist():
+            dist.all_reduce(self.gsums, op=dist.ReduceOp.SUM)
+        self.b()
+        if parallel.is_dist():
+            for g in self.grad_buffers:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        self.c()
+
+
 class GraphedTrainStep(object):
     """train_step as ONE HIP graph per set of optimizer hyper-parameters: forward, device target assignment, fused get_loss,
     the hand-written backward, clip_grad_norm_ + SGD -- ~500 launches replayed with one host call, then the iteration's one
     host sync (the three loss values).  Static shapes: every call must bring an image batch of the first call's shape and at
     most `max_boxes` annotations in total; the annotations are uploaded into fixed device buffers before the replay.
 
-    Covers what the all-HIP training path covers (train_engine.network_supported + the fused loss + lfd_amd.optim.SGD, one
-    process); raises otherwise -- use train_step.  Learning-rate schedules: the update kernel takes lr / momentum / weight decay
+    Under torch.distributed (one process per GPU, image-parallel) the iteration is captured as THREE graphs split at its two
+    collectives (SegmentedIteration: loss-normaliser sums, flat gradient bucket), replayed with the RCCL all-reduces between
+    them -- the same kernels in the same order as the eager train_step of a rank, bit for bit (tests/test_gpu_dist.py).
+
+    Covers what the all-HIP training path covers (train_engine.network_supported + the fused loss + lfd_amd.optim.SGD);
+    raises otherwise -- use train_step.  Learning-rate schedules: the update kernel takes lr / momentum / weight decay
     by value, so a graph belongs to one set of values; a new set runs eagerly once and is captured when it repeats (a
     per-iteration warm-up schedule therefore stays eager, the constant-lr bulk of an epoch replays).
 
@@ -127,8 +162,6 @@ class GraphedTrainStep(object):
     def __init__(self, model, optimizer, grad_clip_cfg=None, max_boxes=4096, max_graphs=4, loss_scaler=None):
         if not isinstance(optimizer, optim.SGD):
             raise RuntimeError('GraphedTrainStep needs lfd_amd.optim.SGD (the flat-buffer optimizer)')
-        if parallel.is_dist():
-            raise RuntimeError('GraphedTrainStep: single process only (the gradient all-reduce is not captured)')
         if grad_clip_cfg is not None and float(grad_clip_cfg.get('norm_type', 2)) != 2.0:
             raise RuntimeError('GraphedTrainStep: L2 gradient clipping only')
         self.model, self.opt = model, optimizer
@@ -218,6 +251,111 @@ class GraphedTrainStep(object):
             norm = None
         return vals.detach(), norm, self.opt.last_norm
 
+    # ------------------------------------------------------------------ the same iteration in three segments (image-parallel)
+    def _segments(self, clip):
+        """-> (SegmentedIteration of eager segments, state dict).  Segment B reads `state['gsums']` (reduced in place between
+        A and B); the values the caller reads are state['vals'] / ['norm'] / ['nc'] after C."""
+        m, opt = self.model, self.opt
+        world = float(parallel.world_size())
+        # d loss / d {classification_loss, regression_loss, loss}: the iteration differentiates `loss` (created here, outside
+        # any capture: a host -> device copy is not capturable)
+        S = {'g001': torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=self.x.device)}
+
+        def seg_a():
+            cls, reg = m(self.x)
+            if self.adesc is None:
+                sizes = [m._head_indexes_to_feature_map_sizes[i] for i in range(m._num_heads)]
+                self.adesc = ops.make_assign_desc(self.x.size(0), sizes, m._point_strides, m._regression_ranges, m._gray_ranges,
+                                                  m._num_classes, m._range_assign_mode, m._regression_loss_type == 'independent')
+            d, total = self.adesc
+            S['cls'], S['reg'] = cls, reg
+            S['cls_t'], S['reg_t'] = ops.assign_targets_device(d, total, m._num_classes, self.boxes, self.labels, self.offs)
+            S['desc'] = m._loss_desc(cls.size(0))
+            sums = ops.get_loss_sums(S['desc'], cls.detach(), reg.detach(), S['cls_t'], S['reg_t'])
+            if 'sums' not in S:
+                S['sums'], S['gsums'] = sums, torch.empty_like(sums)
+            elif S['sums'].data_ptr() != sums.data_ptr():
+                S['sums'].copy_(sums)
+
+        def seg_b():
+            cls, reg = S['cls'], S['reg']
+            fin = ops.get_loss_finalize(S['desc'], S['sums'], S['gsums'], world)
+            gc, gr = ops.get_loss_backward(S['desc'], cls.detach(), reg.detach(), S['cls_t'], S['reg_t'], fin, S['g001'])
+            opt.zero_grad()
+            torch.autograd.backward([cls, reg], [gc.view_as(cls).to(cls.dtype), gr.view_as(reg).to(reg.dtype)])
+            for fg in opt._flat:
+                fg.adopt_grads()
+            S['vals'] = fin[:3]
+
+        def seg_c():
+            if world != 1.0:
+                for fg in opt._flat:
+                    fg.g /= world
+            if clip:
+                S['norm'] = opt.clip_and_step(self.max_norm)
+            else:
+                opt.step()
+                S['norm'] = None
+            S['nc'] = opt.last_norm
+
+        return seg_a, seg_b, seg_c, S
+
+    def _run_dist(self, clip, key):
+        """one image-parallel iteration: eager segments the first time a key shows up, then three captured graphs"""
+        ent = self.graphs.get(key)
+        if ent is None:
+            a, b, c, S = self._segments(clip)
+            capture = self._last_key == key
+            if capture:
+                if len(self.graphs) >= self.max_graphs:
+                    self.graphs.pop(next(iter(self.graphs)))
+                torch.cuda.synchronize()
+                stream = torch.cuda.Stream(device=self.x.device)
+                ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # capture A, run the collective it feeds, capture B against the reduced sums, ... : every capture sees the
+                # buffers in the state a replay finds them in; one memory pool, the replay order of the capture order
+                with torch.cuda.graph(ga, stream=stream):
+                    a()
+                it = SegmentedIteration(lambda: None, lambda: None, lambda: None, S['sums'], S['gsums'], [fg.g for fg in self.opt._flat])
+                ga.replay()
+                it.a = lambda: None
+                it.gsums.copy_(it.sums)
+                import torch.distributed as dist
+                dist.all_reduce(it.gsums, op=dist.ReduceOp.SUM)
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=stream):
+                    b()
+                gb.replay()
+                for g in it.grad_buffers:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                with torch.cuda.graph(gc_, pool=ga.pool(), stream=stream):
+                    c()
+                gc_.replay()
+                it.a, it.b, it.c = ga.replay, gb.replay, gc_.replay
+                ent = (it, S, (ga, gb, gc_))
+                self.graphs[key] = ent
+                self._last_key = key
+                self._bump_versions()
+                return S['vals'], S['norm'], S['nc']
+            it = SegmentedIteration(a, b, c, None, None, [fg.g for fg in self.opt._flat])
+            # (eager: the sums tensor only exists after segment A)
+            a()
+            it.sums, it.gsums = S['sums'], S['gsums']
+            it.a = lambda: None
+            it.run()
+            self._last_key = key
+            return S['vals'], S['norm'], S['nc']
+        it, S, _ = ent
+        it.run()
+        self._last_key = key
+        self._bump_versions()
+        return S['vals'], S['norm'], S['nc']
+
+    def _bump_versions(self):
+        # the replayed kernels rewrote parameters and norm buffers behind autograd's back: the inference engine keys its
+        # packed-weight plans on the tensors' version counters
+        optim.increment_version([p for grp in self.opt.param_groups for p in grp['params']])
+        optim.increment_version(list(self.model.buffers()))
+
     def _key(self, clip):
         return (bool(clip), train_engine.loss_scale()) + tuple((float(g['lr']), float(g['momentum']), float(g['dampening']), float(g['weight_decay']),
                                       bool(g['nesterov'])) for g in self.opt.param_groups)
@@ -231,6 +369,9 @@ class GraphedTrainStep(object):
         self._upload(image_batch, annotation_batch)
         clip = self.max_norm is not None and clip_active
         key = self._key(clip)
+        if parallel.is_dist():
+            vals, norm, nc = self._run_dist(clip, key)
+            return self._finish(vals, norm, nc, sync)
         ent = self.graphs.get(key)
         if ent is None and self._last_key == key:
             # second iteration in a row with these hyper-parameters (the first ran eagerly: momentum buffers, kernel
@@ -249,10 +390,10 @@ class GraphedTrainStep(object):
         else:
             ent[0].replay()
             vals, norm, nc = ent[1], ent[2], ent[3]
-            # the replayed kernels rewrote parameters and norm buffers behind autograd's back: the inference engine keys its
-            # packed-weight plans on the tensors' version counters
-            optim.increment_version([p for grp in self.opt.param_groups for p in grp['params']])
-            optim.increment_version(list(self.model.buffers()))
+            self._bump_versions()
+        return self._finish(vals, norm, nc, sync)
+
+    def _finish(self, vals, norm, nc, sync):
         if not sync:
             slot = self._vals_host[self._vals_i]
             self._vals_i = (self._vals_i + 1) % len(self._vals_host)

@@ -569,11 +569,15 @@ class _Sched(object):
         self.gather = ops.WgradFinals(dev)      # (its row-sum table with one source row = a batched copy)
 
     def buf(self, key, numel, dtype=torch.float32):
-        """a buffer that keeps its address from iteration to iteration (partial sums of the weight gradients)"""
-        t = self.bufs.get(key)
-        if t is None or t.numel() != numel or t.dtype != dtype:
+        """a buffer that keeps its address from iteration to iteration (partial sums of the weight gradients).  One buffer per
+        (key, size): captured training graphs and the job tables of the batched finals hold these addresses, and a batch of
+        another shape (the short last batch of an epoch goes through the eager train_step on the same model) must not free
+        what a later replay writes into -- it gets its own buffers, both sets stay."""
+        k = (key, int(numel), dtype)
+        t = self.bufs.get(k)
+        if t is None:
             t = torch.empty(numel, dtype=dtype, device=self.dev)
-            self.bufs[key] = t
+            self.bufs[k] = t
         return t
 
 
@@ -836,7 +840,7 @@ def _stem_pairs(units, outs):
     for ui, vi in _single_consumers(units, outs).items():
         v = units[vi]
         if (isinstance(v.norm, nn.BatchNorm2d) and v.conv.kernel_size[0] == 1 and v.conv.stride[0] == 1
-                and v.conv.in_channels == 64 and v.conv.out_channels % 32 == 0):
+                and v.conv.in_channels == 64 and v.conv.out_channels in (64, 128)):     # (the kernel's two instances: ADVICE r4)
             out[ui] = vi
     return out
 

@@ -46,6 +46,41 @@ w = torch.nn.Parameter(torch.zeros(3))
 topt = torch.optim.SGD([w], lr=1.0)
 train.backward_and_update(topt, (w * torch.tensor([1.0, 2.0, 3.0]) * float(rank + 1)).sum())
 assert torch.allclose(w.detach(), -1.5 * torch.tensor([1.0, 2.0, 3.0])), w
+# 4d. lfd_amd.train.SegmentedIteration -- the control flow of the graphed image-parallel training step (GraphedTrainStep under
+#     torch.distributed: three captured segments, the iteration's two collectives between them) on a toy model whose
+#     segments do what the real ones do: A local loss sums, B finalize with the GLOBAL normaliser + backward into the flat
+#     gradient buffer, C divide by the world size + update.  Equals the one-process step over the concatenated batch.
+torch.manual_seed(1)
+W0 = torch.randn(3)
+xs = [torch.tensor([[1., 2., 3.], [0., 1., 0.]]), torch.tensor([[2., 0., 1.]])]     # rank 0: 2 items, rank 1: 1 item
+ys = [torch.tensor([1., 0.]), torch.tensor([2.])]
+w = torch.nn.Parameter(W0.clone())
+sopt = optim.SGD([w], lr=0.5)
+S = {}
+def seg_a():
+    S['pred'] = xs[rank] @ w
+    S['sums'].copy_(torch.tensor([float(xs[rank].size(0)), 0.0], dtype=torch.float64))      # local count (the "n_pos")
+def seg_b():
+    n_global = S['gsums'][0]                                   # reduced between A and B
+    loss = ((S['pred'] - ys[rank]) ** 2).sum() / n_global * world     # rank's loss scaled by the world size (lfd.py get_loss)
+    sopt.zero_grad()
+    loss.backward()
+def seg_c():
+    sopt._flat[0].g /= world
+    with torch.no_grad():
+        w.sub_(0.5 * w.grad)                                   # (the update KERNEL is HIP-only; the flat buffer is the bucket)
+S['sums'], S['gsums'] = torch.zeros(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)
+calls = []
+it = train.SegmentedIteration(lambda: (calls.append('a'), seg_a()), lambda: (calls.append('b'), seg_b()),
+                              lambda: (calls.append('c'), seg_c()), S['sums'], S['gsums'], [sopt._flat[0].g])
+it.run()
+assert calls == ['a', 'b', 'c'] and float(S['gsums'][0]) == 3.0
+wr = torch.nn.Parameter(W0.clone())
+lr_ = ((torch.cat(xs) @ wr - torch.cat(ys)) ** 2).sum() / 3.0
+lr_.backward()
+assert torch.allclose(w.detach(), (wr - 0.5 * wr.grad).detach(), atol=1e-6), (w, wr)
+it.run()                                                       # replays keep working on the same buffers
+assert calls == ['a', 'b', 'c', 'a', 'b', 'c']
 # 5. throughput aggregation: max time over ranks
 t = parallel.max_over_ranks(1.0 + rank)
 assert t == 2.0
