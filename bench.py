@@ -294,7 +294,7 @@ def train_bench(dev, steps=10, warmup=3, world=1, rank=0):
         ts = ts_eager
     dt, dt_eager = float(np.median(ts)), float(np.median(ts_eager))
     per_rank = [round(dt * 1e3, 3)]
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt, dt_eager, ts_b2b], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -303,11 +303,11 @@ def train_bench(dev, steps=10, warmup=3, world=1, rank=0):
     gf = 3 * 8.606 * bs
     return dict(workload='WIDERFACE_LFD_S train step 640x640 bs 32 per GPU (forward + targets + loss + backward + clip + SGD), fp16 '
                          'activations / fp32 accumulate + parameters' + ('; image-parallel DDP over %d ranks: all-reduced loss '
-                         'normalisers + one all-reduce of the flat gradient buffer per iteration (RCCL)' % world if world > 1 else ''),
+                         'normalisers + one all-reduce of the flat gradient buffer per iteration (RCCL)' % world if dist.is_initialized() else ''),
                 n_gpus=world, ranks_seen=len(per_rank), ms_per_iter_per_rank=per_rank,
                 ms_per_iter=round(dt * 1e3, 3), images_per_s=round(world * bs / dt, 1), gflop_per_iter_per_gpu=round(gf, 1),
                 tflops_per_gpu=round(gf / dt / 1e3, 1), frac_mfma=round(gf / dt / 1e3 / MFMA_PEAK_TFLOPS, 4), steps=steps, warmup=warmup,
-                loss=lv['loss'], hip_graph=graphed, graphs_per_iter=(3 if world > 1 or dist.is_initialized() else 1),
+                loss=lv['loss'], hip_graph=graphed, graphs_per_iter=(3 if dist.is_initialized() else 1),
                 ms_per_iter_eager=round(dt_eager * 1e3, 3),
                 ms_per_iter_back_to_back=(round(ts_b2b * 1e3, 3) if graphed is True else None),
                 note='ms_per_iter: the iteration as HIP graph(s), the loss values read back after every iteration (median; MAX '
@@ -627,7 +627,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ranks_seen = 1
-    if world > 1:
+    if world > 1 or os.environ.get('LFD_BENCH_FORCE_DIST') == '1':      # (FORCE: the N > 1 code path through RCCL on one GPU)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl')        # RCCL on ROCm
         one = torch.ones(1, dtype=torch.int32, device=dev)
@@ -681,18 +681,18 @@ def main():
         for i in range(args.warmup):
             dets[i % NBUF] = step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             dets[i % NBUF] = step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -847,7 +847,12 @@ def main():
             result['cpu_baseline'] = cpu_baseline()
         else:
             result['cpu_baseline'] = None
-        print(json.dumps(result))
+        try:      # RCCL writes its banner through C stdio: push it out BEFORE the contract lines (it must not end the output)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
         # the driver keeps a 2 KB tail of stdout: the contract line once more, compact, LAST -- headline keys, `roofline`,
         # `cpu_baseline`, the serial / HIP-event figures and one-line summaries of the extra keys (everything is in the long
         # line above and in gpurun_out/bench_full.json)
@@ -856,8 +861,8 @@ def main():
             json.dump(result, open(os.path.join(ROOT, 'gpurun_out', 'bench_full.json'), 'w'))
         except Exception:
             pass
-        print(json.dumps(compact_line(result)))
-    if world > 1:
+        print(json.dumps(compact_line(result)), flush=True)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

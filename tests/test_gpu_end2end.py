@@ -18,10 +18,21 @@ pytestmark = pytest.mark.gpu
 # Unmatched detections (reference rows without a partner + rows of ours without one), gated at the count MEASURED on the MI355X
 # + 1 (round 4, gpurun_out/end2end_counts.json; rounds 1-3 allowed 10 % of the reference's rows).  A candidate whose score sits
 # within the fp16 forward's tolerance of the threshold can fall on the other side of it: that is what these counts are.
-_UNMATCHED_GATE = {'end_to_end/WIDERFACE_LFD_XS': 2,      # measured 1 of 43
-                   'end_to_end/WIDERFACE_LFD_S': 1,       # 0 of 21
-                   'config1/predict_py': 6,               # 5 of 1148 (thr 0.5 / IoU 0.3, predict.py:22)
-                   'config1/q90': 1}                      # 0 of 314
+# Matching is SURVEY 8d G4's: same class, IoU >= 0.99, |score difference| <= 2e-3.  Two modes: 'fp16' (the headline mode:
+# fp16 storage against the reference's fp32) and 'fp32_storage' (the mode inside north_star's tolerance: the reference's rows
+# must come back essentially row for row).
+_IOU, _DSCORE = 0.99, 2e-3
+# Unmatched detections (reference rows without a partner + rows of ours without one): gates = the counts MEASURED on the MI355X
+# (round 5, gpurun_out/end2end_counts.json) + 1 in 'fp16' mode -- a candidate whose score sits within the fp16 forward's
+# tolerance of the threshold can fall on the other side of it -- and the measured counts themselves, ZERO, in 'fp32_storage'.
+_UNMATCHED_GATE = {('end_to_end/WIDERFACE_LFD_XS', 'fp16'): 2,          # measured 1 of 43
+                   ('end_to_end/WIDERFACE_LFD_S', 'fp16'): 1,           # 0 of 21
+                   ('config1/predict_py', 'fp16'): 6,                   # 5 of 1148 (thr 0.5 / IoU 0.3, predict.py:22)
+                   ('config1/q90', 'fp16'): 1,                          # 0 of 314
+                   ('end_to_end/WIDERFACE_LFD_XS', 'fp32_storage'): 0,  # 0 of 43
+                   ('end_to_end/WIDERFACE_LFD_S', 'fp32_storage'): 0,   # 0 of 21
+                   ('config1/predict_py', 'fp32_storage'): 0,           # 0 of 1148 (VERDICT r4 asked <= 1)
+                   ('config1/q90', 'fp32_storage'): 0}                  # 0 of 314
 
 
 def _record(key, value):
@@ -45,12 +56,14 @@ def _iou(a, b):
     return w * h / u if u > 0 else 1.0
 
 
+@pytest.mark.parametrize('precision', ['fp16', 'fp32_storage'])
 @pytest.mark.parametrize('name', ['WIDERFACE_LFD_XS', 'WIDERFACE_LFD_S'])
-def test_end_to_end_detections_match_reference(name):
+def test_end_to_end_detections_match_reference(name, precision):
     g = load_golden('ref_model_%s.npz' % name)
     m = configs.build_model(name, seed=666)
     configs.perturb_weights(m, seed=1)
     m.eval().cuda()
+    m.precision = precision
     N, H, W = [int(v) for v in g['shape']]
     x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(int(g['x_seed']))) * 2 - 1
     m._classification_threshold = float(g['results_thr'])
@@ -67,22 +80,24 @@ def test_end_to_end_detections_match_reference(name):
             total += 1
             best = max(((i, _iou(r[2:], q[2:])) for i, q in enumerate(res[n]) if i not in used and q[0] == r[0]),
                        key=lambda t: t[1], default=(None, 0.0))
-            if best[0] is not None and best[1] >= 0.97 and abs(res[n][best[0]][1] - r[1]) <= 3e-3:
+            if best[0] is not None and best[1] >= _IOU and abs(res[n][best[0]][1] - r[1]) <= _DSCORE:
                 used.add(best[0])
             else:
                 unmatched += 1
         unmatched += len(res[n]) - len(used)
-    print('%s: %d reference detections, %d unmatched' % (name, total, unmatched))
-    _record('end_to_end/' + name, dict(reference_detections=total, unmatched=unmatched))
-    assert unmatched <= _UNMATCHED_GATE['end_to_end/' + name], (unmatched, total)
+    print('%s %s: %d reference detections, %d unmatched' % (name, precision, total, unmatched))
+    _record('end_to_end/%s/%s' % (name, precision), dict(reference_detections=total, unmatched=unmatched))
+    assert unmatched <= _UNMATCHED_GATE[('end_to_end/' + name, precision)], (unmatched, total)
 
 
+@pytest.mark.parametrize('precision', ['fp16', 'fp32_storage'])
 @pytest.mark.parametrize('tag', ['predict_py', 'q90'])
-def test_baseline_config1_predict_for_single_image_matches_the_reference(tag):
+def test_baseline_config1_predict_for_single_image_matches_the_reference(tag, precision):
     """BASELINE config 1: WIDERFACE_LFD_XS.predict_for_single_image on the seeded 640 x 480 uint8 frame against the
     rows the REAL reference's predict_for_single_image returned on its CPU path (tests/golden/make_golden_config1.py):
-    detections matched by class, IoU >= 0.97 and score within 3e-3 (fp16 storage against fp32); candidates whose score sits
-    within the forward tolerance of the threshold may differ -- counted and bounded."""
+    detections matched by class, IoU >= 0.99 and score within 2e-3.  In 'fp16' mode candidates whose score sits
+    within the forward tolerance of the threshold may differ -- counted and bounded; in 'fp32_storage' mode (lfd.py:544-655 at
+    the reference's precision) the reference's 1148 / 314 rows come back row for row."""
     g = load_golden('ref_config1_predict.npz')
     img = np.random.default_rng(0).integers(0, 256, (480, 640, 3)).astype(np.uint8)
 
@@ -91,20 +106,21 @@ def test_baseline_config1_predict_for_single_image_matches_the_reference(tag):
         return sample
     m = configs.build_model('WIDERFACE_LFD_XS', seed=666)
     configs.perturb_weights(m, seed=1)
+    m.precision = precision
     res = m.predict_for_single_image(img, aug, classification_threshold=float(g[tag + '/thr']), nms_threshold=float(g[tag + '/iou']))
     ref = json.loads(str(g[tag + '/results']))
     used, unmatched = set(), 0
     for r in ref:
         best = max(((i, _iou(r[2:], q[2:])) for i, q in enumerate(res) if i not in used and q[0] == r[0]),
                    key=lambda t: t[1], default=(None, 0.0))
-        if best[0] is not None and best[1] >= 0.97 and abs(res[best[0]][1] - r[1]) <= 3e-3:
+        if best[0] is not None and best[1] >= _IOU and abs(res[best[0]][1] - r[1]) <= _DSCORE:
             used.add(best[0])
         else:
             unmatched += 1
     unmatched += len(res) - len(used)
-    print('config 1 %s: %d reference detections, %d unmatched' % (tag, len(ref), unmatched))
-    _record('config1/' + tag, dict(reference_detections=len(ref), unmatched=unmatched))
-    assert unmatched <= _UNMATCHED_GATE['config1/' + tag], (unmatched, len(ref))
+    print('config 1 %s %s: %d reference detections, %d unmatched' % (tag, precision, len(ref), unmatched))
+    _record('config1/%s/%s' % (tag, precision), dict(reference_detections=len(ref), unmatched=unmatched))
+    assert unmatched <= _UNMATCHED_GATE[('config1/' + tag, precision)], (unmatched, len(ref))
 
 
 def test_predict_for_single_image_api():
@@ -150,8 +166,9 @@ def test_train_step_runs_and_decreases_loss():
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
-    """bench.py (the driver's entry point): exactly one JSON line on stdout with the contract's keys, the roofline object of
-    the dominant kernel and -- at N = 1 -- the CPU baseline and the bs-1 latency objects."""
+    """bench.py (the driver's entry point): the full JSON line with the contract's keys, the roofline object of the dominant
+    kernel and -- at N = 1 -- the CPU baseline and the bs-1 latency objects; then, LAST, the same contract line compacted to
+    < 2 KB (the driver keeps a 2 KB tail: headline keys, roofline, cpu_baseline, serial / HIP-event figures, summaries)."""
     import json
     import subprocess
     import sys
@@ -160,8 +177,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, lines
+    assert len(lines) == 2, lines
     d = json.loads(lines[0])
+    c2 = json.loads(lines[1])
+    assert len(lines[1]) < 2048
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data'):
+        assert c2[k] == d[k], k
+    assert c2['roofline']['frac'] == d['roofline']['frac'] and c2['cpu_baseline']['value'] == d['cpu_baseline']['value']
+    assert c2['ms_per_step_serial'] == d['ms_per_step_serial'] and c2['step_ms_hip_events']['median'] > 0
+    assert c2['precise']['images_per_s_bs8'] == d['precise']['images_per_s_bs8'] and c2['train']['ms_per_iter'] == d['train']['ms_per_iter']
+    assert 'workload' in c2['config'] and 'model' not in c2['config']
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'latency_bs1'):
         assert k in d, k
