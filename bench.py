@@ -537,7 +537,8 @@ def compact_line(r):
         if k in r:
             c[k] = {'frac': r[k].get('frac'), 'achieved': r[k].get('achieved')}
     cb = r.get('cpu_baseline')
-    c['cpu_baseline'] = None if not cb else {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+    c['cpu_baseline'] = None if not cb else {k: (cb.get(k)[:110] if k == 'sample' and cb.get(k) else cb.get(k))
+                                               for k in ('value', 'unit', 'cores', 'kind', 'sample')}
     p = r.get('precise') or {}
     c['precise'] = {k: p.get(k) for k in ('images_per_s_bs8', 'ms_per_step_bs8', 'pipeline_depth', 'images_per_s_bs8_serial',
                                           'ms_per_step_bs8_serial', 'end_to_end_bs1_ms', 'error') if k in p}

@@ -485,7 +485,11 @@ int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const 
     case 64 * 10000 + 3200 + 4: return launch_pl<64, 3, 2, 2, true>(a, outm, st);        // two cout groups (grid.y)
     case 64 * 10000 + 1100 + 4: return launch_pl<64, 1, 1, 4, true>(a, outm, st);        // neck 64 -> 128 (+ chained tower conv)
     // ---- 128-channel stages and the head
-    case 128 * 10000 + 3100 + 4: return launch_pl<128, 3, 1, 4, false, 1>(a, outm, st);   // (one 32-pixel MFMA tile per wave: small maps)
+    // (one 32-pixel MFMA tile per wave; small maps -- the 17 x 30 last stage -- as two cout groups of 64: twice the workgroups,
+    //  each streams half of the 2 x 295 KB filter)
+    case 128 * 10000 + 3100 + 4:
+      if ((long)a.N * a.OH * a.OW <= 16384) return launch_pl<128, 3, 1, 2, false, 1>(a, outm, st);
+      return launch_pl<128, 3, 1, 4, false, 1>(a, outm, st);
     case 128 * 10000 + 3200 + 4: return launch_pl<128, 3, 2, 4, false>(a, outm, st);
     case 128 * 10000 + 1100 + 4: return launch_pl<128, 1, 1, 4, true>(a, outm, st);
     case 128 * 10000 + 1100 + 1: return launch_pl<128, 1, 1, 1, true, 1>(a, outm, st);   // cls / reg outputs (<= 32 channels)

@@ -417,7 +417,8 @@ def test_graphed_step_survives_a_loss_scale_cycle_and_a_second_batch_shape():
         # the job tables / buffers of the first graph must not have been rebuilt in place
         b, pb = run(True)
         assert all(np.isfinite(v) for t in b for v in t)
-        assert abs(b[-1][0] - a[-1][0]) <= 0.05 * abs(a[-1][0]), (a, b)
+        # (the disturbed run made one extra update at it == 3: its entry k >= 3 is the undisturbed run's entry k + 1)
+        assert abs(b[-2][0] - a[-1][0]) <= 0.02 * abs(a[-1][0]), (a, b)
         # direct check of the mechanism: tables are kept per content, buffers per (key, size)
         m = configs.build_model(name).cuda().train()
         opt = optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
