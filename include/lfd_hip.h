@@ -518,9 +518,10 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  *     ds_w_packed     : second output ds_out = conv1x1 stride 2 (in) + ds_bias, no ReLU -- the identity branch of a stage's
  *                       first block (lfd_resnet.py:458-468) from the centre tap of a 3x3 stride-2 conv;
  *     residual        : y += residual (planes, same shape as out) before the ReLU (lfd_resnet.py:151-152);
- *   out_mode 0: planes out.  1: planes out + GroupNorm sums: gn_sums[(image * cout/8 + group) * 2 + {0,1}] += {sum, sum of
- *   squares} of the stored values of that 8-channel group as 64-bit two's-complement fixed point (2^-24 units) --
- *   order-independent atomics, so the statistics are bit-reproducible; the caller zeroes gn_sums per forward.  2: fp32
+ *   out_mode 0: planes out.  1: planes out + GroupNorm sums: gn_sums[((replica * n + image) * cout/8 + group) * 2 + {0,1}] +=
+ *   {sum, sum of squares} of the stored values of that 8-channel group as 64-bit two's-complement fixed point (2^-24
+ *   units), replica = workgroup % LFD_PL_GN_REPLICAS (LFD_PL_GN_REPLICAS * n * cout/8 * 2 words; consumers add the replicas)
+ *   -- order-independent integer atomics, so the statistics are bit-reproducible; the caller zeroes gn_sums per forward.  2: fp32
  *   outputs without planes: channel c < f_c0 -> f_out0[image * f_image_stride0 + pixel * f_c0 + c], f_c0 <= c < f_c0 + f_c1
  *   -> f_out1[image * f_image_stride1 + pixel * f_c1 + c - f_c0] * (*scale1) (lfd_head.py:176-183: cls / reg convs + Scale
  *   straight into the level-concatenated [N,P,C'] / [N,P,4] tensors, lfd.py:526-542).
@@ -532,6 +533,7 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  *   otherwise -- the host falls back to lfd_p32_*.  zeros: the 4 KB line of lfd_conv2d_nhwc_f16.
  * lfd_pl_groupnorm_relu: x (planes [n, hw, c]) <- relu?(GroupNorm(c/8 groups)(x) * gamma + beta) in place, mean / rstd in
  *   fp64 from gn_sums (lfd_head.py:97-117 conv -> GroupNorm -> ReLU). */
+#define LFD_PL_GN_REPLICAS 8   /* gn_sums holds this many replicas of [n][cout/8][2]: a producer spreads its atomics, consumers add */
 typedef struct lfd_pl_conv_desc {
   int32_t n, h, w, cin, cout, ks, stride, relu;
   int32_t tail_cout, tail_relu;

@@ -323,7 +323,11 @@ __global__ __launch_bounds__(256) void k_pl_gn_apply(_Float16* x, long plane, lo
   const int n = blockIdx.y, tid = threadIdx.x;
   const int ngrp = c >> 3;
   if (tid < ngrp) {
-    const long long s = (long long)acc[((size_t)n * ngrp + tid) * 2], q = (long long)acc[((size_t)n * ngrp + tid) * 2 + 1];
+    long long s = 0, q = 0;
+    for (int r = 0; r < kGnRep; ++r) {
+      s += (long long)acc[(((size_t)r * gridDim.y + n) * ngrp + tid) * 2];
+      q += (long long)acc[(((size_t)r * gridDim.y + n) * ngrp + tid) * 2 + 1];
+    }
     const double cnt = (double)hw * 8.0;
     const double m = (double)s / kGnFix / cnt;
     double var = (double)q / kGnFix / cnt - m * m;

@@ -31,6 +31,7 @@ namespace pl {
 
 constexpr float kLo = 2048.f, kInvLo = 1.f / 2048.f;
 constexpr double kGnFix = 16777216.0;   // 2^24: fixed-point scale of the GroupNorm sums
+constexpr int kGnRep = LFD_PL_GN_REPLICAS;   // replicas of the sums a producer spreads its atomics over (consumers add them up)
 
 struct PlArgs {
   const _Float16* in;      // hi plane [N,H,W,CIN]; the lo plane `in_plane` halfs behind it
@@ -105,7 +106,8 @@ struct PCfg {
   // RES: the residual tile (this workgroup's channel slice, both planes) arrives by DMA in copy-out order
   static constexpr int RES_OFF = BIAS_OFF + 3 * 128 * 4;
   static constexpr int RES_PLANE = RES ? OUT_PLANE : 0;
-  static constexpr int LDS_BYTES = RES_OFF + 2 * RES_PLANE;
+  static constexpr int GNR_OFF = RES_OFF + 2 * RES_PLANE;    // 1 KB: cross-wave reduction of the GroupNorm sums (OUTM 1)
+  static constexpr int LDS_BYTES = GNR_OFF + 1024;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 };
 
@@ -367,13 +369,31 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         s += __shfl_xor(s, d);
         q += __shfl_xor(q, d);
       }
-      if (lane < OCPP && gn_n >= 0) {
+      // the four waves through LDS, then ONE pair of atomics per group and workgroup, spread over kGnRep replicas of the
+      // sums (workgroup b -> replica b % kGnRep).  Every workgroup of a launch adds to the same 16 x 2 words per image:
+      // one pair per WAVE onto one replica measured 98 us for the 506-tile level of a single 1080p frame against 65 us
+      // for the same level of eight frames -- pure contention on 32 addresses.
+      double* red = reinterpret_cast<double*>(smem + C::GNR_OFF);       // [4 waves][OCPP][2]
+      static_assert(4 * OCPP * 2 * 8 <= 1024, "reduction scratch");
+      if (lane < OCPP) {
+        red[(wave * OCPP + lane) * 2] = s;
+        red[(wave * OCPP + lane) * 2 + 1] = q;
+      }
+      block_barrier();
+      if (wave == 0 && lane < OCPP && gn_n >= 0) {
+        double ts = 0., tq = 0.;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          ts += red[(w4 * OCPP + lane) * 2];
+          tq += red[(w4 * OCPP + lane) * 2 + 1];
+        }
         const int grp = cog * OCPP + lane;
         const int ngrp = (TAIL ? a.cout2 : a.cout) / 8;
-        unsigned long long* dst = a.gn_acc + ((size_t)gn_n * ngrp + grp) * 2;
-        atomicAdd(dst, (unsigned long long)__double2ll_rn(s * kGnFix));
-        atomicAdd(dst + 1, (unsigned long long)__double2ll_rn(q * kGnFix));
+        unsigned long long* dst = a.gn_acc + ((((size_t)(blockIdx.x % kGnRep)) * a.N + gn_n) * ngrp + grp) * 2;
+        atomicAdd(dst, (unsigned long long)__double2ll_rn(ts * kGnFix));
+        atomicAdd(dst + 1, (unsigned long long)__double2ll_rn(tq * kGnFix));
       }
+      block_barrier();
       gn_s = gn_q = 0.;
     }
   };
@@ -422,7 +442,12 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
       const int gc = (int)threadIdx.x & 15;
       if (n != gnin_n) {
         gnin_n = n;
-        const long long s = (long long)a.gnin_acc[((size_t)n * 16 + gc) * 2], q = (long long)a.gnin_acc[((size_t)n * 16 + gc) * 2 + 1];
+        long long s = 0, q = 0;
+#pragma unroll
+        for (int r = 0; r < kGnRep; ++r) {       // (integer adds: order-independent, the statistics stay bit-reproducible)
+          s += (long long)a.gnin_acc[(((size_t)r * a.N + n) * 16 + gc) * 2];
+          q += (long long)a.gnin_acc[(((size_t)r * a.N + n) * 16 + gc) * 2 + 1];
+        }
         const double cnt = (double)a.H * (double)a.W * 8.0;
         const double m = (double)s / kGnFix / cnt;
         double var = (double)q / kGnFix / cnt - m * m;

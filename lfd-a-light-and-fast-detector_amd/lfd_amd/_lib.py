@@ -98,6 +98,7 @@ class PlConvDesc(C.Structure):
                 ('f_image_stride1', C.c_int64)]
 
 
+PL_GN_REPLICAS = 8                      # LFD_PL_GN_REPLICAS
 ABI_VERSION = 3                         # LFD_HIP_ABI_VERSION
 HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS
 HEAD_TOWER1_GROUP_HALFS = 8 * 64 * 8    # LFD_HEAD_TOWER1_GROUP_HALFS

@@ -393,6 +393,6 @@ class _State(object):
             self.P = p
             self.cls = torch.empty((n, p, plan.cls_channels), dtype=torch.float32, device=dev)
             self.reg = torch.empty((n, p, 4), dtype=torch.float32, device=dev)
-            self.gn_sums = torch.zeros((max(plan.num_gn, 1), n, 16, 2), dtype=torch.int64, device=dev)
+            self.gn_sums = torch.zeros((max(plan.num_gn, 1), _lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device=dev)
             self.side = torch.cuda.Stream(device=dev)
         self.graph = {}

@@ -135,7 +135,7 @@ def test_pl_conv_chained_1x1_vs_float64(cin, c, ks, stride, n, h, w):
     # the intermediate is split into planes on its way to the second contraction: reference on the same values
     midv = engine_p2.from_planes(engine_p2.to_planes(mid.float())).double()
     ref = _ref_conv(midv, w2, b2, 1, 1, relu2)
-    gn = torch.zeros((n, c // 8, 2), dtype=torch.int64, device='cuda') if ks == 1 else None
+    gn = torch.zeros((_lib.PL_GN_REPLICAS, n, c // 8, 2), dtype=torch.int64, device='cuda') if ks == 1 else None
     got, _ = _pl_conv(xp, wt, b, ks, stride, True, tail=(w2, b2, relu2), gn=gn)
     err_mid = float((mid - midv).abs().max())
     _close(got, ref, 'chained %d->%d->%d k%d (split of the intermediate %.1e)' % (cin, c, c, ks, err_mid))
@@ -149,7 +149,7 @@ def _check_sums(gn, planes):
     vg = v.reshape(n, -1, c // 8, 8)
     s, q = vg.sum((1, 3)), (vg * vg).sum((1, 3))
     sabs = float(vg.abs().sum((1, 3)).max())
-    got = gn.cpu().double() / 2.0 ** 24
+    got = gn.cpu().sum(0).double() / 2.0 ** 24          # (the replicas a launch spreads its atomics over)
     assert float((got[..., 0] - s).abs().max()) <= 2e-6 * sabs + 1e-5
     assert float((got[..., 1] - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-5
 
@@ -159,7 +159,7 @@ def test_pl_tower_conv_sums_and_groupnorm_vs_float64(n, h, w):
     """conv1x1 128 -> 128 with GroupNorm sums, then GroupNorm(16, 128) + ReLU in place (lfd_head.py:97-117)"""
     g, xp, xv, wt, b = _inputs(3 + h, n, h, w, 128, 128, 1)
     gamma, beta = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
-    sums = torch.zeros((n, 16, 2), dtype=torch.int64, device='cuda')
+    sums = torch.zeros((_lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device='cuda')
     got, _ = _pl_conv(xp, wt, b, 1, 1, False, gn=sums)
     _close(got, _ref_conv(xv, wt, b, 1, 1, False), 'tower conv')
     _check_sums(sums, got)

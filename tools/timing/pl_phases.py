@@ -26,7 +26,7 @@ def case(tag, n, h, w, cin, cout, ks, stride, res=False, tail=False, ds=False, g
     if res: rp = engine_p2.to_planes(torch.randn(n, oh, ow, cout, generator=g)).cuda(); d.res_plane_halfs = rp[0].numel()
     if tail: tw = engine_p2.pack_planes_weight(torch.randn(cout, cout, 1, 1, generator=g) * 0.1).cuda(); d.tail_cout = cout; d.tail_relu = 1
     if ds: dw = engine_p2.pack_planes_weight(torch.randn(cout, cin, 1, 1, generator=g) * 0.1).cuda(); dsd = torch.empty_like(out); d.ds_plane_halfs = out[0].numel()
-    if gn: gs = torch.zeros((n, 16, 2), dtype=torch.int64, device=dev)
+    if gn: gs = torch.zeros((8, n, 16, 2), dtype=torch.int64, device=dev)
     def run():
         check(L.lfd_pl_conv2d(C.byref(d), ptr(xp), ptr(out), ptr(wp), ptr(b), ptr(rp), ptr(tw), ptr(b) if tail else None, ptr(dw), ptr(b) if ds else None,
                               ptr(dsd), ptr(gs), None, None, None, None, None, None, ptr(z), stream_ptr()), tag)
