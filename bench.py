@@ -458,10 +458,10 @@ def stress_and_small_frame_bench(model, x, meta, dev, cls):
     return out
 
 
-def precise_bench(model, x, meta, dev, steps=40):
+def precise_bench(model, x, meta, dev, steps=40, depth=int(os.environ.get('LFD_PRECISE_DEPTH', '2'))):
     """The shipped tolerance-compliant precision mode (LFD.precision = 'fp32_storage': raw logits within 1e-4 of the fp32
     reference, tests/test_gpu_precise.py) on the headline workload, measured like the headline: the whole step one HIP graph,
-    two batches in flight on two HIP streams with their own buffers (wall clock over `steps` steps), next to the strictly
+    `depth` (2) batches in flight on as many HIP streams with their own buffers (wall clock over `steps` steps), next to the strictly
     serial HIP-event median and the bs-1 end-to-end latency."""
     out = {}
     keep_g = model.use_graph
@@ -470,17 +470,17 @@ def precise_bench(model, x, meta, dev, steps=40):
         model.use_graph = True
         ms = _event_median_ms(lambda: model.detect_resident(x, meta), 10, warm=2)
         # two batches in flight (distinct frame buffers, buffer slots 0 / 1), as the fp16 headline runs
-        xs = [x, x.clone()]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        xs = [x] + [x.clone() for _ in range(depth - 1)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 
         def step(i):
-            with torch.cuda.stream(streams[i % 2]):
-                return model.detect_resident(xs[i % 2], meta, slot=i % 2)
+            with torch.cuda.stream(streams[i % depth]):
+                return model.detect_resident(xs[i % depth], meta, slot=i % depth)
         torch.cuda.synchronize()
-        ref = [step(0), step(1)]
+        ref = [step(b) for b in range(depth)]
         torch.cuda.synchronize()
         snap = [(o.counts.clone(), o.dets.clone()) for o in ref]
-        for i in range(6):
+        for i in range(3 * depth):
             step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -488,7 +488,7 @@ def precise_bench(model, x, meta, dev, steps=40):
             step(i)
         torch.cuda.synchronize()
         ms_pipe = (time.perf_counter() - t0) / steps * 1e3
-        for b in range(2):      # overlapped steps == the same step alone
+        for b in range(depth):      # overlapped steps == the same step alone
             o = step(b)
             torch.cuda.synchronize()
             assert torch.equal(o.counts, snap[b][0]) and torch.equal(o.dets, snap[b][1]), 'overlapped precise steps disagree'
@@ -511,7 +511,7 @@ def precise_bench(model, x, meta, dev, steps=40):
                         "GroupNorm from order-independent fixed-point sums (csrc/planes.hip, planes_c3.hip)" if planes else
                         "LFD.precision = 'fp32_storage': fp32 NHWC tensors, one launch per conv (csrc/precise.hip)",
                    ms_per_step_bs8=round(ms_pipe, 4), images_per_s_bs8=round(x.size(0) / ms_pipe * 1e3, 1),
-                   pipeline_depth=2, ms_per_step_bs8_serial=round(ms, 4), images_per_s_bs8_serial=round(x.size(0) / ms * 1e3, 1),
+                   pipeline_depth=depth, ms_per_step_bs8_serial=round(ms, 4), images_per_s_bs8_serial=round(x.size(0) / ms * 1e3, 1),
                    end_to_end_bs1_ms={'p50': round(float(ts[len(ts) // 2]), 4), 'min': round(float(ts[0]), 4)},
                    mfma_tflops_issued=round(3 * 348.8 / ms_pipe, 1),
                    parity='raw logits <= 1e-4, sigma <= 1e-3 vs the fp32 oracle at configs 2 / 3 / 4 (tests/test_gpu_precise.py)')
