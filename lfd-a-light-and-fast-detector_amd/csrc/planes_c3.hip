@@ -3,17 +3,8 @@
 // epilogues read them with VALU right away); here the epilogue pieces run in the shadow of the next tile's MFMAs, the two
 // accumulator sets belong in AccVGPRs and the 256 architectural VGPRs to the operand ring and the pieces.
 #include "planes_impl.h"
-#include <utility>
 
 namespace pl {
-
-// compile-time k loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) -- every piece condition
-// and every register index of the contraction is a constant by construction (an `#pragma unroll` the optimiser declines
-// leaves the 288 weight registers dynamically indexed, i.e. in scratch)
-template <class F, int... Ks>
-__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Ks...>) {
-  (f(std::integral_constant<int, Ks>{}), ...);
-}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_pl_c3: the 3x3 stride-1 64-channel conv (+ residual) of the residual blocks (lfd_resnet.py:96-154) -- 13 of the 18 launches

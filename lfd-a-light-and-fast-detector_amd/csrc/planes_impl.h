@@ -22,12 +22,21 @@
 //     fixed-point atomics, fp32 outputs for the cls / reg convs (+ Scale, lfd_head.py:180-183).
 #pragma once
 #include "common.h"
+#include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace pl {
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) -- every piece condition and
+// every register index of an unrolled contraction is a constant by construction (an `#pragma unroll` the optimiser declines
+// leaves the weight registers dynamically indexed, i.e. in scratch)
+template <class F, int... Ks>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Ks...>) {
+  (f(std::integral_constant<int, Ks>{}), ...);
+}
 
 constexpr float kLo = 2048.f, kInvLo = 1.f / 2048.f;
 constexpr double kGnFix = 16777216.0;   // 2^24: fixed-point scale of the GroupNorm sums
@@ -261,6 +270,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
   };
   // tile-level scalars of the tile being fetched
   int d_n = 0, d_gy0 = 0, d_gx0 = 0;
+  bool d_interior = false;
   char* d_lbase = smem;
   auto dma_setup = [&](int t, int buf) {
     d_n = t / tiles_per_img;
@@ -269,6 +279,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
     d_gy0 = ty0 * C::TH * S - C::PAD;
     d_gx0 = tx0 * C::TW * S - C::PAD;
     d_lbase = smem + buf * 2 * C::IN_BYTES;
+    d_interior = d_gy0 >= 0 && d_gx0 >= 0 && d_gy0 + C::IH <= a.H && d_gx0 + C::IW <= a.W;
   };
   auto dma_piece = [&](int p) {
     if constexpr (FAST) {
@@ -304,6 +315,18 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         const int c = cs ^ ((rem / C::PPR) % C::CPP);
         const int gy = d_gy0 + iy, gx = d_gx0 + ix;
         const bool needed = rem < C::IWs && ix < C::IW;
+        if (d_interior) {
+          // every halo pixel inside the image (all but the border tiles): wave-uniform row base in SGPRs + a 32-bit lane
+          // offset -- no per-lane 64-bit address, no validity selects at the issue site
+          if (8 * j + 8 <= C::IWs || needed) {
+            const char* rb = reinterpret_cast<const char*>(a.in) + ((long)d_n * a.H + gy) * f_rowpitch + (long)d_gx0 * (CIN * 2);
+            const unsigned vo = (unsigned)(ix * (CIN * 2) + c * 16);
+            char* ld = d_lbase + (iy * C::IWs + 8 * j) * C::PIXB;
+            dma16s(rb, vo, ld);
+            dma16s(rb + in_plane_b, vo, ld + C::IN_BYTES);
+          }
+          return;
+        }
         const bool ok = needed && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const char* src = reinterpret_cast<const char*>(a.in) + ((long)d_n * a.H + (ok ? gy : 0)) * f_rowpitch + (long)(ok ? gx : 0) * (CIN * 2) + c * 16;
         if (8 * j + 8 <= C::IWs || needed)
@@ -533,16 +556,17 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
           xql[k][pt] = *reinterpret_cast<const half8*>(p + C::IN_BYTES);
         }
       }
-#pragma unroll
-      for (int k = 0; k < C::NK; ++k) {
+      static_for([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
         if constexpr (DMA_IN_LOOP) {
           if (has_next) {
-#pragma unroll
-            for (int p = 0; p < NPIECE; ++p)
-              if ((p * SPREAD) / NPIECE == k) dma_piece(p);
+            static_for([&](auto pc) {
+              constexpr int p = decltype(pc)::value;
+              if constexpr ((p * SPREAD) / NPIECE == k) dma_piece(p);
+            }, std::make_integer_sequence<int, NPIECE>{});
           }
         }
-        if (k + PD < C::NK) {
+        if constexpr (k + PD < C::NK) {
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) {
             const char* p = xaddr(k + PD, pt);
@@ -558,7 +582,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xqh[k % (PD + 1)][pt], accc[pt], 0, 0, 0);
         if constexpr (DS) {
-          if (k / C::NQ == 4) {     // centre tap = the 1x1 stride-2 branch's input pixel (lfd_resnet.py:458-468)
+          if constexpr (k / C::NQ == 4) {     // centre tap = the 1x1 stride-2 branch's input pixel (lfd_resnet.py:458-468)
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
               adm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdh[k % C::NQ], xqh[k % (PD + 1)][pt], adm[pt], 0, 0, 0);
@@ -568,7 +592,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
           }
         }
         PL_SB();
-      }
+      }, std::make_integer_sequence<int, C::NK>{});
     } else {
       // weights streamed from L2 (128-channel 3x3 layers on the small last-stage maps): a ring of PW (hi, lo) fragment pairs
       constexpr int RK = KS * C::NQ;
