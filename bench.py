@@ -458,6 +458,76 @@ def stress_and_small_frame_bench(model, x, meta, dev, cls):
     return out
 
 
+def precise_breakdown(model, x, dev, reps=20):
+    """Per-launch HIP-event times of the planes plan (eager, one launch at a time on the current stream), grouped by kernel
+    class, with the ALGORITHMIC conv FLOPs (2 MAC; the hi/lo products are an implementation detail: x3 issued) and bytes
+    (both planes of every tensor read / written once) -> roofline entries of the tolerance-compliant mode."""
+    from lfd_amd import engine, engine_p2, engine_p32
+    plan = engine_p32.get_plan(model, x.device)
+    if not isinstance(plan, engine_p2.PlanesPlan):
+        return None
+    fmt, n, h, w = engine._input_format(x)
+    st = plan.state_for(n, h, w, 0)
+    plan.run(x, fmt, st)
+    torch.cuda.synchronize()
+    groups = {}
+    for i, o in enumerate(plan.ops):
+        if o.kind == 'stem':
+            oh, ow = st.dims[o.dst]
+            c = o.channels
+            fl = 2.0 * n * oh * ow * (27 * c + c * c)
+            by = x.numel() * x.element_size() + 4.0 * n * oh * ow * c
+            key = 'stem pair 1: conv3x3 s2 (3->%d) + conv1x1 (k_pl_stem)' % c
+        else:
+            src = st.bufs[o.src]
+            ih, iw = src.shape[2], src.shape[3]
+            oh, ow = (ih + o.stride - 1) // o.stride, (iw + o.stride - 1) // o.stride
+            fl = 2.0 * n * oh * ow * o.cin * o.cout * o.ks * o.ks
+            by = 4.0 * n * ih * iw * o.cin
+            if o.tail is not None:
+                fl += 2.0 * n * oh * ow * o.cout * o.cout
+            if o.ds is not None:
+                fl += 2.0 * n * oh * ow * o.cin * o.cout
+                by += 4.0 * n * oh * ow * o.cout
+            if o.res is not None:
+                by += 4.0 * n * oh * ow * o.cout
+            by += 4.0 * n * oh * ow * (o.cout if o.out_mode != 2 else o.f_c0 + o.f_c1)
+            if o.ks == 3 and o.stride == 1 and o.cin == 64:
+                key = 'conv3x3 s1 64->64 (+ residual) (k_pl_c3)'
+            elif o.ks == 3 and o.stride == 2 and o.tail is not None:
+                key = 'stem pair 2: conv3x3 s2 + conv1x1 (k_pl_conv<64,3,2,TAIL>)'
+            elif o.ks == 3 and o.stride == 2:
+                key = 'stage entry: conv3x3 s2 + 1x1 s2 identity branch (k_pl_conv<.,3,2,DS>)'
+            elif o.ks == 3:
+                key = 'conv3x3 s1 128->128 (k_pl_conv<128,3,1>)'
+            else:
+                key = 'neck + head 1x1 convs, GroupNorm in the consumer (k_pl_conv<.,1,1>)'
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record()
+            plan._launch(x, fmt, st, [i])
+            e1.record()
+        torch.cuda.synchronize()
+        us = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
+        g = groups.setdefault(key, dict(launches=0, time_us=0.0, flops=0.0, bytes=0.0))
+        g['launches'] += 1
+        g['time_us'] += us
+        g['flops'] += fl
+        g['bytes'] += by
+    rows = []
+    for key, g in sorted(groups.items(), key=lambda kv: -kv[1]['time_us']):
+        tf, gbs = g['flops'] / g['time_us'] / 1e6, g['bytes'] / g['time_us'] / 1e3
+        bound = 'mfma' if 3 * tf / MFMA_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS else 'hbm'      # (what the matrix pipe ISSUES decides the bound)
+        rows.append(dict(kernel=key, launches=g['launches'], time_us_per_forward=round(g['time_us'], 1),
+                         avg_launch_us=round(g['time_us'] / g['launches'], 2), bound=bound,
+                         achieved=round(tf if bound == 'mfma' else gbs, 1), peak=MFMA_PEAK_TFLOPS if bound == 'mfma' else HBM_PEAK_GBS,
+                         unit='TFLOP/s' if bound == 'mfma' else 'GB/s',
+                         frac=round(tf / MFMA_PEAK_TFLOPS if bound == 'mfma' else gbs / HBM_PEAK_GBS, 3),
+                         tflops_algorithmic=round(tf, 1), tflops_issued=round(3 * tf, 1), frac_mfma_issued=round(3 * tf / MFMA_PEAK_TFLOPS, 3),
+                         gbs=round(gbs, 0), frac_hbm=round(gbs / HBM_PEAK_GBS, 3)))
+    return rows
+
+
 def precise_bench(model, x, meta, dev, steps=40, depth=int(os.environ.get('LFD_PRECISE_DEPTH', '2'))):
     """The shipped tolerance-compliant precision mode (LFD.precision = 'fp32_storage': raw logits within 1e-4 of the fp32
     reference, tests/test_gpu_precise.py) on the headline workload, measured like the headline: the whole step one HIP graph,
@@ -514,7 +584,18 @@ def precise_bench(model, x, meta, dev, steps=40, depth=int(os.environ.get('LFD_P
                    pipeline_depth=depth, ms_per_step_bs8_serial=round(ms, 4), images_per_s_bs8_serial=round(x.size(0) / ms * 1e3, 1),
                    end_to_end_bs1_ms={'p50': round(float(ts[len(ts) // 2]), 4), 'min': round(float(ts[0]), 4)},
                    mfma_tflops_issued=round(3 * 348.8 / ms_pipe, 1),
-                   parity='raw logits <= 1e-4, sigma <= 1e-3 vs the fp32 oracle at configs 2 / 3 / 4 (tests/test_gpu_precise.py)')
+                   parity='raw logits <= 1e-4, sigma <= 1e-3 vs the fp32 oracle at configs 2 / 3 / 4 (tests/test_gpu_precise.py); the '
+                          "reference's config-1 end-to-end rows (1148 / 314) reproduced with 0 unmatched (tests/test_gpu_end2end.py)")
+        try:
+            rows = precise_breakdown(model, x, dev)
+            if rows:
+                out['kernels'] = rows
+                out['roofline'] = {k: rows[0][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us')}
+                out['roofline']['traffic'] = None
+                out['roofline']['note'] = ('dominant kernel class of this mode; ALGORITHMIC flops / bytes over the live HIP-event '
+                                           'duration (the three hi/lo MFMA products per k-step issue 3 x the algorithmic flops)')
+        except Exception as e:
+            out['kernels'] = {'error': repr(e)}
     finally:
         model.precision = 'fp16'
         model.use_graph = keep_g

@@ -103,9 +103,10 @@ class LFD(nn.Module):
         """Numeric mode of the eval-mode forward (training is unaffected):
         'fp16'          fp16 MFMA operands and fp16 inter-layer storage, fp32 accumulation -- the fused stem / block / head
                         kernels of engine.py; sigma(cls) / sigma(reg) within 1.3e-3 .. 2.3e-3 of the fp32 reference;
-        'fp32_storage'  fp32 inter-layer storage, every conv ONE launch that splits its fp32 operands exactly into fp16
-                        hi + lo parts for the matrix cores (engine_p32.py, csrc/precise.hip); raw logits within 1e-4 of
-                        the fp32 reference (north_star: "tensors within 1e-3"), ~3-5x the time."""
+        'fp32_storage'  every inter-layer tensor as fp16 hi + 2^-11 lo planes (the bytes of fp32), weights split the same
+                        way, three MFMAs per k-step, fp32 accumulation and epilogues (engine_p2.py, csrc/planes*.hip;
+                        engine_p32.py / csrc/precise.hip for layer shapes without a plane kernel); raw logits within 1e-4
+                        of the fp32 reference (north_star: "tensors within 1e-3"; measured 8e-6), ~3.5x the time."""
         return self.__dict__.get('_precision', 'fp16')
 
     @precision.setter

@@ -743,3 +743,63 @@ def test_precise_plan_covers_every_named_configuration(name):
         assert o.b.dtype == torch.float32 and o.b.numel() == ns * 32
         assert o.patch == (o.src == 'input')
     assert len(plan.taps) == nl
+
+
+def test_planes_weight_packing_and_plane_round_trip():
+    """engine_p2 (host side of the hi/lo-plane kernels, csrc/planes.hip): pack_planes_weight = ops.pack_conv_weight order per
+    plane, rows zero-padded to 32; hi + lo / 2^11 restores the fp32 weight to ~2^-22; to_planes / from_planes likewise."""
+    from lfd_amd import engine_p2, ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(40, 64, 3, 3, generator=g) * torch.logspace(-4, 1, 40)[:, None, None, None]
+    pk = engine_p2.pack_planes_weight(w)
+    assert pk.shape == (2, 2, 36, 64, 8) and pk.dtype == torch.float16
+    wp = torch.cat([w, torch.zeros(24, 64, 3, 3)], 0)
+    hi = wp.half()
+    assert torch.equal(pk[0], ops.pack_conv_weight(hi)) and torch.equal(pk[1], ops.pack_conv_weight(((wp - hi.float()) * 2048).half()))
+    rec = pk[0].float() + pk[1].float() / 2048.0           # [slab, kstep = (tap, q), lane = 32 half + cout, j]
+    for (co, ci, dy, dx) in [(0, 0, 0, 0), (39, 63, 2, 2), (33, 17, 1, 2)]:
+        got = float(rec[co // 32, (dy * 3 + dx) * 4 + ci // 16, ((ci % 16) // 8) * 32 + co % 32, ci % 8])
+        assert abs(got - float(w[co, ci, dy, dx])) <= 2.0 ** -21 * abs(float(w[co, ci, dy, dx])) + 1e-10
+    x = torch.randn(2, 5, 7, 32, generator=g) * torch.logspace(-3, 2, 32)
+    p = engine_p2.to_planes(x)
+    assert p.shape == (2, 2, 5, 7, 32) and p.dtype == torch.float16
+    assert float(((engine_p2.from_planes(p) - x).abs() / x.abs().clamp_min(1e-3)).max()) <= 2.0 ** -21
+    ws = engine_p2.pack_planes_stem_weight(torch.randn(64, 3, 3, 3, generator=g))
+    assert ws.shape == (2, 2, 2, 64, 8)
+
+
+@pytest.mark.parametrize('name', sorted(configs.ARCHS))
+def test_planes_plan_covers_the_shipped_configurations(name):
+    """engine_p2.PlanesPlan built on CPU tensors: every WIDERFACE / TT100K configuration gets the plane plan (TL_*: 3x3 head
+    towers -> `Unsupported` -> the fp32-tensor plan of engine_p32); every conv it schedules has an instance in lfd_pl_conv2d's
+    dispatch (engine_p2._DISPATCH mirrors csrc/planes.hip); three launches per pyramid level with merged towers, the consumer
+    of every tower conv carries its GroupNorm; launch ranges for the optional side-stream fork."""
+    from lfd_amd import engine_p2, engine_p32
+    m = configs.build_model(name).eval()
+    if name.startswith('TL_'):
+        with pytest.raises(engine_p2.Unsupported):
+            engine_p2.PlanesPlan(m, torch.device('cpu'))
+        assert isinstance(engine_p32.get_plan(m, torch.device('cpu')), engine_p32.PrecisePlan)
+        return
+    plan = engine_p2.PlanesPlan(m, torch.device('cpu'))
+    assert isinstance(engine_p32.get_plan(m, torch.device('cpu')), engine_p2.PlanesPlan)
+    head = m._head
+    nl = head._num_heads
+    convs = [o for o in plan.ops if o.kind == 'conv']
+    assert plan.ops[0].kind == 'stem' and len(plan.level_ops) == nl and len(plan.tap_ready) == nl
+    for o in convs:
+        opts = engine_p2._DISPATCH[(o.cin, o.ks, o.stride, -(-o.cout // 32))]
+        used = {k for k, v in (('tail', o.tail), ('ds', o.ds), ('res', o.res), ('out32', o.out_mode == 2)) if v not in (None, False)}
+        assert used <= opts and (o.gn is None or 'gn' in opts)
+        assert o.w.shape[0] == 2 and o.w.dtype == torch.float16 and o.b.numel() % 128 == 0
+    towers = 1 if head._merge_path_flag else 2
+    gn_convs = [o for o in convs if o.gn is not None]
+    assert len(gn_convs) == plan.num_gn == nl * towers * head._num_conv_layers
+    assert sum(o.gnin is not None for o in convs) == plan.num_gn          # every set of sums has exactly one consumer
+    outs = [o for o in convs if o.out_mode == 2]
+    assert len(outs) == nl * towers and sorted({o.level for o in outs}) == list(range(nl))
+    for a, b in plan.level_ops:
+        assert b - a == (3 if head._merge_path_flag else 1 + 2 * head._num_conv_layers + 2)
+    # the stage entries carry their identity branch, the closing conv of every block its residual
+    assert sum(o.ds is not None for o in convs) == sum(1 for i in range(len(m._backbone._body_architecture)))
+    assert sum(o.res is not None for o in convs) == sum(m._backbone._body_architecture)
