@@ -161,11 +161,18 @@ __device__ __forceinline__ void block_barrier() {
 //  to v_mul + v_fma_mix{lo,hi}_f16 per element instead of cvt-back + sub + mul + cvt)
 __device__ __forceinline__ void split2(float y0, float y1, uint32_t& hi, uint32_t& lo) {
   lfd_f32x2 f; f[0] = y0; f[1] = y1;
-  union { lfd_f16x2 v; uint32_t u; } h, l;
+  union { lfd_f16x2 v; uint32_t u; } h;
   h.v = __builtin_convertvector(f, lfd_f16x2);
-  l.v[0] = (_Float16)fmaf((float)h.v[0], -kLo, y0 * kLo);
-  l.v[1] = (_Float16)fmaf((float)h.v[1], -kLo, y1 * kLo);
-  hi = h.u; lo = l.u;
+  const lfd_f32x2 sc = f * kLo;
+  // lo halves straight out of the mixed-precision FMA (fp16 hi x fp32 -2048 + fp32 2048 y, rounded to fp16 into the low /
+  // high half of one register): 4 instructions per pair -- v_cvt_pk, v_pk_mul, v_fma_mixlo, v_fma_mixhi.  Left to the
+  // compiler the same expression became cvt-back x 2 + fmamk x 2 + cvt_pk (7 per pair); the splits are most of the VALU
+  // work of every epilogue of this file.
+  uint32_t l;
+  const float m = -kLo;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h.u), "v"(m), "v"(sc[0]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h.u), "v"(m), "v"(sc[1]));
+  hi = h.u; lo = l;
 }
 
 // hi + 2^-11 lo: one v_fma_mix_f32 on the fp16 operands (2^-11 lo is exact, the sum rounds once)
