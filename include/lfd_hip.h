@@ -531,6 +531,11 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  *   (lfd_head.py:97-117) without a pass over the tensor.
  *   Supported shapes: the layers of every named configuration (see the dispatch in csrc/planes.hip); LFD_ERR_UNSUPPORTED
  *   otherwise -- the host falls back to lfd_p32_*.  zeros: the 4 KB line of lfd_conv2d_nhwc_f16.
+ * lfd_pl_conv2d_levels: the same 1x1 conv (desc: n, cin, cout, relu, tail_cout / tail_relu, out_mode, f_c0 / f_c1,
+ *   f_image_stride0 / 1, gn_in_eps; ks = stride = 1; desc->h / w / *_plane_halfs unused) over num_levels <= LFD_MAX_LEVELS
+ *   feature maps in ONE launch -- simple_neck.py:67-74 + lfd_head.py:164-185 apply the same conv stack to every pyramid
+ *   level, each level with its own filters; levels[i] carries what lfd_pl_conv2d takes per call.  Results are identical to
+ *   num_levels lfd_pl_conv2d calls (same arithmetic per tile; the GroupNorm sums are order-independent integers).
  * lfd_pl_groupnorm_relu: x (planes [n, hw, c]) <- relu?(GroupNorm(c/8 groups)(x) * gamma + beta) in place, mean / rstd in
  *   fp64 from gn_sums (lfd_head.py:97-117 conv -> GroupNorm -> ReLU). */
 #define LFD_PL_GN_REPLICAS 8   /* gn_sums holds this many replicas of [n][cout/8][2]: a producer spreads its atomics, consumers add */
@@ -551,6 +556,25 @@ LFD_API int lfd_pl_conv2d(const lfd_pl_conv_desc_t* desc, const void* in, void* 
                           const float* ds_bias, void* ds_out, void* gn_sums, float* f_out0, float* f_out1, const float* scale1,
                           const void* gn_in_sums, const float* gn_in_gamma, const float* gn_in_beta, const void* zeros,
                           lfd_stream_t stream);
+typedef struct lfd_pl_level {
+  const void* in;                 /* planes [n, h, w, cin] */
+  void* out;                      /* planes [n, h, w, cout] (out_mode 0 | 1) */
+  const void* w_packed;
+  const float* bias;
+  const void* tail_w_packed;      /* desc->tail_cout > 0 */
+  const float* tail_bias;
+  void* gn_sums;                  /* out_mode 1 */
+  const void* gn_in_sums;         /* all levels or none */
+  const float* gn_in_gamma;
+  const float* gn_in_beta;
+  float* f_out0;                  /* out_mode 2 */
+  float* f_out1;
+  const float* scale1;
+  int32_t h, w;
+  int64_t in_plane_halfs, out_plane_halfs;
+} lfd_pl_level_t;
+LFD_API int lfd_pl_conv2d_levels(const lfd_pl_conv_desc_t* desc, const lfd_pl_level_t* levels, int32_t num_levels,
+                                 const void* zeros, lfd_stream_t stream);
 LFD_API int lfd_pl_groupnorm_relu(void* x, int64_t plane_halfs, int32_t n, int64_t hw, int32_t c, const void* gn_sums,
                                   const float* gamma, const float* beta, float eps, int32_t relu, lfd_stream_t stream);
 

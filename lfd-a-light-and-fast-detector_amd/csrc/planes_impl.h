@@ -78,6 +78,30 @@ struct PlArgs {
   float gnin_eps;
 };
 
+// One pyramid level of a MULTI-LEVEL launch (ML: the 1x1 convs of the neck / head over all levels' tiles in one persistent grid --
+// the small levels' launches are pure latency: 12 of them took 159 us for a third of the first level's work)
+struct PlLevel {
+  const _Float16* in;
+  _Float16* out;
+  const half8* w;          // every level has its own filters (lfd_head.py:88-139: head%d_* modules) and GroupNorm affine
+  const float* bias;
+  const half8* w2;
+  const float* bias2;
+  const float* gnin_gamma;
+  const float* gnin_beta;
+  unsigned long long* gn_acc;
+  const unsigned long long* gnin_acc;
+  float* f_out0;
+  float* f_out1;
+  const float* scale1;
+  long in_plane, out_plane;
+  int H, W, tiles_x, tiles_y, tile_start, pad_;
+};
+struct PlLevels {
+  PlLevel lv[LFD_MAX_LEVELS];
+  int n;
+};
+
 // PTO: 32-pixel MFMA tiles per wave (0: 2 for stride 1, 1 for stride 2)
 template <int CIN, int KS, int S, int NCT, bool TAIL, bool RES, int PTO>
 struct PCfg {
@@ -181,8 +205,10 @@ __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return fmaf((
 __device__ __forceinline__ float comb(float m, float c) { return fmaf(c, kInvLo, m); }
 
 // OUTM: 0 = planes, 1 = planes + GroupNorm sums (groups of 8 channels), 2 = fp32 outputs (cls / reg)
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN>
-__device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN, bool ML = false>
+__device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, char* smem) {
+  static_assert(!ML || (KS == 1 && S == 1 && WREG && !RES && !DS), "multi-level launches: the 1x1 convs of the neck / head");
+  PlArgs a = a0;            // (ML: the per-level fields are switched when the tile walk enters another level)
   static_assert(!GNIN || (KS == 1 && S == 1 && CIN == 128 && !TAIL && !RES && !DS), "GNIN: a 1x1 conv on a 128-channel GroupNorm(16) input");
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES && OUTM == 0), "DS rides on a 3x3 stride-2 conv");
   static_assert(!TAIL || (!RES && !DS), "TAIL: conv -> 1x1 in one launch");
@@ -256,8 +282,26 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
   const int t_begin = xcd * per_xcd;
   const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
   const int t_step = (nblk + 7 - xcd) / 8;
-  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  int tiles_per_img = a.tiles_x * a.tiles_y, tile0 = 0, cur_l = ML ? -1 : 0;
+  (void)cur_l;
   const long in_plane_b = a.in_plane * 2;    // bytes
+  // ML: the levels' first tiles live in SGPRs (a lookup per tile from the kernel arguments costs a chain of scalar loads --
+  // comparable to the 8 k-steps of a 1x1 tile)
+  int lstart[ML ? LFD_MAX_LEVELS : 1];
+  if constexpr (ML) {
+#pragma unroll
+    for (int i = 0; i < LFD_MAX_LEVELS; ++i) lstart[i] = i < L.n ? L.lv[i].tile_start : 0x7fffffff;
+  }
+  (void)lstart;
+  auto level_of = [&](int t) {
+    int l = 0;
+    if constexpr (ML) {
+#pragma unroll
+      for (int i = 1; i < LFD_MAX_LEVELS; ++i) l += (t >= lstart[i]) ? 1 : 0;
+    }
+    return l;
+  };
+  (void)level_of;
 
   // ---- tile loaders: every DMA of the fp16 kernels (conv_impl.h) issued for both planes; the LDS image of a plane is the
   //      fp16 kernels' (lane-linear lines, XOR chunk swizzle on the source side), the lo plane IN_BYTES behind the hi plane
@@ -271,18 +315,33 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
   constexpr int NP2 = (C::IWs + 7) / 8;                 // (FAST2) instructions per halo row
   constexpr int NPIECE = FAST ? 8 : (FAST2 ? NP2 * ((C::IH + 3) / 4) : (C::NSLOT + 4 * SPW - 1) / (4 * SPW));
   const long f_rowpitch = (long)a.W * (CIN * 2);
-  auto dma2 = [&](const char* src, bool valid, const char* zsrc, char* ldst) {
-    dma16(valid ? src : zsrc, ldst);
-    dma16(valid ? src + in_plane_b : zsrc, ldst + C::IN_BYTES);
-  };
-  // tile-level scalars of the tile being fetched
+  // tile-level scalars of the tile being fetched (ML: of ITS level -- the prefetched tile may lie in the next level)
   int d_n = 0, d_gy0 = 0, d_gx0 = 0;
   bool d_interior = false;
   char* d_lbase = smem;
+  const _Float16* d_in = a.in;
+  long d_inpb = in_plane_b;
+  int d_H = a.H, d_W = a.W;
+  auto dma2 = [&](const char* src, bool valid, const char* zsrc, char* ldst) {
+    dma16(valid ? src : zsrc, ldst);
+    dma16(valid ? src + d_inpb : zsrc, ldst + C::IN_BYTES);
+  };
+  int d_l = -1, d_tpi = tiles_per_img, d_tx = a.tiles_x, d_t0 = 0;
+  (void)d_l;
   auto dma_setup = [&](int t, int buf) {
-    d_n = t / tiles_per_img;
-    const int tr = t - d_n * tiles_per_img;
-    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    if constexpr (ML) {
+      const int l = level_of(t);
+      if (l != d_l) {
+        const PlLevel& lv = L.lv[l];
+        d_l = l;
+        d_in = lv.in; d_inpb = lv.in_plane * 2; d_H = lv.H; d_W = lv.W;
+        d_tpi = lv.tiles_x * lv.tiles_y; d_tx = lv.tiles_x; d_t0 = lv.tile_start;
+      }
+    }
+    const int tpi = d_tpi, tx_ = d_tx, t0 = d_t0;
+    d_n = (t - t0) / tpi;
+    const int tr = (t - t0) - d_n * tpi;
+    const int ty0 = tr / tx_, tx0 = tr - ty0 * tx_;
     d_gy0 = ty0 * C::TH * S - C::PAD;
     d_gx0 = tx0 * C::TW * S - C::PAD;
     d_lbase = smem + buf * 2 * C::IN_BYTES;
@@ -352,8 +411,8 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
         bool needed = ix < C::IW;
         if (KS == 1 && S == 2) needed = needed && !(ix & 1) && !(iy & 1);
         if (needed) {
-          const bool valid = (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
-          const char* src = reinterpret_cast<const char*>(a.in + (((size_t)d_n * a.H + (valid ? gy : 0)) * a.W + (valid ? gx : 0)) * CIN + c * 8);
+          const bool valid = (gy >= 0) && (gy < d_H) && (gx >= 0) && (gx < d_W);
+          const char* src = reinterpret_cast<const char*>(d_in + (((size_t)d_n * d_H + (valid ? gy : 0)) * d_W + (valid ? gx : 0)) * CIN + c * 8);
           dma2(src, valid, reinterpret_cast<const char*>(a.zeros + c * 8), d_lbase + slot0 * C::PIXB);
         }
       }
@@ -463,8 +522,47 @@ __device__ __forceinline__ void pl_block(const PlArgs& a, char* smem) {
       block_barrier();
     }
 
-    const int n = t / tiles_per_img;
-    const int tr = t - n * tiles_per_img;
+    if constexpr (ML) {
+      const int l = level_of(t);
+      if (l != cur_l) {
+        // the walk enters another level: flush the GroupNorm sums of the one it leaves, switch the per-level fields, and --
+        // the neck convs -- reload the stationary filter and bias of the new level
+        if constexpr (OUTM == 1) {
+          gn_flush();
+          gn_n = -1;
+        }
+        const PlLevel& lv = L.lv[l];
+        cur_l = l;
+        a.out = lv.out; a.out_plane = lv.out_plane; a.H = a.OH = lv.H; a.W = a.OW = lv.W;
+        a.tiles_x = lv.tiles_x; a.tiles_y = lv.tiles_y; tiles_per_img = lv.tiles_x * lv.tiles_y; tile0 = lv.tile_start;
+        a.gn_acc = lv.gn_acc; a.gnin_acc = lv.gnin_acc; a.f_out0 = lv.f_out0; a.f_out1 = lv.f_out1; a.scale1 = lv.scale1;
+        a.gnin_gamma = lv.gnin_gamma; a.gnin_beta = lv.gnin_beta;
+        gnin_n = -1;
+        if (lv.w != a.w) {
+          a.w = lv.w; a.bias = lv.bias; a.w2 = lv.w2; a.bias2 = lv.bias2;
+          const half8* ws = a.w + ((size_t)(cog * NCT + ct) * C::NK) * 64 + lane;
+#pragma unroll
+          for (int k = 0; k < NKR; ++k) {
+            wh[k] = ws[(size_t)k * 64];
+            wl[k] = ws[a.w_plane + (size_t)k * 64];
+          }
+          if constexpr (TAIL) {
+#pragma unroll
+            for (int k = 0; k < C::NK2; ++k) {
+              w2h[k] = a.w2[((size_t)ct * C::NK2 + k) * 64 + lane];
+              w2l[k] = a.w2[a.w2_plane + ((size_t)ct * C::NK2 + k) * 64 + lane];
+            }
+          }
+          if (threadIdx.x < NCT * 32) {
+            sbias[threadIdx.x] = a.bias[cog * NCT * 32 + threadIdx.x];
+            if constexpr (TAIL) sbias[256 + threadIdx.x] = a.bias2[threadIdx.x];
+          }
+          block_barrier();
+        }
+      }
+    }
+    const int n = (t - tile0) / tiles_per_img;
+    const int tr = (t - tile0) - n * tiles_per_img;
     const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
     const char* xb = smem + buf * 2 * C::IN_BYTES;
     if constexpr (GNIN) {
@@ -892,7 +990,56 @@ struct PlHeavy {
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN = false>
 __global__ __launch_bounds__(256, (PlHeavy<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO>::value ? 1 : 2)) void k_pl_conv(PlArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO, GNIN>(a, smem);
+  PlLevels none;
+  none.n = 0;
+  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO, GNIN, false>(a, none, smem);
+}
+
+// the same block over the tiles of several pyramid levels (1x1 convs of the neck / head)
+template <int CIN, int NCT, bool TAIL, int OUTM, int PTO, bool GNIN>
+__global__ __launch_bounds__(256, (PlHeavy<CIN, 1, 1, NCT, true, TAIL, false, false, OUTM, PTO>::value ? 1 : 2)) void k_pl_conv_ml(PlArgs a, PlLevels L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pl_block<CIN, 1, 1, NCT, true, TAIL, false, false, OUTM, PTO, GNIN, true>(a, L, smem);
+}
+
+template <int CIN, int NCT, bool TAIL, int OUTM, int PTO, bool GNIN>
+int launch_pl_ml_(const PlArgs& a0, const PlLevels& L0, hipStream_t st) {
+  using C = PCfg<CIN, 1, 1, NCT, TAIL, false, PTO>;
+  PlArgs a = a0;
+  PlLevels L = L0;
+  long nt = 0;
+  for (int i = 0; i < L.n; ++i) {
+    L.lv[i].tiles_x = (L.lv[i].W + C::TW - 1) / C::TW;
+    L.lv[i].tiles_y = (L.lv[i].H + C::TH - 1) / C::TH;
+    L.lv[i].tile_start = (int)nt;
+    nt += (long)a.N * L.lv[i].tiles_x * L.lv[i].tiles_y;
+    if (nt > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
+  }
+  a.ntiles = (int)nt;
+  // level 0's fields as the initial state (the kernel switches at its first tile: cur_l = -1)
+  a.in = L.lv[0].in; a.in_plane = L.lv[0].in_plane; a.out = L.lv[0].out; a.out_plane = L.lv[0].out_plane;
+  a.H = a.OH = L.lv[0].H; a.W = a.OW = L.lv[0].W; a.tiles_x = L.lv[0].tiles_x; a.tiles_y = L.lv[0].tiles_y;
+  a.w = L.lv[0].w; a.bias = L.lv[0].bias; a.w2 = L.lv[0].w2; a.bias2 = L.lv[0].bias2;
+  a.gn_acc = L.lv[0].gn_acc; a.gnin_acc = L.lv[0].gnin_acc; a.gnin_gamma = L.lv[0].gnin_gamma; a.gnin_beta = L.lv[0].gnin_beta;
+  a.f_out0 = L.lv[0].f_out0; a.f_out1 = L.lv[0].f_out1; a.scale1 = L.lv[0].scale1;
+  const int cgroups = TAIL ? 1 : (a.cout + NCT * 32 - 1) / (NCT * 32);
+  constexpr int LDSB = C::LDS_BYTES;
+  auto kern = k_pl_conv_ml<CIN, NCT, TAIL, OUTM, PTO, GNIN>;
+  static unsigned long long attr_done_mask = 0;
+  const int attr_done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
+  }
+  constexpr bool heavy = PlHeavy<CIN, 1, 1, NCT, true, TAIL, false, false, OUTM, PTO>::value;
+  constexpr int per_cu = (heavy || LDSB > 80 * 1024) ? 1 : 2;
+  int blocks = (256 * per_cu) / cgroups;
+  if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kern, dim3(blocks, cgroups), dim3(256), LDSB, st, a, L);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
 }
 
 template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN = false>

@@ -98,6 +98,13 @@ class PlConvDesc(C.Structure):
                 ('f_image_stride1', C.c_int64)]
 
 
+class PlLevel(C.Structure):
+    """lfd_pl_level_t"""
+    _fields_ = [(k, C.c_void_p) for k in ('in_', 'out', 'w_packed', 'bias', 'tail_w_packed', 'tail_bias', 'gn_sums', 'gn_in_sums',
+                                          'gn_in_gamma', 'gn_in_beta', 'f_out0', 'f_out1', 'scale1')] + \
+               [('h', C.c_int32), ('w', C.c_int32), ('in_plane_halfs', C.c_int64), ('out_plane_halfs', C.c_int64)]
+
+
 PL_GN_REPLICAS = 8                      # LFD_PL_GN_REPLICAS
 ABI_VERSION = 3                         # LFD_HIP_ABI_VERSION
 HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS
@@ -255,6 +262,7 @@ _SIGNATURES = {
     'lfd_p32_conv2d_tail_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _I32, _P]),
     'lfd_pl_stem_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
     'lfd_pl_conv2d': (C.c_int, [C.POINTER(PlConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lfd_pl_conv2d_levels': (C.c_int, [C.POINTER(PlConvDesc), C.POINTER(PlLevel), _I32, _P, _P]),
     'lfd_pl_groupnorm_relu': (C.c_int, [_P, _I64, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P]),
     'lfd_p32_groupnorm_workspace_bytes': (_SZ, [_I32, _I32]),
     'lfd_p32_groupnorm_relu_f32': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P]),

@@ -18,6 +18,7 @@ back to the fp32-tensor plan when a layer has no plane kernel (`Unsupported`).  
 splits and packs weights once per parameter version, and walks the launch list.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -95,6 +96,11 @@ def _check_dispatch(cin, cout, ks, stride, tail, ds, res, gn, out32):
 def _fork_enabled():
     import os
     return os.environ.get('LFD_P2_FORK', '0') != '0'
+
+
+def _levels_enabled():
+    """LFD_P2_LEVELS=0: one launch per pyramid level and head conv (A/B timing, tests) instead of one per conv over all levels"""
+    return os.environ.get('LFD_P2_LEVELS', '1') != '0'
 
 
 class _Op(object):
@@ -294,6 +300,27 @@ class PlanesPlan(object):
                 self._conv(tc, cconv.weight.detach().float(), cconv.bias.detach().float(), 1, 1, False, out32=(i, ccls, 0, None), gnin=pc)
                 self._conv(tr, rconv.weight.detach().float(), rconv.bias.detach().float(), 1, 1, False, out32=(i, 0, 4, scale), gnin=pr)
             self.level_ops.append((first_op, len(self.ops)))
+        self.level_groups = self._group_levels()
+
+    def _group_levels(self):
+        """[[op index per level]]: the neck / head convs that run as ONE lfd_pl_conv2d_levels launch -- the k-th conv of every
+        level's stack, split by launch signature (the neck's input channels differ between levels).  Position-major order keeps
+        the producer of every GroupNorm sum in an earlier launch than its consumer."""
+        lens = set(b - a for a, b in self.level_ops)
+        if len(lens) != 1 or len(self.level_ops) > _lib.MAX_LEVELS:
+            return None
+        groups = []
+        for k in range(lens.pop()):
+            by_sig = {}
+            for a, _ in self.level_ops:
+                o = self.ops[a + k]
+                if o.ks != 1 or o.stride != 1 or o.res is not None or o.ds is not None:
+                    return None
+                sig = (o.cin, o.cout, o.relu, o.tail is not None and o.tail[2], o.out_mode, o.gnin is not None and o.gnin[3],
+                       o.f_c0, o.f_c1)
+                by_sig.setdefault(sig, []).append(a + k)
+            groups.extend(by_sig.values())
+        return groups
 
     # ------------------------------------------------------------------ execution
     def state_for(self, n, h, w, slot=0):
@@ -314,7 +341,11 @@ class PlanesPlan(object):
             st.gn_sums.zero_()
         fork = _fork_enabled() and len(self.level_ops) > 1 and self.tap_ready[0] + 1 < self.head_start
         if not fork:
-            self._launch(x, fmt, st, range(len(self.ops)))
+            if self.level_groups is not None and _levels_enabled():
+                self._launch(x, fmt, st, range(self.head_start))
+                self._launch_levels(st)
+            else:
+                self._launch(x, fmt, st, range(len(self.ops)))
             return
         main = torch.cuda.current_stream()
         a, b = self.level_ops[0]
@@ -324,6 +355,64 @@ class PlanesPlan(object):
             self._launch(x, fmt, st, range(a, b))
         self._launch(x, fmt, st, list(range(self.tap_ready[0] + 1, self.head_start)) + list(range(b, len(self.ops))))
         main.wait_stream(st.side)
+
+    def _desc(self, o, st):
+        """(lfd_pl_conv_desc_t, src, dst, res, ds_dst, f_out0, f_out1) of conv op `o` on the buffers of `st`"""
+        src = st.bufs[o.src]
+        d = _lib.PlConvDesc()
+        d.n, d.h, d.w, d.cin, d.cout, d.ks, d.stride, d.relu = st.n, src.shape[2], src.shape[3], o.cin, o.cout, o.ks, o.stride, o.relu
+        d.out_mode = o.out_mode
+        d.in_plane_halfs = src[0].numel()
+        dst = res = dsd = None
+        f0 = f1 = None
+        if o.out_mode == 2:
+            d.f_c0, d.f_c1 = o.f_c0, o.f_c1
+            d.f_image_stride0, d.f_image_stride1 = st.P * o.f_c0, st.P * 4
+            f0 = C.c_void_p(st.cls.data_ptr() + st.p_off[o.level] * o.f_c0 * 4) if o.f_c0 else None
+            f1 = C.c_void_p(st.reg.data_ptr() + st.p_off[o.level] * 4 * 4) if o.f_c1 else None
+        else:
+            dst = st.bufs[o.dst]
+            d.out_plane_halfs = dst[0].numel()
+        if o.res is not None:
+            res = st.bufs[o.res]
+            d.res_plane_halfs = res[0].numel()
+        if o.ds is not None:
+            dsd = st.bufs[o.ds_dst]
+            d.ds_plane_halfs = dsd[0].numel()
+        if o.tail is not None:
+            d.tail_cout, d.tail_relu = o.cout, o.tail[2]
+        if o.gnin is not None:
+            d.gn_in_eps = o.gnin[3]
+        return d, src, dst, res, dsd, f0, f1
+
+    def _launch_levels(self, st):
+        """the neck + head: one launch per conv of the stack (and input width) over all pyramid levels"""
+        l, sp = lib(), stream_ptr()
+        zeros = ptr(ops.zero_line(self.device))
+        if st.level_calls is None:
+            calls = []
+            for grp in self.level_groups:
+                arr = (_lib.PlLevel * len(grp))()
+                d0 = None
+                for j, i in enumerate(grp):
+                    o = self.ops[i]
+                    d, src, dst, _, _, f0, f1 = self._desc(o, st)
+                    d0 = d0 or d
+                    lv, gi = arr[j], o.gnin
+                    lv.in_, lv.out, lv.w_packed, lv.bias = src.data_ptr(), dst.data_ptr() if dst is not None else None, o.w.data_ptr(), o.b.data_ptr()
+                    if o.tail is not None:
+                        lv.tail_w_packed, lv.tail_bias = o.tail[0].data_ptr(), o.tail[1].data_ptr()
+                    if o.gn is not None:
+                        lv.gn_sums = st.gn_sums[o.gn].data_ptr()
+                    if gi is not None:
+                        lv.gn_in_sums, lv.gn_in_gamma, lv.gn_in_beta = st.gn_sums[gi[0]].data_ptr(), gi[1].data_ptr(), gi[2].data_ptr()
+                    lv.f_out0, lv.f_out1 = f0, f1
+                    lv.scale1 = o.scale.data_ptr() if o.scale is not None else None
+                    lv.h, lv.w, lv.in_plane_halfs, lv.out_plane_halfs = src.shape[2], src.shape[3], d.in_plane_halfs, d.out_plane_halfs
+                calls.append((d0, arr, len(grp)))
+            st.level_calls = calls
+        for d, arr, n in st.level_calls:
+            check(l.lfd_pl_conv2d_levels(C.byref(d), arr, n, zeros, sp), 'lfd_pl_conv2d_levels')
 
     def _launch(self, x, fmt, st, indices):
         l, sp = lib(), stream_ptr()
@@ -335,32 +424,8 @@ class PlanesPlan(object):
                 check(l.lfd_pl_stem_pair(ptr(x), fmt, st.n, st.h, st.w, o.channels, ptr(o.w1), ptr(o.b1), ptr(o.w2), ptr(o.b2),
                                          ptr(dst), dst[0].numel(), sp), 'lfd_pl_stem_pair')
                 continue
-            src = st.bufs[o.src]
-            d = _lib.PlConvDesc()
-            d.n, d.h, d.w, d.cin, d.cout, d.ks, d.stride, d.relu = st.n, src.shape[2], src.shape[3], o.cin, o.cout, o.ks, o.stride, o.relu
-            d.out_mode = o.out_mode
-            d.in_plane_halfs = src[0].numel()
-            dst = res = dsd = None
-            f0 = f1 = None
-            if o.out_mode == 2:
-                d.f_c0, d.f_c1 = o.f_c0, o.f_c1
-                d.f_image_stride0, d.f_image_stride1 = st.P * o.f_c0, st.P * 4
-                f0 = C.c_void_p(st.cls.data_ptr() + st.p_off[o.level] * o.f_c0 * 4) if o.f_c0 else None
-                f1 = C.c_void_p(st.reg.data_ptr() + st.p_off[o.level] * 4 * 4) if o.f_c1 else None
-            else:
-                dst = st.bufs[o.dst]
-                d.out_plane_halfs = dst[0].numel()
-            if o.res is not None:
-                res = st.bufs[o.res]
-                d.res_plane_halfs = res[0].numel()
-            if o.ds is not None:
-                dsd = st.bufs[o.ds_dst]
-                d.ds_plane_halfs = dsd[0].numel()
-            if o.tail is not None:
-                d.tail_cout, d.tail_relu = o.cout, o.tail[2]
+            d, src, dst, res, dsd, f0, f1 = self._desc(o, st)
             gi = o.gnin
-            if gi is not None:
-                d.gn_in_eps = gi[3]
             check(l.lfd_pl_conv2d(C.byref(d), ptr(src), ptr(dst), ptr(o.w), ptr(o.b), ptr(res),
                                   ptr(o.tail[0]) if o.tail else None, ptr(o.tail[1]) if o.tail else None,
                                   ptr(o.ds[0]) if o.ds else None, ptr(o.ds[1]) if o.ds else None, ptr(dsd),
@@ -396,3 +461,4 @@ class _State(object):
             self.gn_sums = torch.zeros((max(plan.num_gn, 1), _lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device=dev)
             self.side = torch.cuda.Stream(device=dev)
         self.graph = {}
+        self.level_calls = None

@@ -280,6 +280,16 @@ def test_planes_plan_equals_the_fp32_tensor_plan(name, shape):
         c, r = m(x)
         c2, r2 = m(x)
         assert torch.equal(c, c2) and torch.equal(r, r2)          # deterministic (fixed-point GroupNorm sums)
+        c, r = c.clone(), r.clone()
+        # the neck / head convs as one launch over all pyramid levels (lfd_pl_conv2d_levels, the default) == one launch per
+        # level (lfd_pl_conv2d), bit for bit
+        assert plan.level_groups is not None and len(plan.level_groups) < len(plan.ops) - plan.head_start
+        os.environ['LFD_P2_LEVELS'] = '0'
+        try:
+            c1, r1 = m(x)
+            assert torch.equal(c, c1) and torch.equal(r, r1)
+        finally:
+            del os.environ['LFD_P2_LEVELS']
         old = os.environ.get('LFD_P32_PLANES')
         os.environ['LFD_P32_PLANES'] = '0'
         try:
