@@ -471,46 +471,71 @@ def precise_breakdown(model, x, dev, reps=20):
     plan.run(x, fmt, st)
     torch.cuda.synchronize()
     groups = {}
-    for i, o in enumerate(plan.ops):
+    fused_stem = (plan.stem2x is not None and engine_p2._stem2x_enabled() and fmt == 1 and w % 8 == 0 and x.data_ptr() % 16 == 0)
+    by_levels = plan.level_groups is not None and engine_p2._levels_enabled()
+
+    def cost(o):
         if o.kind == 'stem':
             oh, ow = st.dims[o.dst]
             c = o.channels
-            fl = 2.0 * n * oh * ow * (27 * c + c * c)
-            by = x.numel() * x.element_size() + 4.0 * n * oh * ow * c
-            key = 'stem pair 1: conv3x3 s2 (3->%d) + conv1x1 (k_pl_stem)' % c
+            return (2.0 * n * oh * ow * (27 * c + c * c), x.numel() * x.element_size() + 4.0 * n * oh * ow * c,
+                    'stem pair 1: conv3x3 s2 (3->%d) + conv1x1 (k_pl_stem)' % c)
+        src = st.bufs[o.src]
+        ih, iw = src.shape[2], src.shape[3]
+        oh, ow = (ih + o.stride - 1) // o.stride, (iw + o.stride - 1) // o.stride
+        fl = 2.0 * n * oh * ow * o.cin * o.cout * o.ks * o.ks
+        by = 4.0 * n * ih * iw * o.cin
+        if o.tail is not None:
+            fl += 2.0 * n * oh * ow * o.cout * o.cout
+        if o.ds is not None:
+            fl += 2.0 * n * oh * ow * o.cin * o.cout
+            by += 4.0 * n * oh * ow * o.cout
+        if o.res is not None:
+            by += 4.0 * n * oh * ow * o.cout
+        by += 4.0 * n * oh * ow * (o.cout if o.out_mode != 2 else o.f_c0 + o.f_c1)
+        if o.ks == 3 and o.stride == 1 and o.cin == 64:
+            key = 'conv3x3 s1 64->64 (+ residual) (k_pl_c3)'
+        elif o.ks == 3 and o.stride == 2 and o.tail is not None:
+            key = 'stem pair 2: conv3x3 s2 + conv1x1 (k_pl_conv<64,3,2,TAIL>)'
+        elif o.ks == 3 and o.stride == 2:
+            key = 'stage entry: conv3x3 s2 + 1x1 s2 identity branch (k_pl_conv<.,3,2,DS>)'
+        elif o.ks == 3:
+            key = 'conv3x3 s1 128->128 (k_pl_conv<128,3,1>)'
         else:
-            src = st.bufs[o.src]
-            ih, iw = src.shape[2], src.shape[3]
-            oh, ow = (ih + o.stride - 1) // o.stride, (iw + o.stride - 1) // o.stride
-            fl = 2.0 * n * oh * ow * o.cin * o.cout * o.ks * o.ks
-            by = 4.0 * n * ih * iw * o.cin
-            if o.tail is not None:
-                fl += 2.0 * n * oh * ow * o.cout * o.cout
-            if o.ds is not None:
-                fl += 2.0 * n * oh * ow * o.cin * o.cout
-                by += 4.0 * n * oh * ow * o.cout
-            if o.res is not None:
-                by += 4.0 * n * oh * ow * o.cout
-            by += 4.0 * n * oh * ow * (o.cout if o.out_mode != 2 else o.f_c0 + o.f_c1)
-            if o.ks == 3 and o.stride == 1 and o.cin == 64:
-                key = 'conv3x3 s1 64->64 (+ residual) (k_pl_c3)'
-            elif o.ks == 3 and o.stride == 2 and o.tail is not None:
-                key = 'stem pair 2: conv3x3 s2 + conv1x1 (k_pl_conv<64,3,2,TAIL>)'
-            elif o.ks == 3 and o.stride == 2:
-                key = 'stage entry: conv3x3 s2 + 1x1 s2 identity branch (k_pl_conv<.,3,2,DS>)'
-            elif o.ks == 3:
-                key = 'conv3x3 s1 128->128 (k_pl_conv<128,3,1>)'
-            else:
-                key = 'neck + head 1x1 convs, GroupNorm in the consumer (k_pl_conv<.,1,1>)'
+            key = 'neck + head 1x1 convs, GroupNorm in the consumer (k_pl_conv<.,1,1>)'
+        return fl, by, key
+
+    # launch units: (key, flops, bytes, launches, callable)
+    units, i = [], 0
+    while i < len(plan.ops):
+        if fused_stem and i == 0:
+            (f0, b0, _), (f1, b1, _) = cost(plan.ops[0]), cost(plan.ops[1])
+            mid = 4.0 * n * st.dims[plan.ops[0].dst][0] * st.dims[plan.ops[0].dst][1] * plan.ops[0].channels
+            units.append(('whole stem: conv3x3 s2 (3->64) + 1x1 + conv3x3 s2 + 1x1, pair-1 output never in HBM (k_pl_stem2x)', f0 + f1,
+                          b0 + b1 - 2 * mid, 1, lambda: plan._launch(x, fmt, st, [0, 1])))
+            i = 2
+            continue
+        if by_levels and i == plan.head_start:
+            fl = by = 0.0
+            for o in plan.ops[i:]:
+                f, b, _ = cost(o)
+                fl, by = fl + f, by + b
+            units.append(('neck + head 1x1 convs of all pyramid levels, GroupNorm in the consumer (k_pl_conv_ml)', fl, by, len(plan.level_groups),
+                          lambda: plan._launch_levels(st)))
+            break
+        fl, by, key = cost(plan.ops[i])
+        units.append((key, fl, by, 1, (lambda i=i: plan._launch(x, fmt, st, [i]))))
+        i += 1
+    for key, fl, by, nl, fn in units:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for e0, e1 in evs:
             e0.record()
-            plan._launch(x, fmt, st, [i])
+            fn()
             e1.record()
         torch.cuda.synchronize()
         us = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
         g = groups.setdefault(key, dict(launches=0, time_us=0.0, flops=0.0, bytes=0.0))
-        g['launches'] += 1
+        g['launches'] += nl
         g['time_us'] += us
         g['flops'] += fl
         g['bytes'] += by

@@ -512,6 +512,14 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  * lfd_pl_stem_pair: frame (in_format as lfd_stem_conv_f16) -> conv3x3 s2 (3 -> C) + BN + ReLU -> conv1x1 (C -> C) + BN + ReLU
  *   -> planes [n, (h+1)/2, (w+1)/2, C], C = 32 | 64 (lfd_resnet.py:356-374, :376-395).  w1: [2][C/32][2][64][8] in
  *   engine.pack_stem_weight order per plane.  uint8 / fp32 frames keep their low parts (simple_normalize in fp32).
+ * lfd_pl_stem2x: the whole 'faster' stem (lfd_resnet.py:376-413), frame -> planes [n, ceil(ceil(h/2)/2), ceil(ceil(w/2)/2), 64]
+ *   in one launch: the second pair's persistent workgroups compute their input tile from the frame in LDS, the first pair's
+ *   output (the largest tensor of the network) never exists in HBM.  w1: conv0 AND its bias, [2][2 slabs][2 k-steps][64 lanes][8]
+ *   in the k-slot order of the fused gather (engine_p2.pack_planes_stem2x_weight: per frame row the 10 halfs [pixel left of the
+ *   patch, e0..e8], e = 3 dx + c, as aligned dwords; the bias on the slot of a constant one); w2: the first 1x1 with K in the
+ *   order the conv0 accumulators hold the channels (engine_p2.pack_planes_stem2x_tail_weight), b2 its bias [64]; w3 / w4:
+ *   lfd_pl_conv2d order (3x3 s2 64 -> 64, 1x1 64 -> 64), b3 / b4 [128] zero padded.
+ *   fp16 NHWC frames with w % 8 == 0 arrive by 16-byte LDS-DMA, double-buffered; other formats / widths by loads (same results).
  * lfd_pl_conv2d: planes [n,h,w,cin] -> conv ks x ks / stride (+ bias, ReLU) with ONE of
  *     tail_cout > 0   : a chained 1x1 cout -> cout (+ tail_bias, tail_relu) in the same launch (the intermediate stays in LDS):
  *                       the second stem pair (3x3 s2 -> 1x1, lfd_resnet.py:396-413), the neck conv -> first tower conv;
@@ -551,6 +559,10 @@ typedef struct lfd_pl_conv_desc {
 LFD_API int lfd_pl_stem_pair(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, int32_t channels,
                              const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
                              int64_t out_plane_halfs, lfd_stream_t stream);
+LFD_API int lfd_pl_stem2x(const void* in, int32_t in_format, int32_t n, int32_t h, int32_t w, const void* w1_packed,
+                          const void* w2_packed, const float* b2, const void* w3_packed, const float* b3,
+                          const void* w4_packed, const float* b4, void* out, int64_t out_plane_halfs, const void* zeros,
+                          lfd_stream_t stream);
 LFD_API int lfd_pl_conv2d(const lfd_pl_conv_desc_t* desc, const void* in, void* out, const void* w_packed, const float* bias,
                           const void* residual, const void* tail_w_packed, const float* tail_bias, const void* ds_w_packed,
                           const float* ds_bias, void* ds_out, void* gn_sums, float* f_out0, float* f_out1, const float* scale1,

@@ -16,8 +16,6 @@ namespace {
 
 using namespace pl;
 
-enum { IN_NCHW_F32 = 0, IN_NHWC_F16 = 1, IN_NHWC_U8 = 2 };
-
 struct PlStemArgs {
   const void* in;
   _Float16* out;       // planes [N,OH,OW,C]
@@ -31,26 +29,6 @@ struct PlStemArgs {
   int N, H, W, OH, OW;
   int tiles_x, tiles_y;
 };
-
-// the element as loaded (bit pattern) -- nothing is computed from it at the load site: any use would make the compiler wait for
-// the load right there, i.e. (vmcnt retires in order) for the previous tile's output stores in front of it, a full HBM write
-// round trip per tile (measured: 9-11 k of a tile's 16 k cycles)
-template <int FMT>
-__device__ __forceinline__ uint32_t load_px_raw(const void* in, int n, int H, int W, int gy, int gx, int c) {
-  if (FMT == IN_NCHW_F32) {
-    return reinterpret_cast<const uint32_t*>(in)[(((size_t)n * 3 + c) * H + gy) * W + gx];
-  } else if (FMT == IN_NHWC_F16) {
-    return reinterpret_cast<const uint16_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
-  } else {
-    return reinterpret_cast<const uint8_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
-  }
-}
-template <int FMT>
-__device__ __forceinline__ float px_value(uint32_t raw) {
-  if (FMT == IN_NCHW_F32) return __uint_as_float(raw);
-  if (FMT == IN_NHWC_F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)raw);
-  return ((float)raw / 255.f - 0.5f) / 0.5f;   // simple_normalize (augmentation_pipeline.py:31-36) in fp32, like the reference
-}
 
 // First stem pair (lfd_resnet.py:356-374 'fast' / :376-395 first half of 'faster'): csrc/stem.hip's structure on planes.
 // The frame tile is split into hi / lo raw LDS tiles (fp16 frames: lo = 0, its MFMA is skipped), im2col from LDS, K = 27 -> 32;

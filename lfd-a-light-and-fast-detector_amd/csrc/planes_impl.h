@@ -102,8 +102,64 @@ struct PlLevels {
   int n;
 };
 
+enum { IN_NCHW_F32 = 0, IN_NHWC_F16 = 1, IN_NHWC_U8 = 2 };
+
+// the element as loaded (bit pattern) -- nothing is computed from it at the load site: any use would make the compiler wait for
+// the load right there, i.e. (vmcnt retires in order) for the previous tile's output stores in front of it, a full HBM write
+// round trip per tile (measured: 9-11 k of a tile's 16 k cycles)
+template <int FMT>
+__device__ __forceinline__ uint32_t load_px_raw(const void* in, int n, int H, int W, int gy, int gx, int c) {
+  if (FMT == IN_NCHW_F32) {
+    return reinterpret_cast<const uint32_t*>(in)[(((size_t)n * 3 + c) * H + gy) * W + gx];
+  } else if (FMT == IN_NHWC_F16) {
+    return reinterpret_cast<const uint16_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+  } else {
+    return reinterpret_cast<const uint8_t*>(in)[(((size_t)n * H + gy) * W + gx) * 3 + c];
+  }
+}
+template <int FMT>
+__device__ __forceinline__ float px_value(uint32_t raw) {
+  if (FMT == IN_NCHW_F32) return __uint_as_float(raw);
+  if (FMT == IN_NHWC_F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)raw);
+  return ((float)raw / 255.f - 0.5f) / 0.5f;   // simple_normalize (augmentation_pipeline.py:31-36) in fp32, like the reference
+}
+
+// PRODUCE (k_pl_stem2x, planes_stem2x.hip): the input tile of a 3x3 stride-2 conv on 64 channels is not fetched but COMPUTED
+// in LDS from the frame -- the first stem pair conv3x3 s2 (3 -> 64) + BN + ReLU -> conv1x1 + BN + ReLU (lfd_resnet.py:376-395)
+// feeding the second pair (:396-413) without its 1.06 GB round trip through HBM (bs 8 at 1080p: the largest tensor of the net).
+struct PlProd {
+  const void* frame;       // [N,FH,FW,3] fp16 | uint8, or [N,3,FH,FW] fp32 (in_format of lfd_stem_conv_f16)
+  int FH, FW;
+  int dma_ok;              // fp16 frames with 4-byte aligned rows: the raw tile arrives by LDS-DMA, double-buffered
+  const half8* w1;         // conv0 + its bias, [2 = hi | lo][2 slabs][2 k-steps][64 lanes] in the producer's k-slot order (see gather)
+  const half8* w2;         // 1x1, [2][2][4][64], K in the order the conv0 accumulators hold the channels (see produce)
+  const float* b2;         // [64]
+};
+struct ProdCfg {
+  static constexpr int MH = 9, MW = 33, NPX = MH * MW, NROUND = (NPX + 63) / 64;   // the consumer's 9 x 33 input tile
+  static constexpr int FR = 2 * MH + 1;                  // frame rows of the tile
+  static constexpr int FJ = (2 * MW + 2) * 3;            // halfs of a frame row the gather may touch: one junk pixel + 2 MW + 1 pixels
+  static constexpr int JUNK = 7;                         // halfs left of the patch in an LDS row (3 = one pixel: dword-aligned gather;
+                                                         // + 4: the row's first byte in the frame is 16-byte aligned for the DMA)
+  static constexpr int FPITCH = 256;                     // halfs: 32 DMA lanes x 16 B
+  static constexpr int FRAME_BYTES = (FR + 1) * FPITCH * 2;
+  static constexpr int FRAME_OFF = 0;                    // 2 tiles: DMA double buffer (fp16 frames) | hi + lo of one tile
+  static constexpr int W4_OFF = FRAME_OFF + 2 * FRAME_BYTES;       // the consumer's chained 1x1 [2][2][4][64]
+  static constexpr int W1_OFF = W4_OFF + 2 * 2 * 4 * 64 * 16;      // conv0 [2][2][2][64]
+  static constexpr int PB_OFF = W1_OFF + 2 * 2 * 2 * 64 * 16;      // the producer 1x1's bias [64]
+  static constexpr int XCH_OFF = PB_OFF + 64 * 4;                  // fragment exchange between the two slab waves of a pixel group:
+  static constexpr int XCH_BYTES = 4 * 4 * 1024;                   //   [wave][2 k-steps x (hi, lo)][64 lanes x 16 B], double-buffered
+  static constexpr int BYTES = XCH_OFF + 2 * XCH_BYTES;
+};
+
+// 4-byte LDS-DMA (64 lanes x 4 B contiguous at the wave's LDS base)
+__device__ __forceinline__ void dma4(const void* g, const void* lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(m0v) : "memory");
+}
+
 // PTO: 32-pixel MFMA tiles per wave (0: 2 for stride 1, 1 for stride 2)
-template <int CIN, int KS, int S, int NCT, bool TAIL, bool RES, int PTO>
+template <int CIN, int KS, int S, int NCT, bool TAIL, bool RES, int PTO, bool PROD = false>
 struct PCfg {
   static constexpr int PT = PTO ? PTO : ((S == 1) ? 2 : 1);
   static constexpr int TW = (S == 1 && !(CIN == 64 && KS == 3)) ? 32 : 16;
@@ -133,7 +189,7 @@ struct PCfg {
   // the consumed input buffer when it fits there
   static constexpr int SCR_BYTES = 2 * (MID_PLANE > OUT_PLANE ? MID_PLANE : OUT_PLANE);
   static constexpr bool ALIAS = SCR_BYTES <= 2 * IN_BYTES;
-  static constexpr int NBUF = (S == 1 || (CIN == 64 && KS == 3 && NCT == 2)) ? 2 : 1;
+  static constexpr int NBUF = PROD ? 1 : ((S == 1 || (CIN == 64 && KS == 3 && NCT == 2)) ? 2 : 1);
   static constexpr int SCR_OFF = NBUF * 2 * IN_BYTES;
   static constexpr int BIAS_OFF = SCR_OFF + (ALIAS ? 0 : SCR_BYTES);
   // RES: the residual tile (this workgroup's channel slice, both planes) arrives by DMA in copy-out order
@@ -155,7 +211,7 @@ struct PCfg {
 #ifndef PL_DBG_BLOCK
 #define PL_DBG_BLOCK 0
 #endif
-__device__ unsigned long long g_pl_dbg[8 * 16 + 8 + 8];
+static __device__ unsigned long long g_pl_dbg[8 * 16 + 8 + 8];   // (one per translation unit)
 #define PL_T(i) do { if (blockIdx.x == PL_DBG_BLOCK && blockIdx.y == 0 && threadIdx.x == 0 && dbg_it < 8) g_pl_dbg[dbg_it * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PL_T(i)
@@ -205,15 +261,18 @@ __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return fmaf((
 __device__ __forceinline__ float comb(float m, float c) { return fmaf(c, kInvLo, m); }
 
 // OUTM: 0 = planes, 1 = planes + GroupNorm sums (groups of 8 channels), 2 = fp32 outputs (cls / reg)
-template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN, bool ML = false>
-__device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, char* smem) {
+template <int CIN, int KS, int S, int NCT, bool WREG, bool TAIL, bool RES, bool DS, int OUTM, int PTO, bool GNIN, bool ML = false, int PFMT = -1>
+__device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, char* smem, const PlProd& P) {
+  constexpr bool PROD = PFMT >= 0;
+  static_assert(!PROD || (CIN == 64 && KS == 3 && S == 2 && NCT == 2 && WREG && !RES && !DS && !ML && !GNIN), "PRODUCE: the second stem pair");
   static_assert(!ML || (KS == 1 && S == 1 && WREG && !RES && !DS), "multi-level launches: the 1x1 convs of the neck / head");
   PlArgs a = a0;            // (ML: the per-level fields are switched when the tile walk enters another level)
   static_assert(!GNIN || (KS == 1 && S == 1 && CIN == 128 && !TAIL && !RES && !DS), "GNIN: a 1x1 conv on a 128-channel GroupNorm(16) input");
   static_assert(!DS || (KS == 3 && S == 2 && !TAIL && !RES && OUTM == 0), "DS rides on a 3x3 stride-2 conv");
   static_assert(!TAIL || (!RES && !DS), "TAIL: conv -> 1x1 in one launch");
   static_assert(OUTM != 2 || (!TAIL && !RES && !DS), "fp32 outputs: the bare cls / reg conv");
-  using C = PCfg<CIN, KS, S, NCT, TAIL, RES, PTO>;
+  using C = PCfg<CIN, KS, S, NCT, TAIL, RES, PTO, PROD>;
+  static_assert(!PROD || (C::IH == ProdCfg::MH && C::IW == ProdCfg::MW && C::LDS_BYTES + ProdCfg::BYTES <= 160 * 1024), "producer tile");
   constexpr int PT = C::PT;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -243,8 +302,10 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
       wl[k] = wsrc[a.w_plane + (size_t)k * 64];
     }
   }
-  half8 w2h[TAIL ? C::NK2 : 1], w2l[TAIL ? C::NK2 : 1];
-  if constexpr (TAIL) {
+  // (PRODUCE: the chained 1x1's fragments stay in LDS -- the producer's working set needs their 32 registers)
+  constexpr bool TAILW_REG = TAIL && PFMT < 0;
+  half8 w2h[TAILW_REG ? C::NK2 : 1], w2l[TAILW_REG ? C::NK2 : 1];
+  if constexpr (TAILW_REG) {
 #pragma unroll
     for (int k = 0; k < C::NK2; ++k) {
       w2h[k] = a.w2[((size_t)ct * C::NK2 + k) * 64 + lane];
@@ -487,6 +548,234 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
     }
   };
 
+  int dbg_it = 0; (void)dbg_it;     // tile counter of this workgroup
+  // ---- PRODUCE: the first stem pair computed into the input tile
+  char* const psm = smem + C::LDS_BYTES;
+  half8 pw2h[PROD ? 4 : 1], pw2l[PROD ? 4 : 1];
+  (void)psm; (void)pw2h; (void)pw2l;
+  if constexpr (PROD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // k-steps in the order the wave has them: its own conv0 slab's two first, then the other slab's
+      const int q = j < 2 ? 2 * ct + j : 2 * (ct ^ 1) + (j - 2);
+      pw2h[j] = P.w2[(ct * 4 + q) * 64 + lane];
+      pw2l[j] = P.w2[2 * 4 * 64 + (ct * 4 + q) * 64 + lane];
+    }
+    half8* w1s = reinterpret_cast<half8*>(psm + ProdCfg::W1_OFF);
+    for (int i = threadIdx.x; i < 2 * 2 * 2 * 64; i += 256) w1s[i] = P.w1[i];
+    half8* w4s = reinterpret_cast<half8*>(psm + ProdCfg::W4_OFF);
+    for (int i = threadIdx.x; i < 2 * 2 * 4 * 64; i += 256) w4s[i] = a.w2[i];
+    float* pb = reinterpret_cast<float*>(psm + ProdCfg::PB_OFF);
+    if (threadIdx.x < 64) pb[threadIdx.x] = P.b2[threadIdx.x];
+  }
+  // tile t -> image, mid-tensor origin (gy0, gx0) of the 9 x 33 input tile, frame origin of its 19 x 68 pixel patch
+  auto prod_origin = [&](int t, int& n, int& gy0, int& gx0) {
+    n = t / tiles_per_img;
+    const int tr = t - n * tiles_per_img;
+    const int ty0 = tr / a.tiles_x, tx0 = tr - ty0 * a.tiles_x;
+    gy0 = ty0 * C::TH * 2 - 1;
+    gx0 = tx0 * C::TW * 2 - 1;
+  };
+  // fp16 frames whose rows are 16-byte aligned (FW % 8 == 0): the raw patch by 16-byte LDS-DMA, two 512-byte rows per
+  // instruction.  A row starts ProdCfg::JUNK halfs left of the patch: the byte offset (64 tx0 - 4) * 6 - 8 of that column is a
+  // multiple of 16, and so are both image edges (whole lanes are in or out)
+  auto frame_dma = [&](int t, int fb) {
+    if constexpr (PROD) {
+      int n, gy0, gx0;
+      prod_origin(t, n, gy0, gx0);
+      const int fy0 = 2 * gy0 - 1, fxm = 2 * gx0 - 2;
+      const _Float16* fr = reinterpret_cast<const _Float16*>(P.frame);
+      char* lbase = psm + ProdCfg::FRAME_OFF + fb * ProdCfg::FRAME_BYTES;
+      constexpr int NI = (ProdCfg::FR + 1) / 2;
+      const int hcol = fxm * 3 - ProdCfg::JUNK + 3 + 8 * (lane & 31);
+      const bool colok = (lane & 31) < (ProdCfg::FJ + ProdCfg::JUNK - 3 + 7) / 8 && hcol >= 0 && hcol < P.FW * 3;
+      for (int i = wave; i < NI; i += 4) {
+        const int fy = fy0 + 2 * i + (lane >> 5);
+        const bool ok = colok && fy >= 0 && fy < P.FH;
+        const _Float16* src = ok ? fr + ((size_t)n * P.FH + fy) * P.FW * 3 + hcol : a.zeros;
+        dma16(src, lbase + i * 1024);
+      }
+    }
+  };
+  // any format: load, convert (simple_normalize for uint8), split, store the hi and lo patch -- no prefetch (fallback path)
+  auto frame_fill = [&](int t) {
+    if constexpr (PROD) {
+      int n, gy0, gx0;
+      prod_origin(t, n, gy0, gx0);
+      const int fy0 = 2 * gy0 - 1, fxm = 2 * gx0 - 2;
+      _Float16* f0 = reinterpret_cast<_Float16*>(psm + ProdCfg::FRAME_OFF);
+      _Float16* f1 = reinterpret_cast<_Float16*>(psm + ProdCfg::FRAME_OFF + ProdCfg::FRAME_BYTES);
+      constexpr int NE = ProdCfg::FR * ProdCfg::FJ;
+      for (int i = threadIdx.x; i < NE; i += 256) {
+        const int r = i / ProdCfg::FJ, j = i - r * ProdCfg::FJ;
+        const int px = j / 3, c = j - px * 3;
+        const int fy = fy0 + r, fx = fxm + px;
+        const bool ok = fy >= 0 && fy < P.FH && fx >= 0 && fx < P.FW;
+        const float v = ok ? px_value<PROD ? PFMT : 0>(load_px_raw<PROD ? PFMT : 0>(P.frame, n, P.FH, P.FW, fy, fx, c)) : 0.f;
+        const _Float16 hh = (_Float16)v;
+        f0[r * ProdCfg::FPITCH + ProdCfg::JUNK - 3 + j] = hh;
+        if constexpr (PFMT != IN_NHWC_F16) f1[r * ProdCfg::FPITCH + ProdCfg::JUNK - 3 + j] = (_Float16)((v - (float)hh) * kLo);
+      }
+    }
+  };
+  // the 297 pixels of the input tile in rounds of 64; wave = (cout slab) x (32-pixel group), like the consumer.  A wave computes
+  // conv0 (two k-steps gathered from the raw patch; the bias rides on a constant-one k-slot) for ITS slab of 32 channels.  The
+  // 32x32 accumulator layout hands lane (h, pixel) the channels {8g + 4h + e}: the eight values of two g's, packed to fp16
+  // hi / lo, ARE the lane's B fragment of a k-step of the 1x1 whose K runs in that channel order (the host packs the 1x1's
+  // filter to match) -- the intermediate never takes the [pixel][channel] form.  The two slab waves of a pixel group swap
+  // their two k-steps through LDS in fragment order (4 KB each way, conflict-free b128) and run the 1x1 for their own slab.
+  // (As [pixel][channel] planes in LDS the producer was LDS-bound: 44 KB per wave and round on the CU's one 128 B / clk pipe;
+  //  with every wave computing both slabs itself it was VALU-bound on the doubled hi / lo splits.)
+  auto produce = [&](int t, int fb) {
+    if constexpr (PROD) {
+      constexpr bool HASLO = PFMT != IN_NHWC_F16;
+      constexpr int NR = ProdCfg::NROUND;
+      int n, gy0, gx0;
+      prod_origin(t, n, gy0, gx0);
+      const uint32_t* fh = reinterpret_cast<const uint32_t*>(psm + ProdCfg::FRAME_OFF + (HASLO ? 0 : fb) * ProdCfg::FRAME_BYTES);
+      const uint32_t* fl = reinterpret_cast<const uint32_t*>(psm + ProdCfg::FRAME_OFF + ProdCfg::FRAME_BYTES);
+      const half8* w1s = reinterpret_cast<const half8*>(psm + ProdCfg::W1_OFF) + lane;
+      const float* pb = reinterpret_cast<const float*>(psm + ProdCfg::PB_OFF);
+      constexpr int RD = ProdCfg::FPITCH / 2;      // dwords per patch row
+      // k-slots: step 0 {h=0: row 0 halfs [junk, e0..e6], h=1: row 2 [junk, e0..e6]}, step 1 {h=0: row 1 [junk, e0..e6],
+      // h=1: (row 0 e7 e8, row 1 e7 e8, row 2 e7 e8, ONE, pad)}, e = 3 dx + c; junk / pad slots have zero weights, the slot
+      // of the constant one carries the bias
+      const int go0 = h ? 4 : RD, go1 = h ? RD + 4 : RD + 1, go2 = h ? 2 * RD + 4 : RD + 2;
+      auto gather = [&](const uint32_t* f, int base0, uint32_t one, half8& g0, half8& g1) {
+        union { half8 v; uint32_t u[4]; } f0, f1;
+        const uint32_t* a0p = f + base0 + (h ? 2 * RD : 0);
+        f0.u[0] = a0p[0]; f0.u[1] = a0p[1]; f0.u[2] = a0p[2]; f0.u[3] = a0p[3];
+        const uint32_t* b0 = f + base0;
+        f1.u[0] = b0[go0]; f1.u[1] = b0[go1]; f1.u[2] = b0[go2];
+        const uint32_t last = b0[RD + 3];
+        f1.u[3] = h ? one : last;
+        g0 = f0.v; g1 = f1.v;
+      };
+      // (main, corr) accumulators of 32 channels -> ReLU -> the two k-step fragments (hi, lo) they form
+      auto to_frag = [&](const f32x16& m, const f32x16& c, half8* xh, half8* xl) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          union { half8 v; uint32_t w[4]; } vh, vl;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float y0 = fmaxf(comb(m[8 * u + 2 * k], c[8 * u + 2 * k]), 0.f);
+            const float y1 = fmaxf(comb(m[8 * u + 2 * k + 1], c[8 * u + 2 * k + 1]), 0.f);
+            split2(y0, y1, vh.w[k], vl.w[k]);
+          }
+          xh[u] = vh.v; xl[u] = vl.v;
+        }
+      };
+      // this wave's conv0 fragments (registers for the lifetime of the tile: 16)
+      const half8 wah = w1s[((0 * 2 + ct) * 2 + 0) * 64], wbh = w1s[((0 * 2 + ct) * 2 + 1) * 64];
+      const half8 wal = w1s[((1 * 2 + ct) * 2 + 0) * 64], wbl = w1s[((1 * 2 + ct) * 2 + 1) * 64];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // software pipeline over the rounds -- one wave per SIMD has nobody else to hide its MFMA -> VALU -> LDS chain behind:
+      // conv0 of round r + 1 is issued IN FRONT of the 1x1 of round r, so the VALU splits round r + 1's conv0 result while the
+      // matrix pipe runs the 1x1, then splits the 1x1's output (a serial chain measured 2.1 k cycles a round)
+      f32x16 am, ac;
+      half8 xh[4], xl[4];      // k-steps of the 1x1: this wave's conv0 slab first
+      auto conv0 = [&](int r) {
+        const int p = (2 * r + pg) * 32 + pix;
+        const int pc = p < ProdCfg::NPX ? p : ProdCfg::NPX - 1;
+        const int my = pc / ProdCfg::MW, mx = pc - my * ProdCfg::MW;
+        const int base0 = (2 * my) * RD + 3 * mx + (ProdCfg::JUNK - 1) / 2;
+        half8 x0h, x1h, x0l, x1l;
+        gather(fh, base0, 0x3c00u, x0h, x1h);
+        if constexpr (HASLO) gather(fl, base0, 0u, x0l, x1l);
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah, x0h, zero16, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wal, x0h, zero16, 0, 0, 0);
+        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh, x1h, am, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbl, x1h, ac, 0, 0, 0);
+        if constexpr (HASLO) {
+          ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah, x0l, ac, 0, 0, 0);
+          ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbh, x1l, ac, 0, 0, 0);
+        }
+      };
+      // swap with the other slab's wave of this pixel group (wave = pg * 2 + ct)
+      auto exchange = [&](int r, const half8* oh, const half8* ol) {
+        half8* xw = reinterpret_cast<half8*>(psm + ProdCfg::XCH_OFF + (r & 1) * ProdCfg::XCH_BYTES) + lane;
+        half8* mine = xw + wave * 4 * 64;
+        mine[0] = oh[0]; mine[64] = oh[1]; mine[128] = ol[0]; mine[192] = ol[1];
+        block_barrier();
+        const half8* theirs = xw + (wave ^ 1) * 4 * 64;
+        xh[0] = oh[0]; xh[1] = oh[1]; xl[0] = ol[0]; xl[1] = ol[1];
+        xh[2] = theirs[0]; xh[3] = theirs[64]; xl[2] = theirs[128]; xl[3] = theirs[192];
+      };
+      {
+        conv0(0);
+        half8 oh[2], ol[2];
+        to_frag(am, ac, oh, ol);
+        exchange(0, oh, ol);
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (r == 2) PL_T(1);
+        if (r + 1 < NR) conv0(r + 1);
+        if (r == 2) PL_T(2);
+        // the 1x1 on this wave's slab: bias from LDS into the main accumulators
+        f32x16 tm, tc;
+        {
+          const float* bp = pb + ct * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * g);
+            tm[4 * g + 0] = b4.x; tm[4 * g + 1] = b4.y; tm[4 * g + 2] = b4.z; tm[4 * g + 3] = b4.w;
+          }
+        }
+        tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(pw2h[0], xh[0], tm, 0, 0, 0);
+        tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pw2h[0], xl[0], zero16, 0, 0, 0);
+        tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pw2l[0], xh[0], tc, 0, 0, 0);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(pw2h[q], xh[q], tm, 0, 0, 0);
+          tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pw2h[q], xl[q], tc, 0, 0, 0);
+          tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pw2l[q], xh[q], tc, 0, 0, 0);
+        }
+        half8 oh[2], ol[2];
+        if (r + 1 < NR) {
+          to_frag(am, ac, oh, ol);
+          // a wave's MFMAs issue in order and each waits for the pipe: VALU work overlaps them only from BETWEEN them
+          __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r == 2) PL_T(14);
+        // -> ReLU (zero outside the mid tensor: v_med3(y, 0, +inf | 0)) -> the consumer's input tile
+        const int p = (2 * r + pg) * 32 + pix;
+        const int pc = p < ProdCfg::NPX ? p : ProdCfg::NPX - 1;
+        const int my = pc / ProdCfg::MW, mx = pc - my * ProdCfg::MW;
+        const int gy = gy0 + my, gx = gx0 + mx;
+        const float vmax = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? __builtin_inff() : 0.f;
+        // (lanes past the tile's last pixel write the slot no tap reads -- column IWs - 1 -- instead of branching)
+        const int rem = p < ProdCfg::NPX ? (mx & 1) * C::IWh + (mx >> 1) : C::IWs - 1;
+        const int fk = (rem / C::PPR) % C::CPP;
+        char* dst = smem + (my * C::IWs + rem) * C::PIXB + 8 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = __builtin_amdgcn_fmed3f(comb(tm[4 * g + e], tc[4 * g + e]), 0.f, vmax);
+          uint2 vh, vl;
+          split2(y[0], y[1], vh.x, vl.x);
+          split2(y[2], y[3], vh.y, vl.y);
+          const int o = ((ct * 4 + g) ^ fk) * 16;
+          *reinterpret_cast<uint2*>(dst + o) = vh;
+          *reinterpret_cast<uint2*>(dst + C::IN_BYTES + o) = vl;
+        }
+#ifdef LFD_PL_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (r == 2) PL_T(15);
+        if (r + 1 < NR) exchange(r + 1, oh, ol);
+      }
+    }
+  };
+
   float gn_a[GNIN ? 8 : 1], gn_b[GNIN ? 8 : 1];
   int gnin_n = -1;
   (void)gn_a; (void)gn_b; (void)gnin_n;
@@ -494,7 +783,9 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
   int buf = 0;
   bool first = true;
   if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);
-  int dbg_it = 0; (void)dbg_it;
+  if constexpr (PROD) {
+    if (P.dma_ok && t < t_end) frame_dma(t, 0);
+  }
   for (; t < t_end; t += t_step, buf ^= (C::NBUF - 1), ++dbg_it) {
     bool has_next = false;
     PL_T(0);
@@ -515,6 +806,28 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
         if constexpr (DMA_IN_LOOP) dma_setup(t + t_step, buf ^ 1);
         else issue_dma(t + t_step, buf ^ 1);
       }
+    } else if constexpr (PROD) {
+      // the frame patch of tile t (DMA issued one tile ago, before that tile's copy-out stores: vmcnt retires in order)
+      constexpr int NST = 2 * ((C::OPX * NCT * 4) / 256);
+      static_assert(NST == 4, "copy-out stores per thread");
+      const int fb = dbg_it & 1;
+      if (P.dma_ok) {
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        first = false;
+      }
+      block_barrier();        // patch landed; the previous tile's staging reads of the input-tile bytes are done
+      PL_T(10);
+      if (P.dma_ok) {
+        if (t + t_step < t_end) frame_dma(t + t_step, fb ^ 1);
+      } else {
+        frame_fill(t);
+        block_barrier();
+      }
+      PL_T(11);
+      produce(t, P.dma_ok ? fb : 0);
+      block_barrier();
+      PL_T(12);
     } else {
       block_barrier();
       issue_dma(t, 0);
@@ -814,9 +1127,16 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
           const int o = pb * C::MPIXB + (((2 * q + h) ^ fm) * 16);
           const half8 xh = *reinterpret_cast<const half8*>(mid + o);
           const half8 xl = *reinterpret_cast<const half8*>(mid + C::MID_PLANE + o);
-          accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xh, accm[pt], 0, 0, 0);
-          accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[q], xl, accc[pt], 0, 0, 0);
-          accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[q], xh, accc[pt], 0, 0, 0);
+          half8 wq, wql;
+          if constexpr (TAILW_REG) {
+            wq = w2h[q]; wql = w2l[q];
+          } else {
+            const half8* tws = reinterpret_cast<const half8*>(smem + C::LDS_BYTES + ProdCfg::W4_OFF) + (ct * C::NK2 + q) * 64 + lane;
+            wq = tws[0]; wql = tws[2 * C::NK2 * 64];
+          }
+          accm[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq, xh, accm[pt], 0, 0, 0);
+          accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq, xl, accc[pt], 0, 0, 0);
+          accc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wql, xh, accc[pt], 0, 0, 0);
         }
       }
     }
@@ -992,14 +1312,14 @@ __global__ __launch_bounds__(256, (PlHeavy<CIN, KS, S, NCT, WREG, TAIL, RES, DS,
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PlLevels none;
   none.n = 0;
-  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO, GNIN, false>(a, none, smem);
+  pl_block<CIN, KS, S, NCT, WREG, TAIL, RES, DS, OUTM, PTO, GNIN, false>(a, none, smem, PlProd{});
 }
 
 // the same block over the tiles of several pyramid levels (1x1 convs of the neck / head)
 template <int CIN, int NCT, bool TAIL, int OUTM, int PTO, bool GNIN>
 __global__ __launch_bounds__(256, (PlHeavy<CIN, 1, 1, NCT, true, TAIL, false, false, OUTM, PTO>::value ? 1 : 2)) void k_pl_conv_ml(PlArgs a, PlLevels L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  pl_block<CIN, 1, 1, NCT, true, TAIL, false, false, OUTM, PTO, GNIN, true>(a, L, smem);
+  pl_block<CIN, 1, 1, NCT, true, TAIL, false, false, OUTM, PTO, GNIN, true>(a, L, smem, PlProd{});
 }
 
 template <int CIN, int NCT, bool TAIL, int OUTM, int PTO, bool GNIN>

@@ -261,6 +261,7 @@ _SIGNATURES = {
     'lfd_p32_conv2d_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     'lfd_p32_conv2d_tail_nhwc_f32': (C.c_int, [C.POINTER(P32ConvDesc), _P, _P, _P, _P, _P, _P, _I32, _P]),
     'lfd_pl_stem_pair': (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    'lfd_pl_stem2x': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     'lfd_pl_conv2d': (C.c_int, [C.POINTER(PlConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_pl_conv2d_levels': (C.c_int, [C.POINTER(PlConvDesc), C.POINTER(PlLevel), _I32, _P, _P]),
     'lfd_pl_groupnorm_relu': (C.c_int, [_P, _I64, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P]),

@@ -59,6 +59,52 @@ def pack_planes_stem_weight(w):
     return torch.stack([engine.pack_stem_weight(hi), engine.pack_stem_weight(lo)], 0).contiguous()
 
 
+def pack_planes_stem2x_weight(w, b):
+    """conv0 [64, 3, 3, 3] fp32 + bias [64] -> [2][2 slabs][2 k-steps][64 lanes][8] in the k-slot order of the fused stem's gather
+    (csrc/planes_impl.h produce(): per frame row the aligned dwords [pixel left of the patch, e0..e8], e = 3 dx + c):
+    step 0 {half 0: row 0 (junk, e0..e6), half 1: row 2 (junk, e0..e6)}, step 1 {half 0: row 1 (junk, e0..e6),
+    half 1: (row 0 e7 e8, row 1 e7 e8, row 2 e7 e8, ONE, pad)}; junk / pad slots carry zero weights, the slot whose
+    activation is the constant one carries the bias (split into hi / lo like a weight)."""
+    if tuple(w.shape) != (64, 3, 3, 3) or b.numel() != 64:
+        raise Unsupported('fused stem: conv0 must be [64, 3, 3, 3]')
+    c = 64
+    wr = w.detach().float().permute(0, 2, 3, 1).reshape(c // 32, 32, 3, 9)          # [slab][co][row][e = 3 dx + c]
+    out = torch.zeros(c // 32, 2, 2, 32, 8, dtype=torch.float32, device=w.device)   # [slab][step][half][co][j]
+    out[:, 0, 0, :, 1:] = wr[:, :, 0, :7]
+    out[:, 0, 1, :, 1:] = wr[:, :, 2, :7]
+    out[:, 1, 0, :, 1:] = wr[:, :, 1, :7]
+    for r in range(3):
+        out[:, 1, 1, :, 2 * r:2 * r + 2] = wr[:, :, r, 7:9]
+    out[:, 1, 1, :, 6] = b.detach().float().reshape(c // 32, 32).to(w.device)
+    hi, lo = _split(out.reshape(c // 32, 2, 64, 8))
+    return torch.stack([hi, lo], 0).contiguous()
+
+
+def pack_planes_stem2x_tail_weight(w):
+    """the fused stem's first 1x1 [64, 64, 1, 1] -> [2][2 slabs][4 k-steps][64 lanes][8] with K in the order the conv0
+    accumulators hold the channels: k-step q = 2 s + u, lane half h', element j -> input channel
+    32 s + 16 u + (4 h' + j if j < 4 else 8 + 4 h' + j - 4)  (the 32x32 accumulator layout {8 g + 4 h + e}, g = 2 u + j // 4)"""
+    if tuple(w.shape) != (64, 64, 1, 1):
+        raise Unsupported('fused stem: first 1x1 must be [64, 64, 1, 1]')
+    w2 = w.detach().float().reshape(64, 64)
+    idx = torch.empty(4, 2, 8, dtype=torch.long)
+    for q in range(4):
+        s_, u = q // 2, q % 2
+        for hh in range(2):
+            for j in range(8):
+                idx[q, hh, j] = 32 * s_ + 16 * u + (4 * hh + j if j < 4 else 8 + 4 * hh + j - 4)
+    g = w2[:, idx.reshape(-1).to(w2.device)].reshape(2, 32, 4, 2, 8)          # [slab][co][q][h'][j]
+    out = g.permute(0, 2, 3, 1, 4).reshape(2, 4, 64, 8)                      # [slab][q][lane = 32 h' + co][j]
+    hi, lo = _split(out)
+    return torch.stack([hi, lo], 0).contiguous()
+
+
+def _stem2x_enabled():
+    """LFD_P2_STEM2X=0: the 'faster' stem as two launches (lfd_pl_stem_pair + lfd_pl_conv2d with a chained 1x1) instead of
+    lfd_pl_stem2x (A/B timing, tests); =2: lfd_pl_stem2x for every input format (tests)"""
+    return os.environ.get('LFD_P2_STEM2X', '1') != '0'
+
+
 def _pad_bias(b, mult=32):
     n = -(-b.numel() // mult) * mult
     out = b.new_zeros(n, dtype=torch.float32)
@@ -206,10 +252,20 @@ class PlanesPlan(object):
         o.dst = self._new_buf(c, 2)
         self.ops.append(o)
         cur = o.dst
+        self.stem2x = None
         if len(spec) == 4:
             if tuple(folded[3][0].shape[:2]) != (c, c):
                 raise Unsupported('stem channels')
-            cur = self._conv(cur, folded[2][0], folded[2][1], 3, 2, True, tail=(folded[3][0], folded[3][1], True)).dst
+            pair2 = self._conv(cur, folded[2][0], folded[2][1], 3, 2, True, tail=(folded[3][0], folded[3][1], True))
+            cur = pair2.dst
+            if c == 64:
+                # the whole stem as one launch (lfd_pl_stem2x) in place of ops[0:2]; the two-launch form stays for A/B
+                f = _Op('stem2x')
+                f.w1 = pack_planes_stem2x_weight(folded[0][0], folded[0][1]).to(self.device)
+                f.w2, f.b2 = pack_planes_stem2x_tail_weight(folded[1][0]).to(self.device), o.b2
+                f.dst = cur
+                f.tail = pair2
+                self.stem2x = f
         # ---- residual stages (lfd_resnet.py:96-154, :458-468, :488-501)
         taps = [tuple(t) for t in bb._out_indices]
         self.taps = []
@@ -417,8 +473,19 @@ class PlanesPlan(object):
     def _launch(self, x, fmt, st, indices):
         l, sp = lib(), stream_ptr()
         zeros = ptr(ops.zero_line(self.device))
+        # the one-launch stem where its frame patches arrive by LDS-DMA (fp16 NHWC, 16-byte aligned rows): the resident serving
+        # format; other formats keep the two launches, whose loaders prefetch (lfd_pl_stem2x takes them too, by plain loads)
+        fused = (self.stem2x is not None and _stem2x_enabled() and
+                 (os.environ.get('LFD_P2_STEM2X') == '2' or (fmt == 1 and st.w % 8 == 0 and x.data_ptr() % 16 == 0)))
         for i in indices:
             o = self.ops[i]
+            if fused and i < 2:
+                if i == 0:
+                    f, c2 = self.stem2x, self.stem2x.tail
+                    dst = st.bufs[f.dst]
+                    check(l.lfd_pl_stem2x(ptr(x), fmt, st.n, st.h, st.w, ptr(f.w1), ptr(f.w2), ptr(f.b2), ptr(c2.w), ptr(c2.b),
+                                          ptr(c2.tail[0]), ptr(c2.tail[1]), ptr(dst), dst[0].numel(), zeros, sp), 'lfd_pl_stem2x')
+                continue
             if o.kind == 'stem':
                 dst = st.bufs[o.dst]
                 check(l.lfd_pl_stem_pair(ptr(x), fmt, st.n, st.h, st.w, o.channels, ptr(o.w1), ptr(o.b1), ptr(o.w2), ptr(o.b2),

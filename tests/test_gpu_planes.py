@@ -247,6 +247,45 @@ def test_pl_stem_pair_vs_float64(fmt, c):
     _close(out, ref, 'stem pair fmt %d c %d' % (fmt, c))
 
 
+@pytest.mark.parametrize('fmt,n,h,w', [(1, 2, 75, 132), (1, 1, 270, 480), (1, 2, 37, 131), (0, 2, 37, 131), (2, 1, 70, 133), (1, 1, 8, 6),
+                                       (1, 3, 129, 258)])
+def test_pl_stem2x_vs_float64(fmt, n, h, w):
+    """the whole 'faster' stem in one launch (lfd_pl_stem2x) against float64 convs on the values the planes hold
+    (lfd_resnet.py:376-413); even-width fp16 frames take the LDS-DMA path, the rest the load path"""
+    g = torch.Generator().manual_seed(fmt * 11 + h)
+    c = 64
+    w1, b1 = torch.randn(c, 3, 3, 3, generator=g) * 0.3, torch.randn(c, generator=g)
+    w2, b2 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
+    w3, b3 = torch.randn(c, c, 3, 3, generator=g) * (1.0 / (9 * c) ** 0.5), torch.randn(c, generator=g)
+    w4, b4 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
+    if fmt == 0:
+        x = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+        xr = x.permute(0, 2, 3, 1)
+    elif fmt == 1:
+        x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half()
+        xr = x.float()
+    else:
+        x = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+        xr = (x.float() / 255 - 0.5) / 0.5
+
+    def rt(t):        # round trip through planes: what the next conv is fed
+        return engine_p2.from_planes(engine_p2.to_planes(t.float())).double()
+    y = _ref_conv(rt(xr), w1, b1, 3, 2, True)
+    y = _ref_conv(rt(y), w2, b2, 1, 1, True)
+    y = _ref_conv(rt(y), w3, b3, 3, 2, True)
+    ref = _ref_conv(rt(y), w4, b4, 1, 1, True)
+    oh, ow = ((h + 1) // 2 + 1) // 2, ((w + 1) // 2 + 1) // 2
+    out = torch.full((2, n, oh, ow, c), float('nan'), dtype=torch.float16, device='cuda')
+    xd = x.cuda()
+    keep = [engine_p2.pack_planes_stem2x_weight(w1, b1).cuda(), engine_p2.pack_planes_stem2x_tail_weight(w2).cuda(),
+            engine_p2._pad_bias(b2).cuda(), engine_p2.pack_planes_weight(w3).cuda(), engine_p2._pad_bias(b3, 128).cuda(),
+            engine_p2.pack_planes_weight(w4).cuda(), engine_p2._pad_bias(b4, 128).cuda()]
+    check(lib().lfd_pl_stem2x(ptr(xd), fmt, n, h, w, *[ptr(k) for k in keep], ptr(out), out[0].numel(), ptr(ops.zero_line(xd.device)),
+                              stream_ptr()), 'lfd_pl_stem2x')
+    torch.cuda.synchronize()
+    _close(out, ref, 'stem2x fmt %d %dx%dx%d' % (fmt, n, h, w))
+
+
 def test_pl_conv_refuses_what_it_has_no_instance_for():
     xp = torch.zeros((2, 1, 8, 8, 64), dtype=torch.float16, device='cuda')
     d = _lib.PlConvDesc()
@@ -290,6 +329,17 @@ def test_planes_plan_equals_the_fp32_tensor_plan(name, shape):
             assert torch.equal(c, c1) and torch.equal(r, r1)
         finally:
             del os.environ['LFD_P2_LEVELS']
+        if plan.stem2x is not None:
+            # the whole 'faster' stem as one launch (lfd_pl_stem2x; the default for resident fp16 frames) on this fp32 input
+            # == the two-launch stem up to the summation order of conv0
+            os.environ['LFD_P2_STEM2X'] = '2'
+            try:
+                cf, rf = m(x)
+                ef = max(float((c - cf).abs().max()), float((r - rf).abs().max()))
+                print('%s: one-launch stem vs two launches %.2e' % (name, ef))
+                assert ef <= 2e-5
+            finally:
+                del os.environ['LFD_P2_STEM2X']
         old = os.environ.get('LFD_P32_PLANES')
         os.environ['LFD_P32_PLANES'] = '0'
         try:
