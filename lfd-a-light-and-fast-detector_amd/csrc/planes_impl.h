@@ -587,8 +587,9 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
       const _Float16* fr = reinterpret_cast<const _Float16*>(P.frame);
       char* lbase = psm + ProdCfg::FRAME_OFF + fb * ProdCfg::FRAME_BYTES;
       constexpr int NI = (ProdCfg::FR + 1) / 2;
+      constexpr int NL = (ProdCfg::FJ + ProdCfg::JUNK - 3 + 7) / 8;      // 16-byte lanes of a row
       const int hcol = fxm * 3 - ProdCfg::JUNK + 3 + 8 * (lane & 31);
-      const bool colok = (lane & 31) < (ProdCfg::FJ + ProdCfg::JUNK - 3 + 7) / 8 && hcol >= 0 && hcol < P.FW * 3;
+      const bool colok = (lane & 31) < NL && hcol >= 0 && hcol < P.FW * 3;
       for (int i = wave; i < NI; i += 4) {
         const int fy = fy0 + 2 * i + (lane >> 5);
         const bool ok = colok && fy >= 0 && fy < P.FH;
