@@ -189,7 +189,10 @@ struct PCfg {
   // the consumed input buffer when it fits there
   static constexpr int SCR_BYTES = 2 * (MID_PLANE > OUT_PLANE ? MID_PLANE : OUT_PLANE);
   static constexpr bool ALIAS = SCR_BYTES <= 2 * IN_BYTES;
-  static constexpr int NBUF = PROD ? 1 : ((S == 1 || (CIN == 64 && KS == 3 && NCT == 2)) ? 2 : 1);
+  // (one 32-cout slab of a 128-channel 1x1 -- the cls / reg output conv: 4 x 32 pixels x 512 B = 64 KB per tile; single-buffered
+  //  it fits a CU twice, and two workgroups hide each other's fetch AND each other's GroupNorm transform; double-buffered at
+  //  one workgroup per CU the launch took 1.8 x as long)
+  static constexpr int NBUF = (PROD || (CIN == 128 && KS == 1 && NCT == 1)) ? 1 : ((S == 1 || (CIN == 64 && KS == 3 && NCT == 2)) ? 2 : 1);
   static constexpr int SCR_OFF = NBUF * 2 * IN_BYTES;
   static constexpr int BIAS_OFF = SCR_OFF + (ALIAS ? 0 : SCR_BYTES);
   // RES: the residual tile (this workgroup's channel slice, both planes) arrives by DMA in copy-out order
@@ -780,6 +783,12 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
   float gn_a[GNIN ? 8 : 1], gn_b[GNIN ? 8 : 1];
   int gnin_n = -1;
   (void)gn_a; (void)gn_b; (void)gnin_n;
+  int n_out32 = 0;          // OUTM 2: output store instructions per 32-pixel tile of this wave
+  if constexpr (OUTM == 2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) n_out32 += (co_base + 8 * (i >> 2) + (i & 3) < a.f_c0 + a.f_c1) ? 1 : 0;
+  }
+  (void)n_out32;
   int t = t_begin + bix;
   int buf = 0;
   bool first = true;
@@ -795,7 +804,28 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
       // every lane issues exactly NST of them (out-of-image lanes into the trash line), vmcnt retires in order
       constexpr int NST = (OUTM == 2) ? 0 : 2 * ((C::OPX * NCT * 4) / 256);
       static_assert(NST == 0 || NST == 4 || NST == 8, "copy-out stores per thread");
-      if (first || NST == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (OUTM == 2) {
+        // fp32 outputs: one store instruction per accumulator register that holds an output channel in either lane half
+        // (n_out32 of them per 32-pixel tile, fixed for the launch) -- waiting for vmcnt(0) here exposed the full write
+        // latency of the previous tile's outputs on every tile (the all-levels output conv: 94 us for 184 MB)
+        switch (n_out32 * PT) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+          case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+          case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+          case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+          case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      }
       else if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       first = false;
@@ -1144,23 +1174,31 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
 
     if constexpr (OUTM == 2) {
       // fp32 outputs straight from the accumulator layout (lane = pixel, registers = channels 8g + 4h + e of the slab)
+      // exactly n_out32 store instructions per 32-pixel tile and wave (the counted wait at the loop top): lanes without an
+      // output -- outside the image, or a channel past the last -- write the trash line
       const float sc1 = a.scale1 ? *a.scale1 : 1.f;
+      const int ctot = a.f_c0 + a.f_c1;
+      float* trash = reinterpret_cast<float*>(const_cast<_Float16*>(a.zeros) + 1024) + (threadIdx.x & 127);
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int oy = ty0 * C::TH + (pg * PT + pt) * C::RPT + oyl;
         const int ox = tx0 * C::TW + oxl;
-        if (oy < a.OH && ox < a.OW) {
-          const size_t pixi = (size_t)oy * a.OW + ox;
+        const bool in_img = oy < a.OH && ox < a.OW;
+        const size_t pixi = in_img ? (size_t)oy * a.OW + ox : 0;
+        float* p0 = a.f_out0 + (size_t)n * a.f_img0 + pixi * a.f_c0;
+        float* p1 = a.f_out1 + (size_t)n * a.f_img1 + pixi * a.f_c1 - a.f_c0;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < 4; ++e) {
+            if (co_base + 8 * g + e < ctot) {          // wave-uniform: the lower lane half's channel of this register
               const int co = co_base + 8 * g + 4 * h + e;
               const float y = comb(accm[pt][4 * g + e], accc[pt][4 * g + e]);
-              if (co < a.f_c0) a.f_out0[(size_t)n * a.f_img0 + pixi * a.f_c0 + co] = y;
-              else if (co < a.f_c0 + a.f_c1) a.f_out1[(size_t)n * a.f_img1 + pixi * a.f_c1 + (co - a.f_c0)] = y * sc1;
+              const bool first_out = co < a.f_c0;
+              float* dst = (in_img && co < ctot) ? (first_out ? p0 : p1) + co : trash;
+              *dst = first_out ? y : y * sc1;
             }
-        }
+          }
       }
       continue;
     }
