@@ -803,3 +803,62 @@ def test_planes_plan_covers_the_shipped_configurations(name):
     # the stage entries carry their identity branch, the closing conv of every block its residual
     assert sum(o.ds is not None for o in convs) == sum(1 for i in range(len(m._backbone._body_architecture)))
     assert sum(o.res is not None for o in convs) == sum(m._backbone._body_architecture)
+
+
+def test_planes_plan_groups_the_head_by_level_and_fuses_the_faster_stem():
+    """engine_p2: one lfd_pl_conv2d_levels launch per head conv over all pyramid levels (split where the neck's input width
+    differs), producers of GroupNorm sums in earlier launches than their consumers; the 4-conv 64-channel stem gets the
+    one-launch form (lfd_pl_stem2x), the XS model (32 channels) keeps two launches."""
+    from lfd_amd import engine_p2
+    m = configs.build_model('WIDERFACE_LFD_S').eval()
+    plan = engine_p2.PlanesPlan(m, torch.device('cpu'))
+    nl = len(plan.level_ops)
+    assert plan.stem2x is not None and plan.stem2x.tail is plan.ops[1] and plan.ops[1].tail is not None
+    assert tuple(plan.stem2x.w1.shape) == (2, 2, 2, 64, 8) and tuple(plan.stem2x.w2.shape) == (2, 2, 4, 64, 8)
+    groups = plan.level_groups
+    assert groups is not None and sorted(i for g in groups for i in g) == list(range(plan.head_start, len(plan.ops)))
+    assert len(groups) < len(plan.ops) - plan.head_start and max(len(g) for g in groups) == nl
+    seen = set()
+    for g in groups:
+        sig = {(plan.ops[i].cin, plan.ops[i].cout, plan.ops[i].out_mode, plan.ops[i].tail is not None) for i in g}
+        assert len(sig) == 1                                       # one kernel instance per launch
+        for i in g:
+            if plan.ops[i].gnin is not None:
+                assert plan.ops[i].gnin[0] in seen                 # its producer ran in an earlier launch
+        seen |= {plan.ops[i].gn for i in g if plan.ops[i].gn is not None}
+    xs = engine_p2.PlanesPlan(configs.build_model('WIDERFACE_LFD_XS').eval(), torch.device('cpu'))
+    assert xs.stem2x is None and xs.level_groups is not None
+
+
+def test_fused_stem_weight_packings_reproduce_the_convs_through_the_kernel_s_k_order():
+    """pack_planes_stem2x_weight / pack_planes_stem2x_tail_weight (lfd_pl_stem2x): emulate what the kernel feeds the matrix
+    core -- conv0's B fragment gathered as aligned dwords of the patch rows (a junk half in front, the constant-one slot), the
+    32x32 accumulator layout re-used as the 1x1's B fragment -- and contract it with the packed A fragments: == the convs."""
+    from lfd_amd import engine_p2
+    g = torch.Generator().manual_seed(3)
+    w1, b1 = torch.randn(64, 3, 3, 3, generator=g), torch.randn(64, generator=g)
+    w2 = torch.randn(64, 64, 1, 1, generator=g)
+    p1 = engine_p2.pack_planes_stem2x_weight(w1, b1)
+    p2 = engine_p2.pack_planes_stem2x_tail_weight(w2)
+    a1 = (p1[0].double() + p1[1].double() / 2048).reshape(2, 2, 2, 32, 8)          # [slab][step][half][co][j]
+    patch = torch.randn(3, 10, generator=g).double()       # 3 frame rows x [junk, e0..e8], e = 3 dx + c
+    ref0 = torch.einsum('ocrs,rsc->o', w1.double(), patch[:, 1:].reshape(3, 3, 3)) + b1.double()
+    frag = torch.zeros(2, 2, 8, dtype=torch.float64)        # [step][half][j]: the gather of csrc/planes_impl.h produce()
+    frag[0, 0], frag[0, 1], frag[1, 0] = patch[0, :8], patch[2, :8], patch[1, :8]
+    frag[1, 1] = torch.stack([patch[0, 8], patch[0, 9], patch[1, 8], patch[1, 9], patch[2, 8], patch[2, 9], torch.tensor(1.0, dtype=torch.float64),
+                              torch.tensor(123.0, dtype=torch.float64)])      # (the pad slot's activation is arbitrary)
+    got0 = torch.einsum('tshoj,shj->to', a1, frag).reshape(64)
+    assert float((got0 - ref0).abs().max()) <= 2e-5
+    # the 1x1: lane (h, pixel) of slab s holds channels 32 s + 8 g + 4 h + e; k-step q = 2 s + u takes g = 2 u, 2 u + 1
+    y = torch.randn(64, generator=g).double()
+    ref1 = w2.double().reshape(64, 64) @ y
+    a2 = (p2[0].double() + p2[1].double() / 2048).reshape(2, 4, 2, 32, 8)          # [slab][q][h'][co][j]
+    frag2 = torch.zeros(4, 2, 8, dtype=torch.float64)
+    for q in range(4):
+        s_, u = divmod(q, 2)
+        for hh in range(2):
+            for j in range(8):
+                gg, e = 2 * u + j // 4, j % 4
+                frag2[q, hh, j] = y[32 * s_ + 8 * gg + 4 * hh + e]
+    got1 = torch.einsum('tqhoj,qhj->to', a2, frag2).reshape(64)
+    assert float((got1 - ref1).abs().max()) <= 2e-5
