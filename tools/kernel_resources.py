@@ -21,9 +21,15 @@ def demangle(names):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
     rows = []
+    # the flags the library is built with: csrc/Makefile's FLAGS plus the per-file FLAGS_<name> (e.g. -amdgpu-mfma-vgpr-form=1 for the
+    # one-wave-per-SIMD kernels: without it the fused stem reports 164 B of scratch that the shipped object does not have)
+    mk = open(os.path.join(CSRC, 'Makefile')).read()
+    per_file = {m.group(1): m.group(2).split() for m in re.finditer(r'^FLAGS_(\w+)\s*=\s*(.*)$', mk, re.M)}
     for src in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
-        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-DLFD_BUILDING', '-I' + os.path.join(ROOT, 'include'),
-                            '-c', src, '-o', '/dev/null', '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+        base = os.path.splitext(os.path.basename(src))[0]
+        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
+                            '-DLFD_BUILDING', '-I' + os.path.join(ROOT, 'include')] + per_file.get(base, []) +
+                           ['-c', src, '-o', '/dev/null', '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
         cur = None
         for line in r.stderr.split('\n'):
             m = re.search(r'remark: (?:\[[^\]]*\] )?\s*(Function Name|SGPRs|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\S+)', line)
@@ -36,7 +42,7 @@ def main():
             elif cur is not None:
                 cur[k] = v
     names = demangle([r_['name'] for r_ in rows])
-    lines = ['# compiler-reported resources of every kernel (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage; tools/kernel_resources.py)',
+    lines = ['# compiler-reported resources of every kernel, compiled with the flags of csrc/Makefile incl. the per-file ones (-Rpass-analysis=kernel-resource-usage; tools/kernel_resources.py)',
              '# file | kernel | VGPRs | AGPRs | SGPRs | VGPR spill | scratch B/lane | LDS B/block (static) | occupancy waves/SIMD']
     for r_, n in zip(rows, names):
         n = re.sub(r'\(.*', '', n) if len(n) > 110 else n
