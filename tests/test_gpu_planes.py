@@ -286,6 +286,71 @@ def test_pl_stem2x_vs_float64(fmt, n, h, w):
     _close(out, ref, 'stem2x fmt %d %dx%dx%d' % (fmt, n, h, w))
 
 
+def test_pl_conv2d_levels_equals_one_launch_per_level_and_validates_its_arguments():
+    """lfd_pl_conv2d_levels at the C ABI: three feature maps of different sizes with their own filters in one launch ==
+    lfd_pl_conv2d per level, bit for bit (planes and the fixed-point GroupNorm sums); one level; argument checks"""
+    n = 2
+    shapes = [(23, 41), (12, 21), (1, 3)]
+    g = torch.Generator().manual_seed(17)
+    per_level, keep = [], []
+    arr = (_lib.PlLevel * len(shapes))()
+    for j, (h, w) in enumerate(shapes):
+        _, xp, xv, wt, b = _inputs(40 + j, n, h, w, 128, 128, 1)
+        sums = torch.zeros((_lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device='cuda')
+        ref_out, _ = _pl_conv(xp, wt, b, 1, 1, False, gn=sums)
+        out = torch.full_like(ref_out, float('nan'))
+        sums_ml = torch.zeros_like(sums)
+        wp, bp = engine_p2.pack_planes_weight(wt).cuda(), engine_p2._pad_bias(b, 128).cuda()
+        keep += [xp, wp, bp, out, sums_ml]
+        lv = arr[j]
+        lv.in_, lv.out, lv.w_packed, lv.bias, lv.gn_sums = xp.data_ptr(), out.data_ptr(), wp.data_ptr(), bp.data_ptr(), sums_ml.data_ptr()
+        lv.h, lv.w, lv.in_plane_halfs, lv.out_plane_halfs = h, w, xp[0].numel(), out[0].numel()
+        per_level.append((ref_out, sums, out, sums_ml))
+    d = _lib.PlConvDesc()
+    d.n, d.cin, d.cout, d.ks, d.stride, d.relu, d.out_mode = n, 128, 128, 1, 1, 0, 1
+    z = ops.zero_line(torch.device('cuda'))
+    check(lib().lfd_pl_conv2d_levels(C.byref(d), arr, len(shapes), ptr(z), stream_ptr()), 'lfd_pl_conv2d_levels')
+    torch.cuda.synchronize()
+    for ref_out, sums, out, sums_ml in per_level:      # (which replica a workgroup adds to depends on the grid: their SUM is the statistic)
+        assert torch.equal(out, ref_out) and torch.equal(sums_ml.sum(0), sums.sum(0))
+    # a single level is a valid call
+    per_level[0][2].fill_(float('nan'))
+    per_level[0][3].zero_()
+    check(lib().lfd_pl_conv2d_levels(C.byref(d), arr, 1, ptr(z), stream_ptr()), 'lfd_pl_conv2d_levels')
+    torch.cuda.synchronize()
+    assert torch.equal(per_level[0][2], per_level[0][0]) and torch.equal(per_level[0][3].sum(0), per_level[0][1].sum(0))
+    # argument checks: LFD_ERR_INVALID_ARGUMENT (-1) / LFD_ERR_UNSUPPORTED (-4), nothing launched
+    assert lib().lfd_pl_conv2d_levels(C.byref(d), arr, 0, ptr(z), stream_ptr()) == -1
+    assert lib().lfd_pl_conv2d_levels(C.byref(d), arr, _lib.MAX_LEVELS + 1, ptr(z), stream_ptr()) == -1
+    assert lib().lfd_pl_conv2d_levels(C.byref(d), None, 1, ptr(z), stream_ptr()) == -1
+    d.ks = 3
+    assert lib().lfd_pl_conv2d_levels(C.byref(d), arr, len(shapes), ptr(z), stream_ptr()) == -4
+    d.ks = 1
+    saved = arr[1].gn_sums
+    arr[1].gn_sums = None                      # out_mode 1 without sums
+    assert lib().lfd_pl_conv2d_levels(C.byref(d), arr, len(shapes), ptr(z), stream_ptr()) == -1
+    arr[1].gn_sums = saved
+    d.cout = 96                                # no instance
+    assert lib().lfd_pl_conv2d_levels(C.byref(d), arr, len(shapes), ptr(z), stream_ptr()) == -4
+
+
+def test_pl_stem2x_validates_its_arguments():
+    x = torch.zeros((1, 16, 16, 3), dtype=torch.float16, device='cuda')
+    w = torch.zeros(1 << 16, dtype=torch.float16, device='cuda')
+    b = torch.zeros(128, device='cuda')
+    out = torch.zeros((2, 1, 4, 4, 64), dtype=torch.float16, device='cuda')
+    z = ops.zero_line(x.device)
+    L = lib()
+    args = lambda fmt=1, xin=x, o=out, plane=None: (ptr(xin), fmt, 1, 16, 16, ptr(w), ptr(w), ptr(b), ptr(w), ptr(b), ptr(w), ptr(b), ptr(o),   # noqa: E731
+                                                     o[0].numel() if plane is None else plane, ptr(z), stream_ptr())
+    assert L.lfd_pl_stem2x(*args()) == 0
+    assert L.lfd_pl_stem2x(*args(fmt=7)) == -1
+    assert L.lfd_pl_stem2x(*args(plane=out[0].numel() + 4)) == -1          # plane stride not a multiple of 8 halfs
+    assert L.lfd_pl_stem2x(None, 1, 1, 16, 16, ptr(w), ptr(w), ptr(b), ptr(w), ptr(b), ptr(w), ptr(b), ptr(out), out[0].numel(), ptr(z),
+                           stream_ptr()) == -1
+    torch.cuda.synchronize()
+
+
 def test_pl_conv_refuses_what_it_has_no_instance_for():
     xp = torch.zeros((2, 1, 8, 8, 64), dtype=torch.float16, device='cuda')
     d = _lib.PlConvDesc()
