@@ -543,7 +543,8 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  *   f_image_stride0 / 1, gn_in_eps; ks = stride = 1; desc->h / w / *_plane_halfs unused) over num_levels <= LFD_MAX_LEVELS
  *   feature maps in ONE launch -- simple_neck.py:67-74 + lfd_head.py:164-185 apply the same conv stack to every pyramid
  *   level, each level with its own filters; levels[i] carries what lfd_pl_conv2d takes per call.  Results are identical to
- *   num_levels lfd_pl_conv2d calls (same arithmetic per tile; the GroupNorm sums are order-independent integers).
+ *   num_levels lfd_pl_conv2d calls: same arithmetic per tile; the GroupNorm sums are order-independent integers (which
+ *   REPLICA a workgroup adds to depends on the grid -- the statistic is the sum over the replicas).
  * lfd_pl_groupnorm_relu: x (planes [n, hw, c]) <- relu?(GroupNorm(c/8 groups)(x) * gamma + beta) in place, mean / rstd in
  *   fp64 from gn_sums (lfd_head.py:97-117 conv -> GroupNorm -> ReLU). */
 #define LFD_PL_GN_REPLICAS 8   /* gn_sums holds this many replicas of [n][cout/8][2]: a producer spreads its atomics, consumers add */
