@@ -336,7 +336,7 @@ def test_pl_conv2d_levels_equals_one_launch_per_level_and_validates_its_argument
 
 def test_pl_stem2x_validates_its_arguments():
     x = torch.zeros((1, 16, 16, 3), dtype=torch.float16, device='cuda')
-    w = torch.zeros(1 << 16, dtype=torch.float16, device='cuda')
+    w = torch.zeros(1 << 17, dtype=torch.float16, device='cuda')       # >= the largest packed filter (3x3 64 -> 64: 73,728 halfs)
     b = torch.zeros(128, device='cuda')
     out = torch.zeros((2, 1, 4, 4, 64), dtype=torch.float16, device='cuda')
     z = ops.zero_line(x.device)
