@@ -2,6 +2,10 @@
 (forward + per-location decode + score threshold + NMS, results left resident on the device),
 synthetic 1920x1080 frames, batch 8 per GPU, fp16 NHWC input already resident in HBM.
 
+`value` is quoted in LFD.precision = 'fp32_storage' -- the precision mode whose cls / bbox tensors are within north_star's
+1e-3 of the reference's fp32 path (raw logits <= 1e-4, tests/test_gpu_precise.py).  Rounds 1-5 quoted it in the 'fp16' mode
+(sigma within 2.5e-3: outside that tolerance); that mode is still measured, by the same timed region, under `fp16_mode`.
+
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -35,6 +39,9 @@ NBUF = 4                  # distinct resident frame buffers rotated through the 
 TARGET_K = 256            # candidates per image (SURVEY 8d "sparse-realistic" load), IoU 0.4
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+HEADLINE_MODE = 'fp32_storage'   # the precision mode `value` is quoted in: the one inside north_star's 1e-3 (round 6)
+PMC_SOURCE_PRECISE = ('profiles/pmc_traffic_precise.json: HBM bytes per launch of the fp32_storage kernels (FETCH_SIZE x 2 + WRITE_SIZE, separate '
+                      'rocprofv3 --pmc passes, tools/collect_profiles_p2.sh) committed with the kernels -- not re-measured on this box')
 PMC_SOURCE = ('profiles/pmc_traffic.json: HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, '
               'tools/collect_profiles.sh) committed with the kernels -- a constant of the code, not re-measured on this box')
 
@@ -43,9 +50,10 @@ def conv_flops(n, oh, ow, cin, cout, ks):
     return 2.0 * n * oh * ow * cin * cout * ks * ks
 
 
-def kernel_breakdown(model, plan, st, x, fmt, reps=20):
+def kernel_breakdown(model, plan, st, x, fmt, reps=20, timer=None):
     """Times every launch of the plan with HIP events on the launch stream (torch's current
-    stream is the stream the C ABI receives).  Returns {class: dict(time_us, launches, flops, bytes)}."""
+    stream is the stream the C ABI receives).  Returns {class: dict(time_us, launches, flops, bytes)}.
+    `timer(fn) -> us` replaces the HIP-event loop (tools/power_trace_r6.py: seconds of back-to-back launches under rocm-smi)."""
     import ctypes as C
     from lfd_amd import _lib, engine, ops
     from lfd_amd._lib import check, lib, ptr, stream_ptr
@@ -53,7 +61,9 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
     z = ops.zero_line(plan.device)
     classes = {}
 
-    def timed(fn):
+    def timed(fn, label=''):
+        if timer is not None:
+            return timer(fn, label)
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,7 +88,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
         h1, w1_ = (st.h + 1) // 2, (st.w + 1) // 2
         us = timed(lambda: check(l.lfd_stem_faster_fused_f16(ptr(x), fmt, n, st.h, st.w, c0, ptr(w1), ptr(b1), ptr(w2),
                                                              ptr(b2), ptr(w3), ptr(b3), ptr(w4), ptr(b4), ptr(so),
-                                                             stream_ptr()), 'stem'))
+                                                             stream_ptr()), 'stem'), 'k_stem2x 8x1080p')
         fl = (conv_flops(n, h1, w1_, 3, c0, 3) + conv_flops(n, h1, w1_, c0, c0, 1) +
               conv_flops(n, so.shape[1], so.shape[2], c0, c0, 3) + conv_flops(n, so.shape[1], so.shape[2], c0, c0, 1))
         add('whole faster-stem fused: 3x3s2+1x1+3x3s2+1x1 (k_stem2x)', us, fl, x.numel() * x.element_size() + so.numel() * 2)
@@ -101,7 +111,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             dst2 = st.bufs[c2.dst]
             us = timed(lambda: check(l.lfd_downblock_fused_f16(n, src.shape[1], src.shape[2], ptr(src), ptr(dst2), ptr(c.w), ptr(c.b),
                                                                ptr(c.ds[0]), ptr(c.ds[1]), ptr(c2.w), ptr(c2.b), ptr(z), stream_ptr()),
-                                     'downblock'))
+                                     'downblock'), 'k_down64 -> %dx%d' % (dst2.shape[1], dst2.shape[2]))
             fl = (conv_flops(n, dst2.shape[1], dst2.shape[2], 64, 64, 3) * 2 + conv_flops(n, dst2.shape[1], dst2.shape[2], 64, 64, 1))
             add('downblock_fused_conv3x3_s2+1x1_s2+conv3x3_s1_64to64 (k_down64)', us, fl, (src.numel() + dst2.numel()) * 2)
             skip = c.down
@@ -112,7 +122,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             c2 = plan.convs[c.blk128]
             dst2 = st.bufs[c2.dst]
             us = timed(lambda: check(l.lfd_fasterblock128_fused_f16(n, src.shape[1], src.shape[2], ptr(src), ptr(dst2), ptr(c.w), ptr(c.b),
-                                                                    ptr(c2.w), ptr(c2.b), stream_ptr()), 'block128'))
+                                                                    ptr(c2.w), ptr(c2.b), stream_ptr()), 'block128'), 'k_block128 %dx%d' % (dst2.shape[1], dst2.shape[2]))
             add('fasterblock128_fused_2x_conv3x3_s1_128to128 small map (k_block128)', us,
                 2 * conv_flops(n, dst2.shape[1], dst2.shape[2], 128, 128, 3), (src.numel() + dst2.numel()) * 2 + 2 * 128 * 128 * 9 * 2)
             skip = c.blk128
@@ -131,7 +141,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
                                                      ptr(st.bufs[c.res]) if c.res is not None else None,
                                                      ptr(c.tail[0]) if c.tail else None, ptr(c.tail[1]) if c.tail else None,
                                                      ptr(z), stream_ptr()), 'conv')
-        us = timed(fn)
+        us = timed(fn, '%s %d->%d k%d s%d -> %dx%d' % ('k_block64(_rows)' if c.blk is not None else 'k_conv', c.cin, c.cout, c.ks, c.stride, dst.shape[1], dst.shape[2]))
         fl = conv_flops(n, dst.shape[1], dst.shape[2], c.cin, c.cout, c.ks)
         if c.ds is not None:
             fl += conv_flops(n, dst.shape[1], dst.shape[2], c.cin, c.cout, 1)
@@ -153,7 +163,7 @@ def kernel_breakdown(model, plan, st, x, fmt, reps=20):
             by = (src.numel() + dst.numel()) * 2
             name = 'fasterblock_fused_2x_conv3x3_s1_64to64 (k_block64_rows on large maps, k_block64 on small ones)'
         add(name, us, fl, by)
-    us = timed(lambda: plan.run_head(st))
+    us = timed(lambda: plan.run_head(st), 'neck+head: k_head2 x3 + k_gn_finalize x2')
     hf = 0.0
     hb = 0.0
     for lv, (hh, ww) in zip(plan.levels, st.sizes):
@@ -374,7 +384,8 @@ def other_configs_bench(dev):
     """BASELINE.json configs[2] and configs[3] on ONE GPU, extra key `configs` (the headline stays configs[1]):
       config3  WIDERFACE_LFD_L, one 3840x2160 frame                     (large-activation path)
       config4  TT100K_LFD_L, 4 x 1280x720 = one GPU's share of bs 32 / 8 GPUs, 45 classes, softmax scores, per-class NMS
-    Each: the whole step (forward + decode + NMS) as one HIP graph, HIP-event median; network-only forward; the dominant
+    Each in BOTH precision modes (round 6: the top-level figures are the headline mode's, 'fp32_storage'; the 'fp16' mode's under
+    `fp16`): the whole step (forward + decode + NMS) as one HIP graph, HIP-event median; network-only forward; the dominant
     kernel class with its roofline fraction (same live per-launch timing as the headline's `kernels`)."""
     from lfd_amd import configs, engine
     out = {}
@@ -389,32 +400,55 @@ def other_configs_bench(dev):
         gen = torch.Generator(device=dev).manual_seed(3)
         x = (torch.rand(n, h, w, 3, device=dev, generator=gen) * 2 - 1).half()
         meta = torch.tensor([[float(w), float(h), 1.0]] * n, dtype=torch.float32, device=dev)
-        cls, reg = m.forward_resident(x)
-        sc = (cls[0].float().softmax(-1)[:, :-1] if ce else cls[0].float().sigmoid()).max(-1).values
-        m._classification_threshold = float(torch.quantile(sc[:4_000_000], 1.0 - k_cand / sc.numel()))
         m._nms_cfg = dict(type='nms', iou_thr=0.4 if not ce else 0.1)
-        fwd_ms = _event_median_ms(lambda: m.forward_resident(x), 5, warm=1)
-        m.use_graph = True
-        step_ms = _event_median_ms(lambda: m.detect_resident(x, meta), reps)
-        counts = m.detect_resident(x, meta).counts.cpu().numpy()
-        fmt, n_, h_, w_ = engine._input_format(x)
-        plan = engine.get_plan(m, m._backbone, m._neck, m._head, dev)
-        br = kernel_breakdown(m, plan, plan.state_for(n_, h_, w_), x, fmt, reps=5)
-        tot = sum(c['time_us'] for c in br.values())
-        nm, c = max(br.items(), key=lambda kv: kv[1]['time_us'])
-        tf, gb = c['flops'] / c['time_us'] / 1e6, c['bytes'] / c['time_us'] / 1e3
-        gflop = sum(c_['flops'] for c_ in br.values()) / 1e9
-        out[key] = dict(workload='%s %d x %dx%d fp16 NHWC resident, forward + decode + NMS (one HIP graph)' % (name, n, w, h),
-                        ms_per_step=round(step_ms, 4), images_per_s=round(n / step_ms * 1e3, 1),
-                        forward_eager_ms=round(fwd_ms, 4), kernel_sum_us=round(tot, 1), gflop_per_step=round(gflop, 1),
-                        frac_mfma_whole_step=round(gflop / step_ms / MFMA_PEAK_TFLOPS, 4),
-                        points_per_image=int(cls.shape[1]), candidates_per_image=float(counts[:, 0].mean()),
-                        kept_per_image=float(counts[:, 1].mean()), overflow=int(counts[:, 2].max()),
-                        roofline=dict(kernel=nm, bound='mfma' if tf / MFMA_PEAK_TFLOPS >= gb / HBM_PEAK_GBS else 'hbm',
-                                      tflops=round(tf, 1), gbs=round(gb, 0), frac_mfma=round(tf / MFMA_PEAK_TFLOPS, 3),
-                                      frac_hbm=round(gb / HBM_PEAK_GBS, 3), share_of_forward=round(c['time_us'] / tot, 3),
-                                      avg_launch_us=round(c['time_us'] / c['launches'], 2)))
-        del m, x, cls, reg, plan, br
+        res = {}
+        for mode in (HEADLINE_MODE, 'fp16'):
+            m.precision = mode
+            m.use_graph = False
+            cls, reg = m.forward_resident(x)
+            sc = (cls[0].float().softmax(-1)[:, :-1] if ce else cls[0].float().sigmoid()).max(-1).values
+            m._classification_threshold = float(torch.quantile(sc[:4_000_000], 1.0 - k_cand / sc.numel()))
+            fwd_ms = _event_median_ms(lambda: m.forward_resident(x), 5, warm=1)
+            m.use_graph = True
+            step_ms = _event_median_ms(lambda: m.detect_resident(x, meta), reps)
+            counts = m.detect_resident(x, meta).counts.cpu().numpy()
+            d = dict(ms_per_step=round(step_ms, 4), images_per_s=round(n / step_ms * 1e3, 1), forward_eager_ms=round(fwd_ms, 4),
+                     points_per_image=int(cls.shape[1]), candidates_per_image=float(counts[:, 0].mean()),
+                     kept_per_image=float(counts[:, 1].mean()), overflow=int(counts[:, 2].max()))
+            if mode == 'fp16':
+                fmt, n_, h_, w_ = engine._input_format(x)
+                plan = engine.get_plan(m, m._backbone, m._neck, m._head, dev)
+                br = kernel_breakdown(m, plan, plan.state_for(n_, h_, w_), x, fmt, reps=5)
+                tot = sum(c['time_us'] for c in br.values())
+                nm, c = max(br.items(), key=lambda kv: kv[1]['time_us'])
+                tf, gb = c['flops'] / c['time_us'] / 1e6, c['bytes'] / c['time_us'] / 1e3
+                gflop = sum(c_['flops'] for c_ in br.values()) / 1e9
+                d.update(kernel_sum_us=round(tot, 1), gflop_per_step=round(gflop, 1), frac_mfma_whole_step=round(gflop / step_ms / MFMA_PEAK_TFLOPS, 4),
+                         roofline=dict(kernel=nm, bound='mfma' if tf / MFMA_PEAK_TFLOPS >= gb / HBM_PEAK_GBS else 'hbm',
+                                       tflops=round(tf, 1), gbs=round(gb, 0), frac_mfma=round(tf / MFMA_PEAK_TFLOPS, 3),
+                                       frac_hbm=round(gb / HBM_PEAK_GBS, 3), share_of_forward=round(c['time_us'] / tot, 3),
+                                       avg_launch_us=round(c['time_us'] / c['launches'], 2)))
+                del plan, br
+            else:
+                try:
+                    rows = precise_breakdown(m, x, dev, reps=5)
+                except Exception as e:      # (a layer shape without a plane kernel: the fp32-tensor plan has no per-class table)
+                    rows = None
+                    d['kernels_error'] = repr(e)
+                if rows:
+                    tot = sum(r['time_us_per_forward'] for r in rows)
+                    r0 = rows[0]
+                    d.update(kernel_sum_us=round(tot, 1),
+                             head_share_of_forward=round(sum(r['time_us_per_forward'] for r in rows if r['kernel'].startswith('neck + head')) / tot, 3),
+                             roofline=dict(kernel=r0['kernel'], bound=r0['bound'], achieved=r0['achieved'], peak=r0['peak'], unit=r0['unit'],
+                                           frac=r0['frac'], frac_mfma_issued=r0['frac_mfma_issued'], frac_hbm=r0['frac_hbm'],
+                                           share_of_forward=round(r0['time_us_per_forward'] / tot, 3), avg_launch_us=r0['avg_launch_us']))
+            res[mode] = d
+            del cls, reg
+        out[key] = dict(workload='%s %d x %dx%d fp16 NHWC frames resident, forward + decode + NMS (one HIP graph)' % (name, n, w, h),
+                        precision_mode=HEADLINE_MODE, **res[HEADLINE_MODE])
+        out[key]['fp16'] = res['fp16']
+        del m, x
         torch.cuda.empty_cache()
     return out
 
@@ -458,7 +492,7 @@ def stress_and_small_frame_bench(model, x, meta, dev, cls):
     return out
 
 
-def precise_breakdown(model, x, dev, reps=20):
+def precise_breakdown(model, x, dev, reps=20, timer=None):
     """Per-launch HIP-event times of the planes plan (eager, one launch at a time on the current stream), grouped by kernel
     class, with the ALGORITHMIC conv FLOPs (2 MAC; the hi/lo products are an implementation detail: x3 issued) and bytes
     (both planes of every tensor read / written once) -> roofline entries of the tolerance-compliant mode."""
@@ -527,13 +561,16 @@ def precise_breakdown(model, x, dev, reps=20):
         units.append((key, fl, by, 1, (lambda i=i: plan._launch(x, fmt, st, [i]))))
         i += 1
     for key, fl, by, nl, fn in units:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for e0, e1 in evs:
-            e0.record()
-            fn()
-            e1.record()
-        torch.cuda.synchronize()
-        us = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
+        if timer is not None:       # (tools/power_trace_r6.py: seconds of back-to-back launches under rocm-smi)
+            us = timer(fn, key)
+        else:
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in evs:
+                e0.record()
+                fn()
+                e1.record()
+            torch.cuda.synchronize()
+            us = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e3
         g = groups.setdefault(key, dict(launches=0, time_us=0.0, flops=0.0, bytes=0.0))
         g['launches'] += nl
         g['time_us'] += us
@@ -553,104 +590,42 @@ def precise_breakdown(model, x, dev, reps=20):
     return rows
 
 
-def precise_bench(model, x, meta, dev, steps=40, depth=int(os.environ.get('LFD_PRECISE_DEPTH', '2'))):
-    """The shipped tolerance-compliant precision mode (LFD.precision = 'fp32_storage': raw logits within 1e-4 of the fp32
-    reference, tests/test_gpu_precise.py) on the headline workload, measured like the headline: the whole step one HIP graph,
-    `depth` (2) batches in flight on as many HIP streams with their own buffers (wall clock over `steps` steps), next to the strictly
-    serial HIP-event median and the bs-1 end-to-end latency."""
-    out = {}
-    keep_g = model.use_graph
-    model.precision = 'fp32_storage'
-    try:
-        model.use_graph = True
-        ms = _event_median_ms(lambda: model.detect_resident(x, meta), 10, warm=2)
-        # two batches in flight (distinct frame buffers, buffer slots 0 / 1), as the fp16 headline runs
-        xs = [x] + [x.clone() for _ in range(depth - 1)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-
-        def step(i):
-            with torch.cuda.stream(streams[i % depth]):
-                return model.detect_resident(xs[i % depth], meta, slot=i % depth)
-        torch.cuda.synchronize()
-        ref = [step(b) for b in range(depth)]
-        torch.cuda.synchronize()
-        snap = [(o.counts.clone(), o.dets.clone()) for o in ref]
-        for i in range(3 * depth):
-            step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        torch.cuda.synchronize()
-        ms_pipe = (time.perf_counter() - t0) / steps * 1e3
-        for b in range(depth):      # overlapped steps == the same step alone
-            o = step(b)
-            torch.cuda.synchronize()
-            assert torch.equal(o.counts, snap[b][0]) and torch.equal(o.dets, snap[b][1]), 'overlapped precise steps disagree'
-        x1 = x[:1].contiguous()
-        meta1 = meta[:1].contiguous()
-        for _ in range(3):
-            model.detect_resident(x1, meta1)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(50):
-            t0 = time.perf_counter()
-            model.detect_resident(x1, meta1)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        ts = np.sort(np.array(ts)) * 1e3
-        from lfd_amd import engine_p2, engine_p32
-        planes = isinstance(engine_p32.get_plan(model, x.device), engine_p2.PlanesPlan)
-        out = dict(mode="LFD.precision = 'fp32_storage': inter-layer tensors as fp16 hi + 2^-11 lo planes (the bytes of fp32), "
-                        "weights split the same way, 3 MFMAs per k-step on weights-stationary LDS-DMA kernels, fp32 epilogues, "
-                        "GroupNorm from order-independent fixed-point sums (csrc/planes.hip, planes_c3.hip)" if planes else
-                        "LFD.precision = 'fp32_storage': fp32 NHWC tensors, one launch per conv (csrc/precise.hip)",
-                   ms_per_step_bs8=round(ms_pipe, 4), images_per_s_bs8=round(x.size(0) / ms_pipe * 1e3, 1),
-                   pipeline_depth=depth, ms_per_step_bs8_serial=round(ms, 4), images_per_s_bs8_serial=round(x.size(0) / ms * 1e3, 1),
-                   end_to_end_bs1_ms={'p50': round(float(ts[len(ts) // 2]), 4), 'min': round(float(ts[0]), 4)},
-                   mfma_tflops_issued=round(3 * 348.8 / ms_pipe, 1),
-                   parity='raw logits <= 1e-4, sigma <= 1e-3 vs the fp32 oracle at configs 2 / 3 / 4 (tests/test_gpu_precise.py); the '
-                          "reference's config-1 end-to-end rows (1148 / 314) reproduced with 0 unmatched (tests/test_gpu_end2end.py)")
-        try:
-            rows = precise_breakdown(model, x, dev)
-            if rows:
-                out['kernels'] = rows
-                out['roofline'] = {k: rows[0][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us')}
-                out['roofline']['traffic'] = None
-                out['roofline']['note'] = ('dominant kernel class of this mode; ALGORITHMIC flops / bytes over the live HIP-event '
-                                           'duration (the three hi/lo MFMA products per k-step issue 3 x the algorithmic flops)')
-        except Exception as e:
-            out['kernels'] = {'error': repr(e)}
-    finally:
-        model.precision = 'fp16'
-        model.use_graph = keep_g
-    return out
-
-
 def compact_line(r):
-    """the contract keys + roofline + cpu_baseline + serial figures, <= ~1.8 KB"""
-    keys = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-            'dtype', 'data', 'ms_per_step_serial', 'images_per_s_serial', 'pipeline_depth', 'ranks_seen')
-    c = {k: r[k] for k in keys if k in r}
+    """the contract keys + roofline + cpu_baseline + serial / sustained figures + one-line summaries of the extra keys, < 2 KB"""
+    keys = ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'precision_mode', 'ms_per_step_serial', 'images_per_s_serial', 'pipeline_depth', 'ranks_seen')
+    c = {'metric': "images/sec WIDERFACE-S 1920x1080 bs=8 end-to-end inference, LFD.precision='fp32_storage' (raw logits within 1e-4 of fp32: "
+                   "inside north_star's 1e-3; the 'fp16' mode, sigma 2.5e-3, under fp16_mode)"}
+    c.update({k: r[k] for k in keys if k in r})
+    su = r.get('images_per_s_sustained') or {}
+    c['images_per_s_sustained'] = {k: (su.get(k) or {}).get('images_per_s') for k in ('pipelined', 'serial')}
     cfg = r.get('config', {})
-    c['config'] = {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16', 'global_batch': cfg.get('global_batch'),
+    c['config'] = {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16 frames', 'global_batch': cfg.get('global_batch'),
                    'parallelism': cfg.get('parallelism'), 'hip_graph': cfg.get('hip_graph')}
     ev = r.get('step_ms_hip_events') or {}
     c['step_ms_hip_events'] = {k: ev.get(k) for k in ('median', 'p95')}
     rf = r.get('roofline') or {}
-    c['roofline'] = {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us')}
+    c['roofline'] = {k: (rf.get(k)[:60] if k == 'kernel' and rf.get(k) else rf.get(k))
+                     for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_mfma_issued', 'traffic', 'avg_launch_us')}
     for k in ('roofline_conv3x3_s1_64', 'roofline_backbone_3x3'):
         if k in r:
-            c[k] = {'frac': r[k].get('frac'), 'achieved': r[k].get('achieved')}
+            c[k] = {'frac': r[k].get('frac'), 'frac_mfma_issued': r[k].get('frac_mfma_issued')}
     cb = r.get('cpu_baseline')
-    c['cpu_baseline'] = None if not cb else {k: (cb.get(k)[:110] if k == 'sample' and cb.get(k) else cb.get(k))
+    c['cpu_baseline'] = None if not cb else {k: (cb.get(k)[:90] if k == 'sample' and cb.get(k) else cb.get(k))
                                                for k in ('value', 'unit', 'cores', 'kind', 'sample')}
-    p = r.get('precise') or {}
-    c['precise'] = {k: p.get(k) for k in ('images_per_s_bs8', 'ms_per_step_bs8', 'pipeline_depth', 'images_per_s_bs8_serial',
-                                          'ms_per_step_bs8_serial', 'end_to_end_bs1_ms', 'error') if k in p}
+    f = r.get('fp16_mode') or {}
+    if f:
+        c['fp16_mode'] = {'images_per_s': f.get('images_per_s'), 'ms_per_step': f.get('ms_per_step'), 'images_per_s_serial': f.get('images_per_s_serial'),
+                          'sustained': ((f.get('images_per_s_sustained') or {}).get('pipelined') or {}).get('images_per_s'),
+                          'frac_conv3x3': (f.get('roofline_conv3x3_s1_64') or {}).get('frac'),
+                          'latency_bs1': {k: (v.get('p50') if isinstance(v, dict) else None) for k, v in (f.get('latency_bs1') or {}).items()
+                                          if k in ('forward_ms', 'end_to_end_ms')}}
+    cf = r.get('configs') or {}
+    c['configs'] = {k: (cf.get(k) or {}).get('ms_per_step') for k in ('config3', 'config4') if k in cf}
+    if 'frames_640x480' in cf:
+        c['configs']['640x480_bs8'] = ((cf['frames_640x480'] or {}).get('bs8') or {}).get('ms_per_step')
     t = r.get('train') or {}
-    c['train'] = {k: t.get(k) for k in ('ms_per_iter', 'n_gpus', 'ranks_seen', 'images_per_s', 'graphs_per_iter', 'hip_graph',
-                                        'ms_per_iter_eager', 'error') if k in t}
+    c['train'] = {k: t.get(k) for k in ('ms_per_iter', 'n_gpus', 'ranks_seen', 'images_per_s', 'error') if k in t}
     lb = r.get('latency_bs1') or {}
     if lb:
         c['latency_bs1'] = {k: (v.get('p50') if isinstance(v, dict) else v) for k, v in lb.items() if k in ('forward_ms', 'end_to_end_ms')}
@@ -696,6 +671,163 @@ def latency_bs1(model, dev, iters=200):
     return out
 
 
+def timed_region(model, xs, meta, args, P, streams, dev, sync_ranks):
+    """The contract's timed region for the model's CURRENT precision mode: W untimed warm-up steps, then exactly K steps
+    between barrier + synchronize pairs, every step one complete batch (forward + decode + NMS of 8 frames as one HIP graph).
+    `--pipeline P` keeps P batches in flight: step i is enqueued on HIP stream i % P with buffer slot i % P (own activations,
+    outputs and workspace; weights shared), so that the phases of one batch that leave most CUs idle (small-map stages,
+    post-processing, launch gaps) overlap with the next batch's stem / blocks; P = 1 is the strictly serial replay, always
+    reported beside it.  Step i works on frame buffer i % NBUF (distinct frames, 398 MB in rotation: cold reads) with buffer
+    slot (i % NBUF) % P -- a frame buffer always meets the same slot, so there is one captured graph per frame buffer.
+    Also measured, outside the timed region: the per-step HIP-event distribution of the serial replay, and SUSTAINED rates --
+    >= 1 s of replays enqueued without any host synchronisation in between (round 6: the 20-step region is ~10-30 ms; lessons
+    10 / 37: clocks settle lower once the chip runs gap-free for long)."""
+    def step(i=0, serial=False):
+        b = i % NBUF
+        sl = b % P
+        with torch.cuda.stream(streams[0 if serial else sl]):
+            return model.detect_resident(xs[b], meta, slot=sl)      # one HIP graph per step unless --no-graph
+
+    torch.cuda.synchronize()
+    dets = [None] * NBUF
+    for b in range(NBUF):               # graph capture per frame buffer (setup, not a warm-up step)
+        dets[b] = step(b)
+    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.clock_warmup_s:      # setup: bring the clocks up (not counted as warm-up steps)
+        for i in range(NBUF):
+            step(i)
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        dets[i % NBUF] = step(i)
+    torch.cuda.synchronize()
+    if sync_ranks and dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        dets[i % NBUF] = step(i)
+    torch.cuda.synchronize()
+    if sync_ranks and dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if sync_ranks and dist.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    for i in range(min(NBUF, args.steps + args.warmup), NBUF):
+        dets[i] = step(i)
+    torch.cuda.synchronize()
+    snap = [(d_.counts.clone(), d_.dets.clone()) for d_ in dets]      # what the overlapped steps produced, per frame buffer
+    # the strictly serial replay (one batch in flight), same number of steps: reported next to the headline
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, serial=True)
+    torch.cuda.synchronize()
+    dt_serial = time.perf_counter() - t0
+    for b in range(NBUF):     # every frame buffer alone on one stream == what it produced with two batches in flight
+        o = step(b, serial=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o.counts, snap[b][0]), 'overlapped and serial steps disagree (buffer %d)' % b
+        for j in range(BATCH):
+            k_ = int(o.counts[j, 1])
+            assert torch.equal(o.dets[j, :k_], snap[b][1][j, :k_]), 'overlapped and serial steps disagree (buffer %d)' % b
+    counts = dets[0].counts.cpu().numpy()
+    assert int(counts[:, 2].max()) == 0, 'candidate capacity overflow: raise --max-candidates'
+    # per-step distribution with HIP events on the launch stream (SURVEY 8d protocol: >= 100 iterations, median + p95)
+    nev = max(100, args.steps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
+    with torch.cuda.stream(streams[0]):
+        for e0, e1 in evs:
+            e0.record()
+            model.detect_resident(xs[0], meta, slot=0)
+            e1.record()
+    torch.cuda.synchronize()
+    ev_ms = np.sort(np.array([e0.elapsed_time(e1) for e0, e1 in evs]))
+    # sustained: >= args.sustained_s seconds of device time enqueued back to back, NO host synchronisation inside
+    sustained = None
+    if args.sustained_s > 0 and model.use_graph:
+        sustained = {}
+        for name, serial, per_step in (('pipelined', False, dt / args.steps), ('serial', True, dt_serial / args.steps)):
+            n = max(args.steps, int(args.sustained_s / per_step) + 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                step(i, serial=serial)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            sustained[name] = dict(images_per_s=round(BATCH * n / el, 1), ms_per_step=round(el / n * 1e3, 4), steps=n, seconds=round(el, 2))
+        sustained['note'] = 'gap-free replays for >= %.1f s of device time (no host synchronisation inside), this rank' % args.sustained_s
+    return dict(dt=dt, dt_serial=dt_serial, ev_ms=ev_ms, counts=counts, sustained=sustained)
+
+
+def fp16_mode_report(model, fast, x, dev, args, P, world):
+    """The 'fp16' precision mode on the headline workload (rounds 1-5 quoted `value` in it): sigma within 2.5e-3 of the fp32
+    reference -- OUTSIDE north_star's 1e-3, hence not the headline -- measured by the same timed_region(); its kernel classes
+    with live HIP-event times against the fp16 MFMA / HBM peaks."""
+    from lfd_amd import engine
+    dt, dt_serial, ev_ms = fast['dt'], fast['dt_serial'], fast['ev_ms']
+    out = {'mode': "LFD.precision = 'fp16': fp16 MFMA operands, fp16 inter-layer storage, fp32 accumulation (fused stem / block / head kernels)",
+           'parity': 'sigma(cls), sigma(reg) <= 2.5e-3 vs fp32 (measured <= 2.3e-3): outside the 1e-3 of north_star; NMS bit-exact on identical logits',
+           'images_per_s': round(world * BATCH * args.steps / dt, 1), 'ms_per_step': round(dt / args.steps * 1e3, 4), 'pipeline_depth': P,
+           'images_per_s_serial': round(world * BATCH * args.steps / dt_serial, 1), 'ms_per_step_serial': round(dt_serial / args.steps * 1e3, 4),
+           'images_per_s_sustained': fast['sustained'],
+           'step_ms_hip_events': {'median': round(float(ev_ms[len(ev_ms) // 2]), 4), 'p95': round(float(ev_ms[int(len(ev_ms) * 0.95)]), 4)},
+           'mfma_tflops': round(world * 348.8 * args.steps / dt / 1e3, 1)}
+    fmt, n, h, w = engine._input_format(x)
+    plan = engine.get_plan(model, model._backbone, model._neck, model._head, dev)
+    st = plan.state_for(n, h, w)
+    br = kernel_breakdown(model, plan, st, x, fmt)
+    tot = sum(c['time_us'] for c in br.values())
+    rows = []
+    for name, c in sorted(br.items(), key=lambda kv: -kv[1]['time_us']):
+        tf = c['flops'] / c['time_us'] / 1e6
+        gb = c['bytes'] / c['time_us'] / 1e3
+        rows.append({'kernel': name, 'launches': c['launches'], 'time_us_per_forward': round(c['time_us'], 1),
+                     'share': round(c['time_us'] / tot, 3), 'tflops': round(tf, 1), 'gbs': round(gb, 0),
+                     'frac_mfma': round(tf / MFMA_PEAK_TFLOPS, 3), 'frac_hbm': round(gb / HBM_PEAK_GBS, 3)})
+    dom = rows[0]
+    # every 3x3 stride-1 64->64 conv of the backbone: the fused residual blocks + the stand-alone launches
+    # (the 3x3 s1 conv inside the fused downsample block is not separable from its HBM-bound stride-2 conv: listed on its own)
+    k33c = [c for nm, c in br.items() if nm.startswith('conv3x3_s1_64to64') or nm.startswith('fasterblock_fused')]
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    except Exception:
+        pass
+    if k33c:
+        t33 = sum(c['time_us'] for c in k33c)
+        f33 = sum(c['flops'] for c in k33c)
+        nm33 = 'all conv3x3 s1 64->64 (fused residual blocks k_block64_rows / k_block64 + stand-alone k_conv)'
+        out['roofline_conv3x3_s1_64'] = {'bound': 'mfma', 'achieved': round(f33 / t33 / 1e6, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': round(f33 / t33 / 1e6 / MFMA_PEAK_TFLOPS, 3),
+                                         'avg_launch_us': round(t33 / sum(c['launches'] for c in k33c), 2), 'traffic': pmc.get(nm33),
+                                         'traffic_source': PMC_SOURCE,
+                                         # information beside the contract's peak: what a pure MFMA loop holds on this part when
+                                         # its operands change (power cap; profiles/r03_mfma_operand_power.txt)
+                                         'pure_mfma_loop_random_operands_tflops': 1574.0, 'frac_of_that': round(f33 / t33 / 1e6 / 1574.0, 3),
+                                         'power': 'at the socket power limit: 1375-1390 W, 2.0 GHz (profiles/r06_power_trace.json)'}
+    # every launch of the backbone (stem, residual blocks, downsample blocks, 128-channel convs): north_star's "the 3x3
+    # backbone convs" -- 34.3 of the backbone's 41.0 GFLOP per image are 3x3 taps, the 1x1s are fused into the same launches
+    bbc = [c for nm, c in br.items() if not nm.startswith('neck+head')]
+    tb, fb = sum(c['time_us'] for c in bbc), sum(c['flops'] for c in bbc)
+    out['roofline_backbone_3x3'] = {'kernel': 'all backbone launches (fused stem + residual blocks + downsample blocks + 128-channel convs)',
+                                    'bound': 'mfma', 'achieved': round(fb / tb / 1e6, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': round(fb / tb / 1e6 / MFMA_PEAK_TFLOPS, 3), 'time_us_per_forward': round(tb, 1),
+                                    'launches': sum(c['launches'] for c in bbc), 'gflop_per_forward': round(fb / 1e9, 1)}
+    if dom['frac_mfma'] >= dom['frac_hbm']:
+        out['roofline'] = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': round(dom['tflops'], 1), 'peak': MFMA_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': dom['frac_mfma'], 'traffic': pmc.get(dom['kernel']), 'traffic_source': PMC_SOURCE}
+    else:
+        out['roofline'] = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': dom['frac_hbm'], 'traffic': pmc.get(dom['kernel']), 'traffic_source': PMC_SOURCE}
+    out['roofline']['avg_launch_us'] = round(dom['time_us_per_forward'] / dom['launches'], 2)
+    out['kernels'] = rows
+    out['forward_sum_us'] = round(tot, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -708,6 +840,8 @@ def main():
     ap.add_argument('--no-siblings', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the extra key with BASELINE configs 3 and 4')
     ap.add_argument('--no-precise', action='store_true', help="skip the extra key with the fp32-storage precision mode")
+    ap.add_argument('--no-fp16', action='store_true', help="skip the extra key `fp16_mode` (the faster mode outside the 1e-3 tolerance)")
+    ap.add_argument('--sustained-s', type=float, default=1.0, help='seconds of gap-free replays for `images_per_s_sustained` (0: skip)')
     ap.add_argument('--max-candidates', type=int, default=8192)
     ap.add_argument('--clock-warmup-s', type=float, default=0.3, help='untimed replays before the W warm-up steps: an idle MI355X needs '
                     'milliseconds to ramp its clocks (DESIGN 3, lesson 11)')
@@ -759,104 +893,48 @@ def main():
         thr = float(torch.quantile(cls.float().sigmoid().reshape(BATCH, -1)[0], 1.0 - TARGET_K / cls.shape[1]))
         model._classification_threshold = thr
         model._nms_cfg = dict(type='nms', iou_thr=0.4)
-
-        # Steps are independent batches.  `--pipeline P` keeps P of them in flight: step i is enqueued on HIP stream i % P with
-        # buffer slot i % P (own activations, outputs and workspace; weights shared), so that the phases of one batch that
-        # leave most CUs idle (small-map stages, post-processing, launch gaps) overlap with the next batch's stem / blocks.
-        # Every step still is one complete forward + decode + NMS of 8 frames; P = 1 is the strictly serial replay.
         P = max(1, args.pipeline) if model.use_graph else 1
         streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
 
-        # Step i works on frame buffer i % NBUF (distinct frames, 398 MB in rotation: cold reads) with buffer slot
-        # (i % NBUF) % P -- a frame buffer always meets the same slot, so there is one captured graph per frame buffer.
-        def step(i=0, serial=False):
-            b = i % NBUF
-            sl = b % P
-            with torch.cuda.stream(streams[0 if serial else sl]):
-                return model.detect_resident(xs[b], meta, slot=sl)      # one HIP graph per step unless --no-graph
-
-        torch.cuda.synchronize()
-        dets = [None] * NBUF
-        for b in range(NBUF):               # graph capture per frame buffer (setup, not a warm-up step)
-            dets[b] = step(b)
-        torch.cuda.synchronize()
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < args.clock_warmup_s:      # setup: bring the clocks up (not counted as warm-up steps)
-            for i in range(NBUF):
-                step(i)
-            torch.cuda.synchronize()
-        for i in range(args.warmup):
-            dets[i % NBUF] = step(i)
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            dets[i % NBUF] = step(i)
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if dist.is_initialized():
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        for i in range(min(NBUF, args.steps + args.warmup), NBUF):
-            dets[i] = step(i)
-        torch.cuda.synchronize()
-        det = dets[0]
-        snap = [(d_.counts.clone(), d_.dets.clone()) for d_ in dets]      # what the overlapped steps produced, per frame buffer
-        # the strictly serial replay (one batch in flight), same number of steps: reported next to the headline
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, serial=True)
-        torch.cuda.synchronize()
-        dt_serial = time.perf_counter() - t0
-        for b in range(NBUF):     # every frame buffer alone on one stream == what it produced with two batches in flight
-            o = step(b, serial=True)
-            torch.cuda.synchronize()
-            assert torch.equal(o.counts, snap[b][0]), 'overlapped and serial steps disagree (buffer %d)' % b
-            for j in range(BATCH):
-                k_ = int(o.counts[j, 1])
-                assert torch.equal(o.dets[j, :k_], snap[b][1][j, :k_]), 'overlapped and serial steps disagree (buffer %d)' % b
-        counts = det.counts.cpu().numpy()
-        assert int(counts[:, 2].max()) == 0, 'candidate capacity overflow: raise --max-candidates'
-        # per-step distribution with HIP events on the launch stream (SURVEY 8d protocol: >= 100 iterations, median + p95);
-        # outside the contract's timed region
-        nev = max(100, args.steps)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
-        with torch.cuda.stream(streams[0]):
-            for e0, e1 in evs:
-                e0.record()
-                model.detect_resident(xs[0], meta, slot=0)
-                e1.record()
-        torch.cuda.synchronize()
-        ev_ms = np.sort(np.array([e0.elapsed_time(e1) for e0, e1 in evs]))
+        # ---- the contract's timed region, in the precision mode the metric is quoted in: 'fp32_storage', the mode inside
+        #      north_star's tolerance (cls / bbox within 1e-3: raw logits <= 1e-4 here).  Round 6: rounds 1-5 quoted `value` in
+        #      the 'fp16' mode (sigma within 2.5e-3) -- that figure is measured the same way below and reported as `fp16_mode`.
+        model.precision = HEADLINE_MODE
+        hl = timed_region(model, xs, meta, args, P, streams, dev, sync_ranks=True)
+        model.precision = 'fp16'
+        fast = None
+        if world == 1 and not args.no_fp16:
+            fast = timed_region(model, xs, meta, args, P, streams, dev, sync_ranks=False)
 
         result = None
         if rank == 0:
+            dt, counts = hl['dt'], hl['counts']
             value = world * BATCH * args.steps / dt
+            ev_ms = hl['ev_ms']
             result = {
-                'metric': "images/sec WIDERFACE-S 1920x1080 bs=8 end-to-end inference (forward + decode + NMS), LFD.precision='fp16' "
-                          "(sigma(cls) / sigma(reg) within 2.5e-3 of the fp32 reference, NMS bit-exact on identical logits); the mode "
-                          "inside north_star's 1e-3 is 'fp32_storage', reported under `precise`",
-                'parity_gates': {"fp16 (this value)": 'sigma(cls), sigma(reg) <= 2.5e-3 vs fp32 (measured <= 2.3e-3), raw logits <= 2e-2; '
-                                                      'kept indices bit-exact on identical logits (tests/test_gpu_parity_fullsize.py)',
-                                 "fp32_storage (`precise`)": 'raw logits <= 1e-4 (measured <= 8.5e-6), sigma <= 1e-3 vs fp32 '
-                                                             '(tests/test_gpu_precise.py)'},
+                'metric': "images/sec WIDERFACE-S 1920x1080 bs=8 end-to-end inference (forward + decode + NMS), LFD.precision='fp32_storage': "
+                          "the mode inside north_star's tolerance (cls / bbox raw logits within 1e-4 of the fp32 reference, sigma within "
+                          "1e-3; kept indices bit-exact on identical logits); the faster 'fp16' mode (sigma within 2.5e-3, OUTSIDE the 1e-3) "
+                          "is reported under `fp16_mode`, never as `value`",
+                'parity_gates': {"fp32_storage (this value)": 'raw logits <= 1e-4 (measured <= 8.5e-6), sigma <= 1e-3 vs the fp32 reference at '
+                                                              "configs 2 / 3 / 4 (tests/test_gpu_precise.py); the reference's end-to-end rows "
+                                                              'reproduced with 0 unmatched, kept (point, class) lists identical (tests/test_gpu_end2end.py)',
+                                 "fp16 (`fp16_mode`)": 'sigma(cls), sigma(reg) <= 2.5e-3 vs fp32 (measured <= 2.3e-3), raw logits <= 2e-2; '
+                                                       'kept indices bit-exact on identical logits (tests/test_gpu_parity_fullsize.py)'},
                 'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps,
-                'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-                'clock_warmup_s': args.clock_warmup_s, 'pipeline_depth': P, 'ms_per_step_serial': round(dt_serial / args.steps * 1e3, 4),
-                'images_per_s_serial': round(world * BATCH * args.steps / dt_serial, 1),
+                'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'precision_mode': HEADLINE_MODE,
+                'clock_warmup_s': args.clock_warmup_s, 'pipeline_depth': P, 'ms_per_step_serial': round(hl['dt_serial'] / args.steps * 1e3, 4),
+                'images_per_s_serial': round(world * BATCH * args.steps / hl['dt_serial'], 1),
+                'images_per_s_sustained': hl['sustained'],
                 'step_ms_hip_events': {'median': round(float(ev_ms[len(ev_ms) // 2]), 4), 'p95': round(float(ev_ms[int(len(ev_ms) * 0.95)]), 4),
                                        'min': round(float(ev_ms[0]), 4), 'iterations': int(len(ev_ms)),
                                        'note': 'latency of ONE step replayed alone (serial), HIP events on its stream'},
                 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-                'config': {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16 NHWC resident in HBM: '
-                                       'backbone+neck+head (HIP MFMA convs) + decode + threshold + NMS, results on device',
+                'dtype_note': 'fp16 MFMA operands as hi + 2^-11 lo planes (three products per k-step), fp32 accumulation and epilogues',
+                'mfma_tflops_issued': round(world * 3 * 348.8 * args.steps / dt / 1e3, 1),
+                'config': {'workload': 'WIDERFACE_LFD_S inference bs=8/GPU 1920x1080 fp16 NHWC frames resident in HBM: '
+                                       'backbone+neck+head (HIP MFMA convs on hi/lo fp16 planes) + decode + threshold + NMS, results on device',
                            'global_batch': world * BATCH, 'points_per_image': int(cls.shape[1]),
                            'input_buffers': '%d distinct resident batches rotated (%.0f MB > 256 MiB Infinity Cache)' % (NBUF, NBUF * x.numel() * 2 / 1e6),
                            'candidates_per_image': float(counts[:, 0].mean()), 'kept_per_image': float(counts[:, 1].mean()),
@@ -864,78 +942,74 @@ def main():
                            'hip_graph': bool(model.use_graph),
                            'weights': 'random init (seed 666) + synthetic BN/GN/Scale perturbation (no checkpoints offline)'},
             }
-            # ---- roofline of the dominant kernel classes (live HIP-event timing on the launch stream)
-            fmt, n, h, w = engine._input_format(x)
-            plan = engine.get_plan(model, model._backbone, model._neck, model._head, dev)
-            st = plan.state_for(n, h, w)
-            br = kernel_breakdown(model, plan, st, x, fmt)
-            tot = sum(c['time_us'] for c in br.values())
-            rows = []
-            for name, c in sorted(br.items(), key=lambda kv: -kv[1]['time_us']):
-                tf = c['flops'] / c['time_us'] / 1e6
-                gb = c['bytes'] / c['time_us'] / 1e3
-                rows.append({'kernel': name, 'launches': c['launches'], 'time_us_per_forward': round(c['time_us'], 1),
-                             'share': round(c['time_us'] / tot, 3), 'tflops': round(tf, 1), 'gbs': round(gb, 0),
-                             'frac_mfma': round(tf / MFMA_PEAK_TFLOPS, 3), 'frac_hbm': round(gb / HBM_PEAK_GBS, 3)})
-            dom = rows[0]
-            # every 3x3 stride-1 64->64 conv of the backbone: the fused residual blocks + the stand-alone launches
-            # (the 3x3 s1 conv inside the fused downsample block is not separable from its HBM-bound stride-2 conv: listed on its own)
-            k33c = [c for nm, c in br.items() if nm.startswith('conv3x3_s1_64to64') or nm.startswith('fasterblock_fused')]
-            k33 = []
-            if k33c:
-                t33 = sum(c['time_us'] for c in k33c)
-                f33 = sum(c['flops'] for c in k33c)
-                k33 = [{'kernel': 'all conv3x3 s1 64->64 (fused residual blocks k_block64_rows / k_block64 + stand-alone k_conv)', 'tflops': round(f33 / t33 / 1e6, 1),
-                        'frac_mfma': round(f33 / t33 / 1e6 / MFMA_PEAK_TFLOPS, 3), 'time_us_per_forward': round(t33, 1),
-                        'launches': sum(c['launches'] for c in k33c)}]
-            # every launch of the backbone (stem, residual blocks, downsample blocks, 128-channel convs): north_star's "the 3x3
-            # backbone convs" -- 34.3 of the backbone's 41.0 GFLOP per image are 3x3 taps, the 1x1s are fused into the same launches
-            bbc = [c for nm, c in br.items() if not nm.startswith('neck+head')]
-            tb, fb = sum(c['time_us'] for c in bbc), sum(c['flops'] for c in bbc)
-            result['roofline_backbone_3x3'] = {'kernel': 'all backbone launches (fused stem + residual blocks + downsample blocks + 128-channel convs)',
-                                               'bound': 'mfma', 'achieved': round(fb / tb / 1e6, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                               'frac': round(fb / tb / 1e6 / MFMA_PEAK_TFLOPS, 3), 'time_us_per_forward': round(tb, 1),
-                                               'launches': sum(c['launches'] for c in bbc), 'gflop_per_forward': round(fb / 1e9, 1)}
-            pmc = {}
+            # ---- roofline of the headline mode's kernel classes (live HIP-event timing on the launch stream, eager launches)
             try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            except Exception:
-                pass
-            if dom['frac_mfma'] >= dom['frac_hbm']:
-                result['roofline'] = {'kernel': dom['kernel'], 'bound': 'mfma',
-                                      'achieved': round(dom['tflops'], 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                      'frac': dom['frac_mfma'], 'traffic': pmc.get(dom['kernel']), 'traffic_source': PMC_SOURCE}
-            else:
-                result['roofline'] = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,
-                                      'unit': 'GB/s', 'frac': dom['frac_hbm'], 'traffic': pmc.get(dom['kernel']), 'traffic_source': PMC_SOURCE}
-            result['roofline']['avg_launch_us'] = round(dom['time_us_per_forward'] / dom['launches'], 2)
-            if k33:
-                result['roofline_conv3x3_s1_64'] = {'bound': 'mfma', 'achieved': k33[0]['tflops'], 'peak': MFMA_PEAK_TFLOPS,
-                                                    'unit': 'TFLOP/s', 'frac': k33[0]['frac_mfma'],
-                                                    'avg_launch_us': round(k33[0]['time_us_per_forward'] / k33[0]['launches'], 2),
-                                                    'traffic': pmc.get(k33[0]['kernel']), 'traffic_source': PMC_SOURCE,
-                                                    # information beside the contract's peak: what a pure MFMA loop holds on this
-                                                    # part when its operands change (power cap; profiles/r03_mfma_operand_power.txt)
-                                                    'pure_mfma_loop_random_operands_tflops': 1574.0,
-                                                    'frac_of_that': round(k33[0]['tflops'] / 1574.0, 3)}
-            result['kernels'] = rows
-            result['forward_sum_us'] = round(tot, 1)
+                model.precision = HEADLINE_MODE
+                prow = precise_breakdown(model, x, dev)
+                model.precision = 'fp16'
+                if prow:
+                    ptraffic = {}
+                    try:
+                        ptraffic = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_precise.json')))
+                    except Exception:
+                        pass
+                    dom = prow[0]
+                    result['roofline'] = {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': dom['peak'],
+                                          'unit': dom['unit'], 'frac': dom['frac'], 'avg_launch_us': dom['avg_launch_us'],
+                                          'frac_mfma_issued': dom['frac_mfma_issued'], 'traffic': ptraffic.get(dom['kernel']),
+                                          'traffic_source': PMC_SOURCE_PRECISE,
+                                          'note': 'ALGORITHMIC flops (2 MAC per tap) / bytes over the live HIP-event duration; the three hi/lo '
+                                                  'MFMA products per k-step ISSUE 3 x the algorithmic flops (frac_mfma_issued)'}
+                    for r_ in prow:
+                        r_['traffic'] = ptraffic.get(r_['kernel'])
+                    c3 = [r_ for r_ in prow if r_['kernel'].startswith('conv3x3 s1 64->64')]
+                    if c3:
+                        result['roofline_conv3x3_s1_64'] = {'bound': 'mfma', 'achieved': c3[0]['tflops_algorithmic'], 'peak': MFMA_PEAK_TFLOPS,
+                                                            'unit': 'TFLOP/s', 'frac': round(c3[0]['tflops_algorithmic'] / MFMA_PEAK_TFLOPS, 3),
+                                                            'frac_mfma_issued': c3[0]['frac_mfma_issued'], 'avg_launch_us': c3[0]['avg_launch_us'],
+                                                            'launches': c3[0]['launches'], 'traffic': c3[0]['traffic'],
+                                                            'power': 'at the socket power limit: 1350-1400 W, 2.0 GHz (profiles/r06_power_trace.json)'}
+                    bb = [r_ for r_ in prow if not r_['kernel'].startswith('neck + head')]
+                    tb = sum(r_['time_us_per_forward'] for r_ in bb)
+                    fb = sum(r_['tflops_algorithmic'] * r_['time_us_per_forward'] for r_ in bb)      # TFLOP/s x us = MFLOP
+                    result['roofline_backbone_3x3'] = {'kernel': 'all backbone launches of the headline mode (k_pl_stem2x, k_pl_c3p, stage entries, 128-channel convs)',
+                                                       'bound': 'mfma', 'achieved': round(fb / tb, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                                       'frac': round(fb / tb / MFMA_PEAK_TFLOPS, 3), 'frac_mfma_issued': round(3 * fb / tb / MFMA_PEAK_TFLOPS, 3),
+                                                       'time_us_per_forward': round(tb, 1), 'launches': sum(r_['launches'] for r_ in bb)}
+                    result['kernels'] = prow
+                    result['forward_sum_us'] = round(sum(r_['time_us_per_forward'] for r_ in prow), 1)
+            except Exception as e:
+                model.precision = 'fp16'
+                result['roofline'] = {'error': repr(e)}
+            if fast is not None:
+                result['fp16_mode'] = fp16_mode_report(model, fast, x, dev, args, P, world)
     if rank == 0 and world == 1 and not args.no_latency:
         with torch.no_grad():
+            model.precision = HEADLINE_MODE
             result['latency_bs1'] = latency_bs1(model, dev)
-    if rank == 0 and world == 1 and not args.no_precise:
-        try:
-            with torch.no_grad():
-                result['precise'] = precise_bench(model, x, meta, dev)
-        except Exception as e:
-            result['precise'] = {'error': repr(e)}
+            model.precision = 'fp16'
+            if 'fp16_mode' in result:
+                result['fp16_mode']['latency_bs1'] = latency_bs1(model, dev)
     if rank == 0 and world == 1 and not args.no_configs:
         try:
             with torch.no_grad():
                 result['configs'] = other_configs_bench(dev)
-                result['configs'].update(stress_and_small_frame_bench(model, x, meta, dev, cls))
+                model.precision = HEADLINE_MODE
+                cls_p, _ = model.forward_resident(x)
+                result['configs'].update(stress_and_small_frame_bench(model, x, meta, dev, cls_p))
+                model.precision = 'fp16'
+                if 'fp16_mode' in result:
+                    result['fp16_mode']['configs'] = stress_and_small_frame_bench(model, x, meta, dev, cls)
         except Exception as e:
+            model.precision = 'fp16'
             result['configs'] = {'error': repr(e)}
+    if rank == 0:
+        # (rounds 3-5 reported the tolerance-compliant mode under this key; it IS the headline now -- alias kept for readers of the old layout)
+        lb_ = (result.get('latency_bs1') or {}).get('end_to_end_ms') or {}
+        result['precise'] = {'same_as': 'the headline keys of this line (value / ms_per_step / ms_per_step_serial / images_per_s_sustained / latency_bs1 / configs)',
+                             'images_per_s_bs8': result['value'], 'ms_per_step_bs8': result['ms_per_step'], 'pipeline_depth': result['pipeline_depth'],
+                             'images_per_s_bs8_serial': result['images_per_s_serial'], 'ms_per_step_bs8_serial': result['ms_per_step_serial'],
+                             'end_to_end_bs1_ms': {'p50': lb_.get('p50'), 'min': lb_.get('min')}}
     if not args.no_train:
         # every rank runs the training leg (the DDP iteration has collectives); rank 0 reports
         try:

@@ -80,7 +80,8 @@ typedef enum lfd_tune_key {
   LFD_TUNE_ROWS_WGS = 8,       /* > 0: workgroups per k_block64_rows launch; 0: one per CU                                 default 0 */
   LFD_TUNE_CONV128_SPLITK = 9, /* 1: split-K kernel for 128 -> 128 3x3 convs on maps of <= 16384 pixels                    default 1 */
   LFD_TUNE_CONV0_VALU = 10,    /* 1: the first stem conv of the training path on the VALU kernels instead of MFMA         default 0 */
-  LFD_TUNE_PL_C3 = 11,         /* 1: planes mode, 3x3 s1 64-channel convs on k_pl_c3 (epilogue under the next contraction) default 1 */
+  LFD_TUNE_PL_C3 = 11,         /* planes mode, 3x3 s1 64-channel convs: 2 = k_pl_c3p (K split over a wave pair per SIMD),
+                                  1 = k_pl_c3 (one wave per SIMD, epilogue under the next contraction), 0 = generic      default 2 */
   LFD_TUNE_COUNT = 12
 } lfd_tune_key_t;
 LFD_API int lfd_tuning_set(int32_t key, int32_t value);

@@ -11,6 +11,8 @@
 
 // csrc/planes_c3.hip
 int lfd_pl_c3_launch(const pl::PlArgs& a, bool residual, hipStream_t st);
+// csrc/planes_c3p.hip
+int lfd_pl_c3p_launch(const pl::PlArgs& a, bool residual, hipStream_t st);
 
 namespace {
 
@@ -459,7 +461,10 @@ int lfd_pl_conv2d(const lfd_pl_conv_desc_t* d, const void* in, void* out, const 
     // ---- 64-channel body
     case 64 * 10000 + 3100 + 2:
       // the workhorse of the residual blocks: epilogue pipelined under the next tile's contraction (k_pl_c3); tuning knob
-      // LFD_TUNE_PL_C3 = 0 keeps the generic kernel (A/B timing, tests)
+      // LFD_TUNE_PL_C3 = 0 keeps the generic kernel (A/B timing, tests); 2 = the wave-pair form (k_pl_c3p: the contraction
+      // index split over two waves per SIMD)
+      if (outm == 0 && !tail && !ds_w_packed && lfd_tune(LFD_TUNE_PL_C3) == 2)
+        return lfd_pl_c3p_launch(a, residual != nullptr, st);
       if (outm == 0 && !tail && !ds_w_packed && lfd_tune(LFD_TUNE_PL_C3) != 0)
         return lfd_pl_c3_launch(a, residual != nullptr, st);
       return launch_pl<64, 3, 1, 2, true>(a, outm, st);

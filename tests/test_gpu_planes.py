@@ -112,6 +112,30 @@ def test_pl_conv_plain_and_residual_vs_float64(cin, cout, ks, stride, n, h, w):
             _close(got2, ref2, 'residual relu=%d %d->%d' % (relu, cin, cout))
 
 
+@pytest.mark.parametrize('n,h,w', [(2, 19, 37), (1, 70, 130), (1, 4, 16), (2, 5, 3), (8, 34, 60)])
+def test_pl_c3_kernel_variants_vs_float64(n, h, w):
+    """The three kernels behind the 3x3 stride-1 64-channel conv (+ residual) of the residual blocks (lfd_resnet.py:96-154),
+    selected by LFD_TUNE_PL_C3: 0 generic k_pl_conv, 1 k_pl_c3 (one wave per SIMD), 2 k_pl_c3p (the contraction index split over
+    a wave pair per SIMD, round 6: the default) -- each against float64, and against each other (another order of fp32 sums)."""
+    g, xp, xv, wt, b = _inputs(64000 + h * 7 + w, n, h, w, 64, 64, 3)
+    res = torch.randn(n, h, w, 64, generator=g)
+    rp = engine_p2.to_planes(res)
+    prev = _lib.tune('PL_C3')
+    try:
+        for relu, r in ((True, None), (True, rp), (False, rp)):
+            ref = _ref_conv(xv, wt, b, 3, 1, relu, None if r is None else engine_p2.from_planes(r))
+            got = {}
+            for knob in (0, 1, 2):
+                _lib.tune('PL_C3', knob)
+                out, _ = _pl_conv(xp, wt, b, 3, 1, relu, res=None if r is None else r.cuda())
+                _close(out, ref, 'PL_C3=%d relu=%d res=%d' % (knob, relu, r is not None))
+                got[knob] = engine_p2.from_planes(out.cpu()).double()
+            mag = max(1.0, float(ref.abs().max()))
+            assert float((got[2] - got[1]).abs().max()) <= 2e-6 * mag and float((got[2] - got[0]).abs().max()) <= 2e-6 * mag
+    finally:
+        _lib.tune('PL_C3', prev)
+
+
 @pytest.mark.parametrize('cin,cout,n,h,w', [(64, 64, 2, 33, 50), (64, 64, 1, 135, 240), (64, 128, 2, 34, 60), (128, 128, 2, 21, 39), (32, 64, 2, 20, 28),
                                             (32, 32, 1, 31, 45)])
 def test_pl_conv_stride2_with_identity_branch_vs_float64(cin, cout, n, h, w):

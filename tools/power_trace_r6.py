@@ -1,0 +1,155 @@
+"""Socket power and shader clock of the MI355X per KERNEL CLASS of both precision modes and for the whole steps (round 6;
+VERDICT r5 next-round item 3: "a tools/power_trace.py record under profiles/ showing it at the socket power limit with the
+clock it holds").  Every launch unit of bench.py's two breakdowns runs back to back for SECONDS seconds while rocm-smi is
+polled from a side thread; then the whole steps (HIP graph, one and two batches in flight).
+    python tools/power_trace_r6.py [seconds per unit] [fp16|precise|steps ...]   -> gpurun_out/power_trace_r6.json"""
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'lfd-a-light-and-fast-detector_amd'))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+samples = []
+phase = ['idle']
+stop = [False]
+
+
+def _num(v):
+    try:
+        return float(str(v).strip('()MhzW% ').split()[0].replace('Mhz', ''))
+    except Exception:
+        return None
+
+
+def poll():
+    while not stop[0]:
+        try:
+            out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=10).stdout
+            d = json.loads(out)
+            card = d[sorted(d)[0]]
+            rec = {'phase': phase[0]}
+            for k, v in card.items():
+                kl = k.lower()
+                if 'power' in kl:
+                    rec['power_w'] = _num(v)
+                elif 'sclk clock speed' in kl:
+                    rec['sclk_mhz'] = _num(v)
+            samples.append(rec)
+        except Exception as e:
+            samples.append({'phase': phase[0], 'error': repr(e)})
+        time.sleep(0.05)
+
+
+def summarize(name):
+    rows = [s for s in samples if s['phase'] == name and 'power_w' in s]
+    rows = rows[len(rows) // 4:]        # (the first quarter of a phase is the ramp)
+    if not rows:
+        return {}
+    pw = [r['power_w'] for r in rows if r.get('power_w') is not None]
+    ck = [r['sclk_mhz'] for r in rows if r.get('sclk_mhz') is not None]
+    return dict(samples=len(rows), power_w_mean=round(float(np.mean(pw)), 0) if pw else None, power_w_max=max(pw) if pw else None,
+                sclk_mhz_mean=round(float(np.mean(ck)), 0) if ck else None, sclk_mhz_min=min(ck) if ck else None)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].replace('.', '').isdigit() else 2.0
+    what = [a for a in sys.argv[1:] if not a.replace('.', '').isdigit()] or ['fp16', 'precise', 'steps']
+    import bench
+    from lfd_amd import configs, engine, _lib
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    dev = torch.device('cuda')
+    m = configs.build_model('WIDERFACE_LFD_S')
+    configs.perturb_weights(m)
+    m.eval().cuda()
+    m.use_graph = True
+    xs = [(torch.rand(8, 1080, 1920, 3, device=dev) * 2 - 1).half() for _ in range(2)]
+    x = xs[0]
+    meta = torch.tensor([[1920., 1080., 1.0]] * 8, device=dev)
+    res = {'seconds_per_unit': seconds, 'idle': None, 'units': [], 'steps': []}
+    time.sleep(1.0)
+    res['idle'] = summarize('idle')
+    ctr = [0]
+
+    def timer(fn, label=''):
+        ctr[0] += 1
+        name = 'u%d' % ctr[0]
+        fn(); torch.cuda.synchronize()
+        phase[0] = name
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < seconds:
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            n += 50
+        dt = time.time() - t0
+        phase[0] = 'gap'
+        us = dt / n * 1e6
+        row = dict(unit=label, us_per_launch_back_to_back=round(us, 2))
+        row.update(summarize(name))
+        res['units'].append(row)
+        print(json.dumps(row), flush=True)
+        time.sleep(0.3)
+        return us
+
+    with torch.no_grad():
+        cls, _ = m.forward_resident(x)
+        m._classification_threshold = float(torch.quantile(cls.float().sigmoid().reshape(8, -1)[0], 1.0 - 256 / cls.shape[1]))
+        if 'fp16' in what:
+            fmt, n, h, w = engine._input_format(x)
+            plan = engine.get_plan(m, m._backbone, m._neck, m._head, dev)
+            st = plan.state_for(n, h, w)
+            res['units'].append(dict(unit="==== LFD.precision = 'fp16' launch units"))
+            bench.kernel_breakdown(m, plan, st, x, fmt, timer=timer)
+        if 'precise' in what:
+            m.precision = 'fp32_storage'
+            res['units'].append(dict(unit="==== LFD.precision = 'fp32_storage' launch units (PL_C3 = %d)" % _lib.tune('PL_C3')))
+            bench.precise_breakdown(m, x, dev, timer=timer)
+            m.precision = 'fp16'
+        if 'steps' in what:
+            for mode in ('fp16', 'fp32_storage'):
+                m.precision = mode
+                for depth in (1, 2):
+                    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+
+                    def step(i):
+                        with torch.cuda.stream(streams[i % depth]):
+                            return m.detect_resident(xs[i % depth], meta, slot=i % depth)
+                    for i in range(4):
+                        step(i)
+                    torch.cuda.synchronize()
+                    name = 'step_%s_%d' % (mode, depth)
+                    phase[0] = name
+                    t0 = time.time()
+                    n = 0
+                    while time.time() - t0 < max(seconds, 3.0):
+                        for i in range(20):
+                            step(i)
+                        torch.cuda.synchronize()
+                        n += 20
+                    dt = time.time() - t0
+                    phase[0] = 'gap'
+                    row = dict(step="%s, %d batch(es) in flight, HIP graph replays for %.0f s" % (mode, depth, dt), ms_per_step=round(dt / n * 1e3, 4),
+                               images_per_s=round(8 * n / dt, 1), mfma_tflops_issued=round((3 if mode != 'fp16' else 1) * 348.8 * n / dt / 1e3, 1))
+                    row.update(summarize(name))
+                    res['steps'].append(row)
+                    print(json.dumps(row), flush=True)
+                    time.sleep(0.5)
+            m.precision = 'fp16'
+    stop[0] = True
+    th.join(timeout=5)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    tag = os.environ.get('LFD_POWER_TAG', '')
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'power_trace_r6%s.json' % tag), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
