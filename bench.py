@@ -285,8 +285,21 @@ def train_bench(dev, steps=10, warmup=3, world=1, rank=0):
     # with the two RCCL all-reduces between them when a process group is live)
     graphed = None
     ts_b2b = 0.0
+    step = None
     try:
         step = train.GraphedTrainStep(m, opt, clip, max_boxes=1024)
+    except Exception as e:       # keep the eager number
+        graphed = repr(e)
+    if dist.is_initialized():
+        # the graphed iterations contain collectives: either every rank runs them or none does (a rank that fell back to
+        # eager alone would leave the others blocked in an all-reduce)
+        flag = torch.tensor([0 if step is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            step = None
+            graphed = graphed or 'another rank could not build the graphed step'
+    ts = ts_eager
+    if step is not None:
         ts, lv = timed(lambda: step(x if step.x is None else step.x, ann, True))     # frames written into the step's own buffer
         # the same iterations enqueued back to back (sync=False: no read-back between replays), the last loss read at the end.
         # Measured round 4: NOT faster (7.23 against 7.08 ms) -- without the ~0.13 ms host gap between replays the chip sits
@@ -299,9 +312,6 @@ def train_bench(dev, steps=10, warmup=3, world=1, rank=0):
         torch.cuda.synchronize()
         ts_b2b = (time.perf_counter() - t0) / steps
         graphed = True
-    except Exception as e:       # keep the eager number
-        graphed = repr(e)
-        ts = ts_eager
     dt, dt_eager = float(np.median(ts)), float(np.median(ts_eager))
     per_rank = [round(dt * 1e3, 3)]
     if dist.is_initialized():
@@ -514,8 +524,7 @@ def precise_breakdown(model, x, dev, reps=20, timer=None):
             c = o.channels
             return (2.0 * n * oh * ow * (27 * c + c * c), x.numel() * x.element_size() + 4.0 * n * oh * ow * c,
                     'stem pair 1: conv3x3 s2 (3->%d) + conv1x1 (k_pl_stem)' % c)
-        src = st.bufs[o.src]
-        ih, iw = src.shape[2], src.shape[3]
+        ih, iw = st.dims[o.src]           # (not st.bufs[...]: plane buffers are allocated at their first launch)
         oh, ow = (ih + o.stride - 1) // o.stride, (iw + o.stride - 1) // o.stride
         fl = 2.0 * n * oh * ow * o.cin * o.cout * o.ks * o.ks
         by = 4.0 * n * ih * iw * o.cin
@@ -528,7 +537,7 @@ def precise_breakdown(model, x, dev, reps=20, timer=None):
             by += 4.0 * n * oh * ow * o.cout
         by += 4.0 * n * oh * ow * (o.cout if o.out_mode != 2 else o.f_c0 + o.f_c1)
         if o.ks == 3 and o.stride == 1 and o.cin == 64:
-            key = 'conv3x3 s1 64->64 (+ residual) (k_pl_c3)'
+            key = 'conv3x3 s1 64->64 (+ residual) (k_pl_c3p)'
         elif o.ks == 3 and o.stride == 2 and o.tail is not None:
             key = 'stem pair 2: conv3x3 s2 + conv1x1 (k_pl_conv<64,3,2,TAIL>)'
         elif o.ks == 3 and o.stride == 2:

@@ -509,6 +509,11 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  * fp16 MFMAs per k-step (w_hi x_hi | w_hi x_lo + w_lo x_hi), fp32 accumulation, fp32 epilogue, split on the way out.
  * Packed weights of every entry point: [2 = hi | 2^11 lo][fragments of lfd_conv_packed_weight_halfs order], rows zero-padded
  * to a multiple of 32 (engine_p2.pack_planes_weight); biases fp32 padded likewise.
+ * RANGE: a plane pair has the PRECISION of ~22 bits but the RANGE of fp16 -- |x| <= 65504; the split does not saturate, a larger
+ * value stores hi = +-inf and reads back as NaN (the fp32-tensor form of the mode, lfd_p32_*, has fp32's range and is what to use
+ * for a network whose activations exceed it; BatchNorm / GroupNorm-normalised LFD activations stay below ~1e2).  The fixed-point
+ * GroupNorm sums (2^-24 units in int64) hold a group's sum of squares up to ~5.5e11.  Where the text below says "statistics in
+ * fp64": a thread adds the <= 64 values it copies out of ONE tile in fp32, tiles are combined in fp64, workgroups in fixed point.
  *
  * lfd_pl_stem_pair: frame (in_format as lfd_stem_conv_f16) -> conv3x3 s2 (3 -> C) + BN + ReLU -> conv1x1 (C -> C) + BN + ReLU
  *   -> planes [n, (h+1)/2, (w+1)/2, C], C = 32 | 64 (lfd_resnet.py:356-374, :376-395).  w1: [2][C/32][2][64][8] in

@@ -345,6 +345,9 @@ __global__ __launch_bounds__(256) void k_pl_gn_apply(_Float16* x, long plane, lo
 template <int CIN, int KS, int S, int NCT, bool WREG, int PTO = 0>
 int launch_pl(const PlArgs& a, int outm, hipStream_t st) {
   const bool tail = a.w2 != nullptr, res = a.res != nullptr, ds = a.wds != nullptr, gnin = a.gnin_acc != nullptr;
+  // TAIL: the workgroup holds ALL NCT * 32 channels of the main conv as the chained 1x1's operand (one cout group): a conv with
+  // more output channels than that (e.g. 64 -> 128 3x3 s2 + tail on the <64,3,2,2> instance) has no kernel here
+  if (tail && a.cout != NCT * 32) return LFD_ERR_UNSUPPORTED;
   if (gnin) {
     // normalise + ReLU the landed tile (the producer's GroupNorm): the tower's second conv and the output convs
     if (tail || res || ds) return LFD_ERR_UNSUPPORTED;

@@ -235,6 +235,13 @@ class PlanesPlan(object):
             raise Unsupported('SimpleNeck + LFDHead')
         if bb._input_channels != 3 or (bb._norm_cfg is not None and bb._norm_cfg['type'] != 'BatchNorm2d'):
             raise Unsupported('backbone')
+        # the consumer kernels hard-wire ReLU (lfd_resnet.py / simple_neck.py / lfd_head.py build their activation from
+        # activation_cfg): any other leaf module than conv / norm / ReLU / Scale falls back to the fp32-tensor plan's checks
+        for part in (bb, neck, head):
+            for mod in part.modules():
+                if not any(True for _ in mod.children()) and type(mod).__name__ not in (
+                        'Conv2d', 'BatchNorm2d', 'GroupNorm', 'ReLU', 'Scale', 'Identity', 'Sequential', 'ModuleList'):
+                    raise Unsupported('module %s (activation must be ReLU)' % type(mod).__name__)
         has_norm = bb._norm_cfg is not None
         step = 3 if has_norm else 2
         spec = list(bb.stem_spec())
@@ -314,6 +321,8 @@ class PlanesPlan(object):
                 conv, norm = seq[l * 3], seq[l * 3 + 1]
                 if not isinstance(norm, nn.GroupNorm):
                     raise Unsupported('head norm must be GroupNorm')
+                if not isinstance(seq[l * 3 + 2], nn.ReLU):
+                    raise Unsupported('head activation must be ReLU')
                 bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=conv.weight.device)
                 w = conv.weight.detach().float()
                 if l == 0 and first_tail_of is not None:
@@ -380,6 +389,8 @@ class PlanesPlan(object):
 
     # ------------------------------------------------------------------ execution
     def state_for(self, n, h, w, slot=0):
+        # (not evicted: the step graphs captured over a state replay raw addresses of its buffers -- model/lfd.py keeps them
+        #  per frame buffer; a serving process sees a handful of input shapes)
         key = (n, h, w, slot)
         st = self._shape_cache.get(key)
         if st is None:
@@ -502,13 +513,31 @@ class PlanesPlan(object):
                                   zeros, sp), 'lfd_pl_conv2d')
 
 
+class _LazyBufs(dict):
+    """plane buffer index -> tensor [2, N, H, W, C] fp16, allocated at its first use: a buffer no launch of the chosen launch
+    list touches is never allocated -- the stem's pair-1 output (1.06 GB at 8 x 1080p) when the one-launch lfd_pl_stem2x runs
+    (ADVICE r5).  First uses happen in the eager warm-up call in front of a graph capture (model/lfd.py), never inside one."""
+
+    def __init__(self, st, plan):
+        super().__init__()
+        self._st, self._plan = st, plan
+
+    def __missing__(self, b):
+        hh, ww = self._st.dims[b]
+        with torch.cuda.device(self._plan.device):
+            t = torch.empty((2, self._st.n, hh, ww, self._plan.buf_channels[b]), dtype=torch.float16, device=self._plan.device)
+        self[b] = t
+        return t
+
+
 class _State(object):
     """plane buffers [2, N, H, W, C] fp16, the fp32 [N,P,C'] / [N,P,4] outputs and the GroupNorm sums for one input shape"""
 
     def __init__(self, plan, n, h, w):
         dev = plan.device
         self.n, self.h, self.w = n, h, w
-        self.bufs, self.dims = {}, {}
+        self.dims = {}
+        self.bufs = _LazyBufs(self, plan)
         with torch.cuda.device(dev):
             for b, sc in plan.buf_scale.items():
                 hh, ww, s = h, w, sc
@@ -516,7 +545,6 @@ class _State(object):
                     hh, ww = (hh + 1) // 2, (ww + 1) // 2
                     s //= 2
                 self.dims[b] = (hh, ww)
-                self.bufs[b] = torch.empty((2, n, hh, ww, plan.buf_channels[b]), dtype=torch.float16, device=dev)
             self.sizes = [self.dims[t] for t in plan.taps]
             self.p_off, p = [], 0
             for hh, ww in self.sizes:

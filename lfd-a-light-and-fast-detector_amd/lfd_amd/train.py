@@ -168,6 +168,7 @@ class GraphedTrainStep(object):
         self.max_norm = None if grad_clip_cfg is None else float(grad_clip_cfg['max_norm'])
         self.max_boxes, self.max_graphs = int(max_boxes), int(max_graphs)
         self.graphs, self._last_key, self.x = {}, None, None
+        self._eager_only = set()       # keys some rank could not capture (agreed by all-reduce): eager on every rank
         self.loss_scaler = loss_scaler      # DynamicLossScale or None; a graph belongs to one loss scale (it is in the key)
 
     # ------------------------------------------------------------------ static inputs
@@ -305,36 +306,49 @@ class GraphedTrainStep(object):
         ent = self.graphs.get(key)
         if ent is None:
             a, b, c, S = self._segments(clip)
-            capture = self._last_key == key
+            import torch.distributed as dist
+            # (every rank takes the same branch: the key holds the optimizer's hyper-parameters and the loss scale, identical on
+            #  all ranks of an image-parallel run, and _eager_only is only ever extended by agreement, below)
+            capture = self._last_key == key and key not in self._eager_only
             if capture:
                 if len(self.graphs) >= self.max_graphs:
                     self.graphs.pop(next(iter(self.graphs)))
                 torch.cuda.synchronize()
                 stream = torch.cuda.Stream(device=self.x.device)
                 ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                ok = [True]
+
+                def captured(g, fn, pool):
+                    """capture fn into g and run it once; a capture that fails on THIS rank runs the segment eagerly instead, so
+                    that the rank still meets the others in the collective that follows -- the ranks agree on success below"""
+                    if ok[0]:
+                        try:
+                            with torch.cuda.graph(g, pool=pool, stream=stream):
+                                fn()
+                            g.replay()
+                            return
+                        except Exception:
+                            ok[0] = False
+                    fn()
                 # capture A, run the collective it feeds, capture B against the reduced sums, ... : every capture sees the
                 # buffers in the state a replay finds them in; one memory pool, the replay order of the capture order
-                with torch.cuda.graph(ga, stream=stream):
-                    a()
+                captured(ga, a, None)
                 it = SegmentedIteration(lambda: None, lambda: None, lambda: None, S['sums'], S['gsums'], [fg.g for fg in self.opt._flat])
-                ga.replay()
-                it.a = lambda: None
                 it.gsums.copy_(it.sums)
-                import torch.distributed as dist
                 dist.all_reduce(it.gsums, op=dist.ReduceOp.SUM)
-                with torch.cuda.graph(gb, pool=ga.pool(), stream=stream):
-                    b()
-                gb.replay()
+                captured(gb, b, ga.pool() if ok[0] else None)
                 for g in it.grad_buffers:
                     dist.all_reduce(g, op=dist.ReduceOp.SUM)
-                with torch.cuda.graph(gc_, pool=ga.pool(), stream=stream):
-                    c()
-                gc_.replay()
-                it.a, it.b, it.c = ga.replay, gb.replay, gc_.replay
-                ent = (it, S, (ga, gb, gc_))
-                self.graphs[key] = ent
+                captured(gc_, c, ga.pool() if ok[0] else None)
+                flag = torch.tensor([1 if ok[0] else 0], dtype=torch.int32, device=self.x.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 self._last_key = key
                 self._bump_versions()
+                if int(flag.item()) == 1:
+                    it.a, it.b, it.c = ga.replay, gb.replay, gc_.replay
+                    self.graphs[key] = (it, S, (ga, gb, gc_))
+                else:
+                    self._eager_only.add(key)      # some rank could not capture: every rank stays eager for this key
                 return S['vals'], S['norm'], S['nc']
             it = SegmentedIteration(a, b, c, None, None, [fg.g for fg in self.opt._flat])
             # (eager: the sums tensor only exists after segment A)

@@ -149,4 +149,25 @@ def test_graphed_training_step_under_rccl_equals_the_eager_image_parallel_step(t
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(rec, open(os.path.join(ROOT, 'gpurun_out', 'graphed_dist_step.json'), 'w'))
     # the split costs two graph launches and two world-1 collectives per iteration
-    assert rec['ms_three_graphs_rccl_world1'] <= rec['ms_one_graph_single_process'] + 0.15, rec
+    # (recorded, loosely bounded: a wall-clock comparison across two processes' worth of set-up varies from box to box -- ADVICE r5)
+    assert rec['ms_three_graphs_rccl_world1'] <= 1.5 * rec['ms_one_graph_single_process'] + 0.5, rec
+
+
+def test_bench_line_through_the_distributed_code_path_on_one_gpu():
+    """bench.py's N > 1 branch (process group, barriers around the timed region, MAX over ranks, the DDP training leg as three
+    graphs + two RCCL all-reduces, bench.py: LFD_BENCH_FORCE_DIST) driven through RCCL at world size 1 -- what the driver's
+    `torch.distributed.run ... bench.py --gpus N` executes on every rank, minus the other ranks."""
+    import json
+    env = dict(os.environ, LFD_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--no-siblings',
+                          '--no-configs', '--no-cpu-baseline', '--no-latency', '--no-fp16', '--sustained-s', '0'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    full, compact = json.loads(lines[-2]), json.loads(lines[-1])
+    assert len(lines[-1]) < 2048, 'the compact line must fit the 2 KB tail the driver keeps'
+    for r in (full, compact):
+        assert r['n_gpus'] == 1 and r['ranks_seen'] == 1 and r['value'] > 0 and r['unit'] == 'images/s' and r['precision_mode'] == 'fp32_storage'
+    assert full['train']['graphs_per_iter'] == 3 and full['train']['hip_graph'] is True and full['train']['ranks_seen'] == 1, full['train']
+    assert full['roofline']['frac'] > 0 and full['cpu_baseline'] is None

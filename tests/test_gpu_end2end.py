@@ -35,6 +35,10 @@ _UNMATCHED_GATE = {('end_to_end/WIDERFACE_LFD_XS', 'fp16'): 2,          # measur
                    ('config1/q90', 'fp32_storage'): 0}                  # 0 of 314
 
 
+# rows of the 'fp32_storage' result that are not the reference's row at the same position: the measured counts
+_ORDER_GATE = {'config1/predict_py': 0, 'config1/q90': 0}
+
+
 def _record(key, value):
     from conftest import ROOT
     d = os.path.join(ROOT, 'gpurun_out')
@@ -119,8 +123,20 @@ def test_baseline_config1_predict_for_single_image_matches_the_reference(tag, pr
             unmatched += 1
     unmatched += len(res) - len(used)
     print('config 1 %s %s: %d reference detections, %d unmatched' % (tag, precision, len(ref), unmatched))
-    _record('config1/%s/%s' % (tag, precision), dict(reference_detections=len(ref), unmatched=unmatched))
+    rec = dict(reference_detections=len(ref), unmatched=unmatched)
+    if precision == 'fp32_storage':
+        # IDENTITY, not only matching: the rows come back in the reference's ORDER -- row i of ours is row i
+        # of the reference's (same class, IoU >= 0.99, score within 2e-3).  multiclass_nms orders by score (nms.py:161-220): two
+        # detections whose scores differ by less than the forward's 2e-6 could swap; the count is recorded and gated at what
+        # was measured on the MI355X (0 for both thresholds).
+        assert len(res) == len(ref), (len(res), len(ref))
+        out_of_order = sum(0 if (q[0] == r[0] and _iou(r[2:], q[2:]) >= _IOU and abs(q[1] - r[1]) <= _DSCORE) else 1 for r, q in zip(ref, res))
+        rec['rows_out_of_order'] = out_of_order
+        print('   rows not equal to the reference row of the same position: %d' % out_of_order)
+    _record('config1/%s/%s' % (tag, precision), rec)
     assert unmatched <= _UNMATCHED_GATE[('config1/' + tag, precision)], (unmatched, len(ref))
+    if precision == 'fp32_storage':
+        assert rec['rows_out_of_order'] <= _ORDER_GATE['config1/' + tag], rec
 
 
 def test_predict_for_single_image_api():
@@ -181,12 +197,25 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     d = json.loads(lines[0])
     c2 = json.loads(lines[1])
     assert len(lines[1]) < 2048
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'data'):
+    for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'precision_mode'):
         assert c2[k] == d[k], k
+    assert "fp32_storage" in c2['metric'] and c2['metric'].startswith(d['metric'][:40])      # (the compact line shortens the sentence)
     assert c2['roofline']['frac'] == d['roofline']['frac'] and c2['cpu_baseline']['value'] == d['cpu_baseline']['value']
     assert c2['ms_per_step_serial'] == d['ms_per_step_serial'] and c2['step_ms_hip_events']['median'] > 0
-    assert c2['precise']['images_per_s_bs8'] == d['precise']['images_per_s_bs8'] and c2['train']['ms_per_iter'] == d['train']['ms_per_iter']
+    assert c2['train']['ms_per_iter'] == d['train']['ms_per_iter']
+    # round 6: `value` is quoted in the tolerance-compliant mode; the faster 'fp16' mode and the sustained (>= 1 s, gap-free)
+    # rates ride along; BASELINE configs 3 / 4 and the 640 x 480 frames are timed in the headline mode too
+    assert d['precision_mode'] == 'fp32_storage' and d['precise']['images_per_s_bs8'] == d['value']
+    assert d['fp16_mode']['images_per_s'] > d['value'] and c2['fp16_mode']['images_per_s'] == d['fp16_mode']['images_per_s']
+    for mode in (d, d['fp16_mode']):
+        su = mode['images_per_s_sustained']
+        assert su['pipelined']['seconds'] >= 0.5 and su['pipelined']['images_per_s'] > 0 and su['serial']['images_per_s'] > 0
+    assert c2['images_per_s_sustained']['pipelined'] == d['images_per_s_sustained']['pipelined']['images_per_s']
+    for k in ('config3', 'config4'):
+        assert d['configs'][k]['precision_mode'] == 'fp32_storage' and d['configs'][k]['ms_per_step'] > d['configs'][k]['fp16']['ms_per_step'] > 0
+        assert c2['configs'][k] == d['configs'][k]['ms_per_step']
+    assert d['roofline']['frac_mfma_issued'] > d['roofline']['frac'] and d['fp16_mode']['roofline_conv3x3_s1_64']['frac'] > 0
     assert 'workload' in c2['config'] and 'model' not in c2['config']
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'latency_bs1'):
@@ -215,6 +244,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rb = d['roofline_backbone_3x3']
     assert rb['bound'] == 'mfma' and 0 < rb['frac'] < 1 and abs(rb['frac'] - rb['achieved'] / rb['peak']) < 2e-3
     assert "'fp16'" in d['metric'] and 'fp32_storage' in d['metric'] and len(d['parity_gates']) == 2
+    assert d['fp16_mode']['latency_bs1']['end_to_end_ms']['p50'] > 0 and d['fp16_mode']['configs']['frames_640x480']['bs8']['ms_per_step'] > 0
 
 
 def test_two_batches_in_flight_on_two_streams_match_the_serial_step():

@@ -331,13 +331,72 @@ def test_g3_decode_nms_on_oracle_logits_index_exact_at_the_baseline_grid(key, K)
     dkeys = {(int(p_), int(l)): row for p_, l, row in zip(pa, la, a)}
     assert len(dkeys) == k and len(okeys) == len(olabels)
     only = set(dkeys) ^ set(okeys)
-    assert len(only) <= 2, sorted(only)[:8]
+    # gated at the count measured on the MI355X in rounds 3-5 for all six (config, K) cases: none (rounds 3-5 tolerated 2)
+    assert len(only) == 0, sorted(only)[:8]
     matched = 0
     for key_ in set(dkeys) & set(okeys):
         r1, r2 = dkeys[key_], okeys[key_]
         assert np.abs(r1[:4] - r2[:4]).max() < 5e-4 and abs(r1[4] - r2[4]) < 1e-6 + 2e-5 * r2[4], (key_, r1, r2)
         matched += 1
-    _record('G3 %s K=%d' % (key, K), candidates=int(Kc), kept=k, all_oracle_kept=len(olabels), matched=matched, points=int(P))
+    _record('G3 %s K=%d' % (key, K), candidates=int(Kc), kept=k, all_oracle_kept=len(olabels), matched=matched, points=int(P),
+            kept_only_on_one_side=len(only))
+
+
+@pytest.mark.parametrize('key,K', [('config2', 256), ('config2', 4096), ('config4', 256)])
+def test_fp32_storage_end_to_end_kept_list_is_the_oracle_pipelines_list_in_order(key, K):
+    """north_star: "bit-exact box indices after NMS".  The WHOLE product path in the tolerance-compliant mode -- its own
+    'fp32_storage' forward on the frame + device decode / threshold / NMS (lfd.py:434-509, nms.py:161-220) -- against the
+    all-oracle pipeline on the fp32 oracle's logits of the same frame (oracle/net_oracle.py, pinned to the reference to 2e-5):
+    the kept detections as an ORDERED list of (flat point index, class) must be the same list.  The two forwards differ by
+    <= 8e-6 in the raw logits, so a score within that distance of the threshold, or two kept scores closer than that, could
+    legitimately differ: counted, recorded, and gated at the counts measured on the MI355X (zero)."""
+    cs = _case(key)
+    arch, m, img = cs['arch'], cs['model'], cs['imgs'][0]
+    name, (n, h, w), _ = CASES[key]
+    rc, rr, sizes = cs['ref'][img]['fp32']
+    ce = arch['classification_loss_type'] == 'CrossEntropyLoss'
+    osc = net_oracle.scores_from_logits(rc[0].numpy(), ce)
+    thr = float(np.partition(osc.reshape(-1), -K)[-K])
+    strides = net_oracle.strides_of(arch)
+    iou = 0.4 if not ce else 0.1
+    odets, olabels, ocand, Ko = net_oracle.get_results_single(rc[0].numpy(), rr[0].numpy(), [tuple(s) for s in sizes], strides, arch, thr,
+                                                              iou, False, (h, w), 1.0)
+    oflat = np.flatnonzero(osc.reshape(-1) > np.float32(thr))
+    ncls = osc.shape[1]
+    olist = [(int(oflat[c] // ncls), int(l)) for c, l in zip(ocand, olabels)]
+    keep = (m.precision, m._classification_threshold, dict(m._nms_cfg) if m._nms_cfg else None, m.use_graph)
+    try:
+        m.precision = 'fp32_storage'
+        m._classification_threshold, m._nms_cfg, m.use_graph = thr, dict(type='nms', iou_thr=iou), False
+        m.max_candidates = 8192
+        meta = torch.tensor([[float(w), float(h), 1.0]], dtype=torch.float32).cuda()
+        with torch.no_grad():
+            out = m.detect_resident(cs['x'][img:img + 1].cuda(), meta)
+        counts = out.counts.cpu().numpy()
+        assert counts[0, 2] == 0, 'candidate capacity overflow'
+        k = int(counts[0, 1])
+        dlist = [(int(p_), int(l)) for p_, l in zip(out.point[0, :k].cpu().numpy(), out.labels[0, :k].cpu().numpy())]
+        dd = out.dets[0, :k].cpu().numpy()
+    finally:
+        m.precision, m._classification_threshold, m._nms_cfg, m.use_graph = keep
+    only = set(dlist) ^ set(olist)
+    order = sum(1 for a_, b_ in zip(dlist, olist) if a_ != b_) if not only else None
+    print('%s K=%d: oracle keeps %d, the product %d; on one side only %d; positions that differ %s' % (key, K, len(olist), len(dlist), len(only), order))
+    _record('identity %s K=%d' % (key, K), oracle_kept=len(olist), product_kept=len(dlist), only_on_one_side=len(only), positions_that_differ=order)
+    assert len(olist) > 0 and len(only) == 0, sorted(only)[:8]
+    # the SET is identical.  multiclass_nms orders the kept rows by score (nms.py:215-218): a position may only differ where the
+    # oracle's own scores of the two rows involved are closer than the two forwards are to each other (measured on the MI355X:
+    # config 2: K = 256 one adjacent swap = 2 positions of 243, K = 4096 15 swaps = 30 positions of 3615) -- anything else is an error;
+    # the count is bounded at 1 % of the kept rows
+    oscore = {key_: float(r[4]) for key_, r in zip(olist, odets)}
+    for i, (a_, b_) in enumerate(zip(dlist, olist)):
+        if a_ != b_:
+            assert abs(oscore[a_] - oscore[b_]) < 2e-5, (i, a_, b_, oscore[a_], oscore[b_])
+    assert order <= max(4, len(olist) // 100), order
+    orow = {key_: r for key_, r in zip(olist, odets)}
+    for key_, r1 in zip(dlist, dd):
+        r2 = orow[key_]
+        assert np.abs(r1[:4] - r2[:4]).max() < 2e-3 and abs(r1[4] - r2[4]) < 2e-5, (key_, r1, r2)
 
 
 # ------------------------------------------------------------------------------------------------ (e) crop consistency

@@ -390,6 +390,14 @@ def test_pl_conv_refuses_what_it_has_no_instance_for():
     rc = lib().lfd_pl_conv2d(C.byref(d), ptr(xp), None, ptr(w), ptr(b), None, None, None, None, None, None, None, None, None, None,
                              None, None, None, ptr(z), stream_ptr())
     assert rc == -1       # out == NULL
+    # a chained 1x1 behind a conv whose output channels do not fit ONE workgroup's slabs (64 -> 128 3x3 s2 + tail on the
+    # <64,3,2,2> instance: two cout groups, but the chained operand needs all 128 channels in one): refused, not miscomputed
+    d.cout, d.stride, d.tail_cout, d.tail_relu = 128, 2, 128, 1
+    out2 = torch.zeros((2, 1, 4, 4, 128), dtype=torch.float16, device='cuda')
+    d.out_plane_halfs = out2[0].numel()
+    rc = lib().lfd_pl_conv2d(C.byref(d), ptr(xp), ptr(out2), ptr(w), ptr(b), None, ptr(w), ptr(b), None, None, None, None, None, None, None,
+                             None, None, None, ptr(z), stream_ptr())
+    assert rc == -4
 
 
 @pytest.mark.parametrize('name,shape', [('WIDERFACE_LFD_S', (2, 135, 241)), ('WIDERFACE_LFD_XS', (1, 96, 128)), ('TT100K_LFD_L', (2, 90, 161)),

@@ -18,14 +18,17 @@ for d in ('/tmp/p_sq1', '/tmp/p_sq2'):
             acc[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
             if r.get('Start_Timestamp') and r.get('End_Timestamp') and r['Counter_Name'] in ('SQ_WAVE_CYCLES', 'SQ_BUSY_CU_CYCLES'):
                 dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-print('# per-launch averages, rocprofv3 --pmc (two passes), tools/bench_precise.py; SQ_*_CYCLES count quad-cycles per wave; clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration')
+print('# per-launch averages, rocprofv3 --pmc (two passes), tools/bench_precise.py; SQ_*_CYCLES count quad-cycles per wave; clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration, launches >= 20 us only')
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
     row = {c: x / cnt[(k, c)] for c, x in v.items()}
     util = row.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * row['SQ_BUSY_CU_CYCLES']) if row.get('SQ_BUSY_CU_CYCLES') else float('nan')
     wc = row.get('SQ_WAVE_CYCLES', 0) or float('nan')
     du = sum(dur[k]) / max(len(dur[k]), 1)
-    print('%-80s n %3d  %7.1f us  clock %.2f GHz  mfma_util %.3f  wait_any %.2f  wait_inst %.2f  active %.2f  lds_conf %.2f' % (
-        k, cnt[(k, 'SQ_WAVE_CYCLES')], du, row.get('GRBM_GUI_ACTIVE', 0) / 8 / (du * 1e3) if du else 0, util, row.get('SQ_WAIT_ANY', 0) / wc, row.get('SQ_WAIT_INST_ANY', 0) / wc,
+    # (GRBM_GUI_ACTIVE / duration is only a clock for launches long against the counter's start / stop skew: below 20 us it read
+    #  4.8-10 GHz in round 5 -- not printed there)
+    clk = ('clock %.2f GHz' % (row.get('GRBM_GUI_ACTIVE', 0) / 8 / (du * 1e3))) if du >= 20 else 'clock   n/a   '
+    print('%-80s n %3d  %7.1f us  %s  mfma_util %.3f  wait_any %.2f  wait_inst %.2f  active %.2f  lds_conf %.2f' % (
+        k, cnt[(k, 'SQ_WAVE_CYCLES')], du, clk, util, row.get('SQ_WAIT_ANY', 0) / wc, row.get('SQ_WAIT_INST_ANY', 0) / wc,
         row.get('SQ_ACTIVE_INST_ANY', 0) / wc, row.get('SQ_LDS_BANK_CONFLICT', 0) / max(row.get('SQ_LDS_IDX_ACTIVE', 0), 1)))
     print('    ' + ' '.join('%s=%d' % (c, x) for c, x in sorted(row.items())))
 PY
