@@ -82,7 +82,8 @@ typedef enum lfd_tune_key {
   LFD_TUNE_CONV0_VALU = 10,    /* 1: the first stem conv of the training path on the VALU kernels instead of MFMA         default 0 */
   LFD_TUNE_PL_C3 = 11,         /* planes mode, 3x3 s1 64-channel convs: 2 = k_pl_c3p (K split over a wave pair per SIMD),
                                   1 = k_pl_c3 (one wave per SIMD, epilogue under the next contraction), 0 = generic      default 2 */
-  LFD_TUNE_COUNT = 12
+  LFD_TUNE_PL_HEAD_OUT_REGS = 12, /* 1: lfd_pl_head_levels mode 2 with the fp32 tile landing in registers (k_pl_head_out)           default 1 */
+  LFD_TUNE_COUNT = 13
 } lfd_tune_key_t;
 LFD_API int lfd_tuning_set(int32_t key, int32_t value);
 LFD_API int32_t lfd_tuning_get(int32_t key);
@@ -596,6 +597,45 @@ LFD_API int lfd_pl_conv2d_levels(const lfd_pl_conv_desc_t* desc, const lfd_pl_le
                                  const void* zeros, lfd_stream_t stream);
 LFD_API int lfd_pl_groupnorm_relu(void* x, int64_t plane_halfs, int32_t n, int64_t hw, int32_t c, const void* gn_sums,
                                   const float* gamma, const float* beta, float eps, int32_t relu, lfd_stream_t stream);
+
+/* lfd_pl_head_levels (round 6, csrc/planes_head.hip): the neck + head 1x1 convs of the planes mode (simple_neck.py:67-74,
+ * lfd_head.py:88-139,164-185, lfd.py:526-542) over FLAT pixel lists -- a pyramid level of an image is `pixels` = h * w pixels,
+ * tiles of 64, all levels of a launch in one persistent grid, every level with its own filters.  The pre-GroupNorm outputs of
+ * the tower convs are private to these launches and stored as plain fp32 [n][pixels][128] (the bytes of a plane pair).
+ *   mode 0: in = planes [n][pixels][cin] (cin 64 | 128, the backbone tap) -> conv w0 (cin -> 128) + b0 (+ ReLU if relu0) ->
+ *           conv w1 (128 -> 128) + b1 -> out fp32, gn_sums += {sum, sum of squares} of out per (image, 8-channel group)
+ *           in the fixed-point replica layout of lfd_pl_conv2d (caller zeroes gn_sums per forward)
+ *   mode 1: in = fp32 [n][pixels][128] + its producer's gn_in_sums / gamma / beta (GroupNorm(16, 128), eps) -> ReLU ->
+ *           conv w0 (128 -> 128) + b0 -> out fp32, gn_sums as above
+ *   mode 2: in as mode 1 -> conv w0 (128 -> f_c0 + f_c1 <= 64 channels, packed to 32 | 64 rows) + b0 -> fp32 outputs as
+ *           lfd_pl_conv2d out_mode 2 (f_out0 / f_out1 at the level's point offset, image strides f_image_stride0 / 1, scale1)
+ * Packed weights: engine_p2.pack_planes_weight order ([2 = hi | 2^11 lo][cout / 32][cin / 16][64 lanes] x 8 halfs). */
+typedef struct lfd_pl_head_desc {
+  int32_t mode, n, cin, relu0;
+  int32_t f_c0, f_c1;
+  float gn_in_eps;
+  int32_t pad_;
+  int64_t f_image_stride0, f_image_stride1;
+} lfd_pl_head_desc_t;
+typedef struct lfd_pl_head_level {
+  const void* in;
+  void* out;                      /* fp32 [n][pixels][128] (modes 0, 1) */
+  const void* w0;
+  const float* b0;
+  const void* w1;                 /* mode 0 */
+  const float* b1;
+  void* gn_sums;                  /* modes 0, 1 */
+  const void* gn_in_sums;         /* modes 1, 2 */
+  const float* gn_in_gamma;
+  const float* gn_in_beta;
+  float* f_out0;                  /* mode 2 */
+  float* f_out1;
+  const float* scale1;
+  int64_t in_plane_halfs;         /* mode 0 */
+  int32_t pixels, pad_;
+} lfd_pl_head_level_t;
+LFD_API int lfd_pl_head_levels(const lfd_pl_head_desc_t* desc, const lfd_pl_head_level_t* levels, int32_t num_levels,
+                               const void* zeros, lfd_stream_t stream);
 
 /* First stem unit: conv3x3 s2 (3 -> C) + BN + ReLU chained with conv1x1 (C -> C) + BN + ReLU
  * (lfd_resnet.py:356-374 'fast' stem; first half of the 'faster' stem :376-395).

@@ -343,9 +343,19 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
   const int nblk = gridDim.x;
   const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
   const int per_xcd = (a.ntiles + 7) / 8;
-  const int t_begin = xcd * per_xcd;
-  const int t_end = (t_begin + per_xcd) < a.ntiles ? (t_begin + per_xcd) : a.ntiles;
-  const int t_step = (nblk + 7 - xcd) / 8;
+  const int x_begin = xcd * per_xcd;
+  const int x_end = (x_begin + per_xcd) < a.ntiles ? (x_begin + per_xcd) : a.ntiles;
+  const int wgs_xcd = (nblk + 7 - xcd) / 8;
+  // the workgroup's tiles inside its XCD's range: strided by the workgroups of the XCD -- or, for the multi-level launches
+  // (round 6), ONE contiguous run: a workgroup then stays inside an image for many tiles.  Every image change costs a GNIN
+  // consumer a dependent chain of global loads (the producer's sums -> mean / rstd -> scale / shift, 2-3 us) and an OUTM 1
+  // producer a flush of its sums (two barriers + atomics); with the strided walk every tile of the small pyramid levels
+  // (fewer tiles per image than the stride) paid that: the 25 % of the pixels outside the first level took as long as the
+  // first level (measured on k_pl_head, csrc/planes_head.hip: 121 -> 84 us)
+  const int ml_chunk = (x_end - x_begin + wgs_xcd - 1) / (wgs_xcd > 0 ? wgs_xcd : 1);
+  const int t_begin = ML ? x_begin + bix * ml_chunk : x_begin + bix;
+  const int t_end = ML ? ((t_begin + ml_chunk) < x_end ? (t_begin + ml_chunk) : x_end) : x_end;
+  const int t_step = ML ? 1 : wgs_xcd;
   int tiles_per_img = a.tiles_x * a.tiles_y, tile0 = 0, cur_l = ML ? -1 : 0;
   (void)cur_l;
   const long in_plane_b = a.in_plane * 2;    // bytes
@@ -789,7 +799,7 @@ __device__ __forceinline__ void pl_block(const PlArgs& a0, const PlLevels& L, ch
     for (int i = 0; i < 16; ++i) n_out32 += (co_base + 8 * (i >> 2) + (i & 3) < a.f_c0 + a.f_c1) ? 1 : 0;
   }
   (void)n_out32;
-  int t = t_begin + bix;
+  int t = t_begin;
   int buf = 0;
   bool first = true;
   if (C::NBUF == 2 && t < t_end) issue_dma(t, 0);

@@ -105,6 +105,19 @@ class PlLevel(C.Structure):
                [('h', C.c_int32), ('w', C.c_int32), ('in_plane_halfs', C.c_int64), ('out_plane_halfs', C.c_int64)]
 
 
+class PlHeadDesc(C.Structure):
+    """lfd_pl_head_desc_t"""
+    _fields_ = [('mode', C.c_int32), ('n', C.c_int32), ('cin', C.c_int32), ('relu0', C.c_int32), ('f_c0', C.c_int32), ('f_c1', C.c_int32),
+                ('gn_in_eps', C.c_float), ('pad_', C.c_int32), ('f_image_stride0', C.c_int64), ('f_image_stride1', C.c_int64)]
+
+
+class PlHeadLevel(C.Structure):
+    """lfd_pl_head_level_t"""
+    _fields_ = [(k, C.c_void_p) for k in ('in_', 'out', 'w0', 'b0', 'w1', 'b1', 'gn_sums', 'gn_in_sums', 'gn_in_gamma', 'gn_in_beta',
+                                          'f_out0', 'f_out1', 'scale1')] + \
+               [('in_plane_halfs', C.c_int64), ('pixels', C.c_int32), ('pad_', C.c_int32)]
+
+
 PL_GN_REPLICAS = 8                      # LFD_PL_GN_REPLICAS
 ABI_VERSION = 3                         # LFD_HIP_ABI_VERSION
 HEAD_FOLDED_HALFS = 4 * 9 * 64 * 8      # LFD_HEAD_FOLDED_HALFS
@@ -264,6 +277,7 @@ _SIGNATURES = {
     'lfd_pl_stem2x': (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     'lfd_pl_conv2d': (C.c_int, [C.POINTER(PlConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'lfd_pl_conv2d_levels': (C.c_int, [C.POINTER(PlConvDesc), C.POINTER(PlLevel), _I32, _P, _P]),
+    'lfd_pl_head_levels': (C.c_int, [C.POINTER(PlHeadDesc), C.POINTER(PlHeadLevel), _I32, _P, _P]),
     'lfd_pl_groupnorm_relu': (C.c_int, [_P, _I64, _I32, _I64, _I32, _P, _P, _P, _F, _I32, _P]),
     'lfd_p32_groupnorm_workspace_bytes': (_SZ, [_I32, _I32]),
     'lfd_p32_groupnorm_relu_f32': (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _F, _I32, _P, _SZ, _P]),
@@ -275,7 +289,7 @@ _SIGNATURES = {
 # environment variable any more; this host layer applies them once, explicitly, when it loads the library (tests and the A/B
 # tools that start a fresh interpreter per variant keep working), and `tune()` sets a knob at run time.
 TUNE_KEYS = {'HEAD2': 0, 'H2_CHUNK': 1, 'H2_AGPR': 2, 'H2_A1': 3, 'STEM2X': 4, 'X2_ALN': 5, 'X2_STAGGER': 6, 'BLOCK_ROWS': 7,
-             'ROWS_WGS': 8, 'CONV128_SPLITK': 9, 'CONV0_VALU': 10, 'PL_C3': 11}
+             'ROWS_WGS': 8, 'CONV128_SPLITK': 9, 'CONV0_VALU': 10, 'PL_C3': 11, 'PL_HEAD_OUT_REGS': 12}
 
 
 def tune(name, value=None):

@@ -99,6 +99,12 @@ def pack_planes_stem2x_tail_weight(w):
     return torch.stack([hi, lo], 0).contiguous()
 
 
+def _flat_head_enabled():
+    """LFD_P2_FLATHEAD=0: the neck / head through the generic multi-level conv (lfd_pl_conv2d_levels) instead of the flat-tile
+    kernels of round 6 (lfd_pl_head_levels) -- A/B timing, tests"""
+    return os.environ.get('LFD_P2_FLATHEAD', '1') != '0'
+
+
 def _stem2x_enabled():
     """LFD_P2_STEM2X=0: the 'faster' stem as two launches (lfd_pl_stem_pair + lfd_pl_conv2d with a chained 1x1) instead of
     lfd_pl_stem2x (A/B timing, tests); =2: lfd_pl_stem2x for every input format (tests)"""
@@ -452,8 +458,64 @@ class PlanesPlan(object):
             d.gn_in_eps = o.gnin[3]
         return d, src, dst, res, dsd, f0, f1
 
+    def _flat_head_modes(self):
+        """[mode per launch group] when every neck / head launch is one of the three forms lfd_pl_head_levels covers (round 6,
+        csrc/planes_head.hip: flat pixel tiles, fp32 intermediates) -- neck + first tower conv (0), a later tower conv on a
+        GroupNorm input (1), the cls | reg output conv (2) -- else None: the merged-path heads of the WIDERFACE configurations."""
+        if self.level_groups is None:
+            return None
+        modes = []
+        for grp in self.level_groups:
+            o = self.ops[grp[0]]
+            if o.tail is not None and o.gn is not None and o.gnin is None and o.out_mode == 1 and o.cin in (64, 128) and o.cout == 128 and not o.tail[2]:
+                modes.append(0)
+            elif o.tail is None and o.gnin is not None and o.out_mode == 1 and o.cin == 128 and o.cout == 128:
+                modes.append(1)
+            elif o.tail is None and o.gnin is not None and o.out_mode == 2 and o.cin == 128 and o.f_c0 + o.f_c1 <= 64:
+                modes.append(2)
+            else:
+                return None
+        return modes
+
+    def _launch_levels_flat(self, st, modes):
+        """the neck + head through lfd_pl_head_levels: the plane buffers of the tower convs hold fp32 [N, H, W, 128] (same bytes)"""
+        l, sp = lib(), stream_ptr()
+        zeros = ptr(ops.zero_line(self.device))
+        if st.flat_calls is None:
+            calls = []
+            for grp, mode in zip(self.level_groups, modes):
+                arr = (_lib.PlHeadLevel * len(grp))()
+                d = _lib.PlHeadDesc()
+                for j, i in enumerate(grp):
+                    o = self.ops[i]
+                    src = st.bufs[o.src]
+                    lv, gi = arr[j], o.gnin
+                    lv.in_, lv.w0, lv.b0 = src.data_ptr(), o.w.data_ptr(), o.b.data_ptr()
+                    lv.pixels, lv.in_plane_halfs = src.shape[2] * src.shape[3], src[0].numel()
+                    d.mode, d.n, d.cin, d.relu0 = mode, st.n, o.cin, o.relu
+                    if mode == 0:
+                        lv.w1, lv.b1 = o.tail[0].data_ptr(), o.tail[1].data_ptr()
+                    if mode != 2:
+                        lv.out, lv.gn_sums = st.bufs[o.dst].data_ptr(), st.gn_sums[o.gn].data_ptr()
+                    if gi is not None:
+                        lv.gn_in_sums, lv.gn_in_gamma, lv.gn_in_beta = st.gn_sums[gi[0]].data_ptr(), gi[1].data_ptr(), gi[2].data_ptr()
+                        d.gn_in_eps = gi[3]
+                    if mode == 2:
+                        d.f_c0, d.f_c1 = o.f_c0, o.f_c1
+                        d.f_image_stride0, d.f_image_stride1 = st.P * o.f_c0, st.P * 4
+                        lv.f_out0 = (st.cls.data_ptr() + st.p_off[o.level] * o.f_c0 * 4) if o.f_c0 else None
+                        lv.f_out1 = (st.reg.data_ptr() + st.p_off[o.level] * 4 * 4) if o.f_c1 else None
+                        lv.scale1 = o.scale.data_ptr() if o.scale is not None else None
+                calls.append((d, arr, len(grp)))
+            st.flat_calls = calls
+        for d, arr, n in st.flat_calls:
+            check(l.lfd_pl_head_levels(C.byref(d), arr, n, zeros, sp), 'lfd_pl_head_levels')
+
     def _launch_levels(self, st):
         """the neck + head: one launch per conv of the stack (and input width) over all pyramid levels"""
+        modes = self._flat_head_modes() if _flat_head_enabled() else None
+        if modes is not None:
+            return self._launch_levels_flat(st, modes)
         l, sp = lib(), stream_ptr()
         zeros = ptr(ops.zero_line(self.device))
         if st.level_calls is None:
@@ -557,3 +619,4 @@ class _State(object):
             self.side = torch.cuda.Stream(device=dev)
         self.graph = {}
         self.level_calls = None
+        self.flat_calls = None

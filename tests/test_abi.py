@@ -137,7 +137,9 @@ def test_ctypes_struct_mirrors_match_the_header_layout(tmp_path):
              'lfd_head_desc_t': _lib.HeadDesc, 'lfd_head_level_ptrs_t': _lib.HeadLevelPtrs, 'lfd_assign_desc_t': _lib.AssignDesc,
              'lfd_loss_desc_t': _lib.LossDesc, 'lfd_pack_job_t': _lib.PackJob, 'lfd_detect_ext_t': _lib.DetectExt,
              'lfd_p32_conv_desc_t': _lib.P32ConvDesc, 'lfd_head_out_seg_t': _lib.HeadOutSeg, 'lfd_head_out_level_t': _lib.HeadOutLevel, 'lfd_bn_bwd_level_t': _lib.BnBwdLevel, 'lfd_bn_fwd_level_t': _lib.BnFwdLevel,
-             'lfd_wgrad_job_t': _lib.WgradJob, 'lfd_rowsum_job_t': _lib.RowsumJob}
+             'lfd_wgrad_job_t': _lib.WgradJob, 'lfd_rowsum_job_t': _lib.RowsumJob,
+             'lfd_pl_conv_desc_t': _lib.PlConvDesc, 'lfd_pl_level_t': _lib.PlLevel,
+             'lfd_pl_head_desc_t': _lib.PlHeadDesc, 'lfd_pl_head_level_t': _lib.PlHeadLevel}
     header = open(os.path.join(ROOT, 'include', 'lfd_hip.h')).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lfd_hip.h"', 'int main(void) {']
     for cname, mirror in pairs.items():
@@ -170,7 +172,7 @@ def test_tuning_knobs_are_explicit_state_and_the_library_reads_no_environment():
     count = keys.pop('COUNT')
     assert keys == _lib.TUNE_KEYS and count == len(keys)
     defaults = {'HEAD2': 1, 'H2_CHUNK': 0, 'H2_AGPR': 1, 'H2_A1': 1, 'STEM2X': 1, 'X2_ALN': 1, 'X2_STAGGER': 0, 'BLOCK_ROWS': -1,
-                'ROWS_WGS': 0, 'CONV128_SPLITK': 1, 'CONV0_VALU': 0, 'PL_C3': 2}
+                'ROWS_WGS': 0, 'CONV128_SPLITK': 1, 'CONV0_VALU': 0, 'PL_C3': 2, 'PL_HEAD_OUT_REGS': 1}
     for name, key in keys.items():
         if os.environ.get('LFD_' + name) is None:
             assert l.lfd_tuning_get(key) == defaults[name], name

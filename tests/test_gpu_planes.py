@@ -420,12 +420,24 @@ def test_planes_plan_equals_the_fp32_tensor_plan(name, shape):
         # the neck / head convs as one launch over all pyramid levels (lfd_pl_conv2d_levels, the default) == one launch per
         # level (lfd_pl_conv2d), bit for bit
         assert plan.level_groups is not None and len(plan.level_groups) < len(plan.ops) - plan.head_start
-        os.environ['LFD_P2_LEVELS'] = '0'
+        # round 6: heads of the merged-path form run the flat-tile kernels (lfd_pl_head_levels): another order of sums -- close
+        # to, not bit-equal with, the generic conv; LFD_P2_FLATHEAD=0 selects the generic multi-level conv, which IS bit-equal
+        # to one launch per level
+        flat = plan._flat_head_modes() is not None
+        os.environ['LFD_P2_FLATHEAD'] = '0'
         try:
-            c1, r1 = m(x)
-            assert torch.equal(c, c1) and torch.equal(r, r1)
+            cg, rg = [t.clone() for t in m(x)]
+            os.environ['LFD_P2_LEVELS'] = '0'
+            try:
+                c1, r1 = m(x)
+                assert torch.equal(cg, c1) and torch.equal(rg, r1)
+            finally:
+                del os.environ['LFD_P2_LEVELS']
         finally:
-            del os.environ['LFD_P2_LEVELS']
+            del os.environ['LFD_P2_FLATHEAD']
+        eg = max(float((c - cg).abs().max()), float((r - rg).abs().max()))
+        print('%s: flat-tile head %s; vs the generic multi-level conv %.2e' % (name, flat, eg))
+        assert (eg <= 2e-5) if flat else (eg == 0.0)
         if plan.stem2x is not None:
             # the whole 'faster' stem as one launch (lfd_pl_stem2x; the default for resident fp16 frames) on this fp32 input
             # == the two-launch stem up to the summation order of conv0
@@ -450,3 +462,84 @@ def test_planes_plan_equals_the_fp32_tensor_plan(name, shape):
     err = max(float((c - c0).abs().max()), float((r - r0).abs().max()))
     print('%s: planes vs fp32 tensors %.2e' % (name, err))
     assert err <= 2e-5
+
+
+@pytest.mark.parametrize('cin,sizes,n,ccls', [(64, [(19, 37), (9, 15), (5, 14)], 2, 1), (128, [(17, 30), (3, 5)], 3, 1), (64, [(8, 8)], 1, 46)])
+def test_pl_head_levels_chain_vs_float64(cin, sizes, n, ccls):
+    """lfd_pl_head_levels (csrc/planes_head.hip, round 6): the neck + head of lfd_head.py:164-185 over flat pixel tiles --
+    mode 0 (tap planes -> neck 1x1 + ReLU -> first tower 1x1, fp32 out + GroupNorm sums), mode 1 (GroupNorm + ReLU -> tower
+    1x1), mode 2 (GroupNorm + ReLU -> cls | reg 1x1 (+ Scale) into the level-concatenated fp32 outputs) -- several pyramid
+    levels per launch with their own filters, partial last tiles, against the same chain in float64."""
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(cin + n + len(sizes))
+    z = ops.zero_line(dev)
+    P = [h * w for h, w in sizes]
+    Ptot, poff = sum(P), [sum(P[:i]) for i in range(len(P))]
+    cls = torch.full((n, Ptot, ccls), float('nan'), device=dev)
+    reg = torch.full((n, Ptot, 4), float('nan'), device=dev)
+    gsum = torch.zeros((2, _lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device=dev)
+    keep, lv0, lv1, lv2, refs, w3s = [], (_lib.PlHeadLevel * len(P))(), (_lib.PlHeadLevel * len(P))(), (_lib.PlHeadLevel * len(P))(), [], []
+    for i, p in enumerate(P):
+        x = torch.randn(n, p, cin, generator=g) * 2
+        xp = engine_p2.to_planes(x.reshape(n, p, 1, cin))
+        xv = engine_p2.from_planes(xp).reshape(n, p, cin).double()
+        w0, b0 = torch.randn(128, cin, generator=g) / cin ** 0.5, torch.randn(128, generator=g)
+        w1, b1 = torch.randn(128, 128, generator=g) / 128 ** 0.5, torch.randn(128, generator=g)
+        w2, b2 = torch.randn(128, 128, generator=g) / 128 ** 0.5, torch.randn(128, generator=g)
+        w3, b3 = torch.randn(ccls + 4, 128, generator=g) / 128 ** 0.5, torch.randn(ccls + 4, generator=g)
+        ga1, be1, ga2, be2 = [torch.randn(128, generator=g) * s + o for s, o in ((0.3, 1.0), (0.3, 0.0), (0.3, 1.0), (0.3, 0.0))]
+        scale = torch.tensor([1.7 + i])
+        t1 = (xv @ w0.double().t() + b0.double()).relu() @ w1.double().t() + b1.double()
+        y1 = F.group_norm(t1.permute(0, 2, 1), 16, ga1.double(), be1.double(), 1e-5).permute(0, 2, 1).relu()
+        t2 = y1 @ w2.double().t() + b2.double()
+        y2 = F.group_norm(t2.permute(0, 2, 1), 16, ga2.double(), be2.double(), 1e-5).permute(0, 2, 1).relu()
+        o3 = y2 @ w3.double().t() + b3.double()
+        refs.append((t1, t2, o3[..., :ccls], o3[..., ccls:] * float(scale)))
+        w3s.append(w3.float().contiguous())
+        t1d, t2d = torch.full((n, p, 128), float('nan'), device=dev), torch.full((n, p, 128), float('nan'), device=dev)
+        pk = [engine_p2.pack_planes_weight(w.reshape(w.shape[0], w.shape[1], 1, 1)).to(dev) for w in (w0, w1, w2, w3)]
+        bs = [engine_p2._pad_bias(b, 128).to(dev) for b in (b0, b1, b2, b3)]
+        gn = [t.to(dev) for t in (ga1, be1, ga2, be2, scale)]
+        xpd = xp.to(dev)
+        keep.append((xpd, t1d, t2d, pk, bs, gn))
+        a, b_, c = lv0[i], lv1[i], lv2[i]
+        a.in_, a.out, a.w0, a.b0, a.w1, a.b1, a.gn_sums = xpd.data_ptr(), t1d.data_ptr(), pk[0].data_ptr(), bs[0].data_ptr(), pk[1].data_ptr(), bs[1].data_ptr(), gsum[0].data_ptr()
+        a.in_plane_halfs, a.pixels = xpd[0].numel(), p
+        b_.in_, b_.out, b_.w0, b_.b0, b_.gn_sums = t1d.data_ptr(), t2d.data_ptr(), pk[2].data_ptr(), bs[2].data_ptr(), gsum[1].data_ptr()
+        b_.gn_in_sums, b_.gn_in_gamma, b_.gn_in_beta, b_.pixels = gsum[0].data_ptr(), gn[0].data_ptr(), gn[1].data_ptr(), p
+        c.in_, c.w0, c.b0, c.pixels = t2d.data_ptr(), pk[3].data_ptr(), bs[3].data_ptr(), p
+        c.gn_in_sums, c.gn_in_gamma, c.gn_in_beta = gsum[1].data_ptr(), gn[2].data_ptr(), gn[3].data_ptr()
+        c.f_out0, c.f_out1, c.scale1 = cls.data_ptr() + poff[i] * ccls * 4, reg.data_ptr() + poff[i] * 16, gn[4].data_ptr()
+    # (every level of a launch shares the sums buffer here only because the test gives each level the same image count and
+    #  checks levels one at a time: one level per launch)
+    for i in range(len(P)):
+        gsum.zero_()
+        for mode, arr in ((0, lv0), (1, lv1), (2, lv2)):
+            d = _lib.PlHeadDesc()
+            d.mode, d.n, d.cin, d.relu0, d.gn_in_eps = mode, n, cin, 1, 1e-5
+            d.f_c0, d.f_c1, d.f_image_stride0, d.f_image_stride1 = ccls, 4, Ptot * ccls, Ptot * 4
+            one = (_lib.PlHeadLevel * 1)(arr[i])
+            check(lib().lfd_pl_head_levels(C.byref(d), one, 1, ptr(z), stream_ptr()), 'lfd_pl_head_levels')
+        torch.cuda.synchronize()
+        t1, t2, rc, rr = refs[i]
+        for got, ref, what in ((keep[i][1], t1, 't1'), (keep[i][2], t2, 't2'), (cls[:, poff[i]:poff[i] + P[i]], rc, 'cls'),
+                               (reg[:, poff[i]:poff[i] + P[i]], rr, 'reg')):
+            gg = got.cpu().double()
+            assert not torch.isnan(gg).any(), what + ': unwritten output'
+            err, mag = float((gg - ref).abs().max()), float(ref.abs().max())
+            print('level %d %s: err %.2e (max |y| %.2f)' % (i, what, err, mag))
+            assert err <= 2.5 * TOL * max(1.0, mag), (i, what)
+    # all levels in ONE launch per mode (every level its own sums): the level-concatenated outputs again
+    gs = torch.zeros((len(P), 2, _lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device=dev)
+    for i in range(len(P)):
+        lv0[i].gn_sums, lv1[i].gn_in_sums = gs[i, 0].data_ptr(), gs[i, 0].data_ptr()
+        lv1[i].gn_sums, lv2[i].gn_in_sums = gs[i, 1].data_ptr(), gs[i, 1].data_ptr()
+    c_one, r_one = cls.clone(), reg.clone()
+    cls.fill_(float('nan')); reg.fill_(float('nan'))
+    for mode, arr in ((0, lv0), (1, lv1), (2, lv2)):
+        d = _lib.PlHeadDesc()
+        d.mode, d.n, d.cin, d.relu0, d.gn_in_eps = mode, n, cin, 1, 1e-5
+        d.f_c0, d.f_c1, d.f_image_stride0, d.f_image_stride1 = ccls, 4, Ptot * ccls, Ptot * 4
+        check(lib().lfd_pl_head_levels(C.byref(d), arr, len(P), ptr(z), stream_ptr()), 'lfd_pl_head_levels')
+    torch.cuda.synchronize()
+    assert torch.equal(cls, c_one) and torch.equal(reg, r_one), 'all levels in one launch != one launch per level'
