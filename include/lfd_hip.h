@@ -83,7 +83,8 @@ typedef enum lfd_tune_key {
   LFD_TUNE_PL_C3 = 11,         /* planes mode, 3x3 s1 64-channel convs: 2 = k_pl_c3p (K split over a wave pair per SIMD),
                                   1 = k_pl_c3 (one wave per SIMD, epilogue under the next contraction), 0 = generic      default 2 */
   LFD_TUNE_PL_HEAD_OUT_REGS = 12, /* 1: lfd_pl_head_levels mode 2 with the fp32 tile landing in registers (k_pl_head_out)           default 1 */
-  LFD_TUNE_COUNT = 13
+  LFD_TUNE_PL_HEAD_ROLES = 13,  /* 1: lfd_pl_head_levels mode 1 with producer / consumer waves (k_pl_head_b2)                              default 1 */
+  LFD_TUNE_COUNT = 14
 } lfd_tune_key_t;
 LFD_API int lfd_tuning_set(int32_t key, int32_t value);
 LFD_API int32_t lfd_tuning_get(int32_t key);

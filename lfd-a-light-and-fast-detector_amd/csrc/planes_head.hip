@@ -732,6 +732,272 @@ int launch_pl_head_out(PhArgs& a, hipStream_t st) {
   return LFD_OK;
 }
 
+// ---- MODE 1 with PRODUCER and CONSUMER waves (k_pl_head_b2, round 6).  k_pl_head<1> is a chain per workgroup -- fetch,
+// GroupNorm pass, contraction, stores -- and two workgroups per CU overlap only what happens to fall together (waves waiting
+// 38 % of the time, 4.1 TB/s).  Here a 512-thread workgroup owns the CU: waves 0-3 (P) hold the fp32 tiles of the next TWO
+// steps in registers (64 KB per CU in flight all the time, no raw tile in LDS), normalise tile i + 1 and write its hi / lo operand
+// planes while waves 4-7 (Q, one 32-row slab each) contract tile i, store it and add up its GroupNorm sums; the operand planes
+// are double-buffered, one barrier per tile.
+__global__ __launch_bounds__(512, 1) void k_pl_head_b2(PhArgs a) {
+  constexpr int TPX = 64, OP_PLANE = TPX * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int x_begin = xcd * per_xcd;
+  const int x_end = (x_begin + per_xcd) < a.ntiles ? (x_begin + per_xcd) : a.ntiles;
+  const int wgs_xcd = (nblk + 7 - xcd) / 8;
+  const int chunk = (x_end - x_begin + wgs_xcd - 1) / (wgs_xcd > 0 ? wgs_xcd : 1);
+  const int t_first = x_begin + bix * chunk;
+  const int t_last = (t_first + chunk) < x_end ? (t_first + chunk) : x_end;
+  const int nt = t_last > t_first ? t_last - t_first : 0;
+  int lstart[LFD_MAX_LEVELS];
+#pragma unroll
+  for (int i = 0; i < LFD_MAX_LEVELS; ++i) lstart[i] = i < a.n_levels ? a.lv[i].tile_start : 0x7fffffff;
+  auto level_of = [&](int t) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < LFD_MAX_LEVELS; ++i) l += (t >= lstart[i]) ? 1 : 0;
+    return l;
+  };
+  auto with_level = [&](int l, auto&& f) {
+    static_for([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (l == i) f(a.lv[i]);
+    }, std::make_integer_sequence<int, LFD_MAX_LEVELS>{});
+  };
+  if (wave < 4) {
+    // ================================================ P: fetch + GroupNorm + ReLU -> operand planes =================
+    const int tid = (int)threadIdx.x;                  // 0 .. 255
+    const int pj = tid & 31, gi = pj >> 1, prow = tid >> 5;
+    int d_l = -1, d_P = 1, d_tpi = 1, d_t0 = 0;
+    const char* d_in = nullptr;
+    auto load_tile = [&](int t, float4* dst) {
+      const int l = level_of(t);
+      if (l != d_l) {
+        d_l = l;
+        with_level(l, [&](const PhLevel& v) { d_in = reinterpret_cast<const char*>(v.in); d_P = v.P; d_tpi = v.tiles_per_img; d_t0 = v.tile_start; });
+      }
+      const int rel = t - d_t0;
+      const int n = rel / d_tpi;
+      const int p0 = (rel - n * d_tpi) * TPX;
+      const char* base = d_in + (long)n * d_P * 512 + pj * 16;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int p = p0 + prow + 8 * r;
+        p = p < d_P ? p : d_P - 1;          // (rows past the image: clamped -- their results are never stored, pixels do not mix)
+        dst[r] = *reinterpret_cast<const float4*>(base + (long)p * 512);
+      }
+    };
+    // GroupNorm scale / shift of this thread's four channels for (level, image) of tile t
+    int g_l = -1, g_P = 1, g_tpi = 1, g_t0 = 0;
+    const unsigned long long* g_in = nullptr;
+    const float* g_gamma = nullptr;
+    const float* g_beta = nullptr;
+    auto gn_params = [&](int t, float* ga, float* gb, int& key) {
+      const int l = level_of(t);
+      if (l != g_l) {
+        g_l = l;
+        with_level(l, [&](const PhLevel& v) { g_in = v.gn_in; g_gamma = v.gamma; g_beta = v.beta; g_P = v.P; g_tpi = v.tiles_per_img; g_t0 = v.tile_start; });
+      }
+      const int n = (t - g_t0) / g_tpi;
+      const int k = l * 65536 + n;
+      if (k == key) return;
+      key = k;
+      long long s = 0, q = 0;
+#pragma unroll
+      for (int r = 0; r < kGnRep; ++r) {       // (integer adds: order-independent, the statistics stay bit-reproducible)
+        s += (long long)g_in[(((size_t)r * a.N + n) * 16 + gi) * 2];
+        q += (long long)g_in[(((size_t)r * a.N + n) * 16 + gi) * 2 + 1];
+      }
+      const double cnt = (double)g_P * 8.0;
+      const double m = (double)s / kGnFix / cnt;
+      double var = (double)q / kGnFix / cnt - m * m;
+      var = var > 0. ? var : 0.;
+      const float rstd = (float)(1. / sqrt(var + (double)a.eps)), mean = (float)m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ga[e] = rstd * g_gamma[pj * 4 + e];
+        gb[e] = g_beta[pj * 4 + e] - mean * ga[e];
+      }
+    };
+    float4 r0[8], r1[8], r2[8];
+    float ga[4], gb[4], na[4], nb[4];
+    int key = -1, nkey = -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ga[e] = gb[e] = na[e] = nb[e] = 0.f;
+    if (nt > 0) load_tile(t_first, r0);
+    if (nt > 1) load_tile(t_first + 1, r1);
+    if (nt > 0) gn_params(t_first, na, nb, nkey);
+    for (int i = 0; i <= nt; ++i) {
+      if (i < nt) {
+        if (i + 2 < nt) load_tile(t_first + i + 2, r2);
+        if (nkey != key) {
+          key = nkey;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ga[e] = na[e]; gb[e] = nb[e]; }
+        }
+        char* opw = smem + (i & 1) * 2 * OP_PLANE;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int p = prow + 8 * r;
+          const float4 v = r0[r];
+          const float y0 = fmaxf(fmaf(v.x, ga[0], gb[0]), 0.f), y1 = fmaxf(fmaf(v.y, ga[1], gb[1]), 0.f);
+          const float y2 = fmaxf(fmaf(v.z, ga[2], gb[2]), 0.f), y3 = fmaxf(fmaf(v.w, ga[3], gb[3]), 0.f);
+          uint2 oh, ol;
+          split2(y0, y1, oh.x, ol.x);
+          split2(y2, y3, oh.y, ol.y);
+          const int o = p * 256 + ((gi ^ (p & 15)) * 16) + (pj & 1) * 8;
+          *reinterpret_cast<uint2*>(opw + o) = oh;
+          *reinterpret_cast<uint2*>(opw + OP_PLANE + o) = ol;
+        }
+        // the next tile's scale / shift (a dependent chain of global loads when the image changes) while the consumers work
+        if (i + 1 < nt) gn_params(t_first + i + 1, na, nb, nkey);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { r0[r] = r1[r]; r1[r] = r2[r]; }
+      }
+      block_barrier();
+    }
+  } else {
+    // ================================================ Q: contraction + fp32 stores + GroupNorm sums ==================
+    const int slab = wave - 4;
+    const int h = lane >> 5, pix = lane & 31;
+    half8 wh[8], wl[8];
+    float bias[16];
+    PhLevel lv{};
+    int cur_l = -1;
+    double gs[4], gq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gs[g] = gq[g] = 0.;
+    int gn_n = -1;
+    unsigned long long* gn_dst = nullptr;
+    auto gn_flush = [&]() {
+      if (gn_n >= 0) {
+        unsigned long long* dst = gn_dst + ((((size_t)(blockIdx.x % kGnRep)) * a.N + gn_n) * 16 + slab * 4) * 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const double s = wave_sum(gs[g]), q = wave_sum(gq[g]);
+          if (lane == 0) {
+            atomicAdd(dst + 2 * g, (unsigned long long)__double2ll_rn(s * kGnFix));
+            atomicAdd(dst + 2 * g + 1, (unsigned long long)__double2ll_rn(q * kGnFix));
+          }
+          gs[g] = gq[g] = 0.;
+        }
+      }
+    };
+    const int xkey = (pix & 15) ^ h;
+    for (int i = 0; i <= nt; ++i) {
+      if (i >= 1) {
+        const int t = t_first + i - 1;
+        const int l = level_of(t);
+        if (l != cur_l) {
+          gn_flush();
+          gn_n = -1;
+          cur_l = l;
+          with_level(l, [&](const PhLevel& v) { lv = v; });
+          const half8* ws = lv.w0 + ((size_t)slab * 8) * 64 + lane;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            wh[k] = ws[(size_t)k * 64];
+            wl[k] = ws[a.w_plane0 + (size_t)k * 64];
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(lv.b0 + slab * 32 + 4 * h + 8 * g);
+            bias[4 * g + 0] = b4.x; bias[4 * g + 1] = b4.y; bias[4 * g + 2] = b4.z; bias[4 * g + 3] = b4.w;
+          }
+        }
+        const int rel = t - lv.tile_start;
+        const int n = rel / lv.tiles_per_img;
+        const int p0 = (rel - n * lv.tiles_per_img) * TPX;
+        if (n != gn_n) {
+          gn_flush();
+          gn_n = n; gn_dst = lv.gn_out;
+        }
+        f32x16 am[2], ac[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { am[0][r] = am[1][r] = bias[r]; ac[0][r] = ac[1][r] = 0.f; }
+        const char* op = smem + ((i - 1) & 1) * 2 * OP_PLANE;
+        const char* o0 = op + pix * 256, * o1 = op + (32 + pix) * 256;
+        half8 xh[2][2], xl[2][2];
+        xh[0][0] = *reinterpret_cast<const half8*>(o0 + ((0 ^ xkey) << 4)); xl[0][0] = *reinterpret_cast<const half8*>(o0 + OP_PLANE + ((0 ^ xkey) << 4));
+        xh[0][1] = *reinterpret_cast<const half8*>(o1 + ((0 ^ xkey) << 4)); xl[0][1] = *reinterpret_cast<const half8*>(o1 + OP_PLANE + ((0 ^ xkey) << 4));
+        static_for([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (k + 1 < 8) {
+            constexpr int q2 = 2 * (k + 1);
+            xh[(k + 1) & 1][0] = *reinterpret_cast<const half8*>(o0 + ((q2 ^ xkey) << 4)); xl[(k + 1) & 1][0] = *reinterpret_cast<const half8*>(o0 + OP_PLANE + ((q2 ^ xkey) << 4));
+            xh[(k + 1) & 1][1] = *reinterpret_cast<const half8*>(o1 + ((q2 ^ xkey) << 4)); xl[(k + 1) & 1][1] = *reinterpret_cast<const half8*>(o1 + OP_PLANE + ((q2 ^ xkey) << 4));
+          }
+          PL_SB();
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) am[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xh[k & 1][pt], am[pt], 0, 0, 0);
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) ac[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], xl[k & 1][pt], ac[pt], 0, 0, 0);
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) ac[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], xh[k & 1][pt], ac[pt], 0, 0, 0);
+          PL_SB();
+        }, std::make_integer_sequence<int, 8>{});
+        // stores straight from the accumulator layout: 16 bytes per lane, 32-byte runs per pixel that the four stores of the wave
+        // complete to full 128-byte lines (staged through LDS into whole-line stores the launch was 3-5 us SLOWER: the bytes, not
+        // the store shape, bound it -- a plain copy of the same 357 MB takes 67 us on this part, tools/ub/hbm_rates.py)
+        float* obase = lv.out + ((size_t)n * lv.P + p0) * 128 + slab * 32 + 4 * h;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const int px = pt * 32 + pix;
+          const bool ok = p0 + px < lv.P;
+          float* orow = obase + (size_t)px * 128;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = comb(am[pt][4 * g + 0], ac[pt][4 * g + 0]);
+            v.y = comb(am[pt][4 * g + 1], ac[pt][4 * g + 1]);
+            v.z = comb(am[pt][4 * g + 2], ac[pt][4 * g + 2]);
+            v.w = comb(am[pt][4 * g + 3], ac[pt][4 * g + 3]);
+            if (ok) {
+              *reinterpret_cast<float4*>(orow + 8 * g) = v;
+              const float s = (v.x + v.y) + (v.z + v.w);
+              const float q = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+              gs[g] += (double)s;
+              gq[g] += (double)q;
+            }
+          }
+        }
+      }
+      block_barrier();
+    }
+    gn_flush();
+  }
+}
+
+int launch_pl_head_b2(PhArgs& a, hipStream_t st) {
+  long nt = 0;
+  for (int i = 0; i < a.n_levels; ++i) {
+    a.lv[i].tiles_per_img = (a.lv[i].P + 63) / 64;
+    a.lv[i].tile_start = (int)nt;
+    nt += (long)a.N * a.lv[i].tiles_per_img;
+    if (nt > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
+  }
+  a.ntiles = (int)nt;
+  constexpr int LDSB = 4 * 64 * 256;
+  auto kern = k_pl_head_b2;
+  static unsigned long long attr_done_mask = 0;
+  const int attr_done_dev = lfd_device_ordinal();
+  if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
+      return LFD_ERR_LAUNCH_FAILED;
+    LFD_DONE_ON_DEVICE(attr_done_mask, attr_done_dev);
+  }
+  int blocks = 256;
+  if (blocks > 8 * ((a.ntiles + 7) / 8)) blocks = 8 * ((a.ntiles + 7) / 8);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), LDSB, st, a);
+  LFD_CHECK_LAUNCH();
+  return LFD_OK;
+}
+
 template <int MODE, int CIN, int NSLAB>
 int launch_pl_head(PhArgs& a, hipStream_t st) {
   using C = PhCfg<MODE, CIN, NSLAB>;
@@ -799,7 +1065,7 @@ extern "C" int lfd_pl_head_levels(const lfd_pl_head_desc_t* d, const lfd_pl_head
     l.P = s.pixels;
   }
   if (d->mode == 0) return d->cin == 64 ? pl::launch_pl_head<0, 64, 4>(a, st) : pl::launch_pl_head<0, 128, 4>(a, st);
-  if (d->mode == 1) return pl::launch_pl_head<1, 128, 4>(a, st);
+  if (d->mode == 1) return lfd_tune(LFD_TUNE_PL_HEAD_ROLES) != 0 ? pl::launch_pl_head_b2(a, st) : pl::launch_pl_head<1, 128, 4>(a, st);
   if (lfd_tune(LFD_TUNE_PL_HEAD_OUT_REGS) != 0) return nslab0 == 1 ? pl::launch_pl_head_out<1>(a, st) : pl::launch_pl_head_out<2>(a, st);
   return nslab0 == 1 ? pl::launch_pl_head<2, 128, 1>(a, st) : pl::launch_pl_head<2, 128, 2>(a, st);
 }

@@ -1,13 +1,12 @@
 """Socket power and shader clock of the MI355X per KERNEL CLASS of both precision modes and for the whole steps (round 6;
 VERDICT r5 next-round item 3: "a tools/power_trace.py record under profiles/ showing it at the socket power limit with the
 clock it holds").  Every launch unit of bench.py's two breakdowns runs back to back for SECONDS seconds while rocm-smi is
-polled from a side thread; then the whole steps (HIP graph, one and two batches in flight).
+polled by a child process; then the whole steps (HIP graph, one and two batches in flight).
     python tools/power_trace_r6.py [seconds per unit] [fp16|precise|steps ...]   -> gpurun_out/power_trace_r6.json"""
 import json
 import os
 import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,40 +15,61 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-samples = []
-phase = ['idle']
-stop = [False]
-
-
-def _num(v):
+# rocm-smi is polled by a CHILD PROCESS (round 6: a polling thread in this interpreter shares the GIL with the launch loop and
+# made the host the bottleneck of the short kernels and of the fp16 step); samples carry wall-clock time stamps, phases are
+# (name, t0, t1) windows recorded here
+_POLLER = r"""
+import json, subprocess, sys, time
+out = open(sys.argv[1], 'w')
+def num(v):
     try:
         return float(str(v).strip('()MhzW% ').split()[0].replace('Mhz', ''))
     except Exception:
         return None
+while True:
+    t = time.time()
+    try:
+        d = json.loads(subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=10).stdout)
+        card = d[sorted(d)[0]]
+        rec = {'t': t}
+        for k, v in card.items():
+            kl = k.lower()
+            if 'power' in kl:
+                rec['power_w'] = num(v)
+            elif 'sclk clock speed' in kl:
+                rec['sclk_mhz'] = num(v)
+        out.write(json.dumps(rec) + '\n'); out.flush()
+    except Exception as e:
+        pass
+    time.sleep(0.02)
+"""
+windows = {}
+_poll_file = '/tmp/lfd_power_samples_%d.jsonl' % os.getpid()
+_poll_proc = None
 
 
-def poll():
-    while not stop[0]:
-        try:
-            out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=10).stdout
-            d = json.loads(out)
-            card = d[sorted(d)[0]]
-            rec = {'phase': phase[0]}
-            for k, v in card.items():
-                kl = k.lower()
-                if 'power' in kl:
-                    rec['power_w'] = _num(v)
-                elif 'sclk clock speed' in kl:
-                    rec['sclk_mhz'] = _num(v)
-            samples.append(rec)
-        except Exception as e:
-            samples.append({'phase': phase[0], 'error': repr(e)})
-        time.sleep(0.05)
+def start_poller():
+    global _poll_proc
+    src = '/tmp/lfd_power_poller_%d.py' % os.getpid()
+    open(src, 'w').write(_POLLER)
+    _poll_proc = subprocess.Popen([sys.executable, src, _poll_file])
+
+
+def stop_poller():
+    if _poll_proc is not None:
+        _poll_proc.terminate()
+
+
+def _samples():
+    try:
+        return [json.loads(l) for l in open(_poll_file) if l.strip()]
+    except Exception:
+        return []
 
 
 def summarize(name):
-    rows = [s for s in samples if s['phase'] == name and 'power_w' in s]
-    rows = rows[len(rows) // 4:]        # (the first quarter of a phase is the ramp)
+    t0, t1 = windows[name]
+    rows = [r for r in _samples() if t0 + 0.25 * (t1 - t0) <= r['t'] <= t1]        # (the first quarter of a phase is the ramp)
     if not rows:
         return {}
     pw = [r['power_w'] for r in rows if r.get('power_w') is not None]
@@ -63,18 +83,21 @@ def main():
     what = [a for a in sys.argv[1:] if not a.replace('.', '').isdigit()] or ['fp16', 'precise', 'steps']
     import bench
     from lfd_amd import configs, engine, _lib
-    th = threading.Thread(target=poll, daemon=True)
-    th.start()
+    start_poller()
     dev = torch.device('cuda')
     m = configs.build_model('WIDERFACE_LFD_S')
     configs.perturb_weights(m)
     m.eval().cuda()
     m.use_graph = True
-    xs = [(torch.rand(8, 1080, 1920, 3, device=dev) * 2 - 1).half() for _ in range(2)]
+    m.max_candidates = 8192
+    m._nms_cfg = dict(type='nms', iou_thr=0.4)
+    xs = (torch.rand(bench.NBUF, 8, 1080, 1920, 3, device=dev) * 2 - 1).half()      # bench.py's rotation of resident frame buffers
     x = xs[0]
     meta = torch.tensor([[1920., 1080., 1.0]] * 8, device=dev)
     res = {'seconds_per_unit': seconds, 'idle': None, 'units': [], 'steps': []}
-    time.sleep(1.0)
+    t_idle = time.time()
+    time.sleep(1.5)
+    windows['idle'] = (t_idle, time.time())
     res['idle'] = summarize('idle')
     ctr = [0]
 
@@ -82,16 +105,16 @@ def main():
         ctr[0] += 1
         name = 'u%d' % ctr[0]
         fn(); torch.cuda.synchronize()
-        phase[0] = name
         t0 = time.time()
         n = 0
         while time.time() - t0 < seconds:
-            for _ in range(50):
+            for _ in range(200):
                 fn()
             torch.cuda.synchronize()
-            n += 50
+            n += 200
         dt = time.time() - t0
-        phase[0] = 'gap'
+        windows[name] = (t0, t0 + dt)
+        time.sleep(0.1)
         us = dt / n * 1e6
         row = dict(unit=label, us_per_launch_back_to_back=round(us, 2))
         row.update(summarize(name))
@@ -121,22 +144,23 @@ def main():
                     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 
                     def step(i):
-                        with torch.cuda.stream(streams[i % depth]):
-                            return m.detect_resident(xs[i % depth], meta, slot=i % depth)
-                    for i in range(4):
+                        b = i % bench.NBUF
+                        with torch.cuda.stream(streams[b % depth]):
+                            return m.detect_resident(xs[b], meta, slot=b % depth)
+                    for i in range(2 * bench.NBUF):
                         step(i)
                     torch.cuda.synchronize()
                     name = 'step_%s_%d' % (mode, depth)
-                    phase[0] = name
                     t0 = time.time()
                     n = 0
                     while time.time() - t0 < max(seconds, 3.0):
-                        for i in range(20):
+                        for i in range(400):
                             step(i)
                         torch.cuda.synchronize()
-                        n += 20
+                        n += 400
                     dt = time.time() - t0
-                    phase[0] = 'gap'
+                    windows[name] = (t0, t0 + dt)
+                    time.sleep(0.1)
                     row = dict(step="%s, %d batch(es) in flight, HIP graph replays for %.0f s" % (mode, depth, dt), ms_per_step=round(dt / n * 1e3, 4),
                                images_per_s=round(8 * n / dt, 1), mfma_tflops_issued=round((3 if mode != 'fp16' else 1) * 348.8 * n / dt / 1e3, 1))
                     row.update(summarize(name))
@@ -144,8 +168,7 @@ def main():
                     print(json.dumps(row), flush=True)
                     time.sleep(0.5)
             m.precision = 'fp16'
-    stop[0] = True
-    th.join(timeout=5)
+    stop_poller()
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     tag = os.environ.get('LFD_POWER_TAG', '')
     json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'power_trace_r6%s.json' % tag), 'w'), indent=1)
