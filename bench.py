@@ -763,12 +763,14 @@ def timed_region(model, xs, meta, args, P, streams, dev, sync_ranks):
         for name, serial, per_step in (('pipelined', False, dt / args.steps), ('serial', True, dt_serial / args.steps)):
             n = max(args.steps, int(args.sustained_s / per_step) + 1)
             torch.cuda.synchronize()
+            w0 = time.time()
             t0 = time.perf_counter()
             for i in range(n):
                 step(i, serial=serial)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            sustained[name] = dict(images_per_s=round(BATCH * n / el, 1), ms_per_step=round(el / n * 1e3, 4), steps=n, seconds=round(el, 2))
+            sustained[name] = dict(images_per_s=round(BATCH * n / el, 1), ms_per_step=round(el / n * 1e3, 4), steps=n, seconds=round(el, 2),
+                                   wall_clock_window=[round(w0, 3), round(w0 + el, 3)])      # (tools/power_trace_r6.py joins rocm-smi samples on it)
         sustained['note'] = 'gap-free replays for >= %.1f s of device time (no host synchronisation inside), this rank' % args.sustained_s
     return dict(dt=dt, dt_serial=dt_serial, ev_ms=ev_ms, counts=counts, sustained=sustained)
 

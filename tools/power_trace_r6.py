@@ -138,35 +138,23 @@ def main():
             bench.precise_breakdown(m, x, dev, timer=timer)
             m.precision = 'fp16'
         if 'steps' in what:
+            # the whole steps, measured by bench.py's own timed_region() (graphs captured for the stream set-up they replay on, four
+            # frame buffers in rotation, two batches in flight | serial): its >= 3 s gap-free replays are the power windows
+            import argparse
+            args = argparse.Namespace(steps=20, warmup=5, clock_warmup_s=0.3, sustained_s=max(seconds, 3.0))
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
             for mode in ('fp16', 'fp32_storage'):
                 m.precision = mode
-                for depth in (1, 2):
-                    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-
-                    def step(i):
-                        b = i % bench.NBUF
-                        with torch.cuda.stream(streams[b % depth]):
-                            return m.detect_resident(xs[b], meta, slot=b % depth)
-                    for i in range(2 * bench.NBUF):
-                        step(i)
-                    torch.cuda.synchronize()
-                    name = 'step_%s_%d' % (mode, depth)
-                    t0 = time.time()
-                    n = 0
-                    while time.time() - t0 < max(seconds, 3.0):
-                        for i in range(400):
-                            step(i)
-                        torch.cuda.synchronize()
-                        n += 400
-                    dt = time.time() - t0
-                    windows[name] = (t0, t0 + dt)
-                    time.sleep(0.1)
-                    row = dict(step="%s, %d batch(es) in flight, HIP graph replays for %.0f s" % (mode, depth, dt), ms_per_step=round(dt / n * 1e3, 4),
-                               images_per_s=round(8 * n / dt, 1), mfma_tflops_issued=round((3 if mode != 'fp16' else 1) * 348.8 * n / dt / 1e3, 1))
-                    row.update(summarize(name))
+                r = bench.timed_region(m, xs, meta, args, 2, streams, dev, sync_ranks=False)
+                for name, depth in (('serial', 1), ('pipelined', 2)):
+                    su = r['sustained'][name]
+                    windows['step_%s_%s' % (mode, name)] = tuple(su['wall_clock_window'])
+                    row = dict(step="%s, %d batch(es) in flight, HIP graph replays for %.1f s without host synchronisation" % (mode, depth, su['seconds']),
+                               ms_per_step=su['ms_per_step'], images_per_s=su['images_per_s'],
+                               mfma_tflops_issued=round((3 if mode != 'fp16' else 1) * 348.8 / su['ms_per_step'], 1))
+                    row.update(summarize('step_%s_%s' % (mode, name)))
                     res['steps'].append(row)
                     print(json.dumps(row), flush=True)
-                    time.sleep(0.5)
             m.precision = 'fp16'
     stop_poller()
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
