@@ -610,6 +610,8 @@ LFD_API int lfd_pl_groupnorm_relu(void* x, int64_t plane_halfs, int32_t n, int64
  *           conv w0 (128 -> 128) + b0 -> out fp32, gn_sums as above
  *   mode 2: in as mode 1 -> conv w0 (128 -> f_c0 + f_c1 <= 64 channels, packed to 32 | 64 rows) + b0 -> fp32 outputs as
  *           lfd_pl_conv2d out_mode 2 (f_out0 / f_out1 at the level's point offset, image strides f_image_stride0 / 1, scale1)
+ *   mode 3: in = planes [n][pixels][128] (the stored output of a neck conv: heads with separate cls / reg towers) -> conv w0
+ *           (128 -> 128) + b0 -> out fp32, gn_sums as mode 0
  * Packed weights: engine_p2.pack_planes_weight order ([2 = hi | 2^11 lo][cout / 32][cin / 16][64 lanes] x 8 halfs). */
 typedef struct lfd_pl_head_desc {
   int32_t mode, n, cin, relu0;

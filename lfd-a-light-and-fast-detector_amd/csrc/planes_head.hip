@@ -17,6 +17,7 @@
 // MODE 0 (A): tap planes -> neck 1x1 + bias + ReLU -> (LDS) -> first tower 1x1 + bias -> fp32 t + sums
 // MODE 1 (B): fp32 t -> GroupNorm + ReLU (LDS) -> tower 1x1 + bias -> fp32 t' + sums
 // MODE 2 (C): fp32 t -> GroupNorm + ReLU (LDS) -> cls | reg 1x1 + bias (+ Scale) -> fp32 [N,P,C'] / [N,P,4] at the level's offset
+// MODE 3 (D): planes [N][P][128] (a neck output) -> tower 1x1 + bias -> fp32 t + sums  (separate cls / reg towers: TT100K)
 // All pyramid levels of a launch in one persistent grid (each level its own filters, lfd_head.py:88-139).
 #include "planes_impl.h"
 
@@ -52,16 +53,17 @@ struct PhArgs {
 template <int MODE, int CIN, int NSLAB>
 struct PhCfg {
   static constexpr int TPX = 64;                                   // pixels per tile
-  static constexpr int NK0 = (MODE == 0 ? CIN : 128) / 16;
+  static constexpr bool PLANES_IN = MODE == 0 || MODE == 3;        // the input tile is a plane pair (A: the tap; D: a neck output)
+  static constexpr int NK0 = (PLANES_IN ? CIN : 128) / 16;
   static constexpr int IN_PIXB = CIN * 2;                          // A: bytes per pixel and plane of the tap tile
   static constexpr int IN_PLANE = TPX * IN_PIXB;
-  static constexpr int NBUF = (MODE == 0 && CIN == 64) ? 2 : 1;    // A on the large levels: double-buffered tap tiles
+  static constexpr int NBUF = ((MODE == 0 && CIN == 64) || MODE == 3) ? 2 : 1;    // A on the large levels, D: double-buffered tap tiles
   static constexpr int RAW_BYTES = TPX * 512;                      // B / C: the fp32 tile as it lands
   static constexpr int OP_PLANE = TPX * 256;                       // one operand plane [64 px][128 ch] fp16
   static constexpr int IN_OFF = 0;
-  static constexpr int IN_BYTES = MODE == 0 ? NBUF * 2 * IN_PLANE : RAW_BYTES;
+  static constexpr int IN_BYTES = PLANES_IN ? NBUF * 2 * IN_PLANE : RAW_BYTES;
   static constexpr int OP_OFF = IN_OFF + IN_BYTES;                 // A: the neck's output (operand of the tower conv); B / C: GN output
-  static constexpr int BIAS_OFF = OP_OFF + 2 * OP_PLANE;
+  static constexpr int BIAS_OFF = OP_OFF + (MODE == 3 ? 0 : 2 * OP_PLANE);      // (D contracts the landed tile itself)
   static constexpr int LDS_BYTES = BIAS_OFF + 2 * 128 * 4;
   static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 };
@@ -147,16 +149,17 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
   // B / C: fp32 rows of 512 B, two pixels per instruction, copied as they are (a permuted lane -> address map halves what the
   //    16-lane groups of the address coalescer merge: measured 2.5 TB/s of reads); the GroupNorm pass is organised around
   //    16-byte pieces (4 channels) so that its LDS reads are lane-linear too
-  constexpr int CPP = (MODE == 0 ? CIN : 128) / 8;
+  constexpr bool PLANES_IN = C::PLANES_IN;
+  constexpr int CPP = (PLANES_IN ? CIN : 128) / 8;
   unsigned vo_in;
-  if constexpr (MODE == 0) {
+  if constexpr (PLANES_IN) {
     const int lp = lane / CPP, cs = lane % CPP;
     const int key = (CIN == 64) ? ((4 * wave + (lane >> 4)) & 7) : ((4 * wave + (lane >> 4)) & 15);
     vo_in = (unsigned)(lp * C::IN_PIXB + ((cs ^ key) * 16));
   } else {
     vo_in = (unsigned)(lane * 16);      // a plain copy: 1 KB = two pixel rows per instruction, lanes in address order (coalesced)
   }
-  constexpr int IN_INSTR = MODE == 0 ? (C::IN_PLANE / 1024) : (C::RAW_BYTES / 1024);     // per plane (A) / per tile (B, C)
+  constexpr int IN_INSTR = PLANES_IN ? (C::IN_PLANE / 1024) : (C::RAW_BYTES / 1024);     // per plane (A) / per tile (B, C)
   static_assert(IN_INSTR % 4 == 0, "whole rounds of the four waves");
 
   // tile being fetched
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
     const int j = rel - n * d_tpi;
     const int p0 = j * C::TPX;
     const bool full = p0 + C::TPX <= d_P;
-    if constexpr (MODE == 0) {
+    if constexpr (PLANES_IN) {
       const char* base = d_in + ((long)n * d_P + p0) * C::IN_PIXB;
       const long plane_b = d_plane_b;
       char* ld = smem + C::IN_OFF + buf * 2 * C::IN_PLANE;
@@ -214,16 +217,16 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
   const int xkey = (pix & 15) ^ h;              // (2 q + h) ^ (p % 16) = (2 q) ^ (h ^ (p % 16)): p % 16 = pix % 16 for both tiles
   auto op_addr = [&](const char* base, int q, int pt) { return base + xo[pt] + (((2 * q) ^ xkey) << 4); };
   // A: the tap tile's own layout (CIN channels per pixel)
-  int xi[MODE == 0 ? 2 : 1];
+  int xi[PLANES_IN ? 2 : 1];
   int xikey = 0;
-  if constexpr (MODE == 0) {
+  if constexpr (PLANES_IN) {
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) xi[pt] = (pt * 32 + pix) * C::IN_PIXB;
     xikey = ((CIN == 64) ? ((pix >> 1) & 7) : (pix & 15)) ^ h;
   }
 
   // ---- GroupNorm of the input (B / C): thread = one 16-byte piece (channels 4 j .. 4 j + 3, group j / 2) of the pixels tid / 32 + 8 r
-  float gn_a[MODE == 0 ? 1 : 4], gn_b[MODE == 0 ? 1 : 4];
+  float gn_a[PLANES_IN ? 1 : 4], gn_b[PLANES_IN ? 1 : 4];
   int gnin_key = -1;
   // ---- GroupNorm sums of the output (A / B): lane (h, pix) of slab s holds channels 32 s + 8 g + 4 h + e of its pixels
   double gs[MODE == 2 ? 1 : 4], gq[MODE == 2 ? 1 : 4];
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
     PH_T(1);
     block_barrier();             // tile t landed for every wave; every wave is done with the previous tile's operand planes
     PH_T(2);
-    if constexpr (MODE == 0 && C::NBUF == 2) {
+    if constexpr (PLANES_IN && C::NBUF == 2) {
       if (has_next) issue_in(t + t_step, buf ^ 1);
     }
 
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
     }
 
     const char* op = smem + C::OP_OFF;
-    if constexpr (MODE != 0) {
+    if constexpr (!PLANES_IN) {
       // ---- GroupNorm + ReLU of the landed fp32 tile -> hi / lo operand planes (lfd_head.py:97-117 conv -> GroupNorm -> ReLU)
       const int pj = (int)threadIdx.x & 31, gi = pj >> 1;
       if (gnin_key != n) {
@@ -456,6 +459,11 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
       }
       init_acc(sbias + 128 + slab * 32 + 4 * h);
       contract([&](int q, int pt) { return op_addr(op, q, pt); }, C::OP_PLANE, w1h, w1l, std::integral_constant<int, 8>{});
+    } else if constexpr (MODE == 3) {
+      // D: the landed plane tile IS the operand (a tower's first conv on the neck's stored output, separate-tower heads)
+      const char* xb = smem + C::IN_OFF + buf * 2 * C::IN_PLANE;
+      init_acc(sbias + slab * 32 + 4 * h);
+      contract([&](int q, int pt) { return xb + xi[pt] + (((2 * q) ^ xikey) << 4); }, C::IN_PLANE, w0h, w0l, std::integral_constant<int, C::NK0>{});
     } else {
       if (mfma_wave) {
         init_acc(sbias + slab * 32 + 4 * h);
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_pl_head(PhArgs a) {
           }
       }
     }
-    if constexpr (MODE == 0 && C::NBUF == 2) buf ^= 1;
+    if constexpr (PLANES_IN && C::NBUF == 2) buf ^= 1;
     PH_T(7);
   }
   gn_flush();
@@ -1037,9 +1045,9 @@ extern "C" int lfd_pl_head_levels(const lfd_pl_head_desc_t* d, const lfd_pl_head
                                   lfd_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d || !levels || !zeros || num_levels < 1 || num_levels > LFD_MAX_LEVELS || d->n < 1) return LFD_ERR_INVALID_ARGUMENT;
-  if (d->mode < 0 || d->mode > 2) return LFD_ERR_INVALID_ARGUMENT;
+  if (d->mode < 0 || d->mode > 3) return LFD_ERR_INVALID_ARGUMENT;
   if (d->mode == 0 && d->cin != 64 && d->cin != 128) return LFD_ERR_UNSUPPORTED;
-  if (d->mode >= 2 && (d->f_c0 < 0 || d->f_c1 < 0 || d->f_c0 + d->f_c1 < 1 || d->f_c0 + d->f_c1 > 64)) return LFD_ERR_UNSUPPORTED;
+  if (d->mode == 2 && (d->f_c0 < 0 || d->f_c1 < 0 || d->f_c0 + d->f_c1 < 1 || d->f_c0 + d->f_c1 > 64)) return LFD_ERR_UNSUPPORTED;
   pl::PhArgs a{};
   a.zeros = (const _Float16*)zeros;
   a.n_levels = num_levels; a.N = d->n; a.relu0 = d->relu0; a.eps = d->gn_in_eps;
@@ -1053,9 +1061,9 @@ extern "C" int lfd_pl_head_levels(const lfd_pl_head_desc_t* d, const lfd_pl_head
     if (!s.in || !s.w0 || !s.b0 || s.pixels < 1) return LFD_ERR_INVALID_ARGUMENT;
     if (!lfd_aligned16(s.in) || !lfd_aligned16(s.out) || (s.in_plane_halfs & 7)) return LFD_ERR_INVALID_ARGUMENT;
     if (d->mode == 0 && (!s.w1 || !s.b1)) return LFD_ERR_INVALID_ARGUMENT;
-    if (d->mode < 2 && (!s.out || !s.gn_sums)) return LFD_ERR_INVALID_ARGUMENT;
-    if (d->mode != 0 && (!s.gn_in_sums || !s.gn_in_gamma || !s.gn_in_beta)) return LFD_ERR_INVALID_ARGUMENT;
-    if (d->mode >= 2 && ((d->f_c0 > 0 && !s.f_out0) || (d->f_c1 > 0 && !s.f_out1))) return LFD_ERR_INVALID_ARGUMENT;
+    if (d->mode != 2 && (!s.out || !s.gn_sums)) return LFD_ERR_INVALID_ARGUMENT;
+    if ((d->mode == 1 || d->mode == 2) && (!s.gn_in_sums || !s.gn_in_gamma || !s.gn_in_beta)) return LFD_ERR_INVALID_ARGUMENT;
+    if (d->mode == 2 && ((d->f_c0 > 0 && !s.f_out0) || (d->f_c1 > 0 && !s.f_out1))) return LFD_ERR_INVALID_ARGUMENT;
     pl::PhLevel& l = a.lv[i];
     l.in = s.in; l.in_plane = s.in_plane_halfs; l.out = (float*)s.out;
     l.w0 = (const half8*)s.w0; l.b0 = s.b0; l.w1 = (const half8*)s.w1; l.b1 = s.b1;
@@ -1065,6 +1073,7 @@ extern "C" int lfd_pl_head_levels(const lfd_pl_head_desc_t* d, const lfd_pl_head
     l.P = s.pixels;
   }
   if (d->mode == 0) return d->cin == 64 ? pl::launch_pl_head<0, 64, 4>(a, st) : pl::launch_pl_head<0, 128, 4>(a, st);
+  if (d->mode == 3) return pl::launch_pl_head<3, 128, 4>(a, st);
   if (d->mode == 1) return lfd_tune(LFD_TUNE_PL_HEAD_ROLES) != 0 ? pl::launch_pl_head_b2(a, st) : pl::launch_pl_head<1, 128, 4>(a, st);
   if (lfd_tune(LFD_TUNE_PL_HEAD_OUT_REGS) != 0) return nslab0 == 1 ? pl::launch_pl_head_out<1>(a, st) : pl::launch_pl_head_out<2>(a, st);
   return nslab0 == 1 ? pl::launch_pl_head<2, 128, 1>(a, st) : pl::launch_pl_head<2, 128, 2>(a, st);

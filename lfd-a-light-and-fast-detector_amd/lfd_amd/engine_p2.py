@@ -459,23 +459,55 @@ class PlanesPlan(object):
         return d, src, dst, res, dsd, f0, f1
 
     def _flat_head_modes(self):
-        """[mode per launch group] when every neck / head launch is one of the three forms lfd_pl_head_levels covers (round 6,
-        csrc/planes_head.hip: flat pixel tiles, fp32 intermediates) -- neck + first tower conv (0), a later tower conv on a
-        GroupNorm input (1), the cls | reg output conv (2) -- else None: the merged-path heads of the WIDERFACE configurations."""
+        """[mode per launch group] when every neck / head launch group is one of the forms lfd_pl_head_levels covers (round 6,
+        csrc/planes_head.hip: flat pixel tiles, fp32 intermediates) or a plain neck conv (stays on lfd_pl_conv2d_levels: 'G') --
+        neck + first tower conv (0), a tower conv on a GroupNorm input (1), the cls | reg output conv (2), a tower's first conv
+        on the stored neck output (3: separate cls / reg towers, TT100K) -- else None."""
         if self.level_groups is None:
             return None
         modes = []
         for grp in self.level_groups:
             o = self.ops[grp[0]]
+            plain = o.tail is None and o.gnin is None and o.res is None and o.ds is None
             if o.tail is not None and o.gn is not None and o.gnin is None and o.out_mode == 1 and o.cin in (64, 128) and o.cout == 128 and not o.tail[2]:
                 modes.append(0)
             elif o.tail is None and o.gnin is not None and o.out_mode == 1 and o.cin == 128 and o.cout == 128:
                 modes.append(1)
             elif o.tail is None and o.gnin is not None and o.out_mode == 2 and o.cin == 128 and o.f_c0 + o.f_c1 <= 64:
                 modes.append(2)
+            elif plain and o.gn is not None and o.out_mode == 1 and o.cin == 128 and o.cout == 128:
+                modes.append(3)
+            elif plain and o.gn is None and o.out_mode == 0:
+                modes.append('G')
             else:
                 return None
-        return modes
+        return modes if any(m != 'G' for m in modes) else None
+
+    def _flat_launches(self, modes):
+        """[(mode, [op index])]: the launch groups in order, groups of the same flat mode merged into one launch where the level
+        table has room and every producer of the later group's inputs sits in an EARLIER launch (the cls and reg towers of a
+        separate-tower head: 4 levels x 2 towers = one launch per tower layer)"""
+        launches, made_in = [], {}
+        for grp, mode in zip(self.level_groups, modes):
+            srcs = [self.ops[i].src for i in grp]
+            target = None
+            if mode in (1, 3):
+                for li in range(len(launches) - 1, -1, -1):
+                    m2, ops2 = launches[li]
+                    if m2 == mode and len(ops2) + len(grp) <= _lib.MAX_LEVELS and all(made_in.get(b_, -1) < li for b_ in srcs):
+                        target = li
+                        break
+                    if any(made_in.get(b_, -1) >= li for b_ in srcs):
+                        break
+            if target is None:
+                launches.append((mode, list(grp)))
+                target = len(launches) - 1
+            else:
+                launches[target][1].extend(grp)
+            for i in grp:
+                if self.ops[i].dst is not None:
+                    made_in[self.ops[i].dst] = target
+        return launches
 
     def _launch_levels_flat(self, st, modes):
         """the neck + head through lfd_pl_head_levels: the plane buffers of the tower convs hold fp32 [N, H, W, 128] (same bytes)"""
@@ -483,7 +515,19 @@ class PlanesPlan(object):
         zeros = ptr(ops.zero_line(self.device))
         if st.flat_calls is None:
             calls = []
-            for grp, mode in zip(self.level_groups, modes):
+            for mode, grp in self._flat_launches(modes):
+                if mode == 'G':
+                    arr = (_lib.PlLevel * len(grp))()
+                    d0 = None
+                    for j, i in enumerate(grp):
+                        o = self.ops[i]
+                        d, src, dst, _, _, _, _ = self._desc(o, st)
+                        d0 = d0 or d
+                        lv = arr[j]
+                        lv.in_, lv.out, lv.w_packed, lv.bias = src.data_ptr(), dst.data_ptr(), o.w.data_ptr(), o.b.data_ptr()
+                        lv.h, lv.w, lv.in_plane_halfs, lv.out_plane_halfs = src.shape[2], src.shape[3], d.in_plane_halfs, d.out_plane_halfs
+                    calls.append(('G', d0, arr, len(grp)))
+                    continue
                 arr = (_lib.PlHeadLevel * len(grp))()
                 d = _lib.PlHeadDesc()
                 for j, i in enumerate(grp):
@@ -506,10 +550,13 @@ class PlanesPlan(object):
                         lv.f_out0 = (st.cls.data_ptr() + st.p_off[o.level] * o.f_c0 * 4) if o.f_c0 else None
                         lv.f_out1 = (st.reg.data_ptr() + st.p_off[o.level] * 4 * 4) if o.f_c1 else None
                         lv.scale1 = o.scale.data_ptr() if o.scale is not None else None
-                calls.append((d, arr, len(grp)))
+                calls.append((mode, d, arr, len(grp)))
             st.flat_calls = calls
-        for d, arr, n in st.flat_calls:
-            check(l.lfd_pl_head_levels(C.byref(d), arr, n, zeros, sp), 'lfd_pl_head_levels')
+        for mode, d, arr, n in st.flat_calls:
+            if mode == 'G':
+                check(l.lfd_pl_conv2d_levels(C.byref(d), arr, n, zeros, sp), 'lfd_pl_conv2d_levels')
+            else:
+                check(l.lfd_pl_head_levels(C.byref(d), arr, n, zeros, sp), 'lfd_pl_head_levels')
 
     def _launch_levels(self, st):
         """the neck + head: one launch per conv of the stack (and input width) over all pyramid levels"""

@@ -543,3 +543,41 @@ def test_pl_head_levels_chain_vs_float64(cin, sizes, n, ccls):
         check(lib().lfd_pl_head_levels(C.byref(d), arr, len(P), ptr(z), stream_ptr()), 'lfd_pl_head_levels')
     torch.cuda.synchronize()
     assert torch.equal(cls, c_one) and torch.equal(reg, r_one), 'all levels in one launch != one launch per level'
+
+
+@pytest.mark.parametrize('sizes,n', [([(19, 37), (3, 5)], 2), ([(8, 8)], 3)])
+def test_pl_head_levels_mode3_tower_conv_on_stored_planes_vs_float64(sizes, n):
+    """lfd_pl_head_levels mode 3 (heads with separate cls / reg towers, lfd_head.py:88-139 with merge_path_flag False): the first
+    tower conv reads the neck's STORED output (planes) -> fp32 out + GroupNorm sums; levels in one launch, against float64."""
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(n + len(sizes))
+    z = ops.zero_line(dev)
+    arr = (_lib.PlHeadLevel * len(sizes))()
+    keep, refs = [], []
+    gs = torch.zeros((len(sizes), _lib.PL_GN_REPLICAS, n, 16, 2), dtype=torch.int64, device=dev)
+    for i, (h, w) in enumerate(sizes):
+        p = h * w
+        x = torch.randn(n, p, 128, generator=g) * 2
+        xp = engine_p2.to_planes(x.reshape(n, p, 1, 128))
+        xv = engine_p2.from_planes(xp).reshape(n, p, 128).double()
+        w1, b1 = torch.randn(128, 128, generator=g) / 128 ** 0.5, torch.randn(128, generator=g)
+        refs.append(xv @ w1.double().t() + b1.double())
+        out = torch.full((n, p, 128), float('nan'), device=dev)
+        pk, bs, xpd = engine_p2.pack_planes_weight(w1.reshape(128, 128, 1, 1)).to(dev), engine_p2._pad_bias(b1, 128).to(dev), xp.to(dev)
+        keep.append((out, pk, bs, xpd))
+        a = arr[i]
+        a.in_, a.out, a.w0, a.b0, a.gn_sums, a.in_plane_halfs, a.pixels = xpd.data_ptr(), out.data_ptr(), pk.data_ptr(), bs.data_ptr(), gs[i].data_ptr(), xpd[0].numel(), p
+    d = _lib.PlHeadDesc()
+    d.mode, d.n, d.cin = 3, n, 128
+    check(lib().lfd_pl_head_levels(C.byref(d), arr, len(sizes), ptr(z), stream_ptr()), 'lfd_pl_head_levels mode 3')
+    torch.cuda.synchronize()
+    for i, ref in enumerate(refs):
+        got = keep[i][0].cpu().double()
+        assert not torch.isnan(got).any()
+        err, mag = float((got - ref).abs().max()), float(ref.abs().max())
+        print('level %d: err %.2e (max |y| %.2f)' % (i, err, mag))
+        assert err <= TOL * max(1.0, mag)
+        # the fixed-point GroupNorm sums of what was written: per (image, group of 8 channels) sum and sum of squares
+        sums = gs[i].sum(0).cpu().double() / 2 ** 24
+        r = ref.reshape(n, -1, 16, 8)
+        assert torch.allclose(sums[..., 0], r.sum((1, 3)), rtol=1e-6, atol=1e-3) and torch.allclose(sums[..., 1], (r * r).sum((1, 3)), rtol=1e-6, atol=1e-3)
