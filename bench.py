@@ -554,7 +554,7 @@ def precise_breakdown(model, x, dev, reps=20, timer=None):
         if fused_stem and i == 0:
             (f0, b0, _), (f1, b1, _) = cost(plan.ops[0]), cost(plan.ops[1])
             mid = 4.0 * n * st.dims[plan.ops[0].dst][0] * st.dims[plan.ops[0].dst][1] * plan.ops[0].channels
-            units.append(('whole stem: conv3x3 s2 (3->64) + 1x1 + conv3x3 s2 + 1x1, pair-1 output never in HBM (k_pl_stem2x)', f0 + f1,
+            units.append(('whole stem: conv3x3 s2 (3->64) + 1x1 + conv3x3 s2 + 1x1, pair-1 output never in HBM (k_pl_stem2xs: row stream, producer + consumer waves)', f0 + f1,
                           b0 + b1 - 2 * mid, 1, lambda: plan._launch(x, fmt, st, [0, 1])))
             i = 2
             continue
@@ -1001,7 +1001,7 @@ def main():
                     bb = [r_ for r_ in prow if not r_['kernel'].startswith('neck + head')]
                     tb = sum(r_['time_us_per_forward'] for r_ in bb)
                     fb = sum(r_['tflops_algorithmic'] * r_['time_us_per_forward'] for r_ in bb)      # TFLOP/s x us = MFLOP
-                    result['roofline_backbone_3x3'] = {'kernel': 'all backbone launches of the headline mode (k_pl_stem2x, k_pl_c3p, stage entries, 128-channel convs)',
+                    result['roofline_backbone_3x3'] = {'kernel': 'all backbone launches of the headline mode (k_pl_stem2xs, k_pl_c3p, stage entries, 128-channel convs)',
                                                        'bound': 'mfma', 'achieved': round(fb / tb, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                                        'frac': round(fb / tb / MFMA_PEAK_TFLOPS, 3), 'frac_mfma_issued': round(3 * fb / tb / MFMA_PEAK_TFLOPS, 3),
                                                        'time_us_per_forward': round(tb, 1), 'launches': sum(r_['launches'] for r_ in bb)}

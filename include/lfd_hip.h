@@ -84,7 +84,9 @@ typedef enum lfd_tune_key {
                                   1 = k_pl_c3 (one wave per SIMD, epilogue under the next contraction), 0 = generic      default 2 */
   LFD_TUNE_PL_HEAD_OUT_REGS = 12, /* 1: lfd_pl_head_levels mode 2 with the fp32 tile landing in registers (k_pl_head_out)           default 1 */
   LFD_TUNE_PL_HEAD_ROLES = 13,  /* 1: lfd_pl_head_levels mode 1 with producer / consumer waves (k_pl_head_b2)                              default 1 */
-  LFD_TUNE_COUNT = 14
+  LFD_TUNE_PL_STEM = 14,        /* lfd_pl_stem2x on aligned fp16 frames: 0 = tiles, one wave per SIMD (k_pl_stem2x); 1 = row stream with producer
+                                   and consumer waves (k_pl_stem2xs)                                                          default 1 */
+  LFD_TUNE_COUNT = 15
 } lfd_tune_key_t;
 LFD_API int lfd_tuning_set(int32_t key, int32_t value);
 LFD_API int32_t lfd_tuning_get(int32_t key);

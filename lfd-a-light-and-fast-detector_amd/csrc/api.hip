@@ -4,7 +4,7 @@
 #include "common.h"
 
 // defaults of the tuning knobs, in lfd_tune_key_t order (include/lfd_hip.h)
-static std::atomic<int> g_tune[LFD_TUNE_COUNT] = {{1}, {0}, {1}, {1}, {1}, {1}, {0}, {-1}, {0}, {1}, {0}, {2}, {1}, {1}};
+static std::atomic<int> g_tune[LFD_TUNE_COUNT] = {{1}, {0}, {1}, {1}, {1}, {1}, {0}, {-1}, {0}, {1}, {0}, {2}, {1}, {1}, {1}};
 
 int lfd_tune(int key) { return g_tune[key].load(std::memory_order_relaxed); }
 

@@ -9,6 +9,8 @@
 
 using namespace pl;
 
+int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, hipStream_t st);   // planes_stem2xs.hip
+
 namespace {
 
 template <int FMT>
@@ -72,6 +74,7 @@ extern "C" int lfd_pl_stem2x(const void* in, int32_t in_format, int32_t n, int32
   a.N = n; a.H = (h + 1) / 2; a.W = (w + 1) / 2;          // the mid tensor (pair 1's output) the consumer's geometry refers to
   a.OH = (a.H + 1) / 2; a.OW = (a.W + 1) / 2;
   a.cout = 64; a.cout2 = 64; a.relu = 1; a.relu2 = 1;
+  if (p.dma_ok && lfd_tune(LFD_TUNE_PL_STEM) == 1) return lfd_pl_stem2xs_launch(a, p, st);
   switch (in_format) {
     case IN_NCHW_F32: return launch_stem2x<IN_NCHW_F32>(a, p, st);
     case IN_NHWC_F16: return launch_stem2x<IN_NHWC_F16>(a, p, st);

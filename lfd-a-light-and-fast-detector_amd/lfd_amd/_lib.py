@@ -289,7 +289,7 @@ _SIGNATURES = {
 # environment variable any more; this host layer applies them once, explicitly, when it loads the library (tests and the A/B
 # tools that start a fresh interpreter per variant keep working), and `tune()` sets a knob at run time.
 TUNE_KEYS = {'HEAD2': 0, 'H2_CHUNK': 1, 'H2_AGPR': 2, 'H2_A1': 3, 'STEM2X': 4, 'X2_ALN': 5, 'X2_STAGGER': 6, 'BLOCK_ROWS': 7,
-             'ROWS_WGS': 8, 'CONV128_SPLITK': 9, 'CONV0_VALU': 10, 'PL_C3': 11, 'PL_HEAD_OUT_REGS': 12, 'PL_HEAD_ROLES': 13}
+             'ROWS_WGS': 8, 'CONV128_SPLITK': 9, 'CONV0_VALU': 10, 'PL_C3': 11, 'PL_HEAD_OUT_REGS': 12, 'PL_HEAD_ROLES': 13, 'PL_STEM': 14}
 
 
 def tune(name, value=None):

@@ -172,7 +172,7 @@ def test_tuning_knobs_are_explicit_state_and_the_library_reads_no_environment():
     count = keys.pop('COUNT')
     assert keys == _lib.TUNE_KEYS and count == len(keys)
     defaults = {'HEAD2': 1, 'H2_CHUNK': 0, 'H2_AGPR': 1, 'H2_A1': 1, 'STEM2X': 1, 'X2_ALN': 1, 'X2_STAGGER': 0, 'BLOCK_ROWS': -1,
-                'ROWS_WGS': 0, 'CONV128_SPLITK': 1, 'CONV0_VALU': 0, 'PL_C3': 2, 'PL_HEAD_OUT_REGS': 1, 'PL_HEAD_ROLES': 1}
+                'ROWS_WGS': 0, 'CONV128_SPLITK': 1, 'CONV0_VALU': 0, 'PL_C3': 2, 'PL_HEAD_OUT_REGS': 1, 'PL_HEAD_ROLES': 1, 'PL_STEM': 1}
     for name, key in keys.items():
         if os.environ.get('LFD_' + name) is None:
             assert l.lfd_tuning_get(key) == defaults[name], name

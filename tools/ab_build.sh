@@ -16,6 +16,7 @@ for f in $(sed -n 's/^SRCS *= *//p' Makefile | sed 's/\.hip//g'); do
   [ $f = planes_ml ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   [ $f = planes_head ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   [ $f = planes_stem2x ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+  [ $f = planes_stem2xs ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   [ $f = targets ] && extra="-fhip-fp32-correctly-rounded-divide-sqrt"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -DLFD_BUILDING "$@" $extra -c $f.hip -o $B/$f.o &
 done
