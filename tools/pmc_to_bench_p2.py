@@ -15,7 +15,7 @@ stem = [k for k in raw if k.startswith('k_pl_stem2x')]
 fwd = sum(raw[k]['launches_sampled'] for k in stem) or None
 head = [k for k in raw if k.startswith('k_pl_head') or k.startswith('k_pl_conv_ml')]
 out = {
-    'whole stem: conv3x3 s2 (3->64) + 1x1 + conv3x3 s2 + 1x1, pair-1 output never in HBM (k_pl_stem2x)': wavg(lambda k: k.startswith('k_pl_stem2x')),
+    'whole stem: conv3x3 s2 (3->64) + 1x1 + conv3x3 s2 + 1x1, pair-1 output never in HBM (k_pl_stem2xs: row stream, producer + consumer waves)': wavg(lambda k: k.startswith('k_pl_stem2x')),
     'conv3x3 s1 64->64 (+ residual) (k_pl_c3p)': wavg(lambda k: k.startswith('k_pl_c3')),
     'stage entry: conv3x3 s2 + 1x1 s2 identity branch (k_pl_conv<.,3,2,DS>)': wavg(lambda k: k.startswith('k_pl_conv<64, 3, 2') or k.startswith('k_pl_conv<128, 3, 2')),
     'conv3x3 s1 128->128 (k_pl_conv<128,3,1>)': wavg(lambda k: k.startswith('k_pl_conv<128, 3, 1')),

@@ -2,7 +2,8 @@
 // the multiplier arrays barely toggle).  Eight A and eight B fragments per lane, hashed from (thread, index) to values in
 // [-1, 1), rotated so that consecutive MFMAs of a wave see different operands on both inputs; four independent accumulators
 // as in mfma_long.hip.  Same instruction stream rate -- what differs is the power the chip needs for it, i.e. the clock it can
-// hold under its 1.4 kW cap.  MODE 0: constant operands (control), 1: random operands.
+// hold under its 1.4 kW cap.  MODE 0: constant operands (control), 1: random operands, 2: random operands with the A fragment HELD for four consecutive MFMAs
+// (weights-stationary order: one filter fragment against four pixel tiles), 3: the B fragment held for four.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -26,10 +27,22 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* dbg, in
   for (int i = 0; i < n; i += 2) {
 #pragma unroll
     for (int j = 0; j < 8; j += 4) {
+      if (MODE == 2) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[(j + 3) & 7], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[(j + 6) & 7], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[(j + 1) & 7], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[(j + 4) & 7], c3, 0, 0, 0);
+      } else if (MODE == 3) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[j], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j + 1], b[j], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j + 2], b[j], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j + 3], b[j], c3, 0, 0, 0);
+      } else {
       c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[(j + 3) & 7], c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j + 1], b[(j + 6) & 7], c1, 0, 0, 0);
       c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j + 2], b[(j + 1) & 7], c2, 0, 0, 0);
       c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j + 3], b[(j + 4) & 7], c3, 0, 0, 0);
+      }
     }
   }
   unsigned long long t1 = __builtin_readcyclecounter();
@@ -41,19 +54,19 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* dbg, in
 template <int MODE>
 void run(float* out, unsigned long long* dbg) {
   const int blocks = 256, thr = 512, n = 2000000;
-  for (int rep = 0; rep < 8; ++rep) {
+  for (int rep = 0; rep < 6; ++rep) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); k<MODE><<<blocks, thr>>>(out, dbg, n); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[2]; hipMemcpy(h, dbg, 16, hipMemcpyDeviceToHost);
     double fl = (double)blocks * (thr / 64) * n * 4 * 32768.0;
-    printf("mode %d (%s operands): %8.1f us  %7.1f TFLOP/s  clock %.3f GHz (%.2f cycles per MFMA)\n", MODE, MODE ? "random" : "constant", ms * 1e3,
+    printf("mode %d (%s operands): %8.1f us  %7.1f TFLOP/s  clock %.3f GHz (%.2f cycles per MFMA)\n", MODE, MODE == 0 ? "constant" : MODE == 1 ? "random" : MODE == 2 ? "random, A held x4" : "random, B held x4", ms * 1e3,
            fl / ms / 1e9, h[0] / (h[1] / 100.0) / 1e3, (double)h[0] / (4.0 * n));
   }
 }
 int main(int argc, char** argv) {
   float* out; unsigned long long* dbg; hipMalloc(&out, 1 << 22); hipMalloc(&dbg, 64);
   const int mode = argc > 1 ? atoi(argv[1]) : 1;
-  if (mode) run<1>(out, dbg); else run<0>(out, dbg);
+  if (mode == 1) run<1>(out, dbg); else if (mode == 2) run<2>(out, dbg); else if (mode == 3) run<3>(out, dbg); else run<0>(out, dbg);
   return 0;
 }
