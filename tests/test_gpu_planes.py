@@ -323,6 +323,42 @@ def _stem2x_case(fmt, n, h, w):
     _close(out, ref, 'stem2x fmt %d %dx%dx%d' % (fmt, n, h, w))
 
 
+def test_pl_stem2x_stream_kernel_is_deterministic_under_concurrent_work():
+    """k_pl_stem2xs hands chunks from producer waves to consumer waves through LDS with ONE workgroup barrier per slot (no atomics, fixed
+    order): the same frames must give the same bits on every launch, also with another stream keeping the chip busy -- an LDS hazard
+    would show here as a bit that differs"""
+    n, h, w, c = 3, 258, 520
+    g = torch.Generator().manual_seed(77)
+    w1, b1 = torch.randn(c, 3, 3, 3, generator=g) * 0.3, torch.randn(c, generator=g)
+    w2, b2 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
+    w3, b3 = torch.randn(c, c, 3, 3, generator=g) * (1.0 / (9 * c) ** 0.5), torch.randn(c, generator=g)
+    w4, b4 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
+    x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half().cuda()
+    keep = [engine_p2.pack_planes_stem2x_weight(w1, b1).cuda(), engine_p2.pack_planes_stem2x_tail_weight(w2).cuda(),
+            engine_p2._pad_bias(b2).cuda(), engine_p2.pack_planes_weight(w3).cuda(), engine_p2._pad_bias(b3, 128).cuda(),
+            engine_p2.pack_planes_weight(w4).cuda(), engine_p2._pad_bias(b4, 128).cuda()]
+    oh, ow = ((h + 1) // 2 + 1) // 2, ((w + 1) // 2 + 1) // 2
+    out = torch.empty((2, n, oh, ow, c), dtype=torch.float16, device='cuda')
+    z = ops.zero_line(x.device)
+    assert _lib.tune('PL_STEM') == 1
+
+    def run():
+        out.fill_(float('nan'))
+        check(lib().lfd_pl_stem2x(ptr(x), 1, n, h, w, *[ptr(k) for k in keep], ptr(out), out[0].numel(), ptr(z), stream_ptr()), 'lfd_pl_stem2x')
+        torch.cuda.synchronize()
+    run()
+    ref = out.clone()
+    assert not torch.isnan(ref.float()).any()
+    side, junk = torch.cuda.Stream(), torch.rand(2048, 2048, device='cuda')
+    for i in range(40):
+        if i % 2 == 0:
+            with torch.cuda.stream(side):
+                junk = (junk @ junk).clamp_(-1, 1)
+        run()
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), 'launch %d differs from the first one' % i
+    torch.cuda.synchronize()
+
+
 def test_pl_conv2d_levels_equals_one_launch_per_level_and_validates_its_arguments():
     """lfd_pl_conv2d_levels at the C ABI: three feature maps of different sizes with their own filters in one launch ==
     lfd_pl_conv2d per level, bit for bit (planes and the fixed-point GroupNorm sums); one level; argument checks"""
