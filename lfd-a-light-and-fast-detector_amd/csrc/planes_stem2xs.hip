@@ -166,7 +166,10 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
 
     // one group of 32 stream pixels: q0 = stream index of its first pixel, `limit` = pixels behind it are not written
     auto produce_group = [&](const Walk& w, int q0, int limit, int mlo, const uint32_t* fh) {
-      const int q = q0 + pix;
+      // lanes 0-15 take the group's even stream pixels, lanes 16-31 the odd ones: a 16-lane group of a ring store then covers
+      // consecutive slots of one de-interleaved half-row (8 chunk positions twice) instead of both halves (up to 4 lanes per
+      // bank): 381 -> 377 us
+      const int q = q0 + 2 * (pix & 15) + (pix >> 4);
       const bool valid = q < limit;
       const int m = valid ? q / C::IW : mlo;
       const int mx = valid ? q - m * C::IW : 0;
