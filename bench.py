@@ -497,6 +497,17 @@ def stress_and_small_frame_bench(model, x, meta, dev, cls):
                                      candidates_per_image=float(cn[:, 0].mean()), kept_per_image=float(cn[:, 1].mean()))
         small['workload'] = 'WIDERFACE_LFD_S 640x480 fp16 NHWC resident, ~64 candidates per image, IoU 0.4, forward + decode + NMS (one HIP graph)'
         out['frames_640x480'] = small
+        # the headline batch as the reference's data pipeline hands it over: uint8 NHWC, simple_normalize
+        # (augmentation_pipeline.py:31-36) inside the fused stem
+        x8 = torch.randint(0, 256, tuple(x.shape), device=dev, dtype=torch.uint8, generator=gen)
+        c8, _ = model.forward_resident(x8)
+        model._classification_threshold = float(torch.quantile(c8.float().sigmoid().reshape(x.size(0), -1)[0], 1.0 - 256.0 / c8.shape[1]))
+        ms = _event_median_ms(lambda: model.detect_resident(x8, meta), 50)
+        cn = model.detect_resident(x8, meta).counts.cpu().numpy()
+        out['frames_uint8_1080p'] = dict(workload='WIDERFACE_LFD_S 8 x 1920x1080 uint8 NHWC resident (normalised in the stem), ~256 candidates per '
+                                                  'image, IoU 0.4, forward + decode + NMS (one HIP graph, one batch in flight)',
+                                         ms_per_step=round(ms, 4), images_per_s=round(x.size(0) / ms * 1e3, 1),
+                                         candidates_per_image=float(cn[:, 0].mean()), kept_per_image=float(cn[:, 1].mean()))
     finally:
         model._classification_threshold, model._nms_cfg, model.use_graph = keep[0], dict(keep[1]), keep[2]
     return out
@@ -635,6 +646,8 @@ def compact_line(r):
     c['configs'] = {k: (cf.get(k) or {}).get('ms_per_step') for k in ('config3', 'config4') if k in cf}
     if 'frames_640x480' in cf:
         c['configs']['640x480_bs8'] = ((cf['frames_640x480'] or {}).get('bs8') or {}).get('ms_per_step')
+    if 'frames_uint8_1080p' in cf:
+        c['configs']['uint8_1080p_bs8_serial'] = (cf['frames_uint8_1080p'] or {}).get('ms_per_step')
     t = r.get('train') or {}
     c['train'] = {k: t.get(k) for k in ('ms_per_iter', 'n_gpus', 'ranks_seen', 'images_per_s', 'error') if k in t}
     lb = r.get('latency_bs1') or {}

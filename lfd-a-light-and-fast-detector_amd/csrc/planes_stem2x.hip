@@ -9,7 +9,7 @@
 
 using namespace pl;
 
-int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, hipStream_t st);   // planes_stem2xs.hip
+int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, int uint8_frames, hipStream_t st);   // planes_stem2xs.hip
 
 namespace {
 
@@ -74,7 +74,10 @@ extern "C" int lfd_pl_stem2x(const void* in, int32_t in_format, int32_t n, int32
   a.N = n; a.H = (h + 1) / 2; a.W = (w + 1) / 2;          // the mid tensor (pair 1's output) the consumer's geometry refers to
   a.OH = (a.H + 1) / 2; a.OW = (a.W + 1) / 2;
   a.cout = 64; a.cout2 = 64; a.relu = 1; a.relu2 = 1;
-  if (p.dma_ok && lfd_tune(LFD_TUNE_PL_STEM) == 1) return lfd_pl_stem2xs_launch(a, p, st);
+  if (lfd_tune(LFD_TUNE_PL_STEM) == 1) {
+    if (p.dma_ok) return lfd_pl_stem2xs_launch(a, p, 0, st);
+    if (in_format == IN_NHWC_U8 && (w & 15) == 0 && ((uintptr_t)in & 15) == 0) return lfd_pl_stem2xs_launch(a, p, 1, st);
+  }
   switch (in_format) {
     case IN_NCHW_F32: return launch_stem2x<IN_NCHW_F32>(a, p, st);
     case IN_NHWC_F16: return launch_stem2x<IN_NHWC_F16>(a, p, st);

@@ -1,7 +1,7 @@
 // csrc/planes_stem2xs.hip -- k_pl_stem2xs: the whole 'faster' stem (lfd_resnet.py:376-413: conv3x3 s2 3 -> 64, conv1x1,
 // conv3x3 s2 64 -> 64, conv1x1, each + BN + ReLU) on hi/lo planes in one launch, as a ROW STREAM with producer waves and
-// consumer waves (round 6; fp16 NHWC frames with 16-byte aligned rows -- the resident serving format; everything else runs
-// k_pl_stem2x).
+// consumer waves (round 6; fp16 or uint8 NHWC frames with 16-byte aligned rows -- the resident serving formats; everything else
+// runs k_pl_stem2x).
 //
 // k_pl_stem2x (planes_stem2x.hip, planes_impl.h PROD) runs one wave per SIMD through a serial chain per producer round; the
 // matrix pipe is busy 0.35 of the time at 1.3 kW and the full clock (LESSONS 50-53).  Its eight-wave form with every wave in
@@ -42,7 +42,9 @@ struct SS {
   static constexpr int STG_PITCH = 80, STG_PLANE = 32 * STG_PITCH, STG_WAVE = 2 * STG_PLANE;
   static constexpr int TW_OFF = STG_OFF + 2 * STG_WAVE;           // chained 1x1 filters [2 planes][2 slabs][4][64 lanes] x 16 B
   static constexpr int BIAS_OFF = TW_OFF + 2 * 2 * 4 * 64 * 16;   // producer 1x1 bias [64] | consumer bias [64] | chained 1x1 bias [64]
-  static constexpr int LDS_BYTES = BIAS_OFF + 3 * 256;
+  static constexpr int LUT_OFF = BIAS_OFF + 3 * 256;              // uint8 frames: byte -> (hi | lo << 16) of simple_normalize(byte); entry 256 = zero
+  static constexpr int LDS_BYTES = LUT_OFF + 264 * 4;
+  static constexpr int U8_PITCH = 256, U8_JB = 4;                 // uint8 frames: bytes per patch row; bytes left of the patch's first tap pixel
   static_assert(RING_PLANE < 65536, "lo plane as an immediate offset");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 };
@@ -79,7 +81,7 @@ __device__ __forceinline__ void walk_next(Walk& w, int CY, int tiles_x) {
   if (w.rc >= SS::RR) w.rc -= SS::RR;
 }
 
-template <int KA>
+template <int KA, bool U8>
 __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int CY, int total) {
   using C = SS;
   constexpr int KB = 36 - KA;
@@ -104,6 +106,17 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       sb[threadIdx.x] = P.b2[threadIdx.x];
       sb[64 + threadIdx.x] = a.bias[threadIdx.x];
       sb[128 + threadIdx.x] = a.bias2[threadIdx.x];
+    }
+    if constexpr (U8) {
+      // simple_normalize (augmentation_pipeline.py:31-36) in fp32 like the reference, split like every plane value -- per byte VALUE,
+      // once per workgroup (the tile kernel evaluates the same expressions per patch element: planes_impl.h frame_fill)
+      uint32_t* lut = reinterpret_cast<uint32_t*>(smem + C::LUT_OFF);
+      if (threadIdx.x < 264) {
+        const float v = threadIdx.x < 256 ? px_value<IN_NHWC_U8>(threadIdx.x) : 0.f;
+        const _Float16 hh = (_Float16)v;
+        const _Float16 ll = (_Float16)((v - (float)hh) * kLo);
+        lut[threadIdx.x] = (uint32_t)__builtin_bit_cast(unsigned short, hh) | ((uint32_t)__builtin_bit_cast(unsigned short, ll) << 16);
+      }
     }
   }
 
@@ -151,6 +164,21 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       const int gy_lo = 4 * (w.cy - w.j) - 1 + mlo;
       const int fy0 = 2 * gy_lo - 1;
       const int gx0 = 2 * C::TW * w.tx - 1, fxm = 2 * gx0 - 2;
+      if constexpr (U8) {
+        // bytes: patch byte j of a row = frame byte fxm * 3 - U8_JB + j (a multiple of 16: 192 tx - 16); 16 lanes x 16 B per row,
+        // four rows per instruction
+        const unsigned char* fr8 = reinterpret_cast<const unsigned char*>(P.frame);
+        const int bcol = fxm * 3 - C::U8_JB + 16 * (lane & 15);
+        const bool cok = bcol >= 0 && bcol < P.FW * 3;
+        char* lb8 = smem + C::PATCH_OFF + pbuf * C::PATCH_BYTES;
+        for (int ii = wave; ii < C::PR / 4; ii += 4) {
+          const int fy = fy0 + 4 * ii + (lane >> 4);
+          const bool ok = cok && fy >= 0 && fy < P.FH;
+          const void* src = ok ? (const void*)(fr8 + ((size_t)w.n * P.FH + fy) * P.FW * 3 + bcol) : (const void*)a.zeros;
+          dma16(src, lb8 + ii * 1024);
+        }
+        return;
+      }
       const _Float16* fr = reinterpret_cast<const _Float16*>(P.frame);
       constexpr int NL = (C::FJ + C::JUNK - 3 + 7) / 8;
       const int hcol = fxm * 3 - C::JUNK + 3 + 8 * (lane & 31);
@@ -174,15 +202,73 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       const int m = valid ? q / C::IW : mlo;
       const int mx = valid ? q - m * C::IW : 0;
       const int my = m - mlo;
-      // conv0 (3x3 s2 on the frame, K = 27 + bias slot): two k-steps gathered as aligned dwords
-      const int base0 = (2 * my) * RD + 3 * mx + (C::JUNK - 1) / 2;
-      union { half8 v; uint32_t u[4]; } f0, f1;
-      const uint32_t* a0p = fh + base0 + (h ? 2 * RD : 0);
-      f0.u[0] = a0p[0]; f0.u[1] = a0p[1]; f0.u[2] = a0p[2]; f0.u[3] = a0p[3];
-      const uint32_t* b0 = fh + base0;
-      f1.u[0] = b0[go0]; f1.u[1] = b0[go1]; f1.u[2] = b0[go2];
-      const uint32_t last = b0[RD + 3];
-      f1.u[3] = h ? 0x3c00u : last;
+      // conv0 (3x3 s2 on the frame, K = 27 + bias slot): two k-steps gathered as aligned dwords.  k-slots: step 0 {h = 0: frame row 0
+      // [junk, e0..e6], h = 1: row 2 [junk, e0..e6]}, step 1 {h = 0: row 1 [junk, e0..e6], h = 1: (row 0 e7 e8, row 1 e7 e8, row 2 e7 e8,
+      // ONE, pad)}, e = 3 dx + c
+      union { half8 v; uint32_t u[4]; } f0, f1, f0l, f1l;
+      if constexpr (!U8) {
+        const int base0 = (2 * my) * RD + 3 * mx + (C::JUNK - 1) / 2;
+        const uint32_t* a0p = fh + base0 + (h ? 2 * RD : 0);
+        f0.u[0] = a0p[0]; f0.u[1] = a0p[1]; f0.u[2] = a0p[2]; f0.u[3] = a0p[3];
+        const uint32_t* b0 = fh + base0;
+        f1.u[0] = b0[go0]; f1.u[1] = b0[go1]; f1.u[2] = b0[go2];
+        const uint32_t last = b0[RD + 3];
+        f1.u[3] = h ? 0x3c00u : last;
+      } else {
+        // bytes [j0, j0 + 10) of the three frame rows, j0 = 6 mx + U8_JB + 2 (the byte left of the first tap pixel's blue... junk), as
+        // three aligned dwords per row + a byte shift of 0 or 2; each byte through the table -> (hi, lo)
+        const int j0 = 6 * mx + C::U8_JB + 2;
+        const unsigned sh = (unsigned)(j0 & 3);
+        const char* rb = reinterpret_cast<const char*>(fh) + (2 * my) * C::U8_PITCH + (j0 & ~3);
+        uint32_t d[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const uint32_t* pr = reinterpret_cast<const uint32_t*>(rb + r * C::U8_PITCH);
+          d[r][0] = pr[0]; d[r][1] = pr[1]; d[r][2] = pr[2];
+        }
+        uint32_t w0[3], w1[3], t2[3];               // bytes 0-3, 4-7, 8-9 of [j0, j0 + 10) per row
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          w0[r] = __builtin_amdgcn_alignbyte(d[r][1], d[r][0], sh);
+          w1[r] = __builtin_amdgcn_alignbyte(d[r][2], d[r][1], sh);
+          t2[r] = (d[r][2] >> (8 * sh)) & 0xffffu;
+        }
+        // which taps lie inside the frame (the conv's zero padding is zero AFTER normalisation: table entry 256)
+        const int gyf = 2 * (4 * (w.cy - w.j) - 1 + m) - 1, gxf = 2 * (2 * C::TW * w.tx - 1 + mx) - 1;   // frame row / column of tap (0, 0)
+        bool rok[3], cok[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          rok[r] = gyf + r >= 0 && gyf + r < P.FH;
+          cok[r] = gxf + r >= 0 && gxf + r < P.FW;
+        }
+        const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + C::LUT_OFF);
+        auto look = [&](uint32_t word, int k, bool ok) {
+          const uint32_t b = (word >> (8 * k)) & 0xffu;
+          return lut[ok ? b : 256u];
+        };
+        auto row8 = [&](uint32_t lo4, uint32_t hi4, bool rowok, uint32_t (&uh)[4], uint32_t (&ul)[4]) {
+          // [junk, e0 .. e6]: pixel of element e = e / 3
+          const uint32_t v0 = look(lo4, 0, true), v1 = look(lo4, 1, rowok && cok[0]), v2 = look(lo4, 2, rowok && cok[0]), v3 = look(lo4, 3, rowok && cok[0]);
+          const uint32_t v4 = look(hi4, 0, rowok && cok[1]), v5 = look(hi4, 1, rowok && cok[1]), v6 = look(hi4, 2, rowok && cok[1]), v7 = look(hi4, 3, rowok && cok[2]);
+          uh[0] = __builtin_amdgcn_perm(v1, v0, 0x05040100u); ul[0] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+          uh[1] = __builtin_amdgcn_perm(v3, v2, 0x05040100u); ul[1] = __builtin_amdgcn_perm(v3, v2, 0x07060302u);
+          uh[2] = __builtin_amdgcn_perm(v5, v4, 0x05040100u); ul[2] = __builtin_amdgcn_perm(v5, v4, 0x07060302u);
+          uh[3] = __builtin_amdgcn_perm(v7, v6, 0x05040100u); ul[3] = __builtin_amdgcn_perm(v7, v6, 0x07060302u);
+        };
+        // step 0: row 0 (h = 0) | row 2 (h = 1)
+        row8(h ? w0[2] : w0[0], h ? w1[2] : w1[0], h ? rok[2] : rok[0], f0.u, f0l.u);
+        // step 1: row 1 (h = 0) | the e7 e8 pairs of the three rows + the constant one (byte 255 -> exactly 1.0, 0) + pad (h = 1)
+        if (h == 0) {
+          row8(w0[1], w1[1], rok[1], f1.u, f1l.u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const uint32_t va = look(t2[r], 0, rok[r] && cok[2]), vb = look(t2[r], 1, rok[r] && cok[2]);
+            f1.u[r] = __builtin_amdgcn_perm(vb, va, 0x05040100u); f1l.u[r] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+          }
+          f1.u[3] = 0x3c00u; f1l.u[3] = 0u;
+        }
+      }
       half8 xh[4], xl[4];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -190,6 +276,10 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
         f32x16 ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[ct][0], f0.v, zero16, 0, 0, 0);
         am = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ct][1], f1.v, am, 0, 0, 0);
         ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[ct][1], f1.v, ac, 0, 0, 0);
+        if constexpr (U8) {        // (normalised bytes are not fp16 values: their low parts enter like any activation's)
+          ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ct][0], f0l.v, ac, 0, 0, 0);
+          ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ct][1], f1l.v, ac, 0, 0, 0);
+        }
         // (main, corr) -> ReLU -> the two k-step fragments of the 1x1 they form (its K runs in the accumulator layout's order)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -520,14 +610,15 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_pl_stem2xs_timin
 }
 #endif
 
-int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, hipStream_t st) {
+template <bool U8>
+static int launch_stem2xs(pl::PlArgs a, const pl::PlProd& p, hipStream_t st) {
   using C = pl::SS;
   a.tiles_x = (a.OW + C::TW - 1) / C::TW;
   a.tiles_y = (a.OH + 1) / 2;
   const long nt = (long)a.N * a.tiles_x * a.tiles_y;
   if (nt > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
   a.ntiles = (int)nt;
-  auto kern = pl::k_pl_stem2xs<PL_SS_KA>;
+  auto kern = pl::k_pl_stem2xs<PL_SS_KA, U8>;
   static unsigned long long attr_done_mask = 0;
   const int attr_done_dev = lfd_device_ordinal();
   if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
@@ -540,4 +631,9 @@ int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(blocks, 1), dim3(512), C::LDS_BYTES, st, a, p, a.tiles_y, a.ntiles);
   LFD_CHECK_LAUNCH();
   return LFD_OK;
+}
+
+// fp16 NHWC frames with 16-byte aligned rows (uint8_frames = 0) | uint8 NHWC frames with 16-byte aligned rows (1)
+int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, int uint8_frames, hipStream_t st) {
+  return uint8_frames ? launch_stem2xs<true>(a, p, st) : launch_stem2xs<false>(a, p, st);
 }

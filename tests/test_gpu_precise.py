@@ -234,6 +234,27 @@ def test_precise_mode_at_the_baseline_configs_own_shapes(key, name, shape, imgs)
         assert matched >= len(b) - 2, (matched, len(b))
 
 
+def test_precise_mode_uint8_frames_equal_their_normalised_fp32_frames():
+    """resident uint8 NHWC frames (simple_normalize inside the fused stem, augmentation_pipeline.py:31-36 -- the row-stream stem
+    kernel looks the bytes up in a table of split normalised values) against the SAME frames normalised on the host and fed as
+    fp32 NCHW (the two-launch stem with its loaders): the logits agree like two orders of fp32 sums do, and sit inside the mode's gate
+    against the fp32 oracle"""
+    name = 'WIDERFACE_LFD_S'
+    arch = configs.ARCHS[name]
+    m, sd = _model(name)
+    m.cuda()
+    m.precision = 'fp32_storage'
+    g = torch.Generator().manual_seed(11)
+    x8 = torch.randint(0, 256, (2, 136, 240, 3), generator=g, dtype=torch.uint8)
+    xf = ((x8.float() / 255 - 0.5) / 0.5).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        rc, rr, _ = net_oracle.lfd_forward(sd, arch, xf)
+        c8, r8 = [t.clone() for t in m.forward_resident(x8.cuda())]
+        cf, rf = m(xf.cuda())
+    assert float((c8 - cf).abs().max()) <= 2e-5 and float((r8 - rf).abs().max()) <= 2e-5
+    _gate('uint8 frames %s' % name, arch, c8.cpu(), r8.cpu(), rc, rr)
+
+
 def test_precise_mode_api_graph_replay_and_mode_switch():
     """detect_resident in precise mode (one HIP graph per step) == the eager precise step, bit for bit, twice; switching the
     mode back gives the fp16 engine's outputs again; both differ from each other by the fp16 rounding (sanity: the switch

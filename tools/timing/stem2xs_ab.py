@@ -189,3 +189,30 @@ if 'soak' in sys.argv:
             run(x, n, h, w, keep, out); torch.cuda.synchronize()
             bad += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
         print('soak %d x %d x %d: %d of 100 differ' % (n, h, w, bad), flush=True)
+
+if 'u8' in sys.argv:
+    # uint8 NHWC frames (simple_normalize in the stem): the stream kernel's byte table against the tile kernel's load path
+    n, h, w = 8, 1080, 1920
+    ws, keep = weights(2)
+    xs8 = [torch.randint(0, 256, (n, h, w, 3), device=dev, dtype=torch.uint8) for _ in range(2)]
+    out = torch.empty((2, n, 270, 480, c), dtype=torch.float16, device=dev)
+    outs = {}
+
+    def run8(x):
+        check(L.lfd_pl_stem2x(ptr(x), 2, n, h, w, *[ptr(k) for k in keep], ptr(out), out[0].numel(), ptr(z), stream_ptr()), 'lfd_pl_stem2x')
+    for rep in range(2):
+        for mode in (0, 1):
+            _lib.tune('PL_STEM', mode)
+            for i in range(3):
+                run8(xs8[i & 1])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(20):
+                run8(xs8[i & 1])
+            e1.record(); torch.cuda.synchronize()
+            print('uint8 frames rep %d  %s: %.1f us' % (rep, 'stream' if mode else 'tiles ', e0.elapsed_time(e1) * 50), flush=True)
+            run8(xs8[0]); torch.cuda.synchronize()
+            outs[mode] = engine_p2.from_planes(out.cpu())
+    print('uint8 frames: max |tiles - stream| at 8 x 1080p: %.2e' % float((outs[0] - outs[1]).abs().max()))
+    _lib.tune('PL_STEM', 1)
