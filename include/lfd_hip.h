@@ -529,10 +529,11 @@ LFD_API int lfd_p32_groupnorm_relu_f32(float* x, int32_t n, int64_t hw, int32_t 
  *   patch, e0..e8], e = 3 dx + c, as aligned dwords; the bias on the slot of a constant one); w2: the first 1x1 with K in the
  *   order the conv0 accumulators hold the channels (engine_p2.pack_planes_stem2x_tail_weight), b2 its bias [64]; w3 / w4:
  *   lfd_pl_conv2d order (3x3 s2 64 -> 64, 1x1 64 -> 64), b3 / b4 [128] zero padded.
- *   fp16 NHWC frames with w % 8 == 0, and uint8 NHWC frames with w % 16 == 0, on a 16-byte aligned base (the resident serving
- *   formats) run k_pl_stem2xs (round 6: a row stream down strips of 16 output columns, producer waves and consumer waves, the frame
- *   patch by 16-byte LDS-DMA, uint8 values through a 256-entry table of split simple_normalize values; planes_stem2xs.hip; the tuning
- *   knob PL_STEM set to 0 selects the tile kernel for them too); other formats / widths run the tile kernel k_pl_stem2x with loads.  Both kernels take the same packed filters; their results differ by the order of fp32 sums (<= 2e-6 at 8 x 1080p).
+ *   fp16 NHWC frames with w % 8 == 0, uint8 NHWC frames with w % 16 == 0 and fp32 NCHW frames with w % 4 == 0, on a 16-byte aligned
+ *   base, run k_pl_stem2xs (round 6: a row stream down strips of 16 output columns, producer waves and consumer waves, the frame
+ *   patch by 16-byte LDS-DMA; uint8 values through a 256-entry table of split simple_normalize values, fp32 values split at the
+ *   gather; planes_stem2xs.hip; the tuning knob PL_STEM set to 0 selects the tile kernel for them too); other widths / alignments run
+ *   the tile kernel k_pl_stem2x with loads.  Both kernels take the same packed filters; their results differ by the order of fp32 sums (<= 2e-6 at 8 x 1080p).
  * lfd_pl_conv2d: planes [n,h,w,cin] -> conv ks x ks / stride (+ bias, ReLU) with ONE of
  *     tail_cout > 0   : a chained 1x1 cout -> cout (+ tail_bias, tail_relu) in the same launch (the intermediate stays in LDS):
  *                       the second stem pair (3x3 s2 -> 1x1, lfd_resnet.py:396-413), the neck conv -> first tower conv;

@@ -9,7 +9,7 @@
 
 using namespace pl;
 
-int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, int uint8_frames, hipStream_t st);   // planes_stem2xs.hip
+int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, int in_format, hipStream_t st);   // planes_stem2xs.hip
 
 namespace {
 
@@ -75,8 +75,9 @@ extern "C" int lfd_pl_stem2x(const void* in, int32_t in_format, int32_t n, int32
   a.OH = (a.H + 1) / 2; a.OW = (a.W + 1) / 2;
   a.cout = 64; a.cout2 = 64; a.relu = 1; a.relu2 = 1;
   if (lfd_tune(LFD_TUNE_PL_STEM) == 1) {
-    if (p.dma_ok) return lfd_pl_stem2xs_launch(a, p, 0, st);
-    if (in_format == IN_NHWC_U8 && (w & 15) == 0 && ((uintptr_t)in & 15) == 0) return lfd_pl_stem2xs_launch(a, p, 1, st);
+    if (p.dma_ok) return lfd_pl_stem2xs_launch(a, p, IN_NHWC_F16, st);
+    if (in_format == IN_NHWC_U8 && (w & 15) == 0 && ((uintptr_t)in & 15) == 0) return lfd_pl_stem2xs_launch(a, p, IN_NHWC_U8, st);
+    if (in_format == IN_NCHW_F32 && (w & 3) == 0 && ((uintptr_t)in & 15) == 0) return lfd_pl_stem2xs_launch(a, p, IN_NCHW_F32, st);
   }
   switch (in_format) {
     case IN_NCHW_F32: return launch_stem2x<IN_NCHW_F32>(a, p, st);

@@ -1,7 +1,6 @@
 // csrc/planes_stem2xs.hip -- k_pl_stem2xs: the whole 'faster' stem (lfd_resnet.py:376-413: conv3x3 s2 3 -> 64, conv1x1,
 // conv3x3 s2 64 -> 64, conv1x1, each + BN + ReLU) on hi/lo planes in one launch, as a ROW STREAM with producer waves and
-// consumer waves (round 6; fp16 or uint8 NHWC frames with 16-byte aligned rows -- the resident serving formats; everything else
-// runs k_pl_stem2x).
+// consumer waves (round 6; fp16 / uint8 NHWC and fp32 NCHW frames with 16-byte aligned rows; everything else runs k_pl_stem2x).
 //
 // k_pl_stem2x (planes_stem2x.hip, planes_impl.h PROD) runs one wave per SIMD through a serial chain per producer round; the
 // matrix pipe is busy 0.35 of the time at 1.3 kW and the full clock (LESSONS 50-53).  Its eight-wave form with every wave in
@@ -45,6 +44,11 @@ struct SS {
   static constexpr int LUT_OFF = BIAS_OFF + 3 * 256;              // uint8 frames: byte -> (hi | lo << 16) of simple_normalize(byte); entry 256 = zero
   static constexpr int LDS_BYTES = LUT_OFF + 264 * 4;
   static constexpr int U8_PITCH = 256, U8_JB = 4;                 // uint8 frames: bytes per patch row; bytes left of the patch's first tap pixel
+  // fp32 NCHW frames: a patch row = the three channels' 72 floats side by side (frame columns 64 tx - 4 ..: 18 lanes x 16 B per
+  // channel, one LDS-DMA instruction per patch row); 12 rows = 10368 B -- buffer 0 in the patch area, buffer 1 where the other formats
+  // keep the chained 1x1's filters (this format keeps them in registers)
+  static constexpr int F32_CH = 288, F32_ROW = 3 * F32_CH, F32_PATCH = PR * F32_ROW;
+  static_assert(F32_PATCH <= 2 * PATCH_BYTES && F32_PATCH <= 2 * 2 * 4 * 64 * 16, "fp32 patch buffers");
   static_assert(RING_PLANE < 65536, "lo plane as an immediate offset");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS capacity");
 };
@@ -81,8 +85,10 @@ __device__ __forceinline__ void walk_next(Walk& w, int CY, int tiles_x) {
   if (w.rc >= SS::RR) w.rc -= SS::RR;
 }
 
-template <int KA, bool U8>
+// FMT: IN_NHWC_F16 | IN_NHWC_U8 | IN_NCHW_F32 (planes_impl.h)
+template <int KA, int FMT>
 __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int CY, int total) {
+  constexpr bool U8 = FMT == IN_NHWC_U8, F32 = FMT == IN_NCHW_F32;
   using C = SS;
   constexpr int KB = 36 - KA;
   constexpr int PD = PL_SS_PD;
@@ -96,10 +102,12 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
 #endif
   // ---- shared constants
   {
-    half8* tw = reinterpret_cast<half8*>(smem + C::TW_OFF);
-    for (int i = threadIdx.x; i < 2 * 2 * 4 * 64; i += 512) {
-      const int pl = i >> 9, r = i & 511;
-      tw[i] = a.w2[(size_t)pl * a.w2_plane + r];
+    if constexpr (!F32) {
+      half8* tw = reinterpret_cast<half8*>(smem + C::TW_OFF);
+      for (int i = threadIdx.x; i < 2 * 2 * 4 * 64; i += 512) {
+        const int pl = i >> 9, r = i & 511;
+        tw[i] = a.w2[(size_t)pl * a.w2_plane + r];
+      }
     }
     float* sb = reinterpret_cast<float*>(smem + C::BIAS_OFF);
     if (threadIdx.x < 64) {
@@ -164,6 +172,23 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       const int gy_lo = 4 * (w.cy - w.j) - 1 + mlo;
       const int fy0 = 2 * gy_lo - 1;
       const int gx0 = 2 * C::TW * w.tx - 1, fxm = 2 * gx0 - 2;
+      if constexpr (F32) {
+        // floats: patch column j of (row, channel) = frame column 64 tx - 4 + j; lane = channel * 18 + 16-byte piece (17 used); whole
+        // pieces are inside or outside the frame (W % 4 == 0), outside reads the zero line
+        const float* fr32 = reinterpret_cast<const float*>(P.frame);
+        const int sub = lane / 18, l18 = lane - sub * 18;
+        const int fcol = 4 * C::TW * w.tx - 4 + 4 * l18;
+        const bool act = lane < 54 && l18 < 17;
+        const bool cok = fcol >= 0 && fcol < P.FW;
+        char* lb32 = smem + (pbuf ? C::TW_OFF : C::PATCH_OFF);
+        for (int ii = wave; ii < C::PR; ii += 4) {
+          const int fy = fy0 + ii;
+          const bool ok = cok && fy >= 0 && fy < P.FH;
+          const void* src = ok ? (const void*)(fr32 + (((size_t)w.n * 3 + (act ? sub : 0)) * P.FH + fy) * P.FW + fcol) : (const void*)a.zeros;
+          if (act) dma16(src, lb32 + ii * C::F32_ROW);
+        }
+        return;
+      }
       if constexpr (U8) {
         // bytes: patch byte j of a row = frame byte fxm * 3 - U8_JB + j (a multiple of 16: 192 tx - 16); 16 lanes x 16 B per row,
         // four rows per instruction
@@ -206,7 +231,26 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       // [junk, e0..e6], h = 1: row 2 [junk, e0..e6]}, step 1 {h = 0: row 1 [junk, e0..e6], h = 1: (row 0 e7 e8, row 1 e7 e8, row 2 e7 e8,
       // ONE, pad)}, e = 3 dx + c
       union { half8 v; uint32_t u[4]; } f0, f1, f0l, f1l;
-      if constexpr (!U8) {
+      if constexpr (F32) {
+        // element e = 3 dx + c of frame row r at patch (row 2 my + r, channel c, column 1 + 2 mx + dx); split like every plane value
+        const char* pb32 = reinterpret_cast<const char*>(fh) + (2 * my) * C::F32_ROW + (1 + 2 * mx) * 4;
+        auto elem = [&](int r, int e) { return *reinterpret_cast<const float*>(pb32 + r * C::F32_ROW + (e % 3) * C::F32_CH + (e / 3) * 4); };
+        auto row8 = [&](int r, uint32_t (&uh)[4], uint32_t (&ul)[4]) {        // [junk, e0 .. e6]
+          split2(0.f, elem(r, 0), uh[0], ul[0]);
+          split2(elem(r, 1), elem(r, 2), uh[1], ul[1]);
+          split2(elem(r, 3), elem(r, 4), uh[2], ul[2]);
+          split2(elem(r, 5), elem(r, 6), uh[3], ul[3]);
+        };
+        if (h == 0) {
+          row8(0, f0.u, f0l.u);
+          row8(1, f1.u, f1l.u);
+        } else {
+          row8(2, f0.u, f0l.u);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) split2(elem(r, 7), elem(r, 8), f1.u[r], f1l.u[r]);
+          f1.u[3] = 0x3c00u; f1l.u[3] = 0u;
+        }
+      } else if constexpr (!U8) {
         const int base0 = (2 * my) * RD + 3 * mx + (C::JUNK - 1) / 2;
         const uint32_t* a0p = fh + base0 + (h ? 2 * RD : 0);
         f0.u[0] = a0p[0]; f0.u[1] = a0p[1]; f0.u[2] = a0p[2]; f0.u[3] = a0p[3];
@@ -276,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
         f32x16 ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[ct][0], f0.v, zero16, 0, 0, 0);
         am = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ct][1], f1.v, am, 0, 0, 0);
         ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[ct][1], f1.v, ac, 0, 0, 0);
-        if constexpr (U8) {        // (normalised bytes are not fp16 values: their low parts enter like any activation's)
+        if constexpr (U8 || F32) {   // (normalised bytes / fp32 pixels are not fp16 values: their low parts enter like any activation's)
           ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ct][0], f0l.v, ac, 0, 0, 0);
           ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[ct][1], f1l.v, ac, 0, 0, 0);
         }
@@ -345,7 +389,8 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       SS_T(0, 0);
       if (slot < nchunks) {
         if (slot + 1 < nchunks) patch_dma(nxt, (slot + 1) & 1);
-        const uint32_t* fh = reinterpret_cast<const uint32_t*>(smem + C::PATCH_OFF + (slot & 1) * C::PATCH_BYTES);
+        const uint32_t* fh = reinterpret_cast<const uint32_t*>(F32 ? smem + ((slot & 1) ? C::TW_OFF : C::PATCH_OFF)
+                                                                   : smem + C::PATCH_OFF + (slot & 1) * C::PATCH_BYTES);
         // groups of this chunk: the segment's first chunk = stream pixels [0, 165) in 6 groups (the last one's overhang is left
         // to the next slot); chunk j >= 1 = groups [G(j - 1), G(j)) behind pixel 165, G(j) = ceil(132 j / 32)
         const int j = cur.j;
@@ -398,6 +443,14 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
       }
       const float* sb = reinterpret_cast<const float*>(smem + C::BIAS_OFF);
       const half8* tws = reinterpret_cast<const half8*>(smem + C::TW_OFF) + (s * 4) * 64 + lane;
+      half8 twrh[F32 ? 4 : 1], twrl[F32 ? 4 : 1];      // fp32 frames: the chained 1x1's filters in registers (their LDS area is a patch buffer)
+      if constexpr (F32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          twrh[q] = a.w2[((size_t)s * 4 + q) * 64 + lane];
+          twrl[q] = a.w2[a.w2_plane + ((size_t)s * 4 + q) * 64 + lane];
+        }
+      }
       char* const stg = smem + C::STG_OFF + s * C::STG_WAVE;
       const int fm = (pix >> 1) & 7;
       int p1_n = 0, p1_tx = 0, p1_cy = 0, p2_n = 0, p2_tx = 0, p2_cy = 0;     // chunks slot - 2, slot - 3
@@ -461,7 +514,8 @@ __global__ __launch_bounds__(512, 1) void k_pl_stem2xs(PlArgs a, PlProd P, int C
             const int o = pix * 128 + (((2 * q + h) ^ fm) * 16);
             const half8 xh = *reinterpret_cast<const half8*>(midr + o);
             const half8 xl = *reinterpret_cast<const half8*>(midr + C::MID_PLANE + o);
-            const half8 twh = tws[q * 64], twl = tws[2 * 4 * 64 + q * 64];
+            half8 twh, twl;
+            if constexpr (F32) { twh = twrh[q]; twl = twrl[q]; } else { twh = tws[q * 64]; twl = tws[2 * 4 * 64 + q * 64]; }
             tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(twh, xh, tm, 0, 0, 0);
             tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twh, xl, tc, 0, 0, 0);
             tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(twl, xh, tc, 0, 0, 0);
@@ -610,7 +664,7 @@ extern "C" __attribute__((visibility("default"))) int lfd_debug_pl_stem2xs_timin
 }
 #endif
 
-template <bool U8>
+template <int FMT>
 static int launch_stem2xs(pl::PlArgs a, const pl::PlProd& p, hipStream_t st) {
   using C = pl::SS;
   a.tiles_x = (a.OW + C::TW - 1) / C::TW;
@@ -618,7 +672,7 @@ static int launch_stem2xs(pl::PlArgs a, const pl::PlProd& p, hipStream_t st) {
   const long nt = (long)a.N * a.tiles_x * a.tiles_y;
   if (nt > 0x7fffffffL) return LFD_ERR_UNSUPPORTED;
   a.ntiles = (int)nt;
-  auto kern = pl::k_pl_stem2xs<PL_SS_KA, U8>;
+  auto kern = pl::k_pl_stem2xs<PL_SS_KA, FMT>;
   static unsigned long long attr_done_mask = 0;
   const int attr_done_dev = lfd_device_ordinal();
   if (LFD_ONCE_PER_DEVICE(attr_done_mask, attr_done_dev)) {
@@ -633,7 +687,13 @@ static int launch_stem2xs(pl::PlArgs a, const pl::PlProd& p, hipStream_t st) {
   return LFD_OK;
 }
 
-// fp16 NHWC frames with 16-byte aligned rows (uint8_frames = 0) | uint8 NHWC frames with 16-byte aligned rows (1)
-int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, int uint8_frames, hipStream_t st) {
-  return uint8_frames ? launch_stem2xs<true>(a, p, st) : launch_stem2xs<false>(a, p, st);
+// in_format (lfd_stem_conv_f16's codes): fp16 NHWC frames with w % 8 == 0, uint8 NHWC frames with w % 16 == 0, fp32 NCHW frames with
+// w % 4 == 0 -- 16-byte aligned bases; the caller (lfd_pl_stem2x) checks
+int lfd_pl_stem2xs_launch(pl::PlArgs a, const pl::PlProd& p, int in_format, hipStream_t st) {
+  switch (in_format) {
+    case pl::IN_NHWC_F16: return launch_stem2xs<pl::IN_NHWC_F16>(a, p, st);
+    case pl::IN_NHWC_U8: return launch_stem2xs<pl::IN_NHWC_U8>(a, p, st);
+    case pl::IN_NCHW_F32: return launch_stem2xs<pl::IN_NCHW_F32>(a, p, st);
+    default: return LFD_ERR_INVALID_ARGUMENT;
+  }
 }

@@ -593,10 +593,11 @@ class PlanesPlan(object):
     def _launch(self, x, fmt, st, indices):
         l, sp = lib(), stream_ptr()
         zeros = ptr(ops.zero_line(self.device))
-        # the one-launch stem where its frame patches arrive by LDS-DMA (fp16 or uint8 NHWC, 16-byte aligned rows): the resident
-        # serving formats; other formats keep the two launches, whose loaders prefetch (lfd_pl_stem2x takes them too, by plain loads)
+        # the one-launch stem where its frame patches arrive by LDS-DMA (fp16 / uint8 NHWC, fp32 NCHW, 16-byte aligned rows: the row-stream
+        # kernel); other layouts keep the two launches, whose loaders prefetch (lfd_pl_stem2x takes them too, by plain loads)
         fused = (self.stem2x is not None and _stem2x_enabled() and
-                 (os.environ.get('LFD_P2_STEM2X') == '2' or (x.data_ptr() % 16 == 0 and ((fmt == 1 and st.w % 8 == 0) or (fmt == 2 and st.w % 16 == 0)))))
+                 (os.environ.get('LFD_P2_STEM2X') == '2' or
+                  (x.data_ptr() % 16 == 0 and ((fmt == 1 and st.w % 8 == 0) or (fmt == 2 and st.w % 16 == 0) or (fmt == 0 and st.w % 4 == 0)))))
         for i in indices:
             o = self.ops[i]
             if fused and i < 2:

@@ -274,13 +274,14 @@ def test_pl_stem_pair_vs_float64(fmt, c):
 @pytest.mark.parametrize('fmt,n,h,w', [(1, 2, 75, 132), (1, 1, 270, 480), (1, 2, 37, 131), (0, 2, 37, 131), (2, 1, 70, 133), (1, 1, 8, 6),
                                        (1, 3, 129, 258), (1, 2, 75, 136), (1, 2, 37, 128), (1, 1, 8, 8), (1, 3, 129, 264), (1, 1, 16, 2000),
                                        (1, 2, 1080, 64), (1, 1, 4, 8), (1, 5, 2, 16), (2, 2, 75, 144), (2, 1, 270, 480), (2, 3, 129, 272),
-                                       (2, 1, 8, 16), (2, 1, 16, 2000), (2, 4, 3, 32)])
+                                       (2, 1, 8, 16), (2, 1, 16, 2000), (2, 4, 3, 32), (0, 2, 75, 136), (0, 1, 270, 480), (0, 3, 129, 260),
+                                       (0, 1, 8, 8), (0, 4, 3, 32), (0, 1, 16, 2000)])
 @pytest.mark.parametrize('stem_kernel', [1, 0])
 def test_pl_stem2x_vs_float64(fmt, n, h, w, stem_kernel):
     """the whole 'faster' stem in one launch (lfd_pl_stem2x) against float64 convs on the values the planes hold
-    (lfd_resnet.py:376-413); fp16 and uint8 frames with 16-byte aligned rows run the row-stream kernel k_pl_stem2xs (tuning knob
+    (lfd_resnet.py:376-413); fp16 / uint8 NHWC and fp32 NCHW frames with 16-byte aligned rows run the row-stream kernel k_pl_stem2xs (tuning knob
     PL_STEM = 1, the default) or the tile kernel k_pl_stem2x (0); the rest the tile kernel's load path"""
-    if stem_kernel == 0 and not ((fmt == 1 and w % 8 == 0) or (fmt == 2 and w % 16 == 0)):
+    if stem_kernel == 0 and not ((fmt == 1 and w % 8 == 0) or (fmt == 2 and w % 16 == 0) or (fmt == 0 and w % 4 == 0)):
         pytest.skip('same kernel as PL_STEM = 1 for this format')
     _lib.tune('PL_STEM', stem_kernel)
     try:

@@ -190,6 +190,33 @@ if 'soak' in sys.argv:
             bad += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
         print('soak %d x %d x %d: %d of 100 differ' % (n, h, w, bad), flush=True)
 
+if 'f32' in sys.argv:
+    # fp32 NCHW frames (what the reference's LFD.forward receives)
+    n, h, w = 8, 1080, 1920
+    ws, keep = weights(2)
+    xs32 = [torch.rand(n, 3, h, w, device=dev) * 2 - 1 for _ in range(2)]
+    out = torch.empty((2, n, 270, 480, c), dtype=torch.float16, device=dev)
+    outs = {}
+
+    def run32(x):
+        check(L.lfd_pl_stem2x(ptr(x), 0, n, h, w, *[ptr(k) for k in keep], ptr(out), out[0].numel(), ptr(z), stream_ptr()), 'lfd_pl_stem2x')
+    for rep in range(2):
+        for mode in (0, 1):
+            _lib.tune('PL_STEM', mode)
+            for i in range(3):
+                run32(xs32[i & 1])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(20):
+                run32(xs32[i & 1])
+            e1.record(); torch.cuda.synchronize()
+            print('fp32 NCHW frames rep %d  %s: %.1f us' % (rep, 'stream' if mode else 'tiles ', e0.elapsed_time(e1) * 50), flush=True)
+            run32(xs32[0]); torch.cuda.synchronize()
+            outs[mode] = engine_p2.from_planes(out.cpu())
+    print('fp32 NCHW frames: max |tiles - stream| at 8 x 1080p: %.2e' % float((outs[0] - outs[1]).abs().max()))
+    _lib.tune('PL_STEM', 1)
+
 if 'u8' in sys.argv:
     # uint8 NHWC frames (simple_normalize in the stem): the stream kernel's byte table against the tile kernel's load path
     n, h, w = 8, 1080, 1920
