@@ -508,6 +508,15 @@ def stress_and_small_frame_bench(model, x, meta, dev, cls):
                                                   'image, IoU 0.4, forward + decode + NMS (one HIP graph, one batch in flight)',
                                          ms_per_step=round(ms, 4), images_per_s=round(x.size(0) / ms * 1e3, 1),
                                          candidates_per_image=float(cn[:, 0].mean()), kept_per_image=float(cn[:, 1].mean()))
+        # ... and as the reference's LFD.forward receives it: normalised fp32 NCHW (lfd.py:511-542)
+        x32 = torch.rand((x.size(0), 3, x.size(1), x.size(2)), device=dev, generator=gen) * 2 - 1
+        c32, _ = model.forward_resident(x32)
+        model._classification_threshold = float(torch.quantile(c32.float().sigmoid().reshape(x.size(0), -1)[0], 1.0 - 256.0 / c32.shape[1]))
+        ms = _event_median_ms(lambda: model.detect_resident(x32, meta), 50)
+        out['frames_fp32_nchw_1080p'] = dict(workload='WIDERFACE_LFD_S 8 x 3 x 1080 x 1920 fp32 NCHW resident, ~256 candidates per image, IoU 0.4, '
+                                                      'forward + decode + NMS (one HIP graph, one batch in flight)',
+                                             ms_per_step=round(ms, 4), images_per_s=round(x.size(0) / ms * 1e3, 1))
+        del x8, x32, c8, c32
     finally:
         model._classification_threshold, model._nms_cfg, model.use_graph = keep[0], dict(keep[1]), keep[2]
     return out
@@ -648,6 +657,8 @@ def compact_line(r):
         c['configs']['640x480_bs8'] = ((cf['frames_640x480'] or {}).get('bs8') or {}).get('ms_per_step')
     if 'frames_uint8_1080p' in cf:
         c['configs']['uint8_1080p_bs8_serial'] = (cf['frames_uint8_1080p'] or {}).get('ms_per_step')
+    if 'frames_fp32_nchw_1080p' in cf:
+        c['configs']['fp32_nchw_1080p_bs8_serial'] = (cf['frames_fp32_nchw_1080p'] or {}).get('ms_per_step')
     t = r.get('train') or {}
     c['train'] = {k: t.get(k) for k in ('ms_per_iter', 'n_gpus', 'ranks_seen', 'images_per_s', 'error') if k in t}
     lb = r.get('latency_bs1') or {}
