@@ -325,17 +325,23 @@ def _stem2x_case(fmt, n, h, w):
     _close(out, ref, 'stem2x fmt %d %dx%dx%d' % (fmt, n, h, w))
 
 
-def test_pl_stem2x_stream_kernel_is_deterministic_under_concurrent_work():
+@pytest.mark.parametrize('fmt', [1, 2, 0])
+def test_pl_stem2x_stream_kernel_is_deterministic_under_concurrent_work(fmt):
     """k_pl_stem2xs hands chunks from producer waves to consumer waves through LDS with ONE workgroup barrier per slot (no atomics, fixed
     order): the same frames must give the same bits on every launch, also with another stream keeping the chip busy -- an LDS hazard
     would show here as a bit that differs"""
-    n, h, w, c = 3, 258, 520, 64
+    n, h, w, c = 3, 258, 528, 64
     g = torch.Generator().manual_seed(77)
     w1, b1 = torch.randn(c, 3, 3, 3, generator=g) * 0.3, torch.randn(c, generator=g)
     w2, b2 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
     w3, b3 = torch.randn(c, c, 3, 3, generator=g) * (1.0 / (9 * c) ** 0.5), torch.randn(c, generator=g)
     w4, b4 = torch.randn(c, c, 1, 1, generator=g) * (1.0 / c ** 0.5), torch.randn(c, generator=g)
-    x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half().cuda()
+    if fmt == 1:
+        x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).half().cuda()
+    elif fmt == 2:
+        x = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8).cuda()
+    else:
+        x = (torch.rand(n, 3, h, w, generator=g) * 2 - 1).cuda()
     keep = [engine_p2.pack_planes_stem2x_weight(w1, b1).cuda(), engine_p2.pack_planes_stem2x_tail_weight(w2).cuda(),
             engine_p2._pad_bias(b2).cuda(), engine_p2.pack_planes_weight(w3).cuda(), engine_p2._pad_bias(b3, 128).cuda(),
             engine_p2.pack_planes_weight(w4).cuda(), engine_p2._pad_bias(b4, 128).cuda()]
@@ -346,7 +352,7 @@ def test_pl_stem2x_stream_kernel_is_deterministic_under_concurrent_work():
 
     def run():
         out.fill_(float('nan'))
-        check(lib().lfd_pl_stem2x(ptr(x), 1, n, h, w, *[ptr(k) for k in keep], ptr(out), out[0].numel(), ptr(z), stream_ptr()), 'lfd_pl_stem2x')
+        check(lib().lfd_pl_stem2x(ptr(x), fmt, n, h, w, *[ptr(k) for k in keep], ptr(out), out[0].numel(), ptr(z), stream_ptr()), 'lfd_pl_stem2x')
         torch.cuda.synchronize()
     run()
     ref = out.clone()
